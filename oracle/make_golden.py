@@ -1,0 +1,128 @@
+"""Generate tests/golden/*.npz from the HuggingFace modules the reference executes.
+
+Run in the build container (transformers 5.15.0 importable, no GPU needed):
+
+    python oracle/make_golden.py
+
+What is pinned (SURVEY.md §8c -- the reference itself has no golden vectors for this path):
+  * relpos_buckets.npz   -- HF ``T5Attention._relative_position_bucket`` for every
+                            relative position in [-700, 700], bidirectional and causal.
+  * hf_tiny.npz / hf_small.npz
+      - ``CLIPVisionModel(..., output_hidden_states=True).hidden_states[-2]`` on seeded pixels,
+      - ``T5ForConditionalGeneration(inputs_embeds=..., attention_mask=..., labels=...)``
+        logits and per-sample ``exp(-CrossEntropyLoss(mean))`` on seeded embeddings with a
+        ragged key mask and ragged (-100 padded) labels,
+    all from HF modules in fp32 loaded with the bf16-rounded seeded weights of
+    ``t2v_metrics_amd.weights``.  The glue between the two modules (feature select, projector,
+    splice) is not HF code and is pinned separately by hand-built cases in tests/test_oracle_*.py.
+
+The HF-5.x quirks handled here (SURVEY.md §8c "Oracle gotchas"): lm_head is re-created untied,
+``scale_decoder_outputs`` is forced False, dropout 0 / eval mode.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from t2v_metrics_amd.config import get_config  # noqa: E402
+from t2v_metrics_amd.weights import make_seeded_weights  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def build_hf_vision(cfg, weights):
+    from transformers import CLIPVisionConfig, CLIPVisionModel
+    v = cfg.vision
+    hc = CLIPVisionConfig(hidden_size=v.hidden, intermediate_size=v.mlp, num_hidden_layers=v.layers,
+                          num_attention_heads=v.heads, image_size=v.image, patch_size=v.patch,
+                          hidden_act="quick_gelu", layer_norm_eps=v.ln_eps, attention_dropout=0.0)
+    m = CLIPVisionModel(hc).eval().float()
+    sd = {k[len("vision."):]: w.float() for k, w in weights.items() if k.startswith("vision.")}
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    # post_layernorm is unused by the path (feature comes from hidden_states[-2]); position_ids is a buffer
+    assert all(("post_layernorm" in k) or ("position_ids" in k) for k in missing), missing
+    assert not unexpected, unexpected
+    return m
+
+
+def build_hf_t5(cfg, weights):
+    from transformers import T5Config, T5ForConditionalGeneration
+    t = cfg.t5
+    hc = T5Config(vocab_size=t.vocab, d_model=t.d_model, d_kv=t.d_kv, d_ff=t.d_ff, num_layers=t.layers,
+                  num_decoder_layers=t.dec_layers, num_heads=t.heads,
+                  relative_attention_num_buckets=t.rel_buckets, relative_attention_max_distance=t.rel_max_distance,
+                  dropout_rate=0.0, layer_norm_epsilon=t.ln_eps, feed_forward_proj="gated-gelu",
+                  tie_word_embeddings=False, pad_token_id=t.pad_id, eos_token_id=t.eos_id,
+                  decoder_start_token_id=t.decoder_start_id)
+    m = T5ForConditionalGeneration(hc).eval().float()
+    # HF 5.x ties lm_head to shared on construction; flan-t5 is untied.
+    m.lm_head.weight = torch.nn.Parameter(torch.empty_like(m.shared.weight))
+    m.config.tie_word_embeddings = False
+    m.config.scale_decoder_outputs = False
+    sd = {k: w.float() for k, w in weights.items() if not (k.startswith("vision.") or k.startswith("mm_projector."))}
+    sd["encoder.embed_tokens.weight"] = sd["shared.weight"]
+    sd["decoder.embed_tokens.weight"] = sd["shared.weight"]
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    assert m.lm_head.weight.data_ptr() != m.shared.weight.data_ptr()
+    return m
+
+
+def golden_relpos():
+    from transformers.models.t5.modeling_t5 import T5Attention
+    rp = torch.arange(-700, 701, dtype=torch.long)
+    bi = T5Attention._relative_position_bucket(rp, bidirectional=True, num_buckets=32, max_distance=128)
+    uni = T5Attention._relative_position_bucket(rp, bidirectional=False, num_buckets=32, max_distance=128)
+    np.savez_compressed(os.path.join(GOLDEN, "relpos_buckets.npz"), relative_position=rp.numpy(),
+                        bidirectional=bi.numpy().astype(np.int32), causal=uni.numpy().astype(np.int32))
+    print("relpos_buckets.npz", bi[:5].tolist(), uni[695:705].tolist())
+
+
+def golden_model(name: str, seed: int, n_img: int, B: int, S_e: int, T: int):
+    cfg = get_config(name)
+    w = make_seeded_weights(cfg, seed=seed, device="cpu", dtype=torch.bfloat16)
+    g = torch.Generator().manual_seed(seed + 17)
+    v, t = cfg.vision, cfg.t5
+    pixels = torch.randn(n_img, 3, v.image, v.image, generator=g).to(torch.bfloat16).float()
+    with torch.no_grad():
+        vm = build_hf_vision(cfg, w)
+        hs = vm(pixel_values=pixels, output_hidden_states=True).hidden_states
+        assert len(hs) == v.layers + 1
+        vit_hidden_m2 = hs[v.select_layer]                      # [n_img, 1+P, hidden]
+
+        tm = build_hf_t5(cfg, w)
+        emb = torch.randn(B, S_e, t.d_model, generator=g)
+        lens = torch.randint(S_e // 2, S_e + 1, (B,), generator=g)
+        lens[0] = S_e
+        mask = torch.arange(S_e)[None, :] < lens[:, None]
+        emb = emb * mask[..., None]
+        labels = torch.randint(2, t.vocab, (B, T), generator=g)
+        labels[:, -1] = t.eos_id
+        if T > 2:                                              # ragged answers: -100 padded
+            labels[1, -1] = -100
+            labels[1, -2] = t.eos_id
+        out = tm(inputs_embeds=emb, attention_mask=mask.long(), labels=labels)
+        logits = out.logits
+        ce = torch.nn.CrossEntropyLoss(reduction="mean")       # v3.0 scoring tail
+        scores = torch.stack([(-ce(logits[k], labels[k])).exp() for k in range(B)])
+        enc_out = out.encoder_last_hidden_state
+    path = os.path.join(GOLDEN, f"hf_{name}.npz")
+    np.savez_compressed(
+        path, seed=seed, pixels=pixels.numpy(), vit_hidden_m2=vit_hidden_m2.numpy(), emb=emb.numpy(),
+        mask=mask.numpy(), labels=labels.numpy(), enc_out=enc_out.numpy(), logits=logits.numpy(),
+        scores=scores.numpy())
+    print(path, os.path.getsize(path) // 1024, "KiB", "scores", scores.tolist())
+
+
+if __name__ == "__main__":
+    os.makedirs(GOLDEN, exist_ok=True)
+    torch.manual_seed(0)
+    golden_relpos()
+    golden_model("tiny", seed=3, n_img=2, B=3, S_e=24, T=3)
+    golden_model("small", seed=5, n_img=1, B=2, S_e=40, T=2)
