@@ -1,0 +1,144 @@
+/* libvqs_hip -- MI355X (gfx950) native VQAScore hot path for CLIP-FlanT5.  C ABI.
+ *
+ * The reference (linzhiqiu/t2v_metrics) is pure Python and has no FFI; the forward pass this library
+ * replaces is the one HuggingFace `transformers` executes underneath the v3.0 CLIP-FlanT5 wrapper
+ * (SURVEY.md §0, §8a).  Each entry point below names the reference-side call it stands in for.
+ * INTEGRATION.md shows the ctypes binding a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - every pointer named d_* is a DEVICE pointer (HIP); tensors are dense row-major;
+ *   - bf16 tensors are raw IEEE bfloat16 (uint16_t bits), exactly `torch.bfloat16` storage;
+ *   - `stream` is a hipStream_t passed as void* (e.g. torch.cuda.current_stream().cuda_stream);
+ *   - functions enqueue work on `stream` and return without synchronising it; the caller syncs;
+ *   - the library never allocates device memory: packed weights and workspaces are caller-provided
+ *     (sized by the *_bytes queries);
+ *   - return value 0 = success, negative = error (VQS_ERR_*); vqs_last_error() gives the message;
+ *   - one handle per device/stream; a handle is not re-entrant.
+ */
+#ifndef VQS_H
+#define VQS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VQS_OK 0
+#define VQS_ERR_INVALID (-1)      /* bad argument / unsupported shape */
+#define VQS_ERR_MISSING_WEIGHT (-2)
+#define VQS_ERR_WORKSPACE (-3)    /* caller buffer too small */
+#define VQS_ERR_HIP (-4)          /* a HIP call or kernel launch failed */
+#define VQS_ERR_STATE (-5)        /* e.g. weights not bound */
+
+#define VQS_IMAGE_TOKEN_INDEX (-200) /* /root/reference/t2v_metrics/constants.py:7 */
+#define VQS_IGNORE_INDEX (-100)      /* /root/reference/t2v_metrics/constants.py:6 */
+
+typedef struct vqs_handle vqs_handle;
+
+/* Architecture of one CLIP-FlanT5 checkpoint.  Replaces the HF config objects read by
+ * `model_cls.from_pretrained` (/root/reference/t2v_metrics/models/vqascore_models/mm_utils.py:201,222-229):
+ * CLIPVisionConfig (HF models/clip/configuration_clip.py:97-109) and T5Config
+ * (HF models/t5/configuration_t5.py:44-62). */
+typedef struct vqs_config {
+    /* vision tower */
+    int32_t vis_hidden;      /* 1024 */
+    int32_t vis_layers_run;  /* layers executed = index of hidden_states[-2] = 23 for the 24-layer tower */
+    int32_t vis_heads;       /* 16 (head dim must be 64) */
+    int32_t vis_mlp;         /* 4096 */
+    int32_t vis_patch;       /* 14 */
+    int32_t vis_image;       /* 336 */
+    float vis_ln_eps;        /* 1e-5 */
+    /* T5 */
+    int32_t d_model;         /* 2048 (xl) / 4096 (xxl) */
+    int32_t n_heads;         /* 32 / 64 */
+    int32_t d_kv;            /* 64 (required) */
+    int32_t d_ff;            /* 5120 / 10240 */
+    int32_t enc_layers;      /* 24 */
+    int32_t dec_layers;      /* 24 */
+    int32_t vocab;           /* 32128 */
+    int32_t rel_buckets;     /* 32 */
+    int32_t rel_max_distance;/* 128 */
+    float t5_ln_eps;         /* 1e-6 */
+} vqs_config;
+
+/* One named bf16 device tensor.  Names are the HF state_dict keys listed by
+ * t2v_metrics_amd/weights.py::weight_specs (vision.*, mm_projector.*, T5 keys, lm_head.weight). */
+typedef struct vqs_weight_desc {
+    const char* name;
+    const void* d_data;   /* device, bf16, contiguous */
+    int64_t numel;
+} vqs_weight_desc;
+
+/* Replaces: constructing the HF modules (mm_utils.py:201) -- no device work. */
+int vqs_create(const vqs_config* cfg, vqs_handle** out);
+void vqs_destroy(vqs_handle* h);
+const char* vqs_last_error(const vqs_handle* h);
+
+/* Replaces: `model.to(device, dtype=torch.bfloat16)` (mm_utils.py:228).  The caller keeps every bound
+ * tensor alive.  Fused / re-laid-out copies (QKV concatenation, wi_0|wi_1 interleave, padded patch
+ * kernel, bucket LUT) are written into `d_packed` (vqs_packed_bytes() bytes, caller-owned). */
+size_t vqs_packed_bytes(const vqs_handle* h);
+int vqs_bind_weights(vqs_handle* h, const vqs_weight_desc* weights, int32_t n_weights, void* d_packed,
+                     size_t packed_bytes, void* stream);
+
+/* Replaces: CLIPVisionModel.forward(..., output_hidden_states=True).hidden_states[-2][:, 1:]
+ * (HF models/clip/modeling_clip.py:613-656) followed by the mlp2x_gelu projector.
+ *   d_pixels  bf16 [n_img, 3, image, image]  (already CLIP-normalised)
+ *   d_feats   bf16 [n_img, n_patches, d_model]  (output) */
+size_t vqs_encode_workspace_bytes(const vqs_handle* h, int32_t n_img);
+int vqs_encode_images(vqs_handle* h, const void* d_pixels, int32_t n_img, void* d_feats, void* d_ws, size_t ws_bytes,
+                      void* stream);
+
+/* Replaces: embed + splice, T5ForConditionalGeneration.forward(inputs_embeds, attention_mask, labels)
+ * (HF models/t5/modeling_t5.py:939-1066) and the scoring tail exp(-CrossEntropyLoss(mean)) of the v3.0
+ * wrapper.
+ *   d_feats        bf16  [n_img, n_patches, d_model] from vqs_encode_images
+ *   d_img_index    int32 [B]      row of d_feats used by pair b
+ *   d_input_ids    int32 [B, L]   prompt ids, exactly one VQS_IMAGE_TOKEN_INDEX per row, 0 = right padding
+ *   d_labels       int32 [B, T]   answer ids, VQS_IGNORE_INDEX = padding, T <= 16
+ *   d_label_logprobs float [B, T] (output) log P(label_t | image, prompt, labels_<t); 0 at ignored positions
+ *   d_scores       float [B]      (output) exp(mean of the valid label log-probs)
+ * Encoder length S_e = L - 1 + n_patches must be <= 2048 + n_patches. */
+size_t vqs_score_workspace_bytes(const vqs_handle* h, int32_t B, int32_t L, int32_t T);
+int vqs_score(vqs_handle* h, const void* d_feats, const int32_t* d_img_index, const int32_t* d_input_ids,
+              const int32_t* d_labels, int32_t B, int32_t L, int32_t T, float* d_label_logprobs, float* d_scores,
+              void* d_ws, size_t ws_bytes, void* stream);
+
+/* Byte offset of a named intermediate inside the vqs_score / vqs_encode_images workspace (parity tests read
+ * stages through this): "enc_in" fp32 [B,S_e,D], "enc_out" bf16 [B,S_e,D], "logits" fp32 [B*T, ld],
+ * "vit_hidden" fp32 [n_img, 1+P, hidden], "enc_len" int32 [B], "flags" int32[1] (bit0 = malformed prompt).
+ * For encode-stage names pass B = n_img, L = T = 0.  Returns -1 for an unknown name.
+ * *ld_out (optional) receives the row stride in elements. */
+int64_t vqs_workspace_offset(const vqs_handle* h, const char* name, int32_t B, int32_t L, int32_t T, int64_t* ld_out);
+
+/* Kernel timing for bench.py: when enabled, every GEMM launch is bracketed by HIP events on `stream`.
+ * vqs_profile_read synchronises the recorded events, returns the number of GEMM launches since the last
+ * reset, and fills total GEMM milliseconds and total algorithmic GEMM FLOPs (2*M*N*K). */
+int vqs_profile_enable(vqs_handle* h, int32_t on);
+int vqs_profile_read(vqs_handle* h, double* gemm_ms, double* gemm_flops, int32_t reset);
+
+/* ---- single-kernel entry points (parity tests and micro-benchmarks call the kernels through these) ---- */
+/* epilogue: 0 bf16, 1 bf16+quick_gelu, 2 bf16+erf-gelu, 3 fp32, 4 fp32 + residual, 5 gated gelu_new (W rows
+ * interleaved per 32: wi_0 block then wi_1 block; C is [M, N/2]), 6 head-major scatter (q/k/v = C, C+B*H*S*64, ...) */
+int vqs_gemm(const void* d_A, const void* d_W, void* d_C, const void* d_bias, const float* d_resid, int32_t M, int32_t N,
+             int32_t K, int32_t lda, int32_t ldw, int32_t ldc, int32_t epilogue, int32_t S, int32_t H, int32_t variant,
+             void* stream);
+int vqs_attention(const void* d_q, const void* d_k, const void* d_v, void* d_out, const float* d_bias_table,
+                  const int32_t* d_key_len, int32_t B, int32_t H, int32_t S, float scale, void* stream);
+int vqs_decoder_attention(const void* d_q, const void* d_k, const void* d_v, void* d_out, const float* d_bias_table,
+                          const int32_t* d_key_len, int32_t B, int32_t H, int32_t T, int32_t S, int32_t ldq, int32_t ldk,
+                          int32_t cross, void* stream);
+int vqs_rmsnorm(const float* d_x, const void* d_w, void* d_out, int32_t M, int32_t D, float eps, void* stream);
+int vqs_layernorm(const float* d_x, const void* d_w, const void* d_b, void* d_out, int32_t out_f32, int32_t M, int32_t D,
+                  float eps, void* stream);
+int vqs_score_head(const float* d_logits, int32_t ldl, int32_t V, const int32_t* d_labels, float* d_label_logprobs,
+                   float* d_scores, int32_t B, int32_t T, void* stream);
+/* host-side bucket function used to build the bias tables (HF models/t5/modeling_t5.py:216-262) */
+int32_t vqs_relpos_bucket(int32_t relative_position, int32_t bidirectional, int32_t num_buckets, int32_t max_distance);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VQS_H */

@@ -1,0 +1,358 @@
+// Attention kernels for gfx950 (MI355X).
+//
+// attn_fwd_kernel  -- K4/K5 of SURVEY.md §8(a-bis): softmax(scale*Q.K^T + bias[h, key-query] + key mask).V
+//   * CLIP ViT self-attention  (HF models/clip/modeling_clip.py:259-277: scale = 1/8, fp32 softmax, no mask)
+//   * T5 encoder self-attention (HF models/t5/modeling_t5.py:144-173,196-197: scale = 1.0, additive relative
+//     position bias shared by all layers, additive key-padding mask)
+//   Flash-style: the S x S score matrix is never materialised.  One workgroup = 4 waves x 32 query rows
+//   of one (sample, head); K/V are walked in 64-key tiles staged through LDS.
+//     - scores are computed TRANSPOSED (mfma(a = K tile, b = Q^T)), so a lane owns ONE query and 16 keys
+//       per 32x32 accumulator: the row max/sum are in-lane reductions plus one lane<->lane+32 exchange;
+//     - the accumulator register order of S^T is exactly the B-operand order of the P^T.V^T product when
+//       the k-slot -> key map of that MFMA is chosen as key = 16t + 4*(lane>>5) + 8*(j>>2) + (j&3):
+//       P never moves between lanes (no LDS round trip, no permutes);
+//     - V arrives [key][d] (d contiguous); the MFMA wants keys contiguous per lane, so V is transposed
+//       while it is staged: each thread packs (V[2k][d], V[2k+1][d]) pairs into conflict-free ds_write_b32;
+//       V^T rows are padded to 136 B so the ds_read_b64 fragment reads are conflict-free too;
+//     - the K tile uses the same (row>>1)&7 XOR chunk swizzle as the GEMM (conflict-free ds_read_b128);
+//     - the T5 bias is a per-head [2S-1] fp32 table in LDS indexed by key-query (never an [H,S,S] tensor);
+//     - next tile's global loads are issued before the current tile's MFMAs (register prefetch).
+//   Softmax statistics, the running rescale and the output normalisation are fp32; P is rounded to bf16
+//   for the PV MFMA.
+//
+// dec_attn_kernel  -- K6: the T<=16-row decoder attentions (causal self-attention with the unidirectional
+//   bucket bias; cross-attention over the encoder keys with the key mask), fp32 VALU math: the work is
+//   ~0.1% of the path's FLOPs and latency-bound.
+#include "vqs_kernels.h"
+
+namespace vqs {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+__device__ __forceinline__ float a_bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t a_f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t a_pack2(float a, float b) {
+    return (uint32_t)a_f2bf(a) | ((uint32_t)a_f2bf(b) << 16);
+}
+
+static constexpr int KT = 64;            // keys per tile
+static constexpr int VT_LD = 136;        // bytes per V^T row (64 keys * 2 B + 8 B pad)
+static constexpr int K_LDS = KT * 128;   // 8192
+static constexpr int VT_LDS = 64 * VT_LD;  // 8704
+static constexpr float NEG_BIG = -1.0e30f;
+
+template <bool HAS_BIAS>
+__global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* k_lds = smem;
+    char* vt_lds = smem + K_LDS;
+    float* bias_s = reinterpret_cast<float*>(smem + K_LDS + VT_LDS);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hh = lane >> 5;                 // lane half
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int S = p.S;
+    const size_t bh = (size_t)b * p.H + h;
+    const bf16_t* Q = p.q + bh * S * 64;
+    const bf16_t* K = p.k + bh * S * 64;
+    const bf16_t* V = p.v + bh * S * 64;
+    const int klen = p.key_len ? min(p.key_len[b], S) : S;
+    const int ntiles = (klen + KT - 1) / KT;
+
+    if (HAS_BIAS) {
+        const float* bt = p.bias_table + (size_t)h * (2 * S - 1);
+        for (int i = tid; i < 2 * S - 1; i += 256) bias_s[i] = bt[i];
+    }
+
+    const int qrow = blockIdx.x * 128 + wv * 32 + (lane & 31);
+    const int qrow_c = min(qrow, S - 1);
+    uint4 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+        qf[ks] = *reinterpret_cast<const uint4*>(Q + (size_t)qrow_c * 64 + 16 * ks + 8 * hh);
+
+    // ---- staging assignments
+    // K: thread -> (key = tid>>3 (+32), chunk = tid&7), 16-B chunks, swizzled
+    const int sk_key = tid >> 3, sk_c = tid & 7;
+    // V: thread -> (key pair kp, d-chunk c); a 32-lane half covers 16 kp x 2 c  (conflict-free b32 writes)
+    const int sv_kp = (lane & 15) + 16 * (wv & 1);
+    const int sv_c = ((lane >> 4) & 3) + 4 * (wv >> 1);
+
+    uint4 kreg0, kreg1, vreg0, vreg1;
+    auto load_tile = [&](int kt) {
+        const int kb = kt * KT;
+        kreg0 = *reinterpret_cast<const uint4*>(K + (size_t)min(kb + sk_key, S - 1) * 64 + sk_c * 8);
+        kreg1 = *reinterpret_cast<const uint4*>(K + (size_t)min(kb + sk_key + 32, S - 1) * 64 + sk_c * 8);
+        vreg0 = *reinterpret_cast<const uint4*>(V + (size_t)min(kb + 2 * sv_kp, S - 1) * 64 + sv_c * 8);
+        vreg1 = *reinterpret_cast<const uint4*>(V + (size_t)min(kb + 2 * sv_kp + 1, S - 1) * 64 + sv_c * 8);
+    };
+    auto write_tile = [&]() {
+        *reinterpret_cast<uint4*>(k_lds + sk_key * 128 + ((sk_c ^ ((sk_key >> 1) & 7)) << 4)) = kreg0;
+        *reinterpret_cast<uint4*>(k_lds + (sk_key + 32) * 128 + ((sk_c ^ (((sk_key + 32) >> 1) & 7)) << 4)) = kreg1;
+        // dword j2 of a 16-B chunk holds d = 8c + 2*j2 (low half) and d + 1 (high half)
+#define VQS_VT_WRITE(J2, A, B)                                                                       \
+        {                                                                                            \
+            const uint32_t lo = ((A) & 0xffffu) | ((B) << 16);                                       \
+            const uint32_t hi = ((A) >> 16) | ((B) & 0xffff0000u);                                   \
+            const int d = sv_c * 8 + 2 * (J2);                                                       \
+            *reinterpret_cast<uint32_t*>(vt_lds + d * VT_LD + sv_kp * 4) = lo;                       \
+            *reinterpret_cast<uint32_t*>(vt_lds + (d + 1) * VT_LD + sv_kp * 4) = hi;                 \
+        }
+        VQS_VT_WRITE(0, vreg0.x, vreg1.x)
+        VQS_VT_WRITE(1, vreg0.y, vreg1.y)
+        VQS_VT_WRITE(2, vreg0.z, vreg1.z)
+        VQS_VT_WRITE(3, vreg0.w, vreg1.w)
+#undef VQS_VT_WRITE
+    };
+
+    f32x16 o[2];
+#pragma unroll
+    for (int df = 0; df < 2; ++df)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[df][r] = 0.0f;
+    float m_run = NEG_BIG, l_run = 0.0f;
+
+    const int swr = (lane >> 1) & 7;
+    const int k_rd = (lane & 31) * 128;
+    const int vt_rd = (lane & 31) * VT_LD + 8 * hh;
+
+    if (ntiles > 0) load_tile(0);
+    for (int kt = 0; kt < ntiles; ++kt) {
+        __syncthreads();                 // previous tile's LDS reads are done (also covers bias_s fill)
+        write_tile();
+        if (kt + 1 < ntiles) load_tile(kt + 1);
+        __syncthreads();
+
+        // ---- S^T = K . Q^T   (i <-> key, j <-> query)
+        f32x16 s[2];
+#pragma unroll
+        for (int kf = 0; kf < 2; ++kf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kf][r] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int kf = 0; kf < 2; ++kf) {
+                const uint4 kfr = *reinterpret_cast<const uint4*>(k_lds + kf * 4096 + k_rd + (((2 * ks + hh) ^ swr) << 4));
+                s[kf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kfr),
+                                                                __builtin_bit_cast(bf16x8, qf[ks]), s[kf], 0, 0, 0);
+            }
+        }
+
+        // ---- scale + bias + mask, running max
+        const int kb = kt * KT;
+        float mx = NEG_BIG;
+#pragma unroll
+        for (int kf = 0; kf < 2; ++kf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb + kf * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                float v = s[kf][r] * p.scale;
+                if (HAS_BIAS) {
+                    int idx = key - qrow_c + (S - 1);
+                    idx = min(max(idx, 0), 2 * S - 2);
+                    v += bias_s[idx];
+                }
+                if (key >= klen) v = NEG_BIG;
+                s[kf][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __expf(m_run - m_new);
+        m_run = m_new;
+        l_run *= alpha;
+#pragma unroll
+        for (int kf = 0; kf < 2; ++kf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __expf(s[kf][r] - m_new);
+                s[kf][r] = pv;
+                l_run += pv;
+            }
+#pragma unroll
+        for (int df = 0; df < 2; ++df)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[df][r] *= alpha;
+
+        // ---- O^T += V^T . P^T   (i <-> d, j <-> query, k-slot (half,j) <-> key 16t + 4*half + 8*(j>>2) + (j&3))
+#pragma unroll
+        for (int kf = 0; kf < 2; ++kf)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                uint4 pb;
+                pb.x = a_pack2(s[kf][8 * t + 0], s[kf][8 * t + 1]);
+                pb.y = a_pack2(s[kf][8 * t + 2], s[kf][8 * t + 3]);
+                pb.z = a_pack2(s[kf][8 * t + 4], s[kf][8 * t + 5]);
+                pb.w = a_pack2(s[kf][8 * t + 6], s[kf][8 * t + 7]);
+#pragma unroll
+                for (int df = 0; df < 2; ++df) {
+                    const char* vp = vt_lds + df * 32 * VT_LD + vt_rd + (kf * 32 + 16 * t) * 2;
+                    const uint2 lo = *reinterpret_cast<const uint2*>(vp);
+                    const uint2 hi = *reinterpret_cast<const uint2*>(vp + 16);
+                    uint4 va;
+                    va.x = lo.x; va.y = lo.y; va.z = hi.x; va.w = hi.y;
+                    o[df] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, va),
+                                                                   __builtin_bit_cast(bf16x8, pb), o[df], 0, 0, 0);
+                }
+            }
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
+    if (qrow < S) {
+        bf16_t* orow = p.out + ((size_t)b * S + qrow) * ((size_t)p.H * 64) + h * 64;
+#pragma unroll
+        for (int df = 0; df < 2; ++df)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 v;
+                v.x = a_pack2(o[df][4 * g + 0] * inv, o[df][4 * g + 1] * inv);
+                v.y = a_pack2(o[df][4 * g + 2] * inv, o[df][4 * g + 3] * inv);
+                *reinterpret_cast<uint2*>(orow + df * 32 + 8 * g + 4 * hh) = v;
+            }
+    }
+}
+
+hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
+    if (p.B <= 0 || p.H <= 0 || p.S <= 0) return hipErrorInvalidValue;
+    dim3 grid((p.S + 127) / 128, p.H, p.B), block(256);
+    size_t lds = K_LDS + VT_LDS + (p.bias_table ? (size_t)(2 * p.S - 1) * 4 : 0);
+    lds = (lds + 15) & ~(size_t)15;
+    if (lds > 65536) return hipErrorInvalidValue;
+    if (p.bias_table)
+        hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, block, lds, stream, p);
+    else
+        hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, block, lds, stream, p);
+    return hipGetLastError();
+}
+
+// =====================================================================================================
+// Decoder attention: T query rows per (sample, head); fp32 VALU.
+// =====================================================================================================
+static constexpr int DEC_TMAX = 16;
+
+__device__ __forceinline__ float block_reduce(float v, bool is_max, float* red, int tid) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float o = __shfl_xor(v, off);
+        v = is_max ? fmaxf(v, o) : v + o;
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    float r = red[0];
+#pragma unroll
+    for (int i = 1; i < 4; ++i) r = is_max ? fmaxf(r, red[i]) : r + red[i];
+    return r;
+}
+
+__global__ void __launch_bounds__(256) dec_attn_kernel(const DecAttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int T = p.T, S = p.S;
+    float* q_s = reinterpret_cast<float*>(smem);       // [T][64]
+    float* sc = q_s + T * 64;                          // [T][S]
+    float* part = sc + (size_t)T * S;                  // [4][T][64]
+    float* red = part + 4 * T * 64;                    // [4]
+    float* rsum = red + 4;                             // [T]
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int klen = p.cross ? (p.key_len ? min(p.key_len[b], S) : S) : S;
+
+    for (int i = tid; i < T * 64; i += 256) {
+        const int t = i >> 6, d = i & 63;
+        q_s[i] = a_bf2f(p.q[((size_t)b * T + t) * p.ldq + h * 64 + d]);
+    }
+    __syncthreads();
+
+    // ---- scores
+    for (int j = tid; j < S; j += 256) {
+        const bf16_t* krow = p.cross ? p.k + (((size_t)b * p.H + h) * S + j) * 64
+                                     : p.k + ((size_t)b * T + j) * p.ldk + h * 64;
+        float kv[64];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const uint4 u = *reinterpret_cast<const uint4*>(krow + c * 8);
+            const uint32_t w4[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                kv[c * 8 + 2 * e] = __uint_as_float(w4[e] << 16);
+                kv[c * 8 + 2 * e + 1] = __uint_as_float(w4[e] & 0xffff0000u);
+            }
+        }
+        for (int t = 0; t < T; ++t) {
+            float a = 0.0f;
+#pragma unroll
+            for (int d = 0; d < 64; ++d) a = fmaf(q_s[t * 64 + d], kv[d], a);
+            bool masked;
+            if (p.cross) {
+                masked = j >= klen;
+            } else {
+                masked = j > t;                                    // causal
+                if (!masked && p.bias_table) a += p.bias_table[h * T + (t - j)];
+            }
+            sc[(size_t)t * S + j] = masked ? NEG_BIG : a;
+        }
+    }
+    __syncthreads();
+
+    // ---- softmax statistics per query row
+    for (int t = 0; t < T; ++t) {
+        float mx = NEG_BIG;
+        for (int j = tid; j < S; j += 256) mx = fmaxf(mx, sc[(size_t)t * S + j]);
+        mx = block_reduce(mx, true, red, tid);
+        float sm = 0.0f;
+        for (int j = tid; j < S; j += 256) {
+            const float e = __expf(sc[(size_t)t * S + j] - mx);
+            sc[(size_t)t * S + j] = e;
+            sm += e;
+        }
+        sm = block_reduce(sm, false, red, tid);
+        if (tid == 0) rsum[t] = sm;
+    }
+    __syncthreads();
+
+    // ---- O[t][d] = sum_j p[t][j] V[j][d]; wave wv takes keys j = wv, wv+4, ...; lane = d
+    float acc[DEC_TMAX];
+#pragma unroll
+    for (int t = 0; t < DEC_TMAX; ++t) acc[t] = 0.0f;
+    for (int j = wv; j < S; j += 4) {
+        const bf16_t* vrow = p.cross ? p.v + (((size_t)b * p.H + h) * S + j) * 64
+                                     : p.v + ((size_t)b * T + j) * p.ldk + h * 64;
+        const float vv = a_bf2f(vrow[lane]);
+#pragma unroll
+        for (int t = 0; t < DEC_TMAX; ++t)
+            if (t < T) acc[t] = fmaf(sc[(size_t)t * S + j], vv, acc[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < DEC_TMAX; ++t)
+        if (t < T) part[(wv * T + t) * 64 + lane] = acc[t];
+    __syncthreads();
+    for (int i = tid; i < T * 64; i += 256) {
+        const int t = i >> 6, d = i & 63;
+        const float v = part[(0 * T + t) * 64 + d] + part[(1 * T + t) * 64 + d] + part[(2 * T + t) * 64 + d] +
+                        part[(3 * T + t) * 64 + d];
+        p.out[((size_t)b * T + t) * ((size_t)p.H * 64) + h * 64 + d] = a_f2bf(v / rsum[t]);
+    }
+}
+
+hipError_t launch_decoder_attention(const DecAttnParams& p, hipStream_t stream) {
+    if (p.T <= 0 || p.T > DEC_TMAX || p.S <= 0) return hipErrorInvalidValue;
+    size_t lds = ((size_t)p.T * 64 + (size_t)p.T * p.S + 4 * (size_t)p.T * 64 + 4 + p.T) * sizeof(float);
+    lds = (lds + 15) & ~(size_t)15;
+    if (lds > 65536) return hipErrorInvalidValue;
+    dim3 grid(p.H, p.B), block(256);
+    hipLaunchKernelGGL(dec_attn_kernel, grid, block, lds, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace vqs

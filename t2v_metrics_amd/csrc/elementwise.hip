@@ -1,0 +1,411 @@
+// HBM-bound kernels of the CLIP-FlanT5 path (K2, K3, K7-K10 of SURVEY.md §8(a-bis)) for gfx950.
+// All are row-parallel streaming kernels: one 64-lane wave per row where a row reduction is needed,
+// 16-byte accesses per lane, fp32 math.
+#include "vqs_kernels.h"
+
+namespace vqs {
+
+__device__ __forceinline__ float e_bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t e_f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t e_pack2(float a, float b) {
+    return (uint32_t)e_f2bf(a) | ((uint32_t)e_f2bf(b) << 16);
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// T5 RMSNorm (HF models/t5/modeling_t5.py:59-72): out = w * x * rsqrt(mean(x^2) + eps); fp32 stream in,
+// bf16 GEMM operand out.  One wave per row, two passes over the row (second pass hits L2).
+// D % 4 == 0.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) rmsnorm_kernel(const float* __restrict__ x, const bf16_t* __restrict__ w,
+                                                      bf16_t* __restrict__ out, int M, int D, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * D);
+    const int nv = D >> 2;
+    float ss = 0.0f;
+    for (int i = lane; i < nv; i += 64) {
+        const float4 v = xr[i];
+        ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    ss = wave_sum(ss);
+    const float rs = rsqrtf(ss / (float)D + eps);
+    uint2* orow = reinterpret_cast<uint2*>(out + (size_t)row * D);
+    const uint2* wr = reinterpret_cast<const uint2*>(w);
+    for (int i = lane; i < nv; i += 64) {
+        const float4 v = xr[i];
+        const uint2 wv = wr[i];
+        uint2 o;
+        o.x = e_pack2(v.x * rs * e_bf2f((bf16_t)(wv.x & 0xffff)), v.y * rs * e_bf2f((bf16_t)(wv.x >> 16)));
+        o.y = e_pack2(v.z * rs * e_bf2f((bf16_t)(wv.y & 0xffff)), v.w * rs * e_bf2f((bf16_t)(wv.y >> 16)));
+        orow[i] = o;
+    }
+}
+
+hipError_t launch_rmsnorm(const float* x, const bf16_t* w, bf16_t* out, int M, int D, float eps, hipStream_t s) {
+    if (D % 4) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(rmsnorm_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, w, out, M, D, eps);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// CLIP LayerNorm (torch.nn.LayerNorm at HF models/clip/modeling_clip.py:357-360,642): fp32 stats.
+// ------------------------------------------------------------------------------------------------
+template <bool OUT_F32>
+__global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict__ x, const bf16_t* __restrict__ w,
+                                                        const bf16_t* __restrict__ bsh, void* __restrict__ out, int M,
+                                                        int D, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * D);
+    const int nv = D >> 2;
+    float s1 = 0.0f;
+    for (int i = lane; i < nv; i += 64) {
+        const float4 v = xr[i];
+        s1 += v.x + v.y + v.z + v.w;
+    }
+    const float mu = wave_sum(s1) / (float)D;
+    float s2 = 0.0f;
+    for (int i = lane; i < nv; i += 64) {
+        const float4 v = xr[i];
+        const float a = v.x - mu, b = v.y - mu, c = v.z - mu, d = v.w - mu;
+        s2 += a * a + b * b + c * c + d * d;
+    }
+    const float rs = rsqrtf(wave_sum(s2) / (float)D + eps);
+    const uint2* wr = reinterpret_cast<const uint2*>(w);
+    const uint2* br = reinterpret_cast<const uint2*>(bsh);
+    for (int i = lane; i < nv; i += 64) {
+        const float4 v = xr[i];
+        const uint2 wv = wr[i], bv = br[i];
+        const float o0 = (v.x - mu) * rs * e_bf2f((bf16_t)(wv.x & 0xffff)) + e_bf2f((bf16_t)(bv.x & 0xffff));
+        const float o1 = (v.y - mu) * rs * e_bf2f((bf16_t)(wv.x >> 16)) + e_bf2f((bf16_t)(bv.x >> 16));
+        const float o2 = (v.z - mu) * rs * e_bf2f((bf16_t)(wv.y & 0xffff)) + e_bf2f((bf16_t)(bv.y & 0xffff));
+        const float o3 = (v.w - mu) * rs * e_bf2f((bf16_t)(wv.y >> 16)) + e_bf2f((bf16_t)(bv.y >> 16));
+        if (OUT_F32) {
+            reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)row * D)[i] = make_float4(o0, o1, o2, o3);
+        } else {
+            uint2 o;
+            o.x = e_pack2(o0, o1);
+            o.y = e_pack2(o2, o3);
+            reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(out) + (size_t)row * D)[i] = o;
+        }
+    }
+}
+
+hipError_t launch_layernorm(const float* x, const bf16_t* w, const bf16_t* b, void* out, int out_f32, int M, int D,
+                            float eps, hipStream_t s) {
+    if (D % 4) return hipErrorInvalidValue;
+    if (out_f32)
+        hipLaunchKernelGGL(layernorm_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, s, x, w, b, out, M, D, eps);
+    else
+        hipLaunchKernelGGL(layernorm_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, s, x, w, b, out, M, D, eps);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Patch gather for the 14x14/14 convolution (HF models/clip/modeling_clip.py:209-210) as a GEMM A
+// operand: out[(n*G + gy)*G + gx][c*p*p + ky*p + kx] = pixels[n][c][gy*p+ky][gx*p+kx]; columns
+// >= 3*p*p are zero.  One workgroup per (image, patch row gy): reads whole image rows (coalesced),
+// writes whole output rows.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) im2col_kernel(const bf16_t* __restrict__ px, bf16_t* __restrict__ out, int img,
+                                                     int patch, int kpad) {
+    const int G = img / patch;
+    const int n = blockIdx.y, gy = blockIdx.x;
+    const int kreal = 3 * patch * patch;
+    bf16_t* obase = out + ((size_t)(n * G + gy) * G) * kpad;
+    const int total = G * kpad;
+    for (int i = threadIdx.x; i < total; i += 256) {
+        const int gx = i / kpad, kk = i - gx * kpad;
+        bf16_t v = 0;
+        if (kk < kreal) {
+            const int c = kk / (patch * patch);
+            const int rem = kk - c * patch * patch;
+            const int ky = rem / patch, kx = rem - ky * patch;
+            v = px[(((size_t)n * 3 + c) * img + (gy * patch + ky)) * img + gx * patch + kx];
+        }
+        obase[i] = v;
+    }
+}
+
+hipError_t launch_im2col(const bf16_t* pixels, bf16_t* out, int N, int img, int patch, int kpad, hipStream_t s) {
+    const int G = img / patch;
+    hipLaunchKernelGGL(im2col_kernel, dim3(G, N), dim3(256), 0, s, pixels, out, img, patch, kpad);
+    return hipGetLastError();
+}
+
+// hidden[n,0,:] = cls + pos[0]; hidden[n,1+p,:] = patch_out[n*P+p] + pos[1+p]   (modeling_clip.py:213-217)
+__global__ void __launch_bounds__(256) vit_assemble_kernel(const float* __restrict__ patch_out,
+                                                           const bf16_t* __restrict__ cls,
+                                                           const bf16_t* __restrict__ pos, float* __restrict__ hidden,
+                                                           int P, int D) {
+    const int n = blockIdx.y, t = blockIdx.x;   // token 0..P
+    float* hrow = hidden + ((size_t)n * (P + 1) + t) * D;
+    const bf16_t* prow = pos + (size_t)t * D;
+    for (int i = threadIdx.x; i < D; i += 256) {
+        const float base = (t == 0) ? e_bf2f(cls[i]) : patch_out[((size_t)n * P + (t - 1)) * D + i];
+        hrow[i] = base + e_bf2f(prow[i]);
+    }
+}
+
+hipError_t launch_vit_assemble(const float* patch_out, const bf16_t* cls, const bf16_t* pos, float* hidden, int N,
+                               int P, int D, hipStream_t s) {
+    hipLaunchKernelGGL(vit_assemble_kernel, dim3(P + 1, N), dim3(256), 0, s, patch_out, cls, pos, hidden, P, D);
+    return hipGetLastError();
+}
+
+// feature select: hidden_states[-2][:, 1:] -> bf16 rows for the projector GEMM
+__global__ void __launch_bounds__(256) drop_cls_cast_kernel(const float* __restrict__ hidden, bf16_t* __restrict__ out,
+                                                            int P, int D) {
+    const int n = blockIdx.y, pidx = blockIdx.x;
+    const float4* src = reinterpret_cast<const float4*>(hidden + ((size_t)n * (P + 1) + 1 + pidx) * D);
+    uint2* dst = reinterpret_cast<uint2*>(out + ((size_t)n * P + pidx) * D);
+    for (int i = threadIdx.x; i < (D >> 2); i += 256) {
+        const float4 v = src[i];
+        uint2 o;
+        o.x = e_pack2(v.x, v.y);
+        o.y = e_pack2(v.z, v.w);
+        dst[i] = o;
+    }
+}
+
+hipError_t launch_drop_cls_cast(const float* hidden, bf16_t* out, int N, int P, int D, hipStream_t s) {
+    if (D % 4) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(drop_cls_cast_kernel, dim3(P, N), dim3(256), 0, s, hidden, out, P, D);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Prompt scan: ids [B,L] int32, trailing pad (0), exactly one sentinel (-200) among the non-pad ids
+// (/root/reference/t2v_metrics/models/vqascore_models/mm_utils.py:164-179).  err_flag bit0 = bad prompt.
+// ------------------------------------------------------------------------------------------------
+__global__ void prompt_scan_kernel(const int* __restrict__ ids, int B, int L, int P, int* __restrict__ sent_pos,
+                                   int* __restrict__ enc_len, int* __restrict__ err_flag) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int* r = ids + (size_t)b * L;
+    int n = 0, sp = -1, nsent = 0;
+    bool seen_pad = false, bad = false;
+    for (int i = 0; i < L; ++i) {
+        const int v = r[i];
+        if (v == 0) { seen_pad = true; continue; }
+        if (seen_pad) bad = true;                 // non-pad after pad: not right-padded
+        if (v == -200) { sp = n; ++nsent; }
+        ++n;
+    }
+    if (nsent != 1) bad = true;
+    if (bad) atomicOr(err_flag, 1);
+    sent_pos[b] = sp < 0 ? 0 : sp;
+    enc_len[b] = bad ? 1 : (n - 1 + P);
+}
+
+hipError_t launch_prompt_scan(const int* ids, int B, int L, int P, int* sent_pos, int* enc_len, int* err_flag,
+                              hipStream_t s) {
+    hipLaunchKernelGGL(prompt_scan_kernel, dim3((B + 63) / 64), dim3(64), 0, s, ids, B, L, P, sent_pos, enc_len,
+                       err_flag);
+    return hipGetLastError();
+}
+
+// inputs_embeds[b, s] = shared[id] | proj[img_index[b], s - sent_pos] | 0   
+__global__ void __launch_bounds__(256) embed_splice_kernel(const int* __restrict__ ids, const int* __restrict__ sent_pos,
+                                                           const int* __restrict__ enc_len,
+                                                           const int* __restrict__ img_index,
+                                                           const bf16_t* __restrict__ shared,
+                                                           const bf16_t* __restrict__ proj, float* __restrict__ out,
+                                                           int L, int P, int D, int vocab) {
+    const int b = blockIdx.y, s = blockIdx.x;
+    const int S_e = L - 1 + P;
+    float4* orow = reinterpret_cast<float4*>(out + ((size_t)b * S_e + s) * D);
+    const int sp = sent_pos[b], len = enc_len[b];
+    const bf16_t* src = nullptr;
+    if (s < len) {
+        if (s < sp) {
+            int id = ids[(size_t)b * L + s];
+            id = min(max(id, 0), vocab - 1);
+            src = shared + (size_t)id * D;
+        } else if (s < sp + P) {
+            src = proj + ((size_t)img_index[b] * P + (s - sp)) * D;
+        } else {
+            int id = ids[(size_t)b * L + (s - P + 1)];
+            id = min(max(id, 0), vocab - 1);
+            src = shared + (size_t)id * D;
+        }
+    }
+    for (int i = threadIdx.x; i < (D >> 2); i += 256) {
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (src) {
+            const uint2 v = reinterpret_cast<const uint2*>(src)[i];
+            o.x = e_bf2f((bf16_t)(v.x & 0xffff));
+            o.y = e_bf2f((bf16_t)(v.x >> 16));
+            o.z = e_bf2f((bf16_t)(v.y & 0xffff));
+            o.w = e_bf2f((bf16_t)(v.y >> 16));
+        }
+        orow[i] = o;
+    }
+}
+
+hipError_t launch_embed_splice(const int* ids, const int* sent_pos, const int* enc_len, const int* img_index,
+                               const bf16_t* shared, const bf16_t* proj, float* out, int B, int L, int P, int D,
+                               int vocab, hipStream_t s) {
+    if (D % 4) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(embed_splice_kernel, dim3(L - 1 + P, B), dim3(256), 0, s, ids, sent_pos, enc_len, img_index,
+                       shared, proj, out, L, P, D, vocab);
+    return hipGetLastError();
+}
+
+// decoder_input_ids = shift_right(labels) (HF models/t5/modeling_t5.py:618-637); h = shared[id]
+__global__ void __launch_bounds__(256) decoder_embed_kernel(const int* __restrict__ labels,
+                                                            const bf16_t* __restrict__ shared, float* __restrict__ out,
+                                                            int T, int D, int vocab) {
+    const int b = blockIdx.y, t = blockIdx.x;
+    int id = 0;                                          // decoder_start_token_id = pad = 0
+    if (t > 0) {
+        id = labels[(size_t)b * T + t - 1];
+        if (id == -100) id = 0;
+        id = min(max(id, 0), vocab - 1);
+    }
+    const bf16_t* src = shared + (size_t)id * D;
+    float* orow = out + ((size_t)b * T + t) * D;
+    for (int i = threadIdx.x; i < D; i += 256) orow[i] = e_bf2f(src[i]);
+}
+
+hipError_t launch_decoder_embed(const int* labels, const bf16_t* shared, float* out, int B, int T, int D, int vocab,
+                                hipStream_t s) {
+    hipLaunchKernelGGL(decoder_embed_kernel, dim3(T, B), dim3(256), 0, s, labels, shared, out, T, D, vocab);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Relative position bias tables (HF models/t5/modeling_t5.py:264-279) from a host-computed bucket LUT
+// (integer bucket function evaluated on the host with the oracle-pinned fp32 formula).
+//   enc_table[h][rel + S - 1] = W[bucket_bidir(rel)][h],  rel = key - query in [-(S-1), S-1]
+//   dec_table[h][dist]        = W[bucket_causal(-dist)][h], dist = query - key in [0, T-1]
+// lut index = min(|rel|, lut_len-1); bidirectional adds buckets/2 for rel > 0.
+// ------------------------------------------------------------------------------------------------
+__global__ void relpos_table_kernel(const bf16_t* __restrict__ rel_w, const int* __restrict__ lut_bidir,
+                                    const int* __restrict__ lut_causal, int lut_len, int buckets,
+                                    float* __restrict__ enc_table, int H, int S, float* __restrict__ dec_table, int T) {
+    const int h = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n_enc = 2 * S - 1;
+    if (enc_table && i < n_enc) {
+        const int rel = i - (S - 1);
+        const int a = min(abs(rel), lut_len - 1);
+        const int bucket = lut_bidir[a] + (rel > 0 ? buckets / 2 : 0);
+        enc_table[(size_t)h * n_enc + i] = e_bf2f(rel_w[(size_t)bucket * H + h]);
+    }
+    if (dec_table && i < T) {
+        const int a = min(i, lut_len - 1);
+        dec_table[(size_t)h * T + i] = e_bf2f(rel_w[(size_t)lut_causal[a] * H + h]);
+    }
+}
+
+// two launches (encoder table / decoder table) share this entry point: pass nullptr for the one not wanted
+hipError_t launch_relpos_table(const bf16_t* rel_weight, const int* bucket_lut_bidir, const int* bucket_lut_causal,
+                               int lut_len, int buckets, float* enc_table, int H, int S, float* dec_table, int T,
+                               hipStream_t s) {
+    const int n = enc_table ? 2 * S - 1 : T;
+    hipLaunchKernelGGL(relpos_table_kernel, dim3((n + 255) / 256, H), dim3(256), 0, s, rel_weight, bucket_lut_bidir,
+                       bucket_lut_causal, lut_len, buckets, enc_table, H, S, dec_table, T);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Scoring tail: fp32 log-softmax over the vocabulary + label gather; score = exp(mean over valid labels)
+// (CrossEntropyLoss(reduction='mean', ignore_index=-100) then exp(-loss): SURVEY.md §8a row a21).
+// One workgroup per (b,t) row; a second tiny kernel folds T positions.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) logprob_kernel(const float* __restrict__ logits, int ldl, int V,
+                                                      const int* __restrict__ labels, float* __restrict__ lp) {
+    __shared__ float red[4];
+    const int row = blockIdx.x;
+    const float* lr = logits + (size_t)row * ldl;
+    const int tid = threadIdx.x;
+    float mx = -3.0e38f;
+    for (int i = tid; i < V; i += 256) mx = fmaxf(mx, lr[i]);
+    mx = wave_max(mx);
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sm = 0.0f;
+    for (int i = tid; i < V; i += 256) sm += expf(lr[i] - mx);
+    sm = wave_sum(sm);
+    if ((tid & 63) == 0) red[tid >> 6] = sm;
+    __syncthreads();
+    if (tid == 0) {
+        const float tot = red[0] + red[1] + red[2] + red[3];
+        const int lab = labels[row];
+        lp[row] = (lab < 0 || lab >= V) ? 0.0f : (lr[lab] - mx - logf(tot));
+    }
+}
+
+__global__ void score_fold_kernel(const float* __restrict__ lp, const int* __restrict__ labels,
+                                  float* __restrict__ scores, int B, int T) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float s = 0.0f;
+    int n = 0;
+    for (int t = 0; t < T; ++t)
+        if (labels[(size_t)b * T + t] != -100) { s += lp[(size_t)b * T + t]; ++n; }
+    scores[b] = expf(s / (float)max(n, 1));
+}
+
+hipError_t launch_score_head(const float* logits, int ldl, int V, const int* labels, float* label_logprobs,
+                             float* scores, int B, int T, hipStream_t s) {
+    hipLaunchKernelGGL(logprob_kernel, dim3(B * T), dim3(256), 0, s, logits, ldl, V, labels, label_logprobs);
+    hipLaunchKernelGGL(score_fold_kernel, dim3((B + 63) / 64), dim3(64), 0, s, label_logprobs, labels, scores, B, T);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Bind-time weight packing
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) copy_rows_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
+                                                        int cols, int src_ld, int dst_ld, int dst_row_offset) {
+    const int r = blockIdx.x;
+    const bf16_t* s = src + (size_t)r * src_ld;
+    bf16_t* d = dst + (size_t)(dst_row_offset + r) * dst_ld;
+    for (int i = threadIdx.x; i < dst_ld; i += 256) d[i] = i < cols ? s[i] : (bf16_t)0;
+}
+
+hipError_t launch_copy_rows(const bf16_t* src, bf16_t* dst, int rows, int cols, int src_ld, int dst_ld,
+                            int dst_row_offset, hipStream_t s) {
+    hipLaunchKernelGGL(copy_rows_kernel, dim3(rows), dim3(256), 0, s, src, dst, cols, src_ld, dst_ld, dst_row_offset);
+    return hipGetLastError();
+}
+
+// dst rows [64j, 64j+32) = wi_0[32j .. 32j+32), rows [64j+32, 64j+64) = wi_1[32j .. 32j+32)
+__global__ void __launch_bounds__(256) interleave_gate_kernel(const bf16_t* __restrict__ wi0,
+                                                              const bf16_t* __restrict__ wi1, bf16_t* __restrict__ dst,
+                                                              int D) {
+    const int r = blockIdx.x;                 // 0 .. 2F-1
+    const int blk = r >> 6, within = r & 63;
+    const bf16_t* s = (within < 32 ? wi0 : wi1) + (size_t)(blk * 32 + (within & 31)) * D;
+    bf16_t* d = dst + (size_t)r * D;
+    for (int i = threadIdx.x; i < D; i += 256) d[i] = s[i];
+}
+
+hipError_t launch_interleave_gate(const bf16_t* wi0, const bf16_t* wi1, bf16_t* dst, int F, int D, hipStream_t s) {
+    if (F % 32) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(interleave_gate_kernel, dim3(2 * F), dim3(256), 0, s, wi0, wi1, dst, D);
+    return hipGetLastError();
+}
+
+}  // namespace vqs

@@ -1,0 +1,736 @@
+// Host side of libvqs_hip: the C ABI of include/vqs.h and the launch sequence of the CLIP-FlanT5
+// scoring pass.  The sequence restates what HF executes for the reference:
+//   CLIPVisionModel.forward   HF models/clip/modeling_clip.py:613-656  -> encode_images()
+//   T5Stack encoder           HF models/t5/modeling_t5.py:663-750      -> score(): encoder loop
+//   T5Stack decoder + lm_head HF models/t5/modeling_t5.py:1026-1047    -> score(): decoder loop
+// No device allocation, no stream synchronisation, no CPU fallback: if a launch fails the call
+// returns VQS_ERR_HIP and the message says which one.
+#include "../../include/vqs.h"
+#include "vqs_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+using vqs::bf16_t;
+
+struct WEntry {
+    const bf16_t* p;
+    int64_t numel;
+};
+
+struct vqs_handle {
+    vqs_config c;
+    std::string err;
+    std::unordered_map<std::string, WEntry> w;
+    bool bound = false;
+    int gemm_variant = 0;
+    // derived
+    int P = 0, Sv = 0, kpatch = 0, kpad = 0, I = 0;
+    // packed (device) weights
+    const bf16_t* patch_w = nullptr;
+    std::vector<const bf16_t*> vit_qkv_w, vit_qkv_b, enc_qkv, enc_wi, dec_qkv, dec_ckv, dec_wi;
+    const int* lut_bidir = nullptr;
+    const int* lut_causal = nullptr;
+    int lut_len = 0;
+    std::vector<int> h_lut_bidir, h_lut_causal;
+    // profiling
+    bool prof = false;
+    std::vector<hipEvent_t> ev;
+    size_t ev_used = 0;
+    double prof_flops = 0.0;
+};
+
+namespace {
+
+int fail(vqs_handle* h, int code, const std::string& msg) {
+    if (h) h->err = msg;
+    return code;
+}
+
+inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// Carves named regions out of a caller buffer; with base == nullptr it only measures.
+struct Carver {
+    char* base;
+    size_t off = 0;
+    std::unordered_map<std::string, size_t>* names;
+    template <typename T>
+    T* take(size_t n, const char* name = nullptr) {
+        off = align_up(off);
+        if (names && name) (*names)[name] = off;
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += n * sizeof(T);
+        return p;
+    }
+};
+
+struct EncodeWs {
+    bf16_t* im2col;
+    float* patch_out;
+    float* pre;
+    float* hidden;
+    bf16_t *xn, *q, *k, *v, *attn, *mid, *feat_in, *pmid;
+    size_t total;
+};
+
+EncodeWs carve_encode(const vqs_handle* h, char* base, int N, std::unordered_map<std::string, size_t>* names = nullptr) {
+    const vqs_config& c = h->c;
+    Carver cv{base, 0, names};
+    EncodeWs w;
+    const size_t NP = (size_t)N * h->P, NS = (size_t)N * h->Sv;
+    w.im2col = cv.take<bf16_t>(NP * h->kpad);
+    w.patch_out = cv.take<float>(NP * c.vis_hidden);
+    w.pre = cv.take<float>(NS * c.vis_hidden);
+    w.hidden = cv.take<float>(NS * c.vis_hidden, "vit_hidden");
+    w.xn = cv.take<bf16_t>(NS * c.vis_hidden);
+    w.q = cv.take<bf16_t>(NS * c.vis_hidden);
+    w.k = cv.take<bf16_t>(NS * c.vis_hidden);
+    w.v = cv.take<bf16_t>(NS * c.vis_hidden);
+    w.attn = cv.take<bf16_t>(NS * c.vis_hidden);
+    w.mid = cv.take<bf16_t>(NS * c.vis_mlp);
+    w.feat_in = cv.take<bf16_t>(NP * c.vis_hidden);
+    w.pmid = cv.take<bf16_t>(NP * c.d_model);
+    w.total = align_up(cv.off);
+    return w;
+}
+
+struct ScoreWs {
+    int *sent_pos, *enc_len, *flags;
+    float *enc_table, *dec_table, *hidden;
+    bf16_t *xn, *q, *k, *v, *attn, *ff, *enc_out, *ck, *cv;
+    float* dhid;
+    bf16_t *dxn, *dqkv, *dattn, *dq, *dff;
+    float* logits;
+    int ldl;
+    size_t total;
+};
+
+ScoreWs carve_score(const vqs_handle* h, char* base, int B, int L, int T,
+                    std::unordered_map<std::string, size_t>* names = nullptr) {
+    const vqs_config& c = h->c;
+    Carver cv{base, 0, names};
+    ScoreWs w;
+    const int S = L - 1 + h->P;
+    const size_t M = (size_t)B * S, MT = (size_t)B * T;
+    const int D = c.d_model, I = h->I, F = c.d_ff, H = c.n_heads;
+    w.sent_pos = cv.take<int>(B);
+    w.enc_len = cv.take<int>(B, "enc_len");
+    w.flags = cv.take<int>(4, "flags");
+    w.enc_table = cv.take<float>((size_t)H * (2 * S - 1));
+    w.dec_table = cv.take<float>((size_t)H * T);
+    w.hidden = cv.take<float>(M * D, "enc_in");   // the fp32 residual stream; holds enc_in until layer 0 runs
+    w.xn = cv.take<bf16_t>(M * D);
+    w.q = cv.take<bf16_t>(M * I);
+    w.k = cv.take<bf16_t>(M * I);
+    w.v = cv.take<bf16_t>(M * I);
+    w.attn = cv.take<bf16_t>(M * I);
+    w.ff = cv.take<bf16_t>(M * F);
+    w.enc_out = cv.take<bf16_t>(M * D, "enc_out");
+    w.ck = cv.take<bf16_t>(M * I);
+    w.cv = cv.take<bf16_t>(M * I);
+    w.dhid = cv.take<float>(MT * D);
+    w.dxn = cv.take<bf16_t>(MT * D);
+    w.dqkv = cv.take<bf16_t>(MT * 3 * I);
+    w.dattn = cv.take<bf16_t>(MT * I);
+    w.dq = cv.take<bf16_t>(MT * I);
+    w.dff = cv.take<bf16_t>(MT * F);
+    w.ldl = c.vocab;
+    w.logits = cv.take<float>(MT * w.ldl, "logits");
+    w.total = align_up(cv.off);
+    return w;
+}
+
+struct PackedLayout {
+    size_t patch_w;
+    std::vector<size_t> vit_qkv_w, vit_qkv_b, enc_qkv, enc_wi, dec_qkv, dec_ckv, dec_wi;
+    size_t lut_bidir, lut_causal;
+    size_t total;
+};
+
+PackedLayout packed_layout(const vqs_handle* h) {
+    const vqs_config& c = h->c;
+    Carver cv{nullptr, 0, nullptr};
+    PackedLayout pl;
+    auto take = [&](size_t elems) {
+        cv.off = align_up(cv.off);
+        size_t o = cv.off;
+        cv.off += elems * sizeof(bf16_t);
+        return o;
+    };
+    const size_t hid = c.vis_hidden, D = c.d_model, I = h->I, F = c.d_ff;
+    pl.patch_w = take(hid * h->kpad);
+    for (int i = 0; i < c.vis_layers_run; ++i) {
+        pl.vit_qkv_w.push_back(take(3 * hid * hid));
+        pl.vit_qkv_b.push_back(take(3 * hid));
+    }
+    for (int i = 0; i < c.enc_layers; ++i) {
+        pl.enc_qkv.push_back(take(3 * I * D));
+        pl.enc_wi.push_back(take(2 * F * D));
+    }
+    for (int i = 0; i < c.dec_layers; ++i) {
+        pl.dec_qkv.push_back(take(3 * I * D));
+        pl.dec_ckv.push_back(take(2 * I * D));
+        pl.dec_wi.push_back(take(2 * F * D));
+    }
+    pl.lut_bidir = take(2 * (size_t)(c.rel_max_distance + 1));   // int32 = 2 bf16 slots each
+    pl.lut_causal = take(2 * (size_t)(c.rel_max_distance + 1));
+    pl.total = align_up(cv.off);
+    return pl;
+}
+
+#define HIPCHK(h, expr, what)                                                                          \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess)                                                                          \
+            return fail(h, VQS_ERR_HIP, std::string(what) + ": " + hipGetErrorString(_e));             \
+    } while (0)
+
+int get_w(vqs_handle* h, const std::string& name, int64_t numel, const bf16_t** out) {
+    auto it = h->w.find(name);
+    if (it == h->w.end()) return fail(h, VQS_ERR_MISSING_WEIGHT, "missing weight: " + name);
+    if (it->second.numel != numel)
+        return fail(h, VQS_ERR_INVALID, "weight " + name + ": numel " + std::to_string(it->second.numel) +
+                                            " != expected " + std::to_string(numel));
+    *out = it->second.p;
+    return VQS_OK;
+}
+
+#define GETW(var, name, numel)                                   \
+    const bf16_t* var = nullptr;                                 \
+    do {                                                         \
+        int _r = get_w(h, (name), (int64_t)(numel), &var);       \
+        if (_r != VQS_OK) return _r;                             \
+    } while (0)
+
+struct GemmCall {
+    const bf16_t* A;
+    const bf16_t* W;
+    void* C;
+    const bf16_t* bias = nullptr;
+    const float* resid = nullptr;
+    int M, N, K;
+    int lda, ldw, ldc;
+    int epi;
+    int S = 0, H = 0, inner = 0;
+    bf16_t* heads[3] = {nullptr, nullptr, nullptr};
+};
+
+int run_gemm(vqs_handle* h, const GemmCall& g, hipStream_t st, const char* what) {
+    vqs::GemmParams p;
+    p.A = g.A; p.W = g.W; p.C = g.C; p.bias = g.bias; p.resid = g.resid;
+    p.M = g.M; p.N = g.N; p.K = g.K; p.lda = g.lda; p.ldw = g.ldw; p.ldc = g.ldc;
+    p.S = g.S > 0 ? g.S : 1; p.H = g.H; p.inner = g.inner > 0 ? g.inner : 1;
+    p.heads_out[0] = g.heads[0]; p.heads_out[1] = g.heads[1]; p.heads_out[2] = g.heads[2];
+    if (h->prof) {
+        while (h->ev.size() < h->ev_used + 2) {
+            hipEvent_t e;
+            HIPCHK(h, hipEventCreate(&e), "hipEventCreate");
+            h->ev.push_back(e);
+        }
+        HIPCHK(h, hipEventRecord(h->ev[h->ev_used], st), "hipEventRecord");
+    }
+    HIPCHK(h, vqs::launch_gemm(p, g.epi, h->gemm_variant, st), std::string("gemm ") + what);
+    if (h->prof) {
+        HIPCHK(h, hipEventRecord(h->ev[h->ev_used + 1], st), "hipEventRecord");
+        h->ev_used += 2;
+        h->prof_flops += 2.0 * (double)g.M * (double)g.N * (double)g.K;
+    }
+    return VQS_OK;
+}
+
+#define RUN(expr)                    \
+    do {                             \
+        int _r = (expr);             \
+        if (_r != VQS_OK) return _r; \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int32_t vqs_relpos_bucket(int32_t relative_position, int32_t bidirectional, int32_t num_buckets, int32_t max_distance) {
+    // HF models/t5/modeling_t5.py:238-262, same fp32 operation order as torch.
+    int32_t bucket = 0, nb = num_buckets, rp = relative_position;
+    if (bidirectional) {
+        nb /= 2;
+        if (rp > 0) bucket += nb;
+        if (rp < 0) rp = -rp;
+    } else {
+        rp = rp < 0 ? -rp : 0;
+    }
+    const int32_t max_exact = nb / 2;
+    if (rp < max_exact) return bucket + rp;
+    float v = logf((float)rp / (float)max_exact) / (float)std::log((double)max_distance / (double)max_exact);
+    v = v * (float)(nb - max_exact);
+    int32_t large = max_exact + (int32_t)v;
+    if (large > nb - 1) large = nb - 1;
+    return bucket + large;
+}
+
+int vqs_create(const vqs_config* cfg, vqs_handle** out) {
+    if (!cfg || !out) return VQS_ERR_INVALID;
+    vqs_handle* h = new vqs_handle();
+    h->c = *cfg;
+    const vqs_config& c = h->c;
+    *out = h;
+    auto bad = [&](const char* m) { return fail(h, VQS_ERR_INVALID, m); };
+    if (c.d_kv != 64) return bad("d_kv must be 64");
+    if (c.vis_hidden <= 0 || c.vis_heads <= 0 || c.vis_hidden != c.vis_heads * 64) return bad("vision head dim must be 64");
+    if (c.vis_patch <= 0 || c.vis_image % c.vis_patch) return bad("image size must be a multiple of the patch size");
+    if (c.vis_hidden % 64 || c.vis_mlp % 64 || c.d_model % 64 || c.d_ff % 64) return bad("hidden sizes must be multiples of 64");
+    if (c.vocab % 8) return bad("vocab must be a multiple of 8");
+    if (c.vis_layers_run < 1 || c.enc_layers < 1 || c.dec_layers < 1) return bad("layer counts must be positive");
+    const int g = c.vis_image / c.vis_patch;
+    h->P = g * g;
+    h->Sv = h->P + 1;
+    h->kpatch = 3 * c.vis_patch * c.vis_patch;
+    h->kpad = (h->kpatch + 63) / 64 * 64;
+    h->I = c.n_heads * c.d_kv;
+    h->lut_len = c.rel_max_distance + 1;
+    for (int n = 0; n < h->lut_len; ++n) {
+        // index = |relative position|; bidirectional: the +nb/2 for rel>0 is added on the device
+        h->h_lut_bidir.push_back(vqs_relpos_bucket(-n, 1, c.rel_buckets, c.rel_max_distance));
+        h->h_lut_causal.push_back(vqs_relpos_bucket(-n, 0, c.rel_buckets, c.rel_max_distance));
+    }
+    const char* v = std::getenv("VQS_GEMM_VARIANT");
+    h->gemm_variant = v ? std::atoi(v) : 0;
+    return VQS_OK;
+}
+
+void vqs_destroy(vqs_handle* h) {
+    if (!h) return;
+    for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+    delete h;
+}
+
+const char* vqs_last_error(const vqs_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+size_t vqs_packed_bytes(const vqs_handle* h) { return h ? packed_layout(h).total : 0; }
+
+int vqs_bind_weights(vqs_handle* h, const vqs_weight_desc* weights, int32_t n, void* d_packed, size_t packed_bytes,
+                     void* stream) {
+    if (!h || !weights || n <= 0 || !d_packed) return fail(h, VQS_ERR_INVALID, "bind_weights: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const vqs_config& c = h->c;
+    const PackedLayout pl = packed_layout(h);
+    if (packed_bytes < pl.total) return fail(h, VQS_ERR_WORKSPACE, "bind_weights: packed buffer too small");
+    h->bound = false;
+    h->w.clear();
+    for (int i = 0; i < n; ++i) {
+        if (!weights[i].name || !weights[i].d_data) return fail(h, VQS_ERR_INVALID, "bind_weights: null entry");
+        h->w[weights[i].name] = WEntry{(const bf16_t*)weights[i].d_data, weights[i].numel};
+    }
+    char* pk = (char*)d_packed;
+    auto at = [&](size_t off) { return reinterpret_cast<bf16_t*>(pk + off); };
+    const int hid = c.vis_hidden, D = c.d_model, I = h->I, F = c.d_ff;
+
+    // conv kernel [hid, 3*p*p] -> [hid, kpad] zero padded (K must be a multiple of 64)
+    {
+        GETW(pw, "vision.embeddings.patch_embedding.weight", (int64_t)hid * h->kpatch);
+        HIPCHK(h, vqs::launch_copy_rows(pw, at(pl.patch_w), hid, h->kpatch, h->kpatch, h->kpad, 0, st), "pack patch");
+        h->patch_w = at(pl.patch_w);
+    }
+    h->vit_qkv_w.clear(); h->vit_qkv_b.clear();
+    for (int i = 0; i < c.vis_layers_run; ++i) {
+        const std::string p = "vision.encoder.layers." + std::to_string(i) + ".self_attn.";
+        const char* nm[3] = {"q_proj", "k_proj", "v_proj"};
+        for (int j = 0; j < 3; ++j) {
+            GETW(ww, p + nm[j] + ".weight", (int64_t)hid * hid);
+            GETW(bb, p + nm[j] + ".bias", hid);
+            HIPCHK(h, vqs::launch_copy_rows(ww, at(pl.vit_qkv_w[i]), hid, hid, hid, hid, j * hid, st), "pack vit qkv");
+            HIPCHK(h, vqs::launch_copy_rows(bb, at(pl.vit_qkv_b[i]), 1, hid, hid, hid, j, st), "pack vit qkv bias");
+        }
+        h->vit_qkv_w.push_back(at(pl.vit_qkv_w[i]));
+        h->vit_qkv_b.push_back(at(pl.vit_qkv_b[i]));
+    }
+    auto pack_qkv = [&](const std::string& prefix, bf16_t* dst, int first, int count) -> int {
+        const char* nm[3] = {"q", "k", "v"};
+        for (int j = 0; j < count; ++j) {
+            GETW(ww, prefix + nm[first + j] + ".weight", (int64_t)I * D);
+            HIPCHK(h, vqs::launch_copy_rows(ww, dst, I, D, D, D, j * I, st), "pack t5 qkv");
+        }
+        return VQS_OK;
+    };
+    auto pack_wi = [&](const std::string& prefix, bf16_t* dst) -> int {
+        GETW(w0, prefix + "wi_0.weight", (int64_t)F * D);
+        GETW(w1, prefix + "wi_1.weight", (int64_t)F * D);
+        HIPCHK(h, vqs::launch_interleave_gate(w0, w1, dst, F, D, st), "pack wi");
+        return VQS_OK;
+    };
+    h->enc_qkv.clear(); h->enc_wi.clear(); h->dec_qkv.clear(); h->dec_ckv.clear(); h->dec_wi.clear();
+    for (int i = 0; i < c.enc_layers; ++i) {
+        const std::string p = "encoder.block." + std::to_string(i) + ".";
+        RUN(pack_qkv(p + "layer.0.SelfAttention.", at(pl.enc_qkv[i]), 0, 3));
+        RUN(pack_wi(p + "layer.1.DenseReluDense.", at(pl.enc_wi[i])));
+        h->enc_qkv.push_back(at(pl.enc_qkv[i]));
+        h->enc_wi.push_back(at(pl.enc_wi[i]));
+    }
+    for (int i = 0; i < c.dec_layers; ++i) {
+        const std::string p = "decoder.block." + std::to_string(i) + ".";
+        RUN(pack_qkv(p + "layer.0.SelfAttention.", at(pl.dec_qkv[i]), 0, 3));
+        RUN(pack_qkv(p + "layer.1.EncDecAttention.", at(pl.dec_ckv[i]), 1, 2));
+        RUN(pack_wi(p + "layer.2.DenseReluDense.", at(pl.dec_wi[i])));
+        h->dec_qkv.push_back(at(pl.dec_qkv[i]));
+        h->dec_ckv.push_back(at(pl.dec_ckv[i]));
+        h->dec_wi.push_back(at(pl.dec_wi[i]));
+    }
+    HIPCHK(h, hipMemcpyAsync(pk + pl.lut_bidir, h->h_lut_bidir.data(), h->lut_len * sizeof(int), hipMemcpyHostToDevice, st),
+           "upload bucket lut");
+    HIPCHK(h, hipMemcpyAsync(pk + pl.lut_causal, h->h_lut_causal.data(), h->lut_len * sizeof(int), hipMemcpyHostToDevice, st),
+           "upload bucket lut");
+    h->lut_bidir = reinterpret_cast<const int*>(pk + pl.lut_bidir);
+    h->lut_causal = reinterpret_cast<const int*>(pk + pl.lut_causal);
+    h->bound = true;
+    return VQS_OK;
+}
+
+size_t vqs_encode_workspace_bytes(const vqs_handle* h, int32_t n_img) {
+    if (!h || n_img <= 0) return 0;
+    return carve_encode(h, nullptr, n_img).total;
+}
+
+int vqs_encode_images(vqs_handle* h, const void* d_pixels, int32_t N, void* d_feats, void* d_ws, size_t ws_bytes,
+                      void* stream) {
+    if (!h) return VQS_ERR_INVALID;
+    if (!h->bound) return fail(h, VQS_ERR_STATE, "encode_images: weights not bound");
+    if (!d_pixels || !d_feats || !d_ws || N <= 0) return fail(h, VQS_ERR_INVALID, "encode_images: bad arguments");
+    const vqs_config& c = h->c;
+    const EncodeWs w = carve_encode(h, (char*)d_ws, N);
+    if (ws_bytes < w.total) return fail(h, VQS_ERR_WORKSPACE, "encode_images: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int hid = c.vis_hidden, P = h->P, Sv = h->Sv, mlp = c.vis_mlp, D = c.d_model;
+    const int NP = N * P, NS = N * Sv;
+
+    GETW(cls, "vision.embeddings.class_embedding", hid);
+    GETW(pos, "vision.embeddings.position_embedding.weight", (int64_t)Sv * hid);
+    GETW(pre_w, "vision.pre_layrnorm.weight", hid);
+    GETW(pre_b, "vision.pre_layrnorm.bias", hid);
+
+    HIPCHK(h, vqs::launch_im2col((const bf16_t*)d_pixels, w.im2col, N, c.vis_image, c.vis_patch, h->kpad, st), "im2col");
+    {
+        GemmCall g{w.im2col, h->patch_w, w.patch_out};
+        g.M = NP; g.N = hid; g.K = h->kpad; g.lda = h->kpad; g.ldw = h->kpad; g.ldc = hid; g.epi = vqs::EPI_F32;
+        RUN(run_gemm(h, g, st, "patch_embed"));
+    }
+    HIPCHK(h, vqs::launch_vit_assemble(w.patch_out, cls, pos, w.pre, N, P, hid, st), "vit_assemble");
+    HIPCHK(h, vqs::launch_layernorm(w.pre, pre_w, pre_b, w.hidden, 1, NS, hid, c.vis_ln_eps, st), "pre_layrnorm");
+
+    for (int i = 0; i < c.vis_layers_run; ++i) {
+        const std::string p = "vision.encoder.layers." + std::to_string(i) + ".";
+        GETW(ln1w, p + "layer_norm1.weight", hid);
+        GETW(ln1b, p + "layer_norm1.bias", hid);
+        GETW(ln2w, p + "layer_norm2.weight", hid);
+        GETW(ln2b, p + "layer_norm2.bias", hid);
+        GETW(ow, p + "self_attn.out_proj.weight", (int64_t)hid * hid);
+        GETW(ob, p + "self_attn.out_proj.bias", hid);
+        GETW(f1w, p + "mlp.fc1.weight", (int64_t)mlp * hid);
+        GETW(f1b, p + "mlp.fc1.bias", mlp);
+        GETW(f2w, p + "mlp.fc2.weight", (int64_t)hid * mlp);
+        GETW(f2b, p + "mlp.fc2.bias", hid);
+
+        HIPCHK(h, vqs::launch_layernorm(w.hidden, ln1w, ln1b, w.xn, 0, NS, hid, c.vis_ln_eps, st), "layer_norm1");
+        {
+            GemmCall g{w.xn, h->vit_qkv_w[i], nullptr};
+            g.bias = h->vit_qkv_b[i];
+            g.M = NS; g.N = 3 * hid; g.K = hid; g.lda = hid; g.ldw = hid; g.ldc = 0; g.epi = vqs::EPI_HEADS;
+            g.S = Sv; g.H = c.vis_heads; g.inner = hid;
+            g.heads[0] = w.q; g.heads[1] = w.k; g.heads[2] = w.v;
+            RUN(run_gemm(h, g, st, "vit qkv"));
+        }
+        {
+            vqs::AttnParams a{w.q, w.k, w.v, w.attn, nullptr, nullptr, N, c.vis_heads, Sv, 0.125f};
+            HIPCHK(h, vqs::launch_attention(a, st), "vit attention");
+        }
+        {
+            GemmCall g{w.attn, ow, w.hidden};
+            g.bias = ob; g.resid = w.hidden;
+            g.M = NS; g.N = hid; g.K = hid; g.lda = hid; g.ldw = hid; g.ldc = hid; g.epi = vqs::EPI_F32_RESID;
+            RUN(run_gemm(h, g, st, "vit out_proj"));
+        }
+        HIPCHK(h, vqs::launch_layernorm(w.hidden, ln2w, ln2b, w.xn, 0, NS, hid, c.vis_ln_eps, st), "layer_norm2");
+        {
+            GemmCall g{w.xn, f1w, w.mid};
+            g.bias = f1b;
+            g.M = NS; g.N = mlp; g.K = hid; g.lda = hid; g.ldw = hid; g.ldc = mlp; g.epi = vqs::EPI_BF16_QGELU;
+            RUN(run_gemm(h, g, st, "vit fc1"));
+        }
+        {
+            GemmCall g{w.mid, f2w, w.hidden};
+            g.bias = f2b; g.resid = w.hidden;
+            g.M = NS; g.N = hid; g.K = mlp; g.lda = mlp; g.ldw = mlp; g.ldc = hid; g.epi = vqs::EPI_F32_RESID;
+            RUN(run_gemm(h, g, st, "vit fc2"));
+        }
+    }
+    HIPCHK(h, vqs::launch_drop_cls_cast(w.hidden, w.feat_in, N, P, hid, st), "feature select");
+    GETW(p0w, "mm_projector.0.weight", (int64_t)D * hid);
+    GETW(p0b, "mm_projector.0.bias", D);
+    GETW(p2w, "mm_projector.2.weight", (int64_t)D * D);
+    GETW(p2b, "mm_projector.2.bias", D);
+    {
+        GemmCall g{w.feat_in, p0w, w.pmid};
+        g.bias = p0b;
+        g.M = NP; g.N = D; g.K = hid; g.lda = hid; g.ldw = hid; g.ldc = D; g.epi = vqs::EPI_BF16_GELU;
+        RUN(run_gemm(h, g, st, "mm_projector.0"));
+    }
+    {
+        GemmCall g{w.pmid, p2w, d_feats};
+        g.bias = p2b;
+        g.M = NP; g.N = D; g.K = D; g.lda = D; g.ldw = D; g.ldc = D; g.epi = vqs::EPI_BF16;
+        RUN(run_gemm(h, g, st, "mm_projector.2"));
+    }
+    return VQS_OK;
+}
+
+size_t vqs_score_workspace_bytes(const vqs_handle* h, int32_t B, int32_t L, int32_t T) {
+    if (!h || B <= 0 || L < 1 || T <= 0) return 0;
+    return carve_score(h, nullptr, B, L, T).total;
+}
+
+int vqs_score(vqs_handle* h, const void* d_feats, const int32_t* d_img_index, const int32_t* d_input_ids,
+              const int32_t* d_labels, int32_t B, int32_t L, int32_t T, float* d_lp, float* d_scores, void* d_ws,
+              size_t ws_bytes, void* stream) {
+    if (!h) return VQS_ERR_INVALID;
+    if (!h->bound) return fail(h, VQS_ERR_STATE, "score: weights not bound");
+    if (!d_feats || !d_img_index || !d_input_ids || !d_labels || !d_lp || !d_scores || !d_ws)
+        return fail(h, VQS_ERR_INVALID, "score: null argument");
+    if (B <= 0 || L < 1 || T <= 0 || T > 16) return fail(h, VQS_ERR_INVALID, "score: need B>0, L>=1, 1<=T<=16");
+    const vqs_config& c = h->c;
+    const int P = h->P, S = L - 1 + P;
+    if (L - 1 > 2048) return fail(h, VQS_ERR_INVALID, "score: prompt longer than CONTEXT_LEN (2048)");
+    if ((size_t)(2 * S - 1) * 4 + 16896 + 16 > 65536) return fail(h, VQS_ERR_INVALID, "score: encoder length too large for the bias table");
+    const ScoreWs w = carve_score(h, (char*)d_ws, B, L, T);
+    if (ws_bytes < w.total) return fail(h, VQS_ERR_WORKSPACE, "score: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int D = c.d_model, I = h->I, F = c.d_ff, H = c.n_heads, V = c.vocab;
+    const int M = B * S, MT = B * T;
+
+    GETW(shared, "shared.weight", (int64_t)V * D);
+    GETW(enc_rel, "encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight", (int64_t)c.rel_buckets * H);
+    GETW(dec_rel, "decoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight", (int64_t)c.rel_buckets * H);
+
+    HIPCHK(h, hipMemsetAsync(w.flags, 0, 4 * sizeof(int), st), "memset flags");
+    HIPCHK(h, vqs::launch_prompt_scan(d_input_ids, B, L, P, w.sent_pos, w.enc_len, w.flags, st), "prompt_scan");
+    HIPCHK(h, vqs::launch_relpos_table(enc_rel, h->lut_bidir, h->lut_causal, h->lut_len, c.rel_buckets, w.enc_table, H, S,
+                                       nullptr, T, st), "encoder bias table");
+    HIPCHK(h, vqs::launch_relpos_table(dec_rel, h->lut_bidir, h->lut_causal, h->lut_len, c.rel_buckets, nullptr, H, S,
+                                       w.dec_table, T, st), "decoder bias table");
+    HIPCHK(h, vqs::launch_embed_splice(d_input_ids, w.sent_pos, w.enc_len, d_img_index, shared, (const bf16_t*)d_feats,
+                                       w.hidden, B, L, P, D, V, st), "embed_splice");
+
+    // ---------------- encoder
+    for (int i = 0; i < c.enc_layers; ++i) {
+        const std::string p = "encoder.block." + std::to_string(i) + ".";
+        GETW(ln0, p + "layer.0.layer_norm.weight", D);
+        GETW(ow, p + "layer.0.SelfAttention.o.weight", (int64_t)D * I);
+        GETW(ln1, p + "layer.1.layer_norm.weight", D);
+        GETW(wo, p + "layer.1.DenseReluDense.wo.weight", (int64_t)D * F);
+        HIPCHK(h, vqs::launch_rmsnorm(w.hidden, ln0, w.xn, M, D, c.t5_ln_eps, st), "enc rmsnorm0");
+        {
+            GemmCall g{w.xn, h->enc_qkv[i], nullptr};
+            g.M = M; g.N = 3 * I; g.K = D; g.lda = D; g.ldw = D; g.ldc = 0; g.epi = vqs::EPI_HEADS;
+            g.S = S; g.H = H; g.inner = I;
+            g.heads[0] = w.q; g.heads[1] = w.k; g.heads[2] = w.v;
+            RUN(run_gemm(h, g, st, "enc qkv"));
+        }
+        {
+            vqs::AttnParams a{w.q, w.k, w.v, w.attn, w.enc_table, w.enc_len, B, H, S, 1.0f};
+            HIPCHK(h, vqs::launch_attention(a, st), "enc attention");
+        }
+        {
+            GemmCall g{w.attn, ow, w.hidden};
+            g.resid = w.hidden;
+            g.M = M; g.N = D; g.K = I; g.lda = I; g.ldw = I; g.ldc = D; g.epi = vqs::EPI_F32_RESID;
+            RUN(run_gemm(h, g, st, "enc o"));
+        }
+        HIPCHK(h, vqs::launch_rmsnorm(w.hidden, ln1, w.xn, M, D, c.t5_ln_eps, st), "enc rmsnorm1");
+        {
+            GemmCall g{w.xn, h->enc_wi[i], w.ff};
+            g.M = M; g.N = 2 * F; g.K = D; g.lda = D; g.ldw = D; g.ldc = F; g.epi = vqs::EPI_GATED;
+            RUN(run_gemm(h, g, st, "enc wi"));
+        }
+        {
+            GemmCall g{w.ff, wo, w.hidden};
+            g.resid = w.hidden;
+            g.M = M; g.N = D; g.K = F; g.lda = F; g.ldw = F; g.ldc = D; g.epi = vqs::EPI_F32_RESID;
+            RUN(run_gemm(h, g, st, "enc wo"));
+        }
+    }
+    {
+        GETW(fin, "encoder.final_layer_norm.weight", D);
+        HIPCHK(h, vqs::launch_rmsnorm(w.hidden, fin, w.enc_out, M, D, c.t5_ln_eps, st), "enc final norm");
+    }
+
+    // ---------------- decoder (teacher forced, T rows per pair)
+    HIPCHK(h, vqs::launch_decoder_embed(d_labels, shared, w.dhid, B, T, D, V, st), "decoder embed");
+    for (int i = 0; i < c.dec_layers; ++i) {
+        const std::string p = "decoder.block." + std::to_string(i) + ".";
+        GETW(ln0, p + "layer.0.layer_norm.weight", D);
+        GETW(so, p + "layer.0.SelfAttention.o.weight", (int64_t)D * I);
+        GETW(ln1, p + "layer.1.layer_norm.weight", D);
+        GETW(cq, p + "layer.1.EncDecAttention.q.weight", (int64_t)I * D);
+        GETW(co, p + "layer.1.EncDecAttention.o.weight", (int64_t)D * I);
+        GETW(ln2, p + "layer.2.layer_norm.weight", D);
+        GETW(wo, p + "layer.2.DenseReluDense.wo.weight", (int64_t)D * F);
+
+        HIPCHK(h, vqs::launch_rmsnorm(w.dhid, ln0, w.dxn, MT, D, c.t5_ln_eps, st), "dec rmsnorm0");
+        {
+            GemmCall g{w.dxn, h->dec_qkv[i], w.dqkv};
+            g.M = MT; g.N = 3 * I; g.K = D; g.lda = D; g.ldw = D; g.ldc = 3 * I; g.epi = vqs::EPI_BF16;
+            RUN(run_gemm(h, g, st, "dec self qkv"));
+        }
+        {
+            vqs::DecAttnParams a{w.dqkv, w.dqkv + I, w.dqkv + 2 * I, w.dattn, w.dec_table, nullptr, B, H, T, T, 3 * I, 3 * I, 0};
+            HIPCHK(h, vqs::launch_decoder_attention(a, st), "dec self attention");
+        }
+        {
+            GemmCall g{w.dattn, so, w.dhid};
+            g.resid = w.dhid;
+            g.M = MT; g.N = D; g.K = I; g.lda = I; g.ldw = I; g.ldc = D; g.epi = vqs::EPI_F32_RESID;
+            RUN(run_gemm(h, g, st, "dec self o"));
+        }
+        HIPCHK(h, vqs::launch_rmsnorm(w.dhid, ln1, w.dxn, MT, D, c.t5_ln_eps, st), "dec rmsnorm1");
+        {
+            GemmCall g{w.dxn, cq, w.dq};
+            g.M = MT; g.N = I; g.K = D; g.lda = D; g.ldw = D; g.ldc = I; g.epi = vqs::EPI_BF16;
+            RUN(run_gemm(h, g, st, "dec cross q"));
+        }
+        {
+            GemmCall g{w.enc_out, h->dec_ckv[i], nullptr};
+            g.M = M; g.N = 2 * I; g.K = D; g.lda = D; g.ldw = D; g.ldc = 0; g.epi = vqs::EPI_HEADS;
+            g.S = S; g.H = H; g.inner = I;
+            g.heads[0] = w.ck; g.heads[1] = w.cv; g.heads[2] = nullptr;
+            RUN(run_gemm(h, g, st, "dec cross kv"));
+        }
+        {
+            vqs::DecAttnParams a{w.dq, w.ck, w.cv, w.dattn, nullptr, w.enc_len, B, H, T, S, I, 0, 1};
+            HIPCHK(h, vqs::launch_decoder_attention(a, st), "dec cross attention");
+        }
+        {
+            GemmCall g{w.dattn, co, w.dhid};
+            g.resid = w.dhid;
+            g.M = MT; g.N = D; g.K = I; g.lda = I; g.ldw = I; g.ldc = D; g.epi = vqs::EPI_F32_RESID;
+            RUN(run_gemm(h, g, st, "dec cross o"));
+        }
+        HIPCHK(h, vqs::launch_rmsnorm(w.dhid, ln2, w.dxn, MT, D, c.t5_ln_eps, st), "dec rmsnorm2");
+        {
+            GemmCall g{w.dxn, h->dec_wi[i], w.dff};
+            g.M = MT; g.N = 2 * F; g.K = D; g.lda = D; g.ldw = D; g.ldc = F; g.epi = vqs::EPI_GATED;
+            RUN(run_gemm(h, g, st, "dec wi"));
+        }
+        {
+            GemmCall g{w.dff, wo, w.dhid};
+            g.resid = w.dhid;
+            g.M = MT; g.N = D; g.K = F; g.lda = F; g.ldw = F; g.ldc = D; g.epi = vqs::EPI_F32_RESID;
+            RUN(run_gemm(h, g, st, "dec wo"));
+        }
+    }
+    {
+        GETW(fin, "decoder.final_layer_norm.weight", D);
+        GETW(head, "lm_head.weight", (int64_t)V * D);
+        HIPCHK(h, vqs::launch_rmsnorm(w.dhid, fin, w.dxn, MT, D, c.t5_ln_eps, st), "dec final norm");
+        GemmCall g{w.dxn, head, w.logits};
+        g.M = MT; g.N = V; g.K = D; g.lda = D; g.ldw = D; g.ldc = w.ldl; g.epi = vqs::EPI_F32;
+        RUN(run_gemm(h, g, st, "lm_head"));
+    }
+    HIPCHK(h, vqs::launch_score_head(w.logits, w.ldl, V, d_labels, d_lp, d_scores, B, T, st), "score head");
+    return VQS_OK;
+}
+
+int64_t vqs_workspace_offset(const vqs_handle* h, const char* name, int32_t B, int32_t L, int32_t T, int64_t* ld_out) {
+    if (!h || !name) return -1;
+    std::unordered_map<std::string, size_t> names;
+    int64_t ld = 0;
+    const std::string n(name);
+    if (n == "vit_hidden") {
+        if (B <= 0) return -1;
+        carve_encode(h, nullptr, B, &names);
+        ld = h->c.vis_hidden;
+    } else {
+        if (B <= 0 || L < 1 || T <= 0) return -1;
+        const ScoreWs w = carve_score(h, nullptr, B, L, T, &names);
+        if (n == "logits") ld = w.ldl;
+        else if (n == "enc_in" || n == "enc_out") ld = h->c.d_model;
+        else ld = 1;
+    }
+    auto it = names.find(n);
+    if (it == names.end()) return -1;
+    if (ld_out) *ld_out = ld;
+    return (int64_t)it->second;
+}
+
+int vqs_profile_enable(vqs_handle* h, int32_t on) {
+    if (!h) return VQS_ERR_INVALID;
+    h->prof = on != 0;
+    return VQS_OK;
+}
+
+int vqs_profile_read(vqs_handle* h, double* gemm_ms, double* gemm_flops, int32_t reset) {
+    if (!h) return VQS_ERR_INVALID;
+    double ms = 0.0;
+    for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
+        HIPCHK(h, hipEventSynchronize(h->ev[i + 1]), "hipEventSynchronize");
+        float t = 0.f;
+        HIPCHK(h, hipEventElapsedTime(&t, h->ev[i], h->ev[i + 1]), "hipEventElapsedTime");
+        ms += t;
+    }
+    if (gemm_ms) *gemm_ms = ms;
+    if (gemm_flops) *gemm_flops = h->prof_flops;
+    const int n = (int)(h->ev_used / 2);
+    if (reset) {
+        h->ev_used = 0;
+        h->prof_flops = 0.0;
+    }
+    return n;
+}
+
+// ---------------------------------------------------------------------------- single-kernel entry points
+int vqs_gemm(const void* A, const void* W, void* C, const void* bias, const float* resid, int32_t M, int32_t N, int32_t K,
+             int32_t lda, int32_t ldw, int32_t ldc, int32_t epilogue, int32_t S, int32_t H, int32_t variant, void* stream) {
+    vqs::GemmParams p;
+    p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.C = C; p.bias = (const bf16_t*)bias; p.resid = resid;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc;
+    p.S = S > 0 ? S : 1; p.H = H; p.inner = H * 64 > 0 ? H * 64 : 1;
+    const size_t per = (size_t)(S > 0 ? M / S : 0) * H * S * 64;   // elements per head-major tensor
+    p.heads_out[0] = (bf16_t*)C;
+    p.heads_out[1] = (bf16_t*)C + per;
+    p.heads_out[2] = (bf16_t*)C + 2 * per;
+    return vqs::launch_gemm(p, epilogue, variant, (hipStream_t)stream) == hipSuccess ? VQS_OK : VQS_ERR_HIP;
+}
+
+int vqs_attention(const void* q, const void* k, const void* v, void* out, const float* bias_table, const int32_t* key_len,
+                  int32_t B, int32_t H, int32_t S, float scale, void* stream) {
+    vqs::AttnParams a{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, bias_table, key_len, B, H, S, scale};
+    return vqs::launch_attention(a, (hipStream_t)stream) == hipSuccess ? VQS_OK : VQS_ERR_HIP;
+}
+
+int vqs_decoder_attention(const void* q, const void* k, const void* v, void* out, const float* bias_table,
+                          const int32_t* key_len, int32_t B, int32_t H, int32_t T, int32_t S, int32_t ldq, int32_t ldk,
+                          int32_t cross, void* stream) {
+    vqs::DecAttnParams a{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, bias_table, key_len,
+                         B, H, T, S, ldq, ldk, cross};
+    return vqs::launch_decoder_attention(a, (hipStream_t)stream) == hipSuccess ? VQS_OK : VQS_ERR_HIP;
+}
+
+int vqs_rmsnorm(const float* x, const void* w, void* out, int32_t M, int32_t D, float eps, void* stream) {
+    return vqs::launch_rmsnorm(x, (const bf16_t*)w, (bf16_t*)out, M, D, eps, (hipStream_t)stream) == hipSuccess ? VQS_OK : VQS_ERR_HIP;
+}
+
+int vqs_layernorm(const float* x, const void* w, const void* b, void* out, int32_t out_f32, int32_t M, int32_t D, float eps,
+                  void* stream) {
+    return vqs::launch_layernorm(x, (const bf16_t*)w, (const bf16_t*)b, out, out_f32, M, D, eps, (hipStream_t)stream) == hipSuccess
+               ? VQS_OK : VQS_ERR_HIP;
+}
+
+int vqs_score_head(const float* logits, int32_t ldl, int32_t V, const int32_t* labels, float* lp, float* scores, int32_t B,
+                   int32_t T, void* stream) {
+    return vqs::launch_score_head(logits, ldl, V, labels, lp, scores, B, T, (hipStream_t)stream) == hipSuccess ? VQS_OK : VQS_ERR_HIP;
+}
+
+}  // extern "C"

@@ -1,0 +1,100 @@
+// Internal launcher interface between the C-ABI host code (vqs_api.cpp) and the gfx950 kernels.
+// Everything here is device-pointer plumbing; no torch types, no allocation.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vqs {
+
+typedef uint16_t bf16_t;   // raw bf16 bits
+
+// ---------------------------------------------------------------- GEMM (gemm.hip)
+// C = epilogue(A[M,K] . W[N,K]^T), bf16 operands (both K-contiguous, HF nn.Linear layout), fp32 accumulate.
+enum GemmEpilogue : int {
+    EPI_BF16 = 0,        // C bf16 [M,ldc] = acc (+bias)
+    EPI_BF16_QGELU = 1,  // quick_gelu(acc + bias)           HF activations.py:117-123
+    EPI_BF16_GELU = 2,   // erf-GELU(acc + bias)             mlp2x_gelu projector
+    EPI_F32 = 3,         // C fp32 [M,ldc] = acc (+bias)
+    EPI_F32_RESID = 4,   // C fp32 [M,ldc] = resid + acc (+bias); resid may alias C
+    EPI_GATED = 5,       // C bf16 [M,N/2] = gelu_new(acc[wi_0 col]) * acc[wi_1 col]; W rows interleaved in blocks of 32
+    EPI_HEADS = 6,       // scatter to head-major [B,H,S,64] tensors: which = col / inner selects heads_out[which]
+    EPI_COUNT = 7
+};
+
+struct GemmParams {
+    const bf16_t* A;
+    const bf16_t* W;
+    void* C;
+    const bf16_t* bias;      // [N] or nullptr
+    const float* resid;      // EPI_F32_RESID
+    int M, N, K;
+    int lda, ldw, ldc;       // in elements
+    // EPI_HEADS
+    int S, H, inner;
+    bf16_t* heads_out[3];
+};
+
+// variant 0 = direct-to-LDS (global_load_lds) staging; variant 1 = register-staged (debug / A-B)
+hipError_t launch_gemm(const GemmParams& p, int epilogue, int variant, hipStream_t stream);
+
+// ---------------------------------------------------------------- attention (attn.hip)
+struct AttnParams {
+    const bf16_t* q;          // [B,H,S,64]
+    const bf16_t* k;          // [B,H,S,64]
+    const bf16_t* v;          // [B,H,S,64]
+    bf16_t* out;              // [B*S, H*64] token-major
+    const float* bias_table;  // [H, 2*S-1] fp32 (index = key - query + S - 1) or nullptr
+    const int* key_len;       // [B] valid keys per sample or nullptr (= S)
+    int B, H, S;
+    float scale;
+};
+hipError_t launch_attention(const AttnParams& p, hipStream_t stream);
+
+// decoder attention (T <= 16 query rows per sample; fp32 VALU): self (causal + bucket bias) and cross.
+struct DecAttnParams {
+    const bf16_t* q;          // [B*T, ldq] token-major; head h at columns h*64
+    const bf16_t* k;          // self: [B*T, ldk] token-major; cross: [B,H,S,64] head-major
+    const bf16_t* v;
+    bf16_t* out;              // [B*T, H*64]
+    const float* bias_table;  // self: [H, T] fp32 indexed by (query - key); cross: nullptr
+    const int* key_len;       // cross: [B]; self: nullptr
+    int B, H, T, S;           // S = number of keys (T for self)
+    int ldq, ldk;
+    int cross;
+};
+hipError_t launch_decoder_attention(const DecAttnParams& p, hipStream_t stream);
+
+// ---------------------------------------------------------------- norms + glue (elementwise.hip)
+hipError_t launch_rmsnorm(const float* x, const bf16_t* w, bf16_t* out, int M, int D, float eps, hipStream_t s);
+hipError_t launch_layernorm(const float* x, const bf16_t* w, const bf16_t* b, void* out, int out_f32, int M, int D,
+                            float eps, hipStream_t s);
+// pixels bf16 [N,3,IMG,IMG] -> rows [N*G*G, Kpad] in (c,ky,kx) order, zero padded
+hipError_t launch_im2col(const bf16_t* pixels, bf16_t* out, int N, int img, int patch, int kpad, hipStream_t s);
+// hidden[n, 0] = cls + pos[0]; hidden[n, 1+p] = patch_out[n*P+p] + pos[1+p]   (fp32 out)
+hipError_t launch_vit_assemble(const float* patch_out, const bf16_t* cls, const bf16_t* pos, float* hidden, int N,
+                               int P, int D, hipStream_t s);
+// stream fp32 [N, 1+P, D] -> bf16 [N*P, D] dropping the CLS row
+hipError_t launch_drop_cls_cast(const float* hidden, bf16_t* out, int N, int P, int D, hipStream_t s);
+// per sample: sentinel position and spliced length from int32 ids [B,L] (pad = 0 trailing, sentinel = -200)
+hipError_t launch_prompt_scan(const int* ids, int B, int L, int P, int* sent_pos, int* enc_len, int* err_flag,
+                              hipStream_t s);
+// inputs_embeds fp32 [B, S_e, D]
+hipError_t launch_embed_splice(const int* ids, const int* sent_pos, const int* enc_len, const int* img_index,
+                               const bf16_t* shared, const bf16_t* proj, float* out, int B, int L, int P, int D,
+                               int vocab, hipStream_t s);
+// decoder_input_ids = shift_right(labels); h[b,t] = shared[id]  (fp32 out)
+hipError_t launch_decoder_embed(const int* labels, const bf16_t* shared, float* out, int B, int T, int D, int vocab,
+                                hipStream_t s);
+// bias tables from the [buckets,H] bf16 embedding and a host-computed bucket LUT
+hipError_t launch_relpos_table(const bf16_t* rel_weight, const int* bucket_lut_bidir, const int* bucket_lut_causal,
+                               int lut_len, int buckets, float* enc_table, int H, int S, float* dec_table, int T,
+                               hipStream_t s);
+// logits fp32 [B*T, ldl] -> label_logprobs [B,T] (0 where label == -100) and scores [B]
+hipError_t launch_score_head(const float* logits, int ldl, int V, const int* labels, float* label_logprobs,
+                             float* scores, int B, int T, hipStream_t s);
+// weight packing helpers (bind time)
+hipError_t launch_copy_rows(const bf16_t* src, bf16_t* dst, int rows, int cols, int src_ld, int dst_ld,
+                            int dst_row_offset, hipStream_t s);   // dst[dst_row_offset + r, 0:cols] = src[r, 0:cols], zero pad to dst_ld
+hipError_t launch_interleave_gate(const bf16_t* wi0, const bf16_t* wi1, bf16_t* dst, int F, int D, hipStream_t s);
+
+}  // namespace vqs

@@ -1,0 +1,332 @@
+"""ctypes binding of ``libvqs_hip.so`` (C ABI in ``include/vqs.h``).
+
+PyTorch is used here for device memory and the current HIP stream only; every FLOP of the scoring
+pass runs in the hand-written gfx950 kernels behind the C ABI.  There is deliberately NO fallback:
+if the shared library is missing or a call fails, this module raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from .config import ClipT5Config
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvqs_hip.so")
+
+_c_i32, _c_i64, _c_f32, _c_vp, _c_sz = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+
+
+class VqsConfig(ctypes.Structure):
+    _fields_ = [
+        ("vis_hidden", _c_i32), ("vis_layers_run", _c_i32), ("vis_heads", _c_i32), ("vis_mlp", _c_i32),
+        ("vis_patch", _c_i32), ("vis_image", _c_i32), ("vis_ln_eps", _c_f32),
+        ("d_model", _c_i32), ("n_heads", _c_i32), ("d_kv", _c_i32), ("d_ff", _c_i32), ("enc_layers", _c_i32),
+        ("dec_layers", _c_i32), ("vocab", _c_i32), ("rel_buckets", _c_i32), ("rel_max_distance", _c_i32),
+        ("t5_ln_eps", _c_f32),
+    ]
+
+
+class VqsWeightDesc(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char_p), ("d_data", _c_vp), ("numel", _c_i64)]
+
+
+class VqsError(RuntimeError):
+    pass
+
+
+# every symbol declared in include/vqs.h: (restype, argtypes)
+_SIGNATURES = {
+    "vqs_create": (_c_i32, [ctypes.POINTER(VqsConfig), ctypes.POINTER(_c_vp)]),
+    "vqs_destroy": (None, [_c_vp]),
+    "vqs_last_error": (ctypes.c_char_p, [_c_vp]),
+    "vqs_packed_bytes": (_c_sz, [_c_vp]),
+    "vqs_bind_weights": (_c_i32, [_c_vp, ctypes.POINTER(VqsWeightDesc), _c_i32, _c_vp, _c_sz, _c_vp]),
+    "vqs_encode_workspace_bytes": (_c_sz, [_c_vp, _c_i32]),
+    "vqs_encode_images": (_c_i32, [_c_vp, _c_vp, _c_i32, _c_vp, _c_vp, _c_sz, _c_vp]),
+    "vqs_score_workspace_bytes": (_c_sz, [_c_vp, _c_i32, _c_i32, _c_i32]),
+    "vqs_score": (_c_i32, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i32, _c_i32, _c_i32, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),
+    "vqs_workspace_offset": (_c_i64, [_c_vp, ctypes.c_char_p, _c_i32, _c_i32, _c_i32, ctypes.POINTER(_c_i64)]),
+    "vqs_profile_enable": (_c_i32, [_c_vp, _c_i32]),
+    "vqs_profile_read": (_c_i32, [_c_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), _c_i32]),
+    "vqs_gemm": (_c_i32, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp] + [_c_i32] * 10 + [_c_vp]),
+    "vqs_attention": (_c_i32, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i32, _c_i32, _c_i32, _c_f32, _c_vp]),
+    "vqs_decoder_attention": (_c_i32, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp] + [_c_i32] * 7 + [_c_vp]),
+    "vqs_rmsnorm": (_c_i32, [_c_vp, _c_vp, _c_vp, _c_i32, _c_i32, _c_f32, _c_vp]),
+    "vqs_layernorm": (_c_i32, [_c_vp, _c_vp, _c_vp, _c_vp, _c_i32, _c_i32, _c_i32, _c_f32, _c_vp]),
+    "vqs_score_head": (_c_i32, [_c_vp, _c_i32, _c_i32, _c_vp, _c_vp, _c_vp, _c_i32, _c_i32, _c_vp]),
+    "vqs_relpos_bucket": (_c_i32, [_c_i32, _c_i32, _c_i32, _c_i32]),
+}
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None) -> ctypes.CDLL:
+    """Load libvqs_hip.so and type every exported symbol.  Raises VqsError if it is absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise VqsError(
+            f"{p} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
+            f"or make -C t2v_metrics_amd/csrc).  There is no CPU fallback.")
+    lib = ctypes.CDLL(p)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def _stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def make_vqs_config(cfg: ClipT5Config) -> VqsConfig:
+    v, t = cfg.vision, cfg.t5
+    return VqsConfig(v.hidden, v.layers_run, v.heads, v.mlp, v.patch, v.image, v.ln_eps, t.d_model, t.heads, t.d_kv,
+                     t.d_ff, t.layers, t.dec_layers, t.vocab, t.rel_buckets, t.rel_max_distance, t.ln_eps)
+
+
+class VqsEngine:
+    """One CLIP-FlanT5 replica on one GPU."""
+
+    def __init__(self, cfg: ClipT5Config, weights: Dict[str, torch.Tensor], device="cuda:0"):
+        self.lib = load_library()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise VqsError("VqsEngine needs a HIP device (device='cuda[:i]'); there is no CPU path")
+        self._h = _c_vp()
+        c = make_vqs_config(cfg)
+        rc = self.lib.vqs_create(ctypes.byref(c), ctypes.byref(self._h))
+        if rc != 0:
+            msg = self.lib.vqs_last_error(self._h).decode() if self._h else "vqs_create failed"
+            raise VqsError(f"vqs_create: {msg}")
+        self._ws: Optional[torch.Tensor] = None
+        self._ws_shape = None
+        self._ews: Optional[torch.Tensor] = None
+        self.bind(weights)
+
+    # ------------------------------------------------------------------ helpers
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            raise VqsError(f"{what} failed ({rc}): {self.lib.vqs_last_error(self._h).decode()}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.vqs_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def bind(self, weights: Dict[str, torch.Tensor]):
+        with torch.cuda.device(self.device):
+            self.weights = {}
+            for k, w in weights.items():
+                if w.dtype != torch.bfloat16 or w.device != self.device or not w.is_contiguous():
+                    w = w.to(device=self.device, dtype=torch.bfloat16).contiguous()
+                self.weights[k] = w
+            n = len(self.weights)
+            descs = (VqsWeightDesc * n)()
+            self._names = [k.encode() for k in self.weights]   # keep the char* alive
+            for i, (k, w) in enumerate(self.weights.items()):
+                descs[i] = VqsWeightDesc(self._names[i], w.data_ptr(), w.numel())
+            nbytes = self.lib.vqs_packed_bytes(self._h)
+            self._packed = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            rc = self.lib.vqs_bind_weights(self._h, descs, n, self._packed.data_ptr(), nbytes, _stream_ptr())
+            self._check(rc, "vqs_bind_weights")
+            torch.cuda.current_stream().synchronize()   # the bucket LUT upload reads handle-owned host memory
+
+    # ------------------------------------------------------------------ the two stages
+    def encode_images(self, pixels: torch.Tensor) -> torch.Tensor:
+        """pixels bf16 [N,3,image,image] (CLIP-normalised) -> projected features bf16 [N, n_patches, d_model]."""
+        v = self.cfg.vision
+        if pixels.dim() != 4 or tuple(pixels.shape[1:]) != (3, v.image, v.image):
+            raise VqsError(f"pixels must be [N,3,{v.image},{v.image}], got {tuple(pixels.shape)}")
+        with torch.cuda.device(self.device):
+            px = pixels.to(device=self.device, dtype=torch.bfloat16).contiguous()
+            N = px.shape[0]
+            feats = torch.empty(N, v.n_patches, self.cfg.t5.d_model, dtype=torch.bfloat16, device=self.device)
+            need = self.lib.vqs_encode_workspace_bytes(self._h, N)
+            if self._ews is None or self._ews.numel() < need:
+                self._ews = None
+                self._ews = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._ews_n = N
+            rc = self.lib.vqs_encode_images(self._h, px.data_ptr(), N, feats.data_ptr(), self._ews.data_ptr(),
+                                            self._ews.numel(), _stream_ptr())
+            self._check(rc, "vqs_encode_images")
+            return feats
+
+    def score(self, feats: torch.Tensor, img_index: torch.Tensor, input_ids: torch.Tensor,
+              labels: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """-> (label_logprobs fp32 [B,T], scores fp32 [B]).  input_ids int [B,L] with one -200 per row and
+        trailing 0 padding; labels int [B,T] with -100 padding."""
+        with torch.cuda.device(self.device):
+            B, L = input_ids.shape
+            T = labels.shape[1]
+            if labels.shape[0] != B or img_index.shape[0] != B:
+                raise VqsError("img_index, input_ids and labels must agree on the batch size")
+            ids = input_ids.to(device=self.device, dtype=torch.int32).contiguous()
+            lab = labels.to(device=self.device, dtype=torch.int32).contiguous()
+            idx = img_index.to(device=self.device, dtype=torch.int32).contiguous()
+            feats = feats.contiguous()
+            lp = torch.empty(B, T, dtype=torch.float32, device=self.device)
+            sc = torch.empty(B, dtype=torch.float32, device=self.device)
+            need = self.lib.vqs_score_workspace_bytes(self._h, B, L, T)
+            if need == 0:
+                raise VqsError(f"unsupported score shape B={B} L={L} T={T}")
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = None
+                self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._ws_shape = (B, L, T)
+            rc = self.lib.vqs_score(self._h, feats.data_ptr(), idx.data_ptr(), ids.data_ptr(), lab.data_ptr(), B, L, T,
+                                    lp.data_ptr(), sc.data_ptr(), self._ws.data_ptr(), self._ws.numel(), _stream_ptr())
+            self._check(rc, "vqs_score")
+            return lp, sc
+
+    # ------------------------------------------------------------------ introspection (tests / bench)
+    def stage(self, name: str) -> torch.Tensor:
+        """View of a named intermediate of the most recent call (see vqs_workspace_offset)."""
+        ld = _c_i64(0)
+        t5, v = self.cfg.t5, self.cfg.vision
+        if name == "vit_hidden":
+            N = self._ews_n
+            off = self.lib.vqs_workspace_offset(self._h, name.encode(), N, 0, 0, ctypes.byref(ld))
+            if off < 0:
+                raise VqsError(f"unknown stage {name}")
+            n = N * v.seq * v.hidden
+            return self._ews[off: off + 4 * n].view(torch.float32).view(N, v.seq, v.hidden)
+        B, L, T = self._ws_shape
+        off = self.lib.vqs_workspace_offset(self._h, name.encode(), B, L, T, ctypes.byref(ld))
+        if off < 0:
+            raise VqsError(f"unknown stage {name}")
+        S = L - 1 + v.n_patches
+        if name == "enc_in":
+            return self._ws[off: off + 4 * B * S * t5.d_model].view(torch.float32).view(B, S, t5.d_model)
+        if name == "enc_out":
+            return self._ws[off: off + 2 * B * S * t5.d_model].view(torch.bfloat16).view(B, S, t5.d_model)
+        if name == "logits":
+            return self._ws[off: off + 4 * B * T * ld.value].view(torch.float32).view(B, T, ld.value)[..., : t5.vocab]
+        if name == "enc_len":
+            return self._ws[off: off + 4 * B].view(torch.int32)
+        if name == "flags":
+            return self._ws[off: off + 4].view(torch.int32)
+        raise VqsError(f"unknown stage {name}")
+
+    def profile(self, on: bool):
+        self._check(self.lib.vqs_profile_enable(self._h, 1 if on else 0), "vqs_profile_enable")
+
+    def profile_read(self, reset: bool = True):
+        ms, fl = ctypes.c_double(0), ctypes.c_double(0)
+        n = self.lib.vqs_profile_read(self._h, ctypes.byref(ms), ctypes.byref(fl), 1 if reset else 0)
+        if n < 0:
+            self._check(n, "vqs_profile_read")
+        return n, ms.value, fl.value
+
+
+# ---------------------------------------------------------------------- single-kernel wrappers (tests, microbench)
+def gemm(A, W, epilogue: int, bias=None, resid=None, out=None, S: int = 0, H: int = 0, variant: int = 0):
+    """C = epilogue(A @ W.T).  A [M,K] bf16, W [N,K] bf16.  See include/vqs.h for epilogue codes."""
+    lib = load_library()
+    M, K = A.shape
+    N = W.shape[0]
+    dev = A.device
+    if epilogue in (0, 1, 2):
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=dev) if out is None else out
+        ldc = N
+    elif epilogue in (3, 4):
+        out = torch.empty(M, N, dtype=torch.float32, device=dev) if out is None else out
+        ldc = N
+    elif epilogue == 5:
+        out = torch.empty(M, N // 2, dtype=torch.bfloat16, device=dev) if out is None else out
+        ldc = N // 2
+    elif epilogue == 6:
+        nsel = N // (H * 64)
+        out = torch.empty(nsel, M // S, H, S, 64, dtype=torch.bfloat16, device=dev) if out is None else out
+        ldc = 0
+    else:
+        raise ValueError(epilogue)
+    rc = lib.vqs_gemm(A.data_ptr(), W.data_ptr(), out.data_ptr(), _ptr(bias), _ptr(resid), M, N, K, A.stride(0),
+                      W.stride(0), ldc, epilogue, S, H, variant, _stream_ptr())
+    if rc != 0:
+        raise VqsError(f"vqs_gemm failed ({rc})")
+    return out
+
+
+def attention(q, k, v, scale: float, bias_table=None, key_len=None):
+    lib = load_library()
+    B, H, S, d = q.shape
+    assert d == 64
+    out = torch.empty(B * S, H * 64, dtype=torch.bfloat16, device=q.device)
+    rc = lib.vqs_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), _ptr(bias_table), _ptr(key_len), B, H,
+                           S, scale, _stream_ptr())
+    if rc != 0:
+        raise VqsError(f"vqs_attention failed ({rc})")
+    return out
+
+
+def decoder_attention(q, k, v, B, H, T, S, ldq, ldk, cross: bool, bias_table=None, key_len=None):
+    lib = load_library()
+    out = torch.empty(B * T, H * 64, dtype=torch.bfloat16, device=q.device)
+    rc = lib.vqs_decoder_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), _ptr(bias_table),
+                                   _ptr(key_len), B, H, T, S, ldq, ldk, 1 if cross else 0, _stream_ptr())
+    if rc != 0:
+        raise VqsError(f"vqs_decoder_attention failed ({rc})")
+    return out
+
+
+def rmsnorm(x, w, eps):
+    lib = load_library()
+    M, D = x.shape
+    out = torch.empty(M, D, dtype=torch.bfloat16, device=x.device)
+    rc = lib.vqs_rmsnorm(x.data_ptr(), w.data_ptr(), out.data_ptr(), M, D, eps, _stream_ptr())
+    if rc != 0:
+        raise VqsError(f"vqs_rmsnorm failed ({rc})")
+    return out
+
+
+def layernorm(x, w, b, eps, out_f32=False):
+    lib = load_library()
+    M, D = x.shape
+    out = torch.empty(M, D, dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
+    rc = lib.vqs_layernorm(x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), 1 if out_f32 else 0, M, D, eps,
+                           _stream_ptr())
+    if rc != 0:
+        raise VqsError(f"vqs_layernorm failed ({rc})")
+    return out
+
+
+def score_head(logits, labels):
+    lib = load_library()
+    B, T, V = logits.shape
+    lg = logits.contiguous()
+    lab = labels.to(torch.int32).contiguous()
+    lp = torch.empty(B, T, dtype=torch.float32, device=logits.device)
+    sc = torch.empty(B, dtype=torch.float32, device=logits.device)
+    rc = lib.vqs_score_head(lg.data_ptr(), V, V, lab.data_ptr(), lp.data_ptr(), sc.data_ptr(), B, T, _stream_ptr())
+    if rc != 0:
+        raise VqsError(f"vqs_score_head failed ({rc})")
+    return lp, sc
+
+
+def relpos_bucket(rel: int, bidirectional: bool, num_buckets: int = 32, max_distance: int = 128) -> int:
+    return load_library().vqs_relpos_bucket(rel, 1 if bidirectional else 0, num_buckets, max_distance)

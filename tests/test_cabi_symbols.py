@@ -1,0 +1,57 @@
+"""CPU-side checks of the C-ABI library: it loads without a GPU and exports every symbol include/vqs.h declares."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "vqs.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(vqs_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_loads_and_exports_header_symbols():
+    from t2v_metrics_amd import engine
+    lib = engine.load_library()
+    declared = _declared_symbols()
+    assert len(declared) >= 15
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/vqs.h but not exported"
+    assert set(declared) == set(engine.exported_symbols()), "engine.py signatures out of sync with include/vqs.h"
+
+
+def test_create_rejects_bad_config_and_reports():
+    import ctypes
+    from t2v_metrics_amd import engine
+    from t2v_metrics_amd.config import get_config
+    lib = engine.load_library()
+    c = engine.make_vqs_config(get_config("tiny"))
+    c.d_kv = 32
+    h = ctypes.c_void_p()
+    assert lib.vqs_create(ctypes.byref(c), ctypes.byref(h)) != 0
+    assert b"d_kv" in lib.vqs_last_error(h)
+    lib.vqs_destroy(h)
+    c = engine.make_vqs_config(get_config("clip-flant5-xxl"))
+    assert lib.vqs_create(ctypes.byref(c), ctypes.byref(h)) == 0
+    # sizes are pure arithmetic: no device needed
+    assert lib.vqs_packed_bytes(h) > 2 * 24 * (3 * 4096 * 4096 + 2 * 10240 * 4096)
+    assert lib.vqs_score_workspace_bytes(h, 256, 33, 2) > 256 * 608 * 4096 * 4
+    assert lib.vqs_score_workspace_bytes(h, 0, 33, 2) == 0
+    lib.vqs_destroy(h)
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    from t2v_metrics_amd import engine
+    with pytest.raises(engine.VqsError, match="no CPU fallback"):
+        engine.load_library(str(tmp_path / "nope.so"))
+
+
+def test_engine_refuses_cpu_device():
+    import torch
+    from t2v_metrics_amd import engine
+    from t2v_metrics_amd.config import get_config
+    with pytest.raises(engine.VqsError, match="no CPU path"):
+        engine.VqsEngine(get_config("tiny"), {}, device="cpu")

@@ -1,0 +1,149 @@
+"""End-to-end parity (-m gpu): the HIP scoring pass, through the C ABI, against the CPU oracle
+(oracle/clip_t5_oracle.py, pinned to HF by tests/test_oracle_golden.py) on the same seeded weights and inputs.
+
+Tolerance (BASELINE.json north_star): |delta log P(label)| <= 1e-3 absolute against the fp32 oracle with
+bf16-rounded weights.  Intermediate stages carry looser, stage-appropriate bounds (bf16 storage)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from t2v_metrics_amd.config import get_config
+from t2v_metrics_amd.weights import make_seeded_weights
+
+pytestmark = pytest.mark.gpu
+
+LOGPROB_TOL = 1e-3
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _inputs(cfg, B, n_img, L, T, seed, ragged=True):
+    g = torch.Generator().manual_seed(seed)
+    v, t = cfg.vision, cfg.t5
+    pix = torch.randn(n_img, 3, v.image, v.image, generator=g).to(torch.bfloat16)
+    ids = torch.randint(3, t.vocab, (B, L), generator=g)
+    sent = torch.randint(0, L - 1, (B,), generator=g)
+    for b in range(B):
+        n = L if (not ragged or b == 0) else int(torch.randint(max(2, L // 2), L + 1, (1,), generator=g))
+        sp = min(int(sent[b]), n - 2)
+        ids[b, sp] = -200
+        ids[b, n - 1] = t.eos_id
+        ids[b, n:] = 0
+    labels = torch.randint(3, t.vocab, (B, T), generator=g)
+    labels[:, -1] = t.eos_id
+    if ragged and T > 2 and B > 1:
+        labels[1, -1] = -100
+        labels[1, -2] = t.eos_id
+    img_index = torch.randint(0, n_img, (B,), generator=g)
+    return pix, img_index, ids, labels
+
+
+def _record(name, payload):
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_e2e.jsonl"), "a") as f:
+        f.write(json.dumps({"case": name, **payload}) + "\n")
+
+
+@pytest.mark.parametrize("name,B,n_img,L,T,gain", [("tiny", 3, 2, 9, 3, 1.0), ("tiny", 5, 3, 12, 2, 4.0),
+                                                    ("small", 4, 2, 20, 2, 1.0), ("small", 2, 2, 33, 2, 3.0)])
+def test_end_to_end_vs_oracle(name, B, n_img, L, T, gain):
+    from oracle.clip_t5_oracle import Oracle
+    from t2v_metrics_amd.engine import VqsEngine
+
+    cfg = get_config(name)
+    w = make_seeded_weights(cfg, seed=11, device="cpu", lm_head_gain=gain)
+    pix, img_index, ids, labels = _inputs(cfg, B, n_img, L, T, seed=100 + B)
+    ref = Oracle(cfg, w).forward(pix.float(), img_index, ids, labels, return_stages=True)
+
+    eng = VqsEngine(cfg, w, device="cuda:0")
+    feats = eng.encode_images(pix.cuda())
+    lp, sc = eng.score(feats, img_index, ids, labels)
+    torch.cuda.synchronize()
+    assert int(eng.stage("flags")[0]) == 0
+
+    stats = {}
+
+    def cmp(tag, out, r, atol, rtol, mask=None):
+        o = out.detach().float().cpu()
+        e = (o - r).abs()
+        if mask is not None:
+            e = e * mask
+        stats[tag] = float(e.max())
+        lim = atol + rtol * r.abs()
+        bad = e > lim
+        assert not torch.isnan(o).any(), f"{tag}: NaN"
+        assert not bad.any(), f"{tag}: max err {float(e.max()):.4g} (ref absmax {float(r.abs().max()):.4g}), {int(bad.sum())} bad"
+
+    hid = eng.stage("vit_hidden")
+    cmp("vit_feats", hid[:, 1:], ref["vit_feats"], 0.15, 0.03)
+    cmp("proj", feats, ref["proj"], 0.15, 0.03)
+    m = ref["enc_mask"][..., None].float()
+    cmp("enc_out", eng.stage("enc_out"), ref["enc_out"], 0.08, 0.03, m)
+    valid = (labels != -100)
+    cmp("logits", eng.stage("logits"), ref["logits"], 0.05 * gain, 0.02, valid[..., None].float())
+    assert torch.equal(eng.stage("enc_len").cpu().long(), ref["enc_mask"].sum(-1))
+    dlp = (lp.cpu() - ref["label_logprobs"]).abs()
+    stats["label_logprob"] = float(dlp.max())
+    stats["score"] = float((sc.cpu() - ref["scores"]).abs().max())
+    stats["ref_logprob_range"] = [float(ref["label_logprobs"].min()), float(ref["label_logprobs"].max())]
+    _record(f"{name}-B{B}-L{L}-T{T}-gain{gain}", stats)
+    assert dlp.max().item() <= LOGPROB_TOL, f"|dlogP|={dlp.max().item():.3e} > {LOGPROB_TOL} ({stats})"
+    assert (sc.cpu() - ref["scores"]).abs().max().item() <= 1e-3 * max(1e-3, float(ref["scores"].max())) + 1e-6
+    eng.close()
+
+
+def test_engine_matches_hf_golden_fixture(golden_dir):
+    """The committed HF-module fixture (tests/golden/hf_tiny.npz): vision hidden_states[-2] from the HIP tower."""
+    from t2v_metrics_amd.engine import VqsEngine
+    g = np.load(os.path.join(golden_dir, "hf_tiny.npz"))
+    cfg = get_config("tiny")
+    w = make_seeded_weights(cfg, seed=int(g["seed"]), device="cpu")
+    eng = VqsEngine(cfg, w, device="cuda:0")
+    eng.encode_images(torch.from_numpy(g["pixels"]).to(torch.bfloat16).cuda())
+    torch.cuda.synchronize()
+    hid = eng.stage("vit_hidden").float().cpu()
+    ref = torch.from_numpy(g["vit_hidden_m2"])
+    err = (hid - ref).abs().max().item()
+    assert err <= 0.15 + 0.03 * ref.abs().max().item(), err
+    eng.close()
+
+
+def test_dedup_and_reuse_of_image_features():
+    """M x N grids score each image once: pairs that share an image give identical results to separate calls."""
+    from t2v_metrics_amd.engine import VqsEngine
+    cfg = get_config("tiny")
+    w = make_seeded_weights(cfg, seed=5, device="cpu")
+    pix, _, ids, labels = _inputs(cfg, 4, 2, 8, 2, seed=7, ragged=False)
+    eng = VqsEngine(cfg, w, device="cuda:0")
+    feats = eng.encode_images(pix.cuda())
+    idx = torch.tensor([0, 1, 0, 1])
+    lp_all, _ = eng.score(feats, idx, ids, labels)
+    lp_all = lp_all.clone()
+    lp_01, _ = eng.score(feats, idx[:2], ids[:2], labels[:2])
+    torch.cuda.synchronize()
+    assert torch.equal(lp_all[:2].cpu(), lp_01.cpu())     # batch-size invariant, bit for bit
+    eng.close()
+
+
+def test_missing_weight_and_bad_prompt_are_reported():
+    from t2v_metrics_amd.engine import VqsEngine, VqsError
+    cfg = get_config("tiny")
+    w = make_seeded_weights(cfg, seed=5, device="cpu")
+    w2 = dict(w)
+    del w2["lm_head.weight"]
+    eng = VqsEngine(cfg, w2, device="cuda:0")
+    pix, idx, ids, labels = _inputs(cfg, 2, 1, 6, 2, seed=1, ragged=False)
+    feats = eng.encode_images(pix.cuda())
+    with pytest.raises(VqsError, match="lm_head.weight"):
+        eng.score(feats, idx, ids, labels)
+    eng.close()
+    eng = VqsEngine(cfg, w, device="cuda:0")
+    bad = ids.clone()
+    bad[0][bad[0] == -200] = 7        # no sentinel
+    eng.score(feats, idx, bad, labels)
+    torch.cuda.synchronize()
+    assert int(eng.stage("flags")[0]) == 1
+    eng.close()

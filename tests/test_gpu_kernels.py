@@ -1,0 +1,177 @@
+"""Per-kernel parity (-m gpu): every HIP kernel, called through the C ABI, against a plain fp32 torch
+reference of the same op on the same seeded inputs."""
+import numpy as np
+import pytest
+import torch
+
+from tests.gpu_util import (assert_close, attention_ref, gelu_erf, gelu_new, interleave_gate, quick_gelu, randn_bf16)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a HIP device")
+    from t2v_metrics_amd import engine
+    engine.load_library()
+    return engine
+
+
+GEMM_SHAPES = [(256, 256, 64), (512, 768, 128), (300, 264, 192), (2065, 1024, 1024), (512, 1000, 256), (40, 64, 640)]
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_bf16_and_f32(eng, M, N, K, variant):
+    A = randn_bf16(M, K, seed=1)
+    W = randn_bf16(N, K, seed=2, scale=K ** -0.5)
+    bias = randn_bf16(N, seed=3)
+    ref = A.float() @ W.float().t()
+    out = eng.gemm(A, W, 0, variant=variant)
+    assert_close(out, ref, 2e-2, 1e-2, f"gemm bf16 {M}x{N}x{K} v{variant}")
+    out = eng.gemm(A, W, 0, bias=bias, variant=variant)
+    assert_close(out, ref + bias.float(), 2e-2, 1e-2, "gemm bf16+bias")
+    out = eng.gemm(A, W, 3, bias=bias, variant=variant)
+    assert_close(out, ref + bias.float(), 2e-3, 1e-4, "gemm f32+bias")
+    out = eng.gemm(A, W, 1, bias=bias, variant=variant)
+    assert_close(out, quick_gelu(ref + bias.float()), 2e-2, 1e-2, "gemm quick_gelu")
+    out = eng.gemm(A, W, 2, bias=bias, variant=variant)
+    assert_close(out, gelu_erf(ref + bias.float()), 2e-2, 1e-2, "gemm gelu_erf")
+    resid = torch.randn(M, N, device="cuda", generator=torch.Generator(device="cuda").manual_seed(4))
+    out = eng.gemm(A, W, 4, resid=resid, variant=variant)
+    assert_close(out, ref + resid, 2e-3, 1e-4, "gemm f32+resid")
+    # in place on the residual stream (how the engine uses it)
+    buf = resid.clone()
+    eng.gemm(A, W, 4, bias=bias, resid=buf, out=buf, variant=variant)
+    assert_close(buf, ref + bias.float() + resid, 2e-3, 1e-4, "gemm f32+resid in place")
+
+
+def test_gemm_transpose_detecting(eng):
+    """A = I-like structure with an asymmetric W catches swapped C layouts."""
+    M = N = K = 256
+    A = torch.zeros(M, K, dtype=torch.bfloat16, device="cuda")
+    A[torch.arange(M), torch.arange(K)] = 1.0
+    W = (torch.arange(N, device="cuda")[:, None] * 0.25 + torch.arange(K, device="cuda")[None, :] * 0.001953125)
+    W = W.to(torch.bfloat16)
+    out = eng.gemm(A, W, 3)
+    assert_close(out, W.float().t(), 1e-6, 0, "gemm identity")
+
+
+@pytest.mark.parametrize("M,F,K", [(256, 128, 64), (300, 192, 128), (1029, 640, 256)])
+def test_gemm_gated(eng, M, F, K):
+    A = randn_bf16(M, K, seed=5)
+    w0 = randn_bf16(F, K, seed=6, scale=K ** -0.5)
+    w1 = randn_bf16(F, K, seed=7, scale=K ** -0.5)
+    W = interleave_gate(w0, w1)
+    ref = gelu_new(A.float() @ w0.float().t()) * (A.float() @ w1.float().t())
+    out = eng.gemm(A, W, 5)
+    assert_close(out, ref, 2e-2, 1e-2, f"gemm gated {M}x{F}x{K}")
+
+
+@pytest.mark.parametrize("B,S,H,K,nsel", [(2, 17, 2, 128, 3), (3, 100, 4, 256, 3), (2, 577, 2, 128, 2)])
+def test_gemm_heads(eng, B, S, H, K, nsel):
+    M, I = B * S, H * 64
+    A = randn_bf16(M, K, seed=8)
+    W = randn_bf16(nsel * I, K, seed=9, scale=K ** -0.5)
+    bias = randn_bf16(nsel * I, seed=10)
+    ref = (A.float() @ W.float().t() + bias.float()).reshape(B, S, nsel, H, 64).permute(2, 0, 3, 1, 4)
+    out = eng.gemm(A, W, 6, bias=bias, S=S, H=H)
+    assert_close(out, ref, 2e-2, 1e-2, "gemm heads")
+
+
+@pytest.mark.parametrize("B,H,S,use_bias,ragged", [(1, 1, 64, False, False), (2, 2, 100, False, False),
+                                                   (2, 3, 577, False, False), (2, 2, 128, True, False),
+                                                   (3, 2, 200, True, True), (2, 4, 608, True, True)])
+def test_attention(eng, B, H, S, use_bias, ragged):
+    q = randn_bf16(B, H, S, 64, seed=11, scale=0.5 if use_bias else 1.0)
+    k = randn_bf16(B, H, S, 64, seed=12, scale=0.5 if use_bias else 1.0)
+    v = randn_bf16(B, H, S, 64, seed=13)
+    scale = 1.0 if use_bias else 0.125
+    table = bias = key_len = None
+    if use_bias:
+        table = torch.randn(H, 2 * S - 1, device="cuda", generator=torch.Generator(device="cuda").manual_seed(14))
+        idx = (torch.arange(S)[None, :] - torch.arange(S)[:, None] + S - 1).to("cuda")     # key - query + S-1
+        bias = table[:, idx]
+    if ragged:
+        key_len = torch.tensor([S, max(1, S // 3), S - 1][:B] + [S] * max(0, B - 3), dtype=torch.int32, device="cuda")
+    ref = attention_ref(q, k, v, scale, bias, key_len)
+    out = eng.attention(q, k, v, scale, bias_table=table, key_len=key_len)
+    assert_close(out, ref, 2e-2, 2e-2, f"attention B{B} H{H} S{S} bias={use_bias} ragged={ragged}")
+
+
+def test_attention_spiked_max(eng):
+    """Forces the running-max rescale: one key dominates late in the sequence."""
+    B, H, S = 1, 1, 256
+    q = randn_bf16(B, H, S, 64, seed=15, scale=0.3)
+    k = randn_bf16(B, H, S, 64, seed=16, scale=0.3)
+    v = randn_bf16(B, H, S, 64, seed=17)
+    k[0, 0, 200] = q[0, 0, 5] * 8.0
+    ref = attention_ref(q, k, v, 1.0)
+    out = eng.attention(q, k, v, 1.0)
+    assert_close(out, ref, 2e-2, 2e-2, "attention spiked")
+
+
+@pytest.mark.parametrize("T", [1, 2, 5])
+def test_decoder_attention(eng, T):
+    B, H, S = 3, 2, 77
+    I = H * 64
+    qkv = randn_bf16(B * T, 3 * I, seed=18, scale=0.5)
+    table = torch.randn(H, T, device="cuda", generator=torch.Generator(device="cuda").manual_seed(19))
+    out = eng.decoder_attention(qkv, qkv[:, I:], qkv[:, 2 * I:], B, H, T, T, 3 * I, 3 * I, False, bias_table=table)
+    x = qkv.float().reshape(B, T, 3, H, 64)
+    q, k, v = x[:, :, 0].transpose(1, 2), x[:, :, 1].transpose(1, 2), x[:, :, 2].transpose(1, 2)
+    s = q @ k.transpose(-1, -2)
+    dist = torch.arange(T)[:, None] - torch.arange(T)[None, :]
+    bias = table[:, dist.clamp(min=0).to("cuda")]
+    s = s + bias[None]
+    s = s.masked_fill((dist < 0).to("cuda")[None, None], float("-inf"))
+    ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B * T, I)
+    assert_close(out, ref, 2e-2, 2e-2, f"decoder self attention T{T}")
+
+    qc = randn_bf16(B * T, I, seed=20, scale=0.5)
+    kc = randn_bf16(B, H, S, 64, seed=21, scale=0.5)
+    vc = randn_bf16(B, H, S, 64, seed=22)
+    key_len = torch.tensor([S, 10, 50], dtype=torch.int32, device="cuda")
+    out = eng.decoder_attention(qc, kc, vc, B, H, T, S, I, 0, True, key_len=key_len)
+    qh = qc.float().reshape(B, T, H, 64).transpose(1, 2)
+    s = qh @ kc.float().transpose(-1, -2)
+    mask = torch.arange(S, device="cuda")[None, :] >= key_len[:, None]
+    s = s.masked_fill(mask[:, None, None, :], float("-inf"))
+    ref = (torch.softmax(s, -1) @ vc.float()).transpose(1, 2).reshape(B * T, I)
+    assert_close(out, ref, 2e-2, 2e-2, f"decoder cross attention T{T}")
+
+
+@pytest.mark.parametrize("M,D", [(7, 128), (1000, 2048), (33, 4096), (5, 1024)])
+def test_norms(eng, M, D):
+    x = torch.randn(M, D, device="cuda", generator=torch.Generator(device="cuda").manual_seed(23)) * 3.0 + 0.5
+    w = randn_bf16(D, seed=24)
+    b = randn_bf16(D, seed=25)
+    ref = w.float() * (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6))
+    assert_close(eng.rmsnorm(x, w, 1e-6), ref, 1e-2, 1e-2, "rmsnorm")
+    ref = torch.nn.functional.layer_norm(x, (D,), w.float(), b.float(), 1e-5)
+    assert_close(eng.layernorm(x, w, b, 1e-5), ref, 1e-2, 1e-2, "layernorm bf16")
+    assert_close(eng.layernorm(x, w, b, 1e-5, out_f32=True), ref, 1e-4, 1e-5, "layernorm f32")
+
+
+def test_score_head(eng):
+    B, T, V = 5, 3, 1000
+    logits = torch.randn(B, T, V, device="cuda", generator=torch.Generator(device="cuda").manual_seed(26)) * 4.0
+    labels = torch.randint(0, V, (B, T), generator=torch.Generator().manual_seed(27))
+    labels[1, 2] = -100
+    labels[3, 1:] = -100
+    lp, sc = eng.score_head(logits, labels.cuda())
+    ref = torch.log_softmax(logits, -1).gather(-1, labels.clamp(min=0).cuda()[..., None])[..., 0]
+    valid = (labels != -100).cuda()
+    ref = torch.where(valid, ref, torch.zeros_like(ref))
+    assert_close(lp, ref, 1e-4, 1e-5, "label logprobs")
+    ref_sc = torch.exp((ref * valid).sum(-1) / valid.sum(-1))
+    assert_close(sc, ref_sc, 1e-6, 1e-4, "scores")
+
+
+def test_relpos_bucket_host_function_matches_golden(eng, golden_dir):
+    import os
+    g = np.load(os.path.join(golden_dir, "relpos_buckets.npz"))
+    for r, vb, vc in zip(g["relative_position"], g["bidirectional"], g["causal"]):
+        assert eng.relpos_bucket(int(r), True) == int(vb)
+        assert eng.relpos_bucket(int(r), False) == int(vc)
