@@ -7,6 +7,10 @@ Run in the build container (transformers 5.15.0 importable, no GPU needed):
 What is pinned (SURVEY.md §8c -- the reference itself has no golden vectors for this path):
   * relpos_buckets.npz   -- HF ``T5Attention._relative_position_bucket`` for every
                             relative position in [-700, 700], bidirectional and causal.
+  * e2e_<cfg>_g<gain>.npz -- the whole pipeline assembled from HF modules, run in fp32 ("truth") and with every
+                            module cast to bf16 as the reference does (mm_utils.py:228) on the CPU: label log-probs
+                            and scores of both, plus the inputs.  The bf16 run is the reference's own numerical
+                            noise floor against which the HIP path's error is judged.
   * hf_tiny.npz / hf_small.npz
       - ``CLIPVisionModel(..., output_hidden_states=True).hidden_states[-2]`` on seeded pixels,
       - ``T5ForConditionalGeneration(inputs_embeds=..., attention_mask=..., labels=...)``
@@ -120,9 +124,71 @@ def golden_model(name: str, seed: int, n_img: int, B: int, S_e: int, T: int):
     print(path, os.path.getsize(path) // 1024, "KiB", "scores", scores.tolist())
 
 
+def golden_e2e(name: str, seed: int, n_img: int, B: int, L: int, T: int, gain: float):
+    """Full pipeline from HF modules: CLIPVisionModel -> hidden_states[-2][:,1:] -> mlp2x_gelu (torch Linear/GELU)
+    -> splice -> T5ForConditionalGeneration(inputs_embeds, attention_mask, labels) -> per-sample exp(-CE).
+    Stored twice: modules in fp32 ("truth": bf16-rounded weights, fp32 math) and modules cast to bf16 exactly as
+    the reference does (mm_utils.py:228) and run on the CPU ("reference as shipped")."""
+    cfg = get_config(name)
+    w = make_seeded_weights(cfg, seed=seed, device="cpu", dtype=torch.bfloat16, lm_head_gain=gain)
+    g = torch.Generator().manual_seed(seed + 31)
+    v, t = cfg.vision, cfg.t5
+    P = v.n_patches
+    pixels = torch.randn(n_img, 3, v.image, v.image, generator=g).to(torch.bfloat16)
+    ids = torch.randint(3, t.vocab, (B, L), generator=g)
+    for b in range(B):
+        n = L if b == 0 else int(torch.randint(max(3, L // 2), L + 1, (1,), generator=g))
+        sp = int(torch.randint(0, n - 1, (1,), generator=g))
+        ids[b, sp] = -200
+        ids[b, n - 1] = t.eos_id
+        ids[b, n:] = 0
+    labels = torch.randint(3, t.vocab, (B, T), generator=g)
+    labels[:, -1] = t.eos_id
+    img_index = torch.randint(0, n_img, (B,), generator=g)
+    S_e = L - 1 + P
+
+    def run(dtype):
+        with torch.no_grad():
+            vm = build_hf_vision(cfg, w).to(dtype)
+            tm = build_hf_t5(cfg, w).to(dtype)
+            proj = torch.nn.Sequential(torch.nn.Linear(v.hidden, t.d_model), torch.nn.GELU(),
+                                       torch.nn.Linear(t.d_model, t.d_model)).to(dtype)
+            proj[0].weight.copy_(w["mm_projector.0.weight"]); proj[0].bias.copy_(w["mm_projector.0.bias"])
+            proj[2].weight.copy_(w["mm_projector.2.weight"]); proj[2].bias.copy_(w["mm_projector.2.bias"])
+            hs = vm(pixel_values=pixels.to(dtype), output_hidden_states=True).hidden_states
+            feats = proj(hs[v.select_layer][:, 1:])
+            emb = torch.zeros(B, S_e, t.d_model, dtype=dtype)
+            mask = torch.zeros(B, S_e, dtype=torch.long)
+            for b in range(B):
+                row = ids[b][ids[b] != t.pad_id]
+                sp = int((row == -200).nonzero()[0, 0])
+                r = torch.cat([tm.shared(row[:sp]), feats[int(img_index[b])], tm.shared(row[sp + 1:])], 0)
+                emb[b, : r.shape[0]] = r
+                mask[b, : r.shape[0]] = 1
+            out = tm(inputs_embeds=emb, attention_mask=mask, labels=labels)
+            lp = torch.log_softmax(out.logits.float(), -1).gather(-1, labels[..., None])[..., 0]
+            ce = torch.nn.CrossEntropyLoss(reduction="mean")
+            sc = torch.stack([(-ce(out.logits[k].float(), labels[k])).exp() for k in range(B)])
+        return lp, sc
+
+    lp32, sc32 = run(torch.float32)
+    lp16, sc16 = run(torch.bfloat16)
+    path = os.path.join(GOLDEN, f"e2e_{name}_g{int(gain)}.npz")
+    np.savez_compressed(path, seed=seed, gain=gain, pixels=pixels.float().numpy(), ids=ids.numpy(), labels=labels.numpy(),
+                        img_index=img_index.numpy(), logprobs_fp32=lp32.numpy(), scores_fp32=sc32.numpy(),
+                        logprobs_hf_bf16=lp16.numpy(), scores_hf_bf16=sc16.numpy())
+    d = (lp16 - lp32).abs()
+    print(path, os.path.getsize(path) // 1024, "KiB  HF-bf16 vs HF-fp32 |dlogP| max %.4g mean %.4g" % (d.max(), d.mean()),
+          "logP range", float(lp32.min()), float(lp32.max()))
+
+
 if __name__ == "__main__":
     os.makedirs(GOLDEN, exist_ok=True)
     torch.manual_seed(0)
     golden_relpos()
     golden_model("tiny", seed=3, n_img=2, B=3, S_e=24, T=3)
     golden_model("small", seed=5, n_img=1, B=2, S_e=40, T=2)
+    golden_e2e("tiny", seed=21, n_img=3, B=8, L=12, T=2, gain=1.0)
+    golden_e2e("tiny", seed=22, n_img=3, B=8, L=12, T=2, gain=4.0)
+    golden_e2e("small", seed=23, n_img=2, B=6, L=20, T=2, gain=1.0)
+    golden_e2e("small", seed=24, n_img=2, B=6, L=20, T=2, gain=4.0)

@@ -1,0 +1,202 @@
+"""CLIP-FlanT5 VQAScore model on the MI355X-native engine.
+
+Host-side mirror of the v3.0 wrapper that the reference still documents
+(/root/reference/V_3.0_README.md:209-214; the file itself, ``clip_t5_model.py``, is absent from the v3.1 tree --
+SURVEY.md §0) behind the plugin interface that IS in the tree
+(/root/reference/t2v_metrics/models/vqascore_models/vqa_model.py:7-18, .../models/model.py:16-47).
+
+What runs where:
+  host (this file)   prompt formatting (constants.py:5,8 + V_3.0_README.md:213-214), tokenisation with the image
+                     sentinel (mm_utils.py:164-179), PIL decode + expand2square + CLIP preprocessing;
+  device (engine)    everything from normalised pixels / token ids to the score -- hand-written gfx950 kernels
+                     behind the C ABI (include/vqs.h).  No torch.nn forward, no HF forward, no CPU fallback.
+
+Differences from the reference wrapper that do not change results:
+  * identical image paths inside one call are decoded and encoded once (the reference re-encodes the same image
+    for every text: score.py:105-106);
+  * ``forward`` returns a CPU fp32 tensor like the reference; ``forward_grid`` scores an M x N grid in one pass.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from ...config import get_config
+from ...constants import (CONTEXT_LEN, DEFAULT_IMAGE_TOKEN, HF_CACHE_DIR, IGNORE_INDEX, IMAGE_TOKEN_INDEX, SYSTEM_MSG)
+from ...preprocess import preprocess_batch
+from .mm_utils import t5_tokenizer_image_token
+from .vqa_model import VQAScoreModel
+
+# {} is replaced by the caption (V_3.0_README.md:213-214)
+default_question_template = 'Does this figure show "{}"? Please answer yes or no.'
+default_answer_template = 'Yes'
+
+CLIP_T5_MODELS = {
+    'clip-flant5-xxl': {'config': 'clip-flant5-xxl', 'hf_repo': 'zhiqiulin/clip-flant5-xxl'},
+    'clip-flant5-xl': {'config': 'clip-flant5-xl', 'hf_repo': 'zhiqiulin/clip-flant5-xl'},
+}
+
+
+def format_question(question: str) -> str:
+    """v3.0 conversation style 't5_chat': system message, USER turn with the image placeholder, open ASSISTANT turn."""
+    return SYSTEM_MSG + " USER: " + DEFAULT_IMAGE_TOKEN + "\n" + question + " ASSISTANT: "
+
+
+def format_answer(answer: str) -> str:
+    return answer
+
+
+class CLIPT5Model(VQAScoreModel):
+    """VQAScore with CLIP-FlanT5 (the reference's default model name is still 'clip-flant5-xxl':
+    /root/reference/t2v_metrics/vqascore.py:11)."""
+    video_mode = "concat"
+    allows_image = True
+    allows_video = False
+
+    def __init__(self, model_name='clip-flant5-xxl', device='cuda', cache_dir=HF_CACHE_DIR, *, weights=None,
+                 tokenizer=None, checkpoint: Optional[str] = None, config=None, max_pairs: int = 256,
+                 max_images: int = 256, seed: int = 0, engine=None):
+        """
+        weights:    None -> load ``checkpoint`` (a local HF directory of safetensors); 'seeded' -> seeded random
+                    weights at the exact architecture (benchmarks, tests); or a dict name -> tensor.
+        tokenizer:  any object with ``tokenizer(text).input_ids`` (HF protocol); None -> the slow T5 tokenizer of
+                    the checkpoint directory (the reference uses ``AutoTokenizer(use_fast=False)``, mm_utils.py:198).
+        config:     a ClipT5Config overriding the registry entry (tests use the tiny configurations).
+        engine:     an already constructed engine-like object (tests inject a recording fake).
+        """
+        assert config is not None or model_name in CLIP_T5_MODELS
+        self._weights_arg, self._tokenizer_arg, self._checkpoint = weights, tokenizer, checkpoint
+        self._cfg = config if config is not None else get_config(CLIP_T5_MODELS[model_name]['config'])
+        self._seed, self._engine_arg = seed, engine
+        self.max_pairs, self.max_images = int(max_pairs), int(max_images)
+        self.context_len = CONTEXT_LEN
+        self.image_aspect_ratio = 'pad'          # mm_utils.py:188,235
+        super().__init__(model_name=model_name, device=device, cache_dir=cache_dir)
+
+    # ------------------------------------------------------------------ loading
+    def load_model(self):
+        self.cfg = self._cfg
+        self.tokenizer = self._tokenizer_arg if self._tokenizer_arg is not None else self._load_tokenizer()
+        if self._engine_arg is not None:
+            self.engine = self._engine_arg
+            return
+        from ...engine import VqsEngine   # raises if libvqs_hip.so is missing; no fallback
+        from ...weights import load_checkpoint_weights, make_seeded_weights
+        dev = torch.device(self.device if str(self.device) != 'cuda' else 'cuda:0')
+        if isinstance(self._weights_arg, dict):
+            weights = self._weights_arg
+        elif self._weights_arg == 'seeded':
+            weights = make_seeded_weights(self.cfg, seed=self._seed, device=dev)
+        else:
+            weights = load_checkpoint_weights(self.cfg, self._read_checkpoint(), dev)
+        self.engine = VqsEngine(self.cfg, weights, device=dev)
+
+    def _checkpoint_dir(self) -> str:
+        if self._checkpoint:
+            return self._checkpoint
+        repo = CLIP_T5_MODELS[self.model_name]['hf_repo']
+        return os.path.join(self.cache_dir, repo.split('/')[-1])
+
+    def _load_tokenizer(self):
+        path = self._checkpoint_dir()
+        if not os.path.isdir(path):
+            raise FileNotFoundError(
+                f"no tokenizer: {path} does not exist (no network here). Pass tokenizer=... or checkpoint=<local HF dir>.")
+        from transformers import AutoTokenizer
+        return AutoTokenizer.from_pretrained(path, use_fast=False, model_max_length=self.context_len)
+
+    def _read_checkpoint(self) -> Dict[str, torch.Tensor]:
+        path = self._checkpoint_dir()
+        if not os.path.isdir(path):
+            raise FileNotFoundError(
+                f"no checkpoint at {path} (no network here). Pass checkpoint=<local HF dir> or weights='seeded'.")
+        from safetensors.torch import load_file
+        sd: Dict[str, torch.Tensor] = {}
+        for f in sorted(os.listdir(path)):
+            if f.endswith(".safetensors"):
+                sd.update(load_file(os.path.join(path, f)))
+        if not sd:
+            raise FileNotFoundError(f"no *.safetensors under {path}")
+        return sd
+
+    # ------------------------------------------------------------------ host-side preparation
+    def load_images(self, image: List[str]) -> torch.Tensor:
+        """Decode + pad to square + CLIP-preprocess; returns bf16 [N,3,S,S] on the device."""
+        imgs = [self.image_loader(x) for x in image]
+        px = preprocess_batch(imgs, self.cfg.vision.image, pad_to_square=(self.image_aspect_ratio == 'pad'))
+        if str(self.device).startswith('cuda') and torch.cuda.is_available():
+            return px.pin_memory().to(self.device, non_blocking=True).to(torch.bfloat16)
+        return px.to(torch.bfloat16)
+
+    def tokenize(self, questions: Sequence[str], answers: Sequence[str]) -> Tuple[torch.Tensor, torch.Tensor]:
+        """-> (input_ids int32 [n,L] right-padded with 0, one -200 each; labels int32 [n,T] padded with -100)."""
+        q_ids = [t5_tokenizer_image_token(format_question(q), self.tokenizer, IMAGE_TOKEN_INDEX) for q in questions]
+        a_ids = [t5_tokenizer_image_token(format_answer(a), self.tokenizer, IMAGE_TOKEN_INDEX) for a in answers]
+        q_ids = [ids[: self.context_len] for ids in q_ids]
+        a_ids = [ids[: self.context_len] for ids in a_ids]
+        L = max(len(x) for x in q_ids)
+        T = max(len(x) for x in a_ids)
+        pad = self.cfg.t5.pad_id
+        ids = torch.full((len(q_ids), L), pad, dtype=torch.int32)
+        lab = torch.full((len(a_ids), T), IGNORE_INDEX, dtype=torch.int32)
+        for i, x in enumerate(q_ids):
+            if x.count(IMAGE_TOKEN_INDEX) != 1:
+                raise ValueError("every question must contain exactly one <image> placeholder after templating")
+            if pad in x:
+                raise ValueError("tokenizer produced the pad id inside a prompt")
+            ids[i, : len(x)] = torch.tensor(x, dtype=torch.int32)
+        for i, x in enumerate(a_ids):
+            lab[i, : len(x)] = torch.tensor(x, dtype=torch.int32)
+        return ids, lab
+
+    # ------------------------------------------------------------------ scoring
+    @torch.no_grad()
+    def score_pairs(self, images: Sequence[str], pair_image: Sequence[int], questions: Sequence[str],
+                    answers: Sequence[str], return_logprobs: bool = False):
+        """Score pairs (images[pair_image[k]], questions[k], answers[k]).  Unique images are encoded once."""
+        n = len(questions)
+        assert len(answers) == n and len(pair_image) == n
+        feats_chunks = []
+        for s in range(0, len(images), self.max_images):
+            feats_chunks.append(self.engine.encode_images(self.load_images(list(images[s: s + self.max_images]))))
+        feats = feats_chunks[0] if len(feats_chunks) == 1 else torch.cat(feats_chunks, 0)
+        ids, lab = self.tokenize(questions, answers)
+        idx = torch.as_tensor(list(pair_image), dtype=torch.int32)
+        scores, lps = [], []
+        for s in range(0, n, self.max_pairs):
+            e = min(n, s + self.max_pairs)
+            lp, sc = self.engine.score(feats, idx[s:e], ids[s:e], lab[s:e])
+            scores.append(sc)
+            lps.append(lp)
+        sc = torch.cat(scores).float().cpu()
+        if return_logprobs:
+            return sc, torch.cat(lps).float().cpu()
+        return sc
+
+    def forward(self, images: List[str], texts: List[str], question_template: str = default_question_template,
+                answer_template: str = default_answer_template, return_logprobs: bool = False) -> torch.Tensor:
+        """n scores for n (image, text) pairs; score = exp(mean log P(answer tokens)) = the v3.0
+        ``exp(-CrossEntropyLoss(mean))``."""
+        assert len(images) == len(texts), "Number of images and texts must match"
+        questions = [question_template.format(t) for t in texts]
+        answers = [answer_template.format(t) for t in texts]
+        uniq: Dict[str, int] = {}
+        pair_image = [uniq.setdefault(str(p), len(uniq)) for p in images]
+        return self.score_pairs(list(uniq.keys()), pair_image, questions, answers, return_logprobs)
+
+    def forward_grid(self, images: List[str], texts: List[str], question_template: str = default_question_template,
+                     answer_template: str = default_answer_template) -> torch.Tensor:
+        """All M x N pairs in one batched pass -> fp32 [M, N] on the CPU (row i = image i)."""
+        M, N = len(images), len(texts)
+        questions = [question_template.format(t) for t in texts] * M
+        answers = [answer_template.format(t) for t in texts] * M
+        uniq: Dict[str, int] = {}
+        img_ids = [uniq.setdefault(str(p), len(uniq)) for p in images]
+        pair_image = [img_ids[i] for i in range(M) for _ in range(N)]
+        return self.score_pairs(list(uniq.keys()), pair_image, questions, answers).reshape(M, N)
+
+    def generate(self, *args, **kwargs):
+        # multi-step decoding is outside the scoring hot path
+        raise NotImplementedError("generate() is not part of the MI355X scoring path")
