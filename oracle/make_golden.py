@@ -11,6 +11,8 @@ What is pinned (SURVEY.md §8c -- the reference itself has no golden vectors for
                             module cast to bf16 as the reference does (mm_utils.py:228) on the CPU: label log-probs
                             and scores of both, plus the inputs.  The bf16 run is the reference's own numerical
                             noise floor against which the HIP path's error is judged.
+  * clip_preprocess.npz  -- HF ``CLIPImageProcessor`` (resize shortest edge, centre crop, rescale, normalise) on seeded
+                            uint8 images of several aspect ratios.
   * hf_tiny.npz / hf_small.npz
       - ``CLIPVisionModel(..., output_hidden_states=True).hidden_states[-2]`` on seeded pixels,
       - ``T5ForConditionalGeneration(inputs_embeds=..., attention_mask=..., labels=...)``
@@ -182,10 +184,28 @@ def golden_e2e(name: str, seed: int, n_img: int, B: int, L: int, T: int, gain: f
           "logP range", float(lp32.min()), float(lp32.max()))
 
 
+def golden_preprocess():
+    """HF CLIPImageProcessor (PIL backend here: no torchvision) on seeded images at a small target size."""
+    from PIL import Image
+    from transformers import CLIPImageProcessor
+    size = 56
+    p = CLIPImageProcessor(size={"shortest_edge": size}, crop_size={"height": size, "width": size})
+    rng = np.random.RandomState(7)
+    shapes = [(70, 70), (90, 150), (200, 120), (56, 56), (40, 33)]
+    out = {"size": size}
+    for i, (h, w) in enumerate(shapes):
+        arr = rng.randint(0, 256, (h, w, 3), dtype=np.uint8)
+        out[f"img{i}"] = arr
+        out[f"px{i}"] = p(images=Image.fromarray(arr), return_tensors="np")["pixel_values"][0].astype(np.float32)
+    np.savez_compressed(os.path.join(GOLDEN, "clip_preprocess.npz"), **out)
+    print("clip_preprocess.npz", os.path.getsize(os.path.join(GOLDEN, "clip_preprocess.npz")) // 1024, "KiB")
+
+
 if __name__ == "__main__":
     os.makedirs(GOLDEN, exist_ok=True)
     torch.manual_seed(0)
     golden_relpos()
+    golden_preprocess()
     golden_model("tiny", seed=3, n_img=2, B=3, S_e=24, T=3)
     golden_model("small", seed=5, n_img=1, B=2, S_e=40, T=2)
     golden_e2e("tiny", seed=21, n_img=3, B=8, L=12, T=2, gain=1.0)

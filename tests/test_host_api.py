@@ -1,0 +1,245 @@
+"""Host-side logic of the drop-in boundary, on CPU: prompt recipe, tokenisation with the image sentinel,
+preprocessing against HF, the M x N / dataset loops, batching and image de-duplication, error conventions.
+The device engine is replaced by test doubles here (a recording fake, and the CPU oracle as a checker)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+import t2v_metrics_amd as t2v
+from t2v_metrics_amd.config import get_config
+from t2v_metrics_amd.constants import IMAGE_TOKEN_INDEX, SYSTEM_MSG
+from t2v_metrics_amd.models.vqascore_models import clip_t5_model as cm
+from t2v_metrics_amd.models.vqascore_models.mm_utils import expand2square, t5_tokenizer_image_token
+from t2v_metrics_amd.preprocess import OPENAI_CLIP_MEAN, clip_preprocess
+
+
+class FakeTokenizer:
+    """HF protocol: tokenizer(text).input_ids; whitespace words -> stable ids in [3, vocab), trailing </s> = 1."""
+
+    def __init__(self, vocab=512):
+        self.vocab = vocab
+
+    def __call__(self, text):
+        import zlib
+
+        class R:
+            pass
+
+        r = R()
+        r.input_ids = [3 + zlib.crc32(w.encode()) % (self.vocab - 3) for w in text.split()] + [1]
+        return r
+
+
+class RecordingEngine:
+    """Engine double: remembers what it was asked to do and returns a deterministic function of its inputs."""
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self.encode_calls, self.score_calls = [], []
+
+    def encode_images(self, pixels):
+        self.encode_calls.append(tuple(pixels.shape))
+        # feature "= mean pixel" so that scores depend on the image
+        return pixels.float().mean(dim=(1, 2, 3)).reshape(-1, 1, 1).expand(-1, self.cfg.vision.n_patches, self.cfg.t5.d_model)
+
+    def score(self, feats, img_index, input_ids, labels):
+        self.score_calls.append((tuple(input_ids.shape), tuple(labels.shape), img_index.tolist()))
+        img_term = feats[img_index.long(), 0, 0].float()
+        txt_term = (input_ids.clamp(min=0).float().sum(-1) % 97) / 97.0
+        sc = torch.sigmoid(img_term + txt_term)
+        return torch.log(sc)[:, None].expand(-1, labels.shape[1]).contiguous(), sc
+
+
+class OracleEngine:
+    """The CPU oracle behind the engine interface (checker only; lives in tests/)."""
+
+    def __init__(self, cfg, weights):
+        from oracle.clip_t5_oracle import Oracle
+        self.o = Oracle(cfg, weights)
+
+    def encode_images(self, pixels):
+        with torch.no_grad():
+            return self.o.projector(self.o.vision_features(pixels.float()))
+
+    def score(self, feats, img_index, input_ids, labels):
+        o = self.o
+        with torch.no_grad():
+            emb, mask, _ = o.splice(feats, img_index, input_ids.long())
+            enc = o.t5_encoder(emb, mask)
+            from oracle.clip_t5_oracle import shift_right
+            dec = o.t5_decoder(shift_right(labels.long()), enc, mask)
+            lp = o.label_logprobs(o.lm_logits(dec), labels.long())
+            return lp, o.scores_from_logprobs(lp, labels.long())
+
+
+@pytest.fixture()
+def images(tmp_path):
+    rng = np.random.RandomState(0)
+    paths = []
+    for i, (h, w) in enumerate([(60, 60), (40, 70), (80, 50)]):
+        p = tmp_path / f"im{i}.png"
+        Image.fromarray(rng.randint(0, 256, (h, w, 3), dtype=np.uint8)).save(p)
+        paths.append(str(p))
+    arr = rng.randint(0, 256, (30, 30, 3), dtype=np.uint8)
+    np.save(tmp_path / "bgr.npy", arr)
+    paths.append(str(tmp_path / "bgr.npy"))
+    return paths
+
+
+def make_scorer(tmp_path, engine=None, **kw):
+    cfg = get_config("tiny")
+    engine = engine or RecordingEngine(cfg)
+    s = t2v.VQAScore(model="clip-flant5-xl", device="cpu", cache_dir=str(tmp_path / "cache"), config=cfg, engine=engine,
+                     tokenizer=FakeTokenizer(cfg.t5.vocab), **kw)
+    return s, engine
+
+
+# ----------------------------------------------------------------------------------------- prompt recipe
+def test_registry_and_error_conventions(tmp_path):
+    assert t2v.list_all_models() == ["clip-flant5-xxl", "clip-flant5-xl"]
+    with pytest.raises(AssertionError):                       # score.py:28
+        t2v.VQAScore(model="no-such-model", device="cpu", cache_dir=str(tmp_path))
+    with pytest.raises(NotImplementedError):                  # __init__.py:30-33
+        t2v.get_score_model(model="no-such-model")
+    s, _ = make_scorer(tmp_path)
+    with pytest.raises(AssertionError):                       # forward asserts len(images) == len(texts)
+        s.model.forward(["a.png"], ["x", "y"])
+    with pytest.raises(NotImplementedError):
+        s(images=["clip.mp4"], texts=["x"])
+    assert s.model.video_mode == "concat" and s.model.allows_image
+
+
+def test_question_format_and_templates():
+    q = cm.format_question(cm.default_question_template.format("a dog"))
+    assert q == SYSTEM_MSG + ' USER: <image>\nDoes this figure show "a dog"? Please answer yes or no. ASSISTANT: '
+    assert cm.default_answer_template == "Yes"
+
+
+def test_t5_tokenizer_image_token_places_one_sentinel_between_chunks():
+    tok = FakeTokenizer()
+    ids = t5_tokenizer_image_token("hello world <image> bye", tok)
+    a, b = tok("hello world ").input_ids, tok(" bye").input_ids
+    assert ids == a + [IMAGE_TOKEN_INDEX] + b          # each chunk keeps its own trailing </s>
+    assert ids.count(IMAGE_TOKEN_INDEX) == 1 and a[-1] == 1 and b[-1] == 1
+    assert t5_tokenizer_image_token("no image here", tok) == tok("no image here").input_ids
+    assert torch.equal(t5_tokenizer_image_token("x <image>", tok, return_tensors="pt"),
+                       torch.tensor(tok("x ").input_ids + [IMAGE_TOKEN_INDEX] + tok("").input_ids))
+
+
+def test_tokenize_pads_and_validates(tmp_path):
+    s, _ = make_scorer(tmp_path)
+    ids, lab = s.model.tokenize(["one two three <image>".replace(" <image>", ""), "one"], ["Yes", "Yes it is"])
+    assert ids.dtype == torch.int32 and lab.dtype == torch.int32
+    assert (ids == IMAGE_TOKEN_INDEX).sum(-1).tolist() == [1, 1]
+    assert ids[1, -1] == 0 and ids[0, -1] == 1          # right padded with the pad id
+    assert lab.tolist()[0][-1] == -100 and lab.tolist()[1][-1] == 1
+
+
+# ----------------------------------------------------------------------------------------- images
+def test_expand2square():
+    im = Image.new("RGB", (10, 4), (1, 2, 3))
+    sq = expand2square(im, (9, 9, 9))
+    assert sq.size == (10, 10)
+    a = np.asarray(sq)
+    assert (a[3:7] == (1, 2, 3)).all() and (a[:3] == 9).all() and (a[7:] == 9).all()
+    tall = expand2square(Image.new("RGB", (4, 9), (1, 2, 3)), (9, 9, 9))
+    assert tall.size == (9, 9) and (np.asarray(tall)[:, 2:6] == (1, 2, 3)).all()
+    assert expand2square(Image.new("RGB", (5, 5)), (0, 0, 0)).size == (5, 5)
+
+
+def test_clip_preprocess_matches_hf_fixture(golden_dir):
+    g = np.load(os.path.join(golden_dir, "clip_preprocess.npz"))
+    size = int(g["size"])
+    i = 0
+    while f"img{i}" in g:
+        out = clip_preprocess(Image.fromarray(g[f"img{i}"]), size, pad_to_square=False)
+        assert out.shape == (3, size, size)
+        assert np.abs(out - g[f"px{i}"]).max() < 2e-6, i
+        i += 1
+    assert i == 5
+
+
+def test_load_images_pads_with_clip_mean_and_reads_bgr_npy(tmp_path, images):
+    s, _ = make_scorer(tmp_path)
+    px = s.model.load_images(images)
+    S = s.model.cfg.vision.image
+    assert px.shape == (4, 3, S, S) and px.dtype == torch.bfloat16
+    # image 1 is 40x70 (h x w): padded rows are the CLIP mean colour -> ~0 after normalisation
+    top = px[1, :, 0, :].float().abs().max().item()
+    assert top < 0.02, top
+    arr = np.load(images[3])
+    ref = clip_preprocess(Image.fromarray(arr[:, :, ::-1].copy()), S)
+    assert np.abs(px[3].float().numpy() - ref).max() < 0.02          # bf16 rounding only
+    assert tuple(int(x * 255) for x in OPENAI_CLIP_MEAN) == (122, 116, 104)
+
+
+# ----------------------------------------------------------------------------------------- the loops
+def test_forward_grid_dedups_images_and_batches_pairs(tmp_path, images):
+    s, eng = make_scorer(tmp_path, max_pairs=4)
+    texts = ["a cat", "a dog on a mat", "two birds"]
+    out = s(images=images[:3] + [images[0]], texts=texts)
+    assert out.shape == (4, 3) and out.dtype == torch.float32
+    assert eng.encode_calls == [(3, 3, 56, 56)]                 # 4 image slots, 3 distinct files, encoded once
+    assert [c[0][0] for c in eng.score_calls] == [4, 4, 4]      # 12 pairs in chunks of max_pairs
+    assert torch.equal(out[0], out[3])                          # same file -> same row
+    # row-major pair order: row i = image i
+    assert eng.score_calls[0][2] == [0, 0, 0, 1]
+    single = s(images=images[1], texts=texts[2])
+    assert single.shape == (1, 1) and torch.allclose(single[0, 0], out[1, 2])
+
+
+def test_forward_kwargs_reach_the_model(tmp_path, images):
+    s, eng = make_scorer(tmp_path)
+    a = s(images=images[:1], texts=["x y"])
+    b = s(images=images[:1], texts=["x y"], question_template="Is this {}?", answer_template="{}")
+    assert not torch.equal(a, b)
+    assert eng.score_calls[-1][1][1] == 3                       # answer "{}" -> "x y" -> 2 words + </s>
+
+
+def test_model_forward_matches_reference_row_semantics(tmp_path, images):
+    """score.py:105-106: scores[i] = model.forward([image]*N, texts).  Row i of the grid equals that call."""
+    s, _ = make_scorer(tmp_path)
+    texts = ["alpha", "beta gamma"]
+    grid = s(images=images[:2], texts=texts)
+    for i in range(2):
+        row = s.model.forward([images[i]] * len(texts), texts)
+        assert isinstance(row, torch.Tensor) and row.device.type == "cpu"
+        assert torch.allclose(row, grid[i])
+
+
+def test_batch_forward_shape_and_values(tmp_path, images):
+    s, eng = make_scorer(tmp_path)
+    dataset = [{"images": [images[0], images[1]], "texts": ["t one", "t two", "t three"]},
+               {"images": [images[2], images[0]], "texts": ["u one", "u two", "u three"]},
+               {"images": [images[1], images[1]], "texts": ["v one", "v two", "v three"]}]
+    out = s.batch_forward(dataset, batch_size=2)
+    assert out.shape == (3, 2, 3)
+    for k, d in enumerate(dataset):
+        assert torch.allclose(out[k], s(images=d["images"], texts=d["texts"]))
+    assert torch.equal(out[2, 0], out[2, 1])
+    with pytest.raises(AssertionError):
+        s.batch_forward([dataset[0], {"images": [images[0]], "texts": ["a", "b", "c"]}])
+
+
+def test_full_host_pipeline_against_oracle(tmp_path, images):
+    """Prompt -> ids -> splice -> score through the real host code with the CPU oracle as the engine equals
+    calling the oracle by hand on hand-built inputs."""
+    from oracle.clip_t5_oracle import Oracle
+    from t2v_metrics_amd.weights import make_seeded_weights
+    cfg = get_config("tiny")
+    w = make_seeded_weights(cfg, seed=3, device="cpu")
+    s, _ = make_scorer(tmp_path, engine=OracleEngine(cfg, w))
+    texts = ["red car", "a blue bicycle leaning on a wall"]
+    out = s(images=images[:2], texts=texts)
+    tok = FakeTokenizer(cfg.t5.vocab)
+    px = s.model.load_images(images[:2]).float()
+    for i in range(2):
+        for j, t in enumerate(texts):
+            ids = t5_tokenizer_image_token(cm.format_question(cm.default_question_template.format(t)), tok)
+            lab = tok("Yes").input_ids
+            ref = Oracle(cfg, w).forward(px[i: i + 1], torch.tensor([0]), torch.tensor([ids]), torch.tensor([lab]))
+            assert abs(ref["scores"][0].item() - out[i, j].item()) < 1e-5 * max(1.0, out[i, j].item())
+    assert ((out >= 0) & (out <= 1)).all()                     # the reference's own smoke assertion (test.py:110-112)

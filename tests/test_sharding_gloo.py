@@ -1,0 +1,81 @@
+"""N > 1 path on CPU: world_size-2 gloo processes shard a dataset, score with an engine double, all_gather."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from t2v_metrics_amd import sharding
+
+
+def test_shard_range_partitions_exactly():
+    for n in (0, 1, 7, 8, 100, 12500 * 8 + 3):
+        for ws in (1, 2, 3, 8):
+            blocks = [sharding.shard_range(n, r, ws) for r in range(ws)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == n
+            assert all(blocks[i][1] == blocks[i + 1][0] for i in range(ws - 1))
+            sizes = [b - a for a, b in blocks]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, ws, port, tmp, out_path):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        # raw gather
+        n = 11
+        lo, hi = sharding.shard_range(n)
+        local = torch.arange(lo, hi, dtype=torch.float32)[:, None].repeat(1, 3) + rank * 0.0
+        full = sharding.gather_rows(local, n)
+        assert torch.equal(full, torch.arange(n, dtype=torch.float32)[:, None].repeat(1, 3))
+        # the dataset loop under sharding
+        from tests.test_host_api import FakeTokenizer, RecordingEngine
+        import t2v_metrics_amd as t2v
+        from t2v_metrics_amd.config import get_config
+        cfg = get_config("tiny")
+        eng = RecordingEngine(cfg)
+        s = t2v.VQAScore(model="clip-flant5-xl", device="cpu", cache_dir=os.path.join(tmp, f"c{rank}"), config=cfg,
+                         engine=eng, tokenizer=FakeTokenizer(cfg.t5.vocab))
+        imgs = sorted(os.path.join(tmp, f) for f in os.listdir(tmp) if f.endswith(".png"))
+        dataset = [{"images": [imgs[k % len(imgs)]], "texts": [f"caption number {k}", f"other {k}"]} for k in range(7)]
+        out = s.batch_forward(dataset, batch_size=3)
+        assert out.shape == (7, 1, 2)
+        n_scored = sum(c[0][0] for c in eng.score_calls)
+        lo, hi = sharding.shard_range(7)
+        assert n_scored == (hi - lo) * 2              # each rank scored only its own block
+        if rank == 0:
+            np.save(out_path, out.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_batch_forward_sharded_over_two_gloo_ranks(tmp_path):
+    from PIL import Image
+    rng = np.random.RandomState(1)
+    for i in range(3):
+        Image.fromarray(rng.randint(0, 256, (60, 60, 3), dtype=np.uint8)).save(tmp_path / f"im{i}.png")
+    out_path = str(tmp_path / "sharded.npy")
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), out_path), nprocs=2, join=True)
+    sharded = np.load(out_path)
+    # single-process reference
+    from tests.test_host_api import FakeTokenizer, RecordingEngine
+    import t2v_metrics_amd as t2v
+    from t2v_metrics_amd.config import get_config
+    cfg = get_config("tiny")
+    s = t2v.VQAScore(model="clip-flant5-xl", device="cpu", cache_dir=str(tmp_path / "c"), config=cfg,
+                     engine=RecordingEngine(cfg), tokenizer=FakeTokenizer(cfg.t5.vocab))
+    imgs = sorted(str(tmp_path / f) for f in os.listdir(tmp_path) if f.endswith(".png"))
+    dataset = [{"images": [imgs[k % len(imgs)]], "texts": [f"caption number {k}", f"other {k}"]} for k in range(7)]
+    single = s.batch_forward(dataset, batch_size=3).numpy()
+    assert np.array_equal(sharded, single)
