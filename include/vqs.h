@@ -108,7 +108,7 @@ int vqs_score(vqs_handle* h, const void* d_feats, const int32_t* d_img_index, co
 
 /* Byte offset of a named intermediate inside the vqs_score / vqs_encode_images workspace (parity tests read
  * stages through this): "enc_in" fp32 [B,S_e,D], "enc_out" bf16 [B,S_e,D], "logits" fp32 [B*T, ld],
- * "vit_hidden" fp32 [n_img, 1+P, hidden], "enc_len" int32 [B], "flags" int32[1] (bit0 = malformed prompt).
+ * "vit_hidden" fp32 [n_img, 1+P, hidden] (patch rows = hidden_states[-2]; CLS row lags one sub-layer), "enc_len" int32 [B], "flags" int32[1] (bit0 = malformed prompt).
  * For encode-stage names pass B = n_img, L = T = 0.  Returns -1 for an unknown name.
  * *ld_out (optional) receives the row stride in elements. */
 int64_t vqs_workspace_offset(const vqs_handle* h, const char* name, int32_t B, int32_t L, int32_t T, int64_t* ld_out);
@@ -121,7 +121,8 @@ int vqs_profile_read(vqs_handle* h, double* gemm_ms, double* gemm_flops, int32_t
 
 /* ---- single-kernel entry points (parity tests and micro-benchmarks call the kernels through these) ---- */
 /* epilogue: 0 bf16, 1 bf16+quick_gelu, 2 bf16+erf-gelu, 3 fp32, 4 fp32 + residual, 5 gated gelu_new (W rows
- * interleaved per 32: wi_0 block then wi_1 block; C is [M, N/2]), 6 head-major scatter (q/k/v = C, C+B*H*S*64, ...) */
+ * interleaved per 32: wi_0 block then wi_1 block; C is [M, N/2]), 6 head-major scatter (q/k/v = C, C+B*H*S*64, ...)
+ * variant: 0 one tile per workgroup, 1 register-staged (A/B only), 2 ping-pong, 3 persistent (engine default) */
 int vqs_gemm(const void* d_A, const void* d_W, void* d_C, const void* d_bias, const float* d_resid, int32_t M, int32_t N,
              int32_t K, int32_t lda, int32_t ldw, int32_t ldc, int32_t epilogue, int32_t S, int32_t H, int32_t variant,
              void* stream);
@@ -130,9 +131,11 @@ int vqs_attention(const void* d_q, const void* d_k, const void* d_v, void* d_out
 int vqs_decoder_attention(const void* d_q, const void* d_k, const void* d_v, void* d_out, const float* d_bias_table,
                           const int32_t* d_key_len, int32_t B, int32_t H, int32_t T, int32_t S, int32_t ldq, int32_t ldk,
                           int32_t cross, void* stream);
-int vqs_rmsnorm(const float* d_x, const void* d_w, void* d_out, int32_t M, int32_t D, float eps, void* stream);
-int vqs_layernorm(const float* d_x, const void* d_w, const void* d_b, void* d_out, int32_t out_f32, int32_t M, int32_t D,
-                  float eps, void* stream);
+/* d_delta != NULL: d_x += d_delta (fp32, written back) before normalising -- the fused residual update */
+int vqs_rmsnorm(float* d_x, const float* d_delta, const void* d_w, void* d_out, int32_t M, int32_t D, float eps,
+                void* stream);
+int vqs_layernorm(float* d_x, const float* d_delta, const void* d_w, const void* d_b, void* d_out, int32_t out_f32,
+                  int32_t M, int32_t D, float eps, void* stream);
 int vqs_score_head(const float* d_logits, int32_t ldl, int32_t V, const int32_t* d_labels, float* d_label_logprobs,
                    float* d_scores, int32_t B, int32_t T, void* stream);
 /* host-side bucket function used to build the bias tables (HF models/t5/modeling_t5.py:216-262) */

@@ -29,26 +29,42 @@ __device__ __forceinline__ float wave_max(float v) {
 // ------------------------------------------------------------------------------------------------
 // T5 RMSNorm (HF models/t5/modeling_t5.py:59-72): out = w * x * rsqrt(mean(x^2) + eps); fp32 stream in,
 // bf16 GEMM operand out.  One wave per row, two passes over the row (second pass hits L2).
+// With `delta` the residual update of the previous sub-layer (hidden = hidden + sublayer_out,
+// modeling_t5.py:140,400,431) is fused in front: x += delta is written back, then normalised.
 // D % 4 == 0.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) rmsnorm_kernel(const float* __restrict__ x, const bf16_t* __restrict__ w,
-                                                      bf16_t* __restrict__ out, int M, int D, float eps) {
+template <bool ADD>
+__global__ void __launch_bounds__(256) rmsnorm_kernel(float* __restrict__ x, const float* __restrict__ delta,
+                                                      const bf16_t* __restrict__ w, bf16_t* __restrict__ out, int M, int D,
+                                                      float eps) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= M) return;
-    const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * D);
+    float4* xr = reinterpret_cast<float4*>(x + (size_t)row * D);
     const int nv = D >> 2;
     float ss = 0.0f;
-    for (int i = lane; i < nv; i += 64) {
-        const float4 v = xr[i];
-        ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    if (ADD) {
+        // x <- x + delta (the previous sub-layer's fp32 GEMM output), written back: the residual stream update
+        const float4* dr = reinterpret_cast<const float4*>(delta + (size_t)row * D);
+        for (int i = lane; i < nv; i += 64) {
+            float4 v = xr[i];
+            const float4 d = dr[i];
+            v.x += d.x; v.y += d.y; v.z += d.z; v.w += d.w;
+            xr[i] = v;
+            ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+    } else {
+        for (int i = lane; i < nv; i += 64) {
+            const float4 v = xr[i];
+            ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
     }
     ss = wave_sum(ss);
     const float rs = rsqrtf(ss / (float)D + eps);
     uint2* orow = reinterpret_cast<uint2*>(out + (size_t)row * D);
     const uint2* wr = reinterpret_cast<const uint2*>(w);
     for (int i = lane; i < nv; i += 64) {
-        const float4 v = xr[i];
+        const float4 v = xr[i];        // same lane wrote it in the ADD pass
         const uint2 wv = wr[i];
         uint2 o;
         o.x = e_pack2(v.x * rs * e_bf2f((bf16_t)(wv.x & 0xffff)), v.y * rs * e_bf2f((bf16_t)(wv.x >> 16)));
@@ -57,28 +73,43 @@ __global__ void __launch_bounds__(256) rmsnorm_kernel(const float* __restrict__ 
     }
 }
 
-hipError_t launch_rmsnorm(const float* x, const bf16_t* w, bf16_t* out, int M, int D, float eps, hipStream_t s) {
+hipError_t launch_rmsnorm(float* x, const float* delta, const bf16_t* w, bf16_t* out, int M, int D, float eps,
+                          hipStream_t s) {
     if (D % 4) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(rmsnorm_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, w, out, M, D, eps);
+    if (delta)
+        hipLaunchKernelGGL(rmsnorm_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, s, x, delta, w, out, M, D, eps);
+    else
+        hipLaunchKernelGGL(rmsnorm_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, s, x, delta, w, out, M, D, eps);
     return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------
 // CLIP LayerNorm (torch.nn.LayerNorm at HF models/clip/modeling_clip.py:357-360,642): fp32 stats.
 // ------------------------------------------------------------------------------------------------
-template <bool OUT_F32>
-__global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict__ x, const bf16_t* __restrict__ w,
-                                                        const bf16_t* __restrict__ bsh, void* __restrict__ out, int M,
-                                                        int D, float eps) {
+template <bool OUT_F32, bool ADD>
+__global__ void __launch_bounds__(256) layernorm_kernel(float* __restrict__ x, const float* __restrict__ delta,
+                                                        const bf16_t* __restrict__ w, const bf16_t* __restrict__ bsh,
+                                                        void* __restrict__ out, int M, int D, float eps) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= M) return;
-    const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * D);
+    float4* xr = reinterpret_cast<float4*>(x + (size_t)row * D);
     const int nv = D >> 2;
     float s1 = 0.0f;
-    for (int i = lane; i < nv; i += 64) {
-        const float4 v = xr[i];
-        s1 += v.x + v.y + v.z + v.w;
+    if (ADD) {
+        const float4* dr = reinterpret_cast<const float4*>(delta + (size_t)row * D);
+        for (int i = lane; i < nv; i += 64) {
+            float4 v = xr[i];
+            const float4 d = dr[i];
+            v.x += d.x; v.y += d.y; v.z += d.z; v.w += d.w;
+            xr[i] = v;
+            s1 += v.x + v.y + v.z + v.w;
+        }
+    } else {
+        for (int i = lane; i < nv; i += 64) {
+            const float4 v = xr[i];
+            s1 += v.x + v.y + v.z + v.w;
+        }
     }
     const float mu = wave_sum(s1) / (float)D;
     float s2 = 0.0f;
@@ -108,13 +139,17 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
     }
 }
 
-hipError_t launch_layernorm(const float* x, const bf16_t* w, const bf16_t* b, void* out, int out_f32, int M, int D,
-                            float eps, hipStream_t s) {
+hipError_t launch_layernorm(float* x, const float* delta, const bf16_t* w, const bf16_t* b, void* out, int out_f32, int M,
+                            int D, float eps, hipStream_t s) {
     if (D % 4) return hipErrorInvalidValue;
-    if (out_f32)
-        hipLaunchKernelGGL(layernorm_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, s, x, w, b, out, M, D, eps);
-    else
-        hipLaunchKernelGGL(layernorm_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, s, x, w, b, out, M, D, eps);
+    const dim3 grid((M + 3) / 4), block(256);
+    if (out_f32) {
+        if (delta) hipLaunchKernelGGL((layernorm_kernel<true, true>), grid, block, 0, s, x, delta, w, b, out, M, D, eps);
+        else hipLaunchKernelGGL((layernorm_kernel<true, false>), grid, block, 0, s, x, delta, w, b, out, M, D, eps);
+    } else {
+        if (delta) hipLaunchKernelGGL((layernorm_kernel<false, true>), grid, block, 0, s, x, delta, w, b, out, M, D, eps);
+        else hipLaunchKernelGGL((layernorm_kernel<false, false>), grid, block, 0, s, x, delta, w, b, out, M, D, eps);
+    }
     return hipGetLastError();
 }
 
@@ -171,13 +206,21 @@ hipError_t launch_vit_assemble(const float* patch_out, const bf16_t* cls, const 
 }
 
 // feature select: hidden_states[-2][:, 1:] -> bf16 rows for the projector GEMM
-__global__ void __launch_bounds__(256) drop_cls_cast_kernel(const float* __restrict__ hidden, bf16_t* __restrict__ out,
+__global__ void __launch_bounds__(256) drop_cls_cast_kernel(float* __restrict__ hidden,
+                                                            const float* __restrict__ delta, bf16_t* __restrict__ out,
                                                             int P, int D) {
     const int n = blockIdx.y, pidx = blockIdx.x;
-    const float4* src = reinterpret_cast<const float4*>(hidden + ((size_t)n * (P + 1) + 1 + pidx) * D);
+    const size_t roff = ((size_t)n * (P + 1) + 1 + pidx) * D;
+    float4* src = reinterpret_cast<float4*>(hidden + roff);
+    const float4* dsrc = delta ? reinterpret_cast<const float4*>(delta + roff) : nullptr;
     uint2* dst = reinterpret_cast<uint2*>(out + ((size_t)n * P + pidx) * D);
     for (int i = threadIdx.x; i < (D >> 2); i += 256) {
-        const float4 v = src[i];
+        float4 v = src[i];
+        if (dsrc) {
+            const float4 d = dsrc[i];
+            v.x += d.x; v.y += d.y; v.z += d.z; v.w += d.w;
+            src[i] = v;      // materialise hidden_states[-2] for the patch rows (the CLS row is never needed)
+        }
         uint2 o;
         o.x = e_pack2(v.x, v.y);
         o.y = e_pack2(v.z, v.w);
@@ -185,9 +228,9 @@ __global__ void __launch_bounds__(256) drop_cls_cast_kernel(const float* __restr
     }
 }
 
-hipError_t launch_drop_cls_cast(const float* hidden, bf16_t* out, int N, int P, int D, hipStream_t s) {
+hipError_t launch_drop_cls_cast(float* hidden, const float* delta, bf16_t* out, int N, int P, int D, hipStream_t s) {
     if (D % 4) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(drop_cls_cast_kernel, dim3(P, N), dim3(256), 0, s, hidden, out, P, D);
+    hipLaunchKernelGGL(drop_cls_cast_kernel, dim3(P, N), dim3(256), 0, s, hidden, delta, out, P, D);
     return hipGetLastError();
 }
 

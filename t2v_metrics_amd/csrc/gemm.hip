@@ -20,6 +20,12 @@
 // M and N edges are handled by clamping source rows and predicating stores; K must be a multiple of 64.
 #include "vqs_kernels.h"
 
+// Lab-only ablation switches (tools/gemm_lab.sh builds variants; the product build leaves this at 0):
+//   1 = no global->LDS staging after the first K-tile, 2 = no epilogue stores, 4 = fragments read from LDS once
+#ifndef VQS_ABLATE
+#define VQS_ABLATE 0
+#endif
+
 namespace vqs {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -31,21 +37,27 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 static constexpr int BM = 256, BN = 256, BK = 64;
 static constexpr int STAGE_BYTES = 65536;   // A 32 KiB + W 32 KiB
 static constexpr int W_OFF = 32768;
+static constexpr int PERSISTENT_WGS = 256;   // one 128-KiB-LDS workgroup per CU
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {   // round-to-nearest-even
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ bf16_t f2bf(float f) {   // round-to-nearest-even (v_cvt_pk_bf16_f32 on gfx950)
+    return __builtin_bit_cast(bf16_t, (__bf16)f);
 }
-__device__ __forceinline__ uint32_t pack2(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+    bf16x2_t v;
+    v[0] = (__bf16)a;
+    v[1] = (__bf16)b;
+    return __builtin_bit_cast(uint32_t, v);
+}
 
-__device__ __forceinline__ float act_quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+// x * sigmoid(1.702 x)                                               HF activations.py:117-123
+__device__ __forceinline__ float act_quick_gelu(float x) { return x * __frcp_rn(1.0f + __expf(-1.702f * x)); }
 __device__ __forceinline__ float act_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// 0.5 x (1 + tanh(u)), u = sqrt(2/pi)(x + 0.044715 x^3)  ==  x * sigmoid(2u)      HF activations.py:59-66
 __device__ __forceinline__ float act_gelu_new(float x) {
-    const float k = 0.7978845608028654f;   // sqrt(2/pi)
-    return 0.5f * x * (1.0f + tanhf(k * (x + 0.044715f * x * x * x)));
+    const float u2 = 1.5957691216057308f * (x + 0.044715f * x * x * x);   // 2u
+    return x * __frcp_rn(1.0f + __expf(-u2));
 }
 
 // One 1-KiB direct-to-LDS piece: lane l's 16 bytes from `src` land at LDS byte address dst + 16*l.
@@ -60,14 +72,14 @@ __device__ __forceinline__ void glds16(const void* src, uint32_t lds_dst) {
         "global_load_lds_dwordx4 %1, off\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
-        : "v"(src), "s"(lds_dst)
-        : "memory");
+        : "v"(src), "s"(lds_dst));
 }
 
-template <int EPI, bool GLDS>
+template <int EPI, int VAR>
 __global__ void __launch_bounds__(512) gemm_bf16_kernel(const GemmParams p) {
     __shared__ __attribute__((aligned(16))) char lds[2 * STAGE_BYTES];
 
+    constexpr bool GLDS = (VAR != 1);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -146,19 +158,92 @@ __global__ void __launch_bounds__(512) gemm_bf16_kernel(const GemmParams p) {
         }
     };
 
+    uint4 abl_af[4], abl_wf[2];
+    if constexpr ((VQS_ABLATE & 4) != 0) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) abl_af[m] = *reinterpret_cast<const uint4*>(p.A + (size_t)(lane + m * 64) * 8);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) abl_wf[n] = *reinterpret_cast<const uint4*>(p.W + (size_t)(lane + n * 64) * 8);
+    }
+    if constexpr (VAR == 2) {
+        // ---- ping-pong schedule.  The two waves that share a SIMD (w and w+4, i.e. wr = 0 / 1) run one barrier
+        // apart: while one group is in an MFMA segment (8 MFMAs = one k-step of 16) the other is in a load segment
+        // (its 6 ds_read_b128 of the next k-step, plus the LDS-DMA issue for the next K-tile), then they swap.
+        // Slot k (between barriers k and k+1): group 0 runs L(k/2) | M((k-1)/2), group 1 the other kind.
+        //   - tile t+1 is staged into the stage tile t-1 occupied; its DMA is issued in phases 1 and 2 of tile t,
+        //     i.e. at least one barrier after every wave has waited (lgkmcnt) for its last read of tile t-1;
+        //   - every wave drains its own DMA (vmcnt(0)) in slot 8t+7, one barrier before the first read of tile
+        //     t+1 (group 0: end of its last MFMA segment; group 1: end of its last load segment).
+        auto stage_part = [&](int s, int t, int i0) {
+#pragma unroll
+            for (int i = i0; i < i0 + 2; ++i) {
+                const uint32_t da = lds_base + s * STAGE_BYTES + (i * 8 + w) * 1024;
+                glds16(pa[i] + (size_t)t * BK, da);
+                glds16(pb[i] + (size_t)t * BK, da + W_OFF);
+            }
+        };
+        const bool g1 = (wr == 1);
+        stage_part(0, 0, 0);
+        stage_part(0, 0, 2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (g1) __builtin_amdgcn_s_barrier();
+        for (int t = 0; t < nt; ++t) {
+            const char* sb = lds + (t & 1) * STAGE_BYTES;
+            const bool more = (t + 1 < nt);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                // ---- load segment
+                uint4 af[4], wf[2];
+#pragma unroll
+                for (int n = 0; n < 2; ++n) wf[n] = *reinterpret_cast<const uint4*>(sb + b_row + n * 4096 + koff[ks]);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) af[m] = *reinterpret_cast<const uint4*>(sb + a_row + m * 4096 + koff[ks]);
+                if (more && ks == 1) stage_part((t + 1) & 1, t + 1, 0);
+                if (more && ks == 2) stage_part((t + 1) & 1, t + 1, 2);
+                if (ks == 3 && g1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- MFMA segment
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8, wf[n]), __builtin_bit_cast(bf16x8, af[m]), acc[m][n], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                if (ks == 3 && !g1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (!g1) __builtin_amdgcn_s_barrier();
+    } else {
     stage(0, 0);
     for (int t = 0; t < nt; ++t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                       // tile t landed everywhere; buffer (t+1)&1 no longer read
-        if (t + 1 < nt) stage((t + 1) & 1, t + 1);
-        const char* sb = lds + (t & 1) * STAGE_BYTES;
+        if ((t + 1 < nt) && !(VQS_ABLATE & 1)) stage((t + 1) & 1, t + 1);
+        const char* sb = lds + ((VQS_ABLATE & 1) ? 0 : (t & 1)) * STAGE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             uint4 af[4], wf[2];
+            if constexpr ((VQS_ABLATE & 4) != 0) {
 #pragma unroll
-            for (int m = 0; m < 4; ++m) af[m] = *reinterpret_cast<const uint4*>(sb + a_row + m * 4096 + koff[ks]);
+                for (int m = 0; m < 4; ++m) af[m] = abl_af[m];
 #pragma unroll
-            for (int n = 0; n < 2; ++n) wf[n] = *reinterpret_cast<const uint4*>(sb + b_row + n * 4096 + koff[ks]);
+                for (int n = 0; n < 2; ++n) wf[n] = abl_wf[n];
+            } else {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) af[m] = *reinterpret_cast<const uint4*>(sb + a_row + m * 4096 + koff[ks]);
+#pragma unroll
+                for (int n = 0; n < 2; ++n) wf[n] = *reinterpret_cast<const uint4*>(sb + b_row + n * 4096 + koff[ks]);
+            }
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -166,6 +251,16 @@ __global__ void __launch_bounds__(512) gemm_bf16_kernel(const GemmParams p) {
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                         __builtin_bit_cast(bf16x8, wf[n]), __builtin_bit_cast(bf16x8, af[m]), acc[m][n], 0, 0, 0);
         }
+    }
+    }
+    if constexpr ((VQS_ABLATE & 2) != 0) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[m][n][r]));
+        return;
     }
 
     // ---- epilogue.  acc[m][n][r]: row = m0 + wr*128 + m*32 + (lane&31)
@@ -215,6 +310,14 @@ __global__ void __launch_bounds__(512) gemm_bf16_kernel(const GemmParams p) {
                     bia[n][g][0] = bia[n][g][1] = bia[n][g][2] = bia[n][g][3] = 0.0f;
                 }
             }
+        // EPI_HEADS: a wave's 64 columns are exactly one head of one of the q/k/v tensors (inner % 64 == 0)
+        bf16_t* head_base = nullptr;
+        if constexpr (EPI == EPI_HEADS) {
+            const int cw = min(n0 + wc * 64, p.N - 64);
+            const int which = cw / p.inner;
+            bf16_t* hp = which == 0 ? p.heads_out[0] : (which == 1 ? p.heads_out[1] : p.heads_out[2]);
+            head_base = hp + (size_t)((cw - which * p.inner) >> 6) * p.S * 64;
+        }
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const int row = row_base + m * 32;
@@ -253,10 +356,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_kernel(const GemmParams p) {
                         v.x = pack2(o[0], o[1]);
                         v.y = pack2(o[2], o[3]);
                         if constexpr (EPI == EPI_HEADS) {
-                            const int which = c / p.inner;
-                            const int ci = c - which * p.inner;
-                            const int hh = ci >> 6, d = ci & 63;
-                            bf16_t* dst = p.heads_out[which] + (((size_t)hb * p.H + hh) * p.S + hs) * 64 + d;
+                            bf16_t* dst = head_base + ((size_t)hb * p.H * p.S + hs) * 64 + (c - (n0 + wc * 64));
                             *reinterpret_cast<uint2*>(dst) = v;
                         } else {
                             *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)row * p.ldc + c) = v;
@@ -267,16 +367,340 @@ __global__ void __launch_bounds__(512) gemm_bf16_kernel(const GemmParams p) {
     }
 }
 
+
+// =====================================================================================================
+// Persistent variant (VAR 3): one workgroup per CU walks the tile list; the 2-stage K-tile pipeline runs
+// straight across tile boundaries (the first K-tile of the next tile is in flight during the last K-tile of
+// the current one) and the epilogue stores drain underneath the next tile's first K-tile: the main loop uses
+// raw s_barrier (no fence, so hipcc adds no vmcnt(0) for the stores) and, because gfx950 retires VMEM
+// operations in order on one counter, `s_waitcnt vmcnt(<stores per wave>)` after a full tile's epilogue means
+// "everything older than those stores (= the prefetched K-tile) has landed" without waiting for the stores.
+// The fp32 residual read-modify-write is software-pipelined (loads of row block m+1 are issued before the
+// stores of block m) so that no load ever has to wait behind a just-issued store.
+// Measured motivation (tools/gemm_lab.sh ablations, 155648x10240x2048): stores cost 19 %, staging+prologue 26 %.
+// =====================================================================================================
+__device__ __forceinline__ void st8(void* p, uint2 v) { *reinterpret_cast<uint2*>(p) = v; }
+__device__ __forceinline__ void st16(void* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+#if (VQS_ABLATE & 32)
+__device__ unsigned long long* g_gemm_dbg = nullptr;   // [blocks][8 waves][8 counters], set by vqs_debug_set_gemm_timing
+#define TSTAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define TACC(slot, a, b) tacc[slot] += (b) - (a)
+#else
+#define TSTAMP(var)
+#define TACC(slot, a, b)
+#endif
+
+template <int EPI>
+struct EpiStores { static constexpr int value = (EPI == EPI_GATED) ? 16 : 32; };   // VMEM stores per wave, full tile
+
+template <int EPI>
+__global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * STAGE_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w >> 2, wc = w & 3;
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    const int nwg = tiles_m * tiles_n;
+    const int nt = p.K / BK;
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)LDS_PTR(lds));
+
+    auto tile_coords = [&](int pid, int& m0, int& n0) {
+        const int xcd = pid & 7, local = pid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        const int t_lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+        const int GM = 8;
+        const int width = GM * tiles_n;
+        const int group = t_lin / width;
+        const int first_m = group * GM;
+        const int gsz = min(tiles_m - first_m, GM);
+        m0 = (first_m + (t_lin % width) % gsz) * BM;
+        n0 = ((t_lin % width) / gsz) * BN;
+    };
+
+    const int sw = ((w & 1) << 2) + (lane >> 4);
+    const int gchunk = (lane & 7) ^ sw;
+    const bf16_t* pa[4];
+    const bf16_t* pb[4];
+    auto set_ptrs = [&](int m0, int n0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (i * 8 + w) * 8 + (lane >> 3);
+            pa[i] = p.A + (size_t)min(m0 + row, p.M - 1) * p.lda + gchunk * 8;
+            pb[i] = p.W + (size_t)min(n0 + row, p.N - 1) * p.ldw + gchunk * 8;
+        }
+    };
+    auto stage = [&](int s, int t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t da = lds_base + s * STAGE_BYTES + (i * 8 + w) * 1024;
+            glds16(pa[i] + (size_t)t * BK, da);
+            glds16(pb[i] + (size_t)t * BK, da + W_OFF);
+        }
+    };
+
+    const int swr = (lane >> 1) & 7;
+    int koff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) koff[ks] = (((ks * 2 + (lane >> 5)) ^ swr) << 4);
+    const int a_row = (wr * 128 + (lane & 31)) * 128;
+    const int b_row = W_OFF + (wc * 64 + (lane & 31)) * 128;
+    const int hhalf = lane >> 5;
+
+    int pid = blockIdx.x;
+    if (pid >= nwg) return;
+    int m0, n0;
+    tile_coords(pid, m0, n0);
+    set_ptrs(m0, n0);
+    stage(0, 0);
+#if (VQS_ABLATE & 32)
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+#endif
+    int buf = 0;
+    bool counted = false;     // true: the only VMEM ops younger than the prefetched K-tile are a full epilogue's stores
+
+    while (true) {
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+
+        const int next_pid = pid + gridDim.x;
+        const bool has_next = next_pid < nwg;
+        int nm0 = 0, nn0 = 0;
+
+        for (int t = 0; t < nt; ++t) {
+            TSTAMP(ts0);
+            if (t == 0 && counted) {
+                if constexpr (EpiStores<EPI>::value == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            TSTAMP(ts1);
+            __builtin_amdgcn_s_barrier();
+            TSTAMP(ts2);
+            // source of the stage that is filled during this K-tile: the next K-tile of this tile, or the first
+            // K-tile of the next tile.  The 8 LDS-DMA pieces are issued two per k-step BETWEEN the MFMA groups:
+            // issued back to back they cost 600-1700 cycles per wave (measured) during which the wave's matrix
+            // pipe idles and the early waves then sit at the barrier.
+            int kn = t + 1;
+            bool do_stage = true;
+            if (t + 1 >= nt) {
+                kn = 0;
+                do_stage = has_next;
+                if (has_next) {
+                    tile_coords(next_pid, nm0, nn0);
+                    set_ptrs(nm0, nn0);
+                }
+            }
+            const size_t koffs = (size_t)kn * BK;
+            const uint32_t dst0 = lds_base + (buf ^ 1) * STAGE_BYTES + w * 1024;
+            TSTAMP(ts3);
+            TACC(0, ts0, ts1); TACC(1, ts1, ts2); TACC(2, ts2, ts3);
+            const char* sb = lds + buf * STAGE_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                uint4 af[4], wf[2];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) af[m] = *reinterpret_cast<const uint4*>(sb + a_row + m * 4096 + koff[ks]);
+#pragma unroll
+                for (int n = 0; n < 2; ++n) wf[n] = *reinterpret_cast<const uint4*>(sb + b_row + n * 4096 + koff[ks]);
+                if (do_stage) {
+                    glds16(pa[ks] + koffs, dst0 + ks * 8192);
+                    glds16(pb[ks] + koffs, dst0 + ks * 8192 + W_OFF);
+                }
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8, wf[n]), __builtin_bit_cast(bf16x8, af[m]), acc[m][n], 0, 0, 0);
+            }
+            buf ^= 1;
+#if (VQS_ABLATE & 32)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            { TSTAMP(ts4); TACC(3, ts3, ts4); tacc[5] += 1; }
+#endif
+        }
+        TSTAMP(te0);
+
+        // ---------------- epilogue (same math as the non-persistent kernel; stores via st8/st16)
+        const int row_base = m0 + wr * 128 + (lane & 31);
+        const int col_base = n0 + wc * 64 + 4 * hhalf;
+        const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
+
+        if constexpr (EPI == EPI_GATED) {
+            const int oc_base = ((n0 + wc * 64) >> 1) + 4 * hhalf;
+            const int NO = p.N >> 1;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int row = row_base + m * 32;
+                bf16_t* crow = reinterpret_cast<bf16_t*>(p.C) + (size_t)row * p.ldc;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int oc = oc_base + 8 * g;
+                    float o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = act_gelu_new(acc[m][0][4 * g + e]) * acc[m][1][4 * g + e];
+                    uint2 v;
+                    v.x = pack2(o[0], o[1]);
+                    v.y = pack2(o[2], o[3]);
+                    if (full || (row < p.M && oc < NO)) st8(crow + oc, v);
+                }
+            }
+        } else {
+            float bia[2][4][4];
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c = col_base + n * 32 + 8 * g;
+                    if (p.bias != nullptr && c < p.N) {
+                        const uint2 bv = *reinterpret_cast<const uint2*>(p.bias + c);
+                        bia[n][g][0] = bf2f((bf16_t)(bv.x & 0xffff));
+                        bia[n][g][1] = bf2f((bf16_t)(bv.x >> 16));
+                        bia[n][g][2] = bf2f((bf16_t)(bv.y & 0xffff));
+                        bia[n][g][3] = bf2f((bf16_t)(bv.y >> 16));
+                    } else {
+                        bia[n][g][0] = bia[n][g][1] = bia[n][g][2] = bia[n][g][3] = 0.0f;
+                    }
+                }
+            bf16_t* head_base = nullptr;
+            if constexpr (EPI == EPI_HEADS) {
+                const int cw = min(n0 + wc * 64, p.N - 64);
+                const int which = cw / p.inner;
+                bf16_t* hp = which == 0 ? p.heads_out[0] : (which == 1 ? p.heads_out[1] : p.heads_out[2]);
+                head_base = hp + (size_t)((cw - which * p.inner) >> 6) * p.S * 64;
+            }
+            // fp32 residual: all 32 float4 loads of this lane are issued (two row blocks in flight) and added into
+            // the accumulators BEFORE any store, so no load is ever queued behind a fresh store on the in-order
+            // VMEM counter; the stores then go out back to back and drain under the next tile.
+            if constexpr (EPI == EPI_F32_RESID) {
+                float4 rv[2][4];            // two half-row-blocks (q = 2*m + n) in flight
+                auto load_resid = [&](int q, float4 (&dst)[4]) {
+                    const int rowc = min(row_base + (q >> 1) * 32, p.M - 1);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int c = min(col_base + (q & 1) * 32 + 8 * g, p.N - 4);
+                        dst[g] = *reinterpret_cast<const float4*>(p.resid + (size_t)rowc * p.ldc + c);
+                    }
+                };
+                load_resid(0, rv[0]);
+                load_resid(1, rv[1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 r4 = rv[q & 1][g];
+                        acc[q >> 1][q & 1][4 * g + 0] += r4.x;
+                        acc[q >> 1][q & 1][4 * g + 1] += r4.y;
+                        acc[q >> 1][q & 1][4 * g + 2] += r4.z;
+                        acc[q >> 1][q & 1][4 * g + 3] += r4.w;
+                    }
+                    if (q + 2 < 8) load_resid(q + 2, rv[q & 1]);
+                    __builtin_amdgcn_sched_barrier(0);     // keep at most two half-blocks of loads in flight (VGPRs)
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int row = row_base + m * 32;
+                const int rowc = min(row, p.M - 1);
+                int hb = 0, hs = 0;
+                if constexpr (EPI == EPI_HEADS) {
+                    hb = rowc / p.S;
+                    hs = rowc - hb * p.S;
+                }
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int c = col_base + n * 32 + 8 * g;
+                        const bool ok = full || (row < p.M && c < p.N);
+                        float o[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = acc[m][n][4 * g + e] + bia[n][g][e];
+                        if constexpr (EPI == EPI_BF16_QGELU) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = act_quick_gelu(o[e]);
+                        }
+                        if constexpr (EPI == EPI_BF16_GELU) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = act_gelu_erf(o[e]);
+                        }
+                        if constexpr (EPI == EPI_F32 || EPI == EPI_F32_RESID) {
+                            float* cp = reinterpret_cast<float*>(p.C) + (size_t)row * p.ldc + c;
+                            if (ok) st16(cp, make_float4(o[0], o[1], o[2], o[3]));
+                        } else {
+                            uint2 v;
+                            v.x = pack2(o[0], o[1]);
+                            v.y = pack2(o[2], o[3]);
+                            bf16_t* dst;
+                            if constexpr (EPI == EPI_HEADS) {
+                                dst = head_base + ((size_t)hb * p.H * p.S + hs) * 64 + (c - (n0 + wc * 64));
+                            } else {
+                                dst = reinterpret_cast<bf16_t*>(p.C) + (size_t)row * p.ldc + c;
+                            }
+                            if (ok) st8(dst, v);
+                        }
+                    }
+                }
+            }
+        }
+        counted = full;
+#if (VQS_ABLATE & 32)
+        { TSTAMP(te1); TACC(4, te0, te1); tacc[6] += 1; }
+#endif
+        if (!has_next) break;
+        pid = next_pid;
+        m0 = nm0;
+        n0 = nn0;
+    }
+#if (VQS_ABLATE & 32)
+    if (g_gemm_dbg != nullptr && lane == 0 && blockIdx.x < 64) {
+        tacc[7] = __builtin_amdgcn_s_memtime() - t_start;
+        for (int i = 0; i < 8; ++i) g_gemm_dbg[((size_t)blockIdx.x * 8 + w) * 8 + i] = tacc[i];
+    }
+#endif
+}
+
 template <int EPI>
 static hipError_t launch_epi(const GemmParams& p, int variant, hipStream_t stream) {
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
     dim3 grid(tiles_m * tiles_n), block(512);
     if (variant == 0)
-        hipLaunchKernelGGL((gemm_bf16_kernel<EPI, true>), grid, block, 0, stream, p);
-    else
-        hipLaunchKernelGGL((gemm_bf16_kernel<EPI, false>), grid, block, 0, stream, p);
+        hipLaunchKernelGGL((gemm_bf16_kernel<EPI, 0>), grid, block, 0, stream, p);
+    else if (variant == 1)
+        hipLaunchKernelGGL((gemm_bf16_kernel<EPI, 1>), grid, block, 0, stream, p);
+    else if (variant == 2)
+        hipLaunchKernelGGL((gemm_bf16_kernel<EPI, 2>), grid, block, 0, stream, p);
+    else {
+        if constexpr (EPI == EPI_F32_RESID) {
+            // the in-epilogue fp32 read-modify-write does not fit the persistent kernel's register budget (it
+            // spills); the engine's hot path uses EPI_F32 + a fused add in the following norm kernel instead
+            hipLaunchKernelGGL((gemm_bf16_kernel<EPI, 0>), grid, block, 0, stream, p);
+        } else {
+            const int nwg = tiles_m * tiles_n;
+            dim3 pgrid(nwg < PERSISTENT_WGS ? nwg : PERSISTENT_WGS);
+            hipLaunchKernelGGL((gemm_bf16_persistent<EPI>), pgrid, block, 0, stream, p);
+        }
+    }
     return hipGetLastError();
 }
+
+#if (VQS_ABLATE & 32)
+extern "C" int vqs_debug_set_gemm_timing(void* d_buf) {
+    unsigned long long* p = (unsigned long long*)d_buf;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_dbg), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 hipError_t launch_gemm(const GemmParams& p, int epilogue, int variant, hipStream_t stream) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K % BK) != 0 || (p.N % 8) != 0) return hipErrorInvalidValue;

@@ -76,6 +76,7 @@ struct EncodeWs {
     float* patch_out;
     float* pre;
     float* hidden;
+    float* delta;
     bf16_t *xn, *q, *k, *v, *attn, *mid, *feat_in, *pmid;
     size_t total;
 };
@@ -89,6 +90,7 @@ EncodeWs carve_encode(const vqs_handle* h, char* base, int N, std::unordered_map
     w.patch_out = cv.take<float>(NP * c.vis_hidden);
     w.pre = cv.take<float>(NS * c.vis_hidden);
     w.hidden = cv.take<float>(NS * c.vis_hidden, "vit_hidden");
+    w.delta = cv.take<float>(NS * c.vis_hidden);
     w.xn = cv.take<bf16_t>(NS * c.vis_hidden);
     w.q = cv.take<bf16_t>(NS * c.vis_hidden);
     w.k = cv.take<bf16_t>(NS * c.vis_hidden);
@@ -103,7 +105,7 @@ EncodeWs carve_encode(const vqs_handle* h, char* base, int N, std::unordered_map
 
 struct ScoreWs {
     int *sent_pos, *enc_len, *flags;
-    float *enc_table, *dec_table, *hidden;
+    float *enc_table, *dec_table, *hidden, *delta, *ddelta;
     bf16_t *xn, *q, *k, *v, *attn, *ff, *enc_out, *ck, *cv;
     float* dhid;
     bf16_t *dxn, *dqkv, *dattn, *dq, *dff;
@@ -126,6 +128,7 @@ ScoreWs carve_score(const vqs_handle* h, char* base, int B, int L, int T,
     w.enc_table = cv.take<float>((size_t)H * (2 * S - 1));
     w.dec_table = cv.take<float>((size_t)H * T);
     w.hidden = cv.take<float>(M * D, "enc_in");   // the fp32 residual stream; holds enc_in until layer 0 runs
+    w.delta = cv.take<float>(M * D);              // fp32 sub-layer output waiting to be added by the next norm
     w.xn = cv.take<bf16_t>(M * D);
     w.q = cv.take<bf16_t>(M * I);
     w.k = cv.take<bf16_t>(M * I);
@@ -136,6 +139,7 @@ ScoreWs carve_score(const vqs_handle* h, char* base, int B, int L, int T,
     w.ck = cv.take<bf16_t>(M * I);
     w.cv = cv.take<bf16_t>(M * I);
     w.dhid = cv.take<float>(MT * D);
+    w.ddelta = cv.take<float>(MT * D);
     w.dxn = cv.take<bf16_t>(MT * D);
     w.dqkv = cv.take<bf16_t>(MT * 3 * I);
     w.dattn = cv.take<bf16_t>(MT * I);
@@ -300,7 +304,7 @@ int vqs_create(const vqs_config* cfg, vqs_handle** out) {
         h->h_lut_causal.push_back(vqs_relpos_bucket(-n, 0, c.rel_buckets, c.rel_max_distance));
     }
     const char* v = std::getenv("VQS_GEMM_VARIANT");
-    h->gemm_variant = v ? std::atoi(v) : 0;
+    h->gemm_variant = v ? std::atoi(v) : 3;   // 3 = persistent kernel (gemm.hip)
     return VQS_OK;
 }
 
@@ -420,8 +424,11 @@ int vqs_encode_images(vqs_handle* h, const void* d_pixels, int32_t N, void* d_fe
         RUN(run_gemm(h, g, st, "patch_embed"));
     }
     HIPCHK(h, vqs::launch_vit_assemble(w.patch_out, cls, pos, w.pre, N, P, hid, st), "vit_assemble");
-    HIPCHK(h, vqs::launch_layernorm(w.pre, pre_w, pre_b, w.hidden, 1, NS, hid, c.vis_ln_eps, st), "pre_layrnorm");
+    HIPCHK(h, vqs::launch_layernorm(w.pre, nullptr, pre_w, pre_b, w.hidden, 1, NS, hid, c.vis_ln_eps, st), "pre_layrnorm");
 
+    // Residual stream protocol: a sub-layer's output GEMM writes fp32 into `delta`; the NEXT norm kernel performs
+    // hidden += delta (written back) and normalises in the same pass.  `pend` is the not-yet-added delta.
+    const float* pend = nullptr;
     for (int i = 0; i < c.vis_layers_run; ++i) {
         const std::string p = "vision.encoder.layers." + std::to_string(i) + ".";
         GETW(ln1w, p + "layer_norm1.weight", hid);
@@ -435,7 +442,8 @@ int vqs_encode_images(vqs_handle* h, const void* d_pixels, int32_t N, void* d_fe
         GETW(f2w, p + "mlp.fc2.weight", (int64_t)hid * mlp);
         GETW(f2b, p + "mlp.fc2.bias", hid);
 
-        HIPCHK(h, vqs::launch_layernorm(w.hidden, ln1w, ln1b, w.xn, 0, NS, hid, c.vis_ln_eps, st), "layer_norm1");
+        HIPCHK(h, vqs::launch_layernorm(w.hidden, pend, ln1w, ln1b, w.xn, 0, NS, hid, c.vis_ln_eps, st), "layer_norm1");
+        pend = nullptr;
         {
             GemmCall g{w.xn, h->vit_qkv_w[i], nullptr};
             g.bias = h->vit_qkv_b[i];
@@ -449,12 +457,12 @@ int vqs_encode_images(vqs_handle* h, const void* d_pixels, int32_t N, void* d_fe
             HIPCHK(h, vqs::launch_attention(a, st), "vit attention");
         }
         {
-            GemmCall g{w.attn, ow, w.hidden};
-            g.bias = ob; g.resid = w.hidden;
-            g.M = NS; g.N = hid; g.K = hid; g.lda = hid; g.ldw = hid; g.ldc = hid; g.epi = vqs::EPI_F32_RESID;
+            GemmCall g{w.attn, ow, w.delta};
+            g.bias = ob;
+            g.M = NS; g.N = hid; g.K = hid; g.lda = hid; g.ldw = hid; g.ldc = hid; g.epi = vqs::EPI_F32;
             RUN(run_gemm(h, g, st, "vit out_proj"));
         }
-        HIPCHK(h, vqs::launch_layernorm(w.hidden, ln2w, ln2b, w.xn, 0, NS, hid, c.vis_ln_eps, st), "layer_norm2");
+        HIPCHK(h, vqs::launch_layernorm(w.hidden, w.delta, ln2w, ln2b, w.xn, 0, NS, hid, c.vis_ln_eps, st), "layer_norm2");
         {
             GemmCall g{w.xn, f1w, w.mid};
             g.bias = f1b;
@@ -462,13 +470,15 @@ int vqs_encode_images(vqs_handle* h, const void* d_pixels, int32_t N, void* d_fe
             RUN(run_gemm(h, g, st, "vit fc1"));
         }
         {
-            GemmCall g{w.mid, f2w, w.hidden};
-            g.bias = f2b; g.resid = w.hidden;
-            g.M = NS; g.N = hid; g.K = mlp; g.lda = mlp; g.ldw = mlp; g.ldc = hid; g.epi = vqs::EPI_F32_RESID;
+            GemmCall g{w.mid, f2w, w.delta};
+            g.bias = f2b;
+            g.M = NS; g.N = hid; g.K = mlp; g.lda = mlp; g.ldw = mlp; g.ldc = hid; g.epi = vqs::EPI_F32;
             RUN(run_gemm(h, g, st, "vit fc2"));
+            pend = w.delta;
         }
     }
-    HIPCHK(h, vqs::launch_drop_cls_cast(w.hidden, w.feat_in, N, P, hid, st), "feature select");
+    // hidden_states[-2][:, 1:] = hidden + pending fc2 output, CLS dropped, cast to the projector's operand type
+    HIPCHK(h, vqs::launch_drop_cls_cast(w.hidden, pend, w.feat_in, N, P, hid, st), "feature select");
     GETW(p0w, "mm_projector.0.weight", (int64_t)D * hid);
     GETW(p0b, "mm_projector.0.bias", D);
     GETW(p2w, "mm_projector.2.weight", (int64_t)D * D);
@@ -524,14 +534,16 @@ int vqs_score(vqs_handle* h, const void* d_feats, const int32_t* d_img_index, co
     HIPCHK(h, vqs::launch_embed_splice(d_input_ids, w.sent_pos, w.enc_len, d_img_index, shared, (const bf16_t*)d_feats,
                                        w.hidden, B, L, P, D, V, st), "embed_splice");
 
-    // ---------------- encoder
+    // ---------------- encoder (same pending-delta protocol as the vision tower)
+    const float* pend = nullptr;
     for (int i = 0; i < c.enc_layers; ++i) {
         const std::string p = "encoder.block." + std::to_string(i) + ".";
         GETW(ln0, p + "layer.0.layer_norm.weight", D);
         GETW(ow, p + "layer.0.SelfAttention.o.weight", (int64_t)D * I);
         GETW(ln1, p + "layer.1.layer_norm.weight", D);
         GETW(wo, p + "layer.1.DenseReluDense.wo.weight", (int64_t)D * F);
-        HIPCHK(h, vqs::launch_rmsnorm(w.hidden, ln0, w.xn, M, D, c.t5_ln_eps, st), "enc rmsnorm0");
+        HIPCHK(h, vqs::launch_rmsnorm(w.hidden, pend, ln0, w.xn, M, D, c.t5_ln_eps, st), "enc rmsnorm0");
+        pend = nullptr;
         {
             GemmCall g{w.xn, h->enc_qkv[i], nullptr};
             g.M = M; g.N = 3 * I; g.K = D; g.lda = D; g.ldw = D; g.ldc = 0; g.epi = vqs::EPI_HEADS;
@@ -544,31 +556,31 @@ int vqs_score(vqs_handle* h, const void* d_feats, const int32_t* d_img_index, co
             HIPCHK(h, vqs::launch_attention(a, st), "enc attention");
         }
         {
-            GemmCall g{w.attn, ow, w.hidden};
-            g.resid = w.hidden;
-            g.M = M; g.N = D; g.K = I; g.lda = I; g.ldw = I; g.ldc = D; g.epi = vqs::EPI_F32_RESID;
+            GemmCall g{w.attn, ow, w.delta};
+            g.M = M; g.N = D; g.K = I; g.lda = I; g.ldw = I; g.ldc = D; g.epi = vqs::EPI_F32;
             RUN(run_gemm(h, g, st, "enc o"));
         }
-        HIPCHK(h, vqs::launch_rmsnorm(w.hidden, ln1, w.xn, M, D, c.t5_ln_eps, st), "enc rmsnorm1");
+        HIPCHK(h, vqs::launch_rmsnorm(w.hidden, w.delta, ln1, w.xn, M, D, c.t5_ln_eps, st), "enc rmsnorm1");
         {
             GemmCall g{w.xn, h->enc_wi[i], w.ff};
             g.M = M; g.N = 2 * F; g.K = D; g.lda = D; g.ldw = D; g.ldc = F; g.epi = vqs::EPI_GATED;
             RUN(run_gemm(h, g, st, "enc wi"));
         }
         {
-            GemmCall g{w.ff, wo, w.hidden};
-            g.resid = w.hidden;
-            g.M = M; g.N = D; g.K = F; g.lda = F; g.ldw = F; g.ldc = D; g.epi = vqs::EPI_F32_RESID;
+            GemmCall g{w.ff, wo, w.delta};
+            g.M = M; g.N = D; g.K = F; g.lda = F; g.ldw = F; g.ldc = D; g.epi = vqs::EPI_F32;
             RUN(run_gemm(h, g, st, "enc wo"));
+            pend = w.delta;
         }
     }
     {
         GETW(fin, "encoder.final_layer_norm.weight", D);
-        HIPCHK(h, vqs::launch_rmsnorm(w.hidden, fin, w.enc_out, M, D, c.t5_ln_eps, st), "enc final norm");
+        HIPCHK(h, vqs::launch_rmsnorm(w.hidden, pend, fin, w.enc_out, M, D, c.t5_ln_eps, st), "enc final norm");
     }
 
     // ---------------- decoder (teacher forced, T rows per pair)
     HIPCHK(h, vqs::launch_decoder_embed(d_labels, shared, w.dhid, B, T, D, V, st), "decoder embed");
+    const float* dpend = nullptr;
     for (int i = 0; i < c.dec_layers; ++i) {
         const std::string p = "decoder.block." + std::to_string(i) + ".";
         GETW(ln0, p + "layer.0.layer_norm.weight", D);
@@ -579,7 +591,8 @@ int vqs_score(vqs_handle* h, const void* d_feats, const int32_t* d_img_index, co
         GETW(ln2, p + "layer.2.layer_norm.weight", D);
         GETW(wo, p + "layer.2.DenseReluDense.wo.weight", (int64_t)D * F);
 
-        HIPCHK(h, vqs::launch_rmsnorm(w.dhid, ln0, w.dxn, MT, D, c.t5_ln_eps, st), "dec rmsnorm0");
+        HIPCHK(h, vqs::launch_rmsnorm(w.dhid, dpend, ln0, w.dxn, MT, D, c.t5_ln_eps, st), "dec rmsnorm0");
+        dpend = nullptr;
         {
             GemmCall g{w.dxn, h->dec_qkv[i], w.dqkv};
             g.M = MT; g.N = 3 * I; g.K = D; g.lda = D; g.ldw = D; g.ldc = 3 * I; g.epi = vqs::EPI_BF16;
@@ -590,12 +603,11 @@ int vqs_score(vqs_handle* h, const void* d_feats, const int32_t* d_img_index, co
             HIPCHK(h, vqs::launch_decoder_attention(a, st), "dec self attention");
         }
         {
-            GemmCall g{w.dattn, so, w.dhid};
-            g.resid = w.dhid;
-            g.M = MT; g.N = D; g.K = I; g.lda = I; g.ldw = I; g.ldc = D; g.epi = vqs::EPI_F32_RESID;
+            GemmCall g{w.dattn, so, w.ddelta};
+            g.M = MT; g.N = D; g.K = I; g.lda = I; g.ldw = I; g.ldc = D; g.epi = vqs::EPI_F32;
             RUN(run_gemm(h, g, st, "dec self o"));
         }
-        HIPCHK(h, vqs::launch_rmsnorm(w.dhid, ln1, w.dxn, MT, D, c.t5_ln_eps, st), "dec rmsnorm1");
+        HIPCHK(h, vqs::launch_rmsnorm(w.dhid, w.ddelta, ln1, w.dxn, MT, D, c.t5_ln_eps, st), "dec rmsnorm1");
         {
             GemmCall g{w.dxn, cq, w.dq};
             g.M = MT; g.N = I; g.K = D; g.lda = D; g.ldw = D; g.ldc = I; g.epi = vqs::EPI_BF16;
@@ -613,28 +625,27 @@ int vqs_score(vqs_handle* h, const void* d_feats, const int32_t* d_img_index, co
             HIPCHK(h, vqs::launch_decoder_attention(a, st), "dec cross attention");
         }
         {
-            GemmCall g{w.dattn, co, w.dhid};
-            g.resid = w.dhid;
-            g.M = MT; g.N = D; g.K = I; g.lda = I; g.ldw = I; g.ldc = D; g.epi = vqs::EPI_F32_RESID;
+            GemmCall g{w.dattn, co, w.ddelta};
+            g.M = MT; g.N = D; g.K = I; g.lda = I; g.ldw = I; g.ldc = D; g.epi = vqs::EPI_F32;
             RUN(run_gemm(h, g, st, "dec cross o"));
         }
-        HIPCHK(h, vqs::launch_rmsnorm(w.dhid, ln2, w.dxn, MT, D, c.t5_ln_eps, st), "dec rmsnorm2");
+        HIPCHK(h, vqs::launch_rmsnorm(w.dhid, w.ddelta, ln2, w.dxn, MT, D, c.t5_ln_eps, st), "dec rmsnorm2");
         {
             GemmCall g{w.dxn, h->dec_wi[i], w.dff};
             g.M = MT; g.N = 2 * F; g.K = D; g.lda = D; g.ldw = D; g.ldc = F; g.epi = vqs::EPI_GATED;
             RUN(run_gemm(h, g, st, "dec wi"));
         }
         {
-            GemmCall g{w.dff, wo, w.dhid};
-            g.resid = w.dhid;
-            g.M = MT; g.N = D; g.K = F; g.lda = F; g.ldw = F; g.ldc = D; g.epi = vqs::EPI_F32_RESID;
+            GemmCall g{w.dff, wo, w.ddelta};
+            g.M = MT; g.N = D; g.K = F; g.lda = F; g.ldw = F; g.ldc = D; g.epi = vqs::EPI_F32;
             RUN(run_gemm(h, g, st, "dec wo"));
+            dpend = w.ddelta;
         }
     }
     {
         GETW(fin, "decoder.final_layer_norm.weight", D);
         GETW(head, "lm_head.weight", (int64_t)V * D);
-        HIPCHK(h, vqs::launch_rmsnorm(w.dhid, fin, w.dxn, MT, D, c.t5_ln_eps, st), "dec final norm");
+        HIPCHK(h, vqs::launch_rmsnorm(w.dhid, dpend, fin, w.dxn, MT, D, c.t5_ln_eps, st), "dec final norm");
         GemmCall g{w.dxn, head, w.logits};
         g.M = MT; g.N = V; g.K = D; g.lda = D; g.ldw = D; g.ldc = w.ldl; g.epi = vqs::EPI_F32;
         RUN(run_gemm(h, g, st, "lm_head"));
@@ -718,13 +729,13 @@ int vqs_decoder_attention(const void* q, const void* k, const void* v, void* out
     return vqs::launch_decoder_attention(a, (hipStream_t)stream) == hipSuccess ? VQS_OK : VQS_ERR_HIP;
 }
 
-int vqs_rmsnorm(const float* x, const void* w, void* out, int32_t M, int32_t D, float eps, void* stream) {
-    return vqs::launch_rmsnorm(x, (const bf16_t*)w, (bf16_t*)out, M, D, eps, (hipStream_t)stream) == hipSuccess ? VQS_OK : VQS_ERR_HIP;
+int vqs_rmsnorm(float* x, const float* delta, const void* w, void* out, int32_t M, int32_t D, float eps, void* stream) {
+    return vqs::launch_rmsnorm(x, delta, (const bf16_t*)w, (bf16_t*)out, M, D, eps, (hipStream_t)stream) == hipSuccess ? VQS_OK : VQS_ERR_HIP;
 }
 
-int vqs_layernorm(const float* x, const void* w, const void* b, void* out, int32_t out_f32, int32_t M, int32_t D, float eps,
-                  void* stream) {
-    return vqs::launch_layernorm(x, (const bf16_t*)w, (const bf16_t*)b, out, out_f32, M, D, eps, (hipStream_t)stream) == hipSuccess
+int vqs_layernorm(float* x, const float* delta, const void* w, const void* b, void* out, int32_t out_f32, int32_t M, int32_t D,
+                  float eps, void* stream) {
+    return vqs::launch_layernorm(x, delta, (const bf16_t*)w, (const bf16_t*)b, out, out_f32, M, D, eps, (hipStream_t)stream) == hipSuccess
                ? VQS_OK : VQS_ERR_HIP;
 }
 

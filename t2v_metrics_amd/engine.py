@@ -55,8 +55,8 @@ _SIGNATURES = {
     "vqs_gemm": (_c_i32, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp] + [_c_i32] * 10 + [_c_vp]),
     "vqs_attention": (_c_i32, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i32, _c_i32, _c_i32, _c_f32, _c_vp]),
     "vqs_decoder_attention": (_c_i32, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp] + [_c_i32] * 7 + [_c_vp]),
-    "vqs_rmsnorm": (_c_i32, [_c_vp, _c_vp, _c_vp, _c_i32, _c_i32, _c_f32, _c_vp]),
-    "vqs_layernorm": (_c_i32, [_c_vp, _c_vp, _c_vp, _c_vp, _c_i32, _c_i32, _c_i32, _c_f32, _c_vp]),
+    "vqs_rmsnorm": (_c_i32, [_c_vp, _c_vp, _c_vp, _c_vp, _c_i32, _c_i32, _c_f32, _c_vp]),
+    "vqs_layernorm": (_c_i32, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i32, _c_i32, _c_i32, _c_f32, _c_vp]),
     "vqs_score_head": (_c_i32, [_c_vp, _c_i32, _c_i32, _c_vp, _c_vp, _c_vp, _c_i32, _c_i32, _c_vp]),
     "vqs_relpos_bucket": (_c_i32, [_c_i32, _c_i32, _c_i32, _c_i32]),
 }
@@ -69,7 +69,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("VQS_LIB_PATH", LIB_PATH)    # VQS_LIB_PATH: lab builds (tools/gemm_lab.sh) only
     if not os.path.exists(p):
         raise VqsError(
             f"{p} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
@@ -294,22 +294,23 @@ def decoder_attention(q, k, v, B, H, T, S, ldq, ldk, cross: bool, bias_table=Non
     return out
 
 
-def rmsnorm(x, w, eps):
+def rmsnorm(x, w, eps, delta=None):
+    """out = rmsnorm(x [+ delta]) * w; with delta, x is updated in place (x += delta)."""
     lib = load_library()
     M, D = x.shape
     out = torch.empty(M, D, dtype=torch.bfloat16, device=x.device)
-    rc = lib.vqs_rmsnorm(x.data_ptr(), w.data_ptr(), out.data_ptr(), M, D, eps, _stream_ptr())
+    rc = lib.vqs_rmsnorm(x.data_ptr(), _ptr(delta), w.data_ptr(), out.data_ptr(), M, D, eps, _stream_ptr())
     if rc != 0:
         raise VqsError(f"vqs_rmsnorm failed ({rc})")
     return out
 
 
-def layernorm(x, w, b, eps, out_f32=False):
+def layernorm(x, w, b, eps, out_f32=False, delta=None):
     lib = load_library()
     M, D = x.shape
     out = torch.empty(M, D, dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
-    rc = lib.vqs_layernorm(x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), 1 if out_f32 else 0, M, D, eps,
-                           _stream_ptr())
+    rc = lib.vqs_layernorm(x.data_ptr(), _ptr(delta), w.data_ptr(), b.data_ptr(), out.data_ptr(), 1 if out_f32 else 0, M, D,
+                           eps, _stream_ptr())
     if rc != 0:
         raise VqsError(f"vqs_layernorm failed ({rc})")
     return out

@@ -156,8 +156,8 @@ def test_engine_matches_hf_golden_fixture(golden_dir):
     eng = VqsEngine(cfg, w, device="cuda:0")
     eng.encode_images(torch.from_numpy(g["pixels"]).to(torch.bfloat16).cuda())
     torch.cuda.synchronize()
-    hid = eng.stage("vit_hidden").float().cpu()
-    ref = torch.from_numpy(g["vit_hidden_m2"])
+    hid = eng.stage("vit_hidden").float().cpu()[:, 1:]      # patch rows (the CLS row of the last layer is not materialised)
+    ref = torch.from_numpy(g["vit_hidden_m2"])[:, 1:]
     err = (hid - ref).abs().max().item()
     assert err <= 0.15 + 0.03 * ref.abs().max().item(), err
     eng.close()

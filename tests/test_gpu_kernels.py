@@ -21,7 +21,7 @@ def eng():
 GEMM_SHAPES = [(256, 256, 64), (512, 768, 128), (300, 264, 192), (2065, 1024, 1024), (512, 1000, 256), (40, 64, 640)]
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
 def test_gemm_bf16_and_f32(eng, M, N, K, variant):
     A = randn_bf16(M, K, seed=1)
@@ -47,6 +47,25 @@ def test_gemm_bf16_and_f32(eng, M, N, K, variant):
     assert_close(buf, ref + bias.float() + resid, 2e-3, 1e-4, "gemm f32+resid in place")
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(5000, 768, 256, 0), (70000, 512, 128, 4), (33000, 1024, 64, 3), (9000, 640, 192, 1)])
+def test_gemm_persistent_many_tiles(eng, M, N, K, epi):
+    """More tiles than workgroups: the persistent kernel's cross-tile pipeline (prefetch of the next tile's first
+    K-tile, counted vmcnt behind the epilogue stores, edge tiles in the middle of a run) against variant 0, bitwise."""
+    A = randn_bf16(M, K, seed=31)
+    W = randn_bf16(N, K, seed=32, scale=K ** -0.5)
+    bias = randn_bf16(N, seed=33)
+    resid = torch.randn(M, N, device="cuda", generator=torch.Generator(device="cuda").manual_seed(34)) if epi == 4 else None
+    ref = eng.gemm(A, W, epi, bias=bias, resid=resid, variant=0)
+    for _ in range(3):
+        out = eng.gemm(A, W, epi, bias=bias, resid=resid, variant=3)
+        assert torch.equal(out, ref), describe(out, ref)
+
+
+def describe(out, ref):
+    from tests.gpu_util import describe_mismatch
+    return describe_mismatch(out, ref, 0.0, 0.0, "persistent vs variant 0")
+
+
 def test_gemm_transpose_detecting(eng):
     """A = I-like structure with an asymmetric W catches swapped C layouts."""
     M = N = K = 256
@@ -65,8 +84,9 @@ def test_gemm_gated(eng, M, F, K):
     w1 = randn_bf16(F, K, seed=7, scale=K ** -0.5)
     W = interleave_gate(w0, w1)
     ref = gelu_new(A.float() @ w0.float().t()) * (A.float() @ w1.float().t())
-    out = eng.gemm(A, W, 5)
-    assert_close(out, ref, 2e-2, 1e-2, f"gemm gated {M}x{F}x{K}")
+    for variant in (0, 2, 3):
+        out = eng.gemm(A, W, 5, variant=variant)
+        assert_close(out, ref, 2e-2, 1e-2, f"gemm gated {M}x{F}x{K} v{variant}")
 
 
 @pytest.mark.parametrize("B,S,H,K,nsel", [(2, 17, 2, 128, 3), (3, 100, 4, 256, 3), (2, 577, 2, 128, 2)])
@@ -76,8 +96,9 @@ def test_gemm_heads(eng, B, S, H, K, nsel):
     W = randn_bf16(nsel * I, K, seed=9, scale=K ** -0.5)
     bias = randn_bf16(nsel * I, seed=10)
     ref = (A.float() @ W.float().t() + bias.float()).reshape(B, S, nsel, H, 64).permute(2, 0, 3, 1, 4)
-    out = eng.gemm(A, W, 6, bias=bias, S=S, H=H)
-    assert_close(out, ref, 2e-2, 1e-2, "gemm heads")
+    for variant in (0, 2, 3):
+        out = eng.gemm(A, W, 6, bias=bias, S=S, H=H, variant=variant)
+        assert_close(out, ref, 2e-2, 1e-2, f"gemm heads v{variant}")
 
 
 @pytest.mark.parametrize("B,H,S,use_bias,ragged", [(1, 1, 64, False, False), (2, 2, 100, False, False),
@@ -152,6 +173,17 @@ def test_norms(eng, M, D):
     ref = torch.nn.functional.layer_norm(x, (D,), w.float(), b.float(), 1e-5)
     assert_close(eng.layernorm(x, w, b, 1e-5), ref, 1e-2, 1e-2, "layernorm bf16")
     assert_close(eng.layernorm(x, w, b, 1e-5, out_f32=True), ref, 1e-4, 1e-5, "layernorm f32")
+    # fused residual update: x += delta (in place) then normalise
+    delta = torch.randn(M, D, device="cuda", generator=torch.Generator(device="cuda").manual_seed(26))
+    xs = x + delta
+    x1 = x.clone()
+    out = eng.rmsnorm(x1, w, 1e-6, delta=delta)
+    assert_close(x1, xs, 1e-6, 1e-6, "rmsnorm residual write-back")
+    assert_close(out, w.float() * (xs * torch.rsqrt(xs.pow(2).mean(-1, keepdim=True) + 1e-6)), 1e-2, 1e-2, "rmsnorm+add")
+    x2 = x.clone()
+    out = eng.layernorm(x2, w, b, 1e-5, delta=delta)
+    assert_close(x2, xs, 1e-6, 1e-6, "layernorm residual write-back")
+    assert_close(out, torch.nn.functional.layer_norm(xs, (D,), w.float(), b.float(), 1e-5), 1e-2, 1e-2, "layernorm+add")
 
 
 def test_score_head(eng):

@@ -12,6 +12,7 @@ sys.path.insert(0, ROOT)
 from t2v_metrics_amd import engine  # noqa: E402
 
 OUT = os.path.join(ROOT, "gpurun_out", "microbench.jsonl")
+VARIANTS = tuple(int(x) for x in os.environ.get("VQS_BENCH_VARIANTS", "0,2").split(","))
 
 
 def timeit(fn, reps=8, warm=2):
@@ -40,13 +41,14 @@ def emit(rec):
 def main():
     dev = "cuda"
     quick = "--quick" in sys.argv
+    gemm_only = "--gemm-only" in sys.argv
     g = torch.Generator(device=dev).manual_seed(0)
     shapes = [  # (tag, M, N, K, epilogue)
-        ("vit_qkv", 147712, 3072, 1024, 0), ("vit_out", 147712, 1024, 1024, 4), ("vit_fc1", 147712, 4096, 1024, 1),
-        ("vit_fc2", 147712, 1024, 4096, 4), ("xl_qkv", 155648, 6144, 2048, 0), ("xl_o", 155648, 2048, 2048, 4),
-        ("xl_wi", 155648, 10240, 2048, 5), ("xl_wo", 155648, 2048, 5120, 4), ("xl_dec_skinny", 512, 6144, 2048, 0),
+        ("vit_qkv", 147712, 3072, 1024, 0), ("vit_out", 147712, 1024, 1024, 3), ("vit_fc1", 147712, 4096, 1024, 1),
+        ("vit_fc2", 147712, 1024, 4096, 3), ("xl_qkv", 155648, 6144, 2048, 6), ("xl_o", 155648, 2048, 2048, 3),
+        ("xl_wi", 155648, 10240, 2048, 5), ("xl_wo", 155648, 2048, 5120, 3), ("xl_dec_skinny", 512, 6144, 2048, 0),
         ("xl_lm_head", 512, 32128, 2048, 3), ("sq4096", 4096, 4096, 4096, 0), ("sq8192", 8192, 8192, 8192, 0),
-        ("xxl_wi", 38912, 20480, 4096, 5), ("xxl_wo", 38912, 4096, 10240, 4),
+        ("xxl_wi", 38912, 20480, 4096, 5), ("xxl_wo", 38912, 4096, 10240, 3),
     ]
     if quick:
         shapes = shapes[:2] + shapes[10:11]
@@ -54,13 +56,16 @@ def main():
         A = (torch.randn(M, K, device=dev, generator=g)).to(torch.bfloat16)
         W = (torch.randn(N, K, device=dev, generator=g) * K ** -0.5).to(torch.bfloat16)
         resid = torch.randn(M, N, device=dev, generator=g) if epi == 4 else None
-        for variant in (0, 1):
-            out = engine.gemm(A, W, epi, resid=resid, variant=variant)
-            med, best = timeit(lambda: engine.gemm(A, W, epi, resid=resid, out=out, variant=variant))
+        for variant in VARIANTS:
+            kw = dict(S=608, H=N // 192) if epi == 6 else {}
+            out = engine.gemm(A, W, epi, resid=resid, variant=variant, **kw)
+            med, best = timeit(lambda: engine.gemm(A, W, epi, resid=resid, out=out, variant=variant, **kw))
             fl = 2.0 * M * N * K
             emit({"kernel": "gemm", "tag": tag, "M": M, "N": N, "K": K, "epi": epi, "variant": variant, "ms": med,
                   "tflops": fl / med / 1e9, "tflops_best": fl / best / 1e9})
         del A, W, resid, out
+    if gemm_only:
+        return
     # a torch (hipBLASLt) cross-check number for context on two shapes
     for M, N, K in ((4096, 4096, 4096), (155648, 2048, 2048)):
         A = torch.randn(M, K, device=dev, generator=g).to(torch.bfloat16)
