@@ -150,7 +150,11 @@ def main():
         "config": {"workload": f"{cfg.name} bf16, batch={B} synthetic 224x224 + 32-tok prompts per GPU per step",
                    "pairs_per_gpu_per_step": B, "encoder_len": s_e, "decoder_len": T,
                    "parallelism": f"replica x{world} (pairs sharded, RCCL all_gather of scores)"},
+        # FLOPs of the REFERENCE algorithm (SURVEY.md §8d formula).  The engine's reassociated decoder
+        # cross-attention executes 4*S_e*D*I*layers fewer FLOPs per pair than that (same function);
+        # "roofline" below is computed from the FLOPs the GEMM kernel really executed.
         "algorithmic_tflop_per_pair": flops_pair / 1e12,
+        "executed_gemm_tflop_per_pair": (gemm_flops / max(total_pairs // world, 1)) / 1e12 if n_gemm > 0 else None,
         "model_tflops_per_gpu": value * flops_pair / 1e12 / world,
         "model_frac_of_mfma_peak": value * flops_pair / 1e12 / world / PEAK_BF16_TFLOPS,
     }

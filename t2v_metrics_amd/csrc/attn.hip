@@ -37,8 +37,12 @@ __device__ __forceinline__ bf16_t a_f2bf(float f) {
     u += 0x7fffu + ((u >> 16) & 1u);
     return (bf16_t)(u >> 16);
 }
-__device__ __forceinline__ uint32_t a_pack2(float a, float b) {
-    return (uint32_t)a_f2bf(a) | ((uint32_t)a_f2bf(b) << 16);
+typedef __attribute__((ext_vector_type(2))) __bf16 a_bf16x2;
+__device__ __forceinline__ uint32_t a_pack2(float a, float b) {   // v_cvt_pk_bf16_f32
+    a_bf16x2 v;
+    v[0] = (__bf16)a;
+    v[1] = (__bf16)b;
+    return __builtin_bit_cast(uint32_t, v);
 }
 
 static constexpr int KT = 64;            // keys per tile
@@ -46,6 +50,7 @@ static constexpr int VT_LD = 136;        // bytes per V^T row (64 keys * 2 B + 8
 static constexpr int K_LDS = KT * 128;   // 8192
 static constexpr int VT_LDS = 64 * VT_LD;  // 8704
 static constexpr float NEG_BIG = -1.0e30f;
+static constexpr float RESCALE_THR = 6.0f;    // log2 units
 
 template <bool HAS_BIAS>
 __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnParams p) {
@@ -67,10 +72,13 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnParams p) {
     const int klen = p.key_len ? min(p.key_len[b], S) : S;
     const int ntiles = (klen + KT - 1) / KT;
 
+    // softmax runs in the log2 domain (v_exp_f32 is 2^x): scores and bias are pre-multiplied by log2(e)
+    constexpr float LOG2E = 1.4426950408889634f;
     if (HAS_BIAS) {
         const float* bt = p.bias_table + (size_t)h * (2 * S - 1);
-        for (int i = tid; i < 2 * S - 1; i += 256) bias_s[i] = bt[i];
+        for (int i = tid; i < 2 * S + 64; i += 256) bias_s[i] = i < 2 * S - 1 ? bt[i] * LOG2E : 0.0f;
     }
+    const float sl2 = p.scale * LOG2E;
 
     const int qrow = blockIdx.x * 128 + wv * 32 + (lane & 31);
     const int qrow_c = min(qrow, S - 1);
@@ -124,6 +132,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnParams p) {
     const int k_rd = (lane & 31) * 128;
     const int vt_rd = (lane & 31) * VT_LD + 8 * hh;
 
+    // (a two-stage LDS ring with one barrier per tile was measured 15 % SLOWER than this: 410 -> 346 TFLOP/s)
     if (ntiles > 0) load_tile(0);
     for (int kt = 0; kt < ntiles; ++kt) {
         __syncthreads();                 // previous tile's LDS reads are done (also covers bias_s fill)
@@ -147,41 +156,50 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnParams p) {
             }
         }
 
-        // ---- scale + bias + mask, running max
+        // ---- scale + bias (+ mask on the ragged last tile), running max with deferred rescale
         const int kb = kt * KT;
-        float mx = NEG_BIG;
+        // element (kf, r) is key kb + kf*32 + (r&3) + 8*(r>>2) + 4*hh: table index = that - query + S-1
+        const float* bp = bias_s + (kb + 4 * hh - qrow_c + (S - 1));
 #pragma unroll
         for (int kf = 0; kf < 2; ++kf)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int key = kb + kf * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                float v = s[kf][r] * p.scale;
-                if (HAS_BIAS) {
-                    int idx = key - qrow_c + (S - 1);
-                    idx = min(max(idx, 0), 2 * S - 2);
-                    v += bias_s[idx];
-                }
-                if (key >= klen) v = NEG_BIG;
-                s[kf][r] = v;
-                mx = fmaxf(mx, v);
+                const float bv = HAS_BIAS ? bp[kf * 32 + (r & 3) + 8 * (r >> 2)] : 0.0f;
+                s[kf][r] = fmaf(s[kf][r], sl2, bv);
             }
+        if (kb + KT > klen) {                       // wave-uniform: only the last tile of a sample is ragged
+#pragma unroll
+            for (int kf = 0; kf < 2; ++kf)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kb + kf * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    if (key >= klen) s[kf][r] = NEG_BIG;
+                }
+        }
+        float mx = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s[0][r], s[1][r]));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __expf(m_run - m_new);
-        m_run = m_new;
-        l_run *= alpha;
+        // keep the old running max while the new one is at most 2^RESCALE_THR above it (P stays <= 2^THR, exact in
+        // fp32/bf16 range); rescale O and l only when some row's max really jumps
+        if (__any(mx > m_run + RESCALE_THR)) {
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int df = 0; df < 2; ++df)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[df][r] *= alpha;
+        }
 #pragma unroll
         for (int kf = 0; kf < 2; ++kf)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = __expf(s[kf][r] - m_new);
+                const float pv = __builtin_amdgcn_exp2f(s[kf][r] - m_run);
                 s[kf][r] = pv;
                 l_run += pv;
             }
-#pragma unroll
-        for (int df = 0; df < 2; ++df)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[df][r] *= alpha;
 
         // ---- O^T += V^T . P^T   (i <-> d, j <-> query, k-slot (half,j) <-> key 16t + 4*half + 8*(j>>2) + (j&3))
 #pragma unroll
@@ -225,7 +243,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnParams p) {
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
     if (p.B <= 0 || p.H <= 0 || p.S <= 0) return hipErrorInvalidValue;
     dim3 grid((p.S + 127) / 128, p.H, p.B), block(256);
-    size_t lds = K_LDS + VT_LDS + (p.bias_table ? (size_t)(2 * p.S - 1) * 4 : 0);
+    size_t lds = K_LDS + VT_LDS + (p.bias_table ? (size_t)(2 * p.S + 64) * 4 : 0);
     lds = (lds + 15) & ~(size_t)15;
     if (lds > 65536) return hipErrorInvalidValue;
     if (p.bias_table)
@@ -325,6 +343,7 @@ __global__ void __launch_bounds__(256) dec_attn_kernel(const DecAttnParams p) {
     float acc[DEC_TMAX];
 #pragma unroll
     for (int t = 0; t < DEC_TMAX; ++t) acc[t] = 0.0f;
+#pragma unroll 8
     for (int j = wv; j < S; j += 4) {
         const bf16_t* vrow = p.cross ? p.v + (((size_t)b * p.H + h) * S + j) * 64
                                      : p.v + ((size_t)b * T + j) * p.ldk + h * 64;

@@ -418,6 +418,78 @@ hipError_t launch_score_head(const float* logits, int ldl, int V, const int* lab
 }
 
 // ------------------------------------------------------------------------------------------------
+// Decoder cross-attention through the encoder output (see vqs_api.cpp "reassociated cross-attention"):
+//   enc_out [B,S,D] -> enc_outT [B,D,S_pad] (zero padded keys), once per call, shared by all decoder layers;
+//   masked softmax of the [B, rows, S_pad] fp32 scores into bf16 probabilities (0 for keys >= enc_len[b]).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) transpose_pad_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int S,
+                                                            int D, int S_pad) {
+    __shared__ bf16_t tile[64][66];
+    const int b = blockIdx.z, s0 = blockIdx.x * 64, d0 = blockIdx.y * 64;
+    const bf16_t* ib = in + (size_t)b * S * D;
+    bf16_t* ob = out + (size_t)b * D * S_pad;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;             // r: key within tile, c: feature
+        tile[r][c] = (s0 + r < S) ? ib[(size_t)(s0 + r) * D + d0 + c] : (bf16_t)0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;             // r: feature, c: key
+        ob[(size_t)(d0 + r) * S_pad + s0 + c] = tile[c][r];
+    }
+}
+
+hipError_t launch_transpose_pad(const bf16_t* in, bf16_t* out, int B, int S, int D, int S_pad, hipStream_t s) {
+    if ((D % 64) || (S_pad % 64) || S_pad < S) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(transpose_pad_kernel, dim3(S_pad / 64, D / 64, B), dim3(256), 0, s, in, out, S, D, S_pad);
+    return hipGetLastError();
+}
+
+// scores fp32 [B*rows, S_pad] -> probs bf16 [B*rows, S_pad]; one wave per row; keys >= key_len[b] get 0
+__global__ void __launch_bounds__(256) masked_softmax_kernel(const float* __restrict__ scores, bf16_t* __restrict__ probs,
+                                                             const int* __restrict__ key_len, int rows, int S_pad,
+                                                             int total_rows) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= total_rows) return;
+    const int klen = min(key_len[row / rows], S_pad);
+    const float* sr = scores + (size_t)row * S_pad;
+    bf16_t* pr = probs + (size_t)row * S_pad;
+    float mx = -3.0e38f;
+    for (int j = lane; j < klen; j += 64) mx = fmaxf(mx, sr[j]);
+    mx = wave_max(mx);
+    float sm = 0.0f;
+    for (int j = lane; j < klen; j += 64) sm += __expf(sr[j] - mx);
+    sm = wave_sum(sm);
+    const float inv = sm > 0.0f ? 1.0f / sm : 0.0f;
+    for (int j = lane; j < S_pad; j += 64) pr[j] = j < klen ? e_f2bf(__expf(sr[j] - mx) * inv) : (bf16_t)0;
+}
+
+hipError_t launch_masked_softmax(const float* scores, bf16_t* probs, const int* key_len, int B, int rows, int S_pad,
+                                 hipStream_t s) {
+    const int total = B * rows;
+    hipLaunchKernelGGL(masked_softmax_kernel, dim3((total + 3) / 4), dim3(256), 0, s, scores, probs, key_len, rows, S_pad,
+                       total);
+    return hipGetLastError();
+}
+
+// dst [cols, rows] = src [rows, cols]^T  (bind-time weight transpose; rows, cols multiples of 64)
+__global__ void __launch_bounds__(256) transpose_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int rows,
+                                                        int cols) {
+    __shared__ bf16_t tile[64][66];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) tile[i >> 6][i & 63] = in[(size_t)(r0 + (i >> 6)) * cols + c0 + (i & 63)];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) out[(size_t)(c0 + (i >> 6)) * rows + r0 + (i & 63)] = tile[i & 63][i >> 6];
+}
+
+hipError_t launch_transpose(const bf16_t* in, bf16_t* out, int rows, int cols, hipStream_t s) {
+    if ((rows % 64) || (cols % 64)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(transpose_kernel, dim3(cols / 64, rows / 64), dim3(256), 0, s, in, out, rows, cols);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // Bind-time weight packing
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) copy_rows_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,

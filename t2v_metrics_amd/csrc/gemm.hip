@@ -25,6 +25,9 @@
 #ifndef VQS_ABLATE
 #define VQS_ABLATE 0
 #endif
+#ifndef VQS_PRIO_SPLIT
+#define VQS_PRIO_SPLIT 1
+#endif
 
 namespace vqs {
 
@@ -403,14 +406,18 @@ __global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) 
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = w >> 2, wc = w & 3;
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
-    const int nwg = tiles_m * tiles_n;
+    const int tiles_pb = tiles_m * tiles_n;                 // tiles per batch entry
+    const int nbatch = p.batch > 0 ? p.batch : 1;
+    const int nwg = tiles_pb * nbatch;
     const int nt = p.K / BK;
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)LDS_PTR(lds));
 
-    auto tile_coords = [&](int pid, int& m0, int& n0) {
+    auto tile_coords = [&](int pid, int& m0, int& n0, int& bz) {
         const int xcd = pid & 7, local = pid >> 3;
         const int q = nwg >> 3, r = nwg & 7;
-        const int t_lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+        int t_lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+        bz = t_lin / tiles_pb;                              // batched GEMM: consecutive tiles stay in one batch entry
+        t_lin -= bz * tiles_pb;
         const int GM = 8;
         const int width = GM * tiles_n;
         const int group = t_lin / width;
@@ -424,12 +431,14 @@ __global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) 
     const int gchunk = (lane & 7) ^ sw;
     const bf16_t* pa[4];
     const bf16_t* pb[4];
-    auto set_ptrs = [&](int m0, int n0) {
+    auto set_ptrs = [&](int m0, int n0, int bz) {
+        const bf16_t* Ab = p.A + (size_t)bz * p.sA;
+        const bf16_t* Wb = p.W + (size_t)bz * p.sW;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = (i * 8 + w) * 8 + (lane >> 3);
-            pa[i] = p.A + (size_t)min(m0 + row, p.M - 1) * p.lda + gchunk * 8;
-            pb[i] = p.W + (size_t)min(n0 + row, p.N - 1) * p.ldw + gchunk * 8;
+            pa[i] = Ab + (size_t)min(m0 + row, p.M - 1) * p.lda + gchunk * 8;
+            pb[i] = Wb + (size_t)min(n0 + row, p.N - 1) * p.ldw + gchunk * 8;
         }
     };
     auto stage = [&](int s, int t) {
@@ -451,9 +460,9 @@ __global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) 
 
     int pid = blockIdx.x;
     if (pid >= nwg) return;
-    int m0, n0;
-    tile_coords(pid, m0, n0);
-    set_ptrs(m0, n0);
+    int m0, n0, bz;
+    tile_coords(pid, m0, n0, bz);
+    set_ptrs(m0, n0, bz);
     stage(0, 0);
 #if (VQS_ABLATE & 32)
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -473,7 +482,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) 
 
         const int next_pid = pid + gridDim.x;
         const bool has_next = next_pid < nwg;
-        int nm0 = 0, nn0 = 0;
+        int nm0 = 0, nn0 = 0, nbz = 0;
 
         for (int t = 0; t < nt; ++t) {
             TSTAMP(ts0);
@@ -496,8 +505,8 @@ __global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) 
                 kn = 0;
                 do_stage = has_next;
                 if (has_next) {
-                    tile_coords(next_pid, nm0, nn0);
-                    set_ptrs(nm0, nn0);
+                    tile_coords(next_pid, nm0, nn0, nbz);
+                    set_ptrs(nm0, nn0, nbz);
                 }
             }
             const size_t koffs = (size_t)kn * BK;
@@ -512,6 +521,13 @@ __global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) 
                 for (int m = 0; m < 4; ++m) af[m] = *reinterpret_cast<const uint4*>(sb + a_row + m * 4096 + koff[ks]);
 #pragma unroll
                 for (int n = 0; n < 2; ++n) wf[n] = *reinterpret_cast<const uint4*>(sb + b_row + n * 4096 + koff[ks]);
+#if VQS_PRIO_SPLIT
+                // the older wave of a SIMD wins issue arbitration all the time (measured: its 32 MFMAs take ~2000
+                // cycles, the younger wave's ~2600, and the older half then idles at the barrier): hand the
+                // younger half (waves 4-7) priority for the first two k-steps of every K-tile
+                if (ks == 0 && wr == 1) __builtin_amdgcn_s_setprio(1);
+                if (ks == 2 && wr == 1) __builtin_amdgcn_s_setprio(0);
+#endif
                 if (do_stage) {
                     glds16(pa[ks] + koffs, dst0 + ks * 8192);
                     glds16(pb[ks] + koffs, dst0 + ks * 8192 + W_OFF);
@@ -542,7 +558,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) 
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const int row = row_base + m * 32;
-                bf16_t* crow = reinterpret_cast<bf16_t*>(p.C) + (size_t)row * p.ldc;
+                bf16_t* crow = reinterpret_cast<bf16_t*>(p.C) + (size_t)bz * p.sC + (size_t)row * p.ldc;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int oc = oc_base + 8 * g;
@@ -636,7 +652,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) 
                             for (int e = 0; e < 4; ++e) o[e] = act_gelu_erf(o[e]);
                         }
                         if constexpr (EPI == EPI_F32 || EPI == EPI_F32_RESID) {
-                            float* cp = reinterpret_cast<float*>(p.C) + (size_t)row * p.ldc + c;
+                            float* cp = reinterpret_cast<float*>(p.C) + (size_t)bz * p.sC + (size_t)row * p.ldc + c;
                             if (ok) st16(cp, make_float4(o[0], o[1], o[2], o[3]));
                         } else {
                             uint2 v;
@@ -646,7 +662,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) 
                             if constexpr (EPI == EPI_HEADS) {
                                 dst = head_base + ((size_t)hb * p.H * p.S + hs) * 64 + (c - (n0 + wc * 64));
                             } else {
-                                dst = reinterpret_cast<bf16_t*>(p.C) + (size_t)row * p.ldc + c;
+                                dst = reinterpret_cast<bf16_t*>(p.C) + (size_t)bz * p.sC + (size_t)row * p.ldc + c;
                             }
                             if (ok) st8(dst, v);
                         }
@@ -662,6 +678,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) 
         pid = next_pid;
         m0 = nm0;
         n0 = nn0;
+        bz = nbz;
     }
 #if (VQS_ABLATE & 32)
     if (g_gemm_dbg != nullptr && lane == 0 && blockIdx.x < 64) {
@@ -687,7 +704,7 @@ static hipError_t launch_epi(const GemmParams& p, int variant, hipStream_t strea
             // spills); the engine's hot path uses EPI_F32 + a fused add in the following norm kernel instead
             hipLaunchKernelGGL((gemm_bf16_kernel<EPI, 0>), grid, block, 0, stream, p);
         } else {
-            const int nwg = tiles_m * tiles_n;
+            const int nwg = tiles_m * tiles_n * (p.batch > 0 ? p.batch : 1);
             dim3 pgrid(nwg < PERSISTENT_WGS ? nwg : PERSISTENT_WGS);
             hipLaunchKernelGGL((gemm_bf16_persistent<EPI>), pgrid, block, 0, stream, p);
         }
@@ -703,7 +720,10 @@ extern "C" int vqs_debug_set_gemm_timing(void* d_buf) {
 #endif
 
 hipError_t launch_gemm(const GemmParams& p, int epilogue, int variant, hipStream_t stream) {
-    if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K % BK) != 0 || (p.N % 8) != 0) return hipErrorInvalidValue;
+    // N: a lane stores 4 consecutive columns; fp32 output may have a ragged N if ldc leaves room for the overhang
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K % BK) != 0) return hipErrorInvalidValue;
+    if ((p.N % 8) != 0 && !(epilogue == EPI_F32 && p.ldc >= ((p.N + 3) & ~3) && p.bias == nullptr)) return hipErrorInvalidValue;
+    if (p.batch > 1 && (variant != 3 || epilogue == EPI_HEADS || epilogue == EPI_F32_RESID)) return hipErrorInvalidValue;
     if ((p.lda % 8) != 0 || (p.ldw % 8) != 0) return hipErrorInvalidValue;
     switch (epilogue) {
         case EPI_BF16: return launch_epi<EPI_BF16>(p, variant, stream);

@@ -35,7 +35,8 @@ struct vqs_handle {
     int P = 0, Sv = 0, kpatch = 0, kpad = 0, I = 0;
     // packed (device) weights
     const bf16_t* patch_w = nullptr;
-    std::vector<const bf16_t*> vit_qkv_w, vit_qkv_b, enc_qkv, enc_wi, dec_qkv, dec_ckv, dec_wi;
+    std::vector<const bf16_t*> vit_qkv_w, vit_qkv_b, enc_qkv, enc_wi, dec_qkv, dec_ckv, dec_wi, dec_ckT;
+    int cross_mode = 1;   // 1 = reassociated cross-attention (default), 0 = per-layer K|V projection of the encoder output
     const int* lut_bidir = nullptr;
     const int* lut_causal = nullptr;
     int lut_len = 0;
@@ -109,6 +110,9 @@ struct ScoreWs {
     bf16_t *xn, *q, *k, *v, *attn, *ff, *enc_out, *ck, *cv;
     float* dhid;
     bf16_t *dxn, *dqkv, *dattn, *dq, *dff;
+    bf16_t *enc_outT, *cqk, *cprobs, *cctx;
+    float* cscores;
+    int S_pad;
     float* logits;
     int ldl;
     size_t total;
@@ -145,6 +149,12 @@ ScoreWs carve_score(const vqs_handle* h, char* base, int B, int L, int T,
     w.dattn = cv.take<bf16_t>(MT * I);
     w.dq = cv.take<bf16_t>(MT * I);
     w.dff = cv.take<bf16_t>(MT * F);
+    w.S_pad = (S + 63) / 64 * 64;
+    w.enc_outT = cv.take<bf16_t>((size_t)B * D * w.S_pad);
+    w.cqk = cv.take<bf16_t>(MT * H * D);
+    w.cscores = cv.take<float>(MT * H * w.S_pad);
+    w.cprobs = cv.take<bf16_t>(MT * H * w.S_pad);
+    w.cctx = cv.take<bf16_t>(MT * H * D);
     w.ldl = c.vocab;
     w.logits = cv.take<float>(MT * w.ldl, "logits");
     w.total = align_up(cv.off);
@@ -153,7 +163,7 @@ ScoreWs carve_score(const vqs_handle* h, char* base, int B, int L, int T,
 
 struct PackedLayout {
     size_t patch_w;
-    std::vector<size_t> vit_qkv_w, vit_qkv_b, enc_qkv, enc_wi, dec_qkv, dec_ckv, dec_wi;
+    std::vector<size_t> vit_qkv_w, vit_qkv_b, enc_qkv, enc_wi, dec_qkv, dec_ckv, dec_wi, dec_ckT;
     size_t lut_bidir, lut_causal;
     size_t total;
 };
@@ -181,6 +191,7 @@ PackedLayout packed_layout(const vqs_handle* h) {
     for (int i = 0; i < c.dec_layers; ++i) {
         pl.dec_qkv.push_back(take(3 * I * D));
         pl.dec_ckv.push_back(take(2 * I * D));
+        pl.dec_ckT.push_back(take(I * D));
         pl.dec_wi.push_back(take(2 * F * D));
     }
     pl.lut_bidir = take(2 * (size_t)(c.rel_max_distance + 1));   // int32 = 2 bf16 slots each
@@ -224,6 +235,8 @@ struct GemmCall {
     int epi;
     int S = 0, H = 0, inner = 0;
     bf16_t* heads[3] = {nullptr, nullptr, nullptr};
+    int batch = 1;
+    long long sA = 0, sW = 0, sC = 0;
 };
 
 int run_gemm(vqs_handle* h, const GemmCall& g, hipStream_t st, const char* what) {
@@ -232,6 +245,7 @@ int run_gemm(vqs_handle* h, const GemmCall& g, hipStream_t st, const char* what)
     p.M = g.M; p.N = g.N; p.K = g.K; p.lda = g.lda; p.ldw = g.ldw; p.ldc = g.ldc;
     p.S = g.S > 0 ? g.S : 1; p.H = g.H; p.inner = g.inner > 0 ? g.inner : 1;
     p.heads_out[0] = g.heads[0]; p.heads_out[1] = g.heads[1]; p.heads_out[2] = g.heads[2];
+    p.batch = g.batch; p.sA = g.sA; p.sW = g.sW; p.sC = g.sC;
     if (h->prof) {
         while (h->ev.size() < h->ev_used + 2) {
             hipEvent_t e;
@@ -240,11 +254,11 @@ int run_gemm(vqs_handle* h, const GemmCall& g, hipStream_t st, const char* what)
         }
         HIPCHK(h, hipEventRecord(h->ev[h->ev_used], st), "hipEventRecord");
     }
-    HIPCHK(h, vqs::launch_gemm(p, g.epi, h->gemm_variant, st), std::string("gemm ") + what);
+    HIPCHK(h, vqs::launch_gemm(p, g.epi, g.batch > 1 ? 3 : h->gemm_variant, st), std::string("gemm ") + what);
     if (h->prof) {
         HIPCHK(h, hipEventRecord(h->ev[h->ev_used + 1], st), "hipEventRecord");
         h->ev_used += 2;
-        h->prof_flops += 2.0 * (double)g.M * (double)g.N * (double)g.K;
+        h->prof_flops += 2.0 * (double)g.M * (double)g.N * (double)g.K * (double)g.batch;
     }
     return VQS_OK;
 }
@@ -303,6 +317,7 @@ int vqs_create(const vqs_config* cfg, vqs_handle** out) {
         h->h_lut_bidir.push_back(vqs_relpos_bucket(-n, 1, c.rel_buckets, c.rel_max_distance));
         h->h_lut_causal.push_back(vqs_relpos_bucket(-n, 0, c.rel_buckets, c.rel_max_distance));
     }
+    if (const char* cm = std::getenv("VQS_CROSS_MODE")) h->cross_mode = std::atoi(cm);
     const char* v = std::getenv("VQS_GEMM_VARIANT");
     h->gemm_variant = v ? std::atoi(v) : 3;   // 3 = persistent kernel (gemm.hip)
     return VQS_OK;
@@ -368,7 +383,7 @@ int vqs_bind_weights(vqs_handle* h, const vqs_weight_desc* weights, int32_t n, v
         HIPCHK(h, vqs::launch_interleave_gate(w0, w1, dst, F, D, st), "pack wi");
         return VQS_OK;
     };
-    h->enc_qkv.clear(); h->enc_wi.clear(); h->dec_qkv.clear(); h->dec_ckv.clear(); h->dec_wi.clear();
+    h->enc_qkv.clear(); h->enc_wi.clear(); h->dec_qkv.clear(); h->dec_ckv.clear(); h->dec_wi.clear(); h->dec_ckT.clear();
     for (int i = 0; i < c.enc_layers; ++i) {
         const std::string p = "encoder.block." + std::to_string(i) + ".";
         RUN(pack_qkv(p + "layer.0.SelfAttention.", at(pl.enc_qkv[i]), 0, 3));
@@ -383,6 +398,11 @@ int vqs_bind_weights(vqs_handle* h, const vqs_weight_desc* weights, int32_t n, v
         RUN(pack_wi(p + "layer.2.DenseReluDense.", at(pl.dec_wi[i])));
         h->dec_qkv.push_back(at(pl.dec_qkv[i]));
         h->dec_ckv.push_back(at(pl.dec_ckv[i]));
+        {   // Wk^T [D, I] for the reassociated cross-attention: q'_h = q_h . Wk_h needs Wk_h^T K-contiguous
+            GETW(wk, p + "layer.1.EncDecAttention.k.weight", (int64_t)I * D);
+            HIPCHK(h, vqs::launch_transpose(wk, at(pl.dec_ckT[i]), I, D, st), "pack cross k^T");
+            h->dec_ckT.push_back(at(pl.dec_ckT[i]));
+        }
         h->dec_wi.push_back(at(pl.dec_wi[i]));
     }
     HIPCHK(h, hipMemcpyAsync(pk + pl.lut_bidir, h->h_lut_bidir.data(), h->lut_len * sizeof(int), hipMemcpyHostToDevice, st),
@@ -514,7 +534,7 @@ int vqs_score(vqs_handle* h, const void* d_feats, const int32_t* d_img_index, co
     const vqs_config& c = h->c;
     const int P = h->P, S = L - 1 + P;
     if (L - 1 > 2048) return fail(h, VQS_ERR_INVALID, "score: prompt longer than CONTEXT_LEN (2048)");
-    if ((size_t)(2 * S - 1) * 4 + 16896 + 16 > 65536) return fail(h, VQS_ERR_INVALID, "score: encoder length too large for the bias table");
+    if ((size_t)(2 * S + 64) * 4 + 16896 + 16 > 65536) return fail(h, VQS_ERR_INVALID, "score: encoder length too large for the bias table");
     const ScoreWs w = carve_score(h, (char*)d_ws, B, L, T);
     if (ws_bytes < w.total) return fail(h, VQS_ERR_WORKSPACE, "score: workspace too small");
     hipStream_t st = (hipStream_t)stream;
@@ -576,6 +596,8 @@ int vqs_score(vqs_handle* h, const void* d_feats, const int32_t* d_img_index, co
     {
         GETW(fin, "encoder.final_layer_norm.weight", D);
         HIPCHK(h, vqs::launch_rmsnorm(w.hidden, pend, fin, w.enc_out, M, D, c.t5_ln_eps, st), "enc final norm");
+        if (h->cross_mode != 0)
+            HIPCHK(h, vqs::launch_transpose_pad(w.enc_out, w.enc_outT, B, S, D, w.S_pad, st), "enc_out transpose");
     }
 
     // ---------------- decoder (teacher forced, T rows per pair)
@@ -613,16 +635,49 @@ int vqs_score(vqs_handle* h, const void* d_feats, const int32_t* d_img_index, co
             g.M = MT; g.N = I; g.K = D; g.lda = D; g.ldw = D; g.ldc = I; g.epi = vqs::EPI_BF16;
             RUN(run_gemm(h, g, st, "dec cross q"));
         }
-        {
-            GemmCall g{w.enc_out, h->dec_ckv[i], nullptr};
-            g.M = M; g.N = 2 * I; g.K = D; g.lda = D; g.ldw = D; g.ldc = 0; g.epi = vqs::EPI_HEADS;
-            g.S = S; g.H = H; g.inner = I;
-            g.heads[0] = w.ck; g.heads[1] = w.cv; g.heads[2] = nullptr;
-            RUN(run_gemm(h, g, st, "dec cross kv"));
-        }
-        {
+        if (h->cross_mode == 0) {
+            // direct form (what HF executes): K|V projection of the whole encoder output for this layer
+            {
+                GemmCall g{w.enc_out, h->dec_ckv[i], nullptr};
+                g.M = M; g.N = 2 * I; g.K = D; g.lda = D; g.ldw = D; g.ldc = 0; g.epi = vqs::EPI_HEADS;
+                g.S = S; g.H = H; g.inner = I;
+                g.heads[0] = w.ck; g.heads[1] = w.cv; g.heads[2] = nullptr;
+                RUN(run_gemm(h, g, st, "dec cross kv"));
+            }
             vqs::DecAttnParams a{w.dq, w.ck, w.cv, w.dattn, nullptr, w.enc_len, B, H, T, S, I, 0, 1};
             HIPCHK(h, vqs::launch_decoder_attention(a, st), "dec cross attention");
+        } else {
+            // Reassociated cross-attention.  With E = encoder output [S,D] and T (<=16) decoder rows per pair,
+            //   scores_h = q_h (E Wk_h^T)^T = (q_h Wk_h) E^T          and       out_h = P_h (E Wv_h^T) = (P_h E) Wv_h^T,
+            // so the per-layer [B*S, D] x [D, 2I] projection (4*S*D*I FLOPs per pair and layer, 98 % of the decoder)
+            // becomes five small batched GEMMs over E itself (~30x fewer FLOPs); same function, fp32 accumulation.
+            GETW(cv_w, p + "layer.1.EncDecAttention.v.weight", (int64_t)I * D);
+            const int R = T * H;        // rows per pair, ordered (t, h)
+            {   // q'[(b,t), h, :] = q[(b,t), h*64:(h+1)*64] . Wk_h            batched over heads
+                GemmCall g{w.dq, h->dec_ckT[i], w.cqk};
+                g.M = MT; g.N = D; g.K = 64; g.lda = I; g.ldw = I; g.ldc = H * D; g.epi = vqs::EPI_BF16;
+                g.batch = H; g.sA = 64; g.sW = 64; g.sC = D;
+                RUN(run_gemm(h, g, st, "cross q.Wk"));
+            }
+            {   // scores[b] [R, S] = q'[b] [R, D] . E[b]^T                      batched over pairs
+                GemmCall g{w.cqk, w.enc_out, w.cscores};
+                g.M = R; g.N = S; g.K = D; g.lda = D; g.ldw = D; g.ldc = w.S_pad; g.epi = vqs::EPI_F32;
+                g.batch = B; g.sA = (long long)R * D; g.sW = (long long)S * D; g.sC = (long long)R * w.S_pad;
+                RUN(run_gemm(h, g, st, "cross scores"));
+            }
+            HIPCHK(h, vqs::launch_masked_softmax(w.cscores, w.cprobs, w.enc_len, B, R, w.S_pad, st), "cross softmax");
+            {   // ctx[b] [R, D] = P[b] [R, S_pad] . E[b]  (E^T is K-contiguous)   batched over pairs
+                GemmCall g{w.cprobs, w.enc_outT, w.cctx};
+                g.M = R; g.N = D; g.K = w.S_pad; g.lda = w.S_pad; g.ldw = w.S_pad; g.ldc = D; g.epi = vqs::EPI_BF16;
+                g.batch = B; g.sA = (long long)R * w.S_pad; g.sW = (long long)D * w.S_pad; g.sC = (long long)R * D;
+                RUN(run_gemm(h, g, st, "cross P.E"));
+            }
+            {   // out[(b,t), h*64:(h+1)*64] = ctx[(b,t), h, :] . Wv_h^T          batched over heads
+                GemmCall g{w.cctx, cv_w, w.dattn};
+                g.M = MT; g.N = 64; g.K = D; g.lda = H * D; g.ldw = D; g.ldc = I; g.epi = vqs::EPI_BF16;
+                g.batch = H; g.sA = D; g.sW = (long long)64 * D; g.sC = 64;
+                RUN(run_gemm(h, g, st, "cross ctx.Wv"));
+            }
         }
         {
             GemmCall g{w.dattn, co, w.ddelta};

@@ -32,6 +32,9 @@ struct GemmParams {
     // EPI_HEADS
     int S, H, inner;
     bf16_t* heads_out[3];
+    // batched GEMM (persistent variant only): entry z uses A + z*sA, W + z*sW, C + z*sC (strides in elements)
+    int batch = 1;
+    long long sA = 0, sW = 0, sC = 0;
 };
 
 // variant 0 = direct-to-LDS (global_load_lds) staging; variant 1 = register-staged (debug / A-B)
@@ -95,6 +98,11 @@ hipError_t launch_relpos_table(const bf16_t* rel_weight, const int* bucket_lut_b
 // logits fp32 [B*T, ldl] -> label_logprobs [B,T] (0 where label == -100) and scores [B]
 hipError_t launch_score_head(const float* logits, int ldl, int V, const int* labels, float* label_logprobs,
                              float* scores, int B, int T, hipStream_t s);
+// reassociated decoder cross-attention helpers
+hipError_t launch_transpose_pad(const bf16_t* in, bf16_t* out, int B, int S, int D, int S_pad, hipStream_t s);
+hipError_t launch_masked_softmax(const float* scores, bf16_t* probs, const int* key_len, int B, int rows, int S_pad,
+                                 hipStream_t s);
+hipError_t launch_transpose(const bf16_t* in, bf16_t* out, int rows, int cols, hipStream_t s);
 // weight packing helpers (bind time)
 hipError_t launch_copy_rows(const bf16_t* src, bf16_t* dst, int rows, int cols, int src_ld, int dst_ld,
                             int dst_row_offset, hipStream_t s);   // dst[dst_row_offset + r, 0:cols] = src[r, 0:cols], zero pad to dst_ld

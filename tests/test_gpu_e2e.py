@@ -147,6 +147,29 @@ def test_low_sensitivity_regime_meets_1e3():
     eng.close()
 
 
+def test_reassociated_cross_attention_matches_direct_form(monkeypatch):
+    """VQS_CROSS_MODE=0 projects K|V of the encoder output per decoder layer (what HF executes); the default
+    reassociates ((q Wk) E^T, (P E) Wv^T).  Same function: both must agree with the oracle and with each other."""
+    from oracle.clip_t5_oracle import Oracle
+    from t2v_metrics_amd.engine import VqsEngine
+    cfg = get_config("small")
+    w = make_seeded_weights(cfg, seed=17, device="cpu", lm_head_gain=2.0)
+    pix, img_index, ids, labels = _inputs(cfg, 7, 3, 21, 3, seed=5)
+    ref = Oracle(cfg, w).forward(pix.float(), img_index, ids, labels)["label_logprobs"]
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("VQS_CROSS_MODE", mode)
+        eng = VqsEngine(cfg, w, device="cuda:0")
+        lp, _ = eng.score(eng.encode_images(pix.cuda()), img_index, ids, labels)
+        torch.cuda.synchronize()
+        out[mode] = lp.cpu()
+        eng.close()
+    d01 = (out["0"] - out["1"]).abs().max().item()
+    e0, e1 = (out["0"] - ref).abs().max().item(), (out["1"] - ref).abs().max().item()
+    _record("cross-mode", {"direct_vs_oracle": e0, "reassoc_vs_oracle": e1, "direct_vs_reassoc": d01})
+    assert e0 <= 2 * LOGPROB_TOL_BF16 and e1 <= 2 * LOGPROB_TOL_BF16 and d01 <= 2 * LOGPROB_TOL_BF16, (e0, e1, d01)
+
+
 def test_engine_matches_hf_golden_fixture(golden_dir):
     """The committed HF-module fixture (tests/golden/hf_tiny.npz): vision hidden_states[-2] from the HIP tower."""
     from t2v_metrics_amd.engine import VqsEngine

@@ -42,6 +42,10 @@ def main():
     dev = "cuda"
     quick = "--quick" in sys.argv
     gemm_only = "--gemm-only" in sys.argv
+    if "--no-gemm" in sys.argv:
+        shapes_skip = True
+    else:
+        shapes_skip = False
     g = torch.Generator(device=dev).manual_seed(0)
     shapes = [  # (tag, M, N, K, epilogue)
         ("vit_qkv", 147712, 3072, 1024, 0), ("vit_out", 147712, 1024, 1024, 3), ("vit_fc1", 147712, 4096, 1024, 1),
@@ -52,7 +56,7 @@ def main():
     ]
     if quick:
         shapes = shapes[:2] + shapes[10:11]
-    for tag, M, N, K, epi in shapes:
+    for tag, M, N, K, epi in ([] if shapes_skip else shapes):
         A = (torch.randn(M, K, device=dev, generator=g)).to(torch.bfloat16)
         W = (torch.randn(N, K, device=dev, generator=g) * K ** -0.5).to(torch.bfloat16)
         resid = torch.randn(M, N, device=dev, generator=g) if epi == 4 else None
@@ -67,7 +71,7 @@ def main():
     if gemm_only:
         return
     # a torch (hipBLASLt) cross-check number for context on two shapes
-    for M, N, K in ((4096, 4096, 4096), (155648, 2048, 2048)):
+    for M, N, K in (() if shapes_skip else ((4096, 4096, 4096), (155648, 2048, 2048))):
         A = torch.randn(M, K, device=dev, generator=g).to(torch.bfloat16)
         W = (torch.randn(N, K, device=dev, generator=g) * K ** -0.5).to(torch.bfloat16)
         med, best = timeit(lambda: torch.matmul(A, W.t()))
