@@ -160,7 +160,7 @@ def main():
     }
     if n_gemm > 0 and gemm_ms > 0:
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12
-        out["roofline"] = {"kernel": "vqs::gemm_bf16_kernel", "bound": "mfma", "achieved": achieved,
+        out["roofline"] = {"kernel": "vqs::gemm_bf16_persistent", "bound": "mfma", "achieved": achieved,
                            "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
                            "traffic": None, "launches": n_gemm, "avg_launch_ms": gemm_ms / n_gemm,
                            "gemm_share_of_step_time": gemm_ms * 1e-3 / elapsed}

@@ -688,6 +688,220 @@ __global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) 
 #endif
 }
 
+
+// =====================================================================================================
+// Wave-specialised persistent variant (VAR 4): 12 waves per workgroup.  Waves 0-7 are CONSUMERS (ds_read_b128 +
+// MFMA + epilogue, the same 2x4 layout and LDS image as above); waves 8-11 are LOADERS, one per SIMD, that issue all
+// 64 LDS-DMA pieces of a K-tile (16 each) and do nothing else.  Motivation (tools/gemm_lab.sh): an LDS-DMA costs
+// the issuing wave 75-200 cycles during which it cannot feed the matrix pipe; with the DMA removed from the MFMA
+// waves the same loop ran 26-30 % faster.  3 waves per SIMD => at most 168 VGPRs per wave.
+// One s_barrier per K-tile for everybody: loaders wait for their own DMA (vmcnt(0)) before it, consumers never wait
+// on VMEM at all (their epilogue stores just drain).
+// =====================================================================================================
+template <int EPI>
+__device__ __forceinline__ void ws_epilogue(const GemmParams& p, f32x16 (&acc)[4][2], int m0, int n0, int bz, int wr, int wc,
+                                            int lane) {
+    const int hhalf = lane >> 5;
+    const int row_base = m0 + wr * 128 + (lane & 31);
+    const int col_base = n0 + wc * 64 + 4 * hhalf;
+    const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
+    if constexpr (EPI == EPI_GATED) {
+        const int oc_base = ((n0 + wc * 64) >> 1) + 4 * hhalf;
+        const int NO = p.N >> 1;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int row = row_base + m * 32;
+            bf16_t* crow = reinterpret_cast<bf16_t*>(p.C) + (size_t)bz * p.sC + (size_t)row * p.ldc;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int oc = oc_base + 8 * g;
+                uint2 v;
+                v.x = pack2(act_gelu_new(acc[m][0][4 * g + 0]) * acc[m][1][4 * g + 0],
+                            act_gelu_new(acc[m][0][4 * g + 1]) * acc[m][1][4 * g + 1]);
+                v.y = pack2(act_gelu_new(acc[m][0][4 * g + 2]) * acc[m][1][4 * g + 2],
+                            act_gelu_new(acc[m][0][4 * g + 3]) * acc[m][1][4 * g + 3]);
+                if (full || (row < p.M && oc < NO)) *reinterpret_cast<uint2*>(crow + oc) = v;
+            }
+        }
+    } else {
+        bf16_t* head_base = nullptr;
+        if constexpr (EPI == EPI_HEADS) {
+            const int cw = min(n0 + wc * 64, p.N - 64);
+            const int which = cw / p.inner;
+            bf16_t* hp = which == 0 ? p.heads_out[0] : (which == 1 ? p.heads_out[1] : p.heads_out[2]);
+            head_base = hp + (size_t)((cw - which * p.inner) >> 6) * p.S * 64;
+        }
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = col_base + n * 32 + 8 * g;
+                float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+                if (p.bias != nullptr && c < p.N) {
+                    const uint2 bv = *reinterpret_cast<const uint2*>(p.bias + c);
+                    b0 = bf2f((bf16_t)(bv.x & 0xffff)); b1 = bf2f((bf16_t)(bv.x >> 16));
+                    b2 = bf2f((bf16_t)(bv.y & 0xffff)); b3 = bf2f((bf16_t)(bv.y >> 16));
+                }
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int row = row_base + m * 32;
+                    const bool ok = full || (row < p.M && c < p.N);
+                    float o0 = acc[m][n][4 * g + 0] + b0, o1 = acc[m][n][4 * g + 1] + b1;
+                    float o2 = acc[m][n][4 * g + 2] + b2, o3 = acc[m][n][4 * g + 3] + b3;
+                    if constexpr (EPI == EPI_BF16_QGELU) {
+                        o0 = act_quick_gelu(o0); o1 = act_quick_gelu(o1); o2 = act_quick_gelu(o2); o3 = act_quick_gelu(o3);
+                    }
+                    if constexpr (EPI == EPI_BF16_GELU) {
+                        o0 = act_gelu_erf(o0); o1 = act_gelu_erf(o1); o2 = act_gelu_erf(o2); o3 = act_gelu_erf(o3);
+                    }
+                    if constexpr (EPI == EPI_F32) {
+                        float* cp = reinterpret_cast<float*>(p.C) + (size_t)bz * p.sC + (size_t)row * p.ldc + c;
+                        if (ok) *reinterpret_cast<float4*>(cp) = make_float4(o0, o1, o2, o3);
+                    } else {
+                        uint2 v;
+                        v.x = pack2(o0, o1);
+                        v.y = pack2(o2, o3);
+                        bf16_t* dst;
+                        if constexpr (EPI == EPI_HEADS) {
+                            const int rowc = min(row, p.M - 1);
+                            const int hb = rowc / p.S, hs = rowc - hb * p.S;
+                            dst = head_base + ((size_t)hb * p.H * p.S + hs) * 64 + (c - (n0 + wc * 64));
+                        } else {
+                            dst = reinterpret_cast<bf16_t*>(p.C) + (size_t)bz * p.sC + (size_t)row * p.ldc + c;
+                        }
+                        if (ok) *reinterpret_cast<uint2*>(dst) = v;
+                    }
+                }
+            }
+    }
+}
+
+template <int EPI>
+__global__ void __launch_bounds__(768) gemm_bf16_ws(const GemmParams p) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * STAGE_BYTES];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    const int tiles_pb = tiles_m * tiles_n;
+    const int nwg = tiles_pb * (p.batch > 0 ? p.batch : 1);
+    const int nt = p.K / BK;
+
+    auto tile_coords = [&](int pid, int& m0, int& n0, int& bz) {
+        const int xcd = pid & 7, local = pid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        int t_lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+        bz = t_lin / tiles_pb;
+        t_lin -= bz * tiles_pb;
+        const int GM = 8;
+        const int width = GM * tiles_n;
+        const int group = t_lin / width;
+        const int first_m = group * GM;
+        const int gsz = min(tiles_m - first_m, GM);
+        m0 = (first_m + (t_lin % width) % gsz) * BM;
+        n0 = ((t_lin % width) / gsz) * BN;
+    };
+
+    int pid = blockIdx.x;
+    if (pid >= nwg) return;
+
+    if (w >= 8) {
+        // ------------------------------------------------------------------ loader wave j: pieces p = j, j+4, ...
+        const int j = w - 8;
+        __builtin_amdgcn_s_setprio(3);     // DMA issue must not queue behind the consumers' instruction stream
+        const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)LDS_PTR(lds));
+        const int gchunk = (lane & 7) ^ (((j & 1) << 2) + (lane >> 4));     // (row>>1)&7 of the rows this lane stages
+        const bf16_t* pa[8];
+        const bf16_t* pb[8];
+        auto set_ptrs = [&](int m0, int n0, int bz) {
+            const bf16_t* Ab = p.A + (size_t)bz * p.sA;
+            const bf16_t* Wb = p.W + (size_t)bz * p.sW;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int row = (j + 4 * q) * 8 + (lane >> 3);
+                pa[q] = Ab + (size_t)min(m0 + row, p.M - 1) * p.lda + gchunk * 8;
+                pb[q] = Wb + (size_t)min(n0 + row, p.N - 1) * p.ldw + gchunk * 8;
+            }
+        };
+        auto stage = [&](int s, int t) {
+            const uint32_t d0 = lds_base + s * STAGE_BYTES + j * 1024;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                glds16(pa[q] + (size_t)t * BK, d0 + q * 4096);
+                glds16(pb[q] + (size_t)t * BK, d0 + q * 4096 + W_OFF);
+            }
+        };
+        int m0, n0, bz;
+        tile_coords(pid, m0, n0, bz);
+        set_ptrs(m0, n0, bz);
+        stage(0, 0);
+        int buf = 0;
+        while (true) {
+            const int next_pid = pid + gridDim.x;
+            const bool has_next = next_pid < nwg;
+            for (int t = 0; t < nt; ++t) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (t + 1 < nt) {
+                    stage(buf ^ 1, t + 1);
+                } else if (has_next) {
+                    tile_coords(next_pid, m0, n0, bz);
+                    set_ptrs(m0, n0, bz);
+                    stage(buf ^ 1, 0);
+                }
+                buf ^= 1;
+            }
+            if (!has_next) break;
+            pid = next_pid;
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumer waves
+    const int wr = w >> 2, wc = w & 3;
+    const int swr = (lane >> 1) & 7;
+    int koff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) koff[ks] = (((ks * 2 + (lane >> 5)) ^ swr) << 4);
+    const int a_row = (wr * 128 + (lane & 31)) * 128;
+    const int b_row = W_OFF + (wc * 64 + (lane & 31)) * 128;
+    int buf = 0;
+    while (true) {
+        int m0, n0, bz;
+        tile_coords(pid, m0, n0, bz);
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+        for (int t = 0; t < nt; ++t) {
+            __builtin_amdgcn_s_barrier();
+            const char* sb = lds + buf * STAGE_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                uint4 af[4], wf[2];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) af[m] = *reinterpret_cast<const uint4*>(sb + a_row + m * 4096 + koff[ks]);
+#pragma unroll
+                for (int n = 0; n < 2; ++n) wf[n] = *reinterpret_cast<const uint4*>(sb + b_row + n * 4096 + koff[ks]);
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8, wf[n]), __builtin_bit_cast(bf16x8, af[m]), acc[m][n], 0, 0, 0);
+            }
+            buf ^= 1;
+        }
+        ws_epilogue<EPI>(p, acc, m0, n0, bz, wr, wc, lane);
+        const int next_pid = pid + gridDim.x;
+        if (next_pid >= nwg) break;
+        pid = next_pid;
+    }
+}
+
 template <int EPI>
 static hipError_t launch_epi(const GemmParams& p, int variant, hipStream_t stream) {
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
@@ -698,7 +912,13 @@ static hipError_t launch_epi(const GemmParams& p, int variant, hipStream_t strea
         hipLaunchKernelGGL((gemm_bf16_kernel<EPI, 1>), grid, block, 0, stream, p);
     else if (variant == 2)
         hipLaunchKernelGGL((gemm_bf16_kernel<EPI, 2>), grid, block, 0, stream, p);
-    else {
+    else if (variant == 4 && EPI != EPI_F32_RESID) {
+        if constexpr (EPI != EPI_F32_RESID) {
+            const int nwg = tiles_m * tiles_n * (p.batch > 0 ? p.batch : 1);
+            dim3 pgrid(nwg < PERSISTENT_WGS ? nwg : PERSISTENT_WGS);
+            hipLaunchKernelGGL((gemm_bf16_ws<EPI>), pgrid, dim3(768), 0, stream, p);
+        }
+    } else {
         if constexpr (EPI == EPI_F32_RESID) {
             // the in-epilogue fp32 read-modify-write does not fit the persistent kernel's register budget (it
             // spills); the engine's hot path uses EPI_F32 + a fused add in the following norm kernel instead
@@ -723,7 +943,7 @@ hipError_t launch_gemm(const GemmParams& p, int epilogue, int variant, hipStream
     // N: a lane stores 4 consecutive columns; fp32 output may have a ragged N if ldc leaves room for the overhang
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K % BK) != 0) return hipErrorInvalidValue;
     if ((p.N % 8) != 0 && !(epilogue == EPI_F32 && p.ldc >= ((p.N + 3) & ~3) && p.bias == nullptr)) return hipErrorInvalidValue;
-    if (p.batch > 1 && (variant != 3 || epilogue == EPI_HEADS || epilogue == EPI_F32_RESID)) return hipErrorInvalidValue;
+    if (p.batch > 1 && ((variant != 3 && variant != 4) || epilogue == EPI_HEADS || epilogue == EPI_F32_RESID)) return hipErrorInvalidValue;
     if ((p.lda % 8) != 0 || (p.ldw % 8) != 0) return hipErrorInvalidValue;
     switch (epilogue) {
         case EPI_BF16: return launch_epi<EPI_BF16>(p, variant, stream);
