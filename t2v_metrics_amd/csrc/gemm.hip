@@ -394,8 +394,160 @@ __device__ unsigned long long* g_gemm_dbg = nullptr;   // [blocks][8 waves][8 co
 #define TACC(slot, a, b)
 #endif
 
+
+// ----------------------------------------------------------------------------------------------------
+// Staged epilogue: accumulators -> (bias / activation / gate) -> wave-private 8-KiB LDS region -> row-contiguous
+// 16-B-per-lane global stores.  `reg` is this wave's region inside an LDS stage nobody reads any more.
+//   bf16 outputs : two passes of 64 rows x 128 B (one row = the wave's 64 columns);   gated: 64 rows x 64 B
+//   fp32 outputs : four passes of 32 rows x 256 B
+// LDS image: 16-B chunk index XOR-ed with the row (conflict-free b128 reads, <= 2-way writes).
+// ----------------------------------------------------------------------------------------------------
 template <int EPI>
-struct EpiStores { static constexpr int value = (EPI == EPI_GATED) ? 16 : 32; };   // VMEM stores per wave, full tile
+__device__ __forceinline__ void staged_epilogue(const GemmParams& p, f32x16 (&acc)[4][2], char* reg, int m0, int n0, int bz,
+                                                int wr, int wc, int lane, bool full) {
+    const int hh = lane >> 5, lr = lane & 31;
+    const int row_w = m0 + wr * 128;                 // first row of this wave's tile
+    const int col_w = n0 + wc * 64;                  // first column
+    if constexpr (EPI == EPI_GATED) {
+        const int NO = p.N >> 1;
+        const int ocol_w = col_w >> 1;               // 32 output columns per wave
+#pragma unroll
+        for (int hm = 0; hm < 2; ++hm) {
+#pragma unroll
+            for (int m2 = 0; m2 < 2; ++m2) {
+                const int m = 2 * hm + m2;
+                const int r = m2 * 32 + lr;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint2 v;
+                    v.x = pack2(act_gelu_new(acc[m][0][4 * g + 0]) * acc[m][1][4 * g + 0],
+                                act_gelu_new(acc[m][0][4 * g + 1]) * acc[m][1][4 * g + 1]);
+                    v.y = pack2(act_gelu_new(acc[m][0][4 * g + 2]) * acc[m][1][4 * g + 2],
+                                act_gelu_new(acc[m][0][4 * g + 3]) * acc[m][1][4 * g + 3]);
+                    *reinterpret_cast<uint2*>(reg + r * 64 + ((g ^ ((r >> 1) & 3)) << 4) + hh * 8) = v;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                     // 16 rows x 64 B per instruction
+                const int r = q * 16 + (lane >> 2), c = lane & 3;
+                const uint4 v = *reinterpret_cast<const uint4*>(reg + r * 64 + ((c ^ ((r >> 1) & 3)) << 4));
+                const int row = row_w + hm * 64 + r, oc = ocol_w + c * 8;
+                if (full || (row < p.M && oc < NO))
+                    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)bz * p.sC + (size_t)row * p.ldc + oc) = v;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    } else {
+        // bias of this lane's 2 x 4 column quads
+        float bia[2][4][4];
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = col_w + n * 32 + 8 * g + 4 * hh;
+                if (p.bias != nullptr && c < p.N) {
+                    const uint2 bv = *reinterpret_cast<const uint2*>(p.bias + c);
+                    bia[n][g][0] = bf2f((bf16_t)(bv.x & 0xffff));
+                    bia[n][g][1] = bf2f((bf16_t)(bv.x >> 16));
+                    bia[n][g][2] = bf2f((bf16_t)(bv.y & 0xffff));
+                    bia[n][g][3] = bf2f((bf16_t)(bv.y >> 16));
+                } else {
+                    bia[n][g][0] = bia[n][g][1] = bia[n][g][2] = bia[n][g][3] = 0.0f;
+                }
+            }
+        if constexpr (EPI == EPI_F32 || EPI == EPI_F32_RESID) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {                     // 32 rows x 256 B per pass
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int ch = n * 8 + 2 * g + hh;    // 16-B chunk (4 fp32) within the 256-B row
+                        const float4 v = make_float4(acc[m][n][4 * g + 0] + bia[n][g][0], acc[m][n][4 * g + 1] + bia[n][g][1],
+                                                     acc[m][n][4 * g + 2] + bia[n][g][2], acc[m][n][4 * g + 3] + bia[n][g][3]);
+                        *reinterpret_cast<float4*>(reg + lr * 256 + ((ch ^ (lr & 15)) << 4)) = v;
+                    }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {                 // 4 rows x 256 B per instruction
+                    const int r = q * 4 + (lane >> 4), c = lane & 15;
+                    float4 v = *reinterpret_cast<const float4*>(reg + r * 256 + ((c ^ (r & 15)) << 4));
+                    const int row = row_w + m * 32 + r, col = col_w + c * 4;
+                    if (full || (row < p.M && col < p.N)) {
+                        const size_t off = (size_t)bz * p.sC + (size_t)row * p.ldc + col;
+                        if constexpr (EPI == EPI_F32_RESID) {
+                            const float4 rv = *reinterpret_cast<const float4*>(p.resid + off);
+                            v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                        }
+                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + off) = v;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        } else {
+            bf16_t* head_base = nullptr;
+            if constexpr (EPI == EPI_HEADS) {
+                const int cw = min(col_w, p.N - 64);
+                const int which = cw / p.inner;
+                bf16_t* hp = which == 0 ? p.heads_out[0] : (which == 1 ? p.heads_out[1] : p.heads_out[2]);
+                head_base = hp + (size_t)((cw - which * p.inner) >> 6) * p.S * 64;
+            }
+#pragma unroll
+            for (int hm = 0; hm < 2; ++hm) {                  // 64 rows x 128 B per pass
+#pragma unroll
+                for (int m2 = 0; m2 < 2; ++m2) {
+                    const int m = 2 * hm + m2;
+                    const int r = m2 * 32 + lr;
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            float o[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = acc[m][n][4 * g + e] + bia[n][g][e];
+                            if constexpr (EPI == EPI_BF16_QGELU) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) o[e] = act_quick_gelu(o[e]);
+                            }
+                            if constexpr (EPI == EPI_BF16_GELU) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) o[e] = act_gelu_erf(o[e]);
+                            }
+                            uint2 v;
+                            v.x = pack2(o[0], o[1]);
+                            v.y = pack2(o[2], o[3]);
+                            const int ch = n * 4 + g;         // 16-B chunk (8 bf16) within the 128-B row; hh picks its half
+                            *reinterpret_cast<uint2*>(reg + r * 128 + ((ch ^ (r & 7)) << 4) + hh * 8) = v;
+                        }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {                 // 8 rows x 128 B per instruction
+                    const int r = q * 8 + (lane >> 3), c = lane & 7;
+                    const uint4 v = *reinterpret_cast<const uint4*>(reg + r * 128 + ((c ^ (r & 7)) << 4));
+                    const int row = row_w + hm * 64 + r, col = col_w + c * 8;
+                    if (full || (row < p.M && col < p.N)) {
+                        bf16_t* dst;
+                        if constexpr (EPI == EPI_HEADS) {
+                            const int hb = row / p.S, hs = row - hb * p.S;
+                            dst = head_base + ((size_t)hb * p.H * p.S + hs) * 64 + c * 8;
+                        } else {
+                            dst = reinterpret_cast<bf16_t*>(p.C) + (size_t)bz * p.sC + (size_t)row * p.ldc + col;
+                        }
+                        *reinterpret_cast<uint4*>(dst) = v;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        }
+    }
+}
+
+template <int EPI>
+struct EpiStores {   // VMEM store instructions per wave for a full tile (staged epilogue): 16-B per lane each
+    static constexpr int value = (EPI == EPI_GATED) ? 8 : ((EPI == EPI_F32 || EPI == EPI_F32_RESID) ? 32 : 16);
+};
 
 template <int EPI>
 __global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) {
@@ -456,7 +608,6 @@ __global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) 
     for (int ks = 0; ks < 4; ++ks) koff[ks] = (((ks * 2 + (lane >> 5)) ^ swr) << 4);
     const int a_row = (wr * 128 + (lane & 31)) * 128;
     const int b_row = W_OFF + (wc * 64 + (lane & 31)) * 128;
-    const int hhalf = lane >> 5;
 
     int pid = blockIdx.x;
     if (pid >= nwg) return;
@@ -487,7 +638,8 @@ __global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) 
         for (int t = 0; t < nt; ++t) {
             TSTAMP(ts0);
             if (t == 0 && counted) {
-                if constexpr (EpiStores<EPI>::value == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                if constexpr (EpiStores<EPI>::value == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if constexpr (EpiStores<EPI>::value == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -547,129 +699,12 @@ __global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) 
         }
         TSTAMP(te0);
 
-        // ---------------- epilogue (same math as the non-persistent kernel; stores via st8/st16)
-        const int row_base = m0 + wr * 128 + (lane & 31);
-        const int col_base = n0 + wc * 64 + 4 * hhalf;
+        // ---------------- epilogue: C tile staged through the LDS stage that was just consumed, stored as whole rows.
+        // (Storing straight from the accumulator layout touches 32 rows x 16 B per instruction and measured 10-20 K
+        // cycles per tile; staged, every store instruction writes 8 full 128-B rows / 4 full 256-B rows.)
         const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
-
-        if constexpr (EPI == EPI_GATED) {
-            const int oc_base = ((n0 + wc * 64) >> 1) + 4 * hhalf;
-            const int NO = p.N >> 1;
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const int row = row_base + m * 32;
-                bf16_t* crow = reinterpret_cast<bf16_t*>(p.C) + (size_t)bz * p.sC + (size_t)row * p.ldc;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int oc = oc_base + 8 * g;
-                    float o[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = act_gelu_new(acc[m][0][4 * g + e]) * acc[m][1][4 * g + e];
-                    uint2 v;
-                    v.x = pack2(o[0], o[1]);
-                    v.y = pack2(o[2], o[3]);
-                    if (full || (row < p.M && oc < NO)) st8(crow + oc, v);
-                }
-            }
-        } else {
-            float bia[2][4][4];
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int c = col_base + n * 32 + 8 * g;
-                    if (p.bias != nullptr && c < p.N) {
-                        const uint2 bv = *reinterpret_cast<const uint2*>(p.bias + c);
-                        bia[n][g][0] = bf2f((bf16_t)(bv.x & 0xffff));
-                        bia[n][g][1] = bf2f((bf16_t)(bv.x >> 16));
-                        bia[n][g][2] = bf2f((bf16_t)(bv.y & 0xffff));
-                        bia[n][g][3] = bf2f((bf16_t)(bv.y >> 16));
-                    } else {
-                        bia[n][g][0] = bia[n][g][1] = bia[n][g][2] = bia[n][g][3] = 0.0f;
-                    }
-                }
-            bf16_t* head_base = nullptr;
-            if constexpr (EPI == EPI_HEADS) {
-                const int cw = min(n0 + wc * 64, p.N - 64);
-                const int which = cw / p.inner;
-                bf16_t* hp = which == 0 ? p.heads_out[0] : (which == 1 ? p.heads_out[1] : p.heads_out[2]);
-                head_base = hp + (size_t)((cw - which * p.inner) >> 6) * p.S * 64;
-            }
-            // fp32 residual: all 32 float4 loads of this lane are issued (two row blocks in flight) and added into
-            // the accumulators BEFORE any store, so no load is ever queued behind a fresh store on the in-order
-            // VMEM counter; the stores then go out back to back and drain under the next tile.
-            if constexpr (EPI == EPI_F32_RESID) {
-                float4 rv[2][4];            // two half-row-blocks (q = 2*m + n) in flight
-                auto load_resid = [&](int q, float4 (&dst)[4]) {
-                    const int rowc = min(row_base + (q >> 1) * 32, p.M - 1);
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int c = min(col_base + (q & 1) * 32 + 8 * g, p.N - 4);
-                        dst[g] = *reinterpret_cast<const float4*>(p.resid + (size_t)rowc * p.ldc + c);
-                    }
-                };
-                load_resid(0, rv[0]);
-                load_resid(1, rv[1]);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const float4 r4 = rv[q & 1][g];
-                        acc[q >> 1][q & 1][4 * g + 0] += r4.x;
-                        acc[q >> 1][q & 1][4 * g + 1] += r4.y;
-                        acc[q >> 1][q & 1][4 * g + 2] += r4.z;
-                        acc[q >> 1][q & 1][4 * g + 3] += r4.w;
-                    }
-                    if (q + 2 < 8) load_resid(q + 2, rv[q & 1]);
-                    __builtin_amdgcn_sched_barrier(0);     // keep at most two half-blocks of loads in flight (VGPRs)
-                }
-            }
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const int row = row_base + m * 32;
-                const int rowc = min(row, p.M - 1);
-                int hb = 0, hs = 0;
-                if constexpr (EPI == EPI_HEADS) {
-                    hb = rowc / p.S;
-                    hs = rowc - hb * p.S;
-                }
-#pragma unroll
-                for (int n = 0; n < 2; ++n) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int c = col_base + n * 32 + 8 * g;
-                        const bool ok = full || (row < p.M && c < p.N);
-                        float o[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = acc[m][n][4 * g + e] + bia[n][g][e];
-                        if constexpr (EPI == EPI_BF16_QGELU) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) o[e] = act_quick_gelu(o[e]);
-                        }
-                        if constexpr (EPI == EPI_BF16_GELU) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) o[e] = act_gelu_erf(o[e]);
-                        }
-                        if constexpr (EPI == EPI_F32 || EPI == EPI_F32_RESID) {
-                            float* cp = reinterpret_cast<float*>(p.C) + (size_t)bz * p.sC + (size_t)row * p.ldc + c;
-                            if (ok) st16(cp, make_float4(o[0], o[1], o[2], o[3]));
-                        } else {
-                            uint2 v;
-                            v.x = pack2(o[0], o[1]);
-                            v.y = pack2(o[2], o[3]);
-                            bf16_t* dst;
-                            if constexpr (EPI == EPI_HEADS) {
-                                dst = head_base + ((size_t)hb * p.H * p.S + hs) * 64 + (c - (n0 + wc * 64));
-                            } else {
-                                dst = reinterpret_cast<bf16_t*>(p.C) + (size_t)bz * p.sC + (size_t)row * p.ldc + c;
-                            }
-                            if (ok) st8(dst, v);
-                        }
-                    }
-                }
-            }
-        }
+        __builtin_amdgcn_s_barrier();                       // every wave is done reading stage buf^1
+        staged_epilogue<EPI>(p, acc, lds + (buf ^ 1) * STAGE_BYTES + w * 8192, m0, n0, bz, wr, wc, lane, full);
         counted = full;
 #if (VQS_ABLATE & 32)
         { TSTAMP(te1); TACC(4, te0, te1); tacc[6] += 1; }
