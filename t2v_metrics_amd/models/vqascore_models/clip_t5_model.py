@@ -57,7 +57,7 @@ class CLIPT5Model(VQAScoreModel):
 
     def __init__(self, model_name='clip-flant5-xxl', device='cuda', cache_dir=HF_CACHE_DIR, *, weights=None,
                  tokenizer=None, checkpoint: Optional[str] = None, config=None, max_pairs: int = 256,
-                 max_images: int = 256, seed: int = 0, engine=None):
+                 max_images: int = 256, seed: int = 0, engine=None, num_workers: Optional[int] = None):
         """
         weights:    None -> load ``checkpoint`` (a local HF directory of safetensors); 'seeded' -> seeded random
                     weights at the exact architecture (benchmarks, tests); or a dict name -> tensor.
@@ -65,11 +65,16 @@ class CLIPT5Model(VQAScoreModel):
                     the checkpoint directory (the reference uses ``AutoTokenizer(use_fast=False)``, mm_utils.py:198).
         config:     a ClipT5Config overriding the registry entry (tests use the tiny configurations).
         engine:     an already constructed engine-like object (tests inject a recording fake).
+        num_workers: threads that decode + preprocess images (PIL releases the GIL); None -> min(32, cpu count).
+                    The reference does this serially inside forward(); at ~450 pairs/s the
+                    GPU would otherwise wait on PNG/JPEG decode.
         """
         assert config is not None or model_name in CLIP_T5_MODELS
         self._weights_arg, self._tokenizer_arg, self._checkpoint = weights, tokenizer, checkpoint
         self._cfg = config if config is not None else get_config(CLIP_T5_MODELS[model_name]['config'])
         self._seed, self._engine_arg = seed, engine
+        self.num_workers = min(32, os.cpu_count() or 1) if num_workers is None else max(1, int(num_workers))
+        self._pool = None
         self.max_pairs, self.max_images = int(max_pairs), int(max_images)
         self.context_len = CONTEXT_LEN
         self.image_aspect_ratio = 'pad'          # mm_utils.py:188,235
@@ -122,10 +127,30 @@ class CLIPT5Model(VQAScoreModel):
         return sd
 
     # ------------------------------------------------------------------ host-side preparation
+    def _executor(self):
+        if self._pool is None and self.num_workers > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=self.num_workers, thread_name_prefix="vqs-img")
+        return self._pool
+
+    def _preprocess_one(self, path) -> torch.Tensor:
+        from ...preprocess import clip_preprocess
+        img = self.image_loader(path)
+        return torch.from_numpy(clip_preprocess(img, self.cfg.vision.image, self.image_aspect_ratio == 'pad'))
+
+    def _load_images_host(self, image: List[str]) -> torch.Tensor:
+        """Decode + pad to square + CLIP-preprocess on the host (thread pool) -> fp32 [N,3,S,S]."""
+        S = self.cfg.vision.image
+        out = torch.empty(len(image), 3, S, S, dtype=torch.float32)
+        pool = self._executor()
+        results = pool.map(self._preprocess_one, image) if pool is not None else map(self._preprocess_one, image)
+        for i, t in enumerate(results):
+            out[i] = t
+        return out
+
     def load_images(self, image: List[str]) -> torch.Tensor:
         """Decode + pad to square + CLIP-preprocess; returns bf16 [N,3,S,S] on the device."""
-        imgs = [self.image_loader(x) for x in image]
-        px = preprocess_batch(imgs, self.cfg.vision.image, pad_to_square=(self.image_aspect_ratio == 'pad'))
+        px = self._load_images_host(image)
         if str(self.device).startswith('cuda') and torch.cuda.is_available():
             return px.pin_memory().to(self.device, non_blocking=True).to(torch.bfloat16)
         return px.to(torch.bfloat16)
@@ -158,9 +183,18 @@ class CLIPT5Model(VQAScoreModel):
         """Score pairs (images[pair_image[k]], questions[k], answers[k]).  Unique images are encoded once."""
         n = len(questions)
         assert len(answers) == n and len(pair_image) == n
+        # image chunks: the next chunk is decoded/preprocessed by the pool while the engine encodes the current one
+        chunks = [list(images[s: s + self.max_images]) for s in range(0, len(images), self.max_images)]
         feats_chunks = []
-        for s in range(0, len(images), self.max_images):
-            feats_chunks.append(self.engine.encode_images(self.load_images(list(images[s: s + self.max_images]))))
+        pool = self._executor()
+        pending = pool.submit(self.load_images, chunks[0]) if (pool is not None and len(chunks) > 1) else None
+        for ci, chunk in enumerate(chunks):
+            if pending is not None:
+                px = pending.result()
+                pending = pool.submit(self.load_images, chunks[ci + 1]) if ci + 1 < len(chunks) else None
+            else:
+                px = self.load_images(chunk)
+            feats_chunks.append(self.engine.encode_images(px))
         feats = feats_chunks[0] if len(feats_chunks) == 1 else torch.cat(feats_chunks, 0)
         ids, lab = self.tokenize(questions, answers)
         idx = torch.as_tensor(list(pair_image), dtype=torch.int32)

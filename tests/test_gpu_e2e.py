@@ -222,3 +222,38 @@ def test_missing_weight_and_bad_prompt_are_reported():
     torch.cuda.synchronize()
     assert int(eng.stage("flags")[0]) == 1
     eng.close()
+
+
+def test_drop_in_api_4x4_grid_on_gpu(tmp_path):
+    """BASELINE.json configs[0] shape (4 images x 4 prompts through VQAScore.forward) on the HIP engine, against the
+    same host pipeline driving the CPU oracle; plus the reference's own smoke assertions (test.py:106-144)."""
+    import numpy as np
+    from PIL import Image
+    import t2v_metrics_amd as t2v
+    from tests.test_host_api import FakeTokenizer, OracleEngine
+    cfg = get_config("small")
+    w = make_seeded_weights(cfg, seed=29, device="cpu")
+    rng = np.random.RandomState(4)
+    paths = []
+    for i, (h, wd) in enumerate([(256, 256), (300, 200), (120, 180), (64, 64)]):
+        p = tmp_path / f"img{i}.png"
+        Image.fromarray(rng.randint(0, 256, (h, wd, 3), dtype=np.uint8)).save(p)
+        paths.append(str(p))
+    texts = ["someone talks on the phone angrily while another person sits happily",
+             "someone talks on the phone happily while another person sits angrily",
+             "a photo of an astronaut riding a horse", "a dog"]
+    tok = FakeTokenizer(cfg.t5.vocab)
+    hip = t2v.VQAScore(model="clip-flant5-xl", device="cuda", cache_dir=str(tmp_path / "c1"), config=cfg, weights=w, tokenizer=tok)
+    ref = t2v.VQAScore(model="clip-flant5-xl", device="cpu", cache_dir=str(tmp_path / "c2"), config=cfg, tokenizer=tok,
+                       engine=OracleEngine(cfg, w))
+    s_hip = hip(images=paths, texts=texts)
+    s_ref = ref(images=paths, texts=texts)
+    assert s_hip.shape == (4, 4) and s_hip.device.type == "cuda" and s_hip.dtype == torch.float32
+    assert ((s_hip >= 0) & (s_hip <= 1)).all()
+    rel = ((s_hip.cpu() - s_ref.cpu()).abs() / s_ref.cpu()).max().item()
+    _record("api-4x4", {"max_rel_score_err": rel})
+    assert rel <= 2 * LOGPROB_TOL_BF16, rel          # d(score)/score = d(mean log-prob)
+    one = hip(images=paths[0], texts=texts[0])
+    assert one.shape == (1, 1) and abs(one.item() - s_hip[0, 0].item()) <= 1e-6
+    bf = hip.batch_forward([{"images": paths[:2], "texts": texts[:2]}, {"images": paths[2:], "texts": texts[2:]}], batch_size=2)
+    assert bf.shape == (2, 2, 2) and torch.allclose(bf[0].cpu(), s_hip[:2, :2].cpu(), atol=1e-6)

@@ -243,3 +243,15 @@ def test_full_host_pipeline_against_oracle(tmp_path, images):
             ref = Oracle(cfg, w).forward(px[i: i + 1], torch.tensor([0]), torch.tensor([ids]), torch.tensor([lab]))
             assert abs(ref["scores"][0].item() - out[i, j].item()) < 1e-5 * max(1.0, out[i, j].item())
     assert ((out >= 0) & (out <= 1)).all()                     # the reference's own smoke assertion (test.py:110-112)
+
+
+def test_threaded_image_pipeline_matches_serial(tmp_path, images):
+    """Thread-pool decode/preprocess and chunk prefetch give the same tensors and scores as the serial path."""
+    s1, e1 = make_scorer(tmp_path, num_workers=1, max_images=2)
+    s8, e8 = make_scorer(tmp_path, num_workers=8, max_images=2)
+    a = s1.model.load_images(images)
+    b = s8.model.load_images(images)
+    assert torch.equal(a, b)
+    texts = ["x", "y z"]
+    assert torch.equal(s1(images=images, texts=texts), s8(images=images, texts=texts))
+    assert e8.encode_calls == [(2, 3, 56, 56), (2, 3, 56, 56)] == e1.encode_calls      # 4 images in chunks of max_images
