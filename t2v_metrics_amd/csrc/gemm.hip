@@ -28,6 +28,9 @@
 #ifndef VQS_PRIO_SPLIT
 #define VQS_PRIO_SPLIT 1
 #endif
+#ifndef VQS_DMA_SPLIT
+#define VQS_DMA_SPLIT 0   // 0: two pieces per k-step before the MFMAs (default); 1: halves of the K-tile by wave row; 2: staggered among the MFMAs by wave column -- all measured equal within 2 %
+#endif
 
 namespace vqs {
 
@@ -680,10 +683,36 @@ __global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) 
                 if (ks == 0 && wr == 1) __builtin_amdgcn_s_setprio(1);
                 if (ks == 2 && wr == 1) __builtin_amdgcn_s_setprio(0);
 #endif
+#if VQS_DMA_SPLIT == 2
+                // DMA issue staggered over the CU: wave column wc issues its A piece after its wc-th MFMA of this
+                // k-step and its W piece after the (wc+4)-th, so LDS-DMA requests reach the texture addresser one
+                // at a time instead of in 16-deep bursts (a queued DMA blocks the issuing wave, not just the TA)
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8, wf[n]), __builtin_bit_cast(bf16x8, af[m]), acc[m][n], 0, 0, 0);
+                        const int idx = m * 2 + n;
+                        if (do_stage && idx == wc && !(VQS_ABLATE & 128)) glds16(pa[ks] + koffs, dst0 + ks * 8192);
+                        if (do_stage && idx == wc + 4 && !(VQS_ABLATE & 64)) glds16(pb[ks] + koffs, dst0 + ks * 8192 + W_OFF);
+                    }
+            }
+#else
+#if VQS_DMA_SPLIT == 1
+                if (do_stage && (ks >> 1) == wr) {
+                    const int i0 = (ks & 1) * 2;
+                    glds16(pa[i0] + koffs, dst0 + i0 * 8192);
+                    glds16(pb[i0] + koffs, dst0 + i0 * 8192 + W_OFF);
+                    glds16(pa[i0 + 1] + koffs, dst0 + (i0 + 1) * 8192);
+                    glds16(pb[i0 + 1] + koffs, dst0 + (i0 + 1) * 8192 + W_OFF);
+                }
+#else
                 if (do_stage) {
                     glds16(pa[ks] + koffs, dst0 + ks * 8192);
                     glds16(pb[ks] + koffs, dst0 + ks * 8192 + W_OFF);
                 }
+#endif
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -691,6 +720,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) 
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                             __builtin_bit_cast(bf16x8, wf[n]), __builtin_bit_cast(bf16x8, af[m]), acc[m][n], 0, 0, 0);
             }
+#endif
             buf ^= 1;
 #if (VQS_ABLATE & 32)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
