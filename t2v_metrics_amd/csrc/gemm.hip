@@ -28,6 +28,9 @@
 #ifndef VQS_PRIO_SPLIT
 #define VQS_PRIO_SPLIT 1
 #endif
+#ifndef VQS_DMA_BUFFER
+#define VQS_DMA_BUFFER 1
+#endif
 #ifndef VQS_DMA_SPLIT
 #define VQS_DMA_SPLIT 0   // 0: two pieces per k-step before the MFMAs (default); 1: halves of the K-tile by wave row; 2: staggered among the MFMAs by wave column -- all measured equal within 2 %
 #endif
@@ -552,6 +555,30 @@ struct EpiStores {   // VMEM store instructions per wave for a full tile (staged
     static constexpr int value = (EPI == EPI_GATED) ? 8 : ((EPI == EPI_F32 || EPI == EPI_F32_RESID) ? 32 : 16);
 };
 
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+// MUBUF form of the LDS-DMA: SGPR descriptor + SGPR byte offset (the K-tile) + one 32-bit VGPR offset per lane, so the
+// per-lane address never has to be recomputed or moved as 64 bits.
+__device__ __forceinline__ void bglds16(v4i_t rsrc, uint32_t voff, uint32_t soff, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %2, %4 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(rsrc), "s"(lds_dst), "s"(__builtin_amdgcn_readfirstlane(soff)));
+}
+__device__ __forceinline__ v4i_t make_rsrc(const void* base) {
+    const uint64_t b = (uint64_t)base;
+    v4i_t r;
+    r.x = __builtin_amdgcn_readfirstlane((uint32_t)b);
+    r.y = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32) & 0xffffu);
+    r.z = (int)0xffffffffu;
+    r.w = 0x00020000;
+    return r;
+}
+
 template <int EPI>
 __global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) {
     __shared__ __attribute__((aligned(16))) char lds[2 * STAGE_BYTES];
@@ -584,6 +611,22 @@ __global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) 
 
     const int sw = ((w & 1) << 2) + (lane >> 4);
     const int gchunk = (lane & 7) ^ sw;
+#if VQS_DMA_BUFFER
+    uint32_t pa[4], pb[4];          // byte offsets from the batch entry's base (every operand is < 4 GiB)
+    v4i_t rsA, rsW;
+    auto set_ptrs = [&](int m0, int n0, int bz) {
+        rsA = make_rsrc(p.A + (size_t)bz * p.sA);
+        rsW = make_rsrc(p.W + (size_t)bz * p.sW);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (i * 8 + w) * 8 + (lane >> 3);
+            pa[i] = (uint32_t)(((size_t)min(m0 + row, p.M - 1) * p.lda + gchunk * 8) * 2);
+            pb[i] = (uint32_t)(((size_t)min(n0 + row, p.N - 1) * p.ldw + gchunk * 8) * 2);
+        }
+    };
+#define PGLDS_A(i, koffs, dst) bglds16(rsA, pa[i], (uint32_t)((koffs) * 2), (dst))
+#define PGLDS_W(i, koffs, dst) bglds16(rsW, pb[i], (uint32_t)((koffs) * 2), (dst))
+#else
     const bf16_t* pa[4];
     const bf16_t* pb[4];
     auto set_ptrs = [&](int m0, int n0, int bz) {
@@ -596,12 +639,15 @@ __global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) 
             pb[i] = Wb + (size_t)min(n0 + row, p.N - 1) * p.ldw + gchunk * 8;
         }
     };
+#define PGLDS_A(i, koffs, dst) glds16(pa[i] + (koffs), (dst))
+#define PGLDS_W(i, koffs, dst) glds16(pb[i] + (koffs), (dst))
+#endif
     auto stage = [&](int s, int t) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint32_t da = lds_base + s * STAGE_BYTES + (i * 8 + w) * 1024;
-            glds16(pa[i] + (size_t)t * BK, da);
-            glds16(pb[i] + (size_t)t * BK, da + W_OFF);
+            PGLDS_A(i, (size_t)t * BK, da);
+            PGLDS_W(i, (size_t)t * BK, da + W_OFF);
         }
     };
 
@@ -694,23 +740,23 @@ __global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) 
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                             __builtin_bit_cast(bf16x8, wf[n]), __builtin_bit_cast(bf16x8, af[m]), acc[m][n], 0, 0, 0);
                         const int idx = m * 2 + n;
-                        if (do_stage && idx == wc && !(VQS_ABLATE & 128)) glds16(pa[ks] + koffs, dst0 + ks * 8192);
-                        if (do_stage && idx == wc + 4 && !(VQS_ABLATE & 64)) glds16(pb[ks] + koffs, dst0 + ks * 8192 + W_OFF);
+                        if (do_stage && idx == wc && !(VQS_ABLATE & 128)) PGLDS_A(ks, koffs, dst0 + ks * 8192);
+                        if (do_stage && idx == wc + 4 && !(VQS_ABLATE & 64)) PGLDS_W(ks, koffs, dst0 + ks * 8192 + W_OFF);
                     }
             }
 #else
 #if VQS_DMA_SPLIT == 1
                 if (do_stage && (ks >> 1) == wr) {
                     const int i0 = (ks & 1) * 2;
-                    glds16(pa[i0] + koffs, dst0 + i0 * 8192);
-                    glds16(pb[i0] + koffs, dst0 + i0 * 8192 + W_OFF);
-                    glds16(pa[i0 + 1] + koffs, dst0 + (i0 + 1) * 8192);
-                    glds16(pb[i0 + 1] + koffs, dst0 + (i0 + 1) * 8192 + W_OFF);
+                    PGLDS_A(i0, koffs, dst0 + i0 * 8192);
+                    PGLDS_W(i0, koffs, dst0 + i0 * 8192 + W_OFF);
+                    PGLDS_A(i0 + 1, koffs, dst0 + (i0 + 1) * 8192);
+                    PGLDS_W(i0 + 1, koffs, dst0 + (i0 + 1) * 8192 + W_OFF);
                 }
 #else
                 if (do_stage) {
-                    glds16(pa[ks] + koffs, dst0 + ks * 8192);
-                    glds16(pb[ks] + koffs, dst0 + ks * 8192 + W_OFF);
+                    PGLDS_A(ks, koffs, dst0 + ks * 8192);
+                    PGLDS_W(ks, koffs, dst0 + ks * 8192 + W_OFF);
                 }
 #endif
 #pragma unroll
@@ -753,6 +799,9 @@ __global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) 
 #endif
 }
 
+
+#undef PGLDS_A
+#undef PGLDS_W
 
 // =====================================================================================================
 // Wave-specialised persistent variant (VAR 4): 12 waves per workgroup.  Waves 0-7 are CONSUMERS (ds_read_b128 +
