@@ -45,12 +45,25 @@ __device__ __forceinline__ uint32_t a_pack2(float a, float b) {   // v_cvt_pk_bf
     return __builtin_bit_cast(uint32_t, v);
 }
 
+// v_max3_f32 without the IEEE-mode operand canonicalisation (v_max_f32 x, x) that fmaxf() costs per input:
+// the scores are finite by construction (masking uses NEG_BIG, not -inf)
+__device__ __forceinline__ float a_max3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 static constexpr int KT = 64;            // keys per tile
 static constexpr int VT_LD = 136;        // bytes per V^T row (64 keys * 2 B + 8 B pad)
 static constexpr int K_LDS = KT * 128;   // 8192
 static constexpr int VT_LDS = 64 * VT_LD;  // 8704
 static constexpr float NEG_BIG = -1.0e30f;
 static constexpr float RESCALE_THR = 6.0f;    // log2 units
+
+__host__ __device__ __forceinline__ int bias_copy_chunks(int S) {
+    const int need = (2 * S + 64 + 3 + 3) / 4;              // entries 0 .. 2S+66 are addressable
+    return need + ((4 - (need & 15)) & 15);                  // round up to = 4 (mod 16)
+}
 
 template <bool HAS_BIAS>
 __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnParams p) {
@@ -74,9 +87,16 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnParams p) {
 
     // softmax runs in the log2 domain (v_exp_f32 is 2^x): scores and bias are pre-multiplied by log2(e)
     constexpr float LOG2E = 1.4426950408889634f;
+    // Four copies of the head's bias table, copy c shifted left by c entries, so that the 4 consecutive entries a lane
+    // needs (table index = key - query + S-1, any alignment) are one 16-B aligned ds_read_b128 in copy (index & 3).
+    // Copy stride = 4 (mod 16) chunks: the four copies of a chunk land on four different 16-B bank slots.
+    const int bias_cs = bias_copy_chunks(S);      // 16-B chunks per copy
     if (HAS_BIAS) {
         const float* bt = p.bias_table + (size_t)h * (2 * S - 1);
-        for (int i = tid; i < 2 * S + 64; i += 256) bias_s[i] = i < 2 * S - 1 ? bt[i] * LOG2E : 0.0f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            for (int j = tid; j < bias_cs * 4; j += 256)
+                bias_s[c * bias_cs * 4 + j] = (j + c) < 2 * S - 1 ? bt[j + c] * LOG2E : 0.0f;
     }
     const float sl2 = p.scale * LOG2E;
 
@@ -129,6 +149,8 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnParams p) {
     float m_run = NEG_BIG, l_run = 0.0f;
 
     const int swr = (lane >> 1) & 7;
+    const int jb = 4 * hh - qrow_c + (S - 1);                 // table index of (key kb + 0, this lane's query), kb = 0
+    const char* bias_rd = reinterpret_cast<const char*>(bias_s) + (jb & 3) * bias_cs * 16 + (jb & ~3) * 4;
     const int k_rd = (lane & 31) * 128;
     const int vt_rd = (lane & 31) * VT_LD + 8 * hh;
 
@@ -146,27 +168,42 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnParams p) {
         for (int kf = 0; kf < 2; ++kf)
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[kf][r] = 0.0f;
+        {
+            uint4 kfr[4][2];                 // all 8 fragments in flight before the first MFMA
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+            for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int kf = 0; kf < 2; ++kf) {
-                const uint4 kfr = *reinterpret_cast<const uint4*>(k_lds + kf * 4096 + k_rd + (((2 * ks + hh) ^ swr) << 4));
-                s[kf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kfr),
-                                                                __builtin_bit_cast(bf16x8, qf[ks]), s[kf], 0, 0, 0);
-            }
+                for (int kf = 0; kf < 2; ++kf)
+                    kfr[ks][kf] = *reinterpret_cast<const uint4*>(k_lds + kf * 4096 + k_rd + (((2 * ks + hh) ^ swr) << 4));
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int kf = 0; kf < 2; ++kf)
+                    s[kf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kfr[ks][kf]),
+                                                                    __builtin_bit_cast(bf16x8, qf[ks]), s[kf], 0, 0, 0);
         }
 
         // ---- scale + bias (+ mask on the ragged last tile), running max with deferred rescale
         const int kb = kt * KT;
         // element (kf, r) is key kb + kf*32 + (r&3) + 8*(r>>2) + 4*hh: table index = that - query + S-1
-        const float* bp = bias_s + (kb + 4 * hh - qrow_c + (S - 1));
+        if (HAS_BIAS) {
+            const char* bp = bias_rd + kb * 4;
 #pragma unroll
-        for (int kf = 0; kf < 2; ++kf)
+            for (int kf = 0; kf < 2; ++kf)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float bv = HAS_BIAS ? bp[kf * 32 + (r & 3) + 8 * (r >> 2)] : 0.0f;
-                s[kf][r] = fmaf(s[kf][r], sl2, bv);
-            }
+                for (int g = 0; g < 4; ++g) {
+                    const float4 bv = *reinterpret_cast<const float4*>(bp + kf * 128 + g * 32);
+                    s[kf][4 * g + 0] = fmaf(s[kf][4 * g + 0], sl2, bv.x);
+                    s[kf][4 * g + 1] = fmaf(s[kf][4 * g + 1], sl2, bv.y);
+                    s[kf][4 * g + 2] = fmaf(s[kf][4 * g + 2], sl2, bv.z);
+                    s[kf][4 * g + 3] = fmaf(s[kf][4 * g + 3], sl2, bv.w);
+                }
+        } else {
+#pragma unroll
+            for (int kf = 0; kf < 2; ++kf)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kf][r] *= sl2;
+        }
         if (kb + KT > klen) {                       // wave-uniform: only the last tile of a sample is ragged
 #pragma unroll
             for (int kf = 0; kf < 2; ++kf)
@@ -176,9 +213,12 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnParams p) {
                     if (key >= klen) s[kf][r] = NEG_BIG;
                 }
         }
-        float mx = fmaxf(s[0][0], s[1][0]);
+#define VQS_SV(i) s[(i) >> 4][(i) & 15]
+        float mx = a_max3(VQS_SV(0), VQS_SV(1), VQS_SV(2));
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s[0][r], s[1][r]));
+        for (int i = 3; i < 31; i += 2) mx = a_max3(mx, VQS_SV(i), VQS_SV(i + 1));
+        mx = fmaxf(mx, VQS_SV(31));
+#undef VQS_SV
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         // keep the old running max while the new one is at most 2^RESCALE_THR above it (P stays <= 2^THR, exact in
         // fp32/bf16 range); rescale O and l only when some row's max really jumps
@@ -243,9 +283,14 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnParams p) {
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
     if (p.B <= 0 || p.H <= 0 || p.S <= 0) return hipErrorInvalidValue;
     dim3 grid((p.S + 127) / 128, p.H, p.B), block(256);
-    size_t lds = K_LDS + VT_LDS + (p.bias_table ? (size_t)(2 * p.S + 64) * 4 : 0);
-    lds = (lds + 15) & ~(size_t)15;
-    if (lds > 65536) return hipErrorInvalidValue;
+    size_t lds = K_LDS + VT_LDS + (p.bias_table ? (size_t)bias_copy_chunks(p.S) * 64 : 0);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    if (lds > 65536) {
+        hipError_t e = p.bias_table
+            ? hipFuncSetAttribute((const void*)attn_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+            : hipFuncSetAttribute((const void*)attn_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
     if (p.bias_table)
         hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, block, lds, stream, p);
     else

@@ -1016,6 +1016,246 @@ __global__ void __launch_bounds__(768) gemm_bf16_ws(const GemmParams p) {
     }
 }
 
+// =====================================================================================================
+// Persistent PING-PONG variant (VAR 5).  Same tile, LDS image, tile map and staged epilogue as the persistent kernel
+// above; what changes is WHO feeds the matrix pipe WHEN.  The two waves that share a SIMD (w and w+4, wave row
+// wr = 0 / 1) run one barrier apart: while one is in an MFMA segment (8 MFMAs = one quadrant of its 128x64 output
+// over the whole K-tile, 256 pipe cycles) the other is in a LOAD segment (ds_read_b128 of its next quadrant's
+// fragments + two LDS-DMA pieces), then they swap.  A wave never issues an LDS-DMA or a ds_read between its own
+// MFMAs, so the 60-180 cycles a DMA piece costs its issuer are spent while the other wave owns the pipe.
+//
+//   K-tile = 4 phases: Q1 (A0,W0)  Q2 (A0,W1)  Q3 (A1,W1)  Q4 (A1,W0)     A_i = wave rows m in {2i,2i+1}; W_j = n = j
+//   loads per phase  : Q1 A0+W0 (12 b128)   Q2 W1 (4)   Q3 A1 (8)   Q4 W0 (4)
+//
+// Staging runs as ONE stream of 16-KiB half-tiles (A0 W0 W1 A1 per K-tile, 2 pieces per wave each) three half-tiles
+// ahead of the compute, across K-tiles and across output tiles: phase Q1 issues this K-tile's A1, Q2..Q4 the next
+// K-tile's A0, W0, W1 (into the other stage).  Waits are counted, never 0 in steady state:
+//   a half-tile first read in phase p must be waited for (by EVERY wave, for its own pieces) before the barrier that
+//   opens wave-row 0's phase p: wave row 0 waits at the end of its MFMA segment p-1, wave row 1 at the end of its
+//   LOAD segment p-1 (same barrier).  VMEM retires in order, so vmcnt(2) = "all but the newest half-tile".
+//   After a full tile's epilogue the first wait allows the epilogue's stores on top (they are younger than W1).
+// Tile end: wave row 0 idles one barrier so both rows run the epilogue together, then row 1 idles one to re-stagger.
+// =====================================================================================================
+#define VQS_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define VQS_PIN() __builtin_amdgcn_sched_barrier(0)
+#define VQS_BAR()                           \
+    do {                                    \
+        __builtin_amdgcn_sched_barrier(0);  \
+        __builtin_amdgcn_s_barrier();       \
+        __builtin_amdgcn_sched_barrier(0);  \
+    } while (0)
+
+template <int EPI>
+__global__ void __launch_bounds__(512) gemm_bf16_pingpong(const GemmParams p) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * STAGE_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w >> 2, wc = w & 3;
+    const bool g1 = (wr == 1);
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    const int tiles_pb = tiles_m * tiles_n;
+    const int nbatch = p.batch > 0 ? p.batch : 1;
+    const int nwg = tiles_pb * nbatch;
+    const int nt = p.K / BK;
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)LDS_PTR(lds));
+
+    auto tile_coords = [&](int pid, int& m0, int& n0, int& bz) {
+        const int xcd = pid & 7, local = pid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        int t_lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+        bz = t_lin / tiles_pb;
+        t_lin -= bz * tiles_pb;
+        const int GM = 8;
+        const int width = GM * tiles_n;
+        const int group = t_lin / width;
+        const int first_m = group * GM;
+        const int gsz = min(tiles_m - first_m, GM);
+        m0 = (first_m + (t_lin % width) % gsz) * BM;
+        n0 = ((t_lin % width) / gsz) * BN;
+    };
+
+    // ---- staging stream.  Half-tile A_i = tile rows {c*128 + i*64 + 0..63}, W_j = rows {q*64 + j*32 + 0..31};
+    // each is 16 pieces of 8 rows, wave w takes pieces w and w+8 (c = 0 / 1).  Same XOR chunk swizzle as above.
+    const int sw = ((w & 1) << 2) + (lane >> 4);
+    const int gchunk = (lane & 7) ^ sw;
+    uint32_t pa[4], pb[4];                 // [half * 2 + c]: byte offset of this lane's 16 B (K-tile 0) from the batch base
+    v4i_t rsA, rsW;
+    auto set_ptrs = [&](int m0, int n0, int bz) {
+        rsA = make_rsrc(p.A + (size_t)bz * p.sA);
+        rsW = make_rsrc(p.W + (size_t)bz * p.sW);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int ra = c * 128 + h * 64 + w * 8 + (lane >> 3);
+                const int rw = (c * 2 + (w >> 2)) * 64 + h * 32 + (w & 3) * 8 + (lane >> 3);
+                pa[h * 2 + c] = (uint32_t)(((size_t)min(m0 + ra, p.M - 1) * p.lda + gchunk * 8) * 2);
+                pb[h * 2 + c] = (uint32_t)(((size_t)min(n0 + rw, p.N - 1) * p.ldw + gchunk * 8) * 2);
+            }
+    };
+    int s_pid = blockIdx.x;
+    if (s_pid >= nwg) return;
+    int s_kt = 0, s_buf = 0;
+    bool s_valid = true;
+    auto issue_a = [&](int h) {
+        if (!s_valid) return;
+        const uint32_t base = lds_base + s_buf * STAGE_BYTES + h * 8192 + w * 1024;
+        const uint32_t soff = (uint32_t)s_kt * (BK * 2);
+        bglds16(rsA, pa[h * 2 + 0], soff, base);
+        bglds16(rsA, pa[h * 2 + 1], soff, base + 16384);
+    };
+    auto issue_w = [&](int h) {
+        if (!s_valid) return;
+        const uint32_t base = lds_base + s_buf * STAGE_BYTES + W_OFF + ((w >> 2) * 64 + h * 32 + (w & 3) * 8) * 128;
+        const uint32_t soff = (uint32_t)s_kt * (BK * 2);
+        bglds16(rsW, pb[h * 2 + 0], soff, base);
+        bglds16(rsW, pb[h * 2 + 1], soff, base + 16384);
+    };
+    auto advance = [&]() {                 // stream moves on to the next K-tile (possibly the next tile's first)
+        s_buf ^= 1;
+        if (++s_kt == nt) {
+            s_kt = 0;
+            s_pid += gridDim.x;
+            if (s_pid < nwg) {
+                int sm0, sn0, sbz;
+                tile_coords(s_pid, sm0, sn0, sbz);
+                set_ptrs(sm0, sn0, sbz);
+            } else {
+                s_valid = false;
+            }
+        }
+    };
+
+    // ---- fragment addressing (as in the persistent kernel)
+    const int swr = (lane >> 1) & 7;
+    int koff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) koff[ks] = (((ks * 2 + (lane >> 5)) ^ swr) << 4);
+    const int a_row = (wr * 128 + (lane & 31)) * 128;
+    const int b_row = W_OFF + (wc * 64 + (lane & 31)) * 128;
+
+    int pid = blockIdx.x;
+    int m0, n0, bz;
+    tile_coords(pid, m0, n0, bz);
+    set_ptrs(m0, n0, bz);
+    issue_a(0);
+    issue_w(0);
+    issue_w(1);
+    VQS_VMCNT(2);
+    VQS_BAR();
+    if (g1) VQS_BAR();                     // wave row 1 runs one barrier behind from here on
+
+    int cb = 0;                            // LDS stage of the K-tile being computed
+    bool after_epi = false;                // this tile follows a FULL tile's epilogue (its stores are still counted)
+
+    while (true) {
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+
+        for (int t = 0; t < nt; ++t) {
+            const char* sb = lds + cb * STAGE_BYTES;
+            uint4 af[2][4], wf[4];
+
+#define VQS_LOAD_A(H)                                                                                              \
+    _Pragma("unroll") for (int mm = 0; mm < 2; ++mm) _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) af[mm][ks] = \
+        *reinterpret_cast<const uint4*>(sb + a_row + ((H) * 2 + mm) * 4096 + koff[ks])
+#define VQS_LOAD_W(J) \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) wf[ks] = *reinterpret_cast<const uint4*>(sb + b_row + (J) * 4096 + koff[ks])
+#define VQS_MMA(H, J)                                                                                        \
+    do {                                                                                                     \
+        __builtin_amdgcn_s_setprio(1);                                                                       \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) _Pragma("unroll") for (int mm = 0; mm < 2; ++mm)    \
+            acc[(H) * 2 + mm][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                                  \
+                __builtin_bit_cast(bf16x8, wf[ks]), __builtin_bit_cast(bf16x8, af[mm][ks]), acc[(H) * 2 + mm][J], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                       \
+    } while (0)
+#define VQS_END_LOAD(WAIT)                                  \
+    do {                                                    \
+        VQS_PIN();                                          \
+        if (g1) { WAIT; }                                   \
+        VQS_BAR();                                          \
+    } while (0)
+#define VQS_END_MMA(WAIT)        \
+    do {                         \
+        VQS_PIN();               \
+        if (!g1) { WAIT; }       \
+        VQS_BAR();               \
+    } while (0)
+#define VQS_WAIT_Q1                                                        \
+    do {                                                                   \
+        if (t == 0 && after_epi) {                                         \
+            if constexpr (EpiStores<EPI>::value == 8) VQS_VMCNT(10);       \
+            else if constexpr (EpiStores<EPI>::value == 16) VQS_VMCNT(18); \
+            else VQS_VMCNT(34);                                            \
+        } else {                                                           \
+            VQS_VMCNT(2);                                                  \
+        }                                                                  \
+    } while (0)
+#define VQS_WAIT_NEXT                   \
+    do {                                \
+        if (s_valid) VQS_VMCNT(2);      \
+        else VQS_VMCNT(0);              \
+    } while (0)
+#define VQS_WAIT_NONE \
+    do {              \
+    } while (0)
+
+            // ---- Q1: A0 x W0; stages this K-tile's A1, then the stream moves to the next K-tile
+            VQS_LOAD_A(0);
+            VQS_LOAD_W(0);
+            issue_a(1);
+            advance();
+            VQS_END_LOAD(VQS_WAIT_Q1);            // for Q2: W1 of this K-tile
+            VQS_MMA(0, 0);
+            VQS_END_MMA(VQS_WAIT_Q1);
+            // ---- Q2: A0 x W1; stages the next K-tile's A0
+            VQS_LOAD_W(1);
+            issue_a(0);
+            VQS_END_LOAD(VQS_WAIT_NEXT);          // for Q3: A1 of this K-tile
+            VQS_MMA(0, 1);
+            VQS_END_MMA(VQS_WAIT_NEXT);
+            // ---- Q3: A1 x W1; stages the next K-tile's W0
+            VQS_LOAD_A(1);
+            issue_w(0);
+            VQS_END_LOAD(VQS_WAIT_NONE);          // Q4 reads W0 again: landed since Q1
+            VQS_MMA(1, 1);
+            VQS_END_MMA(VQS_WAIT_NONE);
+            // ---- Q4: A1 x W0; stages the next K-tile's W1
+            VQS_LOAD_W(0);
+            issue_w(1);
+            VQS_END_LOAD(VQS_WAIT_NEXT);          // for the next K-tile's Q1: its A0 and W0
+            VQS_MMA(1, 0);
+            VQS_END_MMA(VQS_WAIT_NEXT);
+            cb ^= 1;
+        }
+
+        // ---------------- tile end: both wave rows run the epilogue together, staged through the stage just consumed
+        const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
+        if (!g1) VQS_BAR();
+        staged_epilogue<EPI>(p, acc, lds + (cb ^ 1) * STAGE_BYTES + w * 8192, m0, n0, bz, wr, wc, lane, full);
+        after_epi = full;
+        pid += gridDim.x;
+        if (pid >= nwg) break;
+        tile_coords(pid, m0, n0, bz);
+        if (g1) VQS_BAR();
+    }
+}
+#undef VQS_LOAD_A
+#undef VQS_LOAD_W
+#undef VQS_MMA
+#undef VQS_END_LOAD
+#undef VQS_END_MMA
+#undef VQS_WAIT_Q1
+#undef VQS_WAIT_NEXT
+#undef VQS_WAIT_NONE
+
 template <int EPI>
 static hipError_t launch_epi(const GemmParams& p, int variant, hipStream_t stream) {
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
@@ -1026,7 +1266,13 @@ static hipError_t launch_epi(const GemmParams& p, int variant, hipStream_t strea
         hipLaunchKernelGGL((gemm_bf16_kernel<EPI, 1>), grid, block, 0, stream, p);
     else if (variant == 2)
         hipLaunchKernelGGL((gemm_bf16_kernel<EPI, 2>), grid, block, 0, stream, p);
-    else if (variant == 4 && EPI != EPI_F32_RESID) {
+    else if (variant == 5 && EPI != EPI_F32_RESID) {
+        if constexpr (EPI != EPI_F32_RESID) {
+            const int nwg = tiles_m * tiles_n * (p.batch > 0 ? p.batch : 1);
+            dim3 pgrid(nwg < PERSISTENT_WGS ? nwg : PERSISTENT_WGS);
+            hipLaunchKernelGGL((gemm_bf16_pingpong<EPI>), pgrid, block, 0, stream, p);
+        }
+    } else if (variant == 4 && EPI != EPI_F32_RESID) {
         if constexpr (EPI != EPI_F32_RESID) {
             const int nwg = tiles_m * tiles_n * (p.batch > 0 ? p.batch : 1);
             dim3 pgrid(nwg < PERSISTENT_WGS ? nwg : PERSISTENT_WGS);
@@ -1057,7 +1303,7 @@ hipError_t launch_gemm(const GemmParams& p, int epilogue, int variant, hipStream
     // N: a lane stores 4 consecutive columns; fp32 output may have a ragged N if ldc leaves room for the overhang
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K % BK) != 0) return hipErrorInvalidValue;
     if ((p.N % 8) != 0 && !(epilogue == EPI_F32 && p.ldc >= ((p.N + 3) & ~3) && p.bias == nullptr)) return hipErrorInvalidValue;
-    if (p.batch > 1 && ((variant != 3 && variant != 4) || epilogue == EPI_HEADS || epilogue == EPI_F32_RESID)) return hipErrorInvalidValue;
+    if (p.batch > 1 && ((variant != 3 && variant != 4 && variant != 5) || epilogue == EPI_HEADS || epilogue == EPI_F32_RESID)) return hipErrorInvalidValue;
     if ((p.lda % 8) != 0 || (p.ldw % 8) != 0) return hipErrorInvalidValue;
     switch (epilogue) {
         case EPI_BF16: return launch_epi<EPI_BF16>(p, variant, stream);
