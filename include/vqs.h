@@ -131,10 +131,11 @@ int vqs_attention(const void* d_q, const void* d_k, const void* d_v, void* d_out
 int vqs_decoder_attention(const void* d_q, const void* d_k, const void* d_v, void* d_out, const float* d_bias_table,
                           const int32_t* d_key_len, int32_t B, int32_t H, int32_t T, int32_t S, int32_t ldq, int32_t ldk,
                           int32_t cross, void* stream);
-/* d_delta != NULL: d_x += d_delta (fp32, written back) before normalising -- the fused residual update */
-int vqs_rmsnorm(float* d_x, const float* d_delta, const void* d_w, void* d_out, int32_t M, int32_t D, float eps,
+/* d_delta != NULL (bf16 [M,D], the previous sub-layer's output): d_x += d_delta, written back to the fp32 stream,
+ * before normalising -- the fused residual update */
+int vqs_rmsnorm(float* d_x, const void* d_delta, const void* d_w, void* d_out, int32_t M, int32_t D, float eps,
                 void* stream);
-int vqs_layernorm(float* d_x, const float* d_delta, const void* d_w, const void* d_b, void* d_out, int32_t out_f32,
+int vqs_layernorm(float* d_x, const void* d_delta, const void* d_w, const void* d_b, void* d_out, int32_t out_f32,
                   int32_t M, int32_t D, float eps, void* stream);
 int vqs_score_head(const float* d_logits, int32_t ldl, int32_t V, const int32_t* d_labels, float* d_label_logprobs,
                    float* d_scores, int32_t B, int32_t T, void* stream);

@@ -27,69 +27,94 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// T5 RMSNorm (HF models/t5/modeling_t5.py:59-72): out = w * x * rsqrt(mean(x^2) + eps); fp32 stream in,
-// bf16 GEMM operand out.  One wave per row, two passes over the row (second pass hits L2).
+// Norm kernels.  One 64-lane wave per row; fp32 residual stream in, bf16 GEMM operand out.
+//   T5 RMSNorm (HF models/t5/modeling_t5.py:59-72): out = w * x * rsqrt(mean(x^2) + eps)
+//   CLIP LayerNorm (torch.nn.LayerNorm at HF models/clip/modeling_clip.py:357-360,642): fp32 statistics
 // With `delta` the residual update of the previous sub-layer (hidden = hidden + sublayer_out,
-// modeling_t5.py:140,400,431) is fused in front: x += delta is written back, then normalised.
-// D % 4 == 0.
+// modeling_t5.py:140,400,431; modeling_clip.py:366,371) is fused in front: x += delta is written back to the fp32
+// stream, then normalised.  `delta` is the sub-layer's output GEMM result in bf16 -- exactly what the reference's bf16
+// nn.Linear hands to its residual add -- while the stream itself stays fp32 here.
+// Algorithmic HBM bytes per element with delta: 4 (x in) + 2 (delta) + 4 (x out) + 2 (out) = 12.
+// D = 1024 / 2048 / 4096 (the model widths): the row lives in registers (NV float4 per lane), every load of the row is in
+// flight before the first use and nothing is read twice.  Other D (test configs): looped fallback, second pass from L2.
 // ------------------------------------------------------------------------------------------------
-template <bool ADD>
-__global__ void __launch_bounds__(256) rmsnorm_kernel(float* __restrict__ x, const float* __restrict__ delta,
-                                                      const bf16_t* __restrict__ w, bf16_t* __restrict__ out, int M, int D,
-                                                      float eps) {
+__device__ __forceinline__ float4 bf4_to_f4(uint2 u) {
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                       __uint_as_float(u.y & 0xffff0000u));
+}
+typedef __attribute__((ext_vector_type(2))) __bf16 e_bf16x2;
+__device__ __forceinline__ uint32_t e_pack2_hw(float a, float b) {   // v_cvt_pk_bf16_f32 (RNE, same result as e_pack2)
+    e_bf16x2 v;
+    v[0] = (__bf16)a;
+    v[1] = (__bf16)b;
+    return __builtin_bit_cast(uint32_t, v);
+}
+
+// KIND 0: RMSNorm (bsh unused); KIND 1: LayerNorm.
+template <int NV, int KIND, bool ADD, bool OUT_F32>
+__global__ void __launch_bounds__(256) norm_rows_reg_kernel(float* __restrict__ x, const bf16_t* __restrict__ delta,
+                                                            const bf16_t* __restrict__ w, const bf16_t* __restrict__ bsh,
+                                                            void* __restrict__ out, int M, float eps) {
+    constexpr int D = NV * 256;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= M) return;
     float4* xr = reinterpret_cast<float4*>(x + (size_t)row * D);
-    const int nv = D >> 2;
-    float ss = 0.0f;
+    float4 v[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] = xr[lane + 64 * j];
     if (ADD) {
-        // x <- x + delta (the previous sub-layer's fp32 GEMM output), written back: the residual stream update
-        const float4* dr = reinterpret_cast<const float4*>(delta + (size_t)row * D);
-        for (int i = lane; i < nv; i += 64) {
-            float4 v = xr[i];
-            const float4 d = dr[i];
-            v.x += d.x; v.y += d.y; v.z += d.z; v.w += d.w;
-            xr[i] = v;
-            ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-        }
-    } else {
-        for (int i = lane; i < nv; i += 64) {
-            const float4 v = xr[i];
-            ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        const uint2* dr = reinterpret_cast<const uint2*>(delta + (size_t)row * D);
+        uint2 d[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) d[j] = dr[lane + 64 * j];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const float4 f = bf4_to_f4(d[j]);
+            v[j].x += f.x; v[j].y += f.y; v[j].z += f.z; v[j].w += f.w;
+            xr[lane + 64 * j] = v[j];
         }
     }
-    ss = wave_sum(ss);
-    const float rs = rsqrtf(ss / (float)D + eps);
-    uint2* orow = reinterpret_cast<uint2*>(out + (size_t)row * D);
+    float mu = 0.0f;
+    if (KIND == 1) {
+        float s1 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) s1 += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+        mu = wave_sum(s1) * (1.0f / (float)D);
+    }
+    float s2 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const float a = v[j].x - mu, b = v[j].y - mu, c = v[j].z - mu, d = v[j].w - mu;
+        s2 += a * a + b * b + c * c + d * d;
+    }
+    const float rs = rsqrtf(wave_sum(s2) * (1.0f / (float)D) + eps);
     const uint2* wr = reinterpret_cast<const uint2*>(w);
-    for (int i = lane; i < nv; i += 64) {
-        const float4 v = xr[i];        // same lane wrote it in the ADD pass
-        const uint2 wv = wr[i];
-        uint2 o;
-        o.x = e_pack2(v.x * rs * e_bf2f((bf16_t)(wv.x & 0xffff)), v.y * rs * e_bf2f((bf16_t)(wv.x >> 16)));
-        o.y = e_pack2(v.z * rs * e_bf2f((bf16_t)(wv.y & 0xffff)), v.w * rs * e_bf2f((bf16_t)(wv.y >> 16)));
-        orow[i] = o;
+    const uint2* br = reinterpret_cast<const uint2*>(bsh);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i = lane + 64 * j;
+        const float4 wv = bf4_to_f4(wr[i]);
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (KIND == 1) bv = bf4_to_f4(br[i]);
+        const float o0 = (v[j].x - mu) * rs * wv.x + bv.x, o1 = (v[j].y - mu) * rs * wv.y + bv.y;
+        const float o2 = (v[j].z - mu) * rs * wv.z + bv.z, o3 = (v[j].w - mu) * rs * wv.w + bv.w;
+        if (OUT_F32) {
+            reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)row * D)[i] = make_float4(o0, o1, o2, o3);
+        } else {
+            uint2 o;
+            o.x = e_pack2_hw(o0, o1);
+            o.y = e_pack2_hw(o2, o3);
+            reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(out) + (size_t)row * D)[i] = o;
+        }
     }
 }
 
-hipError_t launch_rmsnorm(float* x, const float* delta, const bf16_t* w, bf16_t* out, int M, int D, float eps,
-                          hipStream_t s) {
-    if (D % 4) return hipErrorInvalidValue;
-    if (delta)
-        hipLaunchKernelGGL(rmsnorm_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, s, x, delta, w, out, M, D, eps);
-    else
-        hipLaunchKernelGGL(rmsnorm_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, s, x, delta, w, out, M, D, eps);
-    return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------------
-// CLIP LayerNorm (torch.nn.LayerNorm at HF models/clip/modeling_clip.py:357-360,642): fp32 stats.
-// ------------------------------------------------------------------------------------------------
-template <bool OUT_F32, bool ADD>
-__global__ void __launch_bounds__(256) layernorm_kernel(float* __restrict__ x, const float* __restrict__ delta,
-                                                        const bf16_t* __restrict__ w, const bf16_t* __restrict__ bsh,
-                                                        void* __restrict__ out, int M, int D, float eps) {
+// any D % 4 == 0
+template <int KIND, bool ADD, bool OUT_F32>
+__global__ void __launch_bounds__(256) norm_rows_loop_kernel(float* __restrict__ x, const bf16_t* __restrict__ delta,
+                                                             const bf16_t* __restrict__ w, const bf16_t* __restrict__ bsh,
+                                                             void* __restrict__ out, int M, int D, float eps) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= M) return;
@@ -97,21 +122,21 @@ __global__ void __launch_bounds__(256) layernorm_kernel(float* __restrict__ x, c
     const int nv = D >> 2;
     float s1 = 0.0f;
     if (ADD) {
-        const float4* dr = reinterpret_cast<const float4*>(delta + (size_t)row * D);
+        const uint2* dr = reinterpret_cast<const uint2*>(delta + (size_t)row * D);
         for (int i = lane; i < nv; i += 64) {
             float4 v = xr[i];
-            const float4 d = dr[i];
+            const float4 d = bf4_to_f4(dr[i]);
             v.x += d.x; v.y += d.y; v.z += d.z; v.w += d.w;
-            xr[i] = v;
-            s1 += v.x + v.y + v.z + v.w;
+            xr[i] = v;                     // the same lane re-reads it below
+            s1 += (v.x + v.y) + (v.z + v.w);
         }
-    } else {
+    } else if (KIND == 1) {
         for (int i = lane; i < nv; i += 64) {
             const float4 v = xr[i];
-            s1 += v.x + v.y + v.z + v.w;
+            s1 += (v.x + v.y) + (v.z + v.w);
         }
     }
-    const float mu = wave_sum(s1) / (float)D;
+    const float mu = KIND == 1 ? wave_sum(s1) / (float)D : 0.0f;
     float s2 = 0.0f;
     for (int i = lane; i < nv; i += 64) {
         const float4 v = xr[i];
@@ -123,34 +148,52 @@ __global__ void __launch_bounds__(256) layernorm_kernel(float* __restrict__ x, c
     const uint2* br = reinterpret_cast<const uint2*>(bsh);
     for (int i = lane; i < nv; i += 64) {
         const float4 v = xr[i];
-        const uint2 wv = wr[i], bv = br[i];
-        const float o0 = (v.x - mu) * rs * e_bf2f((bf16_t)(wv.x & 0xffff)) + e_bf2f((bf16_t)(bv.x & 0xffff));
-        const float o1 = (v.y - mu) * rs * e_bf2f((bf16_t)(wv.x >> 16)) + e_bf2f((bf16_t)(bv.x >> 16));
-        const float o2 = (v.z - mu) * rs * e_bf2f((bf16_t)(wv.y & 0xffff)) + e_bf2f((bf16_t)(bv.y & 0xffff));
-        const float o3 = (v.w - mu) * rs * e_bf2f((bf16_t)(wv.y >> 16)) + e_bf2f((bf16_t)(bv.y >> 16));
+        const float4 wv = bf4_to_f4(wr[i]);
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (KIND == 1) bv = bf4_to_f4(br[i]);
+        const float o0 = (v.x - mu) * rs * wv.x + bv.x, o1 = (v.y - mu) * rs * wv.y + bv.y;
+        const float o2 = (v.z - mu) * rs * wv.z + bv.z, o3 = (v.w - mu) * rs * wv.w + bv.w;
         if (OUT_F32) {
             reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)row * D)[i] = make_float4(o0, o1, o2, o3);
         } else {
             uint2 o;
-            o.x = e_pack2(o0, o1);
-            o.y = e_pack2(o2, o3);
+            o.x = e_pack2_hw(o0, o1);
+            o.y = e_pack2_hw(o2, o3);
             reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(out) + (size_t)row * D)[i] = o;
         }
     }
 }
 
-hipError_t launch_layernorm(float* x, const float* delta, const bf16_t* w, const bf16_t* b, void* out, int out_f32, int M,
+template <int KIND, bool ADD, bool OUT_F32>
+static hipError_t launch_norm_t(float* x, const bf16_t* delta, const bf16_t* w, const bf16_t* b, void* out, int M, int D,
+                                float eps, hipStream_t s) {
+    const dim3 grid((M + 3) / 4), block(256);
+    if (D == 1024)
+        hipLaunchKernelGGL((norm_rows_reg_kernel<4, KIND, ADD, OUT_F32>), grid, block, 0, s, x, delta, w, b, out, M, eps);
+    else if (D == 2048)
+        hipLaunchKernelGGL((norm_rows_reg_kernel<8, KIND, ADD, OUT_F32>), grid, block, 0, s, x, delta, w, b, out, M, eps);
+    else if (D == 4096)
+        hipLaunchKernelGGL((norm_rows_reg_kernel<16, KIND, ADD, OUT_F32>), grid, block, 0, s, x, delta, w, b, out, M, eps);
+    else
+        hipLaunchKernelGGL((norm_rows_loop_kernel<KIND, ADD, OUT_F32>), grid, block, 0, s, x, delta, w, b, out, M, D, eps);
+    return hipGetLastError();
+}
+
+hipError_t launch_rmsnorm(float* x, const bf16_t* delta, const bf16_t* w, bf16_t* out, int M, int D, float eps,
+                          hipStream_t s) {
+    if (D % 4) return hipErrorInvalidValue;
+    return delta ? launch_norm_t<0, true, false>(x, delta, w, nullptr, out, M, D, eps, s)
+                 : launch_norm_t<0, false, false>(x, delta, w, nullptr, out, M, D, eps, s);
+}
+
+hipError_t launch_layernorm(float* x, const bf16_t* delta, const bf16_t* w, const bf16_t* b, void* out, int out_f32, int M,
                             int D, float eps, hipStream_t s) {
     if (D % 4) return hipErrorInvalidValue;
-    const dim3 grid((M + 3) / 4), block(256);
-    if (out_f32) {
-        if (delta) hipLaunchKernelGGL((layernorm_kernel<true, true>), grid, block, 0, s, x, delta, w, b, out, M, D, eps);
-        else hipLaunchKernelGGL((layernorm_kernel<true, false>), grid, block, 0, s, x, delta, w, b, out, M, D, eps);
-    } else {
-        if (delta) hipLaunchKernelGGL((layernorm_kernel<false, true>), grid, block, 0, s, x, delta, w, b, out, M, D, eps);
-        else hipLaunchKernelGGL((layernorm_kernel<false, false>), grid, block, 0, s, x, delta, w, b, out, M, D, eps);
-    }
-    return hipGetLastError();
+    if (out_f32)
+        return delta ? launch_norm_t<1, true, true>(x, delta, w, b, out, M, D, eps, s)
+                     : launch_norm_t<1, false, true>(x, delta, w, b, out, M, D, eps, s);
+    return delta ? launch_norm_t<1, true, false>(x, delta, w, b, out, M, D, eps, s)
+                 : launch_norm_t<1, false, false>(x, delta, w, b, out, M, D, eps, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -207,17 +250,17 @@ hipError_t launch_vit_assemble(const float* patch_out, const bf16_t* cls, const 
 
 // feature select: hidden_states[-2][:, 1:] -> bf16 rows for the projector GEMM
 __global__ void __launch_bounds__(256) drop_cls_cast_kernel(float* __restrict__ hidden,
-                                                            const float* __restrict__ delta, bf16_t* __restrict__ out,
+                                                            const bf16_t* __restrict__ delta, bf16_t* __restrict__ out,
                                                             int P, int D) {
     const int n = blockIdx.y, pidx = blockIdx.x;
     const size_t roff = ((size_t)n * (P + 1) + 1 + pidx) * D;
     float4* src = reinterpret_cast<float4*>(hidden + roff);
-    const float4* dsrc = delta ? reinterpret_cast<const float4*>(delta + roff) : nullptr;
+    const uint2* dsrc = delta ? reinterpret_cast<const uint2*>(delta + roff) : nullptr;
     uint2* dst = reinterpret_cast<uint2*>(out + ((size_t)n * P + pidx) * D);
     for (int i = threadIdx.x; i < (D >> 2); i += 256) {
         float4 v = src[i];
         if (dsrc) {
-            const float4 d = dsrc[i];
+            const float4 d = bf4_to_f4(dsrc[i]);
             v.x += d.x; v.y += d.y; v.z += d.z; v.w += d.w;
             src[i] = v;      // materialise hidden_states[-2] for the patch rows (the CLS row is never needed)
         }
@@ -228,7 +271,7 @@ __global__ void __launch_bounds__(256) drop_cls_cast_kernel(float* __restrict__ 
     }
 }
 
-hipError_t launch_drop_cls_cast(float* hidden, const float* delta, bf16_t* out, int N, int P, int D, hipStream_t s) {
+hipError_t launch_drop_cls_cast(float* hidden, const bf16_t* delta, bf16_t* out, int N, int P, int D, hipStream_t s) {
     if (D % 4) return hipErrorInvalidValue;
     hipLaunchKernelGGL(drop_cls_cast_kernel, dim3(P, N), dim3(256), 0, s, hidden, delta, out, P, D);
     return hipGetLastError();

@@ -77,7 +77,7 @@ struct EncodeWs {
     float* patch_out;
     float* pre;
     float* hidden;
-    float* delta;
+    bf16_t* delta;
     bf16_t *xn, *q, *k, *v, *attn, *mid, *feat_in, *pmid;
     size_t total;
 };
@@ -91,7 +91,7 @@ EncodeWs carve_encode(const vqs_handle* h, char* base, int N, std::unordered_map
     w.patch_out = cv.take<float>(NP * c.vis_hidden);
     w.pre = cv.take<float>(NS * c.vis_hidden);
     w.hidden = cv.take<float>(NS * c.vis_hidden, "vit_hidden");
-    w.delta = cv.take<float>(NS * c.vis_hidden);
+    w.delta = cv.take<bf16_t>(NS * c.vis_hidden);
     w.xn = cv.take<bf16_t>(NS * c.vis_hidden);
     w.q = cv.take<bf16_t>(NS * c.vis_hidden);
     w.k = cv.take<bf16_t>(NS * c.vis_hidden);
@@ -106,7 +106,8 @@ EncodeWs carve_encode(const vqs_handle* h, char* base, int N, std::unordered_map
 
 struct ScoreWs {
     int *sent_pos, *enc_len, *flags;
-    float *enc_table, *dec_table, *hidden, *delta, *ddelta;
+    float *enc_table, *dec_table, *hidden;
+    bf16_t *delta, *ddelta;
     bf16_t *xn, *q, *k, *v, *attn, *ff, *enc_out, *ck, *cv;
     float* dhid;
     bf16_t *dxn, *dqkv, *dattn, *dq, *dff;
@@ -132,7 +133,7 @@ ScoreWs carve_score(const vqs_handle* h, char* base, int B, int L, int T,
     w.enc_table = cv.take<float>((size_t)H * (2 * S - 1));
     w.dec_table = cv.take<float>((size_t)H * T);
     w.hidden = cv.take<float>(M * D, "enc_in");   // the fp32 residual stream; holds enc_in until layer 0 runs
-    w.delta = cv.take<float>(M * D);              // fp32 sub-layer output waiting to be added by the next norm
+    w.delta = cv.take<bf16_t>(M * D);            // bf16 sub-layer output waiting to be added by the next norm
     w.xn = cv.take<bf16_t>(M * D);
     w.q = cv.take<bf16_t>(M * I);
     w.k = cv.take<bf16_t>(M * I);
@@ -143,7 +144,7 @@ ScoreWs carve_score(const vqs_handle* h, char* base, int B, int L, int T,
     w.ck = cv.take<bf16_t>(M * I);
     w.cv = cv.take<bf16_t>(M * I);
     w.dhid = cv.take<float>(MT * D);
-    w.ddelta = cv.take<float>(MT * D);
+    w.ddelta = cv.take<bf16_t>(MT * D);
     w.dxn = cv.take<bf16_t>(MT * D);
     w.dqkv = cv.take<bf16_t>(MT * 3 * I);
     w.dattn = cv.take<bf16_t>(MT * I);
@@ -446,9 +447,9 @@ int vqs_encode_images(vqs_handle* h, const void* d_pixels, int32_t N, void* d_fe
     HIPCHK(h, vqs::launch_vit_assemble(w.patch_out, cls, pos, w.pre, N, P, hid, st), "vit_assemble");
     HIPCHK(h, vqs::launch_layernorm(w.pre, nullptr, pre_w, pre_b, w.hidden, 1, NS, hid, c.vis_ln_eps, st), "pre_layrnorm");
 
-    // Residual stream protocol: a sub-layer's output GEMM writes fp32 into `delta`; the NEXT norm kernel performs
+    // Residual stream protocol: a sub-layer's output GEMM writes bf16 into `delta`; the NEXT norm kernel performs
     // hidden += delta (written back) and normalises in the same pass.  `pend` is the not-yet-added delta.
-    const float* pend = nullptr;
+    const bf16_t* pend = nullptr;
     for (int i = 0; i < c.vis_layers_run; ++i) {
         const std::string p = "vision.encoder.layers." + std::to_string(i) + ".";
         GETW(ln1w, p + "layer_norm1.weight", hid);
@@ -479,7 +480,7 @@ int vqs_encode_images(vqs_handle* h, const void* d_pixels, int32_t N, void* d_fe
         {
             GemmCall g{w.attn, ow, w.delta};
             g.bias = ob;
-            g.M = NS; g.N = hid; g.K = hid; g.lda = hid; g.ldw = hid; g.ldc = hid; g.epi = vqs::EPI_F32;
+            g.M = NS; g.N = hid; g.K = hid; g.lda = hid; g.ldw = hid; g.ldc = hid; g.epi = vqs::EPI_BF16;
             RUN(run_gemm(h, g, st, "vit out_proj"));
         }
         HIPCHK(h, vqs::launch_layernorm(w.hidden, w.delta, ln2w, ln2b, w.xn, 0, NS, hid, c.vis_ln_eps, st), "layer_norm2");
@@ -492,7 +493,7 @@ int vqs_encode_images(vqs_handle* h, const void* d_pixels, int32_t N, void* d_fe
         {
             GemmCall g{w.mid, f2w, w.delta};
             g.bias = f2b;
-            g.M = NS; g.N = hid; g.K = mlp; g.lda = mlp; g.ldw = mlp; g.ldc = hid; g.epi = vqs::EPI_F32;
+            g.M = NS; g.N = hid; g.K = mlp; g.lda = mlp; g.ldw = mlp; g.ldc = hid; g.epi = vqs::EPI_BF16;
             RUN(run_gemm(h, g, st, "vit fc2"));
             pend = w.delta;
         }
@@ -555,7 +556,7 @@ int vqs_score(vqs_handle* h, const void* d_feats, const int32_t* d_img_index, co
                                        w.hidden, B, L, P, D, V, st), "embed_splice");
 
     // ---------------- encoder (same pending-delta protocol as the vision tower)
-    const float* pend = nullptr;
+    const bf16_t* pend = nullptr;
     for (int i = 0; i < c.enc_layers; ++i) {
         const std::string p = "encoder.block." + std::to_string(i) + ".";
         GETW(ln0, p + "layer.0.layer_norm.weight", D);
@@ -577,7 +578,7 @@ int vqs_score(vqs_handle* h, const void* d_feats, const int32_t* d_img_index, co
         }
         {
             GemmCall g{w.attn, ow, w.delta};
-            g.M = M; g.N = D; g.K = I; g.lda = I; g.ldw = I; g.ldc = D; g.epi = vqs::EPI_F32;
+            g.M = M; g.N = D; g.K = I; g.lda = I; g.ldw = I; g.ldc = D; g.epi = vqs::EPI_BF16;
             RUN(run_gemm(h, g, st, "enc o"));
         }
         HIPCHK(h, vqs::launch_rmsnorm(w.hidden, w.delta, ln1, w.xn, M, D, c.t5_ln_eps, st), "enc rmsnorm1");
@@ -588,7 +589,7 @@ int vqs_score(vqs_handle* h, const void* d_feats, const int32_t* d_img_index, co
         }
         {
             GemmCall g{w.ff, wo, w.delta};
-            g.M = M; g.N = D; g.K = F; g.lda = F; g.ldw = F; g.ldc = D; g.epi = vqs::EPI_F32;
+            g.M = M; g.N = D; g.K = F; g.lda = F; g.ldw = F; g.ldc = D; g.epi = vqs::EPI_BF16;
             RUN(run_gemm(h, g, st, "enc wo"));
             pend = w.delta;
         }
@@ -602,7 +603,7 @@ int vqs_score(vqs_handle* h, const void* d_feats, const int32_t* d_img_index, co
 
     // ---------------- decoder (teacher forced, T rows per pair)
     HIPCHK(h, vqs::launch_decoder_embed(d_labels, shared, w.dhid, B, T, D, V, st), "decoder embed");
-    const float* dpend = nullptr;
+    const bf16_t* dpend = nullptr;
     for (int i = 0; i < c.dec_layers; ++i) {
         const std::string p = "decoder.block." + std::to_string(i) + ".";
         GETW(ln0, p + "layer.0.layer_norm.weight", D);
@@ -626,7 +627,7 @@ int vqs_score(vqs_handle* h, const void* d_feats, const int32_t* d_img_index, co
         }
         {
             GemmCall g{w.dattn, so, w.ddelta};
-            g.M = MT; g.N = D; g.K = I; g.lda = I; g.ldw = I; g.ldc = D; g.epi = vqs::EPI_F32;
+            g.M = MT; g.N = D; g.K = I; g.lda = I; g.ldw = I; g.ldc = D; g.epi = vqs::EPI_BF16;
             RUN(run_gemm(h, g, st, "dec self o"));
         }
         HIPCHK(h, vqs::launch_rmsnorm(w.dhid, w.ddelta, ln1, w.dxn, MT, D, c.t5_ln_eps, st), "dec rmsnorm1");
@@ -681,7 +682,7 @@ int vqs_score(vqs_handle* h, const void* d_feats, const int32_t* d_img_index, co
         }
         {
             GemmCall g{w.dattn, co, w.ddelta};
-            g.M = MT; g.N = D; g.K = I; g.lda = I; g.ldw = I; g.ldc = D; g.epi = vqs::EPI_F32;
+            g.M = MT; g.N = D; g.K = I; g.lda = I; g.ldw = I; g.ldc = D; g.epi = vqs::EPI_BF16;
             RUN(run_gemm(h, g, st, "dec cross o"));
         }
         HIPCHK(h, vqs::launch_rmsnorm(w.dhid, w.ddelta, ln2, w.dxn, MT, D, c.t5_ln_eps, st), "dec rmsnorm2");
@@ -692,7 +693,7 @@ int vqs_score(vqs_handle* h, const void* d_feats, const int32_t* d_img_index, co
         }
         {
             GemmCall g{w.dff, wo, w.ddelta};
-            g.M = MT; g.N = D; g.K = F; g.lda = F; g.ldw = F; g.ldc = D; g.epi = vqs::EPI_F32;
+            g.M = MT; g.N = D; g.K = F; g.lda = F; g.ldw = F; g.ldc = D; g.epi = vqs::EPI_BF16;
             RUN(run_gemm(h, g, st, "dec wo"));
             dpend = w.ddelta;
         }
@@ -784,13 +785,13 @@ int vqs_decoder_attention(const void* q, const void* k, const void* v, void* out
     return vqs::launch_decoder_attention(a, (hipStream_t)stream) == hipSuccess ? VQS_OK : VQS_ERR_HIP;
 }
 
-int vqs_rmsnorm(float* x, const float* delta, const void* w, void* out, int32_t M, int32_t D, float eps, void* stream) {
-    return vqs::launch_rmsnorm(x, delta, (const bf16_t*)w, (bf16_t*)out, M, D, eps, (hipStream_t)stream) == hipSuccess ? VQS_OK : VQS_ERR_HIP;
+int vqs_rmsnorm(float* x, const void* delta, const void* w, void* out, int32_t M, int32_t D, float eps, void* stream) {
+    return vqs::launch_rmsnorm(x, (const bf16_t*)delta, (const bf16_t*)w, (bf16_t*)out, M, D, eps, (hipStream_t)stream) == hipSuccess ? VQS_OK : VQS_ERR_HIP;
 }
 
-int vqs_layernorm(float* x, const float* delta, const void* w, const void* b, void* out, int32_t out_f32, int32_t M, int32_t D,
+int vqs_layernorm(float* x, const void* delta, const void* w, const void* b, void* out, int32_t out_f32, int32_t M, int32_t D,
                   float eps, void* stream) {
-    return vqs::launch_layernorm(x, delta, (const bf16_t*)w, (const bf16_t*)b, out, out_f32, M, D, eps, (hipStream_t)stream) == hipSuccess
+    return vqs::launch_layernorm(x, (const bf16_t*)delta, (const bf16_t*)w, (const bf16_t*)b, out, out_f32, M, D, eps, (hipStream_t)stream) == hipSuccess
                ? VQS_OK : VQS_ERR_HIP;
 }
 

@@ -69,9 +69,9 @@ hipError_t launch_decoder_attention(const DecAttnParams& p, hipStream_t stream);
 
 // ---------------------------------------------------------------- norms + glue (elementwise.hip)
 // delta != nullptr: x += delta (fp32, written back) first -- the fused residual update of the previous sub-layer
-hipError_t launch_rmsnorm(float* x, const float* delta, const bf16_t* w, bf16_t* out, int M, int D, float eps,
+hipError_t launch_rmsnorm(float* x, const bf16_t* delta, const bf16_t* w, bf16_t* out, int M, int D, float eps,
                           hipStream_t s);
-hipError_t launch_layernorm(float* x, const float* delta, const bf16_t* w, const bf16_t* b, void* out, int out_f32, int M,
+hipError_t launch_layernorm(float* x, const bf16_t* delta, const bf16_t* w, const bf16_t* b, void* out, int out_f32, int M,
                             int D, float eps, hipStream_t s);
 // pixels bf16 [N,3,IMG,IMG] -> rows [N*G*G, Kpad] in (c,ky,kx) order, zero padded
 hipError_t launch_im2col(const bf16_t* pixels, bf16_t* out, int N, int img, int patch, int kpad, hipStream_t s);
@@ -79,7 +79,7 @@ hipError_t launch_im2col(const bf16_t* pixels, bf16_t* out, int N, int img, int 
 hipError_t launch_vit_assemble(const float* patch_out, const bf16_t* cls, const bf16_t* pos, float* hidden, int N,
                                int P, int D, hipStream_t s);
 // stream fp32 [N, 1+P, D] -> bf16 [N*P, D] dropping the CLS row
-hipError_t launch_drop_cls_cast(float* hidden, const float* delta, bf16_t* out, int N, int P, int D,
+hipError_t launch_drop_cls_cast(float* hidden, const bf16_t* delta, bf16_t* out, int N, int P, int D,
                                 hipStream_t s);
 // per sample: sentinel position and spliced length from int32 ids [B,L] (pad = 0 trailing, sentinel = -200)
 hipError_t launch_prompt_scan(const int* ids, int B, int L, int P, int* sent_pos, int* enc_len, int* err_flag,

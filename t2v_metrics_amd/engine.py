@@ -295,9 +295,11 @@ def decoder_attention(q, k, v, B, H, T, S, ldq, ldk, cross: bool, bias_table=Non
 
 
 def rmsnorm(x, w, eps, delta=None):
-    """out = rmsnorm(x [+ delta]) * w; with delta, x is updated in place (x += delta)."""
+    """out = rmsnorm(x [+ delta]) * w; with delta (bf16 [M,D]), the fp32 x is updated in place (x += delta)."""
     lib = load_library()
     M, D = x.shape
+    if delta is not None and (delta.dtype != torch.bfloat16 or tuple(delta.shape) != (M, D) or not delta.is_contiguous()):
+        raise VqsError("rmsnorm: delta must be a contiguous bf16 [M, D] tensor")
     out = torch.empty(M, D, dtype=torch.bfloat16, device=x.device)
     rc = lib.vqs_rmsnorm(x.data_ptr(), _ptr(delta), w.data_ptr(), out.data_ptr(), M, D, eps, _stream_ptr())
     if rc != 0:
@@ -308,6 +310,8 @@ def rmsnorm(x, w, eps, delta=None):
 def layernorm(x, w, b, eps, out_f32=False, delta=None):
     lib = load_library()
     M, D = x.shape
+    if delta is not None and (delta.dtype != torch.bfloat16 or tuple(delta.shape) != (M, D) or not delta.is_contiguous()):
+        raise VqsError("layernorm: delta must be a contiguous bf16 [M, D] tensor")
     out = torch.empty(M, D, dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
     rc = lib.vqs_layernorm(x.data_ptr(), _ptr(delta), w.data_ptr(), b.data_ptr(), out.data_ptr(), 1 if out_f32 else 0, M, D,
                            eps, _stream_ptr())

@@ -175,8 +175,8 @@ def test_norms(eng, M, D):
     assert_close(eng.layernorm(x, w, b, 1e-5), ref, 1e-2, 1e-2, "layernorm bf16")
     assert_close(eng.layernorm(x, w, b, 1e-5, out_f32=True), ref, 1e-4, 1e-5, "layernorm f32")
     # fused residual update: x += delta (in place) then normalise
-    delta = torch.randn(M, D, device="cuda", generator=torch.Generator(device="cuda").manual_seed(26))
-    xs = x + delta
+    delta = torch.randn(M, D, device="cuda", generator=torch.Generator(device="cuda").manual_seed(26)).to(torch.bfloat16)
+    xs = x + delta.float()
     x1 = x.clone()
     out = eng.rmsnorm(x1, w, 1e-6, delta=delta)
     assert_close(x1, xs, 1e-6, 1e-6, "rmsnorm residual write-back")

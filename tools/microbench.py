@@ -94,7 +94,13 @@ def main():
         emit({"kernel": "rmsnorm", "M": M, "D": D, "ms": med, "GBps": M * D * 6 / med / 1e6})
         med, best = timeit(lambda: engine.layernorm(x, w, w, 1e-5))
         emit({"kernel": "layernorm", "M": M, "D": D, "ms": med, "GBps": M * D * 6 / med / 1e6})
-        del x
+        # the in-situ form: fused residual add (bf16 delta) + norm; 12 algorithmic bytes per element
+        d = (torch.randn(M, D, device=dev, generator=g) * 0.01).to(torch.bfloat16)
+        med, best = timeit(lambda: engine.rmsnorm(x, w, 1e-6, delta=d))
+        emit({"kernel": "rmsnorm+add", "M": M, "D": D, "ms": med, "GBps": M * D * 12 / med / 1e6})
+        med, best = timeit(lambda: engine.layernorm(x, w, w, 1e-5, delta=d))
+        emit({"kernel": "layernorm+add", "M": M, "D": D, "ms": med, "GBps": M * D * 12 / med / 1e6})
+        del x, d
 
 
 if __name__ == "__main__":
