@@ -40,8 +40,9 @@ CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
 CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
 
 
-def synth_batch(cfg, batch, seed, device):
-    """SURVEY.md §8d "Config 2" generator."""
+def synth_batch(cfg, batch, seed, device, ragged=False):
+    """SURVEY.md §8d "Config 2" generator; ragged=True is the "Config 3" stand-in (caption of 8-40 tokens between the
+    8-token prefix + sentinel and the 24-token template suffix, right-padded with id 0 to the batch maximum)."""
     g = torch.Generator().manual_seed(seed)
     img = torch.randint(0, 256, (batch, 224, 224, 3), generator=g, dtype=torch.uint8)
     x = img.to(device).permute(0, 3, 1, 2).float()
@@ -56,7 +57,18 @@ def synth_batch(cfg, batch, seed, device):
     pre[:, 7] = 1
     suf = torch.randint(3, hi, (batch, 24), generator=g)
     suf[:, 23] = 1
-    ids = torch.cat([pre, torch.full((batch, 1), -200), suf], dim=1).to(torch.int32)
+    if ragged:
+        cap_len = torch.randint(8, 41, (batch,), generator=g)
+        width = 8 + 1 + 40 + 24
+        ids = torch.zeros(batch, width, dtype=torch.int64)
+        for i in range(batch):
+            n = int(cap_len[i])
+            cap = torch.randint(3, hi, (n,), generator=g)
+            row = torch.cat([pre[i], torch.tensor([-200]), cap, suf[i]])
+            ids[i, : row.numel()] = row
+        ids = ids[:, : int(8 + 1 + cap_len.max() + 24)].to(torch.int32)
+    else:
+        ids = torch.cat([pre, torch.full((batch, 1), -200), suf], dim=1).to(torch.int32)
     labels = torch.tensor([[min(2163, vocab - 1), 1]] * batch, dtype=torch.int32)
     img_index = torch.arange(batch, dtype=torch.int32)
     return pixels, img_index.to(device), ids.to(device), labels.to(device)
@@ -70,6 +82,7 @@ def main():
     ap.add_argument("--model", default="clip-flant5-xl")
     ap.add_argument("--batch", type=int, default=256, help="pairs per GPU per step")
     ap.add_argument("--cpu-pairs", type=int, default=2, help="pairs in the CPU-oracle sample (0 = skip)")
+    ap.add_argument("--ragged", action="store_true", help="SURVEY config-3 stand-in: variable-length prompts, padded + masked")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -94,7 +107,7 @@ def main():
     weights = make_seeded_weights(cfg, seed=0, device=device)
     eng = VqsEngine(cfg, weights, device=device)
     B = args.batch
-    pixels, img_index, ids, labels = synth_batch(cfg, B, seed=1234 + rank, device=device)
+    pixels, img_index, ids, labels = synth_batch(cfg, B, seed=1234 + rank, device=device, ragged=args.ragged)
     L, T = ids.shape[1], labels.shape[1]
     s_e = L - 1 + cfg.vision.n_patches
 
@@ -124,6 +137,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     eng.profile(False)
+    gemm_bytes = eng.profile_bytes()
     n_gemm, gemm_ms, gemm_flops = eng.profile_read(reset=True)
 
     t_el = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -133,7 +147,9 @@ def main():
     total_pairs = B * args.steps * world
     value = total_pairs / elapsed if elapsed > 0 and args.steps > 0 else 0.0
 
-    flops_pair = cfg.flops_pair(s_e, T)
+    # real (unpadded) encoder lengths: padding the engine computes over is not algorithmic work
+    lens = ((ids != 0).sum(1) - 1 + cfg.vision.n_patches).tolist()
+    flops_pair = sum(cfg.flops_pair(int(l), T) for l in lens) / len(lens)
     out = {
         "metric": "image-text pairs scored/sec (whole node), " + cfg.name,
         "value": value,
@@ -147,7 +163,8 @@ def main():
         "vs_baseline": None,
         "dtype": "bf16",
         "data": "synthetic (seeded 224x224 uint8 images resized to 336, seeded token ids, seeded random weights)",
-        "config": {"workload": f"{cfg.name} bf16, batch={B} synthetic 224x224 + 32-tok prompts per GPU per step",
+        "config": {"workload": f"{cfg.name} bf16, batch={B} synthetic 224x224 + "
+                               + ("ragged 41-73-tok prompts (padded, masked)" if args.ragged else "32-tok prompts") + " per GPU per step",
                    "pairs_per_gpu_per_step": B, "encoder_len": s_e, "decoder_len": T,
                    "parallelism": f"replica x{world} (pairs sharded, RCCL all_gather of scores)"},
         # FLOPs of the REFERENCE algorithm (SURVEY.md §8d formula).  The engine's reassociated decoder
@@ -160,10 +177,21 @@ def main():
     }
     if n_gemm > 0 and gemm_ms > 0:
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12
-        out["roofline"] = {"kernel": "vqs::gemm_bf16_persistent", "bound": "mfma", "achieved": achieved,
+        out["roofline"] = {"kernel": "vqs::gemm_bf16_persistent / gemm_bf16_pingpong (every GEMM launch of the step)",
+                           "bound": "mfma", "achieved": achieved,
                            "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
                            "traffic": None, "launches": n_gemm, "avg_launch_ms": gemm_ms / n_gemm,
+                           "avg_launch_tflop": gemm_flops / n_gemm / 1e12,
+                           "algorithmic_bytes_per_launch": gemm_bytes / n_gemm,
                            "gemm_share_of_step_time": gemm_ms * 1e-3 / elapsed}
+        # HBM-side bytes per GEMM launch: PMC counters cannot be read from inside the process; they come from the
+        # committed rocprofv3 --pmc passes over this same command (tools/gpu_pmc_bench.sh -> profiles/*gemm_traffic.json)
+        tpath = os.path.join(ROOT, "profiles", "gemm_traffic_%s_b%d.json" % (cfg.name.replace("clip-flant5-", ""), B))
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                tj = json.load(f)
+            out["roofline"]["traffic"] = tj["traffic_bytes_per_launch"]
+            out["roofline"]["traffic_unit"] = "bytes per launch (HBM-side: 2 x FETCH_SIZE + WRITE_SIZE), from " + os.path.basename(tpath)
 
     if rank == 0 and world == 1 and args.cpu_pairs > 0:
         out["cpu_baseline"] = cpu_baseline(cfg, weights, pixels, img_index, ids, labels, args.cpu_pairs, lp)

@@ -118,6 +118,9 @@ int64_t vqs_workspace_offset(const vqs_handle* h, const char* name, int32_t B, i
  * reset, and fills total GEMM milliseconds and total algorithmic GEMM FLOPs (2*M*N*K). */
 int vqs_profile_enable(vqs_handle* h, int32_t on);
 int vqs_profile_read(vqs_handle* h, double* gemm_ms, double* gemm_flops, int32_t reset);
+/* Algorithmic bytes (operands read once + results written once) of the GEMM launches since the last reset;
+ * call before the resetting vqs_profile_read. */
+int vqs_profile_bytes(vqs_handle* h, double* gemm_bytes);
 
 /* ---- single-kernel entry points (parity tests and micro-benchmarks call the kernels through these) ---- */
 /* epilogue: 0 bf16, 1 bf16+quick_gelu, 2 bf16+erf-gelu, 3 fp32, 4 fp32 + residual, 5 gated gelu_new (W rows

@@ -53,6 +53,11 @@ __device__ __forceinline__ float a_max3(float a, float b, float c) {
     return r;
 }
 
+// Lab-only ablations (tools/attn_lab.sh): 1 = no K/V staging after the first tile, 2 = no softmax math (P = S), 4 = no PV MFMAs
+#ifndef VQS_ATTN_ABLATE
+#define VQS_ATTN_ABLATE 0
+#endif
+
 static constexpr int KT = 64;            // keys per tile
 static constexpr int VT_LD = 136;        // bytes per V^T row (64 keys * 2 B + 8 B pad)
 static constexpr int K_LDS = KT * 128;   // 8192
@@ -158,8 +163,10 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnParams p) {
     if (ntiles > 0) load_tile(0);
     for (int kt = 0; kt < ntiles; ++kt) {
         __syncthreads();                 // previous tile's LDS reads are done (also covers bias_s fill)
-        write_tile();
-        if (kt + 1 < ntiles) load_tile(kt + 1);
+        if (!(VQS_ATTN_ABLATE & 1) || kt == 0) {
+            write_tile();
+            if (kt + 1 < ntiles) load_tile(kt + 1);
+        }
         __syncthreads();
 
         // ---- S^T = K . Q^T   (i <-> key, j <-> query)
@@ -183,6 +190,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnParams p) {
                                                                     __builtin_bit_cast(bf16x8, qf[ks]), s[kf], 0, 0, 0);
         }
 
+#if !(VQS_ATTN_ABLATE & 2)
         // ---- scale + bias (+ mask on the ragged last tile), running max with deferred rescale
         const int kb = kt * KT;
         // element (kf, r) is key kb + kf*32 + (r&3) + 8*(r>>2) + 4*hh: table index = that - query + S-1
@@ -241,6 +249,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnParams p) {
                 l_run += pv;
             }
 
+#endif
         // ---- O^T += V^T . P^T   (i <-> d, j <-> query, k-slot (half,j) <-> key 16t + 4*half + 8*(j>>2) + (j&3))
 #pragma unroll
         for (int kf = 0; kf < 2; ++kf)
@@ -258,8 +267,12 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnParams p) {
                     const uint2 hi = *reinterpret_cast<const uint2*>(vp + 16);
                     uint4 va;
                     va.x = lo.x; va.y = lo.y; va.z = hi.x; va.w = hi.y;
+#if (VQS_ATTN_ABLATE & 4)
+                    asm volatile("" ::"v"(va.x), "v"(va.y), "v"(va.z), "v"(va.w), "v"(pb.x), "v"(pb.y), "v"(pb.z), "v"(pb.w));
+#else
                     o[df] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, va),
                                                                    __builtin_bit_cast(bf16x8, pb), o[df], 0, 0, 0);
+#endif
                 }
             }
     }

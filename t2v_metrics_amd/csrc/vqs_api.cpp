@@ -46,6 +46,7 @@ struct vqs_handle {
     std::vector<hipEvent_t> ev;
     size_t ev_used = 0;
     double prof_flops = 0.0;
+    double prof_bytes = 0.0;   // algorithmic operand + result bytes of the profiled GEMM launches
 };
 
 namespace {
@@ -260,6 +261,11 @@ int run_gemm(vqs_handle* h, const GemmCall& g, hipStream_t st, const char* what)
         HIPCHK(h, hipEventRecord(h->ev[h->ev_used + 1], st), "hipEventRecord");
         h->ev_used += 2;
         h->prof_flops += 2.0 * (double)g.M * (double)g.N * (double)g.K * (double)g.batch;
+        {   // every operand read once, every result written once
+            const double out_b = (g.epi == vqs::EPI_F32 || g.epi == vqs::EPI_F32_RESID) ? 4.0 : 2.0;
+            const double out_n = (g.epi == vqs::EPI_GATED) ? 0.5 * (double)g.N : (double)g.N;
+            h->prof_bytes += (double)g.batch * (2.0 * ((double)g.M + (double)g.N) * (double)g.K + out_b * (double)g.M * out_n);
+        }
     }
     return VQS_OK;
 }
@@ -753,8 +759,15 @@ int vqs_profile_read(vqs_handle* h, double* gemm_ms, double* gemm_flops, int32_t
     if (reset) {
         h->ev_used = 0;
         h->prof_flops = 0.0;
+        h->prof_bytes = 0.0;
     }
     return n;
+}
+
+int vqs_profile_bytes(vqs_handle* h, double* gemm_bytes) {
+    if (!h || !gemm_bytes) return VQS_ERR_INVALID;
+    *gemm_bytes = h->prof_bytes;
+    return VQS_OK;
 }
 
 // ---------------------------------------------------------------------------- single-kernel entry points

@@ -52,6 +52,7 @@ _SIGNATURES = {
     "vqs_workspace_offset": (_c_i64, [_c_vp, ctypes.c_char_p, _c_i32, _c_i32, _c_i32, ctypes.POINTER(_c_i64)]),
     "vqs_profile_enable": (_c_i32, [_c_vp, _c_i32]),
     "vqs_profile_read": (_c_i32, [_c_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), _c_i32]),
+    "vqs_profile_bytes": (_c_i32, [_c_vp, ctypes.POINTER(ctypes.c_double)]),
     "vqs_gemm": (_c_i32, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp] + [_c_i32] * 10 + [_c_vp]),
     "vqs_attention": (_c_i32, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i32, _c_i32, _c_i32, _c_f32, _c_vp]),
     "vqs_decoder_attention": (_c_i32, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp] + [_c_i32] * 7 + [_c_vp]),
@@ -241,6 +242,12 @@ class VqsEngine:
         if n < 0:
             self._check(n, "vqs_profile_read")
         return n, ms.value, fl.value
+
+    def profile_bytes(self) -> float:
+        """Algorithmic bytes of the GEMM launches since the last reset (read it BEFORE a resetting profile_read)."""
+        b = ctypes.c_double(0)
+        self._check(self.lib.vqs_profile_bytes(self._h, ctypes.byref(b)), "vqs_profile_bytes")
+        return b.value
 
 
 # ---------------------------------------------------------------------- single-kernel wrappers (tests, microbench)

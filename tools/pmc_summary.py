@@ -19,3 +19,28 @@ for key, c in res.items():
     print(key)
     for cn, (v, n, dur) in c.items():
         print(f"    {cn:34s} {v:16.1f}  (n={n}, avg dur {dur/1e3:.1f} us)")
+
+# HBM-side traffic of the GEMM launches, per launch (bench.py reports it as roofline.traffic):
+#   FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-B read requests as 64 B => x2
+#   (MI355X_MICROARCH.md, "HBM"); WRITE_SIZE is taken as reported (uncalibrated there).
+import json, os
+tot = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}
+cnt = {"FETCH_SIZE": 0, "WRITE_SIZE": 0}
+for key, c in res.items():
+    if "gemm_bf16" not in key[0]:
+        continue
+    for cn in tot:
+        if cn in c:
+            v, n, dur = c[cn]
+            tot[cn] += v * n
+            cnt[cn] += n
+if cnt["FETCH_SIZE"] and cnt["WRITE_SIZE"]:
+    fetch = 2.0 * 1024.0 * tot["FETCH_SIZE"] / cnt["FETCH_SIZE"]
+    write = 1024.0 * tot["WRITE_SIZE"] / cnt["WRITE_SIZE"]
+    out = {"source": "rocprofv3 --kernel-trace --pmc (separate FETCH_SIZE / WRITE_SIZE passes) over bench.py --steps 1 --warmup 1",
+           "kernels": "vqs::gemm_bf16_* (all GEMM launches of the run)", "launches_per_pass": cnt["FETCH_SIZE"],
+           "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write, "traffic_bytes_per_launch": fetch + write,
+           "corrections": "FETCH_SIZE KiB x 1024 x 2 (gfx950 128-B requests tallied at 64 B); WRITE_SIZE KiB x 1024 as reported"}
+    with open(os.path.join(d, "gemm_traffic.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("gemm traffic per launch: fetch %.1f MB + write %.1f MB" % (fetch / 1e6, write / 1e6))
