@@ -24,6 +24,7 @@
 //   bucket bias; cross-attention over the encoder keys with the key mask), fp32 VALU math: the work is
 //   ~0.1% of the path's FLOPs and latency-bound.
 #include "vqs_kernels.h"
+#include <stdlib.h>
 
 namespace vqs {
 
@@ -70,6 +71,29 @@ __host__ __device__ __forceinline__ int bias_copy_chunks(int S) {
     return need + ((4 - (need & 15)) & 15);                  // round up to = 4 (mod 16)
 }
 
+// Table entry j goes to position j - c of copy c (c = 0..3).  Eight independent global loads per thread are in flight
+// before the first LDS store (a load-store-load chain costs a full L2 latency per 256 entries).
+__device__ __forceinline__ void fill_bias_copies(float* bias_s, const float* bt, int n, int cs4, int tid) {
+    constexpr float LOG2E = 1.4426950408889634f;
+    for (int base = 0; base < cs4 + 3; base += 2048) {
+        float bv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int j = base + tid + 256 * i;
+            bv[i] = j < n ? bt[j] * LOG2E : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int j = base + tid + 256 * i;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int jj = j - c;
+                if (jj >= 0 && jj < cs4) bias_s[c * cs4 + jj] = bv[i];
+            }
+        }
+    }
+}
+
 template <bool HAS_BIAS>
 __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -81,8 +105,17 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnParams p) {
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hh = lane >> 5;                 // lane half
-    const int b = blockIdx.z, h = blockIdx.y;
+    // XCD-aware work map (workgroup L runs on XCD L % 8): the q-blocks of one (sample, head) get consecutive slots of
+    // ONE XCD, so its K/V tiles are fetched from HBM once and re-read from that XCD's L2 -- with the natural 3-D
+    // grid the 5 q-blocks landed on 5 different XCDs and the PMC showed K/V crossing the fabric 5 times
+    // (6.9 GB per T5-XL call, 4.6 TB/s: the kernel was fabric-bound).
     const int S = p.S;
+    const int nqb = (S + 127) >> 7;
+    const int slot = blockIdx.x >> 3;
+    const int qb = slot % nqb;
+    const int g = (slot / nqb) * 8 + (blockIdx.x & 7);
+    if (g >= p.B * p.H) return;
+    const int b = g / p.H, h = g - b * p.H;
     const size_t bh = (size_t)b * p.H + h;
     const bf16_t* Q = p.q + bh * S * 64;
     const bf16_t* K = p.k + bh * S * 64;
@@ -96,16 +129,10 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnParams p) {
     // needs (table index = key - query + S-1, any alignment) are one 16-B aligned ds_read_b128 in copy (index & 3).
     // Copy stride = 4 (mod 16) chunks: the four copies of a chunk land on four different 16-B bank slots.
     const int bias_cs = bias_copy_chunks(S);      // 16-B chunks per copy
-    if (HAS_BIAS) {
-        const float* bt = p.bias_table + (size_t)h * (2 * S - 1);
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-            for (int j = tid; j < bias_cs * 4; j += 256)
-                bias_s[c * bias_cs * 4 + j] = (j + c) < 2 * S - 1 ? bt[j + c] * LOG2E : 0.0f;
-    }
+    if (HAS_BIAS) fill_bias_copies(bias_s, p.bias_table + (size_t)h * (2 * S - 1), 2 * S - 1, bias_cs * 4, tid);
     const float sl2 = p.scale * LOG2E;
 
-    const int qrow = blockIdx.x * 128 + wv * 32 + (lane & 31);
+    const int qrow = qb * 128 + wv * 32 + (lane & 31);
     const int qrow_c = min(qrow, S - 1);
     uint4 qf[4];
 #pragma unroll
@@ -293,22 +320,298 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnParams p) {
     }
 }
 
-hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
-    if (p.B <= 0 || p.H <= 0 || p.S <= 0) return hipErrorInvalidValue;
-    dim3 grid((p.S + 127) / 128, p.H, p.B), block(256);
-    size_t lds = K_LDS + VT_LDS + (p.bias_table ? (size_t)bias_copy_chunks(p.S) * 64 : 0);
+// =====================================================================================================
+// attn_fwd_dma_kernel -- same math, same MFMA operand maps and the same softmax code as attn_fwd_kernel; what changes
+// is how K and V reach the matrix pipe (tools/attn_lab.sh ablation of the kernel above, T5-XL shape: 1.80 ms total,
+// 0.57 ms of it the global->VGPR->ds_write staging with its in-register V transpose, and two barriers per tile):
+//   * K and V tiles are staged by LDS-DMA (buffer_load_dwordx4 ... lds), 4 one-KiB pieces per wave per tile, into a
+//     two-stage ring: tile kt+1 is in flight while tile kt is computed, ONE barrier per tile, no staging VALU, no
+//     ds_write, no staging VGPRs;
+//   * K image: [64 keys][128 B] rows, 16-B chunks XOR-swizzled by (key>>1)&7 on the SOURCE address (the DMA writes
+//     lane-linear), read back conflict-free with ds_read_b128 exactly as before;
+//   * V image: 8 sub-tiles [32 keys][16 d] (32-B rows, one DMA piece each).  The PV MFMA wants, per lane, 4+4
+//     consecutive keys of one d column (k-slot j <-> key 16t + 4*half + 8*(j>>2) + (j&3)): that is two
+//     ds_read_b64_tr_b16 (hardware 4x16 transpose inside each 16-lane group; semantics pinned by
+//     tools/probes/probe_tr.hip) -- V is never transposed by software.  The 128-B blocks of the odd-d sub-tiles are
+//     rotated by one so that the two 16-lane groups served together hit different bank halves.
+// =====================================================================================================
+typedef int a_v4i __attribute__((ext_vector_type(4)));
+typedef short a_v4s __attribute__((ext_vector_type(4)));
+#define A_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+__device__ __forceinline__ void a_bglds16(a_v4i rsrc, uint32_t voff, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %2, 0 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(rsrc), "s"(lds_dst));
+}
+__device__ __forceinline__ a_v4i a_make_rsrc(const void* base) {
+    const uint64_t b = (uint64_t)base;
+    a_v4i r;
+    r.x = __builtin_amdgcn_readfirstlane((uint32_t)b);
+    r.y = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32) & 0xffffu);
+    r.z = (int)0xffffffffu;
+    r.w = 0x00020000;
+    return r;
+}
+static constexpr int ST_BYTES = 16384;       // one stage: K 8 KiB + V 8 KiB
+
+template <bool HAS_BIAS>
+__global__ void __launch_bounds__(256) attn_fwd_dma_kernel(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* bias_s = reinterpret_cast<float*>(smem + 2 * ST_BYTES);
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)A_LDS_PTR(smem));
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hh = lane >> 5;
+    // XCD-aware work map (workgroup L runs on XCD L % 8): the q-blocks of one (sample, head) get consecutive slots of
+    // ONE XCD, so its K/V tiles are fetched from HBM once and re-read from that XCD's L2 -- with the natural 3-D
+    // grid the 5 q-blocks landed on 5 different XCDs and the PMC showed K/V crossing the fabric 5 times
+    // (6.9 GB per T5-XL call, 4.6 TB/s: the kernel was fabric-bound).
+    const int S = p.S;
+    const int nqb = (S + 127) >> 7;
+    const int slot = blockIdx.x >> 3;
+    const int qb = slot % nqb;
+    const int g = (slot / nqb) * 8 + (blockIdx.x & 7);
+    if (g >= p.B * p.H) return;
+    const int b = g / p.H, h = g - b * p.H;
+    const size_t bh = (size_t)b * p.H + h;
+    const bf16_t* Q = p.q + bh * S * 64;
+    const bf16_t* K = p.k + bh * S * 64;
+    const bf16_t* V = p.v + bh * S * 64;
+    const int klen = p.key_len ? min(p.key_len[b], S) : S;
+    const int ntiles = (klen + KT - 1) / KT;
+
+    constexpr float LOG2E = 1.4426950408889634f;
+    const int bias_cs = bias_copy_chunks(S);
+    if (HAS_BIAS) fill_bias_copies(bias_s, p.bias_table + (size_t)h * (2 * S - 1), 2 * S - 1, bias_cs * 4, tid);
+    const float sl2 = p.scale * LOG2E;
+
+    const int qrow = qb * 128 + wv * 32 + (lane & 31);
+    const int qrow_c = min(qrow, S - 1);
+    uint4 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+        qf[ks] = *reinterpret_cast<const uint4*>(Q + (size_t)qrow_c * 64 + 16 * ks + 8 * hh);
+
+    // ---- staging: wave wv issues K pieces wv, wv+4 (8 keys each) and V sub-tiles (kh = 0 / 1, db = wv)
+    const a_v4i rsK = a_make_rsrc(K), rsV = a_make_rsrc(V);
+    int k_row[2], v_row[2];
+    uint32_t k_col[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = 8 * (wv + 4 * j) + (lane >> 3);
+        k_row[j] = r;
+        k_col[j] = (uint32_t)(((lane & 7) ^ ((r >> 1) & 7)) << 4);
+        v_row[j] = 32 * j + 4 * (((lane >> 3) - (wv & 1)) & 7) + ((lane >> 1) & 3);
+    }
+    const uint32_t v_col = (uint32_t)((16 * wv + 8 * (lane & 1)) * 2);
+    auto stage = [&](int kt, int st) {
+        const int kb = kt * KT;
+        const uint32_t sb = lds_base + st * ST_BYTES;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            a_bglds16(rsK, (uint32_t)min(kb + k_row[j], S - 1) * 128u + k_col[j], sb + (wv + 4 * j) * 1024);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            a_bglds16(rsV, (uint32_t)min(kb + v_row[j], S - 1) * 128u + v_col, sb + 8192 + (4 * j + wv) * 1024);
+    };
+
+    f32x16 o[2];
+#pragma unroll
+    for (int df = 0; df < 2; ++df)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[df][r] = 0.0f;
+    f32x16 osum;                                  // every row = sum over keys of P[key][query] (ones . P^T)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) osum[r] = 0.0f;
+    float m_run = NEG_BIG;
+    uint4 ones;
+    ones.x = ones.y = ones.z = ones.w = 0x3f803f80u;      // bf16 1.0 x 8
+
+    const int swr = (lane >> 1) & 7;
+    const int jb = 4 * hh - qrow_c + (S - 1);
+    const char* bias_rd = reinterpret_cast<const char*>(bias_s) + (jb & 3) * bias_cs * 16 + (jb & ~3) * 4;
+    const int k_rd = (lane & 31) * 128;
+    // transpose-read addressing: 16-lane group g = lane>>4 -> (half = g>>1 = hh, d half dbl = g&1); lane tq = lane&15
+    // supplies row tq>>2, 8-B column slot tq&3 of its group's [4 keys][16 d] block
+    const int dbl = (lane >> 4) & 1, tq = lane & 15;
+    int v_rd[4];                                  // [2*t + rd]: block (4t + hh + 2rd), rotated by dbl
+#pragma unroll
+    for (int xi = 0; xi < 4; ++xi)
+        v_rd[xi] = 8192 + dbl * 1024 + (((2 * xi + hh + dbl) & 7) << 7) + (tq >> 2) * 32 + (tq & 3) * 8;
+
+    // The Q fragments must be "arrived" for the compiler BEFORE the loop: otherwise it parks its s_waitcnt vmcnt(n) for
+    // them inside the loop body, where every iteration they would also drain the next tile's in-flight DMA.
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[ks].x), "+v"(qf[ks].y), "+v"(qf[ks].z), "+v"(qf[ks].w));
+    if (ntiles > 0) stage(0, 0);
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int st = kt & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of tile kt have landed
+        __syncthreads();                                       // ... everybody's; stage st^1 is no longer read
+        if (kt + 1 < ntiles && !(VQS_ATTN_ABLATE & 1)) stage(kt + 1, st ^ 1);
+        const char* k_lds = smem + ((VQS_ATTN_ABLATE & 1) ? 0 : st) * ST_BYTES;
+
+        // ---- S^T = K . Q^T   (i <-> key, j <-> query)
+        f32x16 s[2];
+#pragma unroll
+        for (int kf = 0; kf < 2; ++kf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kf][r] = 0.0f;
+        {
+            uint4 kfr[4][2];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int kf = 0; kf < 2; ++kf)
+                    kfr[ks][kf] = *reinterpret_cast<const uint4*>(k_lds + kf * 4096 + k_rd + (((2 * ks + hh) ^ swr) << 4));
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int kf = 0; kf < 2; ++kf)
+                    s[kf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kfr[ks][kf]),
+                                                                    __builtin_bit_cast(bf16x8, qf[ks]), s[kf], 0, 0, 0);
+        }
+
+#if !(VQS_ATTN_ABLATE & 2)
+        // ---- softmax numerators.  With a bias the scores move to the log2 domain first (t = s*c + bias, c = scale*log2 e,
+        // one FMA) and p = 2^(t - m) is a subtract + v_exp_f32; without one the row max is taken on the raw scores
+        // (c > 0) and p = 2^(s*c - m) is ONE FMA + v_exp_f32.  The row SUM is not accumulated here: the PV step
+        // below gets it from the matrix pipe (an all-ones A operand), which has slack while the VALU does not.
+        const int kb = kt * KT;
+        if (HAS_BIAS) {
+            const char* bp = bias_rd + kb * 4;
+#pragma unroll
+            for (int kf = 0; kf < 2; ++kf)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 bv = *reinterpret_cast<const float4*>(bp + kf * 128 + g * 32);
+                    s[kf][4 * g + 0] = fmaf(s[kf][4 * g + 0], sl2, bv.x);
+                    s[kf][4 * g + 1] = fmaf(s[kf][4 * g + 1], sl2, bv.y);
+                    s[kf][4 * g + 2] = fmaf(s[kf][4 * g + 2], sl2, bv.z);
+                    s[kf][4 * g + 3] = fmaf(s[kf][4 * g + 3], sl2, bv.w);
+                }
+        }
+        if (kb + KT > klen) {                       // wave-uniform: only the last tile of a sample is ragged
+#pragma unroll
+            for (int kf = 0; kf < 2; ++kf)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kb + kf * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    if (key >= klen) s[kf][r] = NEG_BIG;
+                }
+        }
+#define VQS_SV(i) s[(i) >> 4][(i) & 15]
+        float mx = a_max3(VQS_SV(0), VQS_SV(1), VQS_SV(2));
+#pragma unroll
+        for (int i = 3; i < 31; i += 2) mx = a_max3(mx, VQS_SV(i), VQS_SV(i + 1));
+        mx = fmaxf(mx, VQS_SV(31));
+#undef VQS_SV
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        if (!HAS_BIAS) mx *= sl2;                   // to the log2 domain (scale > 0)
+        // keep the old running max while the new one is at most 2^RESCALE_THR above it; rescale only on a real jump
+        if (__any(mx > m_run + RESCALE_THR)) {
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                o[0][r] *= alpha;
+                o[1][r] *= alpha;
+                osum[r] *= alpha;
+            }
+        }
+        const float neg_m = -m_run;
+#pragma unroll
+        for (int kf = 0; kf < 2; ++kf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                s[kf][r] = __builtin_amdgcn_exp2f(HAS_BIAS ? s[kf][r] + neg_m : fmaf(s[kf][r], sl2, neg_m));
+#endif
+        // ---- O^T += V^T . P^T   (i <-> d, j <-> query, k-slot (half,j) <-> key 16t + 4*half + 8*(j>>2) + (j&3))
+#pragma unroll
+        for (int kf = 0; kf < 2; ++kf)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                uint4 pb;
+                pb.x = a_pack2(s[kf][8 * t + 0], s[kf][8 * t + 1]);
+                pb.y = a_pack2(s[kf][8 * t + 2], s[kf][8 * t + 3]);
+                pb.z = a_pack2(s[kf][8 * t + 4], s[kf][8 * t + 5]);
+                pb.w = a_pack2(s[kf][8 * t + 6], s[kf][8 * t + 7]);
+                osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, pb),
+                                                                osum, 0, 0, 0);
+#pragma unroll
+                for (int df = 0; df < 2; ++df) {
+                    const char* vp = k_lds + kf * 4096 + df * 2048;
+                    const a_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) a_v4s*)A_LDS_PTR(vp + v_rd[2 * t + 0]));
+                    const a_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) a_v4s*)A_LDS_PTR(vp + v_rd[2 * t + 1]));
+                    const uint2 lo2 = __builtin_bit_cast(uint2, lo), hi2 = __builtin_bit_cast(uint2, hi);
+                    uint4 va;
+                    va.x = lo2.x; va.y = lo2.y; va.z = hi2.x; va.w = hi2.y;
+                    o[df] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, va),
+                                                                   __builtin_bit_cast(bf16x8, pb), o[df], 0, 0, 0);
+                }
+            }
+    }
+
+    const float l_tot = osum[0];                  // all 32 rows of the ones-product are the same row sum
+    const float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
+    if (qrow < S) {
+        bf16_t* orow = p.out + ((size_t)b * S + qrow) * ((size_t)p.H * 64) + h * 64;
+#pragma unroll
+        for (int df = 0; df < 2; ++df)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 v;
+                v.x = a_pack2(o[df][4 * g + 0] * inv, o[df][4 * g + 1] * inv);
+                v.y = a_pack2(o[df][4 * g + 2] * inv, o[df][4 * g + 3] * inv);
+                *reinterpret_cast<uint2*>(orow + df * 32 + 8 * g + 4 * hh) = v;
+            }
+    }
+}
+
+
+static int attn_variant() {       // VQS_ATTN_VARIANT=0 selects the register-staged kernel (lab A/B); default = LDS-DMA kernel
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("VQS_ATTN_VARIANT");
+        v = e ? atoi(e) : 1;
+    }
+    return v;
+}
+
+template <typename KernelT>
+static hipError_t launch_attn_t(KernelT kern, const AttnParams& p, size_t lds, hipStream_t stream) {
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (lds > 65536) {
-        hipError_t e = p.bias_table
-            ? hipFuncSetAttribute((const void*)attn_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-            : hipFuncSetAttribute((const void*)attn_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    if (p.bias_table)
-        hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, block, lds, stream, p);
-    else
-        hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, block, lds, stream, p);
+    const int nqb = (p.S + 127) / 128, G = p.B * p.H;
+    dim3 grid(((G + 7) / 8) * 8 * nqb), block(256);
+    hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
     return hipGetLastError();
+}
+
+hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
+    if (p.B <= 0 || p.H <= 0 || p.S <= 0) return hipErrorInvalidValue;
+    const size_t bias_bytes = p.bias_table ? (size_t)bias_copy_chunks(p.S) * 64 : 0;
+    if (attn_variant() == 0) {
+        const size_t lds = K_LDS + VT_LDS + bias_bytes;
+        return p.bias_table ? launch_attn_t(attn_fwd_kernel<true>, p, lds, stream) : launch_attn_t(attn_fwd_kernel<false>, p, lds, stream);
+    }
+    const size_t lds = 2 * ST_BYTES + bias_bytes;
+    return p.bias_table ? launch_attn_t(attn_fwd_dma_kernel<true>, p, lds, stream)
+                        : launch_attn_t(attn_fwd_dma_kernel<false>, p, lds, stream);
 }
 
 // =====================================================================================================
