@@ -139,6 +139,8 @@ def main():
     eng.profile(False)
     gemm_bytes = eng.profile_bytes()
     n_gemm, gemm_ms, gemm_flops = eng.profile_read(reset=True)
+    if rank == 0 and os.environ.get("VQS_BENCH_REPORT"):
+        print(eng.profile_report(), file=sys.stderr, flush=True)
 
     t_el = torch.tensor([elapsed], device=device, dtype=torch.float64)
     if dist is not None:

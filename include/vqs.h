@@ -106,6 +106,13 @@ int vqs_score(vqs_handle* h, const void* d_feats, const int32_t* d_img_index, co
               const int32_t* d_labels, int32_t B, int32_t L, int32_t T, float* d_label_logprobs, float* d_scores,
               void* d_ws, size_t ws_bytes, void* stream);
 
+/* Greedy decoding for `model.generate` (/root/reference/V_3.0_README.md:316-325; HF GenerationMixin greedy search over
+ * T5ForConditionalGeneration, decoder_start_token_id = pad = 0): encoder once, then max_new (<= 16) decoder steps, each
+ * appending argmax(logits) to d_tokens (int32 [B, max_new], device).  Every step is executed (no host sync); the caller
+ * cuts each row at its first EOS (id 1).  Workspace: vqs_score_workspace_bytes(h, B, L, max_new). */
+int vqs_generate(vqs_handle* h, const void* d_feats, const int32_t* d_img_index, const int32_t* d_input_ids, int32_t B,
+                 int32_t L, int32_t max_new, int32_t* d_tokens, void* d_ws, size_t ws_bytes, void* stream);
+
 /* Byte offset of a named intermediate inside the vqs_score / vqs_encode_images workspace (parity tests read
  * stages through this): "enc_in" fp32 [B,S_e,D], "enc_out" bf16 [B,S_e,D], "logits" fp32 [B*T, ld],
  * "vit_hidden" fp32 [n_img, 1+P, hidden] (patch rows = hidden_states[-2]; CLS row lags one sub-layer), "enc_len" int32 [B], "flags" int32[1] (bit0 = malformed prompt).
@@ -121,6 +128,8 @@ int vqs_profile_read(vqs_handle* h, double* gemm_ms, double* gemm_flops, int32_t
 /* Algorithmic bytes (operands read once + results written once) of the GEMM launches since the last reset;
  * call before the resetting vqs_profile_read. */
 int vqs_profile_bytes(vqs_handle* h, double* gemm_bytes);
+/* Text table (one line per GEMM call site: launches, ms, TFLOP/s) of the launches covered by the last vqs_profile_read. */
+const char* vqs_profile_report(vqs_handle* h);
 
 /* ---- single-kernel entry points (parity tests and micro-benchmarks call the kernels through these) ---- */
 /* epilogue: 0 bf16, 1 bf16+quick_gelu, 2 bf16+erf-gelu, 3 fp32, 4 fp32 + residual, 5 gated gelu_new (W rows

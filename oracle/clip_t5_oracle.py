@@ -311,3 +311,28 @@ class Oracle:
         if return_stages:
             out.update(vit_feats=feats, proj=proj, enc_in=emb, enc_mask=mask, enc_out=enc, dec_out=dec, logits=logits)
         return out
+
+    def generate(self, pixel_values: torch.Tensor, img_index: torch.Tensor, input_ids: torch.Tensor, max_new_tokens: int,
+                 return_margins: bool = False):
+        """Greedy search as HF GenerationMixin runs it for T5ForConditionalGeneration (generation/utils.py greedy branch:
+        decoder_start_token_id = 0, next token = argmax of the last position's logits, no KV cache needed for the
+        arithmetic).  Returns int64 [B, max_new_tokens] WITHOUT the start token and without EOS truncation; with
+        return_margins also the top-1 minus top-2 logit gap of every step (tests skip near-ties)."""
+        t = self.cfg.t5
+        with torch.no_grad():
+            feats = self.vision_features(pixel_values)
+            proj = self.projector(feats)
+            emb, mask, lens = self.splice(proj, img_index, input_ids)
+            enc = self.t5_encoder(emb, mask)
+            B = input_ids.shape[0]
+            dec_ids = torch.full((B, 1), t.decoder_start_id, dtype=torch.long)
+            margins = []
+            for _ in range(max_new_tokens):
+                logits = self.lm_logits(self.t5_decoder(dec_ids, enc, mask))[:, -1]
+                top2 = logits.topk(2, dim=-1).values
+                margins.append(top2[:, 0] - top2[:, 1])
+                dec_ids = torch.cat([dec_ids, logits.argmax(-1, keepdim=True)], dim=1)
+        if return_margins:
+            return dec_ids[:, 1:], torch.stack(margins, dim=1)
+        return dec_ids[:, 1:]
+

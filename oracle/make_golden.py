@@ -184,6 +184,56 @@ def golden_e2e(name: str, seed: int, n_img: int, B: int, L: int, T: int, gain: f
           "logP range", float(lp32.min()), float(lp32.max()))
 
 
+def golden_generate(name: str, seed: int, n_img: int, B: int, L: int, max_new: int, gain: float):
+    """HF greedy search: T5ForConditionalGeneration.generate(inputs_embeds, attention_mask, max_new_tokens, do_sample=False)
+    on the spliced embeddings (fp32 modules, bf16-rounded weights).  Stores the generated ids (HF pads finished rows with 0
+    after EOS) and, from a teacher-forced re-run over those ids, the top-1/top-2 logit gap of every step."""
+    cfg = get_config(name)
+    w = make_seeded_weights(cfg, seed=seed, device="cpu", dtype=torch.bfloat16, lm_head_gain=gain)
+    g = torch.Generator().manual_seed(seed + 77)
+    v, t = cfg.vision, cfg.t5
+    P = v.n_patches
+    pixels = torch.randn(n_img, 3, v.image, v.image, generator=g).to(torch.bfloat16)
+    ids = torch.randint(3, t.vocab, (B, L), generator=g)
+    for b in range(B):
+        n = L if b == 0 else int(torch.randint(max(3, L // 2), L + 1, (1,), generator=g))
+        sp = int(torch.randint(0, n - 1, (1,), generator=g))
+        ids[b, sp] = -200
+        ids[b, n - 1] = t.eos_id
+        ids[b, n:] = 0
+    img_index = torch.randint(0, n_img, (B,), generator=g)
+    S_e = L - 1 + P
+    with torch.no_grad():
+        vm = build_hf_vision(cfg, w).float()
+        tm = build_hf_t5(cfg, w).float()
+        proj = torch.nn.Sequential(torch.nn.Linear(v.hidden, t.d_model), torch.nn.GELU(), torch.nn.Linear(t.d_model, t.d_model))
+        proj[0].weight.copy_(w["mm_projector.0.weight"]); proj[0].bias.copy_(w["mm_projector.0.bias"])
+        proj[2].weight.copy_(w["mm_projector.2.weight"]); proj[2].bias.copy_(w["mm_projector.2.bias"])
+        hs = vm(pixel_values=pixels.float(), output_hidden_states=True).hidden_states
+        feats = proj(hs[v.select_layer][:, 1:])
+        emb = torch.zeros(B, S_e, t.d_model)
+        mask = torch.zeros(B, S_e, dtype=torch.long)
+        for b in range(B):
+            row = ids[b][ids[b] != t.pad_id]
+            sp = int((row == -200).nonzero()[0, 0])
+            r = torch.cat([tm.shared(row[:sp]), feats[int(img_index[b])], tm.shared(row[sp + 1:])], 0)
+            emb[b, : r.shape[0]] = r
+            mask[b, : r.shape[0]] = 1
+        out = tm.generate(inputs_embeds=emb, attention_mask=mask, max_new_tokens=max_new, do_sample=False, num_beams=1)
+        toks = out[:, 1:]                                    # drop the decoder start token
+        if toks.shape[1] < max_new:                          # every row hit EOS early
+            toks = torch.cat([toks, torch.zeros(B, max_new - toks.shape[1], dtype=toks.dtype)], 1)
+        logits = tm(inputs_embeds=emb, attention_mask=mask, decoder_input_ids=out[:, :-1]).logits   # steps 0 .. n-1
+        top2 = logits.topk(2, dim=-1).values
+        margins = (top2[..., 0] - top2[..., 1])[:, :max_new]
+        if margins.shape[1] < max_new:
+            margins = torch.cat([margins, torch.zeros(B, max_new - margins.shape[1])], 1)
+    path = os.path.join(GOLDEN, f"generate_{name}_g{int(gain)}.npz")
+    np.savez_compressed(path, seed=seed, gain=gain, max_new=max_new, pixels=pixels.float().numpy(), ids=ids.numpy(),
+                        img_index=img_index.numpy(), tokens=toks.numpy(), margins=margins.numpy())
+    print(path, os.path.getsize(path) // 1024, "KiB tokens", toks.tolist(), "min margin %.3f" % float(margins.min()))
+
+
 def golden_preprocess():
     """HF CLIPImageProcessor (PIL backend here: no torchvision) on seeded images at a small target size."""
     from PIL import Image
@@ -212,3 +262,5 @@ if __name__ == "__main__":
     golden_e2e("tiny", seed=22, n_img=3, B=8, L=12, T=2, gain=4.0)
     golden_e2e("small", seed=23, n_img=2, B=6, L=20, T=2, gain=1.0)
     golden_e2e("small", seed=24, n_img=2, B=6, L=20, T=2, gain=4.0)
+    golden_generate("tiny", seed=41, n_img=2, B=6, L=12, max_new=6, gain=8.0)
+    golden_generate("small", seed=42, n_img=2, B=4, L=20, max_new=5, gain=8.0)

@@ -356,13 +356,13 @@ hipError_t launch_embed_splice(const int* ids, const int* sent_pos, const int* e
 }
 
 // decoder_input_ids = shift_right(labels) (HF models/t5/modeling_t5.py:618-637); h = shared[id]
-__global__ void __launch_bounds__(256) decoder_embed_kernel(const int* __restrict__ labels,
+__global__ void __launch_bounds__(256) decoder_embed_kernel(const int* __restrict__ labels, int ld_labels,
                                                             const bf16_t* __restrict__ shared, float* __restrict__ out,
                                                             int T, int D, int vocab) {
     const int b = blockIdx.y, t = blockIdx.x;
     int id = 0;                                          // decoder_start_token_id = pad = 0
     if (t > 0) {
-        id = labels[(size_t)b * T + t - 1];
+        id = labels[(size_t)b * ld_labels + t - 1];
         if (id == -100) id = 0;
         id = min(max(id, 0), vocab - 1);
     }
@@ -371,9 +371,45 @@ __global__ void __launch_bounds__(256) decoder_embed_kernel(const int* __restric
     for (int i = threadIdx.x; i < D; i += 256) orow[i] = e_bf2f(src[i]);
 }
 
-hipError_t launch_decoder_embed(const int* labels, const bf16_t* shared, float* out, int B, int T, int D, int vocab,
+hipError_t launch_decoder_embed(const int* labels, int ld_labels, const bf16_t* shared, float* out, int B, int T, int D,
+                                int vocab, hipStream_t s) {
+    hipLaunchKernelGGL(decoder_embed_kernel, dim3(T, B), dim3(256), 0, s, labels, ld_labels, shared, out, T, D, vocab);
+    return hipGetLastError();
+}
+
+// Greedy step of vqs_generate: tokens[b, T-1] = argmax_v logits[(b*T + T-1), v] (lowest index on ties, as torch.argmax)
+__global__ void __launch_bounds__(256) argmax_append_kernel(const float* __restrict__ logits, int ldl, int V,
+                                                            int* __restrict__ tokens, int ld_tokens, int T) {
+    __shared__ float s_val[256];
+    __shared__ int s_idx[256];
+    const int b = blockIdx.x;
+    const float* row = logits + ((size_t)b * T + (T - 1)) * ldl;
+    float best = -3.0e38f;
+    int bi = 0;
+    for (int v = threadIdx.x; v < V; v += 256) {
+        const float x = row[v];
+        if (x > best) { best = x; bi = v; }
+    }
+    s_val[threadIdx.x] = best;
+    s_idx[threadIdx.x] = bi;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            const float o = s_val[threadIdx.x + off];
+            const int oi = s_idx[threadIdx.x + off];
+            if (o > s_val[threadIdx.x] || (o == s_val[threadIdx.x] && oi < s_idx[threadIdx.x])) {
+                s_val[threadIdx.x] = o;
+                s_idx[threadIdx.x] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tokens[(size_t)b * ld_tokens + (T - 1)] = s_idx[0];
+}
+
+hipError_t launch_argmax_append(const float* logits, int ldl, int V, int* tokens, int ld_tokens, int B, int T,
                                 hipStream_t s) {
-    hipLaunchKernelGGL(decoder_embed_kernel, dim3(T, B), dim3(256), 0, s, labels, shared, out, T, D, vocab);
+    hipLaunchKernelGGL(argmax_append_kernel, dim3(B), dim3(256), 0, s, logits, ldl, V, tokens, ld_tokens, T);
     return hipGetLastError();
 }
 

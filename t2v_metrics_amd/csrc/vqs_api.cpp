@@ -17,6 +17,8 @@
 #include <string>
 #include <unordered_map>
 #include <vector>
+#include <map>
+#include <array>
 
 using vqs::bf16_t;
 
@@ -45,6 +47,8 @@ struct vqs_handle {
     bool prof = false;
     std::vector<hipEvent_t> ev;
     size_t ev_used = 0;
+    std::vector<std::pair<std::string, double>> ev_what;   // per profiled GEMM launch: call-site label, FLOPs
+    std::string prof_report;
     double prof_flops = 0.0;
     double prof_bytes = 0.0;   // algorithmic operand + result bytes of the profiled GEMM launches
 };
@@ -260,6 +264,7 @@ int run_gemm(vqs_handle* h, const GemmCall& g, hipStream_t st, const char* what)
     if (h->prof) {
         HIPCHK(h, hipEventRecord(h->ev[h->ev_used + 1], st), "hipEventRecord");
         h->ev_used += 2;
+        h->ev_what.emplace_back(what, 2.0 * (double)g.M * (double)g.N * (double)g.K * (double)g.batch);
         h->prof_flops += 2.0 * (double)g.M * (double)g.N * (double)g.K * (double)g.batch;
         {   // every operand read once, every result written once
             const double out_b = (g.epi == vqs::EPI_F32 || g.epi == vqs::EPI_F32_RESID) ? 4.0 : 2.0;
@@ -530,34 +535,23 @@ size_t vqs_score_workspace_bytes(const vqs_handle* h, int32_t B, int32_t L, int3
     return carve_score(h, nullptr, B, L, T).total;
 }
 
-int vqs_score(vqs_handle* h, const void* d_feats, const int32_t* d_img_index, const int32_t* d_input_ids,
-              const int32_t* d_labels, int32_t B, int32_t L, int32_t T, float* d_lp, float* d_scores, void* d_ws,
-              size_t ws_bytes, void* stream) {
-    if (!h) return VQS_ERR_INVALID;
-    if (!h->bound) return fail(h, VQS_ERR_STATE, "score: weights not bound");
-    if (!d_feats || !d_img_index || !d_input_ids || !d_labels || !d_lp || !d_scores || !d_ws)
-        return fail(h, VQS_ERR_INVALID, "score: null argument");
-    if (B <= 0 || L < 1 || T <= 0 || T > 16) return fail(h, VQS_ERR_INVALID, "score: need B>0, L>=1, 1<=T<=16");
+// Encoder half of the scoring pass: prompt scan, bias table, embed + splice, 24 encoder blocks, final norm
+// (+ the transposed copy the reassociated cross-attention reads).  Leaves enc_out / enc_outT / enc_len in the workspace.
+static int encoder_pass(vqs_handle* h, const ScoreWs& w, const void* d_feats, const int32_t* d_img_index,
+                        const int32_t* d_input_ids, int B, int L, hipStream_t st) {
+    const int T = 1;
     const vqs_config& c = h->c;
     const int P = h->P, S = L - 1 + P;
-    if (L - 1 > 2048) return fail(h, VQS_ERR_INVALID, "score: prompt longer than CONTEXT_LEN (2048)");
-    if ((size_t)(2 * S + 64) * 4 + 16896 + 16 > 65536) return fail(h, VQS_ERR_INVALID, "score: encoder length too large for the bias table");
-    const ScoreWs w = carve_score(h, (char*)d_ws, B, L, T);
-    if (ws_bytes < w.total) return fail(h, VQS_ERR_WORKSPACE, "score: workspace too small");
-    hipStream_t st = (hipStream_t)stream;
     const int D = c.d_model, I = h->I, F = c.d_ff, H = c.n_heads, V = c.vocab;
     const int M = B * S, MT = B * T;
-
+    (void)P; (void)M; (void)MT; (void)F; (void)I; (void)V;
     GETW(shared, "shared.weight", (int64_t)V * D);
     GETW(enc_rel, "encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight", (int64_t)c.rel_buckets * H);
-    GETW(dec_rel, "decoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight", (int64_t)c.rel_buckets * H);
 
     HIPCHK(h, hipMemsetAsync(w.flags, 0, 4 * sizeof(int), st), "memset flags");
     HIPCHK(h, vqs::launch_prompt_scan(d_input_ids, B, L, P, w.sent_pos, w.enc_len, w.flags, st), "prompt_scan");
     HIPCHK(h, vqs::launch_relpos_table(enc_rel, h->lut_bidir, h->lut_causal, h->lut_len, c.rel_buckets, w.enc_table, H, S,
-                                       nullptr, T, st), "encoder bias table");
-    HIPCHK(h, vqs::launch_relpos_table(dec_rel, h->lut_bidir, h->lut_causal, h->lut_len, c.rel_buckets, nullptr, H, S,
-                                       w.dec_table, T, st), "decoder bias table");
+                                       nullptr, 1, st), "encoder bias table");
     HIPCHK(h, vqs::launch_embed_splice(d_input_ids, w.sent_pos, w.enc_len, d_img_index, shared, (const bf16_t*)d_feats,
                                        w.hidden, B, L, P, D, V, st), "embed_splice");
 
@@ -607,8 +601,24 @@ int vqs_score(vqs_handle* h, const void* d_feats, const int32_t* d_img_index, co
             HIPCHK(h, vqs::launch_transpose_pad(w.enc_out, w.enc_outT, B, S, D, w.S_pad, st), "enc_out transpose");
     }
 
+    return VQS_OK;
+}
+
+// Decoder half: T teacher-forced rows per pair over the encoder output already in the workspace -> fp32 logits
+// [B*T, ldl].  d_labels[b*ld_labels + t] are the target ids (decoder input = shift_right, HF modeling_t5.py:618-637).
+static int decoder_pass(vqs_handle* h, const ScoreWs& w, const int32_t* d_labels, int ld_labels, int B, int L, int T,
+                        hipStream_t st) {
+    const vqs_config& c = h->c;
+    const int P = h->P, S = L - 1 + P;
+    const int D = c.d_model, I = h->I, F = c.d_ff, H = c.n_heads, V = c.vocab;
+    const int M = B * S, MT = B * T;
+    (void)P; (void)M; (void)MT; (void)F; (void)I; (void)V;
     // ---------------- decoder (teacher forced, T rows per pair)
-    HIPCHK(h, vqs::launch_decoder_embed(d_labels, shared, w.dhid, B, T, D, V, st), "decoder embed");
+    GETW(shared, "shared.weight", (int64_t)V * D);
+    GETW(dec_rel, "decoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight", (int64_t)c.rel_buckets * H);
+    HIPCHK(h, vqs::launch_relpos_table(dec_rel, h->lut_bidir, h->lut_causal, h->lut_len, c.rel_buckets, nullptr, H, S,
+                                       w.dec_table, T, st), "decoder bias table");
+    HIPCHK(h, vqs::launch_decoder_embed(d_labels, ld_labels, shared, w.dhid, B, T, D, V, st), "decoder embed");
     const bf16_t* dpend = nullptr;
     for (int i = 0; i < c.dec_layers; ++i) {
         const std::string p = "decoder.block." + std::to_string(i) + ".";
@@ -712,7 +722,54 @@ int vqs_score(vqs_handle* h, const void* d_feats, const int32_t* d_img_index, co
         g.M = MT; g.N = V; g.K = D; g.lda = D; g.ldw = D; g.ldc = w.ldl; g.epi = vqs::EPI_F32;
         RUN(run_gemm(h, g, st, "lm_head"));
     }
+    return VQS_OK;
+}
+
+int vqs_score(vqs_handle* h, const void* d_feats, const int32_t* d_img_index, const int32_t* d_input_ids,
+              const int32_t* d_labels, int32_t B, int32_t L, int32_t T, float* d_lp, float* d_scores, void* d_ws,
+              size_t ws_bytes, void* stream) {
+    if (!h) return VQS_ERR_INVALID;
+    if (!h->bound) return fail(h, VQS_ERR_STATE, "score: weights not bound");
+    if (!d_feats || !d_img_index || !d_input_ids || !d_labels || !d_lp || !d_scores || !d_ws)
+        return fail(h, VQS_ERR_INVALID, "score: null argument");
+    if (B <= 0 || L < 1 || T <= 0 || T > 16) return fail(h, VQS_ERR_INVALID, "score: need B>0, L>=1, 1<=T<=16");
+    const vqs_config& c = h->c;
+    const int P = h->P, S = L - 1 + P;
+    if (L - 1 > 2048) return fail(h, VQS_ERR_INVALID, "score: prompt longer than CONTEXT_LEN (2048)");
+    if ((size_t)(2 * S + 96) * 16 + 32768 > 160 * 1024) return fail(h, VQS_ERR_INVALID, "score: encoder length too large for the attention kernel's bias tables");
+    const ScoreWs w = carve_score(h, (char*)d_ws, B, L, T);
+    if (ws_bytes < w.total) return fail(h, VQS_ERR_WORKSPACE, "score: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int V = c.vocab;
+
+    RUN(encoder_pass(h, w, d_feats, d_img_index, d_input_ids, B, L, st));
+    RUN(decoder_pass(h, w, d_labels, T, B, L, T, st));
     HIPCHK(h, vqs::launch_score_head(w.logits, w.ldl, V, d_labels, d_lp, d_scores, B, T, st), "score head");
+    return VQS_OK;
+}
+
+
+// Greedy decoding (the reference's `model.generate`, V_3.0_README.md:316-325; HF GenerationMixin greedy search with
+// T5's decoder_start_token_id = pad = 0): the encoder runs once, then step t re-runs the teacher-forced decoder over
+// the t+1 rows decoded so far (no KV cache: the decoder is ~4 % of a scoring pass and generation is off the hot path)
+// and appends argmax(logits[row t]).  No host synchronisation; all max_new steps are executed, the caller truncates
+// at the first EOS.  d_tokens: int32 [B, max_new].
+int vqs_generate(vqs_handle* h, const void* d_feats, const int32_t* d_img_index, const int32_t* d_input_ids, int32_t B,
+                 int32_t L, int32_t max_new, int32_t* d_tokens, void* d_ws, size_t ws_bytes, void* stream) {
+    if (!h) return VQS_ERR_INVALID;
+    if (!h->bound) return fail(h, VQS_ERR_STATE, "generate: weights not bound");
+    if (!d_feats || !d_img_index || !d_input_ids || !d_tokens || !d_ws) return fail(h, VQS_ERR_INVALID, "generate: null argument");
+    if (B <= 0 || L < 1 || max_new <= 0 || max_new > 16) return fail(h, VQS_ERR_INVALID, "generate: need B>0, L>=1, 1<=max_new<=16");
+    if (L - 1 > 2048) return fail(h, VQS_ERR_INVALID, "generate: prompt longer than CONTEXT_LEN (2048)");
+    const ScoreWs w = carve_score(h, (char*)d_ws, B, L, max_new);
+    if (ws_bytes < w.total) return fail(h, VQS_ERR_WORKSPACE, "generate: workspace too small (size it with vqs_score_workspace_bytes(B, L, max_new))");
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(h, hipMemsetAsync(d_tokens, 0, (size_t)B * max_new * sizeof(int32_t), st), "memset tokens");
+    RUN(encoder_pass(h, w, d_feats, d_img_index, d_input_ids, B, L, st));
+    for (int t = 0; t < max_new; ++t) {
+        RUN(decoder_pass(h, w, d_tokens, max_new, B, L, t + 1, st));
+        HIPCHK(h, vqs::launch_argmax_append(w.logits, w.ldl, h->c.vocab, d_tokens, max_new, B, t + 1, st), "argmax");
+    }
     return VQS_OK;
 }
 
@@ -747,22 +804,37 @@ int vqs_profile_enable(vqs_handle* h, int32_t on) {
 int vqs_profile_read(vqs_handle* h, double* gemm_ms, double* gemm_flops, int32_t reset) {
     if (!h) return VQS_ERR_INVALID;
     double ms = 0.0;
+    std::map<std::string, std::array<double, 3>> by;      // label -> {launches, ms, flops}
     for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
         HIPCHK(h, hipEventSynchronize(h->ev[i + 1]), "hipEventSynchronize");
         float t = 0.f;
         HIPCHK(h, hipEventElapsedTime(&t, h->ev[i], h->ev[i + 1]), "hipEventElapsedTime");
         ms += t;
+        if (i / 2 < h->ev_what.size()) {
+            auto& a = by[h->ev_what[i / 2].first];
+            a[0] += 1.0; a[1] += t; a[2] += h->ev_what[i / 2].second;
+        }
+    }
+    h->prof_report.clear();
+    for (const auto& kv : by) {
+        char line[256];
+        snprintf(line, sizeof line, "%-20s launches %6.0f  ms %10.3f  TFLOP/s %8.1f\n", kv.first.c_str(), kv.second[0], kv.second[1],
+                 kv.second[1] > 0 ? kv.second[2] / kv.second[1] / 1e9 : 0.0);
+        h->prof_report += line;
     }
     if (gemm_ms) *gemm_ms = ms;
     if (gemm_flops) *gemm_flops = h->prof_flops;
     const int n = (int)(h->ev_used / 2);
     if (reset) {
         h->ev_used = 0;
+        h->ev_what.clear();
         h->prof_flops = 0.0;
         h->prof_bytes = 0.0;
     }
     return n;
 }
+
+const char* vqs_profile_report(vqs_handle* h) { return h ? h->prof_report.c_str() : ""; }
 
 int vqs_profile_bytes(vqs_handle* h, double* gemm_bytes) {
     if (!h || !gemm_bytes) return VQS_ERR_INVALID;

@@ -89,7 +89,9 @@ hipError_t launch_embed_splice(const int* ids, const int* sent_pos, const int* e
                                const bf16_t* shared, const bf16_t* proj, float* out, int B, int L, int P, int D,
                                int vocab, hipStream_t s);
 // decoder_input_ids = shift_right(labels); h[b,t] = shared[id]  (fp32 out)
-hipError_t launch_decoder_embed(const int* labels, const bf16_t* shared, float* out, int B, int T, int D, int vocab,
+hipError_t launch_decoder_embed(const int* labels, int ld_labels, const bf16_t* shared, float* out, int B, int T, int D,
+                                int vocab, hipStream_t s);
+hipError_t launch_argmax_append(const float* logits, int ldl, int V, int* tokens, int ld_tokens, int B, int T,
                                 hipStream_t s);
 // bias tables from the [buckets,H] bf16 embedding and a host-computed bucket LUT
 hipError_t launch_relpos_table(const bf16_t* rel_weight, const int* bucket_lut_bidir, const int* bucket_lut_causal,

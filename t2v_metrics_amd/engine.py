@@ -50,9 +50,11 @@ _SIGNATURES = {
     "vqs_score_workspace_bytes": (_c_sz, [_c_vp, _c_i32, _c_i32, _c_i32]),
     "vqs_score": (_c_i32, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i32, _c_i32, _c_i32, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),
     "vqs_workspace_offset": (_c_i64, [_c_vp, ctypes.c_char_p, _c_i32, _c_i32, _c_i32, ctypes.POINTER(_c_i64)]),
+    "vqs_generate": (_c_i32, [_c_vp, _c_vp, _c_vp, _c_vp, _c_i32, _c_i32, _c_i32, _c_vp, _c_vp, _c_sz, _c_vp]),
     "vqs_profile_enable": (_c_i32, [_c_vp, _c_i32]),
     "vqs_profile_read": (_c_i32, [_c_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), _c_i32]),
     "vqs_profile_bytes": (_c_i32, [_c_vp, ctypes.POINTER(ctypes.c_double)]),
+    "vqs_profile_report": (ctypes.c_char_p, [_c_vp]),
     "vqs_gemm": (_c_i32, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp] + [_c_i32] * 10 + [_c_vp]),
     "vqs_attention": (_c_i32, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i32, _c_i32, _c_i32, _c_f32, _c_vp]),
     "vqs_decoder_attention": (_c_i32, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp] + [_c_i32] * 7 + [_c_vp]),
@@ -204,6 +206,30 @@ class VqsEngine:
             self._check(rc, "vqs_score")
             return lp, sc
 
+    def generate(self, feats: torch.Tensor, img_index: torch.Tensor, input_ids: torch.Tensor,
+                 max_new_tokens: int = 16) -> torch.Tensor:
+        """Greedy decoding -> int32 [B, max_new_tokens] on the device (every step executed; cut at the first EOS = 1 on
+        the host).  max_new_tokens <= 16."""
+        with torch.cuda.device(self.device):
+            B, L = input_ids.shape
+            if img_index.shape[0] != B:
+                raise VqsError("img_index and input_ids must agree on the batch size")
+            ids = input_ids.to(device=self.device, dtype=torch.int32).contiguous()
+            idx = img_index.to(device=self.device, dtype=torch.int32).contiguous()
+            feats = feats.contiguous()
+            tokens = torch.empty(B, max_new_tokens, dtype=torch.int32, device=self.device)
+            need = self.lib.vqs_score_workspace_bytes(self._h, B, L, max_new_tokens)
+            if need == 0:
+                raise VqsError(f"unsupported generate shape B={B} L={L} max_new_tokens={max_new_tokens}")
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = None
+                self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._ws_shape = (B, L, max_new_tokens)
+            rc = self.lib.vqs_generate(self._h, feats.data_ptr(), idx.data_ptr(), ids.data_ptr(), B, L, max_new_tokens,
+                                       tokens.data_ptr(), self._ws.data_ptr(), self._ws.numel(), _stream_ptr())
+            self._check(rc, "vqs_generate")
+            return tokens
+
     # ------------------------------------------------------------------ introspection (tests / bench)
     def stage(self, name: str) -> torch.Tensor:
         """View of a named intermediate of the most recent call (see vqs_workspace_offset)."""
@@ -242,6 +268,10 @@ class VqsEngine:
         if n < 0:
             self._check(n, "vqs_profile_read")
         return n, ms.value, fl.value
+
+    def profile_report(self) -> str:
+        """Per-call-site GEMM table of the launches covered by the last profile_read()."""
+        return self.lib.vqs_profile_report(self._h).decode()
 
     def profile_bytes(self) -> float:
         """Algorithmic bytes of the GEMM launches since the last reset (read it BEFORE a resetting profile_read)."""

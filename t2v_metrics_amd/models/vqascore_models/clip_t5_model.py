@@ -231,6 +231,30 @@ class CLIPT5Model(VQAScoreModel):
         pair_image = [img_ids[i] for i in range(M) for _ in range(N)]
         return self.score_pairs(list(uniq.keys()), pair_image, questions, answers).reshape(M, N)
 
-    def generate(self, *args, **kwargs):
-        # multi-step decoding is outside the scoring hot path
-        raise NotImplementedError("generate() is not part of the MI355X scoring path")
+    @torch.no_grad()
+    def generate_ids(self, images: List[str], texts: List[str], max_new_tokens: int = 16) -> List[List[int]]:
+        """Greedy decoding of one answer per (image, prompt) pair -> token ids, each cut after its first EOS."""
+        assert len(images) == len(texts), "Number of images and texts must match"
+        if not 1 <= max_new_tokens <= 16:
+            raise ValueError("max_new_tokens must be in [1, 16] (the decoder kernels hold at most 16 rows per pair)")
+        uniq: Dict[str, int] = {}
+        pair_image = [uniq.setdefault(str(p), len(uniq)) for p in images]
+        paths = list(uniq.keys())
+        feats = torch.cat([self.engine.encode_images(self.load_images(paths[s: s + self.max_images]))
+                           for s in range(0, len(paths), self.max_images)], 0)
+        ids, _ = self.tokenize(texts, [""] * len(texts))
+        idx = torch.as_tensor(pair_image, dtype=torch.int32)
+        eos = self.cfg.t5.eos_id
+        out: List[List[int]] = []
+        for s in range(0, len(texts), self.max_pairs):
+            e = min(len(texts), s + self.max_pairs)
+            toks = self.engine.generate(feats, idx[s:e], ids[s:e], max_new_tokens).cpu().tolist()
+            for row in toks:
+                out.append(row[: row.index(eos) + 1] if eos in row else row)
+        return out
+
+    def generate(self, images: List[str], texts: List[str], max_new_tokens: int = 16) -> List[str]:
+        """The reference's ``model.generate(images=..., texts=...)`` (/root/reference/V_3.0_README.md:316-325): greedy
+        decoding of a text answer per pair (HF GenerationMixin greedy search, decoder start = pad).  Runs on the HIP
+        engine: encoder once, then one teacher-forced decoder pass per new token."""
+        return [self.tokenizer.decode(ids, skip_special_tokens=True) for ids in self.generate_ids(images, texts, max_new_tokens)]

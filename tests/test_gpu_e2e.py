@@ -130,6 +130,40 @@ def test_fixture_parity_vs_reference_noise_floor(golden_dir, fixture):
     eng.close()
 
 
+@pytest.mark.parametrize("fixture", ["generate_tiny_g8", "generate_small_g8"])
+def test_greedy_generate_matches_hf_fixture(golden_dir, fixture):
+    """vqs_generate against HF T5ForConditionalGeneration.generate(do_sample=False) (oracle/make_golden.py::golden_generate).
+    Token ids must be identical up to the first step whose top-1/top-2 logit gap in the fp32 reference is below
+    GEN_MARGIN (a bf16 path may legitimately flip a near-tie; everything after such a step is conditioned differently).
+    Also: scoring the generated prefix teacher-forced reproduces the same arg-max path (generate == repeated score)."""
+    GEN_MARGIN = 0.25
+    from t2v_metrics_amd.engine import VqsEngine
+    g = np.load(os.path.join(golden_dir, fixture + ".npz"))
+    cfg = get_config(fixture.split("_")[1])
+    w = make_seeded_weights(cfg, seed=int(g["seed"]), device="cpu", lm_head_gain=float(g["gain"]))
+    eng = VqsEngine(cfg, w, device="cuda:0")
+    feats = eng.encode_images(torch.from_numpy(g["pixels"]).to(torch.bfloat16).cuda())
+    ids, idx = torch.from_numpy(g["ids"]), torch.from_numpy(g["img_index"])
+    max_new = int(g["max_new"])
+    toks = eng.generate(feats, idx, ids, max_new).cpu().long()
+    ref, margins = torch.from_numpy(g["tokens"]).long(), torch.from_numpy(g["margins"])
+    compared = 0
+    for b in range(ref.shape[0]):
+        for t in range(max_new):
+            if margins[b, t] < GEN_MARGIN:
+                break
+            assert toks[b, t] == ref[b, t], (b, t, toks[b].tolist(), ref[b].tolist(), margins[b].tolist())
+            compared += 1
+    assert compared >= ref.numel() // 2, f"fixture too ambiguous: only {compared} of {ref.numel()} steps compared"
+    # teacher-forced scoring of the generated sequence: every generated token is the arg-max of its own step
+    lp, _ = eng.score(feats, idx, ids, toks.to(torch.int32))
+    torch.cuda.synchronize()
+    logits = eng.stage("logits").float().cpu()              # [B, T, vocab] of the teacher-forced pass
+    assert torch.equal(logits.argmax(-1), toks)
+    _record(fixture, {"steps_compared": compared, "steps_total": int(ref.numel())})
+    eng.close()
+
+
 def test_low_sensitivity_regime_meets_1e3():
     """With an unpeaked head (lm_head gain 0.02: logits ~ N(0, 0.02^2)) the literal north_star tolerance holds."""
     from oracle.clip_t5_oracle import Oracle

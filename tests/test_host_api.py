@@ -32,6 +32,9 @@ class FakeTokenizer:
         r.input_ids = [3 + zlib.crc32(w.encode()) % (self.vocab - 3) for w in text.split()] + [1]
         return r
 
+    def decode(self, ids, skip_special_tokens=True):
+        return " ".join(f"<{i}>" for i in ids if not (skip_special_tokens and i in (0, 1)))
+
 
 class RecordingEngine:
     """Engine double: remembers what it was asked to do and returns a deterministic function of its inputs."""
@@ -73,6 +76,17 @@ class OracleEngine:
             dec = o.t5_decoder(shift_right(labels.long()), enc, mask)
             lp = o.label_logprobs(o.lm_logits(dec), labels.long())
             return lp, o.scores_from_logprobs(lp, labels.long())
+
+    def generate(self, feats, img_index, input_ids, max_new_tokens):
+        o = self.o
+        with torch.no_grad():
+            emb, mask, _ = o.splice(feats, img_index, input_ids.long())
+            enc = o.t5_encoder(emb, mask)
+            dec_ids = torch.zeros(input_ids.shape[0], 1, dtype=torch.long)
+            for _ in range(max_new_tokens):
+                nxt = o.lm_logits(o.t5_decoder(dec_ids, enc, mask))[:, -1].argmax(-1, keepdim=True)
+                dec_ids = torch.cat([dec_ids, nxt], 1)
+            return dec_ids[:, 1:].to(torch.int32)
 
 
 @pytest.fixture()
@@ -255,3 +269,23 @@ def test_threaded_image_pipeline_matches_serial(tmp_path, images):
     texts = ["x", "y z"]
     assert torch.equal(s1(images=images, texts=texts), s8(images=images, texts=texts))
     assert e8.encode_calls == [(2, 3, 56, 56), (2, 3, 56, 56)] == e1.encode_calls      # 4 images in chunks of max_images
+
+
+def test_generate_api(tmp_path, images):
+    """model.generate(images, texts) (/root/reference/V_3.0_README.md:316-325): one decoded string per pair, cut at EOS,
+    same answer for the same (image, prompt) wherever it sits in the batch."""
+    from t2v_metrics_amd.weights import make_seeded_weights
+    cfg = get_config("tiny")
+    w = make_seeded_weights(cfg, seed=9, device="cpu", dtype=torch.bfloat16, lm_head_gain=8.0)
+    s, _ = make_scorer(tmp_path, engine=OracleEngine(cfg, {k: v.float() for k, v in w.items()}))
+    texts = ["Please describe this image:", "Is there a dog ?", "Please describe this image:"]
+    out = s.model.generate(images=[images[0], images[1], images[0]], texts=texts, max_new_tokens=4)
+    assert isinstance(out, list) and len(out) == 3 and all(isinstance(x, str) for x in out)
+    assert out[0] == out[2]
+    ids = s.model.generate_ids([images[0]], [texts[0]], max_new_tokens=4)
+    assert 1 <= len(ids[0]) <= 4 and (1 not in ids[0][:-1])
+    with pytest.raises(ValueError):
+        s.model.generate(images=[images[0]], texts=[texts[0]], max_new_tokens=17)
+    with pytest.raises(AssertionError):
+        s.model.generate(images=images[:2], texts=texts[:1])
+

@@ -110,3 +110,22 @@ def test_oracle_end_to_end_shapes_and_range():
     out = o.forward(pix, torch.tensor([0, 1, 1]), ids, labels)
     assert out["scores"].shape == (3,) and out["label_logprobs"].shape == (3, 2)
     assert ((out["scores"] >= 0) & (out["scores"] <= 1)).all()
+
+
+@pytest.mark.parametrize("name", ["generate_tiny_g8", "generate_small_g8"])
+def test_oracle_greedy_generate_matches_hf(name, golden_dir):
+    """Greedy search of HF T5ForConditionalGeneration.generate (fixture from oracle/make_golden.py::golden_generate):
+    the oracle's token ids are identical, step for step."""
+    import numpy as np
+    from oracle.clip_t5_oracle import Oracle
+    from t2v_metrics_amd.config import get_config
+    from t2v_metrics_amd.weights import make_seeded_weights
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    cfg = get_config(name.split("_")[1])
+    w = make_seeded_weights(cfg, seed=int(z["seed"]), device="cpu", dtype=torch.bfloat16, lm_head_gain=float(z["gain"]))
+    o = Oracle(cfg, {k: v.float() for k, v in w.items()})
+    toks, margins = o.generate(torch.from_numpy(z["pixels"]), torch.from_numpy(z["img_index"]), torch.from_numpy(z["ids"]),
+                               int(z["max_new"]), return_margins=True)
+    assert torch.equal(toks, torch.from_numpy(z["tokens"]).long())
+    assert torch.allclose(margins, torch.from_numpy(z["margins"]), atol=2e-3)
+
