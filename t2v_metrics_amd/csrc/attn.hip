@@ -55,6 +55,9 @@ __device__ __forceinline__ float a_max3(float a, float b, float c) {
 }
 
 // Lab-only ablations (tools/attn_lab.sh): 1 = no K/V staging after the first tile, 2 = no softmax math (P = S), 4 = no PV MFMAs
+#ifndef VQS_ATTN_PRIO
+#define VQS_ATTN_PRIO 0
+#endif
 #ifndef VQS_ATTN_ABLATE
 #define VQS_ATTN_ABLATE 0
 #endif
@@ -472,12 +475,18 @@ __global__ void __launch_bounds__(256) attn_fwd_dma_kernel(const AttnParams p) {
 #pragma unroll
                 for (int kf = 0; kf < 2; ++kf)
                     kfr[ks][kf] = *reinterpret_cast<const uint4*>(k_lds + kf * 4096 + k_rd + (((2 * ks + hh) ^ swr) << 4));
+#if VQS_ATTN_PRIO
+            __builtin_amdgcn_s_setprio(1);         // a wave in its MFMA phase goes ahead of waves in their softmax phase
+#endif
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
                 for (int kf = 0; kf < 2; ++kf)
                     s[kf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kfr[ks][kf]),
                                                                     __builtin_bit_cast(bf16x8, qf[ks]), s[kf], 0, 0, 0);
+#if VQS_ATTN_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
         }
 
 #if !(VQS_ATTN_ABLATE & 2)
@@ -536,6 +545,9 @@ __global__ void __launch_bounds__(256) attn_fwd_dma_kernel(const AttnParams p) {
                 s[kf][r] = __builtin_amdgcn_exp2f(HAS_BIAS ? s[kf][r] + neg_m : fmaf(s[kf][r], sl2, neg_m));
 #endif
         // ---- O^T += V^T . P^T   (i <-> d, j <-> query, k-slot (half,j) <-> key 16t + 4*half + 8*(j>>2) + (j&3))
+#if VQS_ATTN_PRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int kf = 0; kf < 2; ++kf)
 #pragma unroll
@@ -561,6 +573,9 @@ __global__ void __launch_bounds__(256) attn_fwd_dma_kernel(const AttnParams p) {
                                                                    __builtin_bit_cast(bf16x8, pb), o[df], 0, 0, 0);
                 }
             }
+#if VQS_ATTN_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
     }
 
     const float l_tot = osum[0];                  // all 32 rows of the ones-product are the same row sum

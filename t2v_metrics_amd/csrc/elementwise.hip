@@ -377,6 +377,31 @@ hipError_t launch_decoder_embed(const int* labels, int ld_labels, const bf16_t* 
     return hipGetLastError();
 }
 
+// Split-K epilogue: out[i] = bf16(sum_s part[s][i]), slices summed in index order (deterministic)
+__global__ void __launch_bounds__(256) reduce_slices_kernel(const float* __restrict__ part, int nslices, size_t n4,
+                                                            uint2* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float4* p = reinterpret_cast<const float4*>(part) + i;
+    float4 a = p[0];
+    for (int s = 1; s < nslices; ++s) {
+        const float4 b = p[(size_t)s * n4];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    uint2 o;
+    o.x = e_pack2_hw(a.x, a.y);
+    o.y = e_pack2_hw(a.z, a.w);
+    out[i] = o;
+}
+
+hipError_t launch_reduce_slices(const float* part, int nslices, size_t n, bf16_t* out, hipStream_t s) {
+    if (n % 4) return hipErrorInvalidValue;
+    const size_t n4 = n / 4;
+    hipLaunchKernelGGL(reduce_slices_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, part, nslices, n4,
+                       reinterpret_cast<uint2*>(out));
+    return hipGetLastError();
+}
+
 // Greedy step of vqs_generate: tokens[b, T-1] = argmax_v logits[(b*T + T-1), v] (lowest index on ties, as torch.argmax)
 __global__ void __launch_bounds__(256) argmax_append_kernel(const float* __restrict__ logits, int ldl, int V,
                                                             int* __restrict__ tokens, int ld_tokens, int T) {

@@ -49,6 +49,7 @@ struct vqs_handle {
     size_t ev_used = 0;
     std::vector<std::pair<std::string, double>> ev_what;   // per profiled GEMM launch: call-site label, FLOPs
     std::string prof_report;
+    int splitk = 1;            // VQS_SPLITK=0 disables split-K in the decoder's skinny GEMMs (lab A/B)
     double prof_flops = 0.0;
     double prof_bytes = 0.0;   // algorithmic operand + result bytes of the profiled GEMM launches
 };
@@ -330,6 +331,7 @@ int vqs_create(const vqs_config* cfg, vqs_handle** out) {
         h->h_lut_causal.push_back(vqs_relpos_bucket(-n, 0, c.rel_buckets, c.rel_max_distance));
     }
     if (const char* cm = std::getenv("VQS_CROSS_MODE")) h->cross_mode = std::atoi(cm);
+    if (const char* sk = std::getenv("VQS_SPLITK")) h->splitk = std::atoi(sk);
     const char* v = std::getenv("VQS_GEMM_VARIANT");
     h->gemm_variant = v ? std::atoi(v) : 3;   // 3 = persistent kernel (gemm.hip)
     return VQS_OK;
@@ -604,6 +606,32 @@ static int encoder_pass(vqs_handle* h, const ScoreWs& w, const void* d_feats, co
     return VQS_OK;
 }
 
+// A decoder nn.Linear: out[MT, N] (bf16) = A[MT, K] . W[N, K]^T with MT = B*T (<= a few hundred rows).  One 256x256 tile per
+// workgroup leaves 16-80 of 256 CUs busy, each walking the whole K (56-133 us per launch at XL for 8-21 MB of weights).
+// Split-K: the same persistent kernel run as a batched GEMM whose batch entries are K-slices (operand pointers advance
+// by K/s columns, fp32 partial tiles go to `scratch`), then one pass sums the s slices in a fixed order into bf16 --
+// deterministic (no atomics).  s = the largest divisor of K/64 with tiles*s <= 256 CUs and >= 4 K-tiles per slice.
+static int dec_linear(vqs_handle* h, const bf16_t* A, const bf16_t* W, bf16_t* out, int MT, int N, int K, float* scratch,
+                      size_t scratch_bytes, hipStream_t st, const char* what) {
+    const int tiles = ((MT + 255) / 256) * ((N + 255) / 256);
+    const int nt = K / 64;
+    int sk = 1;
+    if (h->splitk && MT <= 1024 && (K % 64) == 0 && (N % 8) == 0)
+        for (int s2 = 2; s2 <= 16; ++s2)
+            if (nt % s2 == 0 && tiles * s2 <= 256 && nt / s2 >= 4) sk = s2;
+    if (sk > 1 && (size_t)sk * MT * N * sizeof(float) <= scratch_bytes) {
+        GemmCall g{A, W, scratch};
+        g.M = MT; g.N = N; g.K = K / sk; g.lda = K; g.ldw = K; g.ldc = N; g.epi = vqs::EPI_F32;
+        g.batch = sk; g.sA = K / sk; g.sW = K / sk; g.sC = (long long)MT * N;
+        RUN(run_gemm(h, g, st, what));
+        HIPCHK(h, vqs::launch_reduce_slices(scratch, sk, (size_t)MT * N, out, st), "split-K reduce");
+        return VQS_OK;
+    }
+    GemmCall g{A, W, out};
+    g.M = MT; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldc = N; g.epi = vqs::EPI_BF16;
+    return run_gemm(h, g, st, what);
+}
+
 // Decoder half: T teacher-forced rows per pair over the encoder output already in the workspace -> fp32 logits
 // [B*T, ldl].  d_labels[b*ld_labels + t] are the target ids (decoder input = shift_right, HF modeling_t5.py:618-637).
 static int decoder_pass(vqs_handle* h, const ScoreWs& w, const int32_t* d_labels, int ld_labels, int B, int L, int T,
@@ -615,6 +643,8 @@ static int decoder_pass(vqs_handle* h, const ScoreWs& w, const int32_t* d_labels
     (void)P; (void)M; (void)MT; (void)F; (void)I; (void)V;
     // ---------------- decoder (teacher forced, T rows per pair)
     GETW(shared, "shared.weight", (int64_t)V * D);
+    float* scratch = reinterpret_cast<float*>(w.ff);          // the encoder's FFN buffer [B*S, F] bf16 is idle from here on
+    const size_t scratch_bytes = (size_t)M * F * sizeof(bf16_t);
     GETW(dec_rel, "decoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight", (int64_t)c.rel_buckets * H);
     HIPCHK(h, vqs::launch_relpos_table(dec_rel, h->lut_bidir, h->lut_causal, h->lut_len, c.rel_buckets, nullptr, H, S,
                                        w.dec_table, T, st), "decoder bias table");
@@ -632,26 +662,14 @@ static int decoder_pass(vqs_handle* h, const ScoreWs& w, const int32_t* d_labels
 
         HIPCHK(h, vqs::launch_rmsnorm(w.dhid, dpend, ln0, w.dxn, MT, D, c.t5_ln_eps, st), "dec rmsnorm0");
         dpend = nullptr;
-        {
-            GemmCall g{w.dxn, h->dec_qkv[i], w.dqkv};
-            g.M = MT; g.N = 3 * I; g.K = D; g.lda = D; g.ldw = D; g.ldc = 3 * I; g.epi = vqs::EPI_BF16;
-            RUN(run_gemm(h, g, st, "dec self qkv"));
-        }
+        RUN(dec_linear(h, w.dxn, h->dec_qkv[i], w.dqkv, MT, 3 * I, D, scratch, scratch_bytes, st, "dec self qkv"));
         {
             vqs::DecAttnParams a{w.dqkv, w.dqkv + I, w.dqkv + 2 * I, w.dattn, w.dec_table, nullptr, B, H, T, T, 3 * I, 3 * I, 0};
             HIPCHK(h, vqs::launch_decoder_attention(a, st), "dec self attention");
         }
-        {
-            GemmCall g{w.dattn, so, w.ddelta};
-            g.M = MT; g.N = D; g.K = I; g.lda = I; g.ldw = I; g.ldc = D; g.epi = vqs::EPI_BF16;
-            RUN(run_gemm(h, g, st, "dec self o"));
-        }
+        RUN(dec_linear(h, w.dattn, so, w.ddelta, MT, D, I, scratch, scratch_bytes, st, "dec self o"));
         HIPCHK(h, vqs::launch_rmsnorm(w.dhid, w.ddelta, ln1, w.dxn, MT, D, c.t5_ln_eps, st), "dec rmsnorm1");
-        {
-            GemmCall g{w.dxn, cq, w.dq};
-            g.M = MT; g.N = I; g.K = D; g.lda = D; g.ldw = D; g.ldc = I; g.epi = vqs::EPI_BF16;
-            RUN(run_gemm(h, g, st, "dec cross q"));
-        }
+        RUN(dec_linear(h, w.dxn, cq, w.dq, MT, I, D, scratch, scratch_bytes, st, "dec cross q"));
         if (h->cross_mode == 0) {
             // direct form (what HF executes): K|V projection of the whole encoder output for this layer
             {
@@ -696,23 +714,15 @@ static int decoder_pass(vqs_handle* h, const ScoreWs& w, const int32_t* d_labels
                 RUN(run_gemm(h, g, st, "cross ctx.Wv"));
             }
         }
-        {
-            GemmCall g{w.dattn, co, w.ddelta};
-            g.M = MT; g.N = D; g.K = I; g.lda = I; g.ldw = I; g.ldc = D; g.epi = vqs::EPI_BF16;
-            RUN(run_gemm(h, g, st, "dec cross o"));
-        }
+        RUN(dec_linear(h, w.dattn, co, w.ddelta, MT, D, I, scratch, scratch_bytes, st, "dec cross o"));
         HIPCHK(h, vqs::launch_rmsnorm(w.dhid, w.ddelta, ln2, w.dxn, MT, D, c.t5_ln_eps, st), "dec rmsnorm2");
         {
             GemmCall g{w.dxn, h->dec_wi[i], w.dff};
             g.M = MT; g.N = 2 * F; g.K = D; g.lda = D; g.ldw = D; g.ldc = F; g.epi = vqs::EPI_GATED;
             RUN(run_gemm(h, g, st, "dec wi"));
         }
-        {
-            GemmCall g{w.dff, wo, w.ddelta};
-            g.M = MT; g.N = D; g.K = F; g.lda = F; g.ldw = F; g.ldc = D; g.epi = vqs::EPI_BF16;
-            RUN(run_gemm(h, g, st, "dec wo"));
-            dpend = w.ddelta;
-        }
+        RUN(dec_linear(h, w.dff, wo, w.ddelta, MT, D, F, scratch, scratch_bytes, st, "dec wo"));
+        dpend = w.ddelta;
     }
     {
         GETW(fin, "decoder.final_layer_norm.weight", D);

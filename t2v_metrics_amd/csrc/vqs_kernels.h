@@ -91,6 +91,7 @@ hipError_t launch_embed_splice(const int* ids, const int* sent_pos, const int* e
 // decoder_input_ids = shift_right(labels); h[b,t] = shared[id]  (fp32 out)
 hipError_t launch_decoder_embed(const int* labels, int ld_labels, const bf16_t* shared, float* out, int B, int T, int D,
                                 int vocab, hipStream_t s);
+hipError_t launch_reduce_slices(const float* part, int nslices, size_t n, bf16_t* out, hipStream_t s);
 hipError_t launch_argmax_append(const float* logits, int ldl, int V, int* tokens, int ld_tokens, int B, int T,
                                 hipStream_t s);
 // bias tables from the [buckets,H] bf16 embedding and a host-computed bucket LUT

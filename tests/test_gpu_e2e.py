@@ -204,6 +204,34 @@ def test_reassociated_cross_attention_matches_direct_form(monkeypatch):
     assert e0 <= 2 * LOGPROB_TOL_BF16 and e1 <= 2 * LOGPROB_TOL_BF16 and d01 <= 2 * LOGPROB_TOL_BF16, (e0, e1, d01)
 
 
+def test_decoder_split_k_matches_unsplit(monkeypatch):
+    """The decoder's skinny nn.Linear GEMMs run split-K (fp32 partial slices + a fixed-order reduction) by default;
+    VQS_SPLITK=0 runs them as single GEMMs.  Same function: both agree with the oracle and with each other, and the
+    split path is deterministic run to run (no atomics)."""
+    import dataclasses
+    from oracle.clip_t5_oracle import Oracle
+    from t2v_metrics_amd.engine import VqsEngine
+    base = get_config("small")
+    cfg = dataclasses.replace(base, name="splitk-test",
+                              t5=dataclasses.replace(base.t5, d_model=512, heads=8, d_ff=1024, layers=2, dec_layers=2))
+    w = make_seeded_weights(cfg, seed=19, device="cpu", lm_head_gain=2.0)
+    pix, img_index, ids, labels = _inputs(cfg, 7, 3, 21, 3, seed=6)
+    ref = Oracle(cfg, w).forward(pix.float(), img_index, ids, labels)["label_logprobs"]
+    out = {}
+    for mode in ("0", "1", "1b"):
+        monkeypatch.setenv("VQS_SPLITK", mode[0])
+        eng = VqsEngine(cfg, w, device="cuda:0")
+        lp, _ = eng.score(eng.encode_images(pix.cuda()), img_index, ids, labels)
+        torch.cuda.synchronize()
+        out[mode] = lp.cpu()
+        eng.close()
+    assert torch.equal(out["1"], out["1b"])
+    d01 = (out["0"] - out["1"]).abs().max().item()
+    e0, e1 = (out["0"] - ref).abs().max().item(), (out["1"] - ref).abs().max().item()
+    _record("split-k", {"unsplit_vs_oracle": e0, "split_vs_oracle": e1, "unsplit_vs_split": d01})
+    assert e0 <= 2 * LOGPROB_TOL_BF16 and e1 <= 2 * LOGPROB_TOL_BF16 and d01 <= 2 * LOGPROB_TOL_BF16, (e0, e1, d01)
+
+
 def test_engine_matches_hf_golden_fixture(golden_dir):
     """The committed HF-module fixture (tests/golden/hf_tiny.npz): vision hidden_states[-2] from the HIP tower."""
     from t2v_metrics_amd.engine import VqsEngine
