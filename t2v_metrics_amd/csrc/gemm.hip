@@ -32,7 +32,7 @@
 #define VQS_DMA_BUFFER 1
 #endif
 #ifndef VQS_DMA_SPLIT
-#define VQS_DMA_SPLIT 0   // 0: two pieces per k-step before the MFMAs (default); 1: halves of the K-tile by wave row; 2: staggered among the MFMAs by wave column -- all measured equal within 2 %
+#define VQS_DMA_SPLIT 3   // 3 (default): four pieces in each of the first two k-steps (+2-5 % where operands stream from HBM); 0: two per k-step; 1: halves of the K-tile by wave row; 2: staggered among the MFMAs by wave column (0-2 equal within 2 %); 4: all eight in the first k-step
 #endif
 
 namespace vqs {
@@ -753,6 +753,24 @@ __global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) 
                     PGLDS_A(i0 + 1, koffs, dst0 + (i0 + 1) * 8192);
                     PGLDS_W(i0 + 1, koffs, dst0 + (i0 + 1) * 8192 + W_OFF);
                 }
+#elif VQS_DMA_SPLIT == 4
+                if (do_stage && ks == 0) {
+#pragma unroll
+                    for (int i0 = 0; i0 < 4; ++i0) {
+                        PGLDS_A(i0, koffs, dst0 + i0 * 8192);
+                        PGLDS_W(i0, koffs, dst0 + i0 * 8192 + W_OFF);
+                    }
+                }
+#elif VQS_DMA_SPLIT == 3
+                // all eight pieces in the first two k-steps: the last piece has >= 2 k-steps (~1 300 cycles) to land
+                // instead of one -- for operands streamed from HBM (the K = 1024 ViT shapes wait 350-900 cycles per K-tile)
+                if (do_stage && ks < 2) {
+                    const int i0 = ks * 2;
+                    PGLDS_A(i0, koffs, dst0 + i0 * 8192);
+                    PGLDS_W(i0, koffs, dst0 + i0 * 8192 + W_OFF);
+                    PGLDS_A(i0 + 1, koffs, dst0 + (i0 + 1) * 8192);
+                    PGLDS_W(i0 + 1, koffs, dst0 + (i0 + 1) * 8192 + W_OFF);
+                }
 #else
                 if (do_stage) {
                     PGLDS_A(ks, koffs, dst0 + ks * 8192);
@@ -1289,7 +1307,7 @@ static hipError_t launch_epi(const GemmParams& p, int variant, hipStream_t strea
             // the default (variant 3) picks the schedule by shape: short-K, narrow-N GEMMs (the ViT's qkv / out_proj:
             // K = 1024, N <= 3072) measured 5-10 % faster on the ping-pong schedule, everything else equal or 1-4 %
             // faster on the lock-step one.  Both produce bitwise-identical results.
-            if (p.K <= 1024 && p.N <= 3072 && p.batch <= 1 && nwg >= PERSISTENT_WGS)
+            if (variant != 7 && p.K <= 1024 && p.N <= 3072 && p.batch <= 1 && nwg >= PERSISTENT_WGS)   // 7 = lock-step forced (lab)
                 hipLaunchKernelGGL((gemm_bf16_pingpong<EPI>), pgrid, block, 0, stream, p);
             else
                 hipLaunchKernelGGL((gemm_bf16_persistent<EPI>), pgrid, block, 0, stream, p);
@@ -1309,7 +1327,7 @@ hipError_t launch_gemm(const GemmParams& p, int epilogue, int variant, hipStream
     // N: a lane stores 4 consecutive columns; fp32 output may have a ragged N if ldc leaves room for the overhang
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K % BK) != 0) return hipErrorInvalidValue;
     if ((p.N % 8) != 0 && !(epilogue == EPI_F32 && p.ldc >= ((p.N + 3) & ~3) && p.bias == nullptr)) return hipErrorInvalidValue;
-    if (p.batch > 1 && ((variant != 3 && variant != 4 && variant != 5) || epilogue == EPI_HEADS || epilogue == EPI_F32_RESID)) return hipErrorInvalidValue;
+    if (p.batch > 1 && ((variant != 3 && variant != 4 && variant != 5 && variant != 7) || epilogue == EPI_HEADS || epilogue == EPI_F32_RESID)) return hipErrorInvalidValue;
     if ((p.lda % 8) != 0 || (p.ldw % 8) != 0) return hipErrorInvalidValue;
     switch (epilogue) {
         case EPI_BF16: return launch_epi<EPI_BF16>(p, variant, stream);

@@ -11,13 +11,13 @@ lib.vqs_debug_set_gemm_timing.argtypes = [ctypes.c_void_p]
 dbg = torch.zeros(64 * 8 * 8, dtype=torch.int64, device="cuda")
 assert lib.vqs_debug_set_gemm_timing(dbg.data_ptr()) == 0
 g = torch.Generator(device="cuda").manual_seed(0)
-for tag, M, N, K, epi in (("xl_qkv", 155648, 6144, 2048, 0), ("xl_wi", 155648, 10240, 2048, 5), ("xl_o", 155648, 2048, 2048, 3), ("vit_qkv", 147712, 3072, 1024, 0), ("sq8192", 8192, 8192, 8192, 0)):
+for tag, M, N, K, epi in (("xl_qkv", 155648, 6144, 2048, 0), ("xl_wi", 155648, 10240, 2048, 5), ("xl_o", 155648, 2048, 2048, 0), ("vit_qkv", 147712, 3072, 1024, 0), ("vit_fc1", 147712, 4096, 1024, 1), ("vit_fc2", 147712, 1024, 4096, 0), ("vit_out", 147712, 1024, 1024, 0)):
     A = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
     W = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(torch.bfloat16)
     resid = torch.randn(M, N, device="cuda", generator=g) if epi == 4 else None
-    out = engine.gemm(A, W, epi, resid=resid, variant=3)
+    out = engine.gemm(A, W, epi, resid=resid, variant=7)
     for _ in range(2):
-        engine.gemm(A, W, epi, resid=resid, out=out, variant=3)
+        engine.gemm(A, W, epi, resid=resid, out=out, variant=7)
     torch.cuda.synchronize()
     d = dbg.view(64, 8, 8).double().cpu()
     nk, ntile = d[..., 5].mean().item(), d[..., 6].mean().item()
