@@ -138,6 +138,15 @@ const char* vqs_profile_report(vqs_handle* h);
 int vqs_gemm(const void* d_A, const void* d_W, void* d_C, const void* d_bias, const float* d_resid, int32_t M, int32_t N,
              int32_t K, int32_t lda, int32_t ldw, int32_t ldc, int32_t epilogue, int32_t S, int32_t H, int32_t variant,
              void* stream);
+/* The fused residual + RMSNorm pieces of the T5 encoder, exposed for the parity tests (persistent variants 3 / 5 / 7):
+ *   epilogue 7 (producer): d_hres[M,N] (fp32) += A.W^T in place; d_C bf16 [M,ldc] = d_hres * d_lnw[col] (the NEXT RMSNorm's
+ *     operand without its per-row 1/rms); d_rowss_out[ceil(N/256)][M] = per-256-column-tile sums of squares of the rows;
+ *   d_rowss_in != NULL (consumer, epilogues 0 / 3 / 5 / 6): accumulator row r is scaled by
+ *     rsqrt(sum_p d_rowss_in[p][r] * rs_invd + rs_eps) before the epilogue -- HF modeling_t5.py:59-72 applied after the
+ *     contraction instead of before it. */
+int vqs_gemm_rms(const void* d_A, const void* d_W, void* d_C, float* d_hres, const void* d_lnw, float* d_rowss_out,
+                 const float* d_rowss_in, int32_t rowss_parts, float rs_invd, float rs_eps, int32_t M, int32_t N, int32_t K,
+                 int32_t lda, int32_t ldw, int32_t ldc, int32_t epilogue, int32_t S, int32_t H, int32_t variant, void* stream);
 int vqs_attention(const void* d_q, const void* d_k, const void* d_v, void* d_out, const float* d_bias_table,
                   const int32_t* d_key_len, int32_t B, int32_t H, int32_t S, float scale, void* stream);
 int vqs_decoder_attention(const void* d_q, const void* d_k, const void* d_v, void* d_out, const float* d_bias_table,

@@ -377,6 +377,21 @@ hipError_t launch_decoder_embed(const int* labels, int ld_labels, const bf16_t* 
     return hipGetLastError();
 }
 
+// Fused residual + RMSNorm: per-tile partial row sums of squares [parts][M] -> 1/rms per row (index-order sum)
+__global__ void __launch_bounds__(256) rowss_to_rs_kernel(const float* __restrict__ rowss, int parts, int M, float invd,
+                                                          float eps, float* __restrict__ rs) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    float ss = 0.0f;
+    for (int q = 0; q < parts; ++q) ss += rowss[(size_t)q * M + i];
+    rs[i] = rsqrtf(ss * invd + eps);
+}
+
+hipError_t launch_rowss_to_rs(const float* rowss, int parts, int M, float invd, float eps, float* rs, hipStream_t s) {
+    hipLaunchKernelGGL(rowss_to_rs_kernel, dim3((M + 255) / 256), dim3(256), 0, s, rowss, parts, M, invd, eps, rs);
+    return hipGetLastError();
+}
+
 // Split-K epilogue: out[i] = bf16(sum_s part[s][i]), slices summed in index order (deterministic)
 __global__ void __launch_bounds__(256) reduce_slices_kernel(const float* __restrict__ part, int nslices, size_t n4,
                                                             uint2* __restrict__ out) {

@@ -410,10 +410,123 @@ __device__ unsigned long long* g_gemm_dbg = nullptr;   // [blocks][8 waves][8 co
 // ----------------------------------------------------------------------------------------------------
 template <int EPI>
 __device__ __forceinline__ void staged_epilogue(const GemmParams& p, f32x16 (&acc)[4][2], char* reg, int m0, int n0, int bz,
-                                                int wr, int wc, int lane, bool full) {
+                                                int wr, int wc, int lane, bool full, float* rowred) {
     const int hh = lane >> 5, lr = lane & 31;
     const int row_w = m0 + wr * 128;                 // first row of this wave's tile
     const int col_w = n0 + wc * 64;                  // first column
+    if (p.rowss_in != nullptr) {
+        // Consumer of a fused residual + RMSNorm producer: the A operand was x*lnw WITHOUT the per-row 1/rms factor
+        // (a scalar per row commutes with the contraction); apply it to the accumulators.  rowss_parts == 0: rowss_in
+        // already holds 1/rms per row (the engine's form, one load per row); otherwise it holds the producer's per-tile
+        // partial sums of squares, added here in index order (deterministic).
+        float rsv[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int row = min(row_w + m * 32 + lr, p.M - 1);
+            if (p.rowss_parts == 0) {
+                rsv[m] = p.rowss_in[row];
+            } else {
+                float ss = 0.0f;
+                for (int q = 0; q < p.rowss_parts; ++q) ss += p.rowss_in[(size_t)q * p.M + row];
+                rsv[m] = rsqrtf(ss * p.rs_invd + p.rs_eps);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] *= rsv[m];
+    }
+    if constexpr (EPI == EPI_RESID_RMS) {
+        // [Lab path, VQS_FUSED_NORM=1; measured +1 % end to end, see DESIGN.md §3: a read-modify-write epilogue pays one store-
+        //  acknowledgement latency per batch of loads because VMEM returns in order, ~30 us per tile, and starting the
+        //  workgroups in staggered phase groups did not change that.]
+        // hres += acc (fp32 stream, written back); C = bf16(hres * lnw[col]) -- the next RMSNorm's operand without its
+        // 1/rms factor; per-row sum of squares of this tile's 256 columns -> rowss_out[n0/256][row].
+        // Four passes of 32 rows x 256 B through the wave's LDS region (the fp32 image below); after the transposing
+        // LDS round trip a lane holds 4 consecutive columns of one row and 16 lanes share a row.
+        const int c = lane & 15;
+        const int col = col_w + c * 4;
+        float w4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (col < p.N) {
+            const uint2 wv = *reinterpret_cast<const uint2*>(p.lnw + col);
+            w4[0] = bf2f((bf16_t)(wv.x & 0xffff)); w4[1] = bf2f((bf16_t)(wv.x >> 16));
+            w4[2] = bf2f((bf16_t)(wv.y & 0xffff)); w4[3] = bf2f((bf16_t)(wv.y >> 16));
+        }
+        // The 8 loads of the stream for pass m+1 are issued before the stores of pass m (VMEM retires in order: a load
+        // queued behind stores waits for their acknowledgements), and pass 0's before anything else; the main loop has
+        // touched every line of the tile into L2 during the last K-tile (see the kernel), so these are L2 hits.
+        // Half-passes of 4 x (4 rows x 256 B): the 4 stream loads of half-pass i+1 are issued before the stores of
+        // half-pass i (VMEM retires in order: a load queued behind stores waits for their acknowledgements), the first
+        // ones before anything else; the main loop has touched every line of the tile into L2 during the last K-tile.
+        float4 hv[4];
+        const bool col_ok = col < p.N;
+        auto load_h = [&](int i) {                 // i = 2*m + half
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = row_w + (i >> 1) * 32 + ((i & 1) * 4 + q) * 4 + (lane >> 4);
+                hv[q] = (full || (row < p.M && col_ok)) ? *reinterpret_cast<const float4*>(p.hres + (size_t)row * p.ldh + col)
+                                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        load_h(0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ch = n * 8 + 2 * g + hh;
+                    const float4 v = make_float4(acc[m][n][4 * g + 0], acc[m][n][4 * g + 1], acc[m][n][4 * g + 2], acc[m][n][4 * g + 3]);
+                    *reinterpret_cast<float4*>(reg + lr * 256 + ((ch ^ (lr & 15)) << 4)) = v;
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                float4 v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = (half * 4 + q) * 4 + (lane >> 4);
+                    v[q] = *reinterpret_cast<const float4*>(reg + r * 256 + ((c ^ (r & 15)) << 4));
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v[q].x += hv[q].x; v[q].y += hv[q].y; v[q].z += hv[q].z; v[q].w += hv[q].w;
+                }
+                if (2 * m + half + 1 < 8) load_h(2 * m + half + 1);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = (half * 4 + q) * 4 + (lane >> 4);
+                    const int row = row_w + m * 32 + r;
+                    float ss = 0.0f;
+                    if (full || (row < p.M && col_ok)) {
+                        *reinterpret_cast<float4*>(p.hres + (size_t)row * p.ldh + col) = v[q];
+                        uint2 o;
+                        o.x = pack2(v[q].x * w4[0], v[q].y * w4[1]);
+                        o.y = pack2(v[q].z * w4[2], v[q].w * w4[3]);
+                        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)row * p.ldc + col) = o;
+                        ss = (v[q].x * v[q].x + v[q].y * v[q].y) + (v[q].z * v[q].z + v[q].w * v[q].w);
+                    }
+                    ss += __shfl_xor(ss, 1);
+                    ss += __shfl_xor(ss, 2);
+                    ss += __shfl_xor(ss, 4);
+                    ss += __shfl_xor(ss, 8);
+                    if (c == 0) rowred[wc * 256 + wr * 128 + m * 32 + r] = ss;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __syncthreads();                                       // all four column quarters of every row are in rowred
+        {
+            const int t = threadIdx.x;
+            if (t < 256 && m0 + t < p.M) {
+                const float tot = ((rowred[t] + rowred[256 + t]) + rowred[512 + t]) + rowred[768 + t];
+                p.rowss_out[(size_t)(n0 >> 8) * p.M + m0 + t] = tot;
+            }
+        }
+        return;
+    }
     if constexpr (EPI == EPI_GATED) {
         const int NO = p.N >> 1;
         const int ocol_w = col_w >> 1;               // 32 output columns per wave
@@ -552,7 +665,7 @@ __device__ __forceinline__ void staged_epilogue(const GemmParams& p, f32x16 (&ac
 
 template <int EPI>
 struct EpiStores {   // VMEM store instructions per wave for a full tile (staged epilogue): 16-B per lane each
-    static constexpr int value = (EPI == EPI_GATED) ? 8 : ((EPI == EPI_F32 || EPI == EPI_F32_RESID) ? 32 : 16);
+    static constexpr int value = (EPI == EPI_GATED) ? 8 : ((EPI == EPI_F32 || EPI == EPI_F32_RESID) ? 32 : (EPI == EPI_RESID_RMS ? 64 : 16));
 };
 
 typedef int v4i_t __attribute__((ext_vector_type(4)));
@@ -569,6 +682,18 @@ __device__ __forceinline__ void bglds16(v4i_t rsrc, uint32_t voff, uint32_t soff
         : "=&s"(keep)
         : "v"(voff), "s"(rsrc), "s"(lds_dst), "s"(__builtin_amdgcn_readfirstlane(soff)));
 }
+// dword form, used only to pull lines into L2: the 4 bytes per lane land in a scratch LDS area nobody reads
+__device__ __forceinline__ void bglds4(v4i_t rsrc, uint32_t voff, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dword %1, %2, 0 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(rsrc), "s"(lds_dst));
+}
 __device__ __forceinline__ v4i_t make_rsrc(const void* base) {
     const uint64_t b = (uint64_t)base;
     v4i_t r;
@@ -582,6 +707,8 @@ __device__ __forceinline__ v4i_t make_rsrc(const void* base) {
 template <int EPI>
 __global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) {
     __shared__ __attribute__((aligned(16))) char lds[2 * STAGE_BYTES];
+    __shared__ float rowred[EPI == EPI_RESID_RMS ? 1024 : 1];   // per-row partial sums of squares of the 4 wave columns
+    __shared__ __attribute__((aligned(16))) char touch_sink[EPI == EPI_RESID_RMS ? 2048 : 16];   // landing area of the L2-touch DMA
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -689,6 +816,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) 
             if (t == 0 && counted) {
                 if constexpr (EpiStores<EPI>::value == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                 else if constexpr (EpiStores<EPI>::value == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else if constexpr (EpiStores<EPI>::value == 64) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");   // counter is 6 bits
                 else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -722,6 +850,21 @@ __global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) 
                 for (int m = 0; m < 4; ++m) af[m] = *reinterpret_cast<const uint4*>(sb + a_row + m * 4096 + koff[ks]);
 #pragma unroll
                 for (int n = 0; n < 2; ++n) wf[n] = *reinterpret_cast<const uint4*>(sb + b_row + n * 4096 + koff[ks]);
+                if constexpr (EPI == EPI_RESID_RMS) {
+                    // last K-tile of the tile: touch every 128-B line of the tile's slice of the residual stream (256 rows
+                    // x 1 KiB = 2048 lines, 4 per thread) so that the epilogue's read-modify-write finds it in L2
+                    if (t == nt - 1 && ks == 2) {
+                        const v4i_t rsH = make_rsrc(p.hres);
+                        const uint32_t sink = (uint32_t)(uintptr_t)LDS_PTR(touch_sink) + w * 256;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int l = j * 512 + w * 64 + lane;
+                            const int row = min(m0 + (l >> 3), p.M - 1);
+                            const int colf = min(n0 + (l & 7) * 32, p.N - 1);
+                            bglds4(rsH, (uint32_t)(((size_t)row * p.ldh + colf) * 4), sink);
+                        }
+                    }
+                }
 #if VQS_PRIO_SPLIT
                 // the older wave of a SIMD wins issue arbitration all the time (measured: its 32 MFMAs take ~2000
                 // cycles, the younger wave's ~2600, and the older half then idles at the barrier): hand the
@@ -798,7 +941,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) 
         // cycles per tile; staged, every store instruction writes 8 full 128-B rows / 4 full 256-B rows.)
         const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
         __builtin_amdgcn_s_barrier();                       // every wave is done reading stage buf^1
-        staged_epilogue<EPI>(p, acc, lds + (buf ^ 1) * STAGE_BYTES + w * 8192, m0, n0, bz, wr, wc, lane, full);
+        staged_epilogue<EPI>(p, acc, lds + (buf ^ 1) * STAGE_BYTES + w * 8192, m0, n0, bz, wr, wc, lane, full, rowred);
         counted = full;
 #if (VQS_ABLATE & 32)
         { TSTAMP(te1); TACC(4, te0, te1); tacc[6] += 1; }
@@ -1066,6 +1209,7 @@ __global__ void __launch_bounds__(768) gemm_bf16_ws(const GemmParams p) {
 template <int EPI>
 __global__ void __launch_bounds__(512) gemm_bf16_pingpong(const GemmParams p) {
     __shared__ __attribute__((aligned(16))) char lds[2 * STAGE_BYTES];
+    __shared__ float rowred[EPI == EPI_RESID_RMS ? 1024 : 1];   // per-row partial sums of squares of the 4 wave columns
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1211,6 +1355,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_pingpong(const GemmParams p) {
         if (t == 0 && after_epi) {                                         \
             if constexpr (EpiStores<EPI>::value == 8) VQS_VMCNT(10);       \
             else if constexpr (EpiStores<EPI>::value == 16) VQS_VMCNT(18); \
+            else if constexpr (EpiStores<EPI>::value == 64) VQS_VMCNT(63); \
             else VQS_VMCNT(34);                                            \
         } else {                                                           \
             VQS_VMCNT(2);                                                  \
@@ -1257,7 +1402,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_pingpong(const GemmParams p) {
         // ---------------- tile end: both wave rows run the epilogue together, staged through the stage just consumed
         const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
         if (!g1) VQS_BAR();
-        staged_epilogue<EPI>(p, acc, lds + (cb ^ 1) * STAGE_BYTES + w * 8192, m0, n0, bz, wr, wc, lane, full);
+        staged_epilogue<EPI>(p, acc, lds + (cb ^ 1) * STAGE_BYTES + w * 8192, m0, n0, bz, wr, wc, lane, full, rowred);
         after_epi = full;
         pid += gridDim.x;
         if (pid >= nwg) break;
@@ -1278,6 +1423,16 @@ template <int EPI>
 static hipError_t launch_epi(const GemmParams& p, int variant, hipStream_t stream) {
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
     dim3 grid(tiles_m * tiles_n), block(512);
+    if constexpr (EPI == EPI_RESID_RMS) {
+        // only the persistent kernels carry this epilogue (LDS-staged, needs the cross-wave row reduction)
+        const int nwg = tiles_m * tiles_n;
+        dim3 pgrid(nwg < PERSISTENT_WGS ? nwg : PERSISTENT_WGS);
+        if (variant == 5)
+            hipLaunchKernelGGL((gemm_bf16_pingpong<EPI>), pgrid, block, 0, stream, p);
+        else
+            hipLaunchKernelGGL((gemm_bf16_persistent<EPI>), pgrid, block, 0, stream, p);
+        return hipGetLastError();
+    } else
     if (variant == 0)
         hipLaunchKernelGGL((gemm_bf16_kernel<EPI, 0>), grid, block, 0, stream, p);
     else if (variant == 1)
@@ -1329,6 +1484,8 @@ hipError_t launch_gemm(const GemmParams& p, int epilogue, int variant, hipStream
     if ((p.N % 8) != 0 && !(epilogue == EPI_F32 && p.ldc >= ((p.N + 3) & ~3) && p.bias == nullptr)) return hipErrorInvalidValue;
     if (p.batch > 1 && ((variant != 3 && variant != 4 && variant != 5 && variant != 7) || epilogue == EPI_HEADS || epilogue == EPI_F32_RESID)) return hipErrorInvalidValue;
     if ((p.lda % 8) != 0 || (p.ldw % 8) != 0) return hipErrorInvalidValue;
+    if (p.rowss_in != nullptr && (p.rowss_parts < 0 || (variant != 3 && variant != 5 && variant != 7) || epilogue == EPI_F32_RESID))
+        return hipErrorInvalidValue;   // the row scale lives in the persistent kernels' staged epilogue only
     switch (epilogue) {
         case EPI_BF16: return launch_epi<EPI_BF16>(p, variant, stream);
         case EPI_BF16_QGELU: return launch_epi<EPI_BF16_QGELU>(p, variant, stream);
@@ -1337,6 +1494,10 @@ hipError_t launch_gemm(const GemmParams& p, int epilogue, int variant, hipStream
         case EPI_F32_RESID: return launch_epi<EPI_F32_RESID>(p, variant, stream);
         case EPI_GATED: return launch_epi<EPI_GATED>(p, variant, stream);
         case EPI_HEADS: return launch_epi<EPI_HEADS>(p, variant, stream);
+        case EPI_RESID_RMS:
+            if (!p.hres || !p.lnw || !p.rowss_out || p.batch > 1 || p.bias != nullptr || (p.ldh % 4) != 0 || (p.ldc % 4) != 0)
+                return hipErrorInvalidValue;
+            return launch_epi<EPI_RESID_RMS>(p, variant, stream);
         default: return hipErrorInvalidValue;
     }
 }

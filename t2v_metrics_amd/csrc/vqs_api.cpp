@@ -49,6 +49,7 @@ struct vqs_handle {
     size_t ev_used = 0;
     std::vector<std::pair<std::string, double>> ev_what;   // per profiled GEMM launch: call-site label, FLOPs
     std::string prof_report;
+    int fused_norm = 0;        // VQS_FUSED_NORM=1: residual update + RMSNorm operand in the o / wo GEMM epilogues (lab; +1 %)
     int splitk = 1;            // VQS_SPLITK=0 disables split-K in the decoder's skinny GEMMs (lab A/B)
     double prof_flops = 0.0;
     double prof_bytes = 0.0;   // algorithmic operand + result bytes of the profiled GEMM launches
@@ -114,6 +115,8 @@ struct ScoreWs {
     int *sent_pos, *enc_len, *flags;
     float *enc_table, *dec_table, *hidden;
     bf16_t *delta, *ddelta;
+    float* rowss;             // [ceil(D/256)][B*S] partial row sums of squares (fused residual + RMSNorm)
+    float* rs;                // [B*S] 1/rms per row, derived from rowss
     bf16_t *xn, *q, *k, *v, *attn, *ff, *enc_out, *ck, *cv;
     float* dhid;
     bf16_t *dxn, *dqkv, *dattn, *dq, *dff;
@@ -141,6 +144,8 @@ ScoreWs carve_score(const vqs_handle* h, char* base, int B, int L, int T,
     w.hidden = cv.take<float>(M * D, "enc_in");   // the fp32 residual stream; holds enc_in until layer 0 runs
     w.delta = cv.take<bf16_t>(M * D);            // bf16 sub-layer output waiting to be added by the next norm
     w.xn = cv.take<bf16_t>(M * D);
+    w.rowss = cv.take<float>((size_t)((D + 255) / 256) * M);
+    w.rs = cv.take<float>(M);
     w.q = cv.take<bf16_t>(M * I);
     w.k = cv.take<bf16_t>(M * I);
     w.v = cv.take<bf16_t>(M * I);
@@ -244,6 +249,14 @@ struct GemmCall {
     bf16_t* heads[3] = {nullptr, nullptr, nullptr};
     int batch = 1;
     long long sA = 0, sW = 0, sC = 0;
+    // fused residual + RMSNorm (see vqs_kernels.h)
+    float* hres = nullptr;
+    int ldh = 0;
+    const bf16_t* lnw = nullptr;
+    float* rowss_out = nullptr;
+    const float* rowss_in = nullptr;
+    int rowss_parts = 0;
+    float rs_invd = 0.0f, rs_eps = 0.0f;
 };
 
 int run_gemm(vqs_handle* h, const GemmCall& g, hipStream_t st, const char* what) {
@@ -253,6 +266,8 @@ int run_gemm(vqs_handle* h, const GemmCall& g, hipStream_t st, const char* what)
     p.S = g.S > 0 ? g.S : 1; p.H = g.H; p.inner = g.inner > 0 ? g.inner : 1;
     p.heads_out[0] = g.heads[0]; p.heads_out[1] = g.heads[1]; p.heads_out[2] = g.heads[2];
     p.batch = g.batch; p.sA = g.sA; p.sW = g.sW; p.sC = g.sC;
+    p.hres = g.hres; p.ldh = g.ldh; p.lnw = g.lnw; p.rowss_out = g.rowss_out;
+    p.rowss_in = g.rowss_in; p.rowss_parts = g.rowss_parts; p.rs_invd = g.rs_invd; p.rs_eps = g.rs_eps;
     if (h->prof) {
         while (h->ev.size() < h->ev_used + 2) {
             hipEvent_t e;
@@ -268,7 +283,7 @@ int run_gemm(vqs_handle* h, const GemmCall& g, hipStream_t st, const char* what)
         h->ev_what.emplace_back(what, 2.0 * (double)g.M * (double)g.N * (double)g.K * (double)g.batch);
         h->prof_flops += 2.0 * (double)g.M * (double)g.N * (double)g.K * (double)g.batch;
         {   // every operand read once, every result written once
-            const double out_b = (g.epi == vqs::EPI_F32 || g.epi == vqs::EPI_F32_RESID) ? 4.0 : 2.0;
+            const double out_b = (g.epi == vqs::EPI_F32 || g.epi == vqs::EPI_F32_RESID) ? 4.0 : (g.epi == vqs::EPI_RESID_RMS ? 10.0 : 2.0);
             const double out_n = (g.epi == vqs::EPI_GATED) ? 0.5 * (double)g.N : (double)g.N;
             h->prof_bytes += (double)g.batch * (2.0 * ((double)g.M + (double)g.N) * (double)g.K + out_b * (double)g.M * out_n);
         }
@@ -332,6 +347,7 @@ int vqs_create(const vqs_config* cfg, vqs_handle** out) {
     }
     if (const char* cm = std::getenv("VQS_CROSS_MODE")) h->cross_mode = std::atoi(cm);
     if (const char* sk = std::getenv("VQS_SPLITK")) h->splitk = std::atoi(sk);
+    if (const char* fn = std::getenv("VQS_FUSED_NORM")) h->fused_norm = std::atoi(fn);
     const char* v = std::getenv("VQS_GEMM_VARIANT");
     h->gemm_variant = v ? std::atoi(v) : 3;   // 3 = persistent kernel (gemm.hip)
     return VQS_OK;
@@ -558,20 +574,39 @@ static int encoder_pass(vqs_handle* h, const ScoreWs& w, const void* d_feats, co
                                        w.hidden, B, L, P, D, V, st), "embed_splice");
 
     // ---------------- encoder (same pending-delta protocol as the vision tower)
+    // Fused residual + RMSNorm (VQS_FUSED_NORM=1, off by default): the o / wo GEMM epilogue updates the fp32 stream in
+    // place, writes the NEXT norm's operand x*ln_w (without the per-row 1/rms) and per-tile partial row sums of squares;
+    // the consuming qkv / wi GEMM scales its accumulator rows by 1/rms.  Bit-exact repeatable and parity-tested, but the
+    // read-modify-write epilogue costs the producer GEMMs +0.55 ms per launch against 0.64 ms for the norm kernel it
+    // removes (+1 % end to end, and it lowers the GEMM's own roofline fraction): kept as a lab path.
+    const bool fused = h->fused_norm != 0 && (h->gemm_variant == 3 || h->gemm_variant == 5 || h->gemm_variant == 7);
+    const int parts = (D + 255) / 256;
+    bool scaled = false;          // w.xn holds an un-normalised operand whose row sums are in w.rowss
     const bf16_t* pend = nullptr;
+    auto consume = [&](GemmCall& g) {
+        if (scaled) {
+            g.rowss_in = w.rs; g.rowss_parts = 0;
+        }
+    };
+    auto produce = [&](GemmCall& g, const bf16_t* next_ln) {
+        g.epi = vqs::EPI_RESID_RMS; g.C = w.xn; g.ldc = D; g.hres = w.hidden; g.ldh = D; g.lnw = next_ln; g.rowss_out = w.rowss;
+    };
     for (int i = 0; i < c.enc_layers; ++i) {
         const std::string p = "encoder.block." + std::to_string(i) + ".";
         GETW(ln0, p + "layer.0.layer_norm.weight", D);
         GETW(ow, p + "layer.0.SelfAttention.o.weight", (int64_t)D * I);
         GETW(ln1, p + "layer.1.layer_norm.weight", D);
         GETW(wo, p + "layer.1.DenseReluDense.wo.weight", (int64_t)D * F);
-        HIPCHK(h, vqs::launch_rmsnorm(w.hidden, pend, ln0, w.xn, M, D, c.t5_ln_eps, st), "enc rmsnorm0");
-        pend = nullptr;
+        if (!scaled) {
+            HIPCHK(h, vqs::launch_rmsnorm(w.hidden, pend, ln0, w.xn, M, D, c.t5_ln_eps, st), "enc rmsnorm0");
+            pend = nullptr;
+        }
         {
             GemmCall g{w.xn, h->enc_qkv[i], nullptr};
             g.M = M; g.N = 3 * I; g.K = D; g.lda = D; g.ldw = D; g.ldc = 0; g.epi = vqs::EPI_HEADS;
             g.S = S; g.H = H; g.inner = I;
             g.heads[0] = w.q; g.heads[1] = w.k; g.heads[2] = w.v;
+            consume(g);
             RUN(run_gemm(h, g, st, "enc qkv"));
         }
         {
@@ -581,19 +616,37 @@ static int encoder_pass(vqs_handle* h, const ScoreWs& w, const void* d_feats, co
         {
             GemmCall g{w.attn, ow, w.delta};
             g.M = M; g.N = D; g.K = I; g.lda = I; g.ldw = I; g.ldc = D; g.epi = vqs::EPI_BF16;
+            if (fused) produce(g, ln1);
             RUN(run_gemm(h, g, st, "enc o"));
+            if (fused) HIPCHK(h, vqs::launch_rowss_to_rs(w.rowss, parts, M, 1.0f / (float)D, c.t5_ln_eps, w.rs, st), "row 1/rms");
         }
-        HIPCHK(h, vqs::launch_rmsnorm(w.hidden, w.delta, ln1, w.xn, M, D, c.t5_ln_eps, st), "enc rmsnorm1");
+        if (fused) {
+            scaled = true;
+        } else {
+            HIPCHK(h, vqs::launch_rmsnorm(w.hidden, w.delta, ln1, w.xn, M, D, c.t5_ln_eps, st), "enc rmsnorm1");
+            scaled = false;
+        }
         {
             GemmCall g{w.xn, h->enc_wi[i], w.ff};
             g.M = M; g.N = 2 * F; g.K = D; g.lda = D; g.ldw = D; g.ldc = F; g.epi = vqs::EPI_GATED;
+            consume(g);
             RUN(run_gemm(h, g, st, "enc wi"));
         }
         {
             GemmCall g{w.ff, wo, w.delta};
             g.M = M; g.N = D; g.K = F; g.lda = F; g.ldw = F; g.ldc = D; g.epi = vqs::EPI_BF16;
-            RUN(run_gemm(h, g, st, "enc wo"));
-            pend = w.delta;
+            if (fused && i + 1 < c.enc_layers) {
+                GETW(ln0_next, "encoder.block." + std::to_string(i + 1) + ".layer.0.layer_norm.weight", D);
+                produce(g, ln0_next);
+                RUN(run_gemm(h, g, st, "enc wo"));
+                HIPCHK(h, vqs::launch_rowss_to_rs(w.rowss, parts, M, 1.0f / (float)D, c.t5_ln_eps, w.rs, st), "row 1/rms");
+                scaled = true;
+                pend = nullptr;
+            } else {
+                RUN(run_gemm(h, g, st, "enc wo"));
+                scaled = false;
+                pend = w.delta;
+            }
         }
     }
     {
@@ -853,6 +906,24 @@ int vqs_profile_bytes(vqs_handle* h, double* gemm_bytes) {
 }
 
 // ---------------------------------------------------------------------------- single-kernel entry points
+// GEMM with the fused residual + RMSNorm pieces (tests): epilogue 7 (producer: hres/lnw/rowss_out) and/or a consumer row
+// scale (rowss_in/rowss_parts/rs_invd/rs_eps) in front of epilogues 0, 3, 5, 6.  Persistent variants (3, 5, 7) only.
+int vqs_gemm_rms(const void* A, const void* W, void* C, float* hres, const void* lnw, float* rowss_out, const float* rowss_in,
+                 int32_t rowss_parts, float rs_invd, float rs_eps, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw,
+                 int32_t ldc, int32_t epilogue, int32_t S, int32_t H, int32_t variant, void* stream) {
+    vqs::GemmParams p;
+    p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.C = C; p.bias = nullptr; p.resid = nullptr;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc;
+    p.S = S > 0 ? S : 1; p.H = H; p.inner = H * 64 > 0 ? H * 64 : 1;
+    const size_t per = (size_t)(S > 0 ? M / S : 0) * H * S * 64;
+    p.heads_out[0] = (bf16_t*)C;
+    p.heads_out[1] = (bf16_t*)C + per;
+    p.heads_out[2] = (bf16_t*)C + 2 * per;
+    p.hres = hres; p.ldh = N; p.lnw = (const bf16_t*)lnw; p.rowss_out = rowss_out;
+    p.rowss_in = rowss_in; p.rowss_parts = rowss_parts; p.rs_invd = rs_invd; p.rs_eps = rs_eps;
+    return vqs::launch_gemm(p, epilogue, variant, (hipStream_t)stream) == hipSuccess ? VQS_OK : VQS_ERR_HIP;
+}
+
 int vqs_gemm(const void* A, const void* W, void* C, const void* bias, const float* resid, int32_t M, int32_t N, int32_t K,
              int32_t lda, int32_t ldw, int32_t ldc, int32_t epilogue, int32_t S, int32_t H, int32_t variant, void* stream) {
     vqs::GemmParams p;

@@ -18,7 +18,9 @@ enum GemmEpilogue : int {
     EPI_F32_RESID = 4,   // C fp32 [M,ldc] = resid + acc (+bias); resid may alias C
     EPI_GATED = 5,       // C bf16 [M,N/2] = gelu_new(acc[wi_0 col]) * acc[wi_1 col]; W rows interleaved in blocks of 32
     EPI_HEADS = 6,       // scatter to head-major [B,H,S,64] tensors: which = col / inner selects heads_out[which]
-    EPI_COUNT = 7
+    EPI_RESID_RMS = 7,   // fused residual update + un-normalised RMSNorm operand (persistent kernels only):
+                         //   hres[M,N] (fp32) += acc;  C bf16 [M,ldc] = hres * lnw[col];  rowss_out[n0/256][row] = sum_cols hres^2
+    EPI_COUNT = 8
 };
 
 struct GemmParams {
@@ -35,6 +37,16 @@ struct GemmParams {
     // batched GEMM (persistent variant only): entry z uses A + z*sA, W + z*sW, C + z*sC (strides in elements)
     int batch = 1;
     long long sA = 0, sW = 0, sC = 0;
+    // EPI_RESID_RMS (producer side of the fused residual + RMSNorm)
+    float* hres = nullptr;           // [M, ldh] fp32 residual stream, read-modified-written
+    int ldh = 0;
+    const bf16_t* lnw = nullptr;     // [N] weight of the NEXT RMSNorm
+    float* rowss_out = nullptr;      // [ceil(N/256)][M] per-tile partial sums of squares of the updated rows
+    // consumer side (any epilogue): the A operand is x*lnw un-normalised; scale accumulator row r by
+    // rsqrt(sum_p rowss_in[p][r] * rs_invd + rs_eps) before the epilogue proper
+    const float* rowss_in = nullptr;
+    int rowss_parts = 0;
+    float rs_invd = 0.0f, rs_eps = 0.0f;
 };
 
 // variant 0 = direct-to-LDS (global_load_lds) staging; variant 1 = register-staged (debug / A-B)
@@ -91,6 +103,7 @@ hipError_t launch_embed_splice(const int* ids, const int* sent_pos, const int* e
 // decoder_input_ids = shift_right(labels); h[b,t] = shared[id]  (fp32 out)
 hipError_t launch_decoder_embed(const int* labels, int ld_labels, const bf16_t* shared, float* out, int B, int T, int D,
                                 int vocab, hipStream_t s);
+hipError_t launch_rowss_to_rs(const float* rowss, int parts, int M, float invd, float eps, float* rs, hipStream_t s);
 hipError_t launch_reduce_slices(const float* part, int nslices, size_t n, bf16_t* out, hipStream_t s);
 hipError_t launch_argmax_append(const float* logits, int ldl, int V, int* tokens, int ld_tokens, int B, int T,
                                 hipStream_t s);

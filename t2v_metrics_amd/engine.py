@@ -56,6 +56,8 @@ _SIGNATURES = {
     "vqs_profile_bytes": (_c_i32, [_c_vp, ctypes.POINTER(ctypes.c_double)]),
     "vqs_profile_report": (ctypes.c_char_p, [_c_vp]),
     "vqs_gemm": (_c_i32, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp] + [_c_i32] * 10 + [_c_vp]),
+    "vqs_gemm_rms": (_c_i32, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i32, _c_f32, _c_f32, _c_i32, _c_i32, _c_i32,
+                              _c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_vp]),
     "vqs_attention": (_c_i32, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i32, _c_i32, _c_i32, _c_f32, _c_vp]),
     "vqs_decoder_attention": (_c_i32, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp] + [_c_i32] * 7 + [_c_vp]),
     "vqs_rmsnorm": (_c_i32, [_c_vp, _c_vp, _c_vp, _c_vp, _c_i32, _c_i32, _c_f32, _c_vp]),
@@ -306,6 +308,44 @@ def gemm(A, W, epilogue: int, bias=None, resid=None, out=None, S: int = 0, H: in
                       W.stride(0), ldc, epilogue, S, H, variant, _stream_ptr())
     if rc != 0:
         raise VqsError(f"vqs_gemm failed ({rc})")
+    return out
+
+
+def gemm_resid_rms(A, W, hres, lnw, variant: int = 3):
+    """Producer of the fused residual + RMSNorm: hres (fp32 [M,N], in place) += A @ W.T; returns
+    (xhat bf16 [M,N] = hres * lnw, rowss fp32 [ceil(N/256), M] partial row sums of squares)."""
+    lib = load_library()
+    M, K = A.shape
+    N = W.shape[0]
+    xhat = torch.empty(M, N, dtype=torch.bfloat16, device=A.device)
+    rowss = torch.zeros((N + 255) // 256, M, dtype=torch.float32, device=A.device)
+    rc = lib.vqs_gemm_rms(A.data_ptr(), W.data_ptr(), xhat.data_ptr(), hres.data_ptr(), lnw.data_ptr(), rowss.data_ptr(), None,
+                          0, 0.0, 0.0, M, N, K, A.stride(0), W.stride(0), N, 7, 0, 0, variant, _stream_ptr())
+    if rc != 0:
+        raise VqsError(f"vqs_gemm_rms (producer) failed ({rc})")
+    return xhat, rowss
+
+
+def gemm_rowscaled(A, W, epilogue: int, rowss, d_norm: int, eps: float, S: int = 0, H: int = 0, variant: int = 3):
+    """Consumer: epilogue(rsqrt(mean_sq(row) + eps) * (A @ W.T)) with mean_sq from the producer's partial sums."""
+    lib = load_library()
+    M, K = A.shape
+    N = W.shape[0]
+    dev = A.device
+    if epilogue == 0:
+        out, ldc = torch.empty(M, N, dtype=torch.bfloat16, device=dev), N
+    elif epilogue == 3:
+        out, ldc = torch.empty(M, N, dtype=torch.float32, device=dev), N
+    elif epilogue == 5:
+        out, ldc = torch.empty(M, N // 2, dtype=torch.bfloat16, device=dev), N // 2
+    elif epilogue == 6:
+        out, ldc = torch.empty(N // (H * 64), M // S, H, S, 64, dtype=torch.bfloat16, device=dev), 0
+    else:
+        raise ValueError(epilogue)
+    rc = lib.vqs_gemm_rms(A.data_ptr(), W.data_ptr(), out.data_ptr(), None, None, None, rowss.data_ptr(), rowss.shape[0],
+                          1.0 / d_norm, eps, M, N, K, A.stride(0), W.stride(0), ldc, epilogue, S, H, variant, _stream_ptr())
+    if rc != 0:
+        raise VqsError(f"vqs_gemm_rms (consumer) failed ({rc})")
     return out
 
 

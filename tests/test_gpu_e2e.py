@@ -232,6 +232,31 @@ def test_decoder_split_k_matches_unsplit(monkeypatch):
     assert e0 <= 2 * LOGPROB_TOL_BF16 and e1 <= 2 * LOGPROB_TOL_BF16 and d01 <= 2 * LOGPROB_TOL_BF16, (e0, e1, d01)
 
 
+def test_fused_residual_rmsnorm_matches_separate_kernels(monkeypatch):
+    """VQS_FUSED_NORM=1: the T5 encoder's o / wo GEMM epilogues update the residual stream and hand the next RMSNorm's
+    operand + row sums of squares to the consuming GEMM (no norm kernel).  Default (0): separate add+norm kernels.
+    Same function: both agree with the oracle and with each other; the fused path is bitwise repeatable."""
+    from oracle.clip_t5_oracle import Oracle
+    from t2v_metrics_amd.engine import VqsEngine
+    cfg = get_config("small")
+    w = make_seeded_weights(cfg, seed=23, device="cpu", lm_head_gain=2.0)
+    pix, img_index, ids, labels = _inputs(cfg, 9, 3, 24, 2, seed=8)
+    ref = Oracle(cfg, w).forward(pix.float(), img_index, ids, labels)["label_logprobs"]
+    out = {}
+    for mode in ("0", "1", "1b"):
+        monkeypatch.setenv("VQS_FUSED_NORM", mode[0])
+        eng = VqsEngine(cfg, w, device="cuda:0")
+        lp, _ = eng.score(eng.encode_images(pix.cuda()), img_index, ids, labels)
+        torch.cuda.synchronize()
+        out[mode] = lp.cpu()
+        eng.close()
+    assert torch.equal(out["1"], out["1b"])
+    d01 = (out["0"] - out["1"]).abs().max().item()
+    e0, e1 = (out["0"] - ref).abs().max().item(), (out["1"] - ref).abs().max().item()
+    _record("fused-norm", {"separate_vs_oracle": e0, "fused_vs_oracle": e1, "separate_vs_fused": d01})
+    assert e0 <= 2 * LOGPROB_TOL_BF16 and e1 <= 2 * LOGPROB_TOL_BF16 and d01 <= 2 * LOGPROB_TOL_BF16, (e0, e1, d01)
+
+
 def test_engine_matches_hf_golden_fixture(golden_dir):
     """The committed HF-module fixture (tests/golden/hf_tiny.npz): vision hidden_states[-2] from the HIP tower."""
     from t2v_metrics_amd.engine import VqsEngine

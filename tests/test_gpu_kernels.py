@@ -67,6 +67,37 @@ def describe(out, ref):
     return describe_mismatch(out, ref, 0.0, 0.0, "persistent vs variant 0")
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 512, 128), (1000, 768, 256), (70000, 512, 64)])
+@pytest.mark.parametrize("variant", [3, 5])
+def test_gemm_fused_residual_rmsnorm(eng, M, N, K, variant):
+    """Producer epilogue (hres += A.W^T in place, xhat = hres*ln_w, per-tile row sums of squares) and consumer row scale
+    against fp32 torch: together they must equal  rmsnorm(h + A.W^T) @ W2^T  (HF modeling_t5.py:59-72,140)."""
+    g = torch.Generator(device="cuda").manual_seed(41)
+    A = randn_bf16(M, K, seed=42)
+    W = randn_bf16(N, K, seed=43, scale=K ** -0.5)
+    lnw = (1.0 + 0.25 * torch.randn(N, device="cuda", generator=g)).to(torch.bfloat16)
+    h0 = torch.randn(M, N, device="cuda", generator=g) * 2.0
+    h_ref = h0 + A.float() @ W.float().t()
+    h = h0.clone()
+    xhat, rowss = eng.gemm_resid_rms(A, W, h, lnw, variant=variant)
+    assert_close(h, h_ref, 1e-3, 1e-4, "residual stream update")
+    assert_close(xhat, h_ref * lnw.float(), 1e-2, 1e-2, "un-normalised norm operand")
+    assert_close(rowss.sum(0), h_ref.pow(2).sum(-1), 1e-2, 1e-3, "row sums of squares")
+    for _ in range(2):            # deterministic (no atomics): bitwise repeatable
+        h2 = h0.clone()
+        x2, r2 = eng.gemm_resid_rms(A, W, h2, lnw, variant=variant)
+        assert torch.equal(x2, xhat) and torch.equal(r2, rowss) and torch.equal(h2, h)
+    # consumer: plain bf16 and gated epilogues
+    N2 = 256
+    W2 = randn_bf16(N2, N, seed=44, scale=N ** -0.5)
+    rs = torch.rsqrt(h_ref.pow(2).mean(-1, keepdim=True) + 1e-6)
+    ref = (xhat.float() * rs) @ W2.float().t()
+    out = eng.gemm_rowscaled(xhat, W2, 0, rowss, N, 1e-6, variant=variant)
+    assert_close(out, ref, 2e-2, 1e-2, "row-scaled consumer (bf16)")
+    out = eng.gemm_rowscaled(xhat, W2, 3, rowss, N, 1e-6, variant=variant)
+    assert_close(out, ref, 2e-3, 1e-3, "row-scaled consumer (fp32)")
+
+
 def test_gemm_transpose_detecting(eng):
     """A = I-like structure with an asymmetric W catches swapped C layouts."""
     M = N = K = 256

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""End-to-end throughput of the drop-in API INCLUDING the host input pipeline: PNG decode +
+expand2square + PIL bicubic 336 + CLIP normalise on the thread pool, pinned staging + H2D, tokenisation, engine.
+Seeded weights, a stand-in whitespace tokenizer (no SentencePiece model offline).  Prints one JSON line."""
+import argparse, json, os, sys, tempfile, time, zlib
+import numpy as np
+import torch
+from PIL import Image
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import t2v_metrics_amd as t2v
+
+
+class WordTokenizer:
+    def __init__(self, vocab):
+        self.vocab = vocab
+
+    def __call__(self, text):
+        class R:
+            pass
+        r = R()
+        r.input_ids = [3 + zlib.crc32(w.encode()) % (self.vocab - 3) for w in text.split()] + [1]
+        return r
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--pairs", type=int, default=1024)
+    ap.add_argument("--size", type=int, default=512, help="PNG edge length")
+    ap.add_argument("--model", default="clip-flant5-xl")
+    ap.add_argument("--workers", type=int, default=None)
+    ap.add_argument("--reps", type=int, default=2)
+    args = ap.parse_args()
+    tmp = tempfile.mkdtemp(prefix="vqs_imgs_")
+    rng = np.random.RandomState(0)
+    base = rng.randint(0, 256, (args.size // 8, args.size // 8, 3), dtype=np.uint8)
+    paths = []
+    for i in range(args.pairs):          # smooth-ish images (upsampled noise + per-image offset): realistic PNG sizes
+        im = Image.fromarray(np.roll(base, i, axis=0)).resize((args.size, args.size + (i % 3) * 16), Image.BILINEAR)
+        p = os.path.join(tmp, f"im{i:05d}.png")
+        im.save(p)
+        paths.append(p)
+    texts = [f"a photo number {i} of someone doing something in place {i % 17}" for i in range(args.pairs)]
+    from t2v_metrics_amd.config import get_config
+    cfg = get_config(args.model)
+    scorer = t2v.VQAScore(model=args.model, device="cuda", weights="seeded", tokenizer=WordTokenizer(cfg.t5.vocab),
+                          num_workers=args.workers)
+    m = scorer.model
+    t0 = time.perf_counter()
+    m._load_images_host(paths[:256])
+    host_256 = time.perf_counter() - t0
+    m.forward(paths[:256], texts[:256])          # warm-up (workspaces, pools)
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(args.reps):
+        t0 = time.perf_counter()
+        sc = m.forward(paths, texts)
+        torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    print(json.dumps({"metric": "pairs/s through VQAScoreModel.forward incl. PNG decode, preprocessing, H2D, tokenisation",
+                      "value": args.pairs / best, "pairs": args.pairs, "png_edge": args.size, "model": args.model,
+                      "workers": m.num_workers, "host_cpus": os.cpu_count(),
+                      "host_preprocess_256_images_s": host_256, "score_range": [float(sc.min()), float(sc.max())]}))
+
+
+if __name__ == "__main__":
+    main()
