@@ -92,13 +92,21 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # VQS_BENCH_BACKEND=gloo lets the N > 1 code path be exercised on a box with fewer GPUs than ranks (ranks share
+    # devices, collectives go through host memory); the driver's runs use the default: nccl = RCCL, one GPU per rank.
+    backend = os.environ.get("VQS_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    coll_device = device if backend == "nccl" else torch.device("cpu")
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group(backend="nccl", device_id=device)
+        if backend == "nccl":
+            dist_mod.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist_mod.init_process_group(backend=backend)
         dist = dist_mod
 
     from t2v_metrics_amd.engine import VqsEngine
@@ -132,6 +140,7 @@ def main():
         all_scores.append(sc)
     local = torch.cat(all_scores) if all_scores else torch.zeros(0, device=device)
     if dist is not None:
+        local = local.to(coll_device)
         gathered = [torch.empty_like(local) for _ in range(world)]
         dist.all_gather(gathered, local)            # the path's only exchange: scores to every rank
     barrier()
@@ -142,7 +151,7 @@ def main():
     if rank == 0 and os.environ.get("VQS_BENCH_REPORT"):
         print(eng.profile_report(), file=sys.stderr, flush=True)
 
-    t_el = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    t_el = torch.tensor([elapsed], device=coll_device, dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
     elapsed = float(t_el.item())
