@@ -234,6 +234,81 @@ def golden_generate(name: str, seed: int, n_img: int, B: int, L: int, max_new: i
     print(path, os.path.getsize(path) // 1024, "KiB tokens", toks.tolist(), "min margin %.3f" % float(margins.min()))
 
 
+def build_hf_qwen(cfg, weights):
+    """HF Qwen2_5_VLForConditionalGeneration at the dims of a Qwen25VLConfig, eager attention, fp32, seeded weights."""
+    from transformers import Qwen2_5_VLConfig, Qwen2_5_VLForConditionalGeneration
+    v, t = cfg.vision, cfg.text
+    vis = dict(depth=v.depth, hidden_size=v.hidden, hidden_act="silu", intermediate_size=v.mlp, num_heads=v.heads,
+               in_channels=v.in_channels, patch_size=v.patch, spatial_merge_size=v.spatial_merge,
+               temporal_patch_size=v.temporal_patch, tokens_per_second=v.tokens_per_second, window_size=v.window,
+               out_hidden_size=v.out_hidden, fullatt_block_indexes=list(v.fullatt_blocks))
+    txt = dict(vocab_size=t.vocab, hidden_size=t.hidden, intermediate_size=t.mlp, num_hidden_layers=t.layers,
+               num_attention_heads=t.heads, num_key_value_heads=t.kv_heads, hidden_act="silu", max_position_embeddings=32768,
+               rms_norm_eps=t.rms_eps, tie_word_embeddings=False, use_sliding_window=False,
+               rope_parameters={"rope_type": "default", "rope_theta": t.rope_theta, "mrope_section": list(t.mrope_section)})
+    hc = Qwen2_5_VLConfig(text_config=txt, vision_config=vis, image_token_id=cfg.image_token_id, video_token_id=cfg.video_token_id,
+                          vision_start_token_id=cfg.vision_start_token_id, vision_end_token_id=cfg.vision_end_token_id,
+                          bos_token_id=None, eos_token_id=None, pad_token_id=None)
+    hc._attn_implementation = "eager"
+    m = Qwen2_5_VLForConditionalGeneration(hc).eval().float()
+    missing, unexpected = m.load_state_dict({k: v.float() for k, v in weights.items()}, strict=True)
+    return m
+
+
+def golden_qwen(name: str, seed: int, grids, text_lens, gain: float):
+    """One batch of video samples through HF Qwen2.5-VL (fp32 modules, bf16-rounded seeded weights): per sample a
+    prompt [text | <vision_start> <video_pad>*n <vision_end> | text], run one by one exactly as the reference does
+    (qwen2vl_model.py:190-230: batch 1, generate(max_new_tokens=1, output_scores=True)); stores the inputs, the merged
+    vision tokens, the 3-D rope positions and the last-position logits."""
+    from t2v_metrics_amd.qwen import get_qwen_config
+    from t2v_metrics_amd.qwen.weights import make_seeded_qwen_weights
+    cfg = get_qwen_config(name)
+    w = make_seeded_qwen_weights(cfg, seed=seed, dtype=torch.bfloat16, lm_head_gain=gain)
+    m = build_hf_qwen(cfg, w)
+    g = torch.Generator().manual_seed(seed + 5)
+    v = cfg.vision
+    B = len(grids)
+    pix, ids_rows, merged_all, pos_all, logits_all = [], [], [], [], []
+    for b, ((t, h, wd), (n_pre, n_post)) in enumerate(zip(grids, text_lens)):
+        n_patches = t * h * wd
+        pv = torch.randn(n_patches, v.patch_dim, generator=g).to(torch.bfloat16).float()
+        n_merged = n_patches // v.merge_unit
+        pre = torch.randint(10, cfg.text.vocab, (n_pre,), generator=g)
+        post = torch.randint(10, cfg.text.vocab, (n_post,), generator=g)
+        ids = torch.cat([pre, torch.tensor([cfg.vision_start_token_id]), torch.full((n_merged,), cfg.video_token_id),
+                         torch.tensor([cfg.vision_end_token_id]), post])[None]
+        # mm_token_type_ids is what the HF processor hands over (0 text, 1 image, 2 video); without it the model falls
+        # back to 1-D positions (compute_3d_position_ids :1135-1183) -- the reference passes the processor's dict
+        mm_type = torch.where(ids == cfg.video_token_id, 2, 0)
+        with torch.no_grad():
+            out = m(input_ids=ids, attention_mask=torch.ones_like(ids), pixel_values_videos=pv, mm_token_type_ids=mm_type,
+                    video_grid_thw=torch.tensor([[t, h, wd]]), output_hidden_states=False)
+            m.model.rope_deltas = None
+            gen = m.generate(input_ids=ids, attention_mask=torch.ones_like(ids), pixel_values_videos=pv, mm_token_type_ids=mm_type,
+                             video_grid_thw=torch.tensor([[t, h, wd]]), max_new_tokens=1, do_sample=False,
+                             output_scores=True, return_dict_in_generate=True)
+            m.model.rope_deltas = None
+            assert torch.allclose(gen.scores[0][0], out.logits[0, -1], atol=1e-4), "first generated scores != last prefill logits"
+            merged = m.model.get_video_features(pv, torch.tensor([[t, h, wd]])).pooler_output
+            merged = merged[0] if isinstance(merged, (list, tuple)) else merged
+            pos, _ = m.model.get_rope_index(ids, mm_token_type_ids=mm_type, video_grid_thw=torch.tensor([[t, h, wd]]),
+                                            attention_mask=torch.ones_like(ids))
+        pix.append(pv); ids_rows.append(ids[0]); merged_all.append(merged.float()); pos_all.append(pos[:, 0]); logits_all.append(out.logits[0, -1].float())
+    L = max(len(r) for r in ids_rows)
+    ids_pad = torch.zeros(B, L, dtype=torch.long)
+    mask = torch.zeros(B, L, dtype=torch.long)
+    pos_pad = torch.zeros(3, B, L, dtype=torch.long)
+    for b, r in enumerate(ids_rows):
+        ids_pad[b, : len(r)] = r
+        mask[b, : len(r)] = 1
+        pos_pad[:, b, : len(r)] = pos_all[b]
+    path = os.path.join(GOLDEN, f"qwen_{name.split('-')[-1]}.npz")
+    np.savez_compressed(path, seed=seed, gain=gain, grids=np.asarray(grids), input_ids=ids_pad.numpy(), attention_mask=mask.numpy(),
+                        pixel_values=torch.cat(pix).numpy(), merged=torch.cat(merged_all).numpy(), position_ids=pos_pad.numpy(),
+                        logits=torch.stack(logits_all).numpy())
+    print(path, os.path.getsize(path) // 1024, "KiB", "logits range", float(torch.stack(logits_all).min()), float(torch.stack(logits_all).max()))
+
+
 def golden_preprocess():
     """HF CLIPImageProcessor (PIL backend here: no torchvision) on seeded images at a small target size."""
     from PIL import Image
@@ -264,3 +339,5 @@ if __name__ == "__main__":
     golden_e2e("small", seed=24, n_img=2, B=6, L=20, T=2, gain=4.0)
     golden_generate("tiny", seed=41, n_img=2, B=6, L=12, max_new=6, gain=8.0)
     golden_generate("small", seed=42, n_img=2, B=4, L=20, max_new=5, gain=8.0)
+    golden_qwen("qwen-tiny", seed=51, grids=[(2, 8, 8), (1, 4, 12), (3, 12, 8)], text_lens=[(3, 4), (5, 2), (2, 6)], gain=4.0)
+    golden_qwen("qwen-small", seed=52, grids=[(2, 8, 16), (2, 16, 8)], text_lens=[(4, 5), (3, 7)], gain=4.0)

@@ -1,0 +1,47 @@
+"""Pins the Qwen2.5-VL CPU oracle (oracle/qwen25vl_oracle.py) to HF Qwen2_5_VLForConditionalGeneration outputs on seeded
+weights (fixtures from oracle/make_golden.py::golden_qwen).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.qwen25vl_oracle import QwenOracle, vision_window_index
+from t2v_metrics_amd.qwen import get_qwen_config
+from t2v_metrics_amd.qwen.weights import make_seeded_qwen_weights, qwen_weight_specs
+
+
+@pytest.mark.parametrize("name", ["qwen-tiny", "qwen-small"])
+def test_oracle_matches_hf_fixture(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, f"qwen_{name.split('-')[-1]}.npz"))
+    cfg = get_qwen_config(name)
+    w = make_seeded_qwen_weights(cfg, seed=int(z["seed"]), dtype=torch.bfloat16, lm_head_gain=float(z["gain"]))
+    o = QwenOracle(cfg, w)
+    grids = [tuple(int(x) for x in g) for g in z["grids"]]
+    ids, mask = torch.from_numpy(z["input_ids"]), torch.from_numpy(z["attention_mask"])
+    out = o.forward(ids, mask, torch.from_numpy(z["pixel_values"]), grids, return_stages=True)
+    assert torch.equal(out["position_ids"] * mask[None], torch.from_numpy(z["position_ids"]) * mask[None])   # integer-exact
+    ref_merged, ref_logits = torch.from_numpy(z["merged"]), torch.from_numpy(z["logits"])
+    assert (out["merged"] - ref_merged).abs().max().item() <= 2e-4 * max(1.0, ref_merged.abs().max().item())
+    assert (out["logits"] - ref_logits).abs().max().item() <= 5e-4, (out["logits"] - ref_logits).abs().max().item()
+    # the score the reference reports (qwen2vl_model.py:268-274): softmax(logits)[answer id]
+    p_ref = torch.softmax(ref_logits, -1)[:, 17]
+    assert torch.allclose(o.answer_prob(out["logits"], 17), p_ref, rtol=2e-3, atol=1e-7)
+
+
+def test_window_index_is_a_permutation_with_full_windows():
+    """Config 5 geometry (336 x 448 frames: 24 x 32 patches, 12 x 16 merged cells, 4 x 4-cell windows): every window is
+    full (64 patches), windows tile each temporal patch, the index is a permutation."""
+    idx, cu = vision_window_index([(4, 24, 32)], merge=2, window=112, patch=14)
+    assert sorted(idx.tolist()) == list(range(4 * 12 * 16))
+    assert all(b - a == 64 for a, b in zip(cu[:-1], cu[1:])) and cu[-1] == 4 * 24 * 32
+
+
+def test_weight_inventory_matches_the_public_7b_shapes():
+    specs = {n: s for n, s, _ in qwen_weight_specs(get_qwen_config("qwen2.5-vl-7b"))}
+    assert specs["model.visual.blocks.0.attn.qkv.weight"] == (3840, 1280)
+    assert specs["model.visual.blocks.31.mlp.down_proj.weight"] == (1280, 3420)
+    assert specs["model.visual.merger.mlp.2.weight"] == (3584, 5120)
+    assert specs["model.language_model.layers.27.self_attn.k_proj.weight"] == (512, 3584)
+    assert specs["model.language_model.layers.0.mlp.gate_proj.weight"] == (18944, 3584)
+    assert specs["lm_head.weight"] == (152064, 3584)
