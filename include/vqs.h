@@ -149,6 +149,17 @@ int vqs_gemm_rms(const void* d_A, const void* d_W, void* d_C, float* d_hres, con
                  int32_t lda, int32_t ldw, int32_t ldc, int32_t epilogue, int32_t S, int32_t H, int32_t variant, void* stream);
 int vqs_attention(const void* d_q, const void* d_k, const void* d_v, void* d_out, const float* d_bias_table,
                   const int32_t* d_key_len, int32_t B, int32_t H, int32_t S, float scale, void* stream);
+/* Rotary position embedding (rotate-half), in place on d_x bf16 [B,H,S,hd]; d_cos / d_sin fp32 [B*S, half] hold the per-token
+ * angles' cos / sin for dims i < half (dim i pairs with i + half) -- HF models/qwen2_5_vl/modeling_qwen2_5_vl.py:153-172
+ * (vision, 2-D) and :557-599 (multimodal sections).  Dims >= 2*half are left alone. */
+int vqs_rope(void* d_x, const float* d_cos, const float* d_sin, int32_t B, int32_t H, int32_t S, int32_t hd, int32_t half,
+             void* stream);
+/* Flash attention with head_dim hd = 128, grouped-query heads (query head h reads key/value head h / (H / Hkv)) and an
+ * optional causal mask -- the attention of HF Qwen2_5_VLAttention / Qwen2_5_VLVisionAttention
+ * (models/qwen2_5_vl/modeling_qwen2_5_vl.py:187-208,602-689; 80-wide tower heads zero-padded to 128).
+ * q [B,H,S,hd], k/v [B,Hkv,S,hd] bf16 head-major; out bf16 [B*S, H*hd]; key_len [B] or NULL. */
+int vqs_attention_hd(const void* d_q, const void* d_k, const void* d_v, void* d_out, const int32_t* d_key_len, int32_t B,
+                     int32_t H, int32_t Hkv, int32_t S, int32_t hd, float scale, int32_t causal, void* stream);
 int vqs_decoder_attention(const void* d_q, const void* d_k, const void* d_v, void* d_out, const float* d_bias_table,
                           const int32_t* d_key_len, int32_t B, int32_t H, int32_t T, int32_t S, int32_t ldq, int32_t ldk,
                           int32_t cross, void* stream);

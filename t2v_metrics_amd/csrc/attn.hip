@@ -595,6 +595,222 @@ __global__ void __launch_bounds__(256) attn_fwd_dma_kernel(const AttnParams p) {
 }
 
 
+// =====================================================================================================
+// attn_fwd_hd_kernel<HD, CAUSAL> -- the LDS-DMA flash kernel above generalised for the Qwen2.5-VL row:
+// head_dim HD (128; the tower's 80-wide heads are zero-padded to 128 by the packer), grouped-query attention (query
+// head h reads key/value head h / (H / Hkv)), optional causal mask (HF Qwen2_5_VLAttention is_causal, key <= query),
+// no position bias (RoPE is applied to Q/K beforehand).  Same MFMA operand maps and softmax; per tile 2*HD/16 QK^T
+// MFMAs and (HD/32 + 1) * 4 PV MFMAs per wave; K rows are HD*2 bytes with the 16-B chunk index XOR-ed with row & 15
+// (256-B rows span all 64 banks: 16 rows of a ds_read_b128 lane group land on 16 different slots); V is 2 * HD/16
+// sub-tiles [32 keys][16 d], read with ds_read_b64_tr_b16.
+// q [B, H, S, HD]; k, v [B, Hkv, S, HD]; out [B*S, H*HD].
+// =====================================================================================================
+template <int HD, bool CAUSAL>
+__global__ void __launch_bounds__(256) attn_fwd_hd_kernel(const AttnParams p) {
+    constexpr int KS = HD / 16;                 // k-steps of the QK^T product
+    constexpr int DF = HD / 32;                 // 32-wide output blocks
+    constexpr int ROWB = HD * 2;                // bytes per K row
+    constexpr int KBYTES = KT * ROWB;           // one K (or V) tile
+    constexpr int STB = 2 * KBYTES;             // one stage
+    constexpr int RPP = 1024 / ROWB;            // K rows per 1-KiB DMA piece
+    constexpr int KPW = KT / RPP / 4;           // K pieces per wave per tile
+    constexpr int NDB = HD / 16;                // 16-wide d blocks
+    constexpr int VPW = 2 * NDB / 4;            // V sub-tiles per wave per tile
+    static_assert(HD == 128, "row chunk swizzle below is written for 256-byte rows");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)A_LDS_PTR(smem));
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hh = lane >> 5;
+    const int S = p.S;
+    const int nqb = (S + 127) >> 7;
+    const int slot = blockIdx.x >> 3;
+    const int qb = slot % nqb;
+    const int g = (slot / nqb) * 8 + (blockIdx.x & 7);
+    if (g >= p.B * p.H) return;
+    const int b = g / p.H, h = g - b * p.H;
+    const int Hkv = p.Hkv > 0 ? p.Hkv : p.H;
+    const int hk = h / (p.H / Hkv);
+    const bf16_t* Q = p.q + ((size_t)b * p.H + h) * S * HD;
+    const bf16_t* K = p.k + ((size_t)b * Hkv + hk) * S * HD;
+    const bf16_t* V = p.v + ((size_t)b * Hkv + hk) * S * HD;
+    const int klen = p.key_len ? min(p.key_len[b], S) : S;
+    int ntiles = (klen + KT - 1) / KT;
+    if (CAUSAL) ntiles = min(ntiles, (min(qb * 128 + 127, S - 1) >> 6) + 1);   // keys beyond the block's last query
+
+    constexpr float LOG2E = 1.4426950408889634f;
+    const float sl2 = p.scale * LOG2E;
+    const int qrow = qb * 128 + wv * 32 + (lane & 31);
+    const int qrow_c = min(qrow, S - 1);
+    uint4 qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+        qf[ks] = *reinterpret_cast<const uint4*>(Q + (size_t)qrow_c * HD + 16 * ks + 8 * hh);
+
+    // ---- staging.  K piece q (RPP rows each): wave wv issues pieces wv + 4j; lane = (row in piece, 16-B position).
+    // V sub-tile (kh, db): wave wv issues db = wv + 4*(j>>1), kh = j&1.
+    const a_v4i rsK = a_make_rsrc(K), rsV = a_make_rsrc(V);
+    constexpr int CPR = ROWB / 16;              // 16-B chunks per K row
+    int k_row[KPW], v_row[VPW];
+    uint32_t k_col[KPW], v_col[VPW], v_dst[VPW];
+#pragma unroll
+    for (int j = 0; j < KPW; ++j) {
+        const int r = RPP * (wv + 4 * j) + lane / CPR;
+        k_row[j] = r;
+        k_col[j] = (uint32_t)(((lane % CPR) ^ (r & 15)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < VPW; ++j) {
+        const int db = wv + 4 * (j >> 1), kh = j & 1;
+        v_row[j] = 32 * kh + 4 * (((lane >> 3) - (db & 1)) & 7) + ((lane >> 1) & 3);
+        v_col[j] = (uint32_t)((16 * db + 8 * (lane & 1)) * 2);
+        v_dst[j] = (uint32_t)(KBYTES + (kh * NDB + db) * 1024);
+    }
+    auto stage = [&](int kt, int st) {
+        const int kb = kt * KT;
+        const uint32_t sb = lds_base + st * STB;
+#pragma unroll
+        for (int j = 0; j < KPW; ++j)
+            a_bglds16(rsK, (uint32_t)min(kb + k_row[j], S - 1) * (uint32_t)ROWB + k_col[j], sb + (wv + 4 * j) * 1024);
+#pragma unroll
+        for (int j = 0; j < VPW; ++j)
+            a_bglds16(rsV, (uint32_t)min(kb + v_row[j], S - 1) * (uint32_t)ROWB + v_col[j], sb + v_dst[j]);
+    };
+
+    f32x16 o[DF];
+#pragma unroll
+    for (int df = 0; df < DF; ++df)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[df][r] = 0.0f;
+    f32x16 osum;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) osum[r] = 0.0f;
+    float m_run = NEG_BIG;
+    uint4 ones;
+    ones.x = ones.y = ones.z = ones.w = 0x3f803f80u;
+
+    const int swr = lane & 15;                                  // row & 15 of this lane's K rows (kf*32 + lane&31)
+    const int k_rd = (lane & 31) * ROWB;
+    const int dbl = (lane >> 4) & 1, tq = lane & 15;
+    int v_rd[4];
+#pragma unroll
+    for (int xi = 0; xi < 4; ++xi)
+        v_rd[xi] = KBYTES + dbl * 1024 + (((2 * xi + hh + dbl) & 7) << 7) + (tq >> 2) * 32 + (tq & 3) * 8;
+
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks].x), "+v"(qf[ks].y), "+v"(qf[ks].z), "+v"(qf[ks].w));
+    if (ntiles > 0) stage(0, 0);
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int st = kt & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < ntiles) stage(kt + 1, st ^ 1);
+        const char* k_lds = smem + st * STB;
+
+        // ---- S^T = K . Q^T, four k-steps of fragments in flight at a time
+        f32x16 s[2];
+#pragma unroll
+        for (int kf = 0; kf < 2; ++kf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kf][r] = 0.0f;
+#pragma unroll
+        for (int k4 = 0; k4 < KS; k4 += 4) {
+            uint4 kfr[4][2];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int kf = 0; kf < 2; ++kf)
+                    kfr[ks][kf] = *reinterpret_cast<const uint4*>(k_lds + kf * 32 * ROWB + k_rd + (((2 * (k4 + ks) + hh) ^ swr) << 4));
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int kf = 0; kf < 2; ++kf)
+                    s[kf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kfr[ks][kf]),
+                                                                    __builtin_bit_cast(bf16x8, qf[k4 + ks]), s[kf], 0, 0, 0);
+        }
+
+        // ---- masks (ragged last tile, causal diagonal), running max with deferred rescale, p = 2^(s*c - m)
+        const int kb = kt * KT;
+        if (kb + KT > klen || (CAUSAL && kb + KT - 1 > qb * 128 + wv * 32)) {      // wave-uniform
+#pragma unroll
+            for (int kf = 0; kf < 2; ++kf)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kb + kf * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    if (key >= klen || (CAUSAL && key > qrow)) s[kf][r] = NEG_BIG;
+                }
+        }
+#define VQS_SV(i) s[(i) >> 4][(i) & 15]
+        float mx = a_max3(VQS_SV(0), VQS_SV(1), VQS_SV(2));
+#pragma unroll
+        for (int i = 3; i < 31; i += 2) mx = a_max3(mx, VQS_SV(i), VQS_SV(i + 1));
+        mx = fmaxf(mx, VQS_SV(31));
+#undef VQS_SV
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        mx *= sl2;
+        if (__any(mx > m_run + RESCALE_THR)) {
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+#pragma unroll
+                for (int df = 0; df < DF; ++df) o[df][r] *= alpha;
+                osum[r] *= alpha;
+            }
+        }
+        const float neg_m = -m_run;
+#pragma unroll
+        for (int kf = 0; kf < 2; ++kf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kf][r] = __builtin_amdgcn_exp2f(fmaf(s[kf][r], sl2, neg_m));
+
+        // ---- O^T += V^T . P^T
+#pragma unroll
+        for (int kf = 0; kf < 2; ++kf)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                uint4 pb;
+                pb.x = a_pack2(s[kf][8 * t + 0], s[kf][8 * t + 1]);
+                pb.y = a_pack2(s[kf][8 * t + 2], s[kf][8 * t + 3]);
+                pb.z = a_pack2(s[kf][8 * t + 4], s[kf][8 * t + 5]);
+                pb.w = a_pack2(s[kf][8 * t + 6], s[kf][8 * t + 7]);
+                osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, pb),
+                                                                osum, 0, 0, 0);
+#pragma unroll
+                for (int df = 0; df < DF; ++df) {
+                    const char* vp = k_lds + (kf * NDB + 2 * df) * 1024;
+                    const a_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) a_v4s*)A_LDS_PTR(vp + v_rd[2 * t + 0]));
+                    const a_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) a_v4s*)A_LDS_PTR(vp + v_rd[2 * t + 1]));
+                    const uint2 lo2 = __builtin_bit_cast(uint2, lo), hi2 = __builtin_bit_cast(uint2, hi);
+                    uint4 va;
+                    va.x = lo2.x; va.y = lo2.y; va.z = hi2.x; va.w = hi2.y;
+                    o[df] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, va),
+                                                                   __builtin_bit_cast(bf16x8, pb), o[df], 0, 0, 0);
+                }
+            }
+    }
+
+    const float l_tot = osum[0];
+    const float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
+    if (qrow < S) {
+        bf16_t* orow = p.out + ((size_t)b * S + qrow) * ((size_t)p.H * HD) + h * HD;
+#pragma unroll
+        for (int df = 0; df < DF; ++df)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                uint2 v;
+                v.x = a_pack2(o[df][4 * gq + 0] * inv, o[df][4 * gq + 1] * inv);
+                v.y = a_pack2(o[df][4 * gq + 2] * inv, o[df][4 * gq + 3] * inv);
+                *reinterpret_cast<uint2*>(orow + df * 32 + 8 * gq + 4 * hh) = v;
+            }
+    }
+}
+
 static int attn_variant() {       // VQS_ATTN_VARIANT=0 selects the register-staged kernel (lab A/B); default = LDS-DMA kernel
     static int v = -1;
     if (v < 0) {
@@ -619,6 +835,15 @@ static hipError_t launch_attn_t(KernelT kern, const AttnParams& p, size_t lds, h
 
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
     if (p.B <= 0 || p.H <= 0 || p.S <= 0) return hipErrorInvalidValue;
+    if (p.hd == 128) {
+        const int Hkv = p.Hkv > 0 ? p.Hkv : p.H;
+        if (p.bias_table != nullptr || Hkv <= 0 || (p.H % Hkv) != 0) return hipErrorInvalidValue;
+        const size_t lds = 2 * 2 * (size_t)KT * 128 * 2;            // two stages of K + V tiles
+        return p.causal ? launch_attn_t(attn_fwd_hd_kernel<128, true>, p, lds, stream)
+                        : launch_attn_t(attn_fwd_hd_kernel<128, false>, p, lds, stream);
+    }
+    if (p.hd != 0 && p.hd != 64) return hipErrorInvalidValue;
+    if (p.causal || (p.Hkv > 0 && p.Hkv != p.H)) return hipErrorInvalidValue;
     const size_t bias_bytes = p.bias_table ? (size_t)bias_copy_chunks(p.S) * 64 : 0;
     if (attn_variant() == 0) {
         const size_t lds = K_LDS + VT_LDS + bias_bytes;

@@ -392,6 +392,40 @@ hipError_t launch_rowss_to_rs(const float* rowss, int parts, int M, float invd, 
     return hipGetLastError();
 }
 
+// Rotary position embedding, rotate-half convention, in place on a head-major tensor x [B, H, S, hd] bf16
+// (HF models/qwen2_5_vl/modeling_qwen2_5_vl.py:153-172 vision, :557-599 multimodal sections; fp32 math, cast back):
+//   x[i] <- x[i]*cos[i] - x[i+half]*sin[i],  x[i+half] <- x[i+half]*cos[i] + x[i]*sin[i],  i < half
+// cos/sin: fp32 [B*S, half], already section-selected per token (the tables depend on the batch, not on the layer).
+// Dims >= 2*half (the zero padding of 80-wide heads) are untouched.  One thread per (token, head, pair of i).
+__global__ void __launch_bounds__(256) rope_kernel(bf16_t* __restrict__ x, const float* __restrict__ cs,
+                                                   const float* __restrict__ sn, int B, int H, int S, int hd, int half) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int hp = half >> 1;                                  // two i per thread (4-byte accesses)
+    const size_t total = (size_t)B * H * S * hp;
+    if (idx >= total) return;
+    const int ip = (int)(idx % hp);
+    const size_t row = idx / hp;                               // (b*H + h)*S + s
+    const int s_ = (int)(row % S);
+    const int b = (int)(row / ((size_t)H * S));
+    const size_t tok = (size_t)b * S + s_;
+    bf16_t* xr = x + row * hd;
+    const uint32_t lo = *reinterpret_cast<const uint32_t*>(xr + 2 * ip);
+    const uint32_t hi = *reinterpret_cast<const uint32_t*>(xr + half + 2 * ip);
+    const float2 c = *reinterpret_cast<const float2*>(cs + tok * half + 2 * ip);
+    const float2 sv = *reinterpret_cast<const float2*>(sn + tok * half + 2 * ip);
+    const float a0 = e_bf2f((bf16_t)(lo & 0xffff)), a1 = e_bf2f((bf16_t)(lo >> 16));
+    const float b0 = e_bf2f((bf16_t)(hi & 0xffff)), b1 = e_bf2f((bf16_t)(hi >> 16));
+    *reinterpret_cast<uint32_t*>(xr + 2 * ip) = e_pack2_hw(a0 * c.x - b0 * sv.x, a1 * c.y - b1 * sv.y);
+    *reinterpret_cast<uint32_t*>(xr + half + 2 * ip) = e_pack2_hw(b0 * c.x + a0 * sv.x, b1 * c.y + a1 * sv.y);
+}
+
+hipError_t launch_rope(bf16_t* x, const float* cs, const float* sn, int B, int H, int S, int hd, int half, hipStream_t s) {
+    if ((half & 1) || 2 * half > hd || (hd & 1)) return hipErrorInvalidValue;
+    const size_t total = (size_t)B * H * S * (half >> 1);
+    hipLaunchKernelGGL(rope_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, cs, sn, B, H, S, hd, half);
+    return hipGetLastError();
+}
+
 // Split-K epilogue: out[i] = bf16(sum_s part[s][i]), slices summed in index order (deterministic)
 __global__ void __launch_bounds__(256) reduce_slices_kernel(const float* __restrict__ part, int nslices, size_t n4,
                                                             uint2* __restrict__ out) {

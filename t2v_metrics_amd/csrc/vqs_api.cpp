@@ -943,6 +943,19 @@ int vqs_attention(const void* q, const void* k, const void* v, void* out, const 
     return vqs::launch_attention(a, (hipStream_t)stream) == hipSuccess ? VQS_OK : VQS_ERR_HIP;
 }
 
+int vqs_rope(void* x, const float* cos_t, const float* sin_t, int32_t B, int32_t H, int32_t S, int32_t hd, int32_t half,
+             void* stream) {
+    return vqs::launch_rope((bf16_t*)x, cos_t, sin_t, B, H, S, hd, half, (hipStream_t)stream) == hipSuccess ? VQS_OK : VQS_ERR_HIP;
+}
+
+// Attention with head_dim 128, grouped-query heads and an optional causal mask (the Qwen2.5-VL row)
+int vqs_attention_hd(const void* q, const void* k, const void* v, void* out, const int32_t* key_len, int32_t B, int32_t H,
+                     int32_t Hkv, int32_t S, int32_t hd, float scale, int32_t causal, void* stream) {
+    vqs::AttnParams a{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, nullptr, key_len, B, H, S, scale};
+    a.hd = hd; a.Hkv = Hkv; a.causal = causal;
+    return vqs::launch_attention(a, (hipStream_t)stream) == hipSuccess ? VQS_OK : VQS_ERR_HIP;
+}
+
 int vqs_decoder_attention(const void* q, const void* k, const void* v, void* out, const float* bias_table,
                           const int32_t* key_len, int32_t B, int32_t H, int32_t T, int32_t S, int32_t ldq, int32_t ldk,
                           int32_t cross, void* stream) {

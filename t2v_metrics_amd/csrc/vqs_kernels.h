@@ -62,6 +62,10 @@ struct AttnParams {
     const int* key_len;       // [B] valid keys per sample or nullptr (= S)
     int B, H, S;
     float scale;
+    // generalised kernel (Qwen2.5-VL row): hd = 128 selects it; q [B,H,S,hd], k/v [B,Hkv,S,hd], out [B*S, H*hd]
+    int hd = 0;               // 0 / 64: the kernels above
+    int Hkv = 0;              // key/value heads (0 = H); query head h reads head h / (H / Hkv)
+    int causal = 0;           // key <= query
 };
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream);
 
@@ -103,6 +107,7 @@ hipError_t launch_embed_splice(const int* ids, const int* sent_pos, const int* e
 // decoder_input_ids = shift_right(labels); h[b,t] = shared[id]  (fp32 out)
 hipError_t launch_decoder_embed(const int* labels, int ld_labels, const bf16_t* shared, float* out, int B, int T, int D,
                                 int vocab, hipStream_t s);
+hipError_t launch_rope(bf16_t* x, const float* cs, const float* sn, int B, int H, int S, int hd, int half, hipStream_t s);
 hipError_t launch_rowss_to_rs(const float* rowss, int parts, int M, float invd, float eps, float* rs, hipStream_t s);
 hipError_t launch_reduce_slices(const float* part, int nslices, size_t n, bf16_t* out, hipStream_t s);
 hipError_t launch_argmax_append(const float* logits, int ldl, int V, int* tokens, int ld_tokens, int B, int T,

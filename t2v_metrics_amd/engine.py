@@ -56,6 +56,8 @@ _SIGNATURES = {
     "vqs_profile_bytes": (_c_i32, [_c_vp, ctypes.POINTER(ctypes.c_double)]),
     "vqs_profile_report": (ctypes.c_char_p, [_c_vp]),
     "vqs_gemm": (_c_i32, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp] + [_c_i32] * 10 + [_c_vp]),
+    "vqs_rope": (_c_i32, [_c_vp, _c_vp, _c_vp, _c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_vp]),
+    "vqs_attention_hd": (_c_i32, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_f32, _c_i32, _c_vp]),
     "vqs_gemm_rms": (_c_i32, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i32, _c_f32, _c_f32, _c_i32, _c_i32, _c_i32,
                               _c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_vp]),
     "vqs_attention": (_c_i32, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i32, _c_i32, _c_i32, _c_f32, _c_vp]),
@@ -358,6 +360,30 @@ def attention(q, k, v, scale: float, bias_table=None, key_len=None):
                            S, scale, _stream_ptr())
     if rc != 0:
         raise VqsError(f"vqs_attention failed ({rc})")
+    return out
+
+
+def rope_(x, cos, sin):
+    """In-place rotate-half RoPE on x bf16 [B,H,S,hd] with cos/sin fp32 [B*S, half]."""
+    lib = load_library()
+    B, H, S, hd = x.shape
+    half = cos.shape[-1]
+    rc = lib.vqs_rope(x.data_ptr(), cos.data_ptr(), sin.data_ptr(), B, H, S, hd, half, _stream_ptr())
+    if rc != 0:
+        raise VqsError(f"vqs_rope failed ({rc})")
+    return x
+
+
+def attention_hd(q, k, v, scale: float, causal: bool = False, key_len=None):
+    """q [B,H,S,128], k/v [B,Hkv,S,128] bf16 -> out bf16 [B*S, H*128] (GQA, optional causal mask)."""
+    lib = load_library()
+    B, H, S, d = q.shape
+    Hkv = k.shape[1]
+    out = torch.empty(B * S, H * d, dtype=torch.bfloat16, device=q.device)
+    rc = lib.vqs_attention_hd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), _ptr(key_len), B, H, Hkv, S, d, scale,
+                              1 if causal else 0, _stream_ptr())
+    if rc != 0:
+        raise VqsError(f"vqs_attention_hd failed ({rc})")
     return out
 
 

@@ -165,6 +165,57 @@ def test_attention_spiked_max(eng):
     assert_close(out, ref, 2e-2, 2e-2, "attention spiked")
 
 
+@pytest.mark.parametrize("B,H,S,hd,half", [(2, 3, 37, 128, 64), (1, 4, 64, 128, 40), (3, 2, 5, 128, 64)])
+def test_rope_rotate_half(eng, B, H, S, hd, half):
+    """rotate-half RoPE in place (HF modeling_qwen2_5_vl.py:153-172): fp32 math, bf16 storage; padded dims untouched."""
+    g = torch.Generator(device="cuda").manual_seed(71)
+    x = torch.randn(B, H, S, hd, device="cuda", generator=g).to(torch.bfloat16)
+    ang = torch.rand(B * S, half, device="cuda", generator=g) * 20.0
+    cos, sin = ang.cos().contiguous(), ang.sin().contiguous()
+    xf = x.float()
+    c, s_ = cos.view(B, 1, S, half), sin.view(B, 1, S, half)
+    ref = xf.clone()
+    ref[..., :half] = xf[..., :half] * c - xf[..., half:2 * half] * s_
+    ref[..., half:2 * half] = xf[..., half:2 * half] * c + xf[..., :half] * s_
+    out = eng.rope_(x.clone(), cos, sin)
+    assert_close(out, ref, 1e-2, 1e-2, "rope")
+    assert torch.equal(out[..., 2 * half:], x[..., 2 * half:])
+
+
+@pytest.mark.parametrize("B,H,Hkv,S,causal,ragged", [(2, 4, 4, 64, False, False), (3, 4, 2, 200, True, False),
+                                                     (2, 7, 1, 333, True, True), (4, 2, 2, 768, False, False),
+                                                     (1, 28, 4, 808, True, False)])
+def test_attention_hd128_gqa_causal(eng, B, H, Hkv, S, causal, ragged):
+    """head_dim 128, grouped-query heads, causal / key-padding masks vs fp32 torch (HF eager_attention_forward,
+    models/qwen2_5_vl/modeling_qwen2_5_vl.py:187-208).  The 80-wide tower heads run through the same kernel zero-padded."""
+    g = torch.Generator(device="cuda").manual_seed(61)
+    q = (torch.randn(B, H, S, 128, device="cuda", generator=g) * 1.5).to(torch.bfloat16)
+    k = (torch.randn(B, Hkv, S, 128, device="cuda", generator=g) * 1.5).to(torch.bfloat16)
+    v = torch.randn(B, Hkv, S, 128, device="cuda", generator=g).to(torch.bfloat16)
+    if B >= 4:
+        q[..., 80:] = 0; k[..., 80:] = 0; v[..., 80:] = 0            # the padded vision-head case
+    kl = None
+    if ragged:
+        kl = torch.tensor([S, max(1, S // 3)][:B] + [S] * max(0, B - 2), dtype=torch.int32, device="cuda")
+    scale = 128 ** -0.5 if B < 4 else 80 ** -0.5
+    out = eng.attention_hd(q, k, v, scale, causal=causal, key_len=kl).float().view(B, S, H, 128)
+    rep = H // Hkv
+    kf, vf = k.float().repeat_interleave(rep, 1), v.float().repeat_interleave(rep, 1)
+    s = torch.einsum("bhqd,bhkd->bhqk", q.float(), kf) * scale
+    mask = torch.ones(S, S, dtype=torch.bool, device="cuda").tril() if causal else torch.ones(S, S, dtype=torch.bool, device="cuda")
+    mask = mask[None, None].expand(B, 1, S, S).clone()
+    if kl is not None:
+        mask &= (torch.arange(S, device="cuda")[None, None, None, :] < kl[:, None, None, None])
+    s = s.masked_fill(~mask, float("-inf"))
+    ref = torch.einsum("bhqk,bhkd->bqhd", torch.softmax(s, -1), vf)
+    valid = torch.ones(B, S, dtype=torch.bool, device="cuda")
+    if kl is not None and not causal:
+        pass
+    if kl is not None:
+        valid = torch.arange(S, device="cuda")[None, :] < kl[:, None]   # padded queries are don't-care rows
+    assert_close(out[valid], ref[valid], 2e-2, 2e-2, f"attention hd128 B{B} H{H}/{Hkv} S{S} causal={causal}")
+
+
 @pytest.mark.parametrize("T", [1, 2, 5])
 def test_decoder_attention(eng, T):
     B, H, S = 3, 2, 77
