@@ -1,0 +1,70 @@
+/* libvqs_hip -- C ABI of the Qwen2.5-VL VQAScore row (BASELINE.json configs[4]).
+ *
+ * Replaces, for the reference's Qwen wrapper
+ * (/root/reference/t2v_metrics/models/vqascore_models/qwen2vl_model.py:110-133 load, :190-230 one prefill per sample via
+ * model.generate(max_new_tokens=1, output_scores=True)), the arithmetic HF executes in
+ * Qwen2_5_VLForConditionalGeneration (models/qwen2_5_vl/modeling_qwen2_5_vl.py):
+ *   vqs_qwen_encode_vision  <- Qwen2_5_VisionTransformerPretrainedModel.forward :408-471 (patch embed, 32 window/full
+ *                              attention blocks with 2-D RoPE, patch merger)
+ *   vqs_qwen_score          <- get_placeholder_mask/masked_scatter :1094-1232, Qwen2_5_VLTextModel.forward :790-873,
+ *                              lm_head on the last position (= scores[0] of generate)
+ * Same conventions as include/vqs.h: plain device pointers, caller-owned buffers, no allocation, no stream sync, 0 or a
+ * negative VQS_ERR_* code, message via vqs_qwen_last_error.  Integer layout work (window permutation, rotary tables from
+ * the 3-D positions, placeholder slots) is the caller's: t2v_metrics_amd/qwen/layout.py builds those arrays. */
+#ifndef VQS_QWEN_H
+#define VQS_QWEN_H
+#include <stddef.h>
+#include <stdint.h>
+#include "vqs.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vqs_qwen_handle vqs_qwen_handle;
+
+typedef struct vqs_qwen_config {
+    /* vision tower (Qwen2_5_VLVisionConfig) */
+    int32_t v_depth, v_hidden, v_heads, v_mlp, v_patch_dim, v_merge_unit, v_out_hidden;
+    int32_t v_fullatt_mask;          /* bit i set: block i attends within a whole frame, else within its window */
+    float v_eps;
+    /* language model (Qwen2_5_VLTextConfig) */
+    int32_t t_vocab, t_hidden, t_layers, t_heads, t_kv_heads, t_mlp;
+    float t_eps;
+} vqs_qwen_config;
+
+int vqs_qwen_create(const vqs_qwen_config* cfg, vqs_qwen_handle** out);
+void vqs_qwen_destroy(vqs_qwen_handle* h);
+const char* vqs_qwen_last_error(const vqs_qwen_handle* h);
+
+/* Weights: HF state_dict names ("model.visual.blocks.0.attn.qkv.weight", ...), bf16, device, [out, in] row-major.  The
+ * library packs fused / padded copies (heads padded to 128 lanes, gate|up interleaved, K padded to 64) into d_packed. */
+size_t vqs_qwen_packed_bytes(const vqs_qwen_handle* h);
+int vqs_qwen_bind_weights(vqs_qwen_handle* h, const vqs_weight_desc* descs, int32_t n, void* d_packed, size_t packed_bytes,
+                          void* stream);
+
+/* Vision tower over N patches (all videos/images of the call, HF processor order).
+ *   d_patches    bf16 [N, v_patch_dim]           flattened 2 x 14 x 14 x 3 receptive fields
+ *   d_row_map    int32 [N]                       windowed position -> source patch row (window_index expanded x merge_unit)
+ *   d_cell_inv   int32 [N / merge_unit]          original merged-cell position -> windowed cell position
+ *   d_cos/d_sin  fp32 [N, head_dim/2]            2-D rotary tables in WINDOWED order
+ *   win_len      patches per attention window (every window full), frame_len patches per frame (full-attention blocks)
+ *   d_merged     bf16 [N / merge_unit, v_out_hidden]   out, ORIGINAL cell order */
+size_t vqs_qwen_vision_workspace_bytes(const vqs_qwen_handle* h, int32_t N);
+int vqs_qwen_encode_vision(vqs_qwen_handle* h, const void* d_patches, const int32_t* d_row_map, const int32_t* d_cell_inv,
+                           const float* d_cos, const float* d_sin, int32_t N, int32_t win_len, int32_t frame_len,
+                           void* d_merged, void* d_ws, size_t ws_bytes, void* stream);
+
+/* Language-model prefill + last-position logits.
+ *   d_input_ids  int32 [B, L] right-padded          d_vis_slot int32 [B, L]: row of d_merged for placeholder tokens, else -1
+ *   d_seq_len    int32 [B]                           d_last_row int32 [B] = b*L + seq_len[b] - 1
+ *   d_cos/d_sin  fp32 [B*L, head_dim/2]              M-RoPE tables already section-selected per token
+ *   d_logits     fp32 [B, t_vocab]                   out */
+size_t vqs_qwen_score_workspace_bytes(const vqs_qwen_handle* h, int32_t B, int32_t L);
+int vqs_qwen_score(vqs_qwen_handle* h, const void* d_merged, const int32_t* d_input_ids, const int32_t* d_vis_slot,
+                   const int32_t* d_seq_len, const int32_t* d_last_row, const float* d_cos, const float* d_sin, int32_t B,
+                   int32_t L, float* d_logits, void* d_ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

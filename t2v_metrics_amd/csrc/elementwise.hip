@@ -676,4 +676,71 @@ hipError_t launch_interleave_gate(const bf16_t* wi0, const bf16_t* wi1, bf16_t* 
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Row / column gathers used by the Qwen2.5-VL row (weight packing at bind time, window permutation, splice).
+// ------------------------------------------------------------------------------------------------
+// dst[r][0..dst_ld) = row map[r] of src0 (map >= 0), of src1 (map <= -2: row -map-2), or zeros (map == -1); columns
+// beyond `cols` are zero-filled.  map == nullptr: identity.
+__global__ void __launch_bounds__(256) gather_rows_bf16_kernel(const bf16_t* __restrict__ src0, const bf16_t* __restrict__ src1,
+                                                               const int* __restrict__ map, bf16_t* __restrict__ dst, int cols,
+                                                               int src_ld, int dst_ld) {
+    const int r = blockIdx.x;
+    const int m = map ? map[r] : r;
+    const bf16_t* s = m >= 0 ? src0 + (size_t)m * src_ld : (m <= -2 ? src1 + (size_t)(-m - 2) * src_ld : nullptr);
+    bf16_t* d = dst + (size_t)r * dst_ld;
+    for (int i = threadIdx.x; i < dst_ld; i += 256) d[i] = (s != nullptr && i < cols) ? s[i] : (bf16_t)0;
+}
+hipError_t launch_gather_rows_bf16(const bf16_t* src0, const bf16_t* src1, const int* map, bf16_t* dst, int rows, int cols,
+                                   int src_ld, int dst_ld, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gather_rows_bf16_kernel, dim3(rows), dim3(256), 0, s, src0, src1, map, dst, cols, src_ld, dst_ld);
+    return hipGetLastError();
+}
+
+// dst[r][c] = cmap[c] >= 0 ? src[r][cmap[c]] : 0
+__global__ void __launch_bounds__(256) gather_cols_bf16_kernel(const bf16_t* __restrict__ src, const int* __restrict__ cmap,
+                                                               bf16_t* __restrict__ dst, int src_ld, int dst_cols) {
+    const int r = blockIdx.x;
+    for (int c = threadIdx.x; c < dst_cols; c += 256) {
+        const int m = cmap[c];
+        dst[(size_t)r * dst_cols + c] = m >= 0 ? src[(size_t)r * src_ld + m] : (bf16_t)0;
+    }
+}
+hipError_t launch_gather_cols_bf16(const bf16_t* src, const int* cmap, bf16_t* dst, int rows, int src_ld, int dst_cols,
+                                   hipStream_t s) {
+    hipLaunchKernelGGL(gather_cols_bf16_kernel, dim3(rows), dim3(256), 0, s, src, cmap, dst, src_ld, dst_cols);
+    return hipGetLastError();
+}
+
+// fp32 rows: dst[r] = src[map[r]]
+__global__ void __launch_bounds__(256) gather_rows_f32_kernel(const float* __restrict__ src, const int* __restrict__ map,
+                                                              float* __restrict__ dst, int D) {
+    const int r = blockIdx.x;
+    const float4* s = reinterpret_cast<const float4*>(src + (size_t)map[r] * D);
+    float4* d = reinterpret_cast<float4*>(dst + (size_t)r * D);
+    for (int i = threadIdx.x; i < (D >> 2); i += 256) d[i] = s[i];
+}
+hipError_t launch_gather_rows_f32(const float* src, const int* map, float* dst, int rows, int D, hipStream_t s) {
+    if (D % 4) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gather_rows_f32_kernel, dim3(rows), dim3(256), 0, s, src, map, dst, D);
+    return hipGetLastError();
+}
+
+// Qwen2.5-VL input embeddings (HF modeling_qwen2_5_vl.py:1205-1232): token row = embed[id], or the merged vision token
+// vis_slot[row] where that is >= 0 (masked_scatter of the video/image features in order).  fp32 residual stream out.
+__global__ void __launch_bounds__(256) qwen_embed_kernel(const int* __restrict__ ids, const int* __restrict__ vis_slot,
+                                                         const bf16_t* __restrict__ embed, const bf16_t* __restrict__ merged,
+                                                         float* __restrict__ out, int D, int vocab) {
+    const int r = blockIdx.x;
+    const int vs = vis_slot[r];
+    const bf16_t* s = vs >= 0 ? merged + (size_t)vs * D : embed + (size_t)min(max(ids[r], 0), vocab - 1) * D;
+    float* o = out + (size_t)r * D;
+    for (int i = threadIdx.x; i < D; i += 256) o[i] = e_bf2f(s[i]);
+}
+hipError_t launch_qwen_embed(const int* ids, const int* vis_slot, const bf16_t* embed, const bf16_t* merged, float* out, int rows,
+                             int D, int vocab, hipStream_t s) {
+    hipLaunchKernelGGL(qwen_embed_kernel, dim3(rows), dim3(256), 0, s, ids, vis_slot, embed, merged, out, D, vocab);
+    return hipGetLastError();
+}
+
 }  // namespace vqs

@@ -530,6 +530,25 @@ __device__ __forceinline__ void staged_epilogue(const GemmParams& p, f32x16 (&ac
     if constexpr (EPI == EPI_GATED) {
         const int NO = p.N >> 1;
         const int ocol_w = col_w >> 1;               // 32 output columns per wave
+        if (p.bias != nullptr) {                     // packed (interleaved) order, like the weight rows
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c = col_w + n * 32 + 8 * g + 4 * hh;
+                    if (c < p.N) {
+                        const uint2 bv = *reinterpret_cast<const uint2*>(p.bias + c);
+                        const float b0 = bf2f((bf16_t)(bv.x & 0xffff)), b1 = bf2f((bf16_t)(bv.x >> 16));
+                        const float b2 = bf2f((bf16_t)(bv.y & 0xffff)), b3 = bf2f((bf16_t)(bv.y >> 16));
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) {
+                            acc[m][n][4 * g + 0] += b0; acc[m][n][4 * g + 1] += b1;
+                            acc[m][n][4 * g + 2] += b2; acc[m][n][4 * g + 3] += b3;
+                        }
+                    }
+                }
+        }
+        const bool silu = p.gate_act == 1;           // 0: gelu_new (T5 gated-gelu), 1: SiLU (Qwen SwiGLU)
 #pragma unroll
         for (int hm = 0; hm < 2; ++hm) {
 #pragma unroll
@@ -538,11 +557,16 @@ __device__ __forceinline__ void staged_epilogue(const GemmParams& p, f32x16 (&ac
                 const int r = m2 * 32 + lr;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
+                    float o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float gv = acc[m][0][4 * g + e];
+                        const float a = silu ? gv * __frcp_rn(1.0f + __expf(-gv)) : act_gelu_new(gv);
+                        o[e] = a * acc[m][1][4 * g + e];
+                    }
                     uint2 v;
-                    v.x = pack2(act_gelu_new(acc[m][0][4 * g + 0]) * acc[m][1][4 * g + 0],
-                                act_gelu_new(acc[m][0][4 * g + 1]) * acc[m][1][4 * g + 1]);
-                    v.y = pack2(act_gelu_new(acc[m][0][4 * g + 2]) * acc[m][1][4 * g + 2],
-                                act_gelu_new(acc[m][0][4 * g + 3]) * acc[m][1][4 * g + 3]);
+                    v.x = pack2(o[0], o[1]);
+                    v.y = pack2(o[2], o[3]);
                     *reinterpret_cast<uint2*>(reg + r * 64 + ((g ^ ((r >> 1) & 3)) << 4) + hh * 8) = v;
                 }
             }
@@ -606,11 +630,19 @@ __device__ __forceinline__ void staged_epilogue(const GemmParams& p, f32x16 (&ac
             }
         } else {
             bf16_t* head_base = nullptr;
+            int hx = p.H, hdim = 64;                           // heads of the target tensor, head width
             if constexpr (EPI == EPI_HEADS) {
+                // columns [0, inner) -> q heads, [inner, inner + inner_kv) -> k heads, rest -> v heads; head width hd
+                // (64, or 128: a wave's 64 columns are then one half of a head); grouped-query models have fewer k/v heads
                 const int cw = min(col_w, p.N - 64);
-                const int which = cw / p.inner;
+                hdim = p.hd > 0 ? p.hd : 64;
+                const int ikv = p.inner_kv > 0 ? p.inner_kv : p.inner;
+                const int which = cw < p.inner ? 0 : (cw < p.inner + ikv ? 1 : 2);
+                const int base = which == 0 ? 0 : (which == 1 ? p.inner : p.inner + ikv);
+                hx = which == 0 ? p.H : (p.Hkv > 0 ? p.Hkv : p.H);
                 bf16_t* hp = which == 0 ? p.heads_out[0] : (which == 1 ? p.heads_out[1] : p.heads_out[2]);
-                head_base = hp + (size_t)((cw - which * p.inner) >> 6) * p.S * 64;
+                const int head = (cw - base) / hdim;
+                head_base = hp + (size_t)head * p.S * hdim + ((cw - base) - head * hdim);
             }
 #pragma unroll
             for (int hm = 0; hm < 2; ++hm) {                  // 64 rows x 128 B per pass
@@ -650,7 +682,7 @@ __device__ __forceinline__ void staged_epilogue(const GemmParams& p, f32x16 (&ac
                         bf16_t* dst;
                         if constexpr (EPI == EPI_HEADS) {
                             const int hb = row / p.S, hs = row - hb * p.S;
-                            dst = head_base + ((size_t)hb * p.H * p.S + hs) * 64 + c * 8;
+                            dst = head_base + ((size_t)hb * hx * p.S + hs) * hdim + c * 8;
                         } else {
                             dst = reinterpret_cast<bf16_t*>(p.C) + (size_t)bz * p.sC + (size_t)row * p.ldc + col;
                         }
@@ -1484,6 +1516,9 @@ hipError_t launch_gemm(const GemmParams& p, int epilogue, int variant, hipStream
     if ((p.N % 8) != 0 && !(epilogue == EPI_F32 && p.ldc >= ((p.N + 3) & ~3) && p.bias == nullptr)) return hipErrorInvalidValue;
     if (p.batch > 1 && ((variant != 3 && variant != 4 && variant != 5 && variant != 7) || epilogue == EPI_HEADS || epilogue == EPI_F32_RESID)) return hipErrorInvalidValue;
     if ((p.lda % 8) != 0 || (p.ldw % 8) != 0) return hipErrorInvalidValue;
+    if ((p.hd > 64 || p.inner_kv > 0 || p.Hkv > 0 || p.gate_act != 0 || (epilogue == EPI_GATED && p.bias != nullptr)) &&
+        variant != 3 && variant != 5 && variant != 7)
+        return hipErrorInvalidValue;   // generalised HEADS / GATED epilogues live in the persistent kernels only
     if (p.rowss_in != nullptr && (p.rowss_parts < 0 || (variant != 3 && variant != 5 && variant != 7) || epilogue == EPI_F32_RESID))
         return hipErrorInvalidValue;   // the row scale lives in the persistent kernels' staged epilogue only
     switch (epilogue) {

@@ -34,6 +34,11 @@ struct GemmParams {
     // EPI_HEADS
     int S, H, inner;
     bf16_t* heads_out[3];
+    int hd = 0;              // head width (0 = 64); 128 for Qwen2.5-VL
+    int inner_kv = 0;        // width of the k and of the v column ranges (0 = inner); grouped-query models
+    int Hkv = 0;             // heads of the k / v tensors (0 = H)
+    // EPI_GATED
+    int gate_act = 0;        // 0 gelu_new (T5), 1 SiLU (Qwen SwiGLU); bias (if any) is in packed column order
     // batched GEMM (persistent variant only): entry z uses A + z*sA, W + z*sW, C + z*sC (strides in elements)
     int batch = 1;
     long long sA = 0, sW = 0, sC = 0;
@@ -127,6 +132,13 @@ hipError_t launch_transpose(const bf16_t* in, bf16_t* out, int rows, int cols, h
 // weight packing helpers (bind time)
 hipError_t launch_copy_rows(const bf16_t* src, bf16_t* dst, int rows, int cols, int src_ld, int dst_ld,
                             int dst_row_offset, hipStream_t s);   // dst[dst_row_offset + r, 0:cols] = src[r, 0:cols], zero pad to dst_ld
+hipError_t launch_gather_rows_bf16(const bf16_t* src0, const bf16_t* src1, const int* map, bf16_t* dst, int rows, int cols,
+                                   int src_ld, int dst_ld, hipStream_t s);
+hipError_t launch_gather_cols_bf16(const bf16_t* src, const int* cmap, bf16_t* dst, int rows, int src_ld, int dst_cols,
+                                   hipStream_t s);
+hipError_t launch_gather_rows_f32(const float* src, const int* map, float* dst, int rows, int D, hipStream_t s);
+hipError_t launch_qwen_embed(const int* ids, const int* vis_slot, const bf16_t* embed, const bf16_t* merged, float* out, int rows,
+                             int D, int vocab, hipStream_t s);
 hipError_t launch_interleave_gate(const bf16_t* wi0, const bf16_t* wi1, bf16_t* dst, int F, int D, hipStream_t s);
 
 }  // namespace vqs

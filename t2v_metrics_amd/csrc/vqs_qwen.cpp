@@ -1,0 +1,542 @@
+// Host side of the Qwen2.5-VL row of libvqs_hip (include/vqs_qwen.h): weight packing and the launch sequences of the vision
+// tower and of the language-model prefill.  Restates what HF executes for the reference's one-prefill scoring pass
+// (models/qwen2_5_vl/modeling_qwen2_5_vl.py; the oracle oracle/qwen25vl_oracle.py cites the lines):
+//   Qwen2_5_VisionTransformerPretrainedModel.forward :408-471  -> vqs_qwen_encode_vision
+//   Qwen2_5_VLModel.forward (splice) :1185-1255, Qwen2_5_VLTextModel.forward :790-873, lm_head -> vqs_qwen_score
+// Heads narrower than 128 (the tower's 80) are zero-padded to 128 lanes at bind time so that one attention kernel serves
+// both stacks; K dimensions are zero-padded to multiples of 64, gate|up rows interleaved in blocks of 32 for the gated
+// epilogue.  No device allocation, no stream synchronisation, no CPU fallback.
+#include "../../include/vqs_qwen.h"
+#include "vqs_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+using vqs::bf16_t;
+
+namespace {
+constexpr int HDP = 128;   // padded head width
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct WEnt {
+    const bf16_t* p;
+    int64_t numel;
+};
+}  // namespace
+
+struct vqs_qwen_handle {
+    vqs_qwen_config c;
+    std::string err;
+    std::unordered_map<std::string, WEnt> w;
+    bool bound = false;
+    int v_hd = 0, t_hd = 0, v_kpatch = 0, v_mlp_p = 0, v_ffld = 0, t_mlp_p = 0, t_ffld = 0, t_iq = 0, t_ikv = 0, merge_hidden = 0;
+    // host copies of the packing maps (must outlive the async uploads)
+    std::vector<int> m_vheads, m_theads, m_tkv, m_vgate, m_tgate;
+    // packed device pointers
+    const int *d_vheads = nullptr, *d_theads = nullptr, *d_tkv = nullptr, *d_vgate = nullptr, *d_tgate = nullptr;
+    const bf16_t* patch_w = nullptr;
+    std::vector<const bf16_t*> v_qkv_w, v_qkv_b, v_proj_w, v_gu_w, v_gu_b, v_down_w;
+    std::vector<const bf16_t*> t_qkv_w, t_qkv_b, t_o_w, t_gu_w, t_down_w;
+};
+
+namespace {
+
+int qfail(vqs_qwen_handle* h, int code, const std::string& msg) {
+    if (h) h->err = msg;
+    return code;
+}
+
+#define QHIP(h, expr, what)                                                                                         \
+    do {                                                                                                            \
+        hipError_t _e = (expr);                                                                                     \
+        if (_e != hipSuccess) return qfail((h), VQS_ERR_HIP, std::string(what) + ": " + hipGetErrorString(_e));     \
+    } while (0)
+#define QRUN(expr)                   \
+    do {                             \
+        int _r = (expr);             \
+        if (_r != VQS_OK) return _r; \
+    } while (0)
+
+int get_w(vqs_qwen_handle* h, const std::string& name, int64_t numel, const bf16_t** out) {
+    auto it = h->w.find(name);
+    if (it == h->w.end()) return qfail(h, VQS_ERR_MISSING_WEIGHT, "missing weight " + name);
+    if (it->second.numel != numel)
+        return qfail(h, VQS_ERR_MISSING_WEIGHT, "weight " + name + " has " + std::to_string(it->second.numel) + " elements, expected " + std::to_string(numel));
+    *out = it->second.p;
+    return VQS_OK;
+}
+#define QW(var, name, numel)                                      \
+    const bf16_t* var = nullptr;                                  \
+    QRUN(get_w(h, (name), (int64_t)(numel), &var))
+
+// rows (or columns) of a head-major [n heads x hd] range laid into n x 128 lanes, -1 = zero
+std::vector<int> head_pad_map(int n, int hd) {
+    std::vector<int> m((size_t)n * HDP);
+    for (int head = 0; head < n; ++head)
+        for (int d = 0; d < HDP; ++d) m[(size_t)head * HDP + d] = d < hd ? head * hd + d : -1;
+    return m;
+}
+// interleaved gate|up rows in blocks of 32 (gate block, up block), mlp padded to mlp_p: >= 0 gate row, <= -2 up row, -1 zero
+std::vector<int> gate_up_map(int mlp, int mlp_p) {
+    std::vector<int> m((size_t)2 * mlp_p);
+    for (int r = 0; r < 2 * mlp_p; ++r) {
+        const int blk = r >> 6, within = r & 63, j = blk * 32 + (within & 31);
+        m[r] = j < mlp ? (within < 32 ? j : -j - 2) : -1;
+    }
+    return m;
+}
+
+struct Carver {
+    char* base;
+    size_t off = 0;
+    template <typename T>
+    T* take(size_t n) {
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off = align_up(off + n * sizeof(T));
+        return p;
+    }
+};
+
+struct GCall {
+    const bf16_t* A;
+    const bf16_t* W;
+    void* C;
+    const bf16_t* bias = nullptr;
+    int M = 0, N = 0, K = 0, lda = 0, ldw = 0, ldc = 0, epi = 0;
+    int S = 0, H = 0, inner = 0, hd = 0, inner_kv = 0, Hkv = 0, gate_act = 0;
+    bf16_t* heads[3] = {nullptr, nullptr, nullptr};
+};
+
+int qgemm(vqs_qwen_handle* h, const GCall& g, hipStream_t st, const char* what) {
+    vqs::GemmParams p;
+    p.A = g.A; p.W = g.W; p.C = g.C; p.bias = g.bias; p.resid = nullptr;
+    p.M = g.M; p.N = g.N; p.K = g.K; p.lda = g.lda; p.ldw = g.ldw; p.ldc = g.ldc;
+    p.S = g.S > 0 ? g.S : 1; p.H = g.H; p.inner = g.inner > 0 ? g.inner : 1;
+    p.heads_out[0] = g.heads[0]; p.heads_out[1] = g.heads[1]; p.heads_out[2] = g.heads[2];
+    p.hd = g.hd; p.inner_kv = g.inner_kv; p.Hkv = g.Hkv; p.gate_act = g.gate_act;
+    QHIP(h, vqs::launch_gemm(p, g.epi, 3, st), std::string("gemm ") + what);
+    return VQS_OK;
+}
+
+struct PackPlan {
+    size_t total = 0;
+};
+
+// One pass that either sizes (base == nullptr) or performs the packing.
+int pack(vqs_qwen_handle* h, char* base, size_t* total, hipStream_t st) {
+    const vqs_qwen_config& c = h->c;
+    Carver cv{base};
+    auto up_map = [&](const std::vector<int>& m, const int** dptr) -> int {
+        int* d = cv.take<int>(m.size());
+        if (base) {
+            QHIP(h, hipMemcpyAsync(d, m.data(), m.size() * sizeof(int), hipMemcpyHostToDevice, st), "upload packing map");
+            *dptr = d;
+        }
+        return VQS_OK;
+    };
+    QRUN(up_map(h->m_vheads, &h->d_vheads));
+    QRUN(up_map(h->m_theads, &h->d_theads));
+    QRUN(up_map(h->m_tkv, &h->d_tkv));
+    QRUN(up_map(h->m_vgate, &h->d_vgate));
+    QRUN(up_map(h->m_tgate, &h->d_tgate));
+
+    const int VH = c.v_hidden, VHD = h->v_hd, VNH = c.v_heads, VPK = VNH * HDP;
+    {   // patch embed: [hidden, patch_dim] -> K padded to 64
+        bf16_t* d = cv.take<bf16_t>((size_t)VH * h->v_kpatch);
+        if (base) {
+            QW(w, "model.visual.patch_embed.proj.weight", (int64_t)VH * c.v_patch_dim);
+            QHIP(h, vqs::launch_gather_rows_bf16(w, nullptr, nullptr, d, VH, c.v_patch_dim, c.v_patch_dim, h->v_kpatch, st), "pack patch embed");
+            h->patch_w = d;
+        }
+    }
+    if (base) {
+        h->v_qkv_w.assign(c.v_depth, nullptr); h->v_qkv_b.assign(c.v_depth, nullptr); h->v_proj_w.assign(c.v_depth, nullptr);
+        h->v_gu_w.assign(c.v_depth, nullptr); h->v_gu_b.assign(c.v_depth, nullptr); h->v_down_w.assign(c.v_depth, nullptr);
+        h->t_qkv_w.assign(c.t_layers, nullptr); h->t_qkv_b.assign(c.t_layers, nullptr); h->t_o_w.assign(c.t_layers, nullptr);
+        h->t_gu_w.assign(c.t_layers, nullptr); h->t_down_w.assign(c.t_layers, nullptr);
+    }
+    for (int i = 0; i < c.v_depth; ++i) {
+        const std::string p = "model.visual.blocks." + std::to_string(i) + ".";
+        bf16_t* qkv = cv.take<bf16_t>((size_t)3 * VPK * VH);
+        bf16_t* qkvb = cv.take<bf16_t>((size_t)3 * VPK);
+        bf16_t* proj = cv.take<bf16_t>((size_t)VH * VPK);
+        bf16_t* gu = cv.take<bf16_t>((size_t)2 * h->v_mlp_p * VH);
+        bf16_t* gub = cv.take<bf16_t>((size_t)2 * h->v_mlp_p);
+        bf16_t* down = cv.take<bf16_t>((size_t)VH * h->v_ffld);
+        if (!base) continue;
+        QW(wqkv, p + "attn.qkv.weight", (int64_t)3 * VH * VH);
+        QW(bqkv, p + "attn.qkv.bias", 3 * VH);
+        QW(wproj, p + "attn.proj.weight", (int64_t)VH * VH);
+        QW(wg, p + "mlp.gate_proj.weight", (int64_t)c.v_mlp * VH);
+        QW(bg, p + "mlp.gate_proj.bias", c.v_mlp);
+        QW(wu, p + "mlp.up_proj.weight", (int64_t)c.v_mlp * VH);
+        QW(bu, p + "mlp.up_proj.bias", c.v_mlp);
+        QW(wd, p + "mlp.down_proj.weight", (int64_t)VH * c.v_mlp);
+        for (int which = 0; which < 3; ++which) {   // q | k | v row ranges, every head padded to 128 rows
+            QHIP(h, vqs::launch_gather_rows_bf16(wqkv + (size_t)which * VH * VH, nullptr, h->d_vheads, qkv + (size_t)which * VPK * VH,
+                                                  VPK, VH, VH, VH, st), "pack vision qkv");
+            QHIP(h, vqs::launch_gather_rows_bf16(bqkv + (size_t)which * VH, nullptr, h->d_vheads, qkvb + (size_t)which * VPK, VPK, 1, 1, 1, st),
+                 "pack vision qkv bias");
+        }
+        QHIP(h, vqs::launch_gather_cols_bf16(wproj, h->d_vheads, proj, VH, VH, VPK, st), "pack vision proj");
+        QHIP(h, vqs::launch_gather_rows_bf16(wg, wu, h->d_vgate, gu, 2 * h->v_mlp_p, VH, VH, VH, st), "pack vision gate|up");
+        QHIP(h, vqs::launch_gather_rows_bf16(bg, bu, h->d_vgate, gub, 2 * h->v_mlp_p, 1, 1, 1, st), "pack vision gate|up bias");
+        QHIP(h, vqs::launch_gather_rows_bf16(wd, nullptr, nullptr, down, VH, c.v_mlp, c.v_mlp, h->v_ffld, st), "pack vision down");
+        (void)VHD;
+        h->v_qkv_w[i] = qkv; h->v_qkv_b[i] = qkvb; h->v_proj_w[i] = proj; h->v_gu_w[i] = gu; h->v_gu_b[i] = gub; h->v_down_w[i] = down;
+    }
+    const int TH = c.t_hidden, IQ = h->t_iq, IKV = h->t_ikv, QN = IQ + 2 * IKV, thd = h->t_hd;
+    for (int i = 0; i < c.t_layers; ++i) {
+        const std::string p = "model.language_model.layers." + std::to_string(i) + ".";
+        bf16_t* qkv = cv.take<bf16_t>((size_t)QN * TH);
+        bf16_t* qkvb = cv.take<bf16_t>((size_t)QN);
+        bf16_t* ow = cv.take<bf16_t>((size_t)TH * IQ);
+        bf16_t* gu = cv.take<bf16_t>((size_t)2 * h->t_mlp_p * TH);
+        bf16_t* down = cv.take<bf16_t>((size_t)TH * h->t_ffld);
+        if (!base) continue;
+        const int64_t qn = (int64_t)c.t_heads * thd, kn = (int64_t)c.t_kv_heads * thd;
+        QW(wq, p + "self_attn.q_proj.weight", qn * TH);
+        QW(bq, p + "self_attn.q_proj.bias", qn);
+        QW(wk, p + "self_attn.k_proj.weight", kn * TH);
+        QW(bk, p + "self_attn.k_proj.bias", kn);
+        QW(wv, p + "self_attn.v_proj.weight", kn * TH);
+        QW(bv, p + "self_attn.v_proj.bias", kn);
+        QW(wo, p + "self_attn.o_proj.weight", (int64_t)TH * qn);
+        QW(wg, p + "mlp.gate_proj.weight", (int64_t)c.t_mlp * TH);
+        QW(wu, p + "mlp.up_proj.weight", (int64_t)c.t_mlp * TH);
+        QW(wd, p + "mlp.down_proj.weight", (int64_t)TH * c.t_mlp);
+        QHIP(h, vqs::launch_gather_rows_bf16(wq, nullptr, h->d_theads, qkv, IQ, TH, TH, TH, st), "pack q");
+        QHIP(h, vqs::launch_gather_rows_bf16(wk, nullptr, h->d_tkv, qkv + (size_t)IQ * TH, IKV, TH, TH, TH, st), "pack k");
+        QHIP(h, vqs::launch_gather_rows_bf16(wv, nullptr, h->d_tkv, qkv + (size_t)(IQ + IKV) * TH, IKV, TH, TH, TH, st), "pack v");
+        QHIP(h, vqs::launch_gather_rows_bf16(bq, nullptr, h->d_theads, qkvb, IQ, 1, 1, 1, st), "pack q bias");
+        QHIP(h, vqs::launch_gather_rows_bf16(bk, nullptr, h->d_tkv, qkvb + IQ, IKV, 1, 1, 1, st), "pack k bias");
+        QHIP(h, vqs::launch_gather_rows_bf16(bv, nullptr, h->d_tkv, qkvb + IQ + IKV, IKV, 1, 1, 1, st), "pack v bias");
+        QHIP(h, vqs::launch_gather_cols_bf16(wo, h->d_theads, ow, TH, (int)qn, IQ, st), "pack o");
+        QHIP(h, vqs::launch_gather_rows_bf16(wg, wu, h->d_tgate, gu, 2 * h->t_mlp_p, TH, TH, TH, st), "pack gate|up");
+        QHIP(h, vqs::launch_gather_rows_bf16(wd, nullptr, nullptr, down, TH, c.t_mlp, c.t_mlp, h->t_ffld, st), "pack down");
+        h->t_qkv_w[i] = qkv; h->t_qkv_b[i] = qkvb; h->t_o_w[i] = ow; h->t_gu_w[i] = gu; h->t_down_w[i] = down;
+    }
+    *total = align_up(cv.off);
+    return VQS_OK;
+}
+
+struct VisWs {
+    bf16_t *patches, *xn, *delta, *q, *k, *v, *attn, *ff, *mid, *merged_w;
+    float *pre, *hidden;
+    size_t total;
+};
+VisWs carve_vision(const vqs_qwen_handle* h, char* base, int N) {
+    const vqs_qwen_config& c = h->c;
+    Carver cv{base};
+    VisWs w{};
+    const size_t n = (size_t)N, VPK = (size_t)c.v_heads * HDP;
+    w.patches = cv.take<bf16_t>(n * h->v_kpatch);
+    w.pre = cv.take<float>(n * c.v_hidden);
+    w.hidden = cv.take<float>(n * c.v_hidden);
+    w.xn = cv.take<bf16_t>(n * c.v_hidden);
+    w.delta = cv.take<bf16_t>(n * c.v_hidden);
+    w.q = cv.take<bf16_t>(n * VPK);
+    w.k = cv.take<bf16_t>(n * VPK);
+    w.v = cv.take<bf16_t>(n * VPK);
+    w.attn = cv.take<bf16_t>(n * VPK);
+    w.ff = cv.take<bf16_t>(n * h->v_ffld);
+    w.mid = cv.take<bf16_t>(n / c.v_merge_unit * h->merge_hidden);
+    w.merged_w = cv.take<bf16_t>(n / c.v_merge_unit * c.v_out_hidden);
+    w.total = align_up(cv.off);
+    return w;
+}
+
+struct TxtWs {
+    bf16_t *xn, *delta, *q, *k, *v, *attn, *ff, *last;
+    float* hidden;
+    size_t total;
+};
+TxtWs carve_text(const vqs_qwen_handle* h, char* base, int B, int L) {
+    const vqs_qwen_config& c = h->c;
+    Carver cv{base};
+    TxtWs w{};
+    const size_t M = (size_t)B * L;
+    w.hidden = cv.take<float>(M * c.t_hidden);
+    w.xn = cv.take<bf16_t>(M * c.t_hidden);
+    w.delta = cv.take<bf16_t>(M * c.t_hidden);
+    w.q = cv.take<bf16_t>(M * h->t_iq);
+    w.k = cv.take<bf16_t>(M * h->t_ikv);
+    w.v = cv.take<bf16_t>(M * h->t_ikv);
+    w.attn = cv.take<bf16_t>(M * h->t_iq);
+    w.ff = cv.take<bf16_t>(M * h->t_ffld);
+    w.last = cv.take<bf16_t>((size_t)B * c.t_hidden);
+    w.total = align_up(cv.off);
+    return w;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vqs_qwen_create(const vqs_qwen_config* cfg, vqs_qwen_handle** out) {
+    if (!cfg || !out) return VQS_ERR_INVALID;
+    const vqs_qwen_config& c = *cfg;
+    if (c.v_depth <= 0 || c.v_depth > 32 || c.v_heads <= 0 || c.v_hidden % c.v_heads || c.v_hidden % 64 || c.v_merge_unit <= 0 ||
+        c.t_layers <= 0 || c.t_heads <= 0 || c.t_kv_heads <= 0 || c.t_heads % c.t_kv_heads || c.t_hidden % c.t_heads || c.t_hidden % 64 ||
+        c.v_out_hidden != c.t_hidden || c.t_vocab % 8)
+        return VQS_ERR_INVALID;
+    vqs_qwen_handle* h = new vqs_qwen_handle();
+    h->c = c;
+    h->v_hd = c.v_hidden / c.v_heads;
+    h->t_hd = c.t_hidden / c.t_heads;
+    if (h->v_hd > HDP || h->t_hd > HDP || (h->v_hd & 3) || (h->t_hd & 3)) {
+        delete h;
+        return VQS_ERR_INVALID;
+    }
+    h->v_kpatch = round_up(c.v_patch_dim, 64);
+    h->v_mlp_p = round_up(c.v_mlp, 32);
+    h->v_ffld = round_up(h->v_mlp_p, 64);
+    h->t_mlp_p = round_up(c.t_mlp, 32);
+    h->t_ffld = round_up(h->t_mlp_p, 64);
+    h->t_iq = c.t_heads * HDP;
+    h->t_ikv = c.t_kv_heads * HDP;
+    h->merge_hidden = c.v_hidden * c.v_merge_unit;
+    h->m_vheads = head_pad_map(c.v_heads, h->v_hd);
+    h->m_theads = head_pad_map(c.t_heads, h->t_hd);
+    h->m_tkv = head_pad_map(c.t_kv_heads, h->t_hd);
+    h->m_vgate = gate_up_map(c.v_mlp, h->v_mlp_p);
+    h->m_tgate = gate_up_map(c.t_mlp, h->t_mlp_p);
+    *out = h;
+    return VQS_OK;
+}
+
+void vqs_qwen_destroy(vqs_qwen_handle* h) { delete h; }
+
+const char* vqs_qwen_last_error(const vqs_qwen_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+size_t vqs_qwen_packed_bytes(const vqs_qwen_handle* h) {
+    if (!h) return 0;
+    size_t total = 0;
+    (void)pack(const_cast<vqs_qwen_handle*>(h), nullptr, &total, nullptr);
+    return total;
+}
+
+int vqs_qwen_bind_weights(vqs_qwen_handle* h, const vqs_weight_desc* descs, int32_t n, void* d_packed, size_t packed_bytes,
+                          void* stream) {
+    if (!h || !descs || n <= 0 || !d_packed) return VQS_ERR_INVALID;
+    h->w.clear();
+    for (int i = 0; i < n; ++i) {
+        if (!descs[i].name || !descs[i].d_data) return qfail(h, VQS_ERR_INVALID, "bind: null name or pointer");
+        h->w[descs[i].name] = WEnt{(const bf16_t*)descs[i].d_data, descs[i].numel};
+    }
+    size_t need = 0;
+    QRUN(pack(h, nullptr, &need, nullptr));
+    if (packed_bytes < need) return qfail(h, VQS_ERR_WORKSPACE, "bind: packed buffer too small");
+    QRUN(pack(h, (char*)d_packed, &need, (hipStream_t)stream));
+    // every weight the launch sequences read directly must exist
+    const vqs_qwen_config& c = h->c;
+    const bf16_t* dummy;
+    for (int i = 0; i < c.v_depth; ++i) {
+        const std::string p = "model.visual.blocks." + std::to_string(i) + ".";
+        QRUN(get_w(h, p + "norm1.weight", c.v_hidden, &dummy));
+        QRUN(get_w(h, p + "norm2.weight", c.v_hidden, &dummy));
+        QRUN(get_w(h, p + "attn.proj.bias", c.v_hidden, &dummy));
+        QRUN(get_w(h, p + "mlp.down_proj.bias", c.v_hidden, &dummy));
+    }
+    QRUN(get_w(h, "model.visual.merger.ln_q.weight", c.v_hidden, &dummy));
+    QRUN(get_w(h, "model.visual.merger.mlp.0.weight", (int64_t)h->merge_hidden * h->merge_hidden, &dummy));
+    QRUN(get_w(h, "model.visual.merger.mlp.0.bias", h->merge_hidden, &dummy));
+    QRUN(get_w(h, "model.visual.merger.mlp.2.weight", (int64_t)c.v_out_hidden * h->merge_hidden, &dummy));
+    QRUN(get_w(h, "model.visual.merger.mlp.2.bias", c.v_out_hidden, &dummy));
+    QRUN(get_w(h, "model.language_model.embed_tokens.weight", (int64_t)c.t_vocab * c.t_hidden, &dummy));
+    for (int i = 0; i < c.t_layers; ++i) {
+        const std::string p = "model.language_model.layers." + std::to_string(i) + ".";
+        QRUN(get_w(h, p + "input_layernorm.weight", c.t_hidden, &dummy));
+        QRUN(get_w(h, p + "post_attention_layernorm.weight", c.t_hidden, &dummy));
+    }
+    QRUN(get_w(h, "model.language_model.norm.weight", c.t_hidden, &dummy));
+    QRUN(get_w(h, "lm_head.weight", (int64_t)c.t_vocab * c.t_hidden, &dummy));
+    h->bound = true;
+    return VQS_OK;
+}
+
+size_t vqs_qwen_vision_workspace_bytes(const vqs_qwen_handle* h, int32_t N) {
+    if (!h || N <= 0 || N % h->c.v_merge_unit) return 0;
+    return carve_vision(h, nullptr, N).total;
+}
+
+int vqs_qwen_encode_vision(vqs_qwen_handle* h, const void* d_patches, const int32_t* d_row_map, const int32_t* d_cell_inv,
+                           const float* d_cos, const float* d_sin, int32_t N, int32_t win_len, int32_t frame_len,
+                           void* d_merged, void* d_ws, size_t ws_bytes, void* stream) {
+    if (!h) return VQS_ERR_INVALID;
+    if (!h->bound) return qfail(h, VQS_ERR_STATE, "encode_vision: weights not bound");
+    if (!d_patches || !d_row_map || !d_cell_inv || !d_cos || !d_sin || !d_merged || !d_ws) return qfail(h, VQS_ERR_INVALID, "encode_vision: null argument");
+    const vqs_qwen_config& c = h->c;
+    if (N <= 0 || N % c.v_merge_unit || win_len <= 0 || frame_len <= 0 || N % win_len || N % frame_len)
+        return qfail(h, VQS_ERR_INVALID, "encode_vision: N must be a multiple of merge_unit, win_len and frame_len (every window full)");
+    const VisWs w = carve_vision(h, (char*)d_ws, N);
+    if (ws_bytes < w.total) return qfail(h, VQS_ERR_WORKSPACE, "encode_vision: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int VH = c.v_hidden, VNH = c.v_heads, VPK = VNH * HDP, NC = N / c.v_merge_unit;
+    const float scale = 1.0f / sqrtf((float)h->v_hd);
+
+    // patch embed = matmul over the flattened receptive field (K padded to 64), then the window permutation
+    QHIP(h, vqs::launch_gather_rows_bf16((const bf16_t*)d_patches, nullptr, nullptr, w.patches, N, c.v_patch_dim, c.v_patch_dim, h->v_kpatch, st), "pad patches");
+    {
+        GCall g{w.patches, h->patch_w, w.pre};
+        g.M = N; g.N = VH; g.K = h->v_kpatch; g.lda = h->v_kpatch; g.ldw = h->v_kpatch; g.ldc = VH; g.epi = vqs::EPI_F32;
+        QRUN(qgemm(h, g, st, "patch embed"));
+    }
+    QHIP(h, vqs::launch_gather_rows_f32(w.pre, d_row_map, w.hidden, N, VH, st), "window permutation");
+    QHIP(h, hipMemsetAsync(w.ff, 0, (size_t)N * h->v_ffld * sizeof(bf16_t), st), "clear ff padding");
+
+    const bf16_t* pend = nullptr;
+    for (int i = 0; i < c.v_depth; ++i) {
+        const std::string p = "model.visual.blocks." + std::to_string(i) + ".";
+        QW(n1, p + "norm1.weight", VH);
+        QW(n2, p + "norm2.weight", VH);
+        QW(pb, p + "attn.proj.bias", VH);
+        QW(db, p + "mlp.down_proj.bias", VH);
+        const int S = ((c.v_fullatt_mask >> i) & 1) ? frame_len : win_len;
+        const int Bseg = N / S;
+        QHIP(h, vqs::launch_rmsnorm(w.hidden, pend, n1, w.xn, N, VH, c.v_eps, st), "vision norm1");
+        {
+            GCall g{w.xn, h->v_qkv_w[i], nullptr};
+            g.bias = h->v_qkv_b[i];
+            g.M = N; g.N = 3 * VPK; g.K = VH; g.lda = VH; g.ldw = VH; g.epi = vqs::EPI_HEADS;
+            g.S = S; g.H = VNH; g.inner = VPK; g.hd = HDP;
+            g.heads[0] = w.q; g.heads[1] = w.k; g.heads[2] = w.v;
+            QRUN(qgemm(h, g, st, "vision qkv"));
+        }
+        QHIP(h, vqs::launch_rope(w.q, d_cos, d_sin, Bseg, VNH, S, HDP, h->v_hd / 2, st), "vision rope q");
+        QHIP(h, vqs::launch_rope(w.k, d_cos, d_sin, Bseg, VNH, S, HDP, h->v_hd / 2, st), "vision rope k");
+        {
+            vqs::AttnParams a{w.q, w.k, w.v, w.attn, nullptr, nullptr, Bseg, VNH, S, scale};
+            a.hd = HDP;
+            QHIP(h, vqs::launch_attention(a, st), "vision attention");
+        }
+        {
+            GCall g{w.attn, h->v_proj_w[i], w.delta};
+            g.bias = pb;
+            g.M = N; g.N = VH; g.K = VPK; g.lda = VPK; g.ldw = VPK; g.ldc = VH; g.epi = vqs::EPI_BF16;
+            QRUN(qgemm(h, g, st, "vision proj"));
+        }
+        QHIP(h, vqs::launch_rmsnorm(w.hidden, w.delta, n2, w.xn, N, VH, c.v_eps, st), "vision norm2");
+        {
+            GCall g{w.xn, h->v_gu_w[i], w.ff};
+            g.bias = h->v_gu_b[i];
+            g.M = N; g.N = 2 * h->v_mlp_p; g.K = VH; g.lda = VH; g.ldw = VH; g.ldc = h->v_ffld; g.epi = vqs::EPI_GATED; g.gate_act = 1;
+            QRUN(qgemm(h, g, st, "vision gate|up"));
+        }
+        {
+            GCall g{w.ff, h->v_down_w[i], w.delta};
+            g.bias = db;
+            g.M = N; g.N = VH; g.K = h->v_ffld; g.lda = h->v_ffld; g.ldw = h->v_ffld; g.ldc = VH; g.epi = vqs::EPI_BF16;
+            QRUN(qgemm(h, g, st, "vision down"));
+            pend = w.delta;
+        }
+    }
+    // merger: RMSNorm, 4 neighbouring patches (consecutive rows in windowed order) concatenated, Linear-GELU-Linear, undo
+    // the window permutation
+    QW(lnq, "model.visual.merger.ln_q.weight", VH);
+    QW(m0w, "model.visual.merger.mlp.0.weight", (int64_t)h->merge_hidden * h->merge_hidden);
+    QW(m0b, "model.visual.merger.mlp.0.bias", h->merge_hidden);
+    QW(m2w, "model.visual.merger.mlp.2.weight", (int64_t)c.v_out_hidden * h->merge_hidden);
+    QW(m2b, "model.visual.merger.mlp.2.bias", c.v_out_hidden);
+    QHIP(h, vqs::launch_rmsnorm(w.hidden, pend, lnq, w.xn, N, VH, 1e-6f, st), "merger norm");
+    {
+        GCall g{w.xn, m0w, w.mid};
+        g.bias = m0b;
+        g.M = NC; g.N = h->merge_hidden; g.K = h->merge_hidden; g.lda = h->merge_hidden; g.ldw = h->merge_hidden; g.ldc = h->merge_hidden;
+        g.epi = vqs::EPI_BF16_GELU;
+        QRUN(qgemm(h, g, st, "merger mlp.0"));
+    }
+    {
+        GCall g{w.mid, m2w, w.merged_w};
+        g.bias = m2b;
+        g.M = NC; g.N = c.v_out_hidden; g.K = h->merge_hidden; g.lda = h->merge_hidden; g.ldw = h->merge_hidden; g.ldc = c.v_out_hidden;
+        g.epi = vqs::EPI_BF16;
+        QRUN(qgemm(h, g, st, "merger mlp.2"));
+    }
+    QHIP(h, vqs::launch_gather_rows_bf16(w.merged_w, nullptr, d_cell_inv, (bf16_t*)d_merged, NC, c.v_out_hidden, c.v_out_hidden,
+                                          c.v_out_hidden, st), "undo window permutation");
+    return VQS_OK;
+}
+
+size_t vqs_qwen_score_workspace_bytes(const vqs_qwen_handle* h, int32_t B, int32_t L) {
+    if (!h || B <= 0 || L <= 0) return 0;
+    return carve_text(h, nullptr, B, L).total;
+}
+
+int vqs_qwen_score(vqs_qwen_handle* h, const void* d_merged, const int32_t* d_input_ids, const int32_t* d_vis_slot,
+                   const int32_t* d_seq_len, const int32_t* d_last_row, const float* d_cos, const float* d_sin, int32_t B,
+                   int32_t L, float* d_logits, void* d_ws, size_t ws_bytes, void* stream) {
+    if (!h) return VQS_ERR_INVALID;
+    if (!h->bound) return qfail(h, VQS_ERR_STATE, "score: weights not bound");
+    if (!d_merged || !d_input_ids || !d_vis_slot || !d_seq_len || !d_last_row || !d_cos || !d_sin || !d_logits || !d_ws)
+        return qfail(h, VQS_ERR_INVALID, "score: null argument");
+    if (B <= 0 || L <= 0) return qfail(h, VQS_ERR_INVALID, "score: need B > 0, L > 0");
+    const vqs_qwen_config& c = h->c;
+    const TxtWs w = carve_text(h, (char*)d_ws, B, L);
+    if (ws_bytes < w.total) return qfail(h, VQS_ERR_WORKSPACE, "score: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int TH = c.t_hidden, M = B * L, IQ = h->t_iq, IKV = h->t_ikv;
+    const float scale = 1.0f / sqrtf((float)h->t_hd);
+    QW(embed, "model.language_model.embed_tokens.weight", (int64_t)c.t_vocab * TH);
+    QHIP(h, vqs::launch_qwen_embed(d_input_ids, d_vis_slot, embed, (const bf16_t*)d_merged, w.hidden, M, TH, c.t_vocab, st), "embed + splice");
+    QHIP(h, hipMemsetAsync(w.ff, 0, (size_t)M * h->t_ffld * sizeof(bf16_t), st), "clear ff padding");
+
+    const bf16_t* pend = nullptr;
+    for (int i = 0; i < c.t_layers; ++i) {
+        const std::string p = "model.language_model.layers." + std::to_string(i) + ".";
+        QW(ln1, p + "input_layernorm.weight", TH);
+        QW(ln2, p + "post_attention_layernorm.weight", TH);
+        QHIP(h, vqs::launch_rmsnorm(w.hidden, pend, ln1, w.xn, M, TH, c.t_eps, st), "input_layernorm");
+        {
+            GCall g{w.xn, h->t_qkv_w[i], nullptr};
+            g.bias = h->t_qkv_b[i];
+            g.M = M; g.N = IQ + 2 * IKV; g.K = TH; g.lda = TH; g.ldw = TH; g.epi = vqs::EPI_HEADS;
+            g.S = L; g.H = c.t_heads; g.inner = IQ; g.hd = HDP; g.inner_kv = IKV; g.Hkv = c.t_kv_heads;
+            g.heads[0] = w.q; g.heads[1] = w.k; g.heads[2] = w.v;
+            QRUN(qgemm(h, g, st, "qkv"));
+        }
+        QHIP(h, vqs::launch_rope(w.q, d_cos, d_sin, B, c.t_heads, L, HDP, h->t_hd / 2, st), "rope q");
+        QHIP(h, vqs::launch_rope(w.k, d_cos, d_sin, B, c.t_kv_heads, L, HDP, h->t_hd / 2, st), "rope k");
+        {
+            vqs::AttnParams a{w.q, w.k, w.v, w.attn, nullptr, d_seq_len, B, c.t_heads, L, scale};
+            a.hd = HDP; a.Hkv = c.t_kv_heads; a.causal = 1;
+            QHIP(h, vqs::launch_attention(a, st), "attention");
+        }
+        {
+            GCall g{w.attn, h->t_o_w[i], w.delta};
+            g.M = M; g.N = TH; g.K = IQ; g.lda = IQ; g.ldw = IQ; g.ldc = TH; g.epi = vqs::EPI_BF16;
+            QRUN(qgemm(h, g, st, "o_proj"));
+        }
+        QHIP(h, vqs::launch_rmsnorm(w.hidden, w.delta, ln2, w.xn, M, TH, c.t_eps, st), "post_attention_layernorm");
+        {
+            GCall g{w.xn, h->t_gu_w[i], w.ff};
+            g.M = M; g.N = 2 * h->t_mlp_p; g.K = TH; g.lda = TH; g.ldw = TH; g.ldc = h->t_ffld; g.epi = vqs::EPI_GATED; g.gate_act = 1;
+            QRUN(qgemm(h, g, st, "gate|up"));
+        }
+        {
+            GCall g{w.ff, h->t_down_w[i], w.delta};
+            g.M = M; g.N = TH; g.K = h->t_ffld; g.lda = h->t_ffld; g.ldw = h->t_ffld; g.ldc = TH; g.epi = vqs::EPI_BF16;
+            QRUN(qgemm(h, g, st, "down_proj"));
+            pend = w.delta;
+        }
+    }
+    QW(fin, "model.language_model.norm.weight", TH);
+    QW(head, "lm_head.weight", (int64_t)c.t_vocab * TH);
+    QHIP(h, vqs::launch_rmsnorm(w.hidden, pend, fin, w.xn, M, TH, c.t_eps, st), "final norm");
+    QHIP(h, vqs::launch_gather_rows_bf16(w.xn, nullptr, d_last_row, w.last, B, TH, TH, TH, st), "last positions");
+    {
+        GCall g{w.last, head, d_logits};
+        g.M = B; g.N = c.t_vocab; g.K = TH; g.lda = TH; g.ldw = TH; g.ldc = c.t_vocab; g.epi = vqs::EPI_F32;
+        QRUN(qgemm(h, g, st, "lm_head"));
+    }
+    return VQS_OK;
+}
+
+}  // extern "C"

@@ -75,7 +75,7 @@ QWEN_TINY = Qwen25VLConfig(
 )
 QWEN_SMALL = Qwen25VLConfig(
     name="qwen-small",
-    vision=QwenVisionConfig(depth=4, hidden=160, heads=2, mlp=200, window=112, fullatt_blocks=(3,), out_hidden=256),
+    vision=QwenVisionConfig(depth=4, hidden=320, heads=4, mlp=200, window=112, fullatt_blocks=(3,), out_hidden=256),   # 80-wide heads, mlp not a multiple of 32
     text=QwenTextConfig(vocab=1024, hidden=256, layers=3, heads=2, kv_heads=1, mlp=384, mrope_section=(16, 24, 24)),
     image_token_id=4, video_token_id=5, vision_start_token_id=6, vision_end_token_id=7,
 )

@@ -1,0 +1,120 @@
+"""ctypes binding of the Qwen2.5-VL row of libvqs_hip.so (include/vqs_qwen.h).  PyTorch is used for device memory and
+the current HIP stream only.  No CPU fallback: a missing library or a failed launch raises."""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Sequence, Tuple
+
+import torch
+
+from ..engine import VqsError, VqsWeightDesc, load_library, _stream_ptr
+from .config import Qwen25VLConfig
+from .layout import text_layout, vision_layout
+
+_i32, _f32, _vp, _sz = ctypes.c_int32, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+
+
+class VqsQwenConfig(ctypes.Structure):      # field order = struct vqs_qwen_config
+    _fields_ = [(n, _i32) for n in ("v_depth", "v_hidden", "v_heads", "v_mlp", "v_patch_dim", "v_merge_unit", "v_out_hidden",
+                                    "v_fullatt_mask")] + [("v_eps", _f32)] + \
+               [(n, _i32) for n in ("t_vocab", "t_hidden", "t_layers", "t_heads", "t_kv_heads", "t_mlp")] + [("t_eps", _f32)]
+
+
+_SIGS = {
+    "vqs_qwen_create": (_i32, [ctypes.POINTER(VqsQwenConfig), ctypes.POINTER(_vp)]),
+    "vqs_qwen_destroy": (None, [_vp]),
+    "vqs_qwen_last_error": (ctypes.c_char_p, [_vp]),
+    "vqs_qwen_packed_bytes": (_sz, [_vp]),
+    "vqs_qwen_bind_weights": (_i32, [_vp, ctypes.POINTER(VqsWeightDesc), _i32, _vp, _sz, _vp]),
+    "vqs_qwen_vision_workspace_bytes": (_sz, [_vp, _i32]),
+    "vqs_qwen_encode_vision": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
+    "vqs_qwen_score_workspace_bytes": (_sz, [_vp, _i32, _i32]),
+    "vqs_qwen_score": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _sz, _vp]),
+}
+
+
+class QwenEngine:
+    def __init__(self, cfg: Qwen25VLConfig, weights: Dict[str, torch.Tensor], device="cuda:0"):
+        if not torch.cuda.is_available():
+            raise VqsError("the Qwen2.5-VL HIP path needs an MI355X (no CPU fallback)")
+        self.lib = load_library()
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(self.lib, name)
+            fn.restype, fn.argtypes = res, args
+        self.cfg, self.device = cfg, torch.device(device)
+        v, t = cfg.vision, cfg.text
+        mask = 0
+        for i in v.fullatt_blocks:
+            mask |= 1 << i
+        c = VqsQwenConfig(v.depth, v.hidden, v.heads, v.mlp, v.patch_dim, v.merge_unit, v.out_hidden, mask, v.rms_eps,
+                          t.vocab, t.hidden, t.layers, t.heads, t.kv_heads, t.mlp, t.rms_eps)
+        h = _vp()
+        rc = self.lib.vqs_qwen_create(ctypes.byref(c), ctypes.byref(h))
+        if rc != 0:
+            raise VqsError(f"vqs_qwen_create failed ({rc}): unsupported configuration")
+        self._h = h
+        with torch.cuda.device(self.device):
+            self._weights = {k: w.to(self.device, torch.bfloat16).contiguous() for k, w in weights.items()}
+            descs = (VqsWeightDesc * len(self._weights))(*[VqsWeightDesc(k.encode(), w.data_ptr(), w.numel())
+                                                            for k, w in self._weights.items()])
+            self._packed = torch.empty(self.lib.vqs_qwen_packed_bytes(self._h), dtype=torch.uint8, device=self.device)
+            self._check(self.lib.vqs_qwen_bind_weights(self._h, descs, len(self._weights), self._packed.data_ptr(),
+                                                       self._packed.numel(), _stream_ptr()), "vqs_qwen_bind_weights")
+            torch.cuda.synchronize()
+        self._ws = None
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise VqsError(f"{what} failed ({rc}): {self.lib.vqs_qwen_last_error(self._h).decode()}")
+
+    def _workspace(self, need):
+        if need == 0:
+            raise VqsError("unsupported shape")
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def encode_vision(self, patches: torch.Tensor, grids: Sequence[Tuple[int, int, int]]) -> torch.Tensor:
+        """patches [N, patch_dim] (HF processor order) -> merged vision tokens bf16 [N/4, out_hidden]."""
+        lay = vision_layout(self.cfg, grids)
+        with torch.cuda.device(self.device):
+            dev = self.device
+            px = patches.to(dev, torch.bfloat16).contiguous()
+            N = px.shape[0]
+            rm, ci = lay["row_map"].to(dev), lay["cell_inv"].to(dev)
+            cs, sn = lay["cos"].to(dev), lay["sin"].to(dev)
+            out = torch.empty(N // self.cfg.vision.merge_unit, self.cfg.vision.out_hidden, dtype=torch.bfloat16, device=dev)
+            ws = self._workspace(self.lib.vqs_qwen_vision_workspace_bytes(self._h, N))
+            self._check(self.lib.vqs_qwen_encode_vision(self._h, px.data_ptr(), rm.data_ptr(), ci.data_ptr(), cs.data_ptr(),
+                                                        sn.data_ptr(), N, lay["win_len"], lay["frame_len"], out.data_ptr(),
+                                                        ws.data_ptr(), ws.numel(), _stream_ptr()), "vqs_qwen_encode_vision")
+            return out
+
+    def score_logits(self, merged: torch.Tensor, input_ids: torch.Tensor, attention_mask: torch.Tensor,
+                     grids: Sequence[Tuple[int, int, int]]) -> torch.Tensor:
+        """-> fp32 [B, vocab]: logits of the last valid position of every sample (= scores[0] of HF generate)."""
+        lay = text_layout(self.cfg, input_ids.cpu(), attention_mask.cpu(), grids)
+        with torch.cuda.device(self.device):
+            dev = self.device
+            B, L = input_ids.shape
+            ids = input_ids.to(dev, torch.int32).contiguous()
+            t = {k: lay[k].to(dev) for k in ("vis_slot", "seq_len", "last_row", "cos", "sin")}
+            logits = torch.empty(B, self.cfg.text.vocab, dtype=torch.float32, device=dev)
+            ws = self._workspace(self.lib.vqs_qwen_score_workspace_bytes(self._h, B, L))
+            self._check(self.lib.vqs_qwen_score(self._h, merged.contiguous().data_ptr(), ids.data_ptr(), t["vis_slot"].data_ptr(),
+                                                t["seq_len"].data_ptr(), t["last_row"].data_ptr(), t["cos"].data_ptr(),
+                                                t["sin"].data_ptr(), B, L, logits.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                _stream_ptr()), "vqs_qwen_score")
+            return logits
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.vqs_qwen_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

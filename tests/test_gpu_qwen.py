@@ -1,0 +1,66 @@
+"""Qwen2.5-VL row on the MI355X through the C ABI (include/vqs_qwen.h): parity of the HIP vision
+tower, language-model prefill and answer probability against the HF fixtures and the fp32 oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from t2v_metrics_amd.qwen import get_qwen_config
+from t2v_metrics_amd.qwen.weights import make_seeded_qwen_weights
+
+pytestmark = pytest.mark.gpu
+
+# bf16 operands against fp32 arithmetic: same criterion as the CLIP-FlanT5 row: |d log P(answer)| within the
+# bf16 noise floor measured there
+LOGPROB_TOL_BF16 = 2.5e-2
+
+
+@pytest.mark.parametrize("name", ["qwen-tiny", "qwen-small"])
+def test_qwen_path_matches_hf_fixture(golden_dir, name):
+    from oracle.qwen25vl_oracle import QwenOracle
+    from t2v_metrics_amd.qwen.engine import QwenEngine
+    z = np.load(os.path.join(golden_dir, f"qwen_{name.split('-')[-1]}.npz"))
+    cfg = get_qwen_config(name)
+    w = make_seeded_qwen_weights(cfg, seed=int(z["seed"]), dtype=torch.bfloat16, lm_head_gain=float(z["gain"]))
+    eng = QwenEngine(cfg, w)
+    grids = [tuple(int(x) for x in g) for g in z["grids"]]
+    ids, mask = torch.from_numpy(z["input_ids"]), torch.from_numpy(z["attention_mask"])
+    px = torch.from_numpy(z["pixel_values"])
+    # vision tower, one call per video (different grids), merged tokens in HF order
+    merged, off = [], 0
+    for g in grids:
+        n = g[0] * g[1] * g[2]
+        merged.append(eng.encode_vision(px[off: off + n], [g]))
+        off += n
+    merged = torch.cat(merged)
+    torch.cuda.synchronize()
+    ref_merged = torch.from_numpy(z["merged"])
+    err = (merged.float().cpu() - ref_merged).abs().max().item()
+    assert err <= 0.06 * max(1.0, ref_merged.abs().max().item()), f"merged vision tokens off by {err}"
+    # language model: batched, right-padded
+    logits = eng.score_logits(merged, ids, mask, grids).float().cpu()
+    ref_logits = torch.from_numpy(z["logits"])
+    lp, ref_lp = torch.log_softmax(logits, -1), torch.log_softmax(ref_logits, -1)
+    top = ref_lp.argmax(-1)
+    for b in range(ids.shape[0]):
+        # the answer ids the reference would look at: compare the log-probabilities of the 5 most likely tokens
+        for tok in ref_lp[b].topk(5).indices.tolist():
+            assert abs(lp[b, tok].item() - ref_lp[b, tok].item()) <= 4 * LOGPROB_TOL_BF16, (b, tok, lp[b, tok].item(), ref_lp[b, tok].item())
+    assert (lp.gather(-1, top[:, None]) - ref_lp.gather(-1, top[:, None])).abs().max().item() <= 2 * LOGPROB_TOL_BF16
+    # oracle agrees with the fixture (pinned on the CPU suite) -- here: the HIP path agrees with the oracle on a fresh batch
+    o = QwenOracle(cfg, w)
+    o_logits = o.forward(ids, mask, px, grids)
+    d = (torch.log_softmax(o_logits, -1) - lp).gather(-1, top[:, None]).abs().max().item()
+    assert d <= 2 * LOGPROB_TOL_BF16
+    eng.close()
+
+
+def test_qwen_errors_are_reported():
+    from t2v_metrics_amd.engine import VqsError
+    from t2v_metrics_amd.qwen.engine import QwenEngine
+    cfg = get_qwen_config("qwen-tiny")
+    w = make_seeded_qwen_weights(cfg, seed=1)
+    w.pop("model.visual.blocks.1.attn.proj.bias")
+    with pytest.raises(VqsError, match="missing weight"):
+        QwenEngine(cfg, w)

@@ -45,3 +45,25 @@ def test_weight_inventory_matches_the_public_7b_shapes():
     assert specs["model.language_model.layers.27.self_attn.k_proj.weight"] == (512, 3584)
     assert specs["model.language_model.layers.0.mlp.gate_proj.weight"] == (18944, 3584)
     assert specs["lm_head.weight"] == (152064, 3584)
+
+
+@pytest.mark.parametrize("name", ["qwen-tiny", "qwen-small"])
+def test_host_layout_matches_hf(golden_dir, name):
+    """t2v_metrics_amd/qwen/layout.py (what the HIP path is fed): 3-D rope positions equal HF get_rope_index, the window
+    permutation equals HF get_vision_window_index for full-window grids."""
+    from oracle.qwen25vl_oracle import vision_window_index
+    from t2v_metrics_amd.qwen.layout import text_layout, vision_layout
+    z = np.load(os.path.join(golden_dir, f"qwen_{name.split('-')[-1]}.npz"))
+    cfg = get_qwen_config(name)
+    grids = [tuple(int(x) for x in g) for g in z["grids"]]
+    ids, mask = torch.from_numpy(z["input_ids"]), torch.from_numpy(z["attention_mask"])
+    lay = text_layout(cfg, ids, mask, grids)
+    assert torch.equal(lay["position_ids"] * mask[None], torch.from_numpy(z["position_ids"]) * mask[None])
+    assert lay["vis_slot"].max().item() + 1 == sum(t * h * w for t, h, w in grids) // 4
+    v = cfg.vision
+    for g in grids:
+        vl = vision_layout(cfg, [g, g])
+        widx, cu = vision_window_index([g, g], v.spatial_merge, v.window, v.patch)
+        assert torch.equal(vl["row_map"].long().view(-1, 4)[:, 0] // 4, widx)
+        assert all(b - a == vl["win_len"] for a, b in zip(cu[:-1], cu[1:]))
+
