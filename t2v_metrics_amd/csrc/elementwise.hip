@@ -174,6 +174,10 @@ static hipError_t launch_norm_t(float* x, const bf16_t* delta, const bf16_t* w, 
         hipLaunchKernelGGL((norm_rows_reg_kernel<8, KIND, ADD, OUT_F32>), grid, block, 0, s, x, delta, w, b, out, M, eps);
     else if (D == 4096)
         hipLaunchKernelGGL((norm_rows_reg_kernel<16, KIND, ADD, OUT_F32>), grid, block, 0, s, x, delta, w, b, out, M, eps);
+    else if (D == 1280)     // Qwen2.5-VL vision tower
+        hipLaunchKernelGGL((norm_rows_reg_kernel<5, KIND, ADD, OUT_F32>), grid, block, 0, s, x, delta, w, b, out, M, eps);
+    else if (D == 3584)     // Qwen2.5-VL-7B language model
+        hipLaunchKernelGGL((norm_rows_reg_kernel<14, KIND, ADD, OUT_F32>), grid, block, 0, s, x, delta, w, b, out, M, eps);
     else
         hipLaunchKernelGGL((norm_rows_loop_kernel<KIND, ADD, OUT_F32>), grid, block, 0, s, x, delta, w, b, out, M, D, eps);
     return hipGetLastError();

@@ -1,0 +1,220 @@
+"""Qwen2.5-VL VQAScore wrapper on the MI355X engine -- the plugin-interface counterpart of the reference's
+``Qwen2VLModel`` (/root/reference/t2v_metrics/models/vqascore_models/qwen2vl_model.py:93-301) for ``qwen2.5-vl-7b``.
+
+Same recipe: prompt = chat template around one vision placeholder + ``question_template.format(text)``, one prefill,
+score = softmax(logits_of_the_first_generated_position / temperature)[first answer token]  (:222-289 with the default
+``max_new_tokens=1``).  What differs: samples are batched (the reference runs batch 1, :190), the prefill runs on
+libvqs_hip (include/vqs_qwen.h), frame resizing / patch flattening are restated here instead of going through
+``qwen_vl_utils`` + the HF processor (neither is installable offline).
+
+Input support: ``.npy`` arrays ([H,W,3] image or [T,H,W,3] frames, as qwen2vl_model.py:145-155) and image files; video
+container files need decord/ffmpeg (absent) -> NotImplementedError.  The HIP vision tower requires every attention
+window to be full: the resized frame must be a multiple of 112 px on both sides (true for 336 x 448, BASELINE config 5).
+"""
+from __future__ import annotations
+
+import math
+import os
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+from PIL import Image
+
+from ...constants import HF_CACHE_DIR
+from ...qwen import Qwen25VLConfig, get_qwen_config
+from .vqa_model import VQAScoreModel
+
+QWEN25_VL_MODELS = {
+    'qwen2.5-vl-7b': {'config': 'qwen2.5-vl-7b', 'hf_repo': 'Qwen/Qwen2.5-VL-7B-Instruct', 'fps': 8.0},
+}
+default_question_template = 'Does this figure show "{}"? Please answer Yes or No.'     # qwen2vl_model.py:173
+default_answer_template = 'Yes'
+OPENAI_CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+OPENAI_CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+VIDEO_MAX_PIXELS = 360 * 420                                                              # qwen2vl_model.py:142-144
+IMAGE_PLACEHOLDER, VIDEO_PLACEHOLDER = "<|image_pad|>", "<|video_pad|>"
+
+
+def smart_resize(height: int, width: int, factor: int = 28, min_pixels: int = 56 * 56, max_pixels: int = 14 * 14 * 4 * 1280):
+    """HF models/qwen2_vl/image_processing_qwen2_vl.py:62-88."""
+    if max(height, width) / min(height, width) > 200:
+        raise ValueError("absolute aspect ratio must be smaller than 200")
+    h_bar, w_bar = round(height / factor) * factor, round(width / factor) * factor
+    if h_bar * w_bar > max_pixels:
+        beta = math.sqrt((height * width) / max_pixels)
+        h_bar = max(factor, math.floor(height / beta / factor) * factor)
+        w_bar = max(factor, math.floor(width / beta / factor) * factor)
+    elif h_bar * w_bar < min_pixels:
+        beta = math.sqrt(min_pixels / (height * width))
+        h_bar, w_bar = math.ceil(height * beta / factor) * factor, math.ceil(width * beta / factor) * factor
+    return h_bar, w_bar
+
+
+def patchify(frames: torch.Tensor, patch: int = 14, merge: int = 2, temporal: int = 2) -> Tuple[torch.Tensor, Tuple[int, int, int]]:
+    """frames fp32 [T, 3, H, W] (normalised) -> ([t*h*w, 3*temporal*patch*patch], (t, h, w)): the flat layout of HF
+    Qwen2VLVideoProcessor.patchify (models/qwen2_vl/video_processing_qwen2_vl.py:236-274): the last frame is repeated
+    to an even count, patches ordered block-major over merge x merge cells, features ordered [C, Tp, P, P]."""
+    T, C, H, W = frames.shape
+    if T % temporal:
+        frames = torch.cat([frames, frames[-1:].expand(temporal - T % temporal, -1, -1, -1)], 0)
+        T = frames.shape[0]
+    t, h, w = T // temporal, H // patch, W // patch
+    x = frames.reshape(t, temporal, C, h // merge, merge, patch, w // merge, merge, patch)
+    x = x.permute(0, 3, 6, 4, 7, 2, 1, 5, 8)
+    return x.reshape(t * h * w, C * temporal * patch * patch).contiguous(), (t, h, w)
+
+
+def chat_prompt(question: str, placeholder: str) -> str:
+    """Qwen2.5-VL chat template, one user turn with one vision item followed by the text, generation prompt appended
+    (what processor.apply_chat_template(messages, add_generation_prompt=True) renders, qwen2vl_model.py:196-200)."""
+    return ("<|im_start|>system\nYou are a helpful assistant.<|im_end|>\n<|im_start|>user\n<|vision_start|>" + placeholder +
+            "<|vision_end|>" + question + "<|im_end|>\n<|im_start|>assistant\n")
+
+
+class Qwen25VLModel(VQAScoreModel):
+    video_mode = "direct"
+    allows_image = True
+
+    def __init__(self, model_name='qwen2.5-vl-7b', device='cuda', cache_dir=HF_CACHE_DIR, checkpoint: Optional[str] = None,
+                 weights=None, tokenizer=None, config: Optional[Qwen25VLConfig] = None, engine=None, max_batch: int = 32,
+                 seed: int = 0):
+        """weights: None -> ``checkpoint`` (local HF directory of safetensors); 'seeded' -> seeded random weights at the
+        architecture; or a dict.  tokenizer: object with ``encode(text, add_special_tokens=False) -> List[int]`` that maps
+        the chat-template special tokens (HF protocol); None -> the checkpoint's tokenizer."""
+        assert config is not None or model_name in QWEN25_VL_MODELS, f"Model {model_name} not found in QWEN25_VL_MODELS"
+        self._cfg = config if config is not None else get_qwen_config(QWEN25_VL_MODELS[model_name]['config'])
+        self._weights_arg, self._tokenizer_arg, self._checkpoint, self._engine_arg = weights, tokenizer, checkpoint, engine
+        self._seed, self.max_batch = seed, int(max_batch)
+        super().__init__(model_name=model_name, device=device, cache_dir=cache_dir)
+
+    # ------------------------------------------------------------------ loading
+    def _checkpoint_dir(self) -> str:
+        if self._checkpoint:
+            return self._checkpoint
+        return os.path.join(self.cache_dir, QWEN25_VL_MODELS[self.model_name]['hf_repo'].split('/')[-1])
+
+    def load_model(self):
+        self.cfg = self._cfg
+        if self._tokenizer_arg is not None:
+            self.tokenizer = self._tokenizer_arg
+        else:
+            path = self._checkpoint_dir()
+            if not os.path.isdir(path):
+                raise FileNotFoundError(f"no tokenizer: {path} does not exist (no network here). Pass tokenizer=... or checkpoint=<local HF dir>.")
+            from transformers import AutoTokenizer
+            self.tokenizer = AutoTokenizer.from_pretrained(path)
+        if self._engine_arg is not None:
+            self.engine = self._engine_arg
+            return
+        from ...qwen.engine import QwenEngine          # raises if libvqs_hip.so is missing; no fallback
+        from ...qwen.weights import make_seeded_qwen_weights
+        dev = torch.device(self.device if str(self.device) != 'cuda' else 'cuda:0')
+        if isinstance(self._weights_arg, dict):
+            weights = self._weights_arg
+        elif self._weights_arg == 'seeded':
+            weights = make_seeded_qwen_weights(self.cfg, seed=self._seed)
+        else:
+            path = self._checkpoint_dir()
+            if not os.path.isdir(path):
+                raise FileNotFoundError(f"no checkpoint at {path} (no network here). Pass checkpoint=<local HF dir> or weights='seeded'.")
+            from safetensors.torch import load_file
+            weights = {}
+            for f in sorted(os.listdir(path)):
+                if f.endswith(".safetensors"):
+                    weights.update(load_file(os.path.join(path, f)))
+        self.engine = QwenEngine(self.cfg, weights, device=dev)
+
+    # ------------------------------------------------------------------ host-side preparation
+    def load_images(self, paths: List[str], fps: float = None) -> List[Dict]:
+        """-> [{'type': 'image'|'video', 'frames': uint8 [T,H,W,3]}] (qwen2vl_model.py:135-158)."""
+        out = []
+        for path in paths:
+            low = str(path).lower()
+            if low.endswith(('.mp4', '.avi', '.mov', '.mkv')):
+                raise NotImplementedError("video container files need decord/ffmpeg, which this environment does not have; "
+                                          "pass extracted frames as a [T,H,W,3] .npy array")
+            if low.endswith('.npy'):
+                arr = np.load(path)
+                if arr.ndim == 3:
+                    out.append({'type': 'image', 'frames': arr.astype('uint8')[None]})
+                elif arr.ndim == 4:
+                    out.append({'type': 'video', 'frames': arr.astype('uint8')})
+                else:
+                    raise ValueError(f"Unexpected shape for NumPy array in {path}")
+            else:
+                out.append({'type': 'image', 'frames': np.asarray(Image.open(path).convert('RGB'))[None]})
+        return out
+
+    def preprocess(self, item: Dict) -> Tuple[torch.Tensor, Tuple[int, int, int]]:
+        """Resize (smart_resize to multiples of 28; videos capped at 360*420 pixels as the reference does), rescale,
+        CLIP-normalise, flatten -> (patches fp32 [N, 1176], (t, h, w))."""
+        v = self.cfg.vision
+        frames = item['frames']
+        H, W = frames.shape[1:3]
+        factor = v.patch * v.spatial_merge
+        if item['type'] == 'video':
+            rh, rw = smart_resize(H, W, factor=factor, max_pixels=VIDEO_MAX_PIXELS)
+        else:
+            rh, rw = smart_resize(H, W, factor=factor)
+        if (rh, rw) != (H, W):
+            frames = np.stack([np.asarray(Image.fromarray(f).resize((rw, rh), Image.BICUBIC)) for f in frames])
+        win = v.window
+        if rh % win or rw % win:
+            raise NotImplementedError(f"resized frame {rh}x{rw} is not a multiple of the {win}-px attention window; the HIP vision "
+                                      "tower handles full windows only (e.g. 336x448)")
+        x = torch.from_numpy(np.ascontiguousarray(frames)).permute(0, 3, 1, 2).to(torch.float32) * (1.0 / 255.0)
+        mean = torch.tensor(OPENAI_CLIP_MEAN).view(1, 3, 1, 1)
+        std = torch.tensor(OPENAI_CLIP_STD).view(1, 3, 1, 1)
+        return patchify((x - mean) / std, v.patch, v.spatial_merge, v.temporal_patch)
+
+    def build_ids(self, question: str, kind: str, n_tokens: int) -> List[int]:
+        ph = VIDEO_PLACEHOLDER if kind == 'video' else IMAGE_PLACEHOLDER
+        ids = list(self.tokenizer.encode(chat_prompt(question, ph), add_special_tokens=False))
+        pid = self.cfg.video_token_id if kind == 'video' else self.cfg.image_token_id
+        if ids.count(pid) != 1:
+            raise ValueError("the tokenizer must map the vision placeholder to exactly one token")
+        k = ids.index(pid)
+        # the HIP path splices every vision run through the video placeholder id (image = one-temporal-patch video)
+        return ids[:k] + [self.cfg.video_token_id] * n_tokens + ids[k + 1:]
+
+    # ------------------------------------------------------------------ scoring
+    @torch.no_grad()
+    def forward(self, images: List[str], texts: List[str], fps=None, question_template: str = default_question_template,
+                answer_template: str = default_answer_template, max_new_tokens: int = 1, temperature: float = 1.0) -> torch.Tensor:
+        assert len(images) == len(texts), "Number of images/videos and texts must match"
+        if max_new_tokens != 1:
+            raise NotImplementedError("the HIP path scores the first generated position only (max_new_tokens=1, the reference default)")
+        questions = [question_template.format(t) for t in texts]
+        answers = [answer_template.format(t) for t in texts]
+        items = self.load_images(images, fps)
+        prepared = [self.preprocess(it) for it in items]
+        scores = torch.zeros(len(images), dtype=torch.float32)
+        # batch samples that share a grid (one vision call per group), at most max_batch at a time
+        groups: Dict[Tuple[int, int, int], List[int]] = {}
+        for i, (_, g) in enumerate(prepared):
+            groups.setdefault(g, []).append(i)
+        for g, idxs in groups.items():
+            for s in range(0, len(idxs), self.max_batch):
+                chunk = idxs[s: s + self.max_batch]
+                patches = torch.cat([prepared[i][0] for i in chunk])
+                merged = self.engine.encode_vision(patches, [g] * len(chunk))
+                n_tok = g[0] * g[1] * g[2] // self.cfg.vision.merge_unit
+                rows = [self.build_ids(questions[i], items[i]['type'], n_tok) for i in chunk]
+                L = max(len(r) for r in rows)
+                ids = torch.zeros(len(rows), L, dtype=torch.long)
+                mask = torch.zeros(len(rows), L, dtype=torch.long)
+                for k, r in enumerate(rows):
+                    ids[k, : len(r)] = torch.tensor(r)
+                    mask[k, : len(r)] = 1
+                logits = self.engine.score_logits(merged, ids, mask, [g] * len(chunk)).float().cpu()
+                probs = torch.softmax(logits / temperature, dim=-1)                        # qwen2vl_model.py:160-167
+                for k, i in enumerate(chunk):
+                    a_ids = self.tokenizer.encode(answers[i], add_special_tokens=False)
+                    if len(a_ids) < 1:
+                        raise ValueError("empty answer")
+                    scores[i] = probs[k, a_ids[0]]          # max_new_tokens=1: only the first answer token is scored (:257-262)
+        return scores
+
+    def generate(self, *args, **kwargs):
+        raise NotImplementedError("free-form generation is not part of the MI355X Qwen2.5-VL path yet (scoring only)")

@@ -246,7 +246,7 @@ def test_decoder_attention(eng, T):
     assert_close(out, ref, 2e-2, 2e-2, f"decoder cross attention T{T}")
 
 
-@pytest.mark.parametrize("M,D", [(7, 128), (1000, 2048), (33, 4096), (5, 1024)])
+@pytest.mark.parametrize("M,D", [(7, 128), (1000, 2048), (33, 4096), (5, 1024), (301, 1280), (77, 3584)])
 def test_norms(eng, M, D):
     x = torch.randn(M, D, device="cuda", generator=torch.Generator(device="cuda").manual_seed(23)) * 3.0 + 0.5
     w = randn_bf16(D, seed=24)

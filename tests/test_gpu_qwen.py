@@ -64,3 +64,29 @@ def test_qwen_errors_are_reported():
     w.pop("model.visual.blocks.1.attn.proj.bias")
     with pytest.raises(VqsError, match="missing weight"):
         QwenEngine(cfg, w)
+
+
+def test_qwen_drop_in_api_on_gpu(tmp_path):
+    """t2v_metrics_amd.VQAScore(model='qwen2.5-vl-7b') through the reference's call pattern on the MI355X engine (small
+    configuration, seeded weights, stand-in tokenizer): scores equal the fp32 oracle behind the same wrapper."""
+    import t2v_metrics_amd as t2v
+    from tests.test_qwen_host import FakeQwenTokenizer, OracleQwenEngine
+    cfg = get_qwen_config("qwen-small")
+    w = make_seeded_qwen_weights(cfg, seed=11, dtype=torch.bfloat16, lm_head_gain=4.0)
+    rng = np.random.RandomState(2)
+    paths = []
+    for i, shape in enumerate([(4, 112, 224, 3), (2, 112, 224, 3), (224, 112, 3)]):
+        p = tmp_path / f"v{i}.npy"
+        np.save(p, rng.randint(0, 256, shape, dtype=np.uint8))
+        paths.append(str(p))
+    texts = ["a person waves", "a car turns left", "a red square"]
+    tok = FakeQwenTokenizer(cfg.text.vocab)
+    hip = t2v.VQAScore(model="qwen2.5-vl-7b", device="cuda", config=cfg, weights=w, tokenizer=tok)
+    ref = t2v.VQAScore(model="qwen2.5-vl-7b", device="cpu", config=cfg, engine=OracleQwenEngine(cfg, w), tokenizer=tok)
+    s_hip = hip.model.forward(paths, texts)
+    s_ref = ref.model.forward(paths, texts)
+    d = (torch.log(s_hip) - torch.log(s_ref)).abs().max().item()
+    assert d <= 2 * LOGPROB_TOL_BF16, (s_hip.tolist(), s_ref.tolist())
+    m = hip(images=paths[:2], texts=texts[:2])
+    assert m.shape == (2, 2)
+

@@ -113,7 +113,7 @@ def make_scorer(tmp_path, engine=None, **kw):
 
 # ----------------------------------------------------------------------------------------- prompt recipe
 def test_registry_and_error_conventions(tmp_path):
-    assert t2v.list_all_models() == ["clip-flant5-xxl", "clip-flant5-xl"]
+    assert t2v.list_all_models() == ["clip-flant5-xxl", "clip-flant5-xl", "qwen2.5-vl-7b"]
     with pytest.raises(AssertionError):                       # score.py:28
         t2v.VQAScore(model="no-such-model", device="cpu", cache_dir=str(tmp_path))
     with pytest.raises(NotImplementedError):                  # __init__.py:30-33

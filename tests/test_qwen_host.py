@@ -1,0 +1,111 @@
+"""Host side of the Qwen2.5-VL row (t2v_metrics_amd/models/vqascore_models/qwen25vl_model.py): preprocessing pinned to the
+HF image processor, prompt/placeholder handling, batching by grid, scoring recipe -- on the CPU with the oracle behind the
+engine interface (checker only)."""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+import t2v_metrics_amd as t2v
+from t2v_metrics_amd.models.vqascore_models.qwen25vl_model import (OPENAI_CLIP_MEAN, OPENAI_CLIP_STD, Qwen25VLModel, chat_prompt,
+                                                                   patchify, smart_resize)
+from t2v_metrics_amd.qwen import get_qwen_config
+from t2v_metrics_amd.qwen.weights import make_seeded_qwen_weights
+
+SPECIALS = {"<|im_start|>": 8, "<|im_end|>": 9, "<|vision_start|>": 6, "<|vision_end|>": 7, "<|video_pad|>": 5, "<|image_pad|>": 4}
+
+
+class FakeQwenTokenizer:
+    """HF protocol subset: encode(text, add_special_tokens=False); chat-template specials -> fixed ids, words -> hashed ids."""
+
+    def __init__(self, vocab=512):
+        self.vocab = vocab
+
+    def encode(self, text, add_special_tokens=False):
+        for s in SPECIALS:
+            text = text.replace(s, f" {s} ")
+        return [SPECIALS[w] if w in SPECIALS else 10 + zlib.crc32(w.encode()) % (self.vocab - 10) for w in text.split()]
+
+
+class OracleQwenEngine:
+    def __init__(self, cfg, weights):
+        from oracle.qwen25vl_oracle import QwenOracle
+        self.o, self.cfg = QwenOracle(cfg, weights), cfg
+        self.vision_calls = []
+
+    def encode_vision(self, patches, grids):
+        self.vision_calls.append(list(grids))
+        with torch.no_grad():
+            return self.o.vision_tower(patches.float(), grids)
+
+    def score_logits(self, merged, input_ids, attention_mask, grids):
+        from oracle.qwen25vl_oracle import mrope_position_ids
+        o, c = self.o, self.cfg
+        with torch.no_grad():
+            emb = o._w("model.language_model.embed_tokens.weight")[input_ids]
+            m = (input_ids == c.video_token_id) & attention_mask.bool()
+            emb = emb.masked_scatter(m[..., None].expand_as(emb), merged.float())
+            pos = mrope_position_ids(input_ids, attention_mask, c.image_token_id, c.video_token_id, [], grids,
+                                     c.vision.spatial_merge, c.vision.tokens_per_second)
+            hid = o.text_model(emb, pos, attention_mask)
+            last = attention_mask.long().sum(-1) - 1
+            return hid[torch.arange(hid.shape[0]), last] @ o._w("lm_head.weight").t()
+
+
+def test_patchify_and_smart_resize_match_hf():
+    assert smart_resize(336, 448) == (336, 448) and smart_resize(360, 640, max_pixels=360 * 420) == (280, 504)
+    pil = pytest.importorskip("transformers.models.qwen2_vl.image_processing_pil_qwen2_vl")
+    ip = pil.Qwen2VLImageProcessorPil()
+    img = np.random.RandomState(0).randint(0, 256, (112, 168, 3), dtype=np.uint8)
+    out = ip(images=[img], do_resize=False, return_tensors="pt")
+    x = torch.from_numpy(img).permute(2, 0, 1).float()[None] / 255.0
+    x = (x - torch.tensor(OPENAI_CLIP_MEAN).view(1, 3, 1, 1)) / torch.tensor(OPENAI_CLIP_STD).view(1, 3, 1, 1)
+    mine, g = patchify(x, 14, 2, 2)
+    assert list(g) == out["image_grid_thw"][0].tolist()
+    assert (out["pixel_values"] - mine).abs().max().item() <= 1e-6
+    # a two-frame video of the same picture is the same patch matrix as the still image (HF duplicates the frame)
+    assert torch.equal(patchify(torch.cat([x, x]), 14, 2, 2)[0], mine)
+
+
+def test_forward_recipe_batching_and_errors(tmp_path):
+    cfg = get_qwen_config("qwen-tiny")
+    w = make_seeded_qwen_weights(cfg, seed=3, dtype=torch.bfloat16, lm_head_gain=4.0)
+    eng = OracleQwenEngine(cfg, w)
+    tok = FakeQwenTokenizer(cfg.text.vocab)
+    rng = np.random.RandomState(1)
+    paths = []
+    for i, shape in enumerate([(4, 112, 112, 3), (4, 112, 112, 3), (112, 168, 3), (3, 112, 112, 3)]):
+        p = tmp_path / f"v{i}.npy"
+        np.save(p, rng.randint(0, 256, shape, dtype=np.uint8))
+        paths.append(str(p))
+    scorer = t2v.VQAScore(model="qwen2.5-vl-7b", device="cpu", config=cfg, engine=eng, tokenizer=tok)
+    texts = ["a cat jumps", "a dog runs fast", "two birds", "a cat jumps"]
+    s = scorer.model.forward(paths, texts)
+    assert s.shape == (4,) and bool(((s > 0) & (s < 1)).all())
+    # samples 0, 1 and 3 share the grid (2, 8, 8) (3 frames are padded to 4) -> one vision call for the three
+    assert sorted(len(c) for c in eng.vision_calls) == [1, 3]
+    # the recipe: softmax(last-position logits)[first token of the answer] on the chat-template prompt
+    from oracle.qwen25vl_oracle import QwenOracle
+    item = scorer.model.load_images([paths[2]])[0]
+    patches, grid = scorer.model.preprocess(item)
+    ids = scorer.model.build_ids('Does this figure show "two birds"? Please answer Yes or No.', "image", grid[1] * grid[2] // 4)
+    assert chat_prompt("q", "<|image_pad|>").count("<|vision_start|>") == 1 and ids.count(cfg.video_token_id) == grid[1] * grid[2] // 4
+    ids_t = torch.tensor([ids])
+    logits = QwenOracle(cfg, w).forward(ids_t, torch.ones_like(ids_t), patches, [grid])
+    yes = tok.encode("Yes")[0]
+    assert abs(torch.softmax(logits, -1)[0, yes].item() - s[2].item()) <= 1e-5 * max(1.0, s[2].item()) + 1e-8
+    # temperature and answer template are honoured
+    s_t = scorer.model.forward(paths[:1], texts[:1], temperature=2.0, answer_template="No")
+    assert s_t.shape == (1,) and abs(s_t[0].item() - s[0].item()) > 0
+    # score() through the public API
+    grid_scores = scorer(images=paths[:2], texts=texts[:2])
+    assert grid_scores.shape == (2, 2)
+    with pytest.raises(NotImplementedError):
+        scorer.model.forward(["clip.mp4"], ["x"])
+    bad = tmp_path / "odd.npy"
+    np.save(bad, rng.randint(0, 256, (2, 84, 112, 3), dtype=np.uint8))
+    with pytest.raises(NotImplementedError, match="attention window"):
+        scorer.model.forward([str(bad)], ["x"])
+    with pytest.raises(AssertionError):
+        scorer.model.forward(paths[:2], texts[:1])

@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""Throughput of the Qwen2.5-VL-7B VQAScore row (BASELINE.json configs[4]; SURVEY.md §8d "Config 5"): B synthetic 8-frame
+336x448 videos per step -> grid (4, 24, 32) = 3072 patches -> 768 merged tokens + 40 text tokens per sample, one prefill,
+P("Yes") from the last-position logits.  Seeded random weights at the public 7B dims.  Prints one JSON line; with
+--cpu-samples n also times the fp32 oracle on the host (kind "port") and reports |d log P|."""
+import argparse, json, os, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from t2v_metrics_amd.qwen import get_qwen_config
+from t2v_metrics_amd.qwen.weights import make_seeded_qwen_weights
+
+
+def flops_per_sample(cfg, n_patches, L):
+    v, t = cfg.vision, cfg.text
+    vis = n_patches * (2 * v.patch_dim * v.hidden + v.depth * (8 * v.hidden * v.hidden + 6 * v.hidden * v.mlp))
+    # attention: windows of 64 patches, full blocks over a frame
+    full = len(v.fullatt_blocks)
+    vis += n_patches * 4 * v.hidden * (64 * (v.depth - full) + 768 * full)
+    nm = n_patches // v.merge_unit
+    vis += nm * 2 * (v.hidden * v.merge_unit) * (v.hidden * v.merge_unit + v.out_hidden)
+    kv = t.kv_heads * t.head_dim
+    txt = L * t.layers * (2 * t.hidden * (t.hidden + 2 * kv) + 2 * t.hidden * t.hidden + 6 * t.hidden * t.mlp) + t.layers * 2 * L * L * t.hidden
+    txt += 2 * t.hidden * t.vocab
+    return vis + txt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="qwen2.5-vl-7b")
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--cpu-samples", type=int, default=0)
+    args = ap.parse_args()
+    from t2v_metrics_amd.qwen.engine import QwenEngine
+    cfg = get_qwen_config(args.model)
+    dev = torch.device("cuda:0")
+    t0 = time.perf_counter()
+    w = make_seeded_qwen_weights(cfg, seed=0, device="cpu")
+    eng = QwenEngine(cfg, w, device=dev)
+    t_init = time.perf_counter() - t0
+    B = args.batch
+    grid = (4, 24, 32)
+    n_patches = grid[0] * grid[1] * grid[2]
+    g = torch.Generator().manual_seed(1234)
+    px = torch.randn(B * n_patches, cfg.vision.patch_dim, generator=g).to(torch.bfloat16).to(dev)
+    n_merged = n_patches // cfg.vision.merge_unit
+    yes_id = 9454 % cfg.text.vocab
+    rows = []
+    for b in range(B):
+        pre = torch.randint(10, min(cfg.text.vocab, 150000), (14,), generator=g)
+        post = torch.randint(10, min(cfg.text.vocab, 150000), (24,), generator=g)
+        rows.append(torch.cat([pre, torch.tensor([cfg.vision_start_token_id]), torch.full((n_merged,), cfg.video_token_id),
+                               torch.tensor([cfg.vision_end_token_id]), post]))
+    ids = torch.stack(rows)
+    mask = torch.ones_like(ids)
+    grids = [grid] * B
+
+    def step():
+        merged = eng.encode_vision(px, grids)
+        return eng.score_logits(merged, ids, mask, grids)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        logits = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    L = ids.shape[1]
+    fl = flops_per_sample(cfg, n_patches, L)
+    out = {"metric": "videos scored/sec, " + cfg.name, "value": B * args.steps / dt, "unit": "samples/s", "n_gpus": 1,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "dtype": "bf16",
+           "data": "synthetic (seeded patches, token ids, weights)",
+           "config": {"workload": f"{cfg.name}, batch={B} x 8-frame 336x448 video (3072 patches -> 768 vision tokens) + 40 text tokens", "L": L},
+           "algorithmic_tflop_per_sample": fl / 1e12, "model_tflops": B * args.steps / dt * fl / 1e12,
+           "model_frac_of_mfma_peak": B * args.steps / dt * fl / 1e12 / 2500.0, "init_s": t_init}
+    if args.cpu_samples > 0:
+        from oracle.qwen25vl_oracle import QwenOracle
+        n = args.cpu_samples
+        o = QwenOracle(cfg, w)
+        t0 = time.perf_counter()
+        ref = o.forward(ids[:n], mask[:n], px[: n * n_patches].float().cpu(), grids[:n])
+        dtc = time.perf_counter() - t0
+        lp = torch.log_softmax(logits[:n].float().cpu(), -1)[:, yes_id]
+        lr = torch.log_softmax(ref, -1)[:, yes_id]
+        out["cpu_baseline"] = {"value": n / dtc, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"first {n} sample(s) of the batch, fp32 oracle ({dtc:.1f} s)",
+                               "max_abs_dlogp_hip_vs_oracle": float((lp - lr).abs().max())}
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
