@@ -42,17 +42,22 @@ size_t vqs_qwen_packed_bytes(const vqs_qwen_handle* h);
 int vqs_qwen_bind_weights(vqs_qwen_handle* h, const vqs_weight_desc* descs, int32_t n, void* d_packed, size_t packed_bytes,
                           void* stream);
 
-/* Vision tower over N patches (all videos/images of the call, HF processor order).
+/* Vision tower over N patches of videos/images that share one (t, h, w) grid (HF processor order).  Window blocks run on
+ * a WINDOWED layout of Np >= N rows in which every attention window owns win_len slots (partial windows at the right /
+ * bottom edge are padded); the full-attention blocks run on the original (frame-contiguous) order.
  *   d_patches    bf16 [N, v_patch_dim]           flattened 2 x 14 x 14 x 3 receptive fields
- *   d_row_map    int32 [N]                       windowed position -> source patch row (window_index expanded x merge_unit)
- *   d_cell_inv   int32 [N / merge_unit]          original merged-cell position -> windowed cell position
- *   d_cos/d_sin  fp32 [N, head_dim/2]            2-D rotary tables in WINDOWED order
- *   win_len      patches per attention window (every window full), frame_len patches per frame (full-attention blocks)
+ *   d_row_map    int32 [Np]                      windowed slot -> source patch row, -1 = padding slot
+ *   d_inv_row    int32 [N]                       patch row -> its windowed slot
+ *   d_win_valid  int32 [Np / win_len]            real patches per window (they fill the window's first slots)
+ *   d_cell_inv   int32 [N / merge_unit]          original merged cell -> windowed cell slot
+ *   d_cos_w/d_sin_w  fp32 [Np, head_dim/2]       2-D rotary tables in windowed order;  d_cos_f/d_sin_f [N, ...] original order
+ *   frame_len    patches per frame (h * w)
  *   d_merged     bf16 [N / merge_unit, v_out_hidden]   out, ORIGINAL cell order */
-size_t vqs_qwen_vision_workspace_bytes(const vqs_qwen_handle* h, int32_t N);
-int vqs_qwen_encode_vision(vqs_qwen_handle* h, const void* d_patches, const int32_t* d_row_map, const int32_t* d_cell_inv,
-                           const float* d_cos, const float* d_sin, int32_t N, int32_t win_len, int32_t frame_len,
-                           void* d_merged, void* d_ws, size_t ws_bytes, void* stream);
+size_t vqs_qwen_vision_workspace_bytes(const vqs_qwen_handle* h, int32_t N, int32_t Np);
+int vqs_qwen_encode_vision(vqs_qwen_handle* h, const void* d_patches, int32_t N, const int32_t* d_row_map,
+                           const int32_t* d_inv_row, const int32_t* d_win_valid, const int32_t* d_cell_inv, const float* d_cos_w,
+                           const float* d_sin_w, const float* d_cos_f, const float* d_sin_f, int32_t Np, int32_t win_len,
+                           int32_t frame_len, void* d_merged, void* d_ws, size_t ws_bytes, void* stream);
 
 /* Language-model prefill + last-position logits.
  *   d_input_ids  int32 [B, L] right-padded          d_vis_slot int32 [B, L]: row of d_merged for placeholder tokens, else -1

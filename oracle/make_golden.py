@@ -255,7 +255,7 @@ def build_hf_qwen(cfg, weights):
     return m
 
 
-def golden_qwen(name: str, seed: int, grids, text_lens, gain: float):
+def golden_qwen(name: str, seed: int, grids, text_lens, gain: float, tag: str = ""):
     """One batch of video samples through HF Qwen2.5-VL (fp32 modules, bf16-rounded seeded weights): per sample a
     prompt [text | <vision_start> <video_pad>*n <vision_end> | text], run one by one exactly as the reference does
     (qwen2vl_model.py:190-230: batch 1, generate(max_new_tokens=1, output_scores=True)); stores the inputs, the merged
@@ -302,7 +302,7 @@ def golden_qwen(name: str, seed: int, grids, text_lens, gain: float):
         ids_pad[b, : len(r)] = r
         mask[b, : len(r)] = 1
         pos_pad[:, b, : len(r)] = pos_all[b]
-    path = os.path.join(GOLDEN, f"qwen_{name.split('-')[-1]}.npz")
+    path = os.path.join(GOLDEN, f"qwen_{name.split('-')[-1]}{tag}.npz")
     np.savez_compressed(path, seed=seed, gain=gain, grids=np.asarray(grids), input_ids=ids_pad.numpy(), attention_mask=mask.numpy(),
                         pixel_values=torch.cat(pix).numpy(), merged=torch.cat(merged_all).numpy(), position_ids=pos_pad.numpy(),
                         logits=torch.stack(logits_all).numpy())
@@ -341,3 +341,4 @@ if __name__ == "__main__":
     golden_generate("small", seed=42, n_img=2, B=4, L=20, max_new=5, gain=8.0)
     golden_qwen("qwen-tiny", seed=51, grids=[(2, 8, 8), (1, 4, 12), (3, 12, 8)], text_lens=[(3, 4), (5, 2), (2, 6)], gain=4.0)
     golden_qwen("qwen-small", seed=52, grids=[(2, 8, 16), (2, 16, 8)], text_lens=[(4, 5), (3, 7)], gain=4.0)
+    golden_qwen("qwen-tiny", seed=53, grids=[(2, 6, 10), (1, 10, 6), (2, 6, 10)], text_lens=[(3, 4), (5, 2), (2, 3)], gain=4.0, tag="_ragged")

@@ -720,9 +720,10 @@ hipError_t launch_gather_cols_bf16(const bf16_t* src, const int* cmap, bf16_t* d
 __global__ void __launch_bounds__(256) gather_rows_f32_kernel(const float* __restrict__ src, const int* __restrict__ map,
                                                               float* __restrict__ dst, int D) {
     const int r = blockIdx.x;
-    const float4* s = reinterpret_cast<const float4*>(src + (size_t)map[r] * D);
+    const int m = map[r];                                     // -1: zero row (padding slot of a partial window)
+    const float4* s = reinterpret_cast<const float4*>(src + (size_t)max(m, 0) * D);
     float4* d = reinterpret_cast<float4*>(dst + (size_t)r * D);
-    for (int i = threadIdx.x; i < (D >> 2); i += 256) d[i] = s[i];
+    for (int i = threadIdx.x; i < (D >> 2); i += 256) d[i] = m >= 0 ? s[i] : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 hipError_t launch_gather_rows_f32(const float* src, const int* map, float* dst, int rows, int D, hipStream_t s) {
     if (D % 4) return hipErrorInvalidValue;

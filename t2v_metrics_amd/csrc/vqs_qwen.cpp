@@ -228,27 +228,30 @@ int pack(vqs_qwen_handle* h, char* base, size_t* total, hipStream_t st) {
 }
 
 struct VisWs {
-    bf16_t *patches, *xn, *delta, *q, *k, *v, *attn, *ff, *mid, *merged_w;
+    bf16_t *patches, *xn, *delta, *q, *k, *v, *attn, *ff, *mid, *merged_w, *xc, *dc;
     float *pre, *hidden;
     size_t total;
 };
-VisWs carve_vision(const vqs_qwen_handle* h, char* base, int N) {
+// N real patches, Np >= N rows of the windowed layout (partial windows padded to win_len slots)
+VisWs carve_vision(const vqs_qwen_handle* h, char* base, int N, int Np) {
     const vqs_qwen_config& c = h->c;
     Carver cv{base};
     VisWs w{};
-    const size_t n = (size_t)N, VPK = (size_t)c.v_heads * HDP;
+    const size_t n = (size_t)N, np = (size_t)Np, VPK = (size_t)c.v_heads * HDP;
     w.patches = cv.take<bf16_t>(n * h->v_kpatch);
     w.pre = cv.take<float>(n * c.v_hidden);
-    w.hidden = cv.take<float>(n * c.v_hidden);
-    w.xn = cv.take<bf16_t>(n * c.v_hidden);
-    w.delta = cv.take<bf16_t>(n * c.v_hidden);
-    w.q = cv.take<bf16_t>(n * VPK);
-    w.k = cv.take<bf16_t>(n * VPK);
-    w.v = cv.take<bf16_t>(n * VPK);
-    w.attn = cv.take<bf16_t>(n * VPK);
-    w.ff = cv.take<bf16_t>(n * h->v_ffld);
-    w.mid = cv.take<bf16_t>(n / c.v_merge_unit * h->merge_hidden);
-    w.merged_w = cv.take<bf16_t>(n / c.v_merge_unit * c.v_out_hidden);
+    w.hidden = cv.take<float>(np * c.v_hidden);
+    w.xn = cv.take<bf16_t>(np * c.v_hidden);
+    w.delta = cv.take<bf16_t>(np * c.v_hidden);
+    w.q = cv.take<bf16_t>(np * VPK);
+    w.k = cv.take<bf16_t>(np * VPK);
+    w.v = cv.take<bf16_t>(np * VPK);
+    w.attn = cv.take<bf16_t>(np * VPK);
+    w.ff = cv.take<bf16_t>(np * h->v_ffld);
+    w.xc = cv.take<bf16_t>(n * c.v_hidden);        // frame-compact copies around the full-attention blocks
+    w.dc = cv.take<bf16_t>(n * c.v_hidden);
+    w.mid = cv.take<bf16_t>(np / c.v_merge_unit * h->merge_hidden);
+    w.merged_w = cv.take<bf16_t>(np / c.v_merge_unit * c.v_out_hidden);
     w.total = align_up(cv.off);
     return w;
 }
@@ -362,35 +365,40 @@ int vqs_qwen_bind_weights(vqs_qwen_handle* h, const vqs_weight_desc* descs, int3
     return VQS_OK;
 }
 
-size_t vqs_qwen_vision_workspace_bytes(const vqs_qwen_handle* h, int32_t N) {
-    if (!h || N <= 0 || N % h->c.v_merge_unit) return 0;
-    return carve_vision(h, nullptr, N).total;
+size_t vqs_qwen_vision_workspace_bytes(const vqs_qwen_handle* h, int32_t N, int32_t Np) {
+    if (!h || N <= 0 || Np < N || N % h->c.v_merge_unit || Np % h->c.v_merge_unit) return 0;
+    return carve_vision(h, nullptr, N, Np).total;
 }
 
-int vqs_qwen_encode_vision(vqs_qwen_handle* h, const void* d_patches, const int32_t* d_row_map, const int32_t* d_cell_inv,
-                           const float* d_cos, const float* d_sin, int32_t N, int32_t win_len, int32_t frame_len,
-                           void* d_merged, void* d_ws, size_t ws_bytes, void* stream) {
+int vqs_qwen_encode_vision(vqs_qwen_handle* h, const void* d_patches, int32_t N, const int32_t* d_row_map,
+                           const int32_t* d_inv_row, const int32_t* d_win_valid, const int32_t* d_cell_inv, const float* d_cos_w,
+                           const float* d_sin_w, const float* d_cos_f, const float* d_sin_f, int32_t Np, int32_t win_len,
+                           int32_t frame_len, void* d_merged, void* d_ws, size_t ws_bytes, void* stream) {
     if (!h) return VQS_ERR_INVALID;
     if (!h->bound) return qfail(h, VQS_ERR_STATE, "encode_vision: weights not bound");
-    if (!d_patches || !d_row_map || !d_cell_inv || !d_cos || !d_sin || !d_merged || !d_ws) return qfail(h, VQS_ERR_INVALID, "encode_vision: null argument");
+    if (!d_patches || !d_row_map || !d_inv_row || !d_win_valid || !d_cell_inv || !d_cos_w || !d_sin_w || !d_cos_f || !d_sin_f ||
+        !d_merged || !d_ws)
+        return qfail(h, VQS_ERR_INVALID, "encode_vision: null argument");
     const vqs_qwen_config& c = h->c;
-    if (N <= 0 || N % c.v_merge_unit || win_len <= 0 || frame_len <= 0 || N % win_len || N % frame_len)
-        return qfail(h, VQS_ERR_INVALID, "encode_vision: N must be a multiple of merge_unit, win_len and frame_len (every window full)");
-    const VisWs w = carve_vision(h, (char*)d_ws, N);
+    if (N <= 0 || Np < N || N % c.v_merge_unit || win_len <= 0 || frame_len <= 0 || Np % win_len || N % frame_len ||
+        win_len % c.v_merge_unit)
+        return qfail(h, VQS_ERR_INVALID, "encode_vision: need N % merge_unit == 0, Np % win_len == 0, N % frame_len == 0");
+    const VisWs w = carve_vision(h, (char*)d_ws, N, Np);
     if (ws_bytes < w.total) return qfail(h, VQS_ERR_WORKSPACE, "encode_vision: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     const int VH = c.v_hidden, VNH = c.v_heads, VPK = VNH * HDP, NC = N / c.v_merge_unit;
     const float scale = 1.0f / sqrtf((float)h->v_hd);
 
-    // patch embed = matmul over the flattened receptive field (K padded to 64), then the window permutation
+    // patch embed = matmul over the flattened receptive field (K padded to 64), then the window permutation into the
+    // padded windowed layout (slots of partial windows are zero rows)
     QHIP(h, vqs::launch_gather_rows_bf16((const bf16_t*)d_patches, nullptr, nullptr, w.patches, N, c.v_patch_dim, c.v_patch_dim, h->v_kpatch, st), "pad patches");
     {
         GCall g{w.patches, h->patch_w, w.pre};
         g.M = N; g.N = VH; g.K = h->v_kpatch; g.lda = h->v_kpatch; g.ldw = h->v_kpatch; g.ldc = VH; g.epi = vqs::EPI_F32;
         QRUN(qgemm(h, g, st, "patch embed"));
     }
-    QHIP(h, vqs::launch_gather_rows_f32(w.pre, d_row_map, w.hidden, N, VH, st), "window permutation");
-    QHIP(h, hipMemsetAsync(w.ff, 0, (size_t)N * h->v_ffld * sizeof(bf16_t), st), "clear ff padding");
+    QHIP(h, vqs::launch_gather_rows_f32(w.pre, d_row_map, w.hidden, Np, VH, st), "window permutation");
+    QHIP(h, hipMemsetAsync(w.ff, 0, (size_t)Np * h->v_ffld * sizeof(bf16_t), st), "clear ff padding");
 
     const bf16_t* pend = nullptr;
     for (int i = 0; i < c.v_depth; ++i) {
@@ -399,64 +407,75 @@ int vqs_qwen_encode_vision(vqs_qwen_handle* h, const void* d_patches, const int3
         QW(n2, p + "norm2.weight", VH);
         QW(pb, p + "attn.proj.bias", VH);
         QW(db, p + "mlp.down_proj.bias", VH);
-        const int S = ((c.v_fullatt_mask >> i) & 1) ? frame_len : win_len;
-        const int Bseg = N / S;
-        QHIP(h, vqs::launch_rmsnorm(w.hidden, pend, n1, w.xn, N, VH, c.v_eps, st), "vision norm1");
+        const bool full = ((c.v_fullatt_mask >> i) & 1) != 0;
+        QHIP(h, vqs::launch_rmsnorm(w.hidden, pend, n1, w.xn, Np, VH, c.v_eps, st), "vision norm1");
+        // window blocks run on the padded windowed layout (every window = win_len slots, d_win_valid of them real);
+        // full-attention blocks on a frame-compact copy (original patch order), scattered back afterwards
+        const bf16_t* xin = w.xn;
+        int rows = Np, S = win_len;
+        if (full) {
+            QHIP(h, vqs::launch_gather_rows_bf16(w.xn, nullptr, d_inv_row, w.xc, N, VH, VH, VH, st), "compact frame rows");
+            xin = w.xc; rows = N; S = frame_len;
+        }
+        const int Bseg = rows / S;
         {
-            GCall g{w.xn, h->v_qkv_w[i], nullptr};
+            GCall g{xin, h->v_qkv_w[i], nullptr};
             g.bias = h->v_qkv_b[i];
-            g.M = N; g.N = 3 * VPK; g.K = VH; g.lda = VH; g.ldw = VH; g.epi = vqs::EPI_HEADS;
+            g.M = rows; g.N = 3 * VPK; g.K = VH; g.lda = VH; g.ldw = VH; g.epi = vqs::EPI_HEADS;
             g.S = S; g.H = VNH; g.inner = VPK; g.hd = HDP;
             g.heads[0] = w.q; g.heads[1] = w.k; g.heads[2] = w.v;
             QRUN(qgemm(h, g, st, "vision qkv"));
         }
-        QHIP(h, vqs::launch_rope(w.q, d_cos, d_sin, Bseg, VNH, S, HDP, h->v_hd / 2, st), "vision rope q");
-        QHIP(h, vqs::launch_rope(w.k, d_cos, d_sin, Bseg, VNH, S, HDP, h->v_hd / 2, st), "vision rope k");
+        QHIP(h, vqs::launch_rope(w.q, full ? d_cos_f : d_cos_w, full ? d_sin_f : d_sin_w, Bseg, VNH, S, HDP, h->v_hd / 2, st), "vision rope q");
+        QHIP(h, vqs::launch_rope(w.k, full ? d_cos_f : d_cos_w, full ? d_sin_f : d_sin_w, Bseg, VNH, S, HDP, h->v_hd / 2, st), "vision rope k");
         {
-            vqs::AttnParams a{w.q, w.k, w.v, w.attn, nullptr, nullptr, Bseg, VNH, S, scale};
+            vqs::AttnParams a{w.q, w.k, w.v, w.attn, nullptr, full ? nullptr : d_win_valid, Bseg, VNH, S, scale};
             a.hd = HDP;
             QHIP(h, vqs::launch_attention(a, st), "vision attention");
         }
         {
-            GCall g{w.attn, h->v_proj_w[i], w.delta};
+            GCall g{w.attn, h->v_proj_w[i], full ? (void*)w.dc : (void*)w.delta};
             g.bias = pb;
-            g.M = N; g.N = VH; g.K = VPK; g.lda = VPK; g.ldw = VPK; g.ldc = VH; g.epi = vqs::EPI_BF16;
+            g.M = rows; g.N = VH; g.K = VPK; g.lda = VPK; g.ldw = VPK; g.ldc = VH; g.epi = vqs::EPI_BF16;
             QRUN(qgemm(h, g, st, "vision proj"));
         }
-        QHIP(h, vqs::launch_rmsnorm(w.hidden, w.delta, n2, w.xn, N, VH, c.v_eps, st), "vision norm2");
+        if (full)
+            QHIP(h, vqs::launch_gather_rows_bf16(w.dc, nullptr, d_row_map, w.delta, Np, VH, VH, VH, st), "scatter frame rows back");
+        QHIP(h, vqs::launch_rmsnorm(w.hidden, w.delta, n2, w.xn, Np, VH, c.v_eps, st), "vision norm2");
         {
             GCall g{w.xn, h->v_gu_w[i], w.ff};
             g.bias = h->v_gu_b[i];
-            g.M = N; g.N = 2 * h->v_mlp_p; g.K = VH; g.lda = VH; g.ldw = VH; g.ldc = h->v_ffld; g.epi = vqs::EPI_GATED; g.gate_act = 1;
+            g.M = Np; g.N = 2 * h->v_mlp_p; g.K = VH; g.lda = VH; g.ldw = VH; g.ldc = h->v_ffld; g.epi = vqs::EPI_GATED; g.gate_act = 1;
             QRUN(qgemm(h, g, st, "vision gate|up"));
         }
         {
             GCall g{w.ff, h->v_down_w[i], w.delta};
             g.bias = db;
-            g.M = N; g.N = VH; g.K = h->v_ffld; g.lda = h->v_ffld; g.ldw = h->v_ffld; g.ldc = VH; g.epi = vqs::EPI_BF16;
+            g.M = Np; g.N = VH; g.K = h->v_ffld; g.lda = h->v_ffld; g.ldw = h->v_ffld; g.ldc = VH; g.epi = vqs::EPI_BF16;
             QRUN(qgemm(h, g, st, "vision down"));
             pend = w.delta;
         }
     }
-    // merger: RMSNorm, 4 neighbouring patches (consecutive rows in windowed order) concatenated, Linear-GELU-Linear, undo
-    // the window permutation
+    // merger: RMSNorm, the 4 patches of a cell (consecutive rows in the windowed layout) concatenated, Linear-GELU-Linear,
+    // then original cell order (padding cells are simply never gathered)
     QW(lnq, "model.visual.merger.ln_q.weight", VH);
     QW(m0w, "model.visual.merger.mlp.0.weight", (int64_t)h->merge_hidden * h->merge_hidden);
     QW(m0b, "model.visual.merger.mlp.0.bias", h->merge_hidden);
     QW(m2w, "model.visual.merger.mlp.2.weight", (int64_t)c.v_out_hidden * h->merge_hidden);
     QW(m2b, "model.visual.merger.mlp.2.bias", c.v_out_hidden);
-    QHIP(h, vqs::launch_rmsnorm(w.hidden, pend, lnq, w.xn, N, VH, 1e-6f, st), "merger norm");
+    const int NCp = Np / c.v_merge_unit;
+    QHIP(h, vqs::launch_rmsnorm(w.hidden, pend, lnq, w.xn, Np, VH, 1e-6f, st), "merger norm");
     {
         GCall g{w.xn, m0w, w.mid};
         g.bias = m0b;
-        g.M = NC; g.N = h->merge_hidden; g.K = h->merge_hidden; g.lda = h->merge_hidden; g.ldw = h->merge_hidden; g.ldc = h->merge_hidden;
+        g.M = NCp; g.N = h->merge_hidden; g.K = h->merge_hidden; g.lda = h->merge_hidden; g.ldw = h->merge_hidden; g.ldc = h->merge_hidden;
         g.epi = vqs::EPI_BF16_GELU;
         QRUN(qgemm(h, g, st, "merger mlp.0"));
     }
     {
         GCall g{w.mid, m2w, w.merged_w};
         g.bias = m2b;
-        g.M = NC; g.N = c.v_out_hidden; g.K = h->merge_hidden; g.lda = h->merge_hidden; g.ldw = h->merge_hidden; g.ldc = c.v_out_hidden;
+        g.M = NCp; g.N = c.v_out_hidden; g.K = h->merge_hidden; g.lda = h->merge_hidden; g.ldw = h->merge_hidden; g.ldc = c.v_out_hidden;
         g.epi = vqs::EPI_BF16;
         QRUN(qgemm(h, g, st, "merger mlp.2"));
     }

@@ -8,8 +8,8 @@ libvqs_hip (include/vqs_qwen.h), frame resizing / patch flattening are restated 
 ``qwen_vl_utils`` + the HF processor (neither is installable offline).
 
 Input support: ``.npy`` arrays ([H,W,3] image or [T,H,W,3] frames, as qwen2vl_model.py:145-155) and image files; video
-container files need decord/ffmpeg (absent) -> NotImplementedError.  The HIP vision tower requires every attention
-window to be full: the resized frame must be a multiple of 112 px on both sides (true for 336 x 448, BASELINE config 5).
+container files need decord/ffmpeg (absent) -> NotImplementedError.  Any frame size smart_resize produces is accepted
+(partial attention windows at the frame edge are handled by the engine's padded windowed layout).
 """
 from __future__ import annotations
 
@@ -159,10 +159,6 @@ class Qwen25VLModel(VQAScoreModel):
             rh, rw = smart_resize(H, W, factor=factor)
         if (rh, rw) != (H, W):
             frames = np.stack([np.asarray(Image.fromarray(f).resize((rw, rh), Image.BICUBIC)) for f in frames])
-        win = v.window
-        if rh % win or rw % win:
-            raise NotImplementedError(f"resized frame {rh}x{rw} is not a multiple of the {win}-px attention window; the HIP vision "
-                                      "tower handles full windows only (e.g. 336x448)")
         x = torch.from_numpy(np.ascontiguousarray(frames)).permute(0, 3, 1, 2).to(torch.float32) * (1.0 / 255.0)
         mean = torch.tensor(OPENAI_CLIP_MEAN).view(1, 3, 1, 1)
         std = torch.tensor(OPENAI_CLIP_STD).view(1, 3, 1, 1)

@@ -26,8 +26,8 @@ _SIGS = {
     "vqs_qwen_last_error": (ctypes.c_char_p, [_vp]),
     "vqs_qwen_packed_bytes": (_sz, [_vp]),
     "vqs_qwen_bind_weights": (_i32, [_vp, ctypes.POINTER(VqsWeightDesc), _i32, _vp, _sz, _vp]),
-    "vqs_qwen_vision_workspace_bytes": (_sz, [_vp, _i32]),
-    "vqs_qwen_encode_vision": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
+    "vqs_qwen_vision_workspace_bytes": (_sz, [_vp, _i32, _i32]),
+    "vqs_qwen_encode_vision": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
     "vqs_qwen_score_workspace_bytes": (_sz, [_vp, _i32, _i32]),
     "vqs_qwen_score": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _sz, _vp]),
 }
@@ -81,14 +81,17 @@ class QwenEngine:
         with torch.cuda.device(self.device):
             dev = self.device
             px = patches.to(dev, torch.bfloat16).contiguous()
-            N = px.shape[0]
-            rm, ci = lay["row_map"].to(dev), lay["cell_inv"].to(dev)
-            cs, sn = lay["cos"].to(dev), lay["sin"].to(dev)
+            N, Np = lay["N"], lay["Np"]
+            if px.shape[0] != N:
+                raise VqsError(f"{px.shape[0]} patch rows for grids that hold {N}")
+            d = {k: lay[k].to(dev) for k in ("row_map", "inv_row", "win_valid", "cell_inv", "cos_w", "sin_w", "cos_f", "sin_f")}
             out = torch.empty(N // self.cfg.vision.merge_unit, self.cfg.vision.out_hidden, dtype=torch.bfloat16, device=dev)
-            ws = self._workspace(self.lib.vqs_qwen_vision_workspace_bytes(self._h, N))
-            self._check(self.lib.vqs_qwen_encode_vision(self._h, px.data_ptr(), rm.data_ptr(), ci.data_ptr(), cs.data_ptr(),
-                                                        sn.data_ptr(), N, lay["win_len"], lay["frame_len"], out.data_ptr(),
-                                                        ws.data_ptr(), ws.numel(), _stream_ptr()), "vqs_qwen_encode_vision")
+            ws = self._workspace(self.lib.vqs_qwen_vision_workspace_bytes(self._h, N, Np))
+            self._check(self.lib.vqs_qwen_encode_vision(self._h, px.data_ptr(), N, d["row_map"].data_ptr(), d["inv_row"].data_ptr(),
+                                                        d["win_valid"].data_ptr(), d["cell_inv"].data_ptr(), d["cos_w"].data_ptr(),
+                                                        d["sin_w"].data_ptr(), d["cos_f"].data_ptr(), d["sin_f"].data_ptr(), Np,
+                                                        lay["win_len"], lay["frame_len"], out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                        _stream_ptr()), "vqs_qwen_encode_vision")
             return out
 
     def score_logits(self, merged: torch.Tensor, input_ids: torch.Tensor, attention_mask: torch.Tensor,

@@ -1,8 +1,8 @@
 """Integer layout work of the Qwen2.5-VL path that stays on the host (as in the reference, where the HF processor and
 ``get_rope_index`` run on the CPU): window permutation of the vision tower, rotary tables, placeholder slots.
 Implements what HF computes in vision_utils.py:81-188 and modeling_qwen2_5_vl.py:892-1061 for the input class the HIP
-path supports: every video of a call has the same (t, h, w) grid and its merged grid is a multiple of the window
-(every attention window full -- true for BASELINE.json configs[4]: 336 x 448 frames)."""
+path supports: every video of one vision call has the same (t, h, w) grid (the wrapper groups samples by grid); partial
+attention windows at the right / bottom edge of a frame are handled by a padded windowed layout."""
 from __future__ import annotations
 
 from typing import Dict, List, Sequence, Tuple
@@ -12,29 +12,45 @@ import torch
 from .config import Qwen25VLConfig
 
 
-def window_cells(t: int, h: int, w: int, merge: int, window: int, patch: int) -> torch.Tensor:
-    """Merged-cell order that makes windows contiguous: long [t * (h/merge) * (w/merge)]."""
+def window_slots(t: int, h: int, w: int, merge: int, window: int, patch: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Windowed, padded cell layout of ONE video: (slots long [n_windows * ws*ws] = original cell index or -1,
+    valid_cells long [n_windows]).  Windows ordered (t, window row, window column), the cells of a window row-major with
+    the present ones first -- the order HF's get_vision_window_index produces (vision_utils.py:130-188) once its padding
+    entries are dropped; partial windows at the right / bottom edge keep their empty slots here."""
     gh, gw, ws = h // merge, w // merge, window // merge // patch
-    if gh % ws or gw % ws:
-        raise ValueError(f"grid {gh}x{gw} merged cells is not a multiple of the {ws}x{ws}-cell attention window")
-    idx = torch.arange(t * gh * gw).reshape(t, gh // ws, ws, gw // ws, ws)
-    return idx.permute(0, 1, 3, 2, 4).reshape(-1)
+    nh, nw = -(-gh // ws), -(-gw // ws)
+    index = torch.arange(t * gh * gw).reshape(t, gh, gw)
+    padded = torch.nn.functional.pad(index, (0, nw * ws - gw, 0, nh * ws - gh), value=-1)
+    win = padded.reshape(t, nh, ws, nw, ws).permute(0, 1, 3, 2, 4).reshape(t * nh * nw, ws * ws)
+    valid = (win >= 0).sum(-1)
+    # present cells first inside every window (stable: keeps row-major order)
+    order = torch.argsort((win < 0).to(torch.int8), dim=-1, stable=True)
+    win = torch.gather(win, 1, order)
+    keep = valid > 0
+    return win[keep].reshape(-1), valid[keep]
 
 
 def vision_layout(cfg: Qwen25VLConfig, grids: Sequence[Tuple[int, int, int]]) -> Dict[str, torch.Tensor]:
-    """For the videos of one call (same grid each): row_map int32 [N] (windowed position -> source patch row),
-    cell_inv int32 [N/4] (original cell -> windowed cell), cos/sin fp32 [N, head_dim/2] in windowed order,
-    win_len, frame_len."""
+    """Arrays vqs_qwen_encode_vision needs for the videos of one call (same grid each); see include/vqs_qwen.h."""
     v = cfg.vision
     if len(set(tuple(g) for g in grids)) != 1:
         raise ValueError("all videos of a call must share one (t, h, w) grid")
     t, h, w = grids[0]
     unit = v.merge_unit
     cells_per = t * (h // v.spatial_merge) * (w // v.spatial_merge)
-    wc = window_cells(t, h, w, v.spatial_merge, v.window, v.patch)
-    cell_order = torch.cat([wc + i * cells_per for i in range(len(grids))])          # windowed cell -> original cell
-    row_map = (cell_order[:, None] * unit + torch.arange(unit)[None, :]).reshape(-1)
-    cell_inv = torch.argsort(cell_order)
+    slots1, valid1 = window_slots(t, h, w, v.spatial_merge, v.window, v.patch)
+    ws = v.window // v.spatial_merge // v.patch
+    slots = torch.cat([torch.where(slots1 >= 0, slots1 + i * cells_per, slots1) for i in range(len(grids))])   # [n_win * ws*ws]
+    valid = valid1.repeat(len(grids))
+    row_map = torch.where(slots[:, None] >= 0, slots[:, None] * unit + torch.arange(unit)[None, :], torch.full((1, unit), -1)).reshape(-1)
+    N = cells_per * len(grids) * unit
+    Np = row_map.numel()
+    real = row_map >= 0
+    inv_row = torch.empty(N, dtype=torch.long)
+    inv_row[row_map[real]] = torch.nonzero(real)[:, 0]
+    cell_inv = torch.empty(N // unit, dtype=torch.long)
+    cell_real = slots >= 0
+    cell_inv[slots[cell_real]] = torch.nonzero(cell_real)[:, 0]
     # 2-D rotary angles per ORIGINAL patch row (block-major over merge x merge, repeated per temporal patch)
     hp, wp = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
     shape = (h // v.spatial_merge, v.spatial_merge, w // v.spatial_merge, v.spatial_merge)
@@ -42,11 +58,12 @@ def vision_layout(cfg: Qwen25VLConfig, grids: Sequence[Tuple[int, int, int]]) ->
     wp = wp.reshape(shape).transpose(1, 2).flatten().repeat(t)
     dim = v.head_dim // 2
     inv_freq = 1.0 / (10000.0 ** (torch.arange(0, dim, 2, dtype=torch.float32) / dim))
-    ang = torch.cat([hp[:, None].float() * inv_freq, wp[:, None].float() * inv_freq], dim=1)   # [t*h*w, head_dim/2]
-    ang = ang.repeat(len(grids), 1)[row_map]
-    ws = v.window // v.spatial_merge // v.patch
-    return {"row_map": row_map.to(torch.int32), "cell_inv": cell_inv.to(torch.int32), "cos": ang.cos().contiguous(),
-            "sin": ang.sin().contiguous(), "win_len": ws * ws * unit, "frame_len": h * w}
+    ang_f = torch.cat([hp[:, None].float() * inv_freq, wp[:, None].float() * inv_freq], dim=1).repeat(len(grids), 1)   # [N, hd/2]
+    ang_w = torch.where(real[:, None], ang_f[row_map.clamp(min=0)], torch.zeros(1, ang_f.shape[1]))
+    return {"row_map": row_map.to(torch.int32), "inv_row": inv_row.to(torch.int32), "win_valid": (valid * unit).to(torch.int32),
+            "cell_inv": cell_inv.to(torch.int32), "cos_w": ang_w.cos().contiguous(), "sin_w": ang_w.sin().contiguous(),
+            "cos_f": ang_f.cos().contiguous(), "sin_f": ang_f.sin().contiguous(), "N": N, "Np": Np,
+            "win_len": ws * ws * unit, "frame_len": h * w}
 
 
 def text_layout(cfg: Qwen25VLConfig, input_ids: torch.Tensor, attention_mask: torch.Tensor,

@@ -16,11 +16,11 @@ pytestmark = pytest.mark.gpu
 LOGPROB_TOL_BF16 = 2.5e-2
 
 
-@pytest.mark.parametrize("name", ["qwen-tiny", "qwen-small"])
-def test_qwen_path_matches_hf_fixture(golden_dir, name):
+@pytest.mark.parametrize("name,fixture", [("qwen-tiny", "qwen_tiny"), ("qwen-small", "qwen_small"), ("qwen-tiny", "qwen_tiny_ragged")])
+def test_qwen_path_matches_hf_fixture(golden_dir, name, fixture):
     from oracle.qwen25vl_oracle import QwenOracle
     from t2v_metrics_amd.qwen.engine import QwenEngine
-    z = np.load(os.path.join(golden_dir, f"qwen_{name.split('-')[-1]}.npz"))
+    z = np.load(os.path.join(golden_dir, fixture + ".npz"))     # "_ragged": grids with partial attention windows
     cfg = get_qwen_config(name)
     w = make_seeded_qwen_weights(cfg, seed=int(z["seed"]), dtype=torch.bfloat16, lm_head_gain=float(z["gain"]))
     eng = QwenEngine(cfg, w)

@@ -103,9 +103,8 @@ def test_forward_recipe_batching_and_errors(tmp_path):
     assert grid_scores.shape == (2, 2)
     with pytest.raises(NotImplementedError):
         scorer.model.forward(["clip.mp4"], ["x"])
-    bad = tmp_path / "odd.npy"
-    np.save(bad, rng.randint(0, 256, (2, 84, 112, 3), dtype=np.uint8))
-    with pytest.raises(NotImplementedError, match="attention window"):
-        scorer.model.forward([str(bad)], ["x"])
+    odd = tmp_path / "odd.npy"                      # 84 x 140 px: 3 x 5 merged cells, partial 2 x 2-cell windows at the edges
+    np.save(odd, rng.randint(0, 256, (2, 84, 140, 3), dtype=np.uint8))
+    assert scorer.model.forward([str(odd)], ["x"]).shape == (1,)
     with pytest.raises(AssertionError):
         scorer.model.forward(paths[:2], texts[:1])

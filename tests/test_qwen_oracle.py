@@ -11,9 +11,9 @@ from t2v_metrics_amd.qwen import get_qwen_config
 from t2v_metrics_amd.qwen.weights import make_seeded_qwen_weights, qwen_weight_specs
 
 
-@pytest.mark.parametrize("name", ["qwen-tiny", "qwen-small"])
-def test_oracle_matches_hf_fixture(golden_dir, name):
-    z = np.load(os.path.join(golden_dir, f"qwen_{name.split('-')[-1]}.npz"))
+@pytest.mark.parametrize("name,fixture", [("qwen-tiny", "qwen_tiny"), ("qwen-small", "qwen_small"), ("qwen-tiny", "qwen_tiny_ragged")])
+def test_oracle_matches_hf_fixture(golden_dir, name, fixture):
+    z = np.load(os.path.join(golden_dir, fixture + ".npz"))
     cfg = get_qwen_config(name)
     w = make_seeded_qwen_weights(cfg, seed=int(z["seed"]), dtype=torch.bfloat16, lm_head_gain=float(z["gain"]))
     o = QwenOracle(cfg, w)
@@ -61,9 +61,16 @@ def test_host_layout_matches_hf(golden_dir, name):
     assert torch.equal(lay["position_ids"] * mask[None], torch.from_numpy(z["position_ids"]) * mask[None])
     assert lay["vis_slot"].max().item() + 1 == sum(t * h * w for t, h, w in grids) // 4
     v = cfg.vision
-    for g in grids:
+    for g in list(grids) + [(2, 6, 10), (1, 10, 6), (3, 14, 18)]:            # the extra grids have partial windows
         vl = vision_layout(cfg, [g, g])
         widx, cu = vision_window_index([g, g], v.spatial_merge, v.window, v.patch)
-        assert torch.equal(vl["row_map"].long().view(-1, 4)[:, 0] // 4, widx)
-        assert all(b - a == vl["win_len"] for a, b in zip(cu[:-1], cu[1:]))
+        rm = vl["row_map"].long()
+        cells = rm.view(-1, 4)[:, 0]
+        assert torch.equal(cells[cells >= 0] // 4, widx)                      # HF's order once the padding slots are dropped
+        assert vl["win_valid"].tolist() == [b - a for a, b in zip(cu[:-1], cu[1:])]
+        assert torch.equal(rm[vl["inv_row"].long()], torch.arange(vl["N"]))
+        # inside every window the real slots come first
+        for wi, nv in enumerate(vl["win_valid"].tolist()):
+            blk = rm[wi * vl["win_len"]: (wi + 1) * vl["win_len"]]
+            assert bool((blk[:nv] >= 0).all()) and bool((blk[nv:] < 0).all())
 
