@@ -33,6 +33,12 @@ default_answer_template = 'Yes'
 OPENAI_CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
 OPENAI_CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
 VIDEO_MAX_PIXELS = 360 * 420                                                              # qwen2vl_model.py:142-144
+# qwen_vl_utils (not installable here) resizes BEFORE the HF processor (the reference then passes do_resize=False,
+# qwen2vl_model.py:208-216): its defaults are IMAGE_FACTOR = 28, MIN_PIXELS = 4*28*28, MAX_PIXELS = 16384*28*28
+# [RECALLED from qwen_vl_utils/vision_process.py]; frames given as a list go through the same per-image routine with the
+# message's max_pixels.
+QVU_MIN_PIXELS = 4 * 28 * 28
+QVU_MAX_PIXELS = 16384 * 28 * 28
 IMAGE_PLACEHOLDER, VIDEO_PLACEHOLDER = "<|image_pad|>", "<|video_pad|>"
 
 
@@ -154,9 +160,9 @@ class Qwen25VLModel(VQAScoreModel):
         H, W = frames.shape[1:3]
         factor = v.patch * v.spatial_merge
         if item['type'] == 'video':
-            rh, rw = smart_resize(H, W, factor=factor, max_pixels=VIDEO_MAX_PIXELS)
+            rh, rw = smart_resize(H, W, factor=factor, min_pixels=QVU_MIN_PIXELS, max_pixels=VIDEO_MAX_PIXELS)
         else:
-            rh, rw = smart_resize(H, W, factor=factor)
+            rh, rw = smart_resize(H, W, factor=factor, min_pixels=QVU_MIN_PIXELS, max_pixels=QVU_MAX_PIXELS)
         if (rh, rw) != (H, W):
             frames = np.stack([np.asarray(Image.fromarray(f).resize((rw, rh), Image.BICUBIC)) for f in frames])
         x = torch.from_numpy(np.ascontiguousarray(frames)).permute(0, 3, 1, 2).to(torch.float32) * (1.0 / 255.0)
