@@ -1,0 +1,86 @@
+"""GenAI-Bench evaluation driver: metrics against scipy / a brute-force restatement of the
+reference's pair loop, dataset wrapper and score cache on a synthetic on-disk dataset."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from t2v_metrics_amd.genai_bench import (GENAI_MODELS, GenAIBenchImage, calc_pearson, kendall_tau_b,
+                                         pairwise_acc_with_tie_optimization, run_genai_image_eval)
+
+
+def brute_force_acc23(gold, metric):
+    """tau_optimization.py:203-298 for one row, literally: flip pairs to metric ties in order of |difference|."""
+    n = len(gold)
+    pairs = [(abs(metric[i] - metric[j]), gold[i], gold[j], metric[i], metric[j]) for i in range(n) for j in range(i + 1, n)]
+
+    def correct(h1, h2, m1, m2, tie):
+        if tie or m1 == m2:
+            return h1 == h2
+        return h1 != h2 and ((h1 > h2) == (m1 > m2))
+
+    P = len(pairs)
+    thresholds = [0.0] + sorted(set(p[0] for p in pairs))
+    best, best_t = -1.0, None
+    for t in sorted(set(thresholds)):
+        acc = sum(correct(h1, h2, m1, m2, d <= t) for d, h1, h2, m1, m2 in pairs) / P
+        if acc > best:
+            best, best_t = acc, t
+    return best, best_t
+
+
+def test_metrics_match_scipy_and_the_reference_pair_loop():
+    import scipy.stats
+    rng = np.random.RandomState(0)
+    for n in (7, 40):
+        gold = rng.randint(1, 6, size=n).astype(float)                    # human ratings tie a lot
+        metric = np.round(rng.rand(n) + 0.15 * gold, 2)
+        assert abs(calc_pearson(gold, metric) - 100 * scipy.stats.pearsonr(gold, metric)[0]) < 1e-9
+        assert abs(kendall_tau_b(gold, metric) - scipy.stats.kendalltau(gold, metric, variant="b")[0]) < 1e-12
+        acc, thr = pairwise_acc_with_tie_optimization(gold, metric)
+        ref_acc, ref_thr = brute_force_acc23(gold.tolist(), metric.tolist())
+        assert abs(acc - ref_acc) < 1e-12 and abs(thr - ref_thr) < 1e-12
+    assert np.isnan(kendall_tau_b([1, 1, 1], [0.1, 0.2, 0.3]))
+    with pytest.raises(ValueError):
+        pairwise_acc_with_tie_optimization([1, 2], [1, 2], sample_rate=0.0)
+
+
+def _make_dataset(root, n_prompts=5):
+    d = os.path.join(root, "GenAI-Image-527")
+    os.makedirs(d)
+    rng = np.random.RandomState(1)
+    meta = {f"{i:05d}": {"prompt": f"prompt number {i}", "models": {m: rng.randint(1, 6, size=3).tolist() for m in GENAI_MODELS}}
+            for i in range(n_prompts)}
+    json.dump(meta, open(os.path.join(d, "genai_image.json"), "w"))
+    json.dump({"counting": [0, 1, 2], "spatial": [2, 3, 4]}, open(os.path.join(d, "genai_skills.json"), "w"))
+    return d
+
+
+class FakeScorer:
+    def __init__(self):
+        self.calls = 0
+
+    def batch_forward(self, dataset, batch_size=16, **kw):
+        self.calls += 1
+        g = torch.Generator().manual_seed(5)
+        return torch.rand(len(dataset), 1, 1, generator=g)
+
+
+def test_dataset_wrapper_and_cached_driver(tmp_path):
+    _make_dataset(str(tmp_path))
+    ds = GenAIBenchImage(root_dir=str(tmp_path), num_prompts=527)
+    assert len(ds) == 5 * len(GENAI_MODELS)
+    it = ds[7]
+    assert it["texts"] == ["prompt number 2"] and it["images"][0].endswith(os.path.join("SDXL_Turbo", "00002.jpeg"))
+    scorer = FakeScorer()
+    res = run_genai_image_eval(scorer, ds, str(tmp_path / "results"), "fake-model", num_prompts=527)
+    assert set(res["alignment"]) == {"pearson", "kendall_b", "pairwise_acc"} and set(res["per_skill"]) == {"counting", "spatial"}
+    assert os.path.exists(tmp_path / "results" / "fake-model_527_prompts.pt")
+    res2 = run_genai_image_eval(scorer, ds, str(tmp_path / "results"), "fake-model", num_prompts=527)
+    assert scorer.calls == 1 and res2["alignment"] == res["alignment"]                       # second run read the cache
+    with pytest.raises(FileNotFoundError):
+        GenAIBenchImage(root_dir=str(tmp_path / "nowhere"), num_prompts=1600)
+    with pytest.raises(RuntimeError, match="no network"):
+        GenAIBenchImage(root_dir=str(tmp_path / "nowhere"), num_prompts=1600, download=True)
