@@ -149,6 +149,13 @@ int vqs_gemm_rms(const void* d_A, const void* d_W, void* d_C, float* d_hres, con
                  int32_t lda, int32_t ldw, int32_t ldc, int32_t epilogue, int32_t S, int32_t H, int32_t variant, void* stream);
 int vqs_attention(const void* d_q, const void* d_k, const void* d_v, void* d_out, const float* d_bias_table,
                   const int32_t* d_key_len, int32_t B, int32_t H, int32_t S, float scale, void* stream);
+/* Input-pipeline tail: d_u8 uint8 [N,H,W,3] (host-decoded, padded, PIL-resized RGB) -> d_out bf16 [N,3,H,W] =
+ * ((x * 1/255) - mean[c]) / std[c] in fp32, rounded to bf16 -- HF CLIPImageProcessor rescale + normalize
+ * (models/clip/image_processing_clip.py:22-33) followed by the reference's .to(bfloat16) (mm_utils.py:228).
+ * mean3 / std3 are HOST pointers to 3 floats. */
+int vqs_normalize_u8(const void* d_u8, void* d_out, int32_t N, int32_t H, int32_t W, const float* mean3, const float* std3,
+                     void* stream);
+
 /* Rotary position embedding (rotate-half), in place on d_x bf16 [B,H,S,hd]; d_cos / d_sin fp32 [B*S, half] hold the per-token
  * angles' cos / sin for dims i < half (dim i pairs with i + half) -- HF models/qwen2_5_vl/modeling_qwen2_5_vl.py:153-172
  * (vision, 2-D) and :557-599 (multimodal sections).  Dims >= 2*half are left alone. */

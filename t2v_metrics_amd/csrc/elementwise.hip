@@ -748,4 +748,32 @@ hipError_t launch_qwen_embed(const int* ids, const int* vis_slot, const bf16_t* 
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Input pipeline tail on the device: uint8 [N, H, W, 3] (decoded, padded, resized on the host by
+// PIL exactly as the reference does) -> CLIP-normalised bf16 [N, 3, H, W].  Same fp32 arithmetic as the HF processor
+// (HF image_processing_backends rescale + normalize: x * (1/255), then (x - mean) / std), then the reference's
+// .to(bfloat16) (mm_utils.py:228).  Moves the per-pixel float work and 3/4 of the H2D bytes off the host.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) u8_to_norm_bf16_kernel(const unsigned char* __restrict__ in, bf16_t* __restrict__ out,
+                                                              int HW, float m0, float m1, float m2, float s0, float s1,
+                                                              float s2) {
+    const int n = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;           // pixel index inside the image
+    if (p >= HW) return;
+    const unsigned char* px = in + ((size_t)n * HW + p) * 3;
+    const float r = (float)px[0] * (1.0f / 255.0f), g = (float)px[1] * (1.0f / 255.0f), b = (float)px[2] * (1.0f / 255.0f);
+    bf16_t* o = out + (size_t)n * 3 * HW + p;
+    o[0] = e_f2bf((r - m0) / s0);
+    o[HW] = e_f2bf((g - m1) / s1);
+    o[2 * (size_t)HW] = e_f2bf((b - m2) / s2);
+}
+hipError_t launch_u8_to_norm_bf16(const unsigned char* in, bf16_t* out, int N, int H, int W, const float* mean3,
+                                  const float* std3, hipStream_t s) {
+    if (N <= 0 || H <= 0 || W <= 0) return hipErrorInvalidValue;
+    const int HW = H * W;
+    hipLaunchKernelGGL(u8_to_norm_bf16_kernel, dim3((HW + 255) / 256, N), dim3(256), 0, s, in, out, HW, mean3[0], mean3[1],
+                       mean3[2], std3[0], std3[1], std3[2]);
+    return hipGetLastError();
+}
+
 }  // namespace vqs

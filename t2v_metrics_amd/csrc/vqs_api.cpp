@@ -943,6 +943,13 @@ int vqs_attention(const void* q, const void* k, const void* v, void* out, const 
     return vqs::launch_attention(a, (hipStream_t)stream) == hipSuccess ? VQS_OK : VQS_ERR_HIP;
 }
 
+int vqs_normalize_u8(const void* d_u8, void* d_out, int32_t N, int32_t H, int32_t W, const float* mean3, const float* std3,
+                     void* stream) {
+    if (!d_u8 || !d_out || !mean3 || !std3) return VQS_ERR_INVALID;
+    return vqs::launch_u8_to_norm_bf16((const unsigned char*)d_u8, (bf16_t*)d_out, N, H, W, mean3, std3, (hipStream_t)stream) == hipSuccess
+               ? VQS_OK : VQS_ERR_HIP;
+}
+
 int vqs_rope(void* x, const float* cos_t, const float* sin_t, int32_t B, int32_t H, int32_t S, int32_t hd, int32_t half,
              void* stream) {
     return vqs::launch_rope((bf16_t*)x, cos_t, sin_t, B, H, S, hd, half, (hipStream_t)stream) == hipSuccess ? VQS_OK : VQS_ERR_HIP;

@@ -139,6 +139,8 @@ hipError_t launch_gather_cols_bf16(const bf16_t* src, const int* cmap, bf16_t* d
 hipError_t launch_gather_rows_f32(const float* src, const int* map, float* dst, int rows, int D, hipStream_t s);
 hipError_t launch_qwen_embed(const int* ids, const int* vis_slot, const bf16_t* embed, const bf16_t* merged, float* out, int rows,
                              int D, int vocab, hipStream_t s);
+hipError_t launch_u8_to_norm_bf16(const unsigned char* in, bf16_t* out, int N, int H, int W, const float* mean3,
+                                  const float* std3, hipStream_t s);
 hipError_t launch_interleave_gate(const bf16_t* wi0, const bf16_t* wi1, bf16_t* dst, int F, int D, hipStream_t s);
 
 }  // namespace vqs

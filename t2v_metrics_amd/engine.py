@@ -56,6 +56,7 @@ _SIGNATURES = {
     "vqs_profile_bytes": (_c_i32, [_c_vp, ctypes.POINTER(ctypes.c_double)]),
     "vqs_profile_report": (ctypes.c_char_p, [_c_vp]),
     "vqs_gemm": (_c_i32, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp] + [_c_i32] * 10 + [_c_vp]),
+    "vqs_normalize_u8": (_c_i32, [_c_vp, _c_vp, _c_i32, _c_i32, _c_i32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), _c_vp]),
     "vqs_rope": (_c_i32, [_c_vp, _c_vp, _c_vp, _c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_vp]),
     "vqs_attention_hd": (_c_i32, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_f32, _c_i32, _c_vp]),
     "vqs_gemm_rms": (_c_i32, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i32, _c_f32, _c_f32, _c_i32, _c_i32, _c_i32,
@@ -210,6 +211,10 @@ class VqsEngine:
             self._check(rc, "vqs_score")
             return lp, sc
 
+    def normalize_u8(self, x_u8: torch.Tensor, mean, std) -> torch.Tensor:
+        with torch.cuda.device(self.device):
+            return normalize_u8(x_u8.to(self.device), mean, std)
+
     def generate(self, feats: torch.Tensor, img_index: torch.Tensor, input_ids: torch.Tensor,
                  max_new_tokens: int = 16) -> torch.Tensor:
         """Greedy decoding -> int32 [B, max_new_tokens] on the device (every step executed; cut at the first EOS = 1 on
@@ -360,6 +365,21 @@ def attention(q, k, v, scale: float, bias_table=None, key_len=None):
                            S, scale, _stream_ptr())
     if rc != 0:
         raise VqsError(f"vqs_attention failed ({rc})")
+    return out
+
+
+def normalize_u8(x_u8: torch.Tensor, mean, std) -> torch.Tensor:
+    """uint8 [N,H,W,3] on the device -> CLIP-normalised bf16 [N,3,H,W] (the fp32 arithmetic of the HF processor)."""
+    lib = load_library()
+    N, H, W, C = x_u8.shape
+    if C != 3 or x_u8.dtype != torch.uint8 or not x_u8.is_cuda:
+        raise VqsError("normalize_u8 expects a uint8 [N,H,W,3] tensor on the GPU")
+    out = torch.empty(N, 3, H, W, dtype=torch.bfloat16, device=x_u8.device)
+    m3 = (ctypes.c_float * 3)(*[float(v) for v in mean])
+    s3 = (ctypes.c_float * 3)(*[float(v) for v in std])
+    rc = lib.vqs_normalize_u8(x_u8.contiguous().data_ptr(), out.data_ptr(), N, H, W, m3, s3, _stream_ptr())
+    if rc != 0:
+        raise VqsError(f"vqs_normalize_u8 failed ({rc})")
     return out
 
 

@@ -50,13 +50,19 @@ def _center_crop(arr: np.ndarray, size: int) -> np.ndarray:
     return out
 
 
-def clip_preprocess(img: Image.Image, image_size: int = 336, pad_to_square: bool = True) -> np.ndarray:
-    """PIL RGB image -> float32 [3, image_size, image_size]."""
+def clip_preprocess_u8(img: Image.Image, image_size: int = 336, pad_to_square: bool = True) -> np.ndarray:
+    """The integer part of the preprocessing (pad, PIL bicubic resize, centre crop) -> uint8 [image_size, image_size, 3];
+    the float part (rescale + normalise + bf16) runs on the GPU (vqs_normalize_u8) with the same fp32 arithmetic."""
     img = img.convert("RGB")
     if pad_to_square:
         img = expand2square(img, tuple(int(x * 255) for x in OPENAI_CLIP_MEAN))
     img = _resize_shortest_edge(img, image_size)
-    arr = _center_crop(np.asarray(img), image_size).astype(np.float32) * np.float32(1.0 / 255.0)
+    return np.ascontiguousarray(_center_crop(np.asarray(img), image_size))
+
+
+def clip_preprocess(img: Image.Image, image_size: int = 336, pad_to_square: bool = True) -> np.ndarray:
+    """PIL RGB image -> float32 [3, image_size, image_size]."""
+    arr = clip_preprocess_u8(img, image_size, pad_to_square).astype(np.float32) * np.float32(1.0 / 255.0)
     arr = (arr - np.asarray(OPENAI_CLIP_MEAN, dtype=np.float32)) / np.asarray(OPENAI_CLIP_STD, dtype=np.float32)
     return np.ascontiguousarray(arr.transpose(2, 0, 1))
 

@@ -269,6 +269,19 @@ def test_norms(eng, M, D):
     assert_close(out, torch.nn.functional.layer_norm(xs, (D,), w.float(), b.float(), 1e-5), 1e-2, 1e-2, "layernorm+add")
 
 
+def test_normalize_u8_matches_the_host_processor_arithmetic(eng):
+    """vqs_normalize_u8 == ((x * 1/255) - mean) / std in fp32, rounded to bf16: bit-exact against the host path
+    (t2v_metrics_amd/preprocess.py, itself pinned to HF's CLIPImageProcessor in tests/golden/clip_preprocess.npz)."""
+    from t2v_metrics_amd.preprocess import OPENAI_CLIP_MEAN, OPENAI_CLIP_STD
+    g = torch.Generator().manual_seed(81)
+    x = torch.randint(0, 256, (3, 37, 53, 3), generator=g, dtype=torch.uint8)
+    out = eng.normalize_u8(x.cuda(), OPENAI_CLIP_MEAN, OPENAI_CLIP_STD).cpu()
+    arr = x.numpy().astype(np.float32) * np.float32(1.0 / 255.0)
+    ref = (arr - np.asarray(OPENAI_CLIP_MEAN, dtype=np.float32)) / np.asarray(OPENAI_CLIP_STD, dtype=np.float32)
+    ref = torch.from_numpy(ref).permute(0, 3, 1, 2).contiguous().to(torch.bfloat16)
+    assert torch.equal(out, ref)
+
+
 def test_score_head(eng):
     B, T, V = 5, 3, 1000
     logits = torch.randn(B, T, V, device="cuda", generator=torch.Generator(device="cuda").manual_seed(26)) * 4.0
