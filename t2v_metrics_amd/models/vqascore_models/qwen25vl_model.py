@@ -84,7 +84,7 @@ class Qwen25VLModel(VQAScoreModel):
 
     def __init__(self, model_name='qwen2.5-vl-7b', device='cuda', cache_dir=HF_CACHE_DIR, checkpoint: Optional[str] = None,
                  weights=None, tokenizer=None, config: Optional[Qwen25VLConfig] = None, engine=None, max_batch: int = 32,
-                 seed: int = 0):
+                 seed: int = 0, num_workers: Optional[int] = None):
         """weights: None -> ``checkpoint`` (local HF directory of safetensors); 'seeded' -> seeded random weights at the
         architecture; or a dict.  tokenizer: object with ``encode(text, add_special_tokens=False) -> List[int]`` that maps
         the chat-template special tokens (HF protocol); None -> the checkpoint's tokenizer."""
@@ -92,6 +92,7 @@ class Qwen25VLModel(VQAScoreModel):
         self._cfg = config if config is not None else get_qwen_config(QWEN25_VL_MODELS[model_name]['config'])
         self._weights_arg, self._tokenizer_arg, self._checkpoint, self._engine_arg = weights, tokenizer, checkpoint, engine
         self._seed, self.max_batch = seed, int(max_batch)
+        self.num_workers = min(16, os.cpu_count() or 1) if num_workers is None else max(1, int(num_workers))
         super().__init__(model_name=model_name, device=device, cache_dir=cache_dir)
 
     # ------------------------------------------------------------------ loading
@@ -190,7 +191,13 @@ class Qwen25VLModel(VQAScoreModel):
         questions = [question_template.format(t) for t in texts]
         answers = [answer_template.format(t) for t in texts]
         items = self.load_images(images, fps)
-        prepared = [self.preprocess(it) for it in items]
+        # decode/resize/patch-flatten on a thread pool (PIL and torch release the GIL in their inner loops)
+        if len(items) > 1 and self.num_workers > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=min(self.num_workers, len(items))) as pool:
+                prepared = list(pool.map(self.preprocess, items))
+        else:
+            prepared = [self.preprocess(it) for it in items]
         scores = torch.zeros(len(images), dtype=torch.float32)
         # batch samples that share a grid (one vision call per group), at most max_batch at a time
         groups: Dict[Tuple[int, int, int], List[int]] = {}
