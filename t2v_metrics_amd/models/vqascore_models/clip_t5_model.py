@@ -213,6 +213,9 @@ class CLIPT5Model(VQAScoreModel):
         """Score pairs (images[pair_image[k]], questions[k], answers[k]).  Unique images are encoded once."""
         n = len(questions)
         assert len(answers) == n and len(pair_image) == n
+        if n == 0:           # empty M x N grids are legal in the reference (score.py:104 builds a [M, N] tensor of zeros)
+            empty = torch.zeros(0, dtype=torch.float32)
+            return (empty, torch.zeros(0, 0, dtype=torch.float32)) if return_logprobs else empty
         # Pipeline: the pool decodes/preprocesses image chunk i+1 while the GPU works on chunk i, and a batch of pairs is
         # scored as soon as all of its images are encoded -- so the (long) T5 scoring of early pairs overlaps the host work
         # for later images instead of waiting for every image first.  Launches are asynchronous; nothing here syncs.

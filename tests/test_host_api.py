@@ -289,3 +289,13 @@ def test_generate_api(tmp_path, images):
     with pytest.raises(AssertionError):
         s.model.generate(images=images[:2], texts=texts[:1])
 
+
+def test_empty_inputs_follow_the_reference(tmp_path, images):
+    """score.py:104-106: an empty image or text list gives an empty [M, N] tensor, not an error."""
+    s, eng = make_scorer(tmp_path)
+    assert tuple(s(images=[], texts=[]).shape) == (0, 0)
+    assert tuple(s(images=images[:2], texts=[]).shape) == (2, 0)
+    assert tuple(s(images=[], texts=["a", "b"]).shape) == (0, 2)
+    assert tuple(s.model.forward([], []).shape) == (0,)
+    assert eng.score_calls == []
+
