@@ -820,8 +820,18 @@ static int attn_variant() {       // VQS_ATTN_VARIANT=0 selects the register-sta
     return v;
 }
 
+static size_t attn_lds_pad() {    // lab: VQS_ATTN_LDS_PAD=<bytes> inflates the dynamic LDS request to lower the occupancy
+    static long v = -1;
+    if (v < 0) {
+        const char* e = getenv("VQS_ATTN_LDS_PAD");
+        v = e ? atol(e) : 0;
+    }
+    return (size_t)v;
+}
+
 template <typename KernelT>
 static hipError_t launch_attn_t(KernelT kern, const AttnParams& p, size_t lds, hipStream_t stream) {
+    lds += attn_lds_pad();
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (lds > 65536) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
