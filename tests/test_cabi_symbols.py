@@ -1,4 +1,4 @@
-"""CPU-side checks of the C-ABI library: it loads without a GPU and exports every symbol include/vqs.h declares."""
+"""CPU-side checks of the C-ABI library: it loads without a GPU and exports every symbol include/*.h declares."""
 import os
 import re
 
@@ -7,8 +7,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_symbols():
-    src = open(os.path.join(ROOT, "include", "vqs.h")).read()
+def _declared_symbols(header="vqs.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(vqs_[a-z_0-9]+)\s*\(", src)))
 
@@ -21,6 +21,34 @@ def test_library_loads_and_exports_header_symbols():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/vqs.h but not exported"
     assert set(declared) == set(engine.exported_symbols()), "engine.py signatures out of sync with include/vqs.h"
+
+
+def test_qwen_header_symbols_are_exported_and_bound():
+    """include/vqs_qwen.h: every declared entry point is exported and has a ctypes signature in qwen/engine.py; sizes are
+    pure arithmetic (no device needed)."""
+    import ctypes
+    from t2v_metrics_amd import engine
+    from t2v_metrics_amd.qwen import engine as qengine
+    lib = engine.load_library()
+    declared = _declared_symbols("vqs_qwen.h")
+    assert len(declared) >= 9
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/vqs_qwen.h but not exported"
+    assert set(declared) == set(qengine._SIGS), "qwen/engine.py signatures out of sync with include/vqs_qwen.h"
+    for name, (res, args) in qengine._SIGS.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    c = qengine.VqsQwenConfig(32, 1280, 16, 3420, 1176, 4, 3584, (1 << 7) | (1 << 15) | (1 << 23) | (1 << 31), 1e-6,
+                              152064, 3584, 28, 28, 4, 18944, 1e-6)
+    h = ctypes.c_void_p()
+    assert lib.vqs_qwen_create(ctypes.byref(c), ctypes.byref(h)) == 0
+    assert lib.vqs_qwen_packed_bytes(h) > 2 * 28 * 2 * 18944 * 3584          # at least the interleaved gate|up copies
+    assert lib.vqs_qwen_vision_workspace_bytes(h, 3072, 3072) > 3072 * 1280 * 4
+    assert lib.vqs_qwen_vision_workspace_bytes(h, 3071, 3072) == 0
+    assert lib.vqs_qwen_score_workspace_bytes(h, 32, 808) > 32 * 808 * 3584 * 4
+    lib.vqs_qwen_destroy(h)
+    c.v_hidden = 1281
+    assert lib.vqs_qwen_create(ctypes.byref(c), ctypes.byref(h)) != 0
 
 
 def test_create_rejects_bad_config_and_reports():
