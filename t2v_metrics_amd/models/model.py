@@ -1,7 +1,12 @@
-"""Plugin base class of the scoring API (interface of /root/reference/t2v_metrics/models/model.py:10-47)."""
+"""Plugin base class of the scoring API.
+
+Interface contract (what a scorer plugin must provide) follows /root/reference/t2v_metrics/models/model.py:10-47:
+a constructor taking ``(model_name, device, cache_dir)`` that ends by calling ``load_model()``, plus ``load_images`` and
+``forward``; ``self.image_loader`` is the decode hook wrappers call per path.
+"""
 from abc import ABC, abstractmethod
+from pathlib import Path
 from typing import List
-import os
 
 import numpy as np
 import torch
@@ -10,31 +15,34 @@ from PIL import Image
 from ..constants import HF_CACHE_DIR
 
 
-def image_loader(image_path):
-    """``.npy`` arrays are BGR (OpenCV order) and are flipped to RGB; everything else goes through PIL."""
-    if str(image_path).split('.')[-1] == 'npy':
-        return Image.fromarray(np.load(image_path)[:, :, [2, 1, 0]], 'RGB')
-    return Image.open(image_path).convert("RGB")
+def image_loader(image_path) -> Image.Image:
+    """Decode one image path to an RGB PIL image.  ``.npy`` files hold OpenCV-style BGR arrays [H, W, 3] and are
+    channel-flipped (reference model.py:10-14); every other suffix is handed to PIL."""
+    if Path(str(image_path)).suffix.lower() == '.npy':
+        bgr = np.load(image_path)
+        return Image.fromarray(np.ascontiguousarray(bgr[..., ::-1]), 'RGB')
+    with Image.open(image_path) as im:
+        return im.convert("RGB")
 
 
 class ScoreModel(ABC):
+    """Base of every scorer plugin: stores the three constructor arguments, makes sure the cache directory exists and
+    triggers ``load_model()``."""
+
     def __init__(self, model_name='clip-flant5-xxl', device='cuda', cache_dir=HF_CACHE_DIR):
-        self.model_name = model_name
-        self.device = device
-        self.cache_dir = cache_dir
-        if not os.path.exists(self.cache_dir):
-            os.makedirs(self.cache_dir)
+        self.model_name, self.device, self.cache_dir = model_name, device, cache_dir
+        Path(self.cache_dir).mkdir(parents=True, exist_ok=True)
         self.image_loader = image_loader
         self.load_model()
 
     @abstractmethod
     def load_model(self):
-        """Load the model, tokenizer, etc."""
+        """Build everything the plugin needs (weights, tokenizer, engine)."""
 
     @abstractmethod
     def load_images(self, image: List[str]) -> torch.Tensor:
-        """Load the image(s) and return a preprocessed tensor on self.device."""
+        """Decode + preprocess the given paths; the result lives on ``self.device``."""
 
     @abstractmethod
     def forward(self, images: List[str], texts: List[str]) -> torch.Tensor:
-        """n scores for n (image, text) pairs."""
+        """One score per (image, text) pair, pairs given as two parallel lists."""

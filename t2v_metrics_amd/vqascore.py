@@ -1,14 +1,21 @@
-"""``VQAScore`` (interface of /root/reference/t2v_metrics/vqascore.py:9-23)."""
+"""``VQAScore`` -- the user-facing scorer class.
+
+Interface of /root/reference/t2v_metrics/vqascore.py:9-23: a ``Score`` whose plugin comes from the VQAScore model registry.
+``VQAScore(model='clip-flant5-xxl', device='cuda', cache_dir=..., **kw)``; extra keyword arguments reach the plugin's
+constructor unchanged (this build uses them for ``weights=``, ``tokenizer=``, ``checkpoint=``, ``config=``, ``engine=``).
+"""
 from typing import List
 
-from .constants import HF_CACHE_DIR
-from .models.vqascore_models import get_vqascore_model, list_all_vqascore_models
+from . import constants
+from .models import vqascore_models as _registry
 from .score import Score
 
 
 class VQAScore(Score):
-    def prepare_scoremodel(self, model='clip-flant5-xxl', device='cuda', cache_dir=HF_CACHE_DIR, **kwargs):
-        return get_vqascore_model(model, device=device, cache_dir=cache_dir, **kwargs)
+    """P(answer | image, question) scorers: CLIP-FlanT5 (XL / XXL) and Qwen2.5-VL-7B on the MI355X engine."""
+
+    def prepare_scoremodel(self, model='clip-flant5-xxl', device='cuda', cache_dir=constants.HF_CACHE_DIR, **kwargs):
+        return _registry.get_vqascore_model(model, device=device, cache_dir=cache_dir, **kwargs)
 
     def list_all_models(self) -> List[str]:
-        return list_all_vqascore_models()
+        return _registry.list_all_vqascore_models()
