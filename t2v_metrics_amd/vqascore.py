@@ -8,6 +8,7 @@ from typing import List
 
 from . import constants
 from .models import vqascore_models as _registry
+from .models.vqascore_models import list_all_vqascore_models  # noqa: F401  (re-exported: t2v_metrics_amd/__init__.py)
 from .score import Score
 
 
