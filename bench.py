@@ -85,6 +85,16 @@ def main():
     ap.add_argument("--ragged", action="store_true", help="SURVEY config-3 stand-in: variable-length prompts, padded + masked")
     args = ap.parse_args()
 
+    if args.model.startswith("qwen"):
+        # BASELINE.json configs[4] (Qwen2.5-VL-7B, 8-frame video): measured by tools/bench_qwen.py, one GPU
+        if args.gpus != 1:
+            raise SystemExit("the Qwen2.5-VL bench line is single-GPU (replicas need no collective: run one process per GPU)")
+        sys.argv = [os.path.join(ROOT, "tools", "bench_qwen.py"), "--model", args.model, "--steps", str(args.steps), "--warmup",
+                    str(args.warmup), "--batch", str(min(args.batch, 64)), "--cpu-samples", str(min(args.cpu_pairs, 1))]
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_qwen
+        return bench_qwen.main()
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
