@@ -176,6 +176,13 @@ int vqs_rmsnorm(float* d_x, const void* d_delta, const void* d_w, void* d_out, i
                 void* stream);
 int vqs_layernorm(float* d_x, const void* d_delta, const void* d_w, const void* d_b, void* d_out, int32_t out_f32,
                   int32_t M, int32_t D, float eps, void* stream);
+/* Deferred-store forms of the fused residual update (both norms of a transformer layer then move 22 instead of 24 bytes
+ * per element; same fp32 additions in the same order as two stored updates -- HF modeling_t5.py:140,400,431,
+ * modeling_clip.py:366,371):  d_delta2 == NULL, store_x == 0: normalise d_x + d_delta, d_x is NOT modified;
+ * d_delta2 != NULL (store_x must be 1): d_x = (d_x + d_delta) + d_delta2, stored, then normalised.
+ * kind 0 = RMSNorm (d_b ignored), 1 = LayerNorm; output bf16. */
+int vqs_norm_deferred(int32_t kind, float* d_x, const void* d_delta, const void* d_delta2, int32_t store_x, const void* d_w,
+                      const void* d_b, void* d_out, int32_t M, int32_t D, float eps, void* stream);
 int vqs_score_head(const float* d_logits, int32_t ldl, int32_t V, const int32_t* d_labels, float* d_label_logprobs,
                    float* d_scores, int32_t B, int32_t T, void* stream);
 /* host-side bucket function used to build the bias tables (HF models/t5/modeling_t5.py:216-262) */

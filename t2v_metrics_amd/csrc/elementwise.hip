@@ -35,6 +35,9 @@ __device__ __forceinline__ float wave_max(float v) {
 // stream, then normalised.  `delta` is the sub-layer's output GEMM result in bf16 -- exactly what the reference's bf16
 // nn.Linear hands to its residual add -- while the stream itself stays fp32 here.
 // Algorithmic HBM bytes per element with delta: 4 (x in) + 2 (delta) + 4 (x out) + 2 (out) = 12.
+// ADD modes: 0 none; 1 x += delta, stored; 2 x + delta normalised but NOT stored (the caller keeps `delta` alive and
+// hands it to the next norm again: 8 B/elem); 3 x = (x + delta) + delta2, stored (14 B/elem).  A layer's two norms as
+// mode 2 then mode 3 move 22 B/elem instead of 24 and produce bit-identical streams ((x + d1) + d2 in fp32 either way).
 // D = 1024 / 2048 / 4096 (the model widths): the row lives in registers (NV float4 per lane), every load of the row is in
 // flight before the first use and nothing is read twice.  Other D (test configs): looped fallback, second pass from L2.
 // ------------------------------------------------------------------------------------------------
@@ -51,8 +54,9 @@ __device__ __forceinline__ uint32_t e_pack2_hw(float a, float b) {   // v_cvt_pk
 }
 
 // KIND 0: RMSNorm (bsh unused); KIND 1: LayerNorm.
-template <int NV, int KIND, bool ADD, bool OUT_F32>
+template <int NV, int KIND, int ADD, bool OUT_F32>
 __global__ void __launch_bounds__(256) norm_rows_reg_kernel(float* __restrict__ x, const bf16_t* __restrict__ delta,
+                                                            const bf16_t* __restrict__ delta2,
                                                             const bf16_t* __restrict__ w, const bf16_t* __restrict__ bsh,
                                                             void* __restrict__ out, int M, float eps) {
     constexpr int D = NV * 256;
@@ -63,16 +67,30 @@ __global__ void __launch_bounds__(256) norm_rows_reg_kernel(float* __restrict__ 
     float4 v[NV];
 #pragma unroll
     for (int j = 0; j < NV; ++j) v[j] = xr[lane + 64 * j];
-    if (ADD) {
+    if (ADD != 0) {
         const uint2* dr = reinterpret_cast<const uint2*>(delta + (size_t)row * D);
         uint2 d[NV];
 #pragma unroll
         for (int j = 0; j < NV; ++j) d[j] = dr[lane + 64 * j];
+        if (ADD == 3) {
+            const uint2* er = reinterpret_cast<const uint2*>(delta2 + (size_t)row * D);
+            uint2 e[NV];
 #pragma unroll
-        for (int j = 0; j < NV; ++j) {
-            const float4 f = bf4_to_f4(d[j]);
-            v[j].x += f.x; v[j].y += f.y; v[j].z += f.z; v[j].w += f.w;
-            xr[lane + 64 * j] = v[j];
+            for (int j = 0; j < NV; ++j) e[j] = er[lane + 64 * j];
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const float4 f = bf4_to_f4(d[j]), g = bf4_to_f4(e[j]);
+                v[j].x = (v[j].x + f.x) + g.x; v[j].y = (v[j].y + f.y) + g.y;
+                v[j].z = (v[j].z + f.z) + g.z; v[j].w = (v[j].w + f.w) + g.w;
+                xr[lane + 64 * j] = v[j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const float4 f = bf4_to_f4(d[j]);
+                v[j].x += f.x; v[j].y += f.y; v[j].z += f.z; v[j].w += f.w;
+                if (ADD == 1) xr[lane + 64 * j] = v[j];
+            }
         }
     }
     float mu = 0.0f;
@@ -111,35 +129,51 @@ __global__ void __launch_bounds__(256) norm_rows_reg_kernel(float* __restrict__ 
 }
 
 // any D % 4 == 0
-template <int KIND, bool ADD, bool OUT_F32>
+template <int KIND, int ADD, bool OUT_F32>
 __global__ void __launch_bounds__(256) norm_rows_loop_kernel(float* __restrict__ x, const bf16_t* __restrict__ delta,
+                                                             const bf16_t* __restrict__ delta2,
                                                              const bf16_t* __restrict__ w, const bf16_t* __restrict__ bsh,
                                                              void* __restrict__ out, int M, int D, float eps) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= M) return;
     float4* xr = reinterpret_cast<float4*>(x + (size_t)row * D);
+    const uint2* dr = ADD != 0 ? reinterpret_cast<const uint2*>(delta + (size_t)row * D) : nullptr;
+    const uint2* er = ADD == 3 ? reinterpret_cast<const uint2*>(delta2 + (size_t)row * D) : nullptr;
     const int nv = D >> 2;
+    // the row value as the later passes see it: stored modes re-read what the first pass wrote (same lane), mode 2
+    // (not stored) re-adds the delta
+    auto value = [&](int i) {
+        float4 v = xr[i];
+        if (ADD == 2) {
+            const float4 d = bf4_to_f4(dr[i]);
+            v.x += d.x; v.y += d.y; v.z += d.z; v.w += d.w;
+        }
+        return v;
+    };
     float s1 = 0.0f;
-    if (ADD) {
-        const uint2* dr = reinterpret_cast<const uint2*>(delta + (size_t)row * D);
+    if (ADD == 1 || ADD == 3) {
         for (int i = lane; i < nv; i += 64) {
             float4 v = xr[i];
             const float4 d = bf4_to_f4(dr[i]);
             v.x += d.x; v.y += d.y; v.z += d.z; v.w += d.w;
-            xr[i] = v;                     // the same lane re-reads it below
+            if (ADD == 3) {
+                const float4 e = bf4_to_f4(er[i]);
+                v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w;
+            }
+            xr[i] = v;
             s1 += (v.x + v.y) + (v.z + v.w);
         }
     } else if (KIND == 1) {
         for (int i = lane; i < nv; i += 64) {
-            const float4 v = xr[i];
+            const float4 v = value(i);
             s1 += (v.x + v.y) + (v.z + v.w);
         }
     }
     const float mu = KIND == 1 ? wave_sum(s1) / (float)D : 0.0f;
     float s2 = 0.0f;
     for (int i = lane; i < nv; i += 64) {
-        const float4 v = xr[i];
+        const float4 v = value(i);
         const float a = v.x - mu, b = v.y - mu, c = v.z - mu, d = v.w - mu;
         s2 += a * a + b * b + c * c + d * d;
     }
@@ -147,7 +181,7 @@ __global__ void __launch_bounds__(256) norm_rows_loop_kernel(float* __restrict__
     const uint2* wr = reinterpret_cast<const uint2*>(w);
     const uint2* br = reinterpret_cast<const uint2*>(bsh);
     for (int i = lane; i < nv; i += 64) {
-        const float4 v = xr[i];
+        const float4 v = value(i);
         const float4 wv = bf4_to_f4(wr[i]);
         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (KIND == 1) bv = bf4_to_f4(br[i]);
@@ -164,40 +198,60 @@ __global__ void __launch_bounds__(256) norm_rows_loop_kernel(float* __restrict__
     }
 }
 
-template <int KIND, bool ADD, bool OUT_F32>
-static hipError_t launch_norm_t(float* x, const bf16_t* delta, const bf16_t* w, const bf16_t* b, void* out, int M, int D,
-                                float eps, hipStream_t s) {
+template <int KIND, int ADD, bool OUT_F32>
+static hipError_t launch_norm_t(float* x, const bf16_t* delta, const bf16_t* delta2, const bf16_t* w, const bf16_t* b, void* out,
+                                int M, int D, float eps, hipStream_t s) {
     const dim3 grid((M + 3) / 4), block(256);
     if (D == 1024)
-        hipLaunchKernelGGL((norm_rows_reg_kernel<4, KIND, ADD, OUT_F32>), grid, block, 0, s, x, delta, w, b, out, M, eps);
+        hipLaunchKernelGGL((norm_rows_reg_kernel<4, KIND, ADD, OUT_F32>), grid, block, 0, s, x, delta, delta2, w, b, out, M, eps);
     else if (D == 2048)
-        hipLaunchKernelGGL((norm_rows_reg_kernel<8, KIND, ADD, OUT_F32>), grid, block, 0, s, x, delta, w, b, out, M, eps);
+        hipLaunchKernelGGL((norm_rows_reg_kernel<8, KIND, ADD, OUT_F32>), grid, block, 0, s, x, delta, delta2, w, b, out, M, eps);
     else if (D == 4096)
-        hipLaunchKernelGGL((norm_rows_reg_kernel<16, KIND, ADD, OUT_F32>), grid, block, 0, s, x, delta, w, b, out, M, eps);
+        hipLaunchKernelGGL((norm_rows_reg_kernel<16, KIND, ADD, OUT_F32>), grid, block, 0, s, x, delta, delta2, w, b, out, M, eps);
     else if (D == 1280)     // Qwen2.5-VL vision tower
-        hipLaunchKernelGGL((norm_rows_reg_kernel<5, KIND, ADD, OUT_F32>), grid, block, 0, s, x, delta, w, b, out, M, eps);
+        hipLaunchKernelGGL((norm_rows_reg_kernel<5, KIND, ADD, OUT_F32>), grid, block, 0, s, x, delta, delta2, w, b, out, M, eps);
     else if (D == 3584)     // Qwen2.5-VL-7B language model
-        hipLaunchKernelGGL((norm_rows_reg_kernel<14, KIND, ADD, OUT_F32>), grid, block, 0, s, x, delta, w, b, out, M, eps);
+        hipLaunchKernelGGL((norm_rows_reg_kernel<14, KIND, ADD, OUT_F32>), grid, block, 0, s, x, delta, delta2, w, b, out, M, eps);
     else
-        hipLaunchKernelGGL((norm_rows_loop_kernel<KIND, ADD, OUT_F32>), grid, block, 0, s, x, delta, w, b, out, M, D, eps);
+        hipLaunchKernelGGL((norm_rows_loop_kernel<KIND, ADD, OUT_F32>), grid, block, 0, s, x, delta, delta2, w, b, out, M, D, eps);
     return hipGetLastError();
 }
 
+// add mode from the arguments: delta only -> 1 (stored) or 2 (store_x == false); delta + delta2 -> 3 (always stored)
+static int norm_add_mode(const bf16_t* delta, const bf16_t* delta2, bool store_x) {
+    if (!delta) return (delta2 || !store_x) ? -1 : 0;
+    if (delta2) return store_x ? 3 : -1;
+    return store_x ? 1 : 2;
+}
+
 hipError_t launch_rmsnorm(float* x, const bf16_t* delta, const bf16_t* w, bf16_t* out, int M, int D, float eps,
-                          hipStream_t s) {
+                          hipStream_t s, const bf16_t* delta2, bool store_x) {
     if (D % 4) return hipErrorInvalidValue;
-    return delta ? launch_norm_t<0, true, false>(x, delta, w, nullptr, out, M, D, eps, s)
-                 : launch_norm_t<0, false, false>(x, delta, w, nullptr, out, M, D, eps, s);
+    switch (norm_add_mode(delta, delta2, store_x)) {
+        case 0: return launch_norm_t<0, 0, false>(x, delta, delta2, w, nullptr, out, M, D, eps, s);
+        case 1: return launch_norm_t<0, 1, false>(x, delta, delta2, w, nullptr, out, M, D, eps, s);
+        case 2: return launch_norm_t<0, 2, false>(x, delta, delta2, w, nullptr, out, M, D, eps, s);
+        case 3: return launch_norm_t<0, 3, false>(x, delta, delta2, w, nullptr, out, M, D, eps, s);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 hipError_t launch_layernorm(float* x, const bf16_t* delta, const bf16_t* w, const bf16_t* b, void* out, int out_f32, int M,
-                            int D, float eps, hipStream_t s) {
+                            int D, float eps, hipStream_t s, const bf16_t* delta2, bool store_x) {
     if (D % 4) return hipErrorInvalidValue;
-    if (out_f32)
-        return delta ? launch_norm_t<1, true, true>(x, delta, w, b, out, M, D, eps, s)
-                     : launch_norm_t<1, false, true>(x, delta, w, b, out, M, D, eps, s);
-    return delta ? launch_norm_t<1, true, false>(x, delta, w, b, out, M, D, eps, s)
-                 : launch_norm_t<1, false, false>(x, delta, w, b, out, M, D, eps, s);
+    const int mode = norm_add_mode(delta, delta2, store_x);
+    if (out_f32) {          // fp32 output is only needed for the plain and the stored single-delta form
+        if (mode == 0) return launch_norm_t<1, 0, true>(x, delta, delta2, w, b, out, M, D, eps, s);
+        if (mode == 1) return launch_norm_t<1, 1, true>(x, delta, delta2, w, b, out, M, D, eps, s);
+        return hipErrorInvalidValue;
+    }
+    switch (mode) {
+        case 0: return launch_norm_t<1, 0, false>(x, delta, delta2, w, b, out, M, D, eps, s);
+        case 1: return launch_norm_t<1, 1, false>(x, delta, delta2, w, b, out, M, D, eps, s);
+        case 2: return launch_norm_t<1, 2, false>(x, delta, delta2, w, b, out, M, D, eps, s);
+        case 3: return launch_norm_t<1, 3, false>(x, delta, delta2, w, b, out, M, D, eps, s);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -49,6 +49,7 @@ struct vqs_handle {
     size_t ev_used = 0;
     std::vector<std::pair<std::string, double>> ev_what;   // per profiled GEMM launch: call-site label, FLOPs
     std::string prof_report;
+    int norm_defer = 1;        // VQS_NORM_DEFER=0: every norm stores the updated fp32 stream (24 instead of 22 B/elem per layer)
     int fused_norm = 0;        // VQS_FUSED_NORM=1: residual update + RMSNorm operand in the o / wo GEMM epilogues (lab; +1 %)
     int splitk = 1;            // VQS_SPLITK=0 disables split-K in the decoder's skinny GEMMs (lab A/B)
     double prof_flops = 0.0;
@@ -84,7 +85,7 @@ struct EncodeWs {
     float* patch_out;
     float* pre;
     float* hidden;
-    bf16_t* delta;
+    bf16_t *delta, *delta2;
     bf16_t *xn, *q, *k, *v, *attn, *mid, *feat_in, *pmid;
     size_t total;
 };
@@ -99,6 +100,7 @@ EncodeWs carve_encode(const vqs_handle* h, char* base, int N, std::unordered_map
     w.pre = cv.take<float>(NS * c.vis_hidden);
     w.hidden = cv.take<float>(NS * c.vis_hidden, "vit_hidden");
     w.delta = cv.take<bf16_t>(NS * c.vis_hidden);
+    w.delta2 = cv.take<bf16_t>(NS * c.vis_hidden);
     w.xn = cv.take<bf16_t>(NS * c.vis_hidden);
     w.q = cv.take<bf16_t>(NS * c.vis_hidden);
     w.k = cv.take<bf16_t>(NS * c.vis_hidden);
@@ -114,7 +116,7 @@ EncodeWs carve_encode(const vqs_handle* h, char* base, int N, std::unordered_map
 struct ScoreWs {
     int *sent_pos, *enc_len, *flags;
     float *enc_table, *dec_table, *hidden;
-    bf16_t *delta, *ddelta;
+    bf16_t *delta, *delta2, *ddelta;
     float* rowss;             // [ceil(D/256)][B*S] partial row sums of squares (fused residual + RMSNorm)
     float* rs;                // [B*S] 1/rms per row, derived from rowss
     bf16_t *xn, *q, *k, *v, *attn, *ff, *enc_out, *ck, *cv;
@@ -143,6 +145,7 @@ ScoreWs carve_score(const vqs_handle* h, char* base, int B, int L, int T,
     w.dec_table = cv.take<float>((size_t)H * T);
     w.hidden = cv.take<float>(M * D, "enc_in");   // the fp32 residual stream; holds enc_in until layer 0 runs
     w.delta = cv.take<bf16_t>(M * D);            // bf16 sub-layer output waiting to be added by the next norm
+    w.delta2 = cv.take<bf16_t>(M * D);           // second pending delta (deferred stream store, VQS_NORM_DEFER)
     w.xn = cv.take<bf16_t>(M * D);
     w.rowss = cv.take<float>((size_t)((D + 255) / 256) * M);
     w.rs = cv.take<float>(M);
@@ -348,6 +351,7 @@ int vqs_create(const vqs_config* cfg, vqs_handle** out) {
     if (const char* cm = std::getenv("VQS_CROSS_MODE")) h->cross_mode = std::atoi(cm);
     if (const char* sk = std::getenv("VQS_SPLITK")) h->splitk = std::atoi(sk);
     if (const char* fn = std::getenv("VQS_FUSED_NORM")) h->fused_norm = std::atoi(fn);
+    if (const char* nd = std::getenv("VQS_NORM_DEFER")) h->norm_defer = std::atoi(nd);
     const char* v = std::getenv("VQS_GEMM_VARIANT");
     h->gemm_variant = v ? std::atoi(v) : 3;   // 3 = persistent kernel (gemm.hip)
     return VQS_OK;
@@ -478,8 +482,13 @@ int vqs_encode_images(vqs_handle* h, const void* d_pixels, int32_t N, void* d_fe
 
     // Residual stream protocol: a sub-layer's output GEMM writes bf16 into `delta`; the NEXT norm kernel performs
     // hidden += delta (written back) and normalises in the same pass.  `pend` is the not-yet-added delta.
+    // Deferred store (norm_defer, every layer but the last): layer_norm2 normalises hidden + delta_attn WITHOUT writing
+    // the stream and the next layer_norm1 stores (hidden + delta_attn) + delta_mlp -- the same fp32 additions in the
+    // same order, 22 instead of 24 bytes per element and layer.
     const bf16_t* pend = nullptr;
+    const bf16_t* pend_attn = nullptr;
     for (int i = 0; i < c.vis_layers_run; ++i) {
+        const bool defer = h->norm_defer != 0 && i + 1 < c.vis_layers_run;
         const std::string p = "vision.encoder.layers." + std::to_string(i) + ".";
         GETW(ln1w, p + "layer_norm1.weight", hid);
         GETW(ln1b, p + "layer_norm1.bias", hid);
@@ -492,8 +501,12 @@ int vqs_encode_images(vqs_handle* h, const void* d_pixels, int32_t N, void* d_fe
         GETW(f2w, p + "mlp.fc2.weight", (int64_t)hid * mlp);
         GETW(f2b, p + "mlp.fc2.bias", hid);
 
-        HIPCHK(h, vqs::launch_layernorm(w.hidden, pend, ln1w, ln1b, w.xn, 0, NS, hid, c.vis_ln_eps, st), "layer_norm1");
+        if (pend_attn)
+            HIPCHK(h, vqs::launch_layernorm(w.hidden, pend_attn, ln1w, ln1b, w.xn, 0, NS, hid, c.vis_ln_eps, st, pend), "layer_norm1");
+        else
+            HIPCHK(h, vqs::launch_layernorm(w.hidden, pend, ln1w, ln1b, w.xn, 0, NS, hid, c.vis_ln_eps, st), "layer_norm1");
         pend = nullptr;
+        pend_attn = nullptr;
         {
             GemmCall g{w.xn, h->vit_qkv_w[i], nullptr};
             g.bias = h->vit_qkv_b[i];
@@ -512,7 +525,8 @@ int vqs_encode_images(vqs_handle* h, const void* d_pixels, int32_t N, void* d_fe
             g.M = NS; g.N = hid; g.K = hid; g.lda = hid; g.ldw = hid; g.ldc = hid; g.epi = vqs::EPI_BF16;
             RUN(run_gemm(h, g, st, "vit out_proj"));
         }
-        HIPCHK(h, vqs::launch_layernorm(w.hidden, w.delta, ln2w, ln2b, w.xn, 0, NS, hid, c.vis_ln_eps, st), "layer_norm2");
+        HIPCHK(h, vqs::launch_layernorm(w.hidden, w.delta, ln2w, ln2b, w.xn, 0, NS, hid, c.vis_ln_eps, st, nullptr, !defer), "layer_norm2");
+        if (defer) pend_attn = w.delta;
         {
             GemmCall g{w.xn, f1w, w.mid};
             g.bias = f1b;
@@ -520,11 +534,12 @@ int vqs_encode_images(vqs_handle* h, const void* d_pixels, int32_t N, void* d_fe
             RUN(run_gemm(h, g, st, "vit fc1"));
         }
         {
-            GemmCall g{w.mid, f2w, w.delta};
+            bf16_t* dst = defer ? w.delta2 : w.delta;
+            GemmCall g{w.mid, f2w, dst};
             g.bias = f2b;
             g.M = NS; g.N = hid; g.K = mlp; g.lda = mlp; g.ldw = mlp; g.ldc = hid; g.epi = vqs::EPI_BF16;
             RUN(run_gemm(h, g, st, "vit fc2"));
-            pend = w.delta;
+            pend = dst;
         }
     }
     // hidden_states[-2][:, 1:] = hidden + pending fc2 output, CLS dropped, cast to the projector's operand type
@@ -583,6 +598,8 @@ static int encoder_pass(vqs_handle* h, const ScoreWs& w, const void* d_feats, co
     const int parts = (D + 255) / 256;
     bool scaled = false;          // w.xn holds an un-normalised operand whose row sums are in w.rowss
     const bf16_t* pend = nullptr;
+    const bf16_t* pend_attn = nullptr;   // deferred store (see the vision tower): the attention delta the stream has not absorbed yet
+    const bool defer = h->norm_defer != 0 && !fused;
     auto consume = [&](GemmCall& g) {
         if (scaled) {
             g.rowss_in = w.rs; g.rowss_parts = 0;
@@ -598,8 +615,12 @@ static int encoder_pass(vqs_handle* h, const ScoreWs& w, const void* d_feats, co
         GETW(ln1, p + "layer.1.layer_norm.weight", D);
         GETW(wo, p + "layer.1.DenseReluDense.wo.weight", (int64_t)D * F);
         if (!scaled) {
-            HIPCHK(h, vqs::launch_rmsnorm(w.hidden, pend, ln0, w.xn, M, D, c.t5_ln_eps, st), "enc rmsnorm0");
+            if (pend_attn)
+                HIPCHK(h, vqs::launch_rmsnorm(w.hidden, pend_attn, ln0, w.xn, M, D, c.t5_ln_eps, st, pend), "enc rmsnorm0");
+            else
+                HIPCHK(h, vqs::launch_rmsnorm(w.hidden, pend, ln0, w.xn, M, D, c.t5_ln_eps, st), "enc rmsnorm0");
             pend = nullptr;
+            pend_attn = nullptr;
         }
         {
             GemmCall g{w.xn, h->enc_qkv[i], nullptr};
@@ -623,7 +644,8 @@ static int encoder_pass(vqs_handle* h, const ScoreWs& w, const void* d_feats, co
         if (fused) {
             scaled = true;
         } else {
-            HIPCHK(h, vqs::launch_rmsnorm(w.hidden, w.delta, ln1, w.xn, M, D, c.t5_ln_eps, st), "enc rmsnorm1");
+            HIPCHK(h, vqs::launch_rmsnorm(w.hidden, w.delta, ln1, w.xn, M, D, c.t5_ln_eps, st, nullptr, !defer), "enc rmsnorm1");
+            if (defer) pend_attn = w.delta;
             scaled = false;
         }
         {
@@ -633,7 +655,8 @@ static int encoder_pass(vqs_handle* h, const ScoreWs& w, const void* d_feats, co
             RUN(run_gemm(h, g, st, "enc wi"));
         }
         {
-            GemmCall g{w.ff, wo, w.delta};
+            bf16_t* dst = defer ? w.delta2 : w.delta;
+            GemmCall g{w.ff, wo, dst};
             g.M = M; g.N = D; g.K = F; g.lda = F; g.ldw = F; g.ldc = D; g.epi = vqs::EPI_BF16;
             if (fused && i + 1 < c.enc_layers) {
                 GETW(ln0_next, "encoder.block." + std::to_string(i + 1) + ".layer.0.layer_norm.weight", D);
@@ -645,13 +668,16 @@ static int encoder_pass(vqs_handle* h, const ScoreWs& w, const void* d_feats, co
             } else {
                 RUN(run_gemm(h, g, st, "enc wo"));
                 scaled = false;
-                pend = w.delta;
+                pend = dst;
             }
         }
     }
     {
         GETW(fin, "encoder.final_layer_norm.weight", D);
-        HIPCHK(h, vqs::launch_rmsnorm(w.hidden, pend, fin, w.enc_out, M, D, c.t5_ln_eps, st), "enc final norm");
+        if (pend_attn)
+            HIPCHK(h, vqs::launch_rmsnorm(w.hidden, pend_attn, fin, w.enc_out, M, D, c.t5_ln_eps, st, pend), "enc final norm");
+        else
+            HIPCHK(h, vqs::launch_rmsnorm(w.hidden, pend, fin, w.enc_out, M, D, c.t5_ln_eps, st), "enc final norm");
         if (h->cross_mode != 0)
             HIPCHK(h, vqs::launch_transpose_pad(w.enc_out, w.enc_outT, B, S, D, w.S_pad, st), "enc_out transpose");
     }
@@ -973,6 +999,17 @@ int vqs_decoder_attention(const void* q, const void* k, const void* v, void* out
 
 int vqs_rmsnorm(float* x, const void* delta, const void* w, void* out, int32_t M, int32_t D, float eps, void* stream) {
     return vqs::launch_rmsnorm(x, (const bf16_t*)delta, (const bf16_t*)w, (bf16_t*)out, M, D, eps, (hipStream_t)stream) == hipSuccess ? VQS_OK : VQS_ERR_HIP;
+}
+
+int vqs_norm_deferred(int32_t kind, float* x, const void* delta, const void* delta2, int32_t store_x, const void* w, const void* b,
+                      void* out, int32_t M, int32_t D, float eps, void* stream) {
+    if (!x || !delta || !w || !out || (kind == 1 && !b) || (kind != 0 && kind != 1)) return VQS_ERR_INVALID;
+    const hipError_t e = kind == 0
+        ? vqs::launch_rmsnorm(x, (const bf16_t*)delta, (const bf16_t*)w, (bf16_t*)out, M, D, eps, (hipStream_t)stream,
+                              (const bf16_t*)delta2, store_x != 0)
+        : vqs::launch_layernorm(x, (const bf16_t*)delta, (const bf16_t*)w, (const bf16_t*)b, out, 0, M, D, eps, (hipStream_t)stream,
+                                (const bf16_t*)delta2, store_x != 0);
+    return e == hipSuccess ? VQS_OK : (e == hipErrorInvalidValue ? VQS_ERR_INVALID : VQS_ERR_HIP);
 }
 
 int vqs_layernorm(float* x, const void* delta, const void* w, const void* b, void* out, int32_t out_f32, int32_t M, int32_t D,

@@ -90,10 +90,12 @@ hipError_t launch_decoder_attention(const DecAttnParams& p, hipStream_t stream);
 
 // ---------------------------------------------------------------- norms + glue (elementwise.hip)
 // delta != nullptr: x += delta (fp32, written back) first -- the fused residual update of the previous sub-layer
+// delta2 / store_x select the deferred-store forms (elementwise.hip): (delta, store_x=false) normalises x + delta without
+// writing the stream; (delta, delta2) stores x = (x + delta) + delta2.
 hipError_t launch_rmsnorm(float* x, const bf16_t* delta, const bf16_t* w, bf16_t* out, int M, int D, float eps,
-                          hipStream_t s);
+                          hipStream_t s, const bf16_t* delta2 = nullptr, bool store_x = true);
 hipError_t launch_layernorm(float* x, const bf16_t* delta, const bf16_t* w, const bf16_t* b, void* out, int out_f32, int M,
-                            int D, float eps, hipStream_t s);
+                            int D, float eps, hipStream_t s, const bf16_t* delta2 = nullptr, bool store_x = true);
 // pixels bf16 [N,3,IMG,IMG] -> rows [N*G*G, Kpad] in (c,ky,kx) order, zero padded
 hipError_t launch_im2col(const bf16_t* pixels, bf16_t* out, int N, int img, int patch, int kpad, hipStream_t s);
 // hidden[n, 0] = cls + pos[0]; hidden[n, 1+p] = patch_out[n*P+p] + pos[1+p]   (fp32 out)

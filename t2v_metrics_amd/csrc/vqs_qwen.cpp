@@ -228,7 +228,7 @@ int pack(vqs_qwen_handle* h, char* base, size_t* total, hipStream_t st) {
 }
 
 struct VisWs {
-    bf16_t *patches, *xn, *delta, *q, *k, *v, *attn, *ff, *mid, *merged_w, *xc, *dc;
+    bf16_t *patches, *xn, *delta, *delta2, *q, *k, *v, *attn, *ff, *mid, *merged_w, *xc, *dc;
     float *pre, *hidden;
     size_t total;
 };
@@ -243,6 +243,7 @@ VisWs carve_vision(const vqs_qwen_handle* h, char* base, int N, int Np) {
     w.hidden = cv.take<float>(np * c.v_hidden);
     w.xn = cv.take<bf16_t>(np * c.v_hidden);
     w.delta = cv.take<bf16_t>(np * c.v_hidden);
+    w.delta2 = cv.take<bf16_t>(np * c.v_hidden);   // second pending delta (deferred stream store, see elementwise.hip)
     w.q = cv.take<bf16_t>(np * VPK);
     w.k = cv.take<bf16_t>(np * VPK);
     w.v = cv.take<bf16_t>(np * VPK);
@@ -257,7 +258,7 @@ VisWs carve_vision(const vqs_qwen_handle* h, char* base, int N, int Np) {
 }
 
 struct TxtWs {
-    bf16_t *xn, *delta, *q, *k, *v, *attn, *ff, *last;
+    bf16_t *xn, *delta, *delta2, *q, *k, *v, *attn, *ff, *last;
     float* hidden;
     size_t total;
 };
@@ -269,6 +270,7 @@ TxtWs carve_text(const vqs_qwen_handle* h, char* base, int B, int L) {
     w.hidden = cv.take<float>(M * c.t_hidden);
     w.xn = cv.take<bf16_t>(M * c.t_hidden);
     w.delta = cv.take<bf16_t>(M * c.t_hidden);
+    w.delta2 = cv.take<bf16_t>(M * c.t_hidden);
     w.q = cv.take<bf16_t>(M * h->t_iq);
     w.k = cv.take<bf16_t>(M * h->t_ikv);
     w.v = cv.take<bf16_t>(M * h->t_ikv);
@@ -401,6 +403,7 @@ int vqs_qwen_encode_vision(vqs_qwen_handle* h, const void* d_patches, int32_t N,
     QHIP(h, hipMemsetAsync(w.ff, 0, (size_t)Np * h->v_ffld * sizeof(bf16_t), st), "clear ff padding");
 
     const bf16_t* pend = nullptr;
+    const bf16_t* pend_attn = nullptr;   // attention delta the fp32 stream has not absorbed yet
     for (int i = 0; i < c.v_depth; ++i) {
         const std::string p = "model.visual.blocks." + std::to_string(i) + ".";
         QW(n1, p + "norm1.weight", VH);
@@ -408,7 +411,9 @@ int vqs_qwen_encode_vision(vqs_qwen_handle* h, const void* d_patches, int32_t N,
         QW(pb, p + "attn.proj.bias", VH);
         QW(db, p + "mlp.down_proj.bias", VH);
         const bool full = ((c.v_fullatt_mask >> i) & 1) != 0;
-        QHIP(h, vqs::launch_rmsnorm(w.hidden, pend, n1, w.xn, Np, VH, c.v_eps, st), "vision norm1");
+        // deferred store: norm2 normalises hidden + attention delta without writing the stream; the next norm1 (or the
+        // merger norm) stores (hidden + attention delta) + mlp delta -- same fp32 sums, 22 instead of 24 B per element
+        QHIP(h, vqs::launch_rmsnorm(w.hidden, pend_attn ? pend_attn : pend, n1, w.xn, Np, VH, c.v_eps, st, pend_attn ? pend : nullptr), "vision norm1");
         // window blocks run on the padded windowed layout (every window = win_len slots, d_win_valid of them real);
         // full-attention blocks on a frame-compact copy (original patch order), scattered back afterwards
         const bf16_t* xin = w.xn;
@@ -441,7 +446,8 @@ int vqs_qwen_encode_vision(vqs_qwen_handle* h, const void* d_patches, int32_t N,
         }
         if (full)
             QHIP(h, vqs::launch_gather_rows_bf16(w.dc, nullptr, d_row_map, w.delta, Np, VH, VH, VH, st), "scatter frame rows back");
-        QHIP(h, vqs::launch_rmsnorm(w.hidden, w.delta, n2, w.xn, Np, VH, c.v_eps, st), "vision norm2");
+        QHIP(h, vqs::launch_rmsnorm(w.hidden, w.delta, n2, w.xn, Np, VH, c.v_eps, st, nullptr, false), "vision norm2");
+        pend_attn = w.delta;
         {
             GCall g{w.xn, h->v_gu_w[i], w.ff};
             g.bias = h->v_gu_b[i];
@@ -449,11 +455,11 @@ int vqs_qwen_encode_vision(vqs_qwen_handle* h, const void* d_patches, int32_t N,
             QRUN(qgemm(h, g, st, "vision gate|up"));
         }
         {
-            GCall g{w.ff, h->v_down_w[i], w.delta};
+            GCall g{w.ff, h->v_down_w[i], w.delta2};
             g.bias = db;
             g.M = Np; g.N = VH; g.K = h->v_ffld; g.lda = h->v_ffld; g.ldw = h->v_ffld; g.ldc = VH; g.epi = vqs::EPI_BF16;
             QRUN(qgemm(h, g, st, "vision down"));
-            pend = w.delta;
+            pend = w.delta2;
         }
     }
     // merger: RMSNorm, the 4 patches of a cell (consecutive rows in the windowed layout) concatenated, Linear-GELU-Linear,
@@ -464,7 +470,7 @@ int vqs_qwen_encode_vision(vqs_qwen_handle* h, const void* d_patches, int32_t N,
     QW(m2w, "model.visual.merger.mlp.2.weight", (int64_t)c.v_out_hidden * h->merge_hidden);
     QW(m2b, "model.visual.merger.mlp.2.bias", c.v_out_hidden);
     const int NCp = Np / c.v_merge_unit;
-    QHIP(h, vqs::launch_rmsnorm(w.hidden, pend, lnq, w.xn, Np, VH, 1e-6f, st), "merger norm");
+    QHIP(h, vqs::launch_rmsnorm(w.hidden, pend_attn ? pend_attn : pend, lnq, w.xn, Np, VH, 1e-6f, st, pend_attn ? pend : nullptr), "merger norm");
     {
         GCall g{w.xn, m0w, w.mid};
         g.bias = m0b;
@@ -508,11 +514,12 @@ int vqs_qwen_score(vqs_qwen_handle* h, const void* d_merged, const int32_t* d_in
     QHIP(h, hipMemsetAsync(w.ff, 0, (size_t)M * h->t_ffld * sizeof(bf16_t), st), "clear ff padding");
 
     const bf16_t* pend = nullptr;
+    const bf16_t* pend_attn = nullptr;   // attention delta the fp32 stream has not absorbed yet
     for (int i = 0; i < c.t_layers; ++i) {
         const std::string p = "model.language_model.layers." + std::to_string(i) + ".";
         QW(ln1, p + "input_layernorm.weight", TH);
         QW(ln2, p + "post_attention_layernorm.weight", TH);
-        QHIP(h, vqs::launch_rmsnorm(w.hidden, pend, ln1, w.xn, M, TH, c.t_eps, st), "input_layernorm");
+        QHIP(h, vqs::launch_rmsnorm(w.hidden, pend_attn ? pend_attn : pend, ln1, w.xn, M, TH, c.t_eps, st, pend_attn ? pend : nullptr), "input_layernorm");
         {
             GCall g{w.xn, h->t_qkv_w[i], nullptr};
             g.bias = h->t_qkv_b[i];
@@ -533,22 +540,23 @@ int vqs_qwen_score(vqs_qwen_handle* h, const void* d_merged, const int32_t* d_in
             g.M = M; g.N = TH; g.K = IQ; g.lda = IQ; g.ldw = IQ; g.ldc = TH; g.epi = vqs::EPI_BF16;
             QRUN(qgemm(h, g, st, "o_proj"));
         }
-        QHIP(h, vqs::launch_rmsnorm(w.hidden, w.delta, ln2, w.xn, M, TH, c.t_eps, st), "post_attention_layernorm");
+        QHIP(h, vqs::launch_rmsnorm(w.hidden, w.delta, ln2, w.xn, M, TH, c.t_eps, st, nullptr, false), "post_attention_layernorm");
+        pend_attn = w.delta;
         {
             GCall g{w.xn, h->t_gu_w[i], w.ff};
             g.M = M; g.N = 2 * h->t_mlp_p; g.K = TH; g.lda = TH; g.ldw = TH; g.ldc = h->t_ffld; g.epi = vqs::EPI_GATED; g.gate_act = 1;
             QRUN(qgemm(h, g, st, "gate|up"));
         }
         {
-            GCall g{w.ff, h->t_down_w[i], w.delta};
+            GCall g{w.ff, h->t_down_w[i], w.delta2};
             g.M = M; g.N = TH; g.K = h->t_ffld; g.lda = h->t_ffld; g.ldw = h->t_ffld; g.ldc = TH; g.epi = vqs::EPI_BF16;
             QRUN(qgemm(h, g, st, "down_proj"));
-            pend = w.delta;
+            pend = w.delta2;
         }
     }
     QW(fin, "model.language_model.norm.weight", TH);
     QW(head, "lm_head.weight", (int64_t)c.t_vocab * TH);
-    QHIP(h, vqs::launch_rmsnorm(w.hidden, pend, fin, w.xn, M, TH, c.t_eps, st), "final norm");
+    QHIP(h, vqs::launch_rmsnorm(w.hidden, pend_attn ? pend_attn : pend, fin, w.xn, M, TH, c.t_eps, st, pend_attn ? pend : nullptr), "final norm");
     QHIP(h, vqs::launch_gather_rows_bf16(w.xn, nullptr, d_last_row, w.last, B, TH, TH, TH, st), "last positions");
     {
         GCall g{w.last, head, d_logits};

@@ -65,6 +65,7 @@ _SIGNATURES = {
     "vqs_decoder_attention": (_c_i32, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp] + [_c_i32] * 7 + [_c_vp]),
     "vqs_rmsnorm": (_c_i32, [_c_vp, _c_vp, _c_vp, _c_vp, _c_i32, _c_i32, _c_f32, _c_vp]),
     "vqs_layernorm": (_c_i32, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i32, _c_i32, _c_i32, _c_f32, _c_vp]),
+    "vqs_norm_deferred": (_c_i32, [_c_i32, _c_vp, _c_vp, _c_vp, _c_i32, _c_vp, _c_vp, _c_vp, _c_i32, _c_i32, _c_f32, _c_vp]),
     "vqs_score_head": (_c_i32, [_c_vp, _c_i32, _c_i32, _c_vp, _c_vp, _c_vp, _c_i32, _c_i32, _c_vp]),
     "vqs_relpos_bucket": (_c_i32, [_c_i32, _c_i32, _c_i32, _c_i32]),
 }
@@ -440,6 +441,22 @@ def layernorm(x, w, b, eps, out_f32=False, delta=None):
                            eps, _stream_ptr())
     if rc != 0:
         raise VqsError(f"vqs_layernorm failed ({rc})")
+    return out
+
+
+def norm_deferred(x, w, eps, delta, delta2=None, store_x=True, b=None):
+    """The deferred-store norm forms (include/vqs.h): (delta, store_x=False) leaves x untouched; (delta, delta2) stores
+    x = (x + delta) + delta2.  RMSNorm when b is None, LayerNorm otherwise; bf16 output."""
+    lib = load_library()
+    M, D = x.shape
+    for d in (delta, delta2):
+        if d is not None and (d.dtype != torch.bfloat16 or tuple(d.shape) != (M, D) or not d.is_contiguous()):
+            raise VqsError("norm_deferred: deltas must be contiguous bf16 [M, D] tensors")
+    out = torch.empty(M, D, dtype=torch.bfloat16, device=x.device)
+    rc = lib.vqs_norm_deferred(0 if b is None else 1, x.data_ptr(), _ptr(delta), _ptr(delta2), 1 if store_x else 0, w.data_ptr(),
+                               _ptr(b), out.data_ptr(), M, D, eps, _stream_ptr())
+    if rc != 0:
+        raise VqsError(f"vqs_norm_deferred failed ({rc})")
     return out
 
 

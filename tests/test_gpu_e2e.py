@@ -257,6 +257,28 @@ def test_fused_residual_rmsnorm_matches_separate_kernels(monkeypatch):
     assert e0 <= 2 * LOGPROB_TOL_BF16 and e1 <= 2 * LOGPROB_TOL_BF16 and d01 <= 2 * LOGPROB_TOL_BF16, (e0, e1, d01)
 
 
+def test_deferred_stream_store_is_bitwise_the_stored_form(monkeypatch):
+    """Default: the post-attention norm of a layer does not write the fp32 stream and the next pre-norm stores
+    (hidden + attention delta) + mlp delta (22 instead of 24 bytes per element and layer).  VQS_NORM_DEFER=0 stores in
+    every norm.  The fp32 additions are the same in the same order, so features, log-probs and scores must be bitwise
+    equal (vision tower, T5 encoder; the decoder always stores)."""
+    from t2v_metrics_amd.engine import VqsEngine
+    cfg = get_config("small")
+    w = make_seeded_weights(cfg, seed=29, device="cpu", lm_head_gain=2.0)
+    pix, img_index, ids, labels = _inputs(cfg, 6, 3, 19, 2, seed=10)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("VQS_NORM_DEFER", mode)
+        eng = VqsEngine(cfg, w, device="cuda:0")
+        feats = eng.encode_images(pix.cuda())
+        lp, sc = eng.score(feats, img_index, ids, labels)
+        torch.cuda.synchronize()
+        out[mode] = (feats.cpu().clone(), lp.cpu(), sc.cpu())
+        eng.close()
+    for a, b in zip(out["0"], out["1"]):
+        assert torch.equal(a, b)
+
+
 def test_engine_matches_hf_golden_fixture(golden_dir):
     """The committed HF-module fixture (tests/golden/hf_tiny.npz): vision hidden_states[-2] from the HIP tower."""
     from t2v_metrics_amd.engine import VqsEngine

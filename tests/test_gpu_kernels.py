@@ -269,6 +269,39 @@ def test_norms(eng, M, D):
     assert_close(out, torch.nn.functional.layer_norm(xs, (D,), w.float(), b.float(), 1e-5), 1e-2, 1e-2, "layernorm+add")
 
 
+@pytest.mark.parametrize("M,D", [(9, 96), (257, 1024), (130, 2048), (33, 4096), (65, 1280), (40, 3584)])
+@pytest.mark.parametrize("kind", ["rms", "layer"])
+def test_norm_deferred_store_is_bitwise_the_stored_form(eng, M, D, kind):
+    """vqs_norm_deferred: a layer's two norms as (x + d1, not stored) then (x = (x + d1) + d2, stored) must reproduce --
+    bit for bit, stream and outputs -- the two stored single-delta updates they replace (HF modeling_t5.py:140,400;
+    modeling_clip.py:366,371), and the not-stored form must leave the stream untouched."""
+    g = torch.Generator(device="cuda").manual_seed(91)
+    x0 = torch.randn(M, D, device="cuda", generator=g) * 3.0 + 0.25
+    d1 = torch.randn(M, D, device="cuda", generator=g).to(torch.bfloat16)
+    d2 = (torch.randn(M, D, device="cuda", generator=g) * 0.5).to(torch.bfloat16)
+    w = randn_bf16(D, seed=92)
+    b = randn_bf16(D, seed=93) if kind == "layer" else None
+    eps = 1e-5 if kind == "layer" else 1e-6
+
+    def stored(x, delta):
+        return eng.layernorm(x, w, b, eps, delta=delta) if kind == "layer" else eng.rmsnorm(x, w, eps, delta=delta)
+
+    xa = x0.clone()
+    out_a1 = stored(xa, d1)
+    mid = xa.clone()
+    out_a2 = stored(xa, d2)
+    xb = x0.clone()
+    out_b1 = eng.norm_deferred(xb, w, eps, d1, store_x=False, b=b)
+    assert torch.equal(xb, x0), "the not-stored form modified the stream"
+    assert torch.equal(out_b1, out_a1)
+    out_b2 = eng.norm_deferred(xb, w, eps, d1, delta2=d2, b=b)
+    assert torch.equal(xb, xa) and torch.equal(out_b2, out_a2)
+    assert_close(mid, x0 + d1.float(), 1e-6, 1e-6, "first stored update")
+    assert_close(xa, (x0 + d1.float()) + d2.float(), 1e-6, 1e-6, "second stored update")
+    with pytest.raises(eng.VqsError):           # two deltas cannot be combined with "do not store"
+        eng.norm_deferred(xb, w, eps, d1, delta2=d2, store_x=False, b=b)
+
+
 def test_normalize_u8_matches_the_host_processor_arithmetic(eng):
     """vqs_normalize_u8 == ((x * 1/255) - mean) / std in fp32, rounded to bf16: bit-exact against the host path
     (t2v_metrics_amd/preprocess.py, itself pinned to HF's CLIPImageProcessor in tests/golden/clip_preprocess.npz)."""
