@@ -19,6 +19,7 @@
 //     of tiles, walked in groups of 8 M-tiles x all N-tiles so neighbours share panels in that L2).
 // M and N edges are handled by clamping source rows and predicating stores; K must be a multiple of 64.
 #include "vqs_kernels.h"
+#include <cstdlib>
 
 // Lab-only ablation switches (tools/gemm_lab.sh builds variants; the product build leaves this at 0):
 //   1 = no global->LDS staging after the first K-tile, 2 = no epilogue stores, 4 = fragments read from LDS once
@@ -726,6 +727,18 @@ __device__ __forceinline__ void bglds4(v4i_t rsrc, uint32_t voff, uint32_t lds_d
         : "=&s"(keep)
         : "v"(voff), "s"(rsrc), "s"(lds_dst));
 }
+// the same with an SGPR byte offset (the K-tile): L2 prefetch of a K-tile two ahead (TOUCH variant of the persistent kernel)
+__device__ __forceinline__ void bglds4s(v4i_t rsrc, uint32_t voff, uint32_t soff, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dword %1, %2, %4 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(rsrc), "s"(lds_dst), "s"(__builtin_amdgcn_readfirstlane(soff)));
+}
 __device__ __forceinline__ v4i_t make_rsrc(const void* base) {
     const uint64_t b = (uint64_t)base;
     v4i_t r;
@@ -736,11 +749,14 @@ __device__ __forceinline__ v4i_t make_rsrc(const void* base) {
     return r;
 }
 
-template <int EPI>
+// TOUCH (lab, VQS_L2_TOUCH): waves 0 and 4 pull the lines of the K-tile TWO ahead into L2 with one dword LDS-DMA per
+// K-tile (64 A rows / 32 W rows each: the 4 / 8 workgroups of an XCD's 8x4 tile window that share a panel split it), so
+// that the real staging DMA of an operand streamed from HBM finds it in L2.  A hint only: results are unaffected.
+template <int EPI, int TOUCH = 0>   // TOUCH: 0 off, 1 A and W panels, 2 A panel only
 __global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) {
     __shared__ __attribute__((aligned(16))) char lds[2 * STAGE_BYTES];
     __shared__ float rowred[EPI == EPI_RESID_RMS ? 1024 : 1];   // per-row partial sums of squares of the 4 wave columns
-    __shared__ __attribute__((aligned(16))) char touch_sink[EPI == EPI_RESID_RMS ? 2048 : 16];   // landing area of the L2-touch DMA
+    __shared__ __attribute__((aligned(16))) char touch_sink[(EPI == EPI_RESID_RMS || TOUCH != 0) ? 2048 : 16];   // landing area of the L2-touch DMA
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -829,6 +845,21 @@ __global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) 
 #endif
     int buf = 0;
     bool counted = false;     // true: the only VMEM ops younger than the prefetched K-tile are a full epilogue's stores
+    // TOUCH state (batch <= 1 only, enforced by the launcher)
+    constexpr int TDIST = 2;            // K-tiles ahead (3 measured the same)
+    const bool touch_wave = TOUCH != 0 && (w == 0 || (w == 4 && TOUCH == 1)) && nt >= TDIST;
+    const v4i_t rsT = make_rsrc(w < 4 ? (const void*)p.A : (const void*)p.W);
+    const uint32_t touch_dst = (uint32_t)(uintptr_t)LDS_PTR(touch_sink) + w * 256;
+    auto touch_off = [&](int tm0, int tn0) -> uint32_t {
+        if (w < 4) {
+            const int row = min(tm0 + 64 * ((tn0 / BN) & 3) + lane, p.M - 1);
+            return (uint32_t)((size_t)row * p.lda * 2);
+        }
+        const int row = min(tn0 + 32 * ((tm0 / BM) & 7) + (lane & 31), p.N - 1);
+        return (uint32_t)((size_t)row * p.ldw * 2);
+    };
+    uint32_t t_cur = 0, t_nxt = 0;
+    bool did_touch = false;
 
     while (true) {
         f32x16 acc[4][2];
@@ -842,6 +873,16 @@ __global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) 
         const int next_pid = pid + gridDim.x;
         const bool has_next = next_pid < nwg;
         int nm0 = 0, nn0 = 0, nbz = 0;
+        if constexpr (TOUCH) {
+            if (touch_wave) {
+                t_cur = touch_off(m0, n0);
+                if (has_next) {
+                    int xm0, xn0, xbz;
+                    tile_coords(next_pid, xm0, xn0, xbz);
+                    t_nxt = touch_off(xm0, xn0);
+                }
+            }
+        }
 
         for (int t = 0; t < nt; ++t) {
             TSTAMP(ts0);
@@ -850,9 +891,12 @@ __global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) 
                 else if constexpr (EpiStores<EPI>::value == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
                 else if constexpr (EpiStores<EPI>::value == 64) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");   // counter is 6 bits
                 else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            } else if (TOUCH != 0 && t > 0 && did_touch) {
+                asm volatile("s_waitcnt vmcnt(1)" ::: "memory");     // the touch issued after this K-tile's DMA may still fly
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
+            did_touch = false;
             TSTAMP(ts1);
             __builtin_amdgcn_s_barrier();
             TSTAMP(ts2);
@@ -894,6 +938,22 @@ __global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) 
                             const int row = min(m0 + (l >> 3), p.M - 1);
                             const int colf = min(n0 + (l & 7) * 32, p.N - 1);
                             bglds4(rsH, (uint32_t)(((size_t)row * p.ldh + colf) * 4), sink);
+                        }
+                    }
+                }
+                if constexpr (TOUCH) {
+                    if (ks == 2 && touch_wave) {
+                        int kt2 = t + TDIST;
+                        uint32_t voff = t_cur;
+                        bool ok = true;
+                        if (kt2 >= nt) {
+                            kt2 -= nt;
+                            voff = t_nxt;
+                            ok = has_next;
+                        }
+                        if (ok) {
+                            bglds4s(rsT, voff, (uint32_t)(kt2 * BK * 2), touch_dst);
+                            did_touch = true;
                         }
                     }
                 }
@@ -1451,6 +1511,13 @@ __global__ void __launch_bounds__(512) gemm_bf16_pingpong(const GemmParams p) {
 #undef VQS_WAIT_NEXT
 #undef VQS_WAIT_NONE
 
+// VQS_L2_TOUCH: 4 (default) = A-panel touch for N <= 2048; 3 = A and W panels for N <= 2048; 1 = A and W for every
+// lock-step launch; 0 = off
+static int l2_touch_mode() {
+    static const int mode = [] { const char* e = std::getenv("VQS_L2_TOUCH"); return e ? std::atoi(e) : 4; }();
+    return mode;
+}
+
 template <int EPI>
 static hipError_t launch_epi(const GemmParams& p, int variant, hipStream_t stream) {
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
@@ -1491,11 +1558,19 @@ static hipError_t launch_epi(const GemmParams& p, int variant, hipStream_t strea
         } else {
             const int nwg = tiles_m * tiles_n * (p.batch > 0 ? p.batch : 1);
             dim3 pgrid(nwg < PERSISTENT_WGS ? nwg : PERSISTENT_WGS);
-            // the default (variant 3) picks the schedule by shape: short-K, narrow-N GEMMs (the ViT's qkv / out_proj:
-            // K = 1024, N <= 3072) measured 5-10 % faster on the ping-pong schedule, everything else equal or 1-4 %
-            // faster on the lock-step one.  Both produce bitwise-identical results.
-            if (variant != 7 && p.K <= 1024 && p.N <= 3072 && p.batch <= 1 && nwg >= PERSISTENT_WGS)   // 7 = lock-step forced (lab)
+            // L2 touch (see gemm_bf16_persistent): shapes whose A panel has at most two window columns of reuse (N <= 2048:
+            // ViT out_proj / fc2, T5 o / wo) stream A from HBM and gain 2-8 % from the prefetch; wider shapes re-read A
+            // from L2 / Infinity Cache and lose 1-3 % to the extra requests, so they keep the plain kernel.
+            const int tm = l2_touch_mode();
+            const bool touch = tm != 0 && p.batch <= 1 && nwg >= PERSISTENT_WGS && p.K >= 4 * BK && (tm == 1 || p.N <= 2048);
+            // schedule by shape: the ViT qkv (K = 1024, 2048 < N <= 3072) is 0-1 % faster on the ping-pong schedule; with
+            // the touch the lock-step kernel wins on out_proj (+7 %).  All of them produce bitwise-identical results.
+            if (variant != 7 && !touch && p.K <= 1024 && p.N <= 3072 && p.batch <= 1 && nwg >= PERSISTENT_WGS)   // 7 = lock-step forced (lab)
                 hipLaunchKernelGGL((gemm_bf16_pingpong<EPI>), pgrid, block, 0, stream, p);
+            else if (touch && (tm == 1 || tm == 3))
+                hipLaunchKernelGGL((gemm_bf16_persistent<EPI, 1>), pgrid, block, 0, stream, p);
+            else if (touch)
+                hipLaunchKernelGGL((gemm_bf16_persistent<EPI, 2>), pgrid, block, 0, stream, p);
             else
                 hipLaunchKernelGGL((gemm_bf16_persistent<EPI>), pgrid, block, 0, stream, p);
         }
