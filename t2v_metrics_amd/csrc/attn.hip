@@ -352,18 +352,6 @@ __device__ __forceinline__ void a_bglds16(a_v4i rsrc, uint32_t voff, uint32_t ld
         : "=&s"(keep)
         : "v"(voff), "s"(rsrc), "s"(lds_dst));
 }
-// dword form: pulls one 128-B line per lane into L2; the 4 bytes land in a sink nobody reads
-__device__ __forceinline__ void a_bglds4(a_v4i rsrc, uint32_t voff, uint32_t lds_dst) {
-    uint32_t keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %3\n\t"
-        "s_nop 0\n\t"
-        "buffer_load_dword %1, %2, 0 offen lds\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(voff), "s"(rsrc), "s"(lds_dst));
-}
 __device__ __forceinline__ a_v4i a_make_rsrc(const void* base) {
     const uint64_t b = (uint64_t)base;
     a_v4i r;
@@ -378,7 +366,6 @@ static constexpr int ST_BYTES = 16384;       // one stage: K 8 KiB + V 8 KiB
 template <bool HAS_BIAS>
 __global__ void __launch_bounds__(256) attn_fwd_dma_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ __attribute__((aligned(16))) char touch_sink[512];
     float* bias_s = reinterpret_cast<float*>(smem + 2 * ST_BYTES);
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)A_LDS_PTR(smem));
 
@@ -467,24 +454,12 @@ __global__ void __launch_bounds__(256) attn_fwd_dma_kernel(const AttnParams p) {
     // them inside the loop body, where every iteration they would also drain the next tile's in-flight DMA.
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[ks].x), "+v"(qf[ks].y), "+v"(qf[ks].z), "+v"(qf[ks].w));
-    // L2 touch (p.touch): wave 0 / wave 1 pull the 64 K / V rows (one 128-B line each) of the tile TWO ahead into L2 with
-    // one dword DMA per tile, issued after the staging pieces so that vmcnt(1) lets it stay in flight over the barrier
-    const bool touch_wave = p.touch != 0 && wv < 2;
-    const a_v4i rsT = wv == 0 ? rsK : rsV;
-    const uint32_t touch_dst = (uint32_t)(uintptr_t)A_LDS_PTR(touch_sink) + wv * 256;
-    bool touched = false;
     if (ntiles > 0) stage(0, 0);
     for (int kt = 0; kt < ntiles; ++kt) {
         const int st = kt & 1;
-        if (touched) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile kt have landed
-        touched = false;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of tile kt have landed
         __syncthreads();                                       // ... everybody's; stage st^1 is no longer read
         if (kt + 1 < ntiles && !(VQS_ATTN_ABLATE & 1)) stage(kt + 1, st ^ 1);
-        if (touch_wave && kt + 2 < ntiles) {
-            a_bglds4(rsT, (uint32_t)min((kt + 2) * KT + lane, S - 1) * 128u, touch_dst);
-            touched = true;
-        }
         const char* k_lds = smem + ((VQS_ATTN_ABLATE & 1) ? 0 : st) * ST_BYTES;
 
         // ---- S^T = K . Q^T   (i <-> key, j <-> query)
@@ -885,11 +860,8 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
         return p.bias_table ? launch_attn_t(attn_fwd_kernel<true>, p, lds, stream) : launch_attn_t(attn_fwd_kernel<false>, p, lds, stream);
     }
     const size_t lds = 2 * ST_BYTES + bias_bytes;
-    static const int touch = [] { const char* e = getenv("VQS_ATTN_TOUCH"); return e ? atoi(e) : 0; }();
-    AttnParams q = p;
-    q.touch = touch;
-    return p.bias_table ? launch_attn_t(attn_fwd_dma_kernel<true>, q, lds, stream)
-                        : launch_attn_t(attn_fwd_dma_kernel<false>, q, lds, stream);
+    return p.bias_table ? launch_attn_t(attn_fwd_dma_kernel<true>, p, lds, stream)
+                        : launch_attn_t(attn_fwd_dma_kernel<false>, p, lds, stream);
 }
 
 // =====================================================================================================

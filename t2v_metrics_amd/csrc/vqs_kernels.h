@@ -71,7 +71,6 @@ struct AttnParams {
     int hd = 0;               // 0 / 64: the kernels above
     int Hkv = 0;              // key/value heads (0 = H); query head h reads head h / (H / Hkv)
     int causal = 0;           // key <= query
-    int touch = 0;            // hd-64 DMA kernel: L2 prefetch of the K / V tile two ahead (set by the launcher, VQS_ATTN_TOUCH)
 };
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream);
 
