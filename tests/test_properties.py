@@ -1,0 +1,146 @@
+"""Property tests (hypothesis) of the integer / host logic around the hot path: they run on the CPU and need no GPU.
+Each property is the size-independent statement the corresponding fixture test checks at a few points."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+from hypothesis import given, settings, strategies as st
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ------------------------------------------------------------------ sharding (score.py:104-106 cells are independent)
+@settings(max_examples=200, deadline=None)
+@given(n=st.integers(0, 5000), ws=st.integers(1, 64))
+def test_shard_range_is_a_balanced_contiguous_partition(n, ws):
+    from t2v_metrics_amd.sharding import shard_range
+    blocks = [shard_range(n, r, ws) for r in range(ws)]
+    assert blocks[0][0] == 0 and blocks[-1][1] == n
+    sizes = []
+    for (lo, hi), nxt in zip(blocks, blocks[1:] + [(n, n)]):
+        assert 0 <= lo <= hi <= n and hi == nxt[0]
+        sizes.append(hi - lo)
+    assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+
+
+# ------------------------------------------------------------------ T5 relative-position buckets (HF modeling_t5.py:224-269)
+def _c_bucket_lib():
+    so = os.path.join(ROOT, "oracle", "_build", "librelpos_oracle.so")
+    if not os.path.exists(so):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+    return ctypes.CDLL(so)
+
+
+@settings(max_examples=60, deadline=None)
+@given(rel=st.lists(st.integers(-6000, 6000), min_size=1, max_size=64), bidir=st.booleans(),
+       nb=st.sampled_from([8, 16, 32, 64]), md=st.sampled_from([16, 64, 128, 256]))
+def test_relpos_bucket_three_restatements_agree_with_hf(rel, bidir, nb, md):
+    """numpy oracle == C oracle == the library's host function == HF's T5Attention._relative_position_bucket, for any
+    distance, direction, bucket count and max distance (the fixture pins 1 401 points of the (32, 128) case)."""
+    from oracle.clip_t5_oracle import relative_position_bucket
+    from t2v_metrics_amd import engine
+    rp = np.asarray(rel, dtype=np.int32)
+    ref_np = relative_position_bucket(rp, bidir, nb, md).astype(np.int64)
+    out = np.empty(rp.size, dtype=np.int32)
+    _c_bucket_lib().t5_relpos_bucket_many(rp.ctypes.data_as(ctypes.c_void_p), ctypes.c_int32(rp.size), ctypes.c_int32(int(bidir)),
+                                          ctypes.c_int32(nb), ctypes.c_int32(md), out.ctypes.data_as(ctypes.c_void_p))
+    assert np.array_equal(out.astype(np.int64), ref_np)
+    lib_out = np.asarray([engine.relpos_bucket(int(r), bidir, nb, md) for r in rel], dtype=np.int64)
+    assert np.array_equal(lib_out, ref_np)
+    try:
+        from transformers.models.t5.modeling_t5 import T5Attention
+    except Exception:            # transformers is part of the image; keep the test meaningful without it
+        return
+    hf = T5Attention._relative_position_bucket(torch.from_numpy(rp.astype(np.int64)), bidirectional=bidir, num_buckets=nb,
+                                               max_distance=md).numpy()
+    assert np.array_equal(hf, ref_np)
+    assert ref_np.min() >= 0 and ref_np.max() < nb
+
+
+# ------------------------------------------------------------------ Qwen2.5-VL host layout (HF vision_utils.py:81-188)
+@settings(max_examples=80, deadline=None)
+@given(t=st.integers(1, 3), gh=st.integers(1, 20), gw=st.integers(1, 20))
+def test_window_slots_place_every_cell_exactly_once(t, gh, gw):
+    from t2v_metrics_amd.qwen.layout import window_slots
+    merge, window, patch = 2, 112, 14
+    ws = window // merge // patch
+    slots, valid = window_slots(t, gh * merge, gw * merge, merge, window, patch)
+    assert slots.numel() == valid.numel() * ws * ws
+    present = slots[slots >= 0]
+    assert torch.equal(torch.sort(present).values, torch.arange(t * gh * gw))        # a permutation of the cells
+    assert int(valid.sum()) == t * gh * gw and int(valid.min()) >= 1 and int(valid.max()) <= ws * ws
+    win = slots.reshape(-1, ws * ws)
+    for row, v in zip(win, valid):                 # present cells first, in row-major (increasing) order, then padding
+        v = int(v)
+        assert bool((row[:v] >= 0).all()) and bool((row[v:] < 0).all())
+        assert torch.equal(row[:v], torch.sort(row[:v]).values)
+    # every window lies inside one frame and one ws x ws block of cells
+    frame = present.new_tensor([int(c) // (gh * gw) for c in win[:, 0]])
+    for row, v, f in zip(win, valid, frame):
+        cells = row[: int(v)]
+        assert bool((cells // (gh * gw) == f).all())
+        r, c = (cells % (gh * gw)) // gw, (cells % (gh * gw)) % gw
+        assert int(r.max() - r.min()) < ws and int(c.max() - c.min()) < ws
+
+
+@settings(max_examples=40, deadline=None)
+@given(t=st.integers(1, 2), gh=st.integers(1, 12), gw=st.integers(1, 12), nvid=st.integers(1, 3))
+def test_vision_layout_maps_are_mutually_inverse(t, gh, gw, nvid):
+    from t2v_metrics_amd.qwen.config import get_qwen_config
+    from t2v_metrics_amd.qwen.layout import vision_layout
+    cfg = get_qwen_config("qwen-tiny")
+    m = cfg.vision.spatial_merge
+    lay = vision_layout(cfg, [(t, gh * m, gw * m)] * nvid)
+    N, Np, unit = lay["N"], lay["Np"], cfg.vision.merge_unit
+    row_map, inv_row = lay["row_map"].long(), lay["inv_row"].long()
+    assert N == nvid * t * gh * gw * unit and row_map.numel() == Np and Np % lay["win_len"] == 0
+    assert torch.equal(row_map[inv_row], torch.arange(N))                 # windowed slot of patch i holds patch i
+    real = row_map >= 0
+    assert int(real.sum()) == N and int(lay["win_valid"].sum()) == N
+    assert torch.equal(inv_row[row_map[real]], torch.nonzero(real)[:, 0])
+    cell_inv = lay["cell_inv"].long()
+    assert torch.equal(torch.sort(cell_inv).values, torch.unique(cell_inv)) and cell_inv.numel() == N // unit
+    # the 4 patches of a merge cell stay consecutive in the windowed layout (the merger concatenates them)
+    first = row_map.reshape(-1, unit)[:, 0]
+    assert bool(((row_map.reshape(-1, unit) - first[:, None])[first >= 0] == torch.arange(unit)).all())
+    # padded slots carry a zero rotation (cos 1, sin 0), real ones the frame table's entry of their patch
+    assert torch.equal(lay["cos_w"][~real], torch.ones_like(lay["cos_w"][~real]))
+    assert torch.equal(lay["cos_w"][real], lay["cos_f"][row_map[real]])
+
+
+@settings(max_examples=300, deadline=None)
+@given(h=st.integers(16, 5000), w=st.integers(16, 5000))
+def test_smart_resize_properties_and_hf_equality(h, w):
+    from t2v_metrics_amd.models.vqascore_models.qwen25vl_model import smart_resize
+    if max(h, w) / min(h, w) > 200:
+        with pytest.raises(ValueError):
+            smart_resize(h, w)
+        return
+    factor, lo, hi = 28, 56 * 56, 14 * 14 * 4 * 1280
+    hb, wb = smart_resize(h, w, factor, lo, hi)
+    assert hb % factor == 0 and wb % factor == 0 and hb >= factor and wb >= factor
+    assert hb * wb <= hi
+    if h * w >= lo:
+        assert hb * wb >= lo or min(hb, wb) == factor
+    try:
+        from transformers.models.qwen2_vl.image_processing_qwen2_vl import smart_resize as hf_smart_resize
+    except Exception:
+        return
+    assert (hb, wb) == tuple(hf_smart_resize(h, w, factor=factor, min_pixels=lo, max_pixels=hi))
+
+
+# ------------------------------------------------------------------ decoder inputs (HF modeling_t5.py:618-640)
+@settings(max_examples=100, deadline=None)
+@given(rows=st.lists(st.lists(st.integers(-1, 50), min_size=1, max_size=6), min_size=1, max_size=4))
+def test_shift_right_matches_the_hf_rule(rows):
+    from oracle.clip_t5_oracle import shift_right
+    T = max(len(r) for r in rows)
+    lab = torch.tensor([[(-100 if v < 0 else v) for v in r] + [-100] * (T - len(r)) for r in rows])
+    out = shift_right(lab)
+    assert out.shape == lab.shape and bool((out[:, 0] == 0).all())
+    exp = lab[:, :-1].clone()
+    exp[exp == -100] = 0
+    assert torch.equal(out[:, 1:], exp)
