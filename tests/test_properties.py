@@ -6,7 +6,9 @@ import os
 import numpy as np
 import pytest
 import torch
-from hypothesis import given, settings, strategies as st
+
+pytest.importorskip("hypothesis")
+from hypothesis import assume, given, settings, strategies as st  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -42,6 +44,10 @@ def test_relpos_bucket_three_restatements_agree_with_hf(rel, bidir, nb, md):
     distance, direction, bucket count and max distance (the fixture pins 1 401 points of the (32, 128) case)."""
     from oracle.clip_t5_oracle import relative_position_bucket
     from t2v_metrics_amd import engine
+    # the formula divides by log(max_distance / max_exact): configurations with max_distance <= max_exact are degenerate
+    # in HF itself (0/0 cast to an integer) and no T5 uses them (T5 / Flan-T5: 32 buckets, max distance 128)
+    max_exact = (nb // 2 if bidir else nb) // 2
+    assume(md > max_exact)
     rp = np.asarray(rel, dtype=np.int32)
     ref_np = relative_position_bucket(rp, bidir, nb, md).astype(np.int64)
     out = np.empty(rp.size, dtype=np.int32)
