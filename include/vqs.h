@@ -186,6 +186,10 @@ int vqs_norm_deferred(int32_t kind, float* d_x, const void* d_delta, const void*
 int vqs_score_head(const float* d_logits, int32_t ldl, int32_t V, const int32_t* d_labels, float* d_label_logprobs,
                    float* d_scores, int32_t B, int32_t T, void* stream);
 /* host-side bucket function used to build the bias tables (HF models/t5/modeling_t5.py:216-262) */
+/* Host-side arithmetic, no device access: dynamic LDS bytes vqs_attention / vqs_attention_hd request per workgroup for
+ * sequence length S (hd 0 / 64 / 128).  The kernels' occupancy hangs on it (160 KiB of LDS per CU in 1 280-B granules);
+ * -1 on bad arguments. */
+int64_t vqs_attention_lds_bytes(int32_t S, int32_t has_bias, int32_t hd);
 int32_t vqs_relpos_bucket(int32_t relative_position, int32_t bidirectional, int32_t num_buckets, int32_t max_distance);
 
 #ifdef __cplusplus

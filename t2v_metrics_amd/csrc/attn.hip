@@ -864,6 +864,15 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
                         : launch_attn_t(attn_fwd_dma_kernel<false>, p, lds, stream);
 }
 
+// Dynamic LDS request of the self-attention kernel launch_attention() picks for (S, bias, hd): what the occupancy of the
+// kernel hangs on (gfx950 allocates LDS in 1 280-B granules out of 160 KiB per CU; T5-XL, S = 608 with bias: 53 504 B ->
+// three workgroups per CU with 1.1 KiB to spare each -- tests/test_build_invariants.py guards it).
+size_t attention_lds_bytes(int S, bool has_bias, int hd) {
+    if (hd == 128) return 2 * 2 * (size_t)KT * 128 * 2;
+    const size_t bias_bytes = has_bias ? (size_t)bias_copy_chunks(S) * 64 : 0;
+    return (attn_variant() == 0 ? (size_t)(K_LDS + VT_LDS) : (size_t)(2 * ST_BYTES)) + bias_bytes;
+}
+
 // =====================================================================================================
 // Decoder attention: T query rows per (sample, head); fp32 VALU.
 // =====================================================================================================

@@ -304,6 +304,11 @@ int run_gemm(vqs_handle* h, const GemmCall& g, hipStream_t st, const char* what)
 
 extern "C" {
 
+int64_t vqs_attention_lds_bytes(int32_t S, int32_t has_bias, int32_t hd) {
+    if (S <= 0 || (hd != 0 && hd != 64 && hd != 128)) return -1;
+    return (int64_t)vqs::attention_lds_bytes(S, has_bias != 0, hd);
+}
+
 int32_t vqs_relpos_bucket(int32_t relative_position, int32_t bidirectional, int32_t num_buckets, int32_t max_distance) {
     // HF models/t5/modeling_t5.py:238-262, same fp32 operation order as torch.
     int32_t bucket = 0, nb = num_buckets, rp = relative_position;

@@ -73,6 +73,7 @@ struct AttnParams {
     int causal = 0;           // key <= query
 };
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream);
+size_t attention_lds_bytes(int S, bool has_bias, int hd);   // dynamic LDS request of that launch (host-side arithmetic)
 
 // decoder attention (T <= 16 query rows per sample; fp32 VALU): self (causal + bucket bias) and cross.
 struct DecAttnParams {
