@@ -62,12 +62,16 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {
 }
 
 // x * sigmoid(1.702 x)                                               HF activations.py:117-123
-__device__ __forceinline__ float act_quick_gelu(float x) { return x * __frcp_rn(1.0f + __expf(-1.702f * x)); }
+// sigmoid's reciprocal is the hardware v_rcp_f32 (1 ulp): __frcp_rn is a correctly rounded division -- two v_div_scale, v_rcp,
+// five FMAs, v_div_fmas, v_div_fixup per element (ISA), 9 extra VALU instructions per output element in an epilogue that no
+// MFMA work overlaps -- for a result that is rounded to bf16 next.  The argument lies in [1, +inf]; rcp(+inf) = 0.
+__device__ __forceinline__ float fast_rcp(float y) { return __builtin_amdgcn_rcpf(y); }
+__device__ __forceinline__ float act_quick_gelu(float x) { return x * fast_rcp(1.0f + __expf(-1.702f * x)); }
 __device__ __forceinline__ float act_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 // 0.5 x (1 + tanh(u)), u = sqrt(2/pi)(x + 0.044715 x^3)  ==  x * sigmoid(2u)      HF activations.py:59-66
 __device__ __forceinline__ float act_gelu_new(float x) {
     const float u2 = 1.5957691216057308f * (x + 0.044715f * x * x * x);   // 2u
-    return x * __frcp_rn(1.0f + __expf(-u2));
+    return x * fast_rcp(1.0f + __expf(-u2));
 }
 
 // One 1-KiB direct-to-LDS piece: lane l's 16 bytes from `src` land at LDS byte address dst + 16*l.
@@ -562,7 +566,7 @@ __device__ __forceinline__ void staged_epilogue(const GemmParams& p, f32x16 (&ac
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float gv = acc[m][0][4 * g + e];
-                        const float a = silu ? gv * __frcp_rn(1.0f + __expf(-gv)) : act_gelu_new(gv);
+                        const float a = silu ? gv * fast_rcp(1.0f + __expf(-gv)) : act_gelu_new(gv);
                         o[e] = a * acc[m][1][4 * g + e];
                     }
                     uint2 v;
