@@ -186,6 +186,10 @@ int vqs_norm_deferred(int32_t kind, float* d_x, const void* d_delta, const void*
 int vqs_score_head(const float* d_logits, int32_t ldl, int32_t V, const int32_t* d_labels, float* d_label_logprobs,
                    float* d_scores, int32_t B, int32_t T, void* stream);
 /* host-side bucket function used to build the bias tables (HF models/t5/modeling_t5.py:216-262) */
+/* Host-side test hook, no device access: the element offsets into a head-major [B, hx, S, hdim] tensor that the GEMM's
+ * head-major epilogue (EPI_HEADS, the QKV projections' scatter -- HF modeling_t5.py:311-323 view/transpose) uses for the
+ * rows row0 + 8k, k = 0..n-1, computed by the SAME inline functions as the kernel (one division, then steps).  S >= 8. */
+int vqs_debug_heads_rows(int32_t row0, int32_t S, int32_t hx, int32_t hdim, int32_t n, int64_t* off_out);
 /* Host-side arithmetic, no device access: dynamic LDS bytes vqs_attention / vqs_attention_hd request per workgroup for
  * sequence length S (hd 0 / 64 / 128).  The kernels' occupancy hangs on it (160 KiB of LDS per CU in 1 280-B granules);
  * -1 on bad arguments. */

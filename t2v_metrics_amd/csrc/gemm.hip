@@ -649,6 +649,14 @@ __device__ __forceinline__ void staged_epilogue(const GemmParams& p, f32x16 (&ac
                 const int head = (cw - base) / hdim;
                 head_base = hp + (size_t)head * p.S * hdim + ((cw - base) - head * hdim);
             }
+            // EPI_HEADS: this lane's 16 stores go to rows row_w + (lane >> 3) + 8k, k = 0..15, in that order: split the first
+            // row into (sample, position) once, then step (needs S >= 8: the launcher sends shorter sequences to variant 0)
+            int hs_run = 0;
+            long long off_run = 0, off_wrap = 0;              // element offset of the current row; what a sample boundary adds
+            if constexpr (EPI == EPI_HEADS) {
+                heads_off_first(row_w + (lane >> 3), p.S, hx, hdim, hs_run, off_run);
+                off_wrap = (long long)(hx - 1) * p.S * hdim;
+            }
 #pragma unroll
             for (int hm = 0; hm < 2; ++hm) {                  // 64 rows x 128 B per pass
 #pragma unroll
@@ -686,13 +694,13 @@ __device__ __forceinline__ void staged_epilogue(const GemmParams& p, f32x16 (&ac
                     if (full || (row < p.M && col < p.N)) {
                         bf16_t* dst;
                         if constexpr (EPI == EPI_HEADS) {
-                            const int hb = row / p.S, hs = row - hb * p.S;
-                            dst = head_base + ((size_t)hb * hx * p.S + hs) * hdim + c * 8;
+                            dst = head_base + off_run + c * 8;
                         } else {
                             dst = reinterpret_cast<bf16_t*>(p.C) + (size_t)bz * p.sC + (size_t)row * p.ldc + col;
                         }
                         *reinterpret_cast<uint4*>(dst) = v;
                     }
+                    if constexpr (EPI == EPI_HEADS) heads_off_step8(p.S, hdim, off_wrap, hs_run, off_run);   // next row of this lane: + 8 (also across the hm passes)
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
@@ -1536,7 +1544,7 @@ static hipError_t launch_epi(const GemmParams& p, int variant, hipStream_t strea
             hipLaunchKernelGGL((gemm_bf16_persistent<EPI>), pgrid, block, 0, stream, p);
         return hipGetLastError();
     } else
-    if (variant == 0)
+    if (variant == 0 || (EPI == EPI_HEADS && p.S < 8 && variant != 1 && variant != 2))   // the staged epilogue steps rows by 8 within a sample
         hipLaunchKernelGGL((gemm_bf16_kernel<EPI, 0>), grid, block, 0, stream, p);
     else if (variant == 1)
         hipLaunchKernelGGL((gemm_bf16_kernel<EPI, 1>), grid, block, 0, stream, p);

@@ -304,6 +304,19 @@ int run_gemm(vqs_handle* h, const GemmCall& g, hipStream_t st, const char* what)
 
 extern "C" {
 
+int vqs_debug_heads_rows(int32_t row0, int32_t S, int32_t hx, int32_t hdim, int32_t n, int64_t* off_out) {
+    if (row0 < 0 || S < 8 || hx <= 0 || hdim <= 0 || n <= 0 || !off_out) return VQS_ERR_INVALID;
+    int hs;
+    long long off;
+    vqs::heads_off_first(row0, S, hx, hdim, hs, off);
+    const long long wrap = (long long)(hx - 1) * S * hdim;
+    for (int k = 0; k < n; ++k) {          // exactly the use-then-step order of the GEMM epilogue
+        off_out[k] = off;
+        vqs::heads_off_step8(S, hdim, wrap, hs, off);
+    }
+    return VQS_OK;
+}
+
 int64_t vqs_attention_lds_bytes(int32_t S, int32_t has_bias, int32_t hd) {
     if (S <= 0 || (hd != 0 && hd != 64 && hd != 128)) return -1;
     return (int64_t)vqs::attention_lds_bytes(S, has_bias != 0, hd);

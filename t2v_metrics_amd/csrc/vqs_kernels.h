@@ -54,6 +54,31 @@ struct GemmParams {
     float rs_invd = 0.0f, rs_eps = 0.0f;
 };
 
+// EPI_HEADS row split, shared by the kernel and its host-side test hook (vqs_debug_heads_rows): GEMM row -> (sample,
+// position).  A lane stores 16 rows per tile, 8 apart: one division for the first, then a step -- an integer division by the
+// run-time S costs ~28 VALU instructions, 16 of them per lane and tile were 460 of the epilogue's 1 278 (ISA).
+#if defined(__HIPCC__)
+#define VQS_HD __host__ __device__
+#else
+#define VQS_HD
+#endif
+// Row `row` of the GEMM is position hs = row % S of sample hb = row / S; its head-major destination is element
+// (hb * hx * S + hs) * hdim of the target tensor ([B, hx, S, hdim], this head's base already added).
+VQS_HD inline void heads_off_first(int row, int S, int hx, int hdim, int& hs, long long& off) {
+    const int hb = row / S;
+    hs = row - hb * S;
+    off = ((long long)hb * hx * S + hs) * hdim;
+}
+// row += 8 (requires S >= 8: at most one sample boundary per step); wrap = (hx - 1) * S * hdim
+VQS_HD inline void heads_off_step8(int S, int hdim, long long wrap, int& hs, long long& off) {
+    hs += 8;
+    off += 8 * hdim;
+    if (hs >= S) {
+        hs -= S;
+        off += wrap;
+    }
+}
+
 // variant 0 = direct-to-LDS (global_load_lds) staging; variant 1 = register-staged (debug / A-B)
 hipError_t launch_gemm(const GemmParams& p, int epilogue, int variant, hipStream_t stream);
 

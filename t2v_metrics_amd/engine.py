@@ -68,6 +68,7 @@ _SIGNATURES = {
     "vqs_norm_deferred": (_c_i32, [_c_i32, _c_vp, _c_vp, _c_vp, _c_i32, _c_vp, _c_vp, _c_vp, _c_i32, _c_i32, _c_f32, _c_vp]),
     "vqs_score_head": (_c_i32, [_c_vp, _c_i32, _c_i32, _c_vp, _c_vp, _c_vp, _c_i32, _c_i32, _c_vp]),
     "vqs_attention_lds_bytes": (ctypes.c_int64, [_c_i32, _c_i32, _c_i32]),
+    "vqs_debug_heads_rows": (_c_i32, [_c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_vp]),
     "vqs_relpos_bucket": (_c_i32, [_c_i32, _c_i32, _c_i32, _c_i32]),
 }
 

@@ -150,3 +150,26 @@ def test_shift_right_matches_the_hf_rule(rows):
     exp = lab[:, :-1].clone()
     exp[exp == -100] = 0
     assert torch.equal(out[:, 1:], exp)
+
+
+# ------------------------------------------------------------------ head-major scatter of the QKV GEMM epilogue (HF modeling_t5.py:311-323)
+@settings(max_examples=300, deadline=None)
+@given(row0=st.integers(0, 200_000), S=st.integers(8, 1300), hx=st.integers(1, 64), hdim=st.sampled_from([64, 128]),
+       n=st.integers(1, 64))
+def test_heads_epilogue_stepped_offsets_equal_the_division(row0, S, hx, hdim, n):
+    """The GEMM's head-major epilogue splits a lane's first row into (sample, position) once and then steps 8 rows at a
+    time (vqs_kernels.h: heads_off_first / heads_off_step8, the same inline functions the kernel compiles); the host hook
+    must reproduce  ((row // S) * hx * S + row % S) * hdim  for every row of the sequence."""
+    from t2v_metrics_amd import engine
+    lib = engine.load_library()
+    out = np.empty(n, dtype=np.int64)
+    assert lib.vqs_debug_heads_rows(row0, S, hx, hdim, n, out.ctypes.data_as(ctypes.c_void_p)) == 0
+    rows = row0 + 8 * np.arange(n, dtype=np.int64)
+    assert np.array_equal(out, ((rows // S) * hx * S + rows % S) * hdim)
+
+
+def test_heads_epilogue_hook_rejects_short_sequences():
+    from t2v_metrics_amd import engine
+    lib = engine.load_library()
+    out = np.empty(4, dtype=np.int64)
+    assert lib.vqs_debug_heads_rows(0, 7, 2, 64, 4, out.ctypes.data_as(ctypes.c_void_p)) != 0      # S < 8 runs variant 0 instead
