@@ -114,7 +114,7 @@ int vqs_generate(vqs_handle* h, const void* d_feats, const int32_t* d_img_index,
                  int32_t L, int32_t max_new, int32_t* d_tokens, void* d_ws, size_t ws_bytes, void* stream);
 
 /* Byte offset of a named intermediate inside the vqs_score / vqs_encode_images workspace (parity tests read
- * stages through this): "enc_in" fp32 [B,S_e,D], "enc_out" bf16 [B,S_e,D], "logits" fp32 [B*T, ld],
+ * stages through this): "enc_in" fp32 [B,S_e,D], "enc_out" bf16 [B,S_e,D], "dec_out" bf16 [B*T,D] (final decoder norm = lm_head operand), "logits" fp32 [B*T, ld],
  * "vit_hidden" fp32 [n_img, 1+P, hidden] (patch rows = hidden_states[-2]; CLS row lags one sub-layer), "enc_len" int32 [B], "flags" int32[1] (bit0 = malformed prompt).
  * For encode-stage names pass B = n_img, L = T = 0.  Returns -1 for an unknown name.
  * *ld_out (optional) receives the row stride in elements. */
@@ -186,6 +186,15 @@ int vqs_norm_deferred(int32_t kind, float* d_x, const void* d_delta, const void*
 int vqs_score_head(const float* d_logits, int32_t ldl, int32_t V, const int32_t* d_labels, float* d_label_logprobs,
                    float* d_scores, int32_t B, int32_t T, void* stream);
 /* host-side bucket function used to build the bias tables (HF models/t5/modeling_t5.py:216-262) */
+/* Stage tap (parity tests): register a caller-owned device buffer for a named intermediate of the NEXT passes; when a
+ * pass produces it, it is copied there on the pass's stream (device to device, no synchronisation).  The workspace
+ * buffers are reused layer after layer, so this is how a test reads EVERY layer's tensors and checks each launch
+ * against the oracle on the engine's own inputs (tests/test_gpu_stage_locked.py).  Names: "<stack>.<layer>.<what>" or
+ * "<stack>.<what>": vit.{patch_out,h0,feat_in,pmid}; vit.<i>.{xn0,q,k,v,attn,d_attn,xn1,mid,d_mlp};
+ * enc.emb; enc.<i>.{xn0,q,k,v,attn,d_attn,xn1,ff,d_ff}; dec.emb; dec.<i>.{xn0,qkv,sattn,d_self,xn1,cq,cqk,cscores,cprobs,cctx,
+ * cattn,d_cross,xn2,ff,d_ff}.  bytes = capacity of d_dst (a pass fails with VQS_ERR_WORKSPACE if it is too small);
+ * name == NULL clears every tap, d_dst == NULL removes one.  With no tap registered a pass pays one empty() test. */
+int vqs_debug_tap(vqs_handle* h, const char* name, void* d_dst, size_t bytes);
 /* Host-side test hook, no device access: the element offsets into a head-major [B, hx, S, hdim] tensor that the GEMM's
  * head-major epilogue (EPI_HEADS, the QKV projections' scatter -- HF modeling_t5.py:311-323 view/transpose) uses for the
  * rows row0 + 8k, k = 0..n-1, computed by the SAME inline functions as the kernel (one division, then steps).  S >= 8. */

@@ -54,6 +54,9 @@ struct vqs_handle {
     int splitk = 1;            // VQS_SPLITK=0 disables split-K in the decoder's skinny GEMMs (lab A/B)
     double prof_flops = 0.0;
     double prof_bytes = 0.0;   // algorithmic operand + result bytes of the profiled GEMM launches
+    // stage taps (vqs_debug_tap): point name -> (caller buffer, capacity); the pass copies the named intermediate there
+    struct Tap { void* dst; size_t cap; };
+    std::unordered_map<std::string, Tap> taps;
 };
 
 namespace {
@@ -159,7 +162,7 @@ ScoreWs carve_score(const vqs_handle* h, char* base, int B, int L, int T,
     w.cv = cv.take<bf16_t>(M * I);
     w.dhid = cv.take<float>(MT * D);
     w.ddelta = cv.take<bf16_t>(MT * D);
-    w.dxn = cv.take<bf16_t>(MT * D);
+    w.dxn = cv.take<bf16_t>(MT * D, "dec_out");   // after a pass: the final-norm output (lm_head operand)
     w.dqkv = cv.take<bf16_t>(MT * 3 * I);
     w.dattn = cv.take<bf16_t>(MT * I);
     w.dq = cv.take<bf16_t>(MT * I);
@@ -300,9 +303,31 @@ int run_gemm(vqs_handle* h, const GemmCall& g, hipStream_t st, const char* what)
         if (_r != VQS_OK) return _r; \
     } while (0)
 
+// Copy an intermediate to a caller buffer registered with vqs_debug_tap (in-stream, device to device).  The workspace
+// buffers are reused layer after layer, so the parity tests that check EVERY launch of a pass against the oracle on the
+// engine's own inputs (tests/test_gpu_stage_locked.py) read them through this.  One empty() test when nothing is registered.
+int tap(vqs_handle* h, const char* stack, int layer, const char* what, const void* src, size_t bytes, hipStream_t st) {
+    if (h->taps.empty()) return VQS_OK;
+    const std::string name = layer >= 0 ? std::string(stack) + "." + std::to_string(layer) + "." + what : std::string(stack) + "." + what;
+    auto it = h->taps.find(name);
+    if (it == h->taps.end()) return VQS_OK;
+    if (it->second.cap < bytes) return fail(h, VQS_ERR_WORKSPACE, "tap " + name + ": buffer too small (" + std::to_string(bytes) + " bytes needed)");
+    HIPCHK(h, hipMemcpyAsync(it->second.dst, src, bytes, hipMemcpyDeviceToDevice, st), "tap copy");
+    return VQS_OK;
+}
+#define TAP(stack, layer, what, ptr, elems) RUN(tap(h, stack, layer, what, ptr, (size_t)(elems) * sizeof(*(ptr)), st))
+
 }  // namespace
 
 extern "C" {
+
+int vqs_debug_tap(vqs_handle* h, const char* name, void* d_dst, size_t bytes) {
+    if (!h) return VQS_ERR_INVALID;
+    if (!name) { h->taps.clear(); return VQS_OK; }
+    if (!d_dst || bytes == 0) { h->taps.erase(name); return VQS_OK; }
+    h->taps[name] = vqs_handle::Tap{d_dst, bytes};
+    return VQS_OK;
+}
 
 int vqs_debug_heads_rows(int32_t row0, int32_t S, int32_t hx, int32_t hdim, int32_t n, int64_t* off_out) {
     if (row0 < 0 || S < 8 || hx <= 0 || hdim <= 0 || n <= 0 || !off_out) return VQS_ERR_INVALID;
@@ -497,6 +522,8 @@ int vqs_encode_images(vqs_handle* h, const void* d_pixels, int32_t N, void* d_fe
     }
     HIPCHK(h, vqs::launch_vit_assemble(w.patch_out, cls, pos, w.pre, N, P, hid, st), "vit_assemble");
     HIPCHK(h, vqs::launch_layernorm(w.pre, nullptr, pre_w, pre_b, w.hidden, 1, NS, hid, c.vis_ln_eps, st), "pre_layrnorm");
+    TAP("vit", -1, "patch_out", w.patch_out, (size_t)NP * hid);
+    TAP("vit", -1, "h0", w.hidden, (size_t)NS * hid);
 
     // Residual stream protocol: a sub-layer's output GEMM writes bf16 into `delta`; the NEXT norm kernel performs
     // hidden += delta (written back) and normalises in the same pass.  `pend` is the not-yet-added delta.
@@ -525,6 +552,7 @@ int vqs_encode_images(vqs_handle* h, const void* d_pixels, int32_t N, void* d_fe
             HIPCHK(h, vqs::launch_layernorm(w.hidden, pend, ln1w, ln1b, w.xn, 0, NS, hid, c.vis_ln_eps, st), "layer_norm1");
         pend = nullptr;
         pend_attn = nullptr;
+        TAP("vit", i, "xn0", w.xn, (size_t)NS * hid);
         {
             GemmCall g{w.xn, h->vit_qkv_w[i], nullptr};
             g.bias = h->vit_qkv_b[i];
@@ -535,21 +563,28 @@ int vqs_encode_images(vqs_handle* h, const void* d_pixels, int32_t N, void* d_fe
         }
         {
             vqs::AttnParams a{w.q, w.k, w.v, w.attn, nullptr, nullptr, N, c.vis_heads, Sv, 0.125f};
+            TAP("vit", i, "q", w.q, (size_t)NS * hid);
+            TAP("vit", i, "k", w.k, (size_t)NS * hid);
+            TAP("vit", i, "v", w.v, (size_t)NS * hid);
             HIPCHK(h, vqs::launch_attention(a, st), "vit attention");
+            TAP("vit", i, "attn", w.attn, (size_t)NS * hid);
         }
         {
             GemmCall g{w.attn, ow, w.delta};
             g.bias = ob;
             g.M = NS; g.N = hid; g.K = hid; g.lda = hid; g.ldw = hid; g.ldc = hid; g.epi = vqs::EPI_BF16;
             RUN(run_gemm(h, g, st, "vit out_proj"));
+            TAP("vit", i, "d_attn", w.delta, (size_t)NS * hid);
         }
         HIPCHK(h, vqs::launch_layernorm(w.hidden, w.delta, ln2w, ln2b, w.xn, 0, NS, hid, c.vis_ln_eps, st, nullptr, !defer), "layer_norm2");
         if (defer) pend_attn = w.delta;
+        TAP("vit", i, "xn1", w.xn, (size_t)NS * hid);
         {
             GemmCall g{w.xn, f1w, w.mid};
             g.bias = f1b;
             g.M = NS; g.N = mlp; g.K = hid; g.lda = hid; g.ldw = hid; g.ldc = mlp; g.epi = vqs::EPI_BF16_QGELU;
             RUN(run_gemm(h, g, st, "vit fc1"));
+            TAP("vit", i, "mid", w.mid, (size_t)NS * mlp);
         }
         {
             bf16_t* dst = defer ? w.delta2 : w.delta;
@@ -557,11 +592,13 @@ int vqs_encode_images(vqs_handle* h, const void* d_pixels, int32_t N, void* d_fe
             g.bias = f2b;
             g.M = NS; g.N = hid; g.K = mlp; g.lda = mlp; g.ldw = mlp; g.ldc = hid; g.epi = vqs::EPI_BF16;
             RUN(run_gemm(h, g, st, "vit fc2"));
+            TAP("vit", i, "d_mlp", dst, (size_t)NS * hid);
             pend = dst;
         }
     }
     // hidden_states[-2][:, 1:] = hidden + pending fc2 output, CLS dropped, cast to the projector's operand type
     HIPCHK(h, vqs::launch_drop_cls_cast(w.hidden, pend, w.feat_in, N, P, hid, st), "feature select");
+    TAP("vit", -1, "feat_in", w.feat_in, (size_t)NP * hid);
     GETW(p0w, "mm_projector.0.weight", (int64_t)D * hid);
     GETW(p0b, "mm_projector.0.bias", D);
     GETW(p2w, "mm_projector.2.weight", (int64_t)D * D);
@@ -571,6 +608,7 @@ int vqs_encode_images(vqs_handle* h, const void* d_pixels, int32_t N, void* d_fe
         g.bias = p0b;
         g.M = NP; g.N = D; g.K = hid; g.lda = hid; g.ldw = hid; g.ldc = D; g.epi = vqs::EPI_BF16_GELU;
         RUN(run_gemm(h, g, st, "mm_projector.0"));
+        TAP("vit", -1, "pmid", w.pmid, (size_t)NP * D);
     }
     {
         GemmCall g{w.pmid, p2w, d_feats};
@@ -605,6 +643,7 @@ static int encoder_pass(vqs_handle* h, const ScoreWs& w, const void* d_feats, co
                                        nullptr, 1, st), "encoder bias table");
     HIPCHK(h, vqs::launch_embed_splice(d_input_ids, w.sent_pos, w.enc_len, d_img_index, shared, (const bf16_t*)d_feats,
                                        w.hidden, B, L, P, D, V, st), "embed_splice");
+    TAP("enc", -1, "emb", w.hidden, (size_t)M * D);
 
     // ---------------- encoder (same pending-delta protocol as the vision tower)
     // Fused residual + RMSNorm (VQS_FUSED_NORM=1, off by default): the o / wo GEMM epilogue updates the fp32 stream in
@@ -640,6 +679,7 @@ static int encoder_pass(vqs_handle* h, const ScoreWs& w, const void* d_feats, co
             pend = nullptr;
             pend_attn = nullptr;
         }
+        TAP("enc", i, "xn0", w.xn, (size_t)M * D);
         {
             GemmCall g{w.xn, h->enc_qkv[i], nullptr};
             g.M = M; g.N = 3 * I; g.K = D; g.lda = D; g.ldw = D; g.ldc = 0; g.epi = vqs::EPI_HEADS;
@@ -650,13 +690,18 @@ static int encoder_pass(vqs_handle* h, const ScoreWs& w, const void* d_feats, co
         }
         {
             vqs::AttnParams a{w.q, w.k, w.v, w.attn, w.enc_table, w.enc_len, B, H, S, 1.0f};
+            TAP("enc", i, "q", w.q, (size_t)M * I);
+            TAP("enc", i, "k", w.k, (size_t)M * I);
+            TAP("enc", i, "v", w.v, (size_t)M * I);
             HIPCHK(h, vqs::launch_attention(a, st), "enc attention");
+            TAP("enc", i, "attn", w.attn, (size_t)M * I);
         }
         {
             GemmCall g{w.attn, ow, w.delta};
             g.M = M; g.N = D; g.K = I; g.lda = I; g.ldw = I; g.ldc = D; g.epi = vqs::EPI_BF16;
             if (fused) produce(g, ln1);
             RUN(run_gemm(h, g, st, "enc o"));
+            if (!fused) TAP("enc", i, "d_attn", w.delta, (size_t)M * D);
             if (fused) HIPCHK(h, vqs::launch_rowss_to_rs(w.rowss, parts, M, 1.0f / (float)D, c.t5_ln_eps, w.rs, st), "row 1/rms");
         }
         if (fused) {
@@ -665,12 +710,14 @@ static int encoder_pass(vqs_handle* h, const ScoreWs& w, const void* d_feats, co
             HIPCHK(h, vqs::launch_rmsnorm(w.hidden, w.delta, ln1, w.xn, M, D, c.t5_ln_eps, st, nullptr, !defer), "enc rmsnorm1");
             if (defer) pend_attn = w.delta;
             scaled = false;
+            TAP("enc", i, "xn1", w.xn, (size_t)M * D);
         }
         {
             GemmCall g{w.xn, h->enc_wi[i], w.ff};
             g.M = M; g.N = 2 * F; g.K = D; g.lda = D; g.ldw = D; g.ldc = F; g.epi = vqs::EPI_GATED;
             consume(g);
             RUN(run_gemm(h, g, st, "enc wi"));
+            TAP("enc", i, "ff", w.ff, (size_t)M * F);
         }
         {
             bf16_t* dst = defer ? w.delta2 : w.delta;
@@ -685,6 +732,7 @@ static int encoder_pass(vqs_handle* h, const ScoreWs& w, const void* d_feats, co
                 pend = nullptr;
             } else {
                 RUN(run_gemm(h, g, st, "enc wo"));
+                TAP("enc", i, "d_ff", dst, (size_t)M * D);
                 scaled = false;
                 pend = dst;
             }
@@ -746,6 +794,7 @@ static int decoder_pass(vqs_handle* h, const ScoreWs& w, const int32_t* d_labels
     HIPCHK(h, vqs::launch_relpos_table(dec_rel, h->lut_bidir, h->lut_causal, h->lut_len, c.rel_buckets, nullptr, H, S,
                                        w.dec_table, T, st), "decoder bias table");
     HIPCHK(h, vqs::launch_decoder_embed(d_labels, ld_labels, shared, w.dhid, B, T, D, V, st), "decoder embed");
+    TAP("dec", -1, "emb", w.dhid, (size_t)MT * D);
     const bf16_t* dpend = nullptr;
     for (int i = 0; i < c.dec_layers; ++i) {
         const std::string p = "decoder.block." + std::to_string(i) + ".";
@@ -759,14 +808,20 @@ static int decoder_pass(vqs_handle* h, const ScoreWs& w, const int32_t* d_labels
 
         HIPCHK(h, vqs::launch_rmsnorm(w.dhid, dpend, ln0, w.dxn, MT, D, c.t5_ln_eps, st), "dec rmsnorm0");
         dpend = nullptr;
+        TAP("dec", i, "xn0", w.dxn, (size_t)MT * D);
         RUN(dec_linear(h, w.dxn, h->dec_qkv[i], w.dqkv, MT, 3 * I, D, scratch, scratch_bytes, st, "dec self qkv"));
+        TAP("dec", i, "qkv", w.dqkv, (size_t)MT * 3 * I);
         {
             vqs::DecAttnParams a{w.dqkv, w.dqkv + I, w.dqkv + 2 * I, w.dattn, w.dec_table, nullptr, B, H, T, T, 3 * I, 3 * I, 0};
             HIPCHK(h, vqs::launch_decoder_attention(a, st), "dec self attention");
+            TAP("dec", i, "sattn", w.dattn, (size_t)MT * I);
         }
         RUN(dec_linear(h, w.dattn, so, w.ddelta, MT, D, I, scratch, scratch_bytes, st, "dec self o"));
+        TAP("dec", i, "d_self", w.ddelta, (size_t)MT * D);
         HIPCHK(h, vqs::launch_rmsnorm(w.dhid, w.ddelta, ln1, w.dxn, MT, D, c.t5_ln_eps, st), "dec rmsnorm1");
+        TAP("dec", i, "xn1", w.dxn, (size_t)MT * D);
         RUN(dec_linear(h, w.dxn, cq, w.dq, MT, I, D, scratch, scratch_bytes, st, "dec cross q"));
+        TAP("dec", i, "cq", w.dq, (size_t)MT * I);
         if (h->cross_mode == 0) {
             // direct form (what HF executes): K|V projection of the whole encoder output for this layer
             {
@@ -790,19 +845,23 @@ static int decoder_pass(vqs_handle* h, const ScoreWs& w, const int32_t* d_labels
                 g.M = MT; g.N = D; g.K = 64; g.lda = I; g.ldw = I; g.ldc = H * D; g.epi = vqs::EPI_BF16;
                 g.batch = H; g.sA = 64; g.sW = 64; g.sC = D;
                 RUN(run_gemm(h, g, st, "cross q.Wk"));
+                TAP("dec", i, "cqk", w.cqk, (size_t)MT * H * D);
             }
             {   // scores[b] [R, S] = q'[b] [R, D] . E[b]^T                      batched over pairs
                 GemmCall g{w.cqk, w.enc_out, w.cscores};
                 g.M = R; g.N = S; g.K = D; g.lda = D; g.ldw = D; g.ldc = w.S_pad; g.epi = vqs::EPI_F32;
                 g.batch = B; g.sA = (long long)R * D; g.sW = (long long)S * D; g.sC = (long long)R * w.S_pad;
                 RUN(run_gemm(h, g, st, "cross scores"));
+                TAP("dec", i, "cscores", w.cscores, (size_t)MT * H * w.S_pad);
             }
             HIPCHK(h, vqs::launch_masked_softmax(w.cscores, w.cprobs, w.enc_len, B, R, w.S_pad, st), "cross softmax");
+            TAP("dec", i, "cprobs", w.cprobs, (size_t)MT * H * w.S_pad);
             {   // ctx[b] [R, D] = P[b] [R, S_pad] . E[b]  (E^T is K-contiguous)   batched over pairs
                 GemmCall g{w.cprobs, w.enc_outT, w.cctx};
                 g.M = R; g.N = D; g.K = w.S_pad; g.lda = w.S_pad; g.ldw = w.S_pad; g.ldc = D; g.epi = vqs::EPI_BF16;
                 g.batch = B; g.sA = (long long)R * w.S_pad; g.sW = (long long)D * w.S_pad; g.sC = (long long)R * D;
                 RUN(run_gemm(h, g, st, "cross P.E"));
+                TAP("dec", i, "cctx", w.cctx, (size_t)MT * H * D);
             }
             {   // out[(b,t), h*64:(h+1)*64] = ctx[(b,t), h, :] . Wv_h^T          batched over heads
                 GemmCall g{w.cctx, cv_w, w.dattn};
@@ -811,14 +870,19 @@ static int decoder_pass(vqs_handle* h, const ScoreWs& w, const int32_t* d_labels
                 RUN(run_gemm(h, g, st, "cross ctx.Wv"));
             }
         }
+        TAP("dec", i, "cattn", w.dattn, (size_t)MT * I);
         RUN(dec_linear(h, w.dattn, co, w.ddelta, MT, D, I, scratch, scratch_bytes, st, "dec cross o"));
+        TAP("dec", i, "d_cross", w.ddelta, (size_t)MT * D);
         HIPCHK(h, vqs::launch_rmsnorm(w.dhid, w.ddelta, ln2, w.dxn, MT, D, c.t5_ln_eps, st), "dec rmsnorm2");
+        TAP("dec", i, "xn2", w.dxn, (size_t)MT * D);
         {
             GemmCall g{w.dxn, h->dec_wi[i], w.dff};
             g.M = MT; g.N = 2 * F; g.K = D; g.lda = D; g.ldw = D; g.ldc = F; g.epi = vqs::EPI_GATED;
             RUN(run_gemm(h, g, st, "dec wi"));
+            TAP("dec", i, "ff", w.dff, (size_t)MT * F);
         }
         RUN(dec_linear(h, w.dff, wo, w.ddelta, MT, D, F, scratch, scratch_bytes, st, "dec wo"));
+        TAP("dec", i, "d_ff", w.ddelta, (size_t)MT * D);
         dpend = w.ddelta;
     }
     {
@@ -893,7 +957,7 @@ int64_t vqs_workspace_offset(const vqs_handle* h, const char* name, int32_t B, i
         if (B <= 0 || L < 1 || T <= 0) return -1;
         const ScoreWs w = carve_score(h, nullptr, B, L, T, &names);
         if (n == "logits") ld = w.ldl;
-        else if (n == "enc_in" || n == "enc_out") ld = h->c.d_model;
+        else if (n == "enc_in" || n == "enc_out" || n == "dec_out") ld = h->c.d_model;
         else ld = 1;
     }
     auto it = names.find(n);

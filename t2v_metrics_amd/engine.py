@@ -68,6 +68,7 @@ _SIGNATURES = {
     "vqs_norm_deferred": (_c_i32, [_c_i32, _c_vp, _c_vp, _c_vp, _c_i32, _c_vp, _c_vp, _c_vp, _c_i32, _c_i32, _c_f32, _c_vp]),
     "vqs_score_head": (_c_i32, [_c_vp, _c_i32, _c_i32, _c_vp, _c_vp, _c_vp, _c_i32, _c_i32, _c_vp]),
     "vqs_attention_lds_bytes": (ctypes.c_int64, [_c_i32, _c_i32, _c_i32]),
+    "vqs_debug_tap": (_c_i32, [_c_vp, ctypes.c_char_p, _c_vp, ctypes.c_size_t]),
     "vqs_debug_heads_rows": (_c_i32, [_c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_vp]),
     "vqs_relpos_bucket": (_c_i32, [_c_i32, _c_i32, _c_i32, _c_i32]),
 }
@@ -263,6 +264,8 @@ class VqsEngine:
             return self._ws[off: off + 4 * B * S * t5.d_model].view(torch.float32).view(B, S, t5.d_model)
         if name == "enc_out":
             return self._ws[off: off + 2 * B * S * t5.d_model].view(torch.bfloat16).view(B, S, t5.d_model)
+        if name == "dec_out":
+            return self._ws[off: off + 2 * B * T * t5.d_model].view(torch.bfloat16).view(B, T, t5.d_model)
         if name == "logits":
             return self._ws[off: off + 4 * B * T * ld.value].view(torch.float32).view(B, T, ld.value)[..., : t5.vocab]
         if name == "enc_len":
@@ -270,6 +273,15 @@ class VqsEngine:
         if name == "flags":
             return self._ws[off: off + 4].view(torch.int32)
         raise VqsError(f"unknown stage {name}")
+
+    def tap(self, name: Optional[str], dst: Optional[torch.Tensor] = None):
+        """Register `dst` (device tensor, kept alive by the caller) to receive the named intermediate of the next passes
+        (vqs_debug_tap); name None clears all taps."""
+        if name is None:
+            self._check(self.lib.vqs_debug_tap(self._h, None, None, 0), "vqs_debug_tap")
+            return
+        nbytes = 0 if dst is None else dst.numel() * dst.element_size()
+        self._check(self.lib.vqs_debug_tap(self._h, name.encode(), _ptr(dst), nbytes), "vqs_debug_tap")
 
     def profile(self, on: bool):
         self._check(self.lib.vqs_profile_enable(self._h, 1 if on else 0), "vqs_profile_enable")

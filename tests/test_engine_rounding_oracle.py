@@ -1,0 +1,103 @@
+"""CPU pins of the rounding-matched oracle (oracle/clip_t5_engine_rounding.py), which is what the -m gpu tests hold
+the HIP path to at 1e-3: its structure (tiled online softmax with the deferred running max, reassociated
+cross-attention, fp32 stream with bf16 deltas) must be the SAME FUNCTION as the HF-pinned fp32 oracle -- identical to
+fp32 accuracy when the roundings are switched off -- and with the roundings on it must sit at the bf16 noise floor."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.clip_t5_engine_rounding import EngineRoundedOracle, bf16_round, tiled_attention
+from oracle.clip_t5_oracle import Oracle
+from t2v_metrics_amd.config import get_config
+from t2v_metrics_amd.weights import make_seeded_weights
+
+
+def _case(name, seed=2):
+    cfg = get_config(name)
+    w = make_seeded_weights(cfg, seed=1, device="cpu", lm_head_gain=2.0)
+    g = torch.Generator().manual_seed(seed)
+    pix = torch.randn(3, 3, cfg.vision.image, cfg.vision.image, generator=g).to(torch.bfloat16)
+    ids = torch.tensor([[11, 12, -200, 13, 14, 1, 7, 8, 1], [21, -200, 22, 1, 0, 0, 0, 0, 0], [5, 6, 7, -200, 9, 1, 0, 0, 0]])
+    labels = torch.tensor([[40, 1, 9], [41, 1, -100], [42, 7, 1]])
+    return cfg, w, pix, torch.tensor([0, 2, 1]), ids, labels
+
+
+@pytest.mark.parametrize("name", ["tiny", "small"])
+def test_without_roundings_it_is_the_fp32_oracle(name):
+    cfg, w, pix, idx, ids, labels = _case(name)
+    ref = Oracle(cfg, w).forward(pix.float(), idx, ids, labels, return_stages=True)
+    out = EngineRoundedOracle(cfg, w, round_fn=lambda x: x.float()).forward(pix.float(), idx, ids, labels, return_stages=True)
+    m = ref["enc_mask"][..., None].float()
+    for k, tol in (("vit_feats", 2e-5), ("proj", 2e-5), ("enc_out", 2e-5), ("dec_out", 2e-5), ("logits", 2e-5), ("label_logprobs", 2e-5)):
+        a, b = ref[k], out[k]
+        if k == "enc_out":
+            a, b = a * m, b * m
+        assert (a - b).abs().max().item() <= tol * max(1.0, a.abs().max().item()), k
+
+
+@pytest.mark.parametrize("name", ["tiny", "small"])
+def test_with_roundings_it_sits_at_the_bf16_floor_and_dispatches_from_oracle(name):
+    cfg, w, pix, idx, ids, labels = _case(name)
+    emu = Oracle(cfg, w, emulate="engine")
+    assert isinstance(emu, EngineRoundedOracle)
+    ref = Oracle(cfg, w).forward(pix.float(), idx, ids, labels)["label_logprobs"]
+    out = emu.forward(pix.float(), idx, ids, labels, return_stages=True)
+    d = (out["label_logprobs"] - ref).abs().max().item()
+    assert 1e-5 < d < 8e-2, d                    # roundings are really applied, and only roundings
+    for k in ("vit_feats", "proj", "enc_out", "dec_out"):       # bf16-held tensors are exactly representable
+        assert torch.equal(out[k], bf16_round(out[k])), k
+    with pytest.raises(ValueError):
+        Oracle(cfg, w, emulate="nonsense")
+
+
+@pytest.mark.parametrize("S,klen,bias", [(70, None, False), (150, [150, 97, 64, 1], True), (608, [608, 601], True)])
+def test_tiled_attention_is_softmax_attention(S, klen, bias):
+    """Unrounded, the 64-key-tile online softmax with the deferred running max equals softmax(QK^T*scale + bias) V."""
+    g = torch.Generator().manual_seed(S)
+    B = len(klen) if klen else 2
+    H = 3
+    q, k, v = (bf16_round(torch.randn(B, H, S, 64, generator=g) * (2.0 if i == 0 else 1.0)) for i in range(3))
+    table = torch.randn(H, 2 * S - 1, generator=g) * 2 if bias else None
+    kl = torch.tensor(klen) if klen else None
+    out = tiled_attention(q, k, v, 0.125 if not bias else 1.0, table, kl, round_fn=lambda x: x.float())
+    s = (q.double() @ k.double().transpose(-1, -2)) * (0.125 if not bias else 1.0)
+    if bias:
+        rel = torch.arange(S)[None, :] - torch.arange(S)[:, None] + (S - 1)
+        s = s + table[:, rel][None].double()
+    if klen:
+        s = s.masked_fill((torch.arange(S)[None, :] >= kl[:, None])[:, None, None, :], float("-inf"))
+    ref = (torch.softmax(s, -1) @ v.double()).transpose(1, 2).reshape(B, S, H * 64).float()
+    assert (out - ref).abs().max().item() <= 2e-5
+    # with P rounded to bf16 the result moves by bf16 noise only, and stays a convex combination of V rows
+    out_r = tiled_attention(q, k, v, 0.125 if not bias else 1.0, table, kl)
+    assert 0 < (out_r - ref).abs().max().item() <= 0.05
+    assert out_r.abs().max().item() <= v.abs().max().item() * 1.01
+
+
+@pytest.mark.parametrize("name", ["tiny", "small"])
+def test_stage_locked_run_on_its_own_record_reports_zero(name):
+    """Plumbing of the stage-locked mode (tap names, shapes, masks): fed with the intermediates of its own free-running
+    pass it must find every op result identical, cover every tap of tap_shapes(), and return the same log-probs."""
+    cfg, w, pix, idx, ids, labels = _case(name)
+    emu = EngineRoundedOracle(cfg, w)
+    emu.record = {}
+    free = emu.forward(pix.float(), idx, ids, labels)
+    rec, emu.record = emu.record, None
+    shapes = emu.tap_shapes(pix.shape[0], ids.shape[0], ids.shape[1], labels.shape[1])
+    assert set(shapes) | {"proj", "enc_out", "dec_out", "logits"} == set(rec)
+    for n, (shape, dt) in shapes.items():
+        assert rec[n].numel() == int(np.prod(shape)), n
+    # hand the taps over the way the engine does: flat 2-D buffers in the engine's dtypes
+    taps = {n: (rec[n].reshape(shapes[n][0]).to(shapes[n][1]) if n in shapes else rec[n]) for n in rec}
+    report, lp = emu.forward_locked(taps, pix.float(), idx, ids, labels)
+    assert set(report) == set(rec)
+    assert all(r["max_abs"] == 0.0 for r in report.values()), {n: r for n, r in report.items() if r["max_abs"] > 0}
+    assert torch.equal(lp, free["label_logprobs"])
+    # and it localises a planted defect: the op that produced the tensor and the one op that consumes it, nothing else
+    taps["enc.1.attn"] = taps["enc.1.attn"].clone()
+    taps["enc.1.attn"][0, :8] += 0.5
+    report, _ = emu.forward_locked(taps, pix.float(), idx, ids, labels)
+    off = [n for n, r in report.items() if r["max_abs"] > 0]
+    assert off == ["enc.1.attn", "enc.1.d_attn"], off
