@@ -1,29 +1,47 @@
 #!/usr/bin/env python3
 """VQAScore throughput bench (driver contract: one JSON line on rank 0).
 
-Workload = BASELINE.json configs[1]: clip-flant5-xl, bf16, batch of 256 (image, text) pairs per GPU per
-step, synthetic 224x224 uint8 images (bicubic-resized to the tower's 336x336 and CLIP-normalised once,
-outside the timed region, pixels resident in HBM as bf16) + 32-position prompts (8 prefix ids, the image
-sentinel, 24 suffix ids => encoder length 576 + 32 = 608), labels [2163, 1] (T = 2).  Distinct image per
-pair (no ViT reuse).  Weights: seeded random at the exact architecture (no checkpoint offline).
+Default workload = the configuration BASELINE.json's metric is quoted on: clip-flant5-XXL, bf16, one batch of 256
+(image, text) pairs per GPU per step, synthetic 224x224 uint8 images (bicubic-resized to the tower's 336x336 and
+CLIP-normalised once, outside the timed region, pixels resident in HBM as bf16) + 32-position prompts (8 prefix ids,
+the image sentinel, 24 suffix ids => encoder length 576 + 32 = 608), labels [2163, 1] (T = 2) -- SURVEY.md §8d
+"Config 2" generator at the XXL size.  Distinct image per pair (no ViT reuse).  Weights: seeded random at the exact
+architecture (no checkpoint offline).  `--model clip-flant5-xl` is BASELINE.json configs[1].
 
-A "step" = one full scoring pass over the batch: ViT-L/14-336 (23 layers) + projector + T5 encoder (24) +
-2-row teacher-forced decoder (24) + lm_head + log-softmax/score.  N > 1: one process per GPU (torchrun),
-independent replicas over disjoint pair shards (weak scaling), one RCCL all_gather of the scores at the end
-of the timed region.
+A "step" = one full scoring pass over one batch: ViT-L/14-336 (23 layers) + projector + T5 encoder (24) + 2-row
+teacher-forced decoder (24) + lm_head + log-softmax/score.
+
+Other workloads (whole-job runs; --steps is then derived from the job):
+  --workload genai1600   BASELINE.json configs[2] stand-in (the real prompt file is fetched at run time by the reference,
+                         dataset.py:1247-1281, unreachable offline): 1 600 prompts x 6 images = 9 600 pairs
+                         (dataset.py:1226,1235), caption lengths uniform 8-40 tokens (seed 1600) => encoder lengths
+                         616-648; pairs are sorted by prompt length into batches of --batch (no padding waste), scores
+                         scattered back to input order inside the timed region.
+  --pairs N              BASELINE.json configs[3]: N pairs in total (100 000 in the config), inputs a function of the
+                         GLOBAL pair block index (so sharding does not change them), contiguous blocks per rank.
+
+N > 1: one process per GPU.  `python bench.py --gpus N` launches its own ranks (re-executes itself under
+torch.distributed.run on 127.0.0.1); under an existing launcher (RANK/WORLD_SIZE set) it just joins.  Ranks are
+independent replicas over disjoint pairs (weak scaling by default: per-GPU work fixed), no data-path collective, ONE RCCL
+all_gather of the fp32 scores at the end of the timed region.
 
 Extra objects:
-  roofline     -- dominant kernel = vqs::gemm_bf16_kernel: algorithmic GEMM FLOPs (2*M*N*K per launch) over
-                  the summed per-launch durations measured with HIP events on the launch stream during the
-                  timed region (vqs_profile_*), against the 2.5 PFLOP/s dense bf16 MFMA peak.
-  cpu_baseline -- the CPU oracle (oracle/clip_t5_oracle.py, fp32, bf16-rounded weights; kind "port") timed
-                  on the host cores on a bounded sample of the same workload (rank 0, N = 1 only).
+  roofline     -- dominant kernel family = vqs::gemm_bf16_* : algorithmic GEMM FLOPs (2*M*N*K per launch) over the summed
+                  per-launch durations measured with HIP events on the launch stream during the timed region
+                  (vqs_profile_*), against the 2.5 PFLOP/s dense bf16 MFMA peak; `traffic` from the committed
+                  rocprofv3 --pmc passes over this same command (profiles/gemm_traffic_<model>_b<batch>.json).
+  cpu_baseline -- the reference's own arithmetic (HF CLIPVisionModel + T5ForConditionalGeneration cast to bf16 as
+                  mm_utils.py:228 does, oracle/hf_reference.py) timed on the host cores: 1 warm-up + 3 repetitions on
+                  the first pair(s) of the same batch (rank 0, N = 1 only), the fp32 port beside it, and the three-way
+                  |delta log P| table BASELINE.md §3 prescribes.
 """
 from __future__ import annotations
 
 import argparse
+import importlib
 import json
 import os
+import socket
 import sys
 import time
 
@@ -33,57 +51,134 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from t2v_metrics_amd.config import get_config  # noqa: E402
+from t2v_metrics_amd.sharding import shard_range  # noqa: E402
 from t2v_metrics_amd.weights import make_seeded_weights  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0     # dense; /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
 CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+METRIC = "image-text pairs scored/sec (whole node), "
+
+
+def synth_pixels(cfg, n, gen, device):
+    """seeded 224x224 uint8 images -> bicubic 336 -> CLIP-normalised bf16 [n,3,336,336] on `device` (a4+a5 of SURVEY §8)."""
+    out = []
+    for s in range(0, n, 256):
+        m = min(256, n - s)
+        img = torch.randint(0, 256, (m, 224, 224, 3), generator=gen, dtype=torch.uint8)
+        x = img.to(device).permute(0, 3, 1, 2).float()
+        x = torch.nn.functional.interpolate(x, size=(cfg.vision.image, cfg.vision.image), mode="bicubic", align_corners=False)
+        x = x.clamp(0, 255) / 255.0
+        mean = torch.tensor(CLIP_MEAN, device=device).view(1, 3, 1, 1)
+        std = torch.tensor(CLIP_STD, device=device).view(1, 3, 1, 1)
+        out.append(((x - mean) / std).to(torch.bfloat16))
+    return torch.cat(out).contiguous()
+
+
+def synth_prompts(cfg, n, gen, cap_len=None):
+    """int32 ids [n, L]: 8 prefix ids (last = 1) + sentinel -200 + [caption of cap_len[i] ids] + 24 suffix ids (last = 1),
+    right-padded with 0 to the longest row.  cap_len None = SURVEY §8d config 2 (L = 33, no caption, no padding)."""
+    hi = min(32100, cfg.t5.vocab)
+    pre = torch.randint(3, hi, (n, 8), generator=gen)
+    pre[:, 7] = 1
+    suf = torch.randint(3, hi, (n, 24), generator=gen)
+    suf[:, 23] = 1
+    sent = torch.full((n, 1), -200)
+    if cap_len is None:
+        return torch.cat([pre, sent, suf], dim=1).to(torch.int32)
+    width = 33 + int(cap_len.max())
+    ids = torch.zeros(n, width, dtype=torch.int64)
+    cap = torch.randint(3, hi, (n, int(cap_len.max())), generator=gen)
+    for i in range(n):
+        c = int(cap_len[i])
+        row = torch.cat([pre[i], sent[i], cap[i, :c], suf[i]])
+        ids[i, : row.numel()] = row
+    return ids.to(torch.int32)
 
 
 def synth_batch(cfg, batch, seed, device, ragged=False):
-    """SURVEY.md §8d "Config 2" generator; ragged=True is the "Config 3" stand-in (caption of 8-40 tokens between the
-    8-token prefix + sentinel and the 24-token template suffix, right-padded with id 0 to the batch maximum)."""
+    """SURVEY.md §8d "Config 2" generator (one batch); ragged=True draws a caption of 8-40 tokens per pair."""
     g = torch.Generator().manual_seed(seed)
-    img = torch.randint(0, 256, (batch, 224, 224, 3), generator=g, dtype=torch.uint8)
-    x = img.to(device).permute(0, 3, 1, 2).float()
-    x = torch.nn.functional.interpolate(x, size=(cfg.vision.image, cfg.vision.image), mode="bicubic", align_corners=False)
-    x = x.clamp(0, 255) / 255.0
-    mean = torch.tensor(CLIP_MEAN, device=device).view(1, 3, 1, 1)
-    std = torch.tensor(CLIP_STD, device=device).view(1, 3, 1, 1)
-    pixels = ((x - mean) / std).to(torch.bfloat16).contiguous()
-    vocab = cfg.t5.vocab
-    hi = min(32100, vocab)
-    pre = torch.randint(3, hi, (batch, 8), generator=g)
-    pre[:, 7] = 1
-    suf = torch.randint(3, hi, (batch, 24), generator=g)
-    suf[:, 23] = 1
-    if ragged:
-        cap_len = torch.randint(8, 41, (batch,), generator=g)
-        width = 8 + 1 + 40 + 24
-        ids = torch.zeros(batch, width, dtype=torch.int64)
-        for i in range(batch):
-            n = int(cap_len[i])
-            cap = torch.randint(3, hi, (n,), generator=g)
-            row = torch.cat([pre[i], torch.tensor([-200]), cap, suf[i]])
-            ids[i, : row.numel()] = row
-        ids = ids[:, : int(8 + 1 + cap_len.max() + 24)].to(torch.int32)
-    else:
-        ids = torch.cat([pre, torch.full((batch, 1), -200), suf], dim=1).to(torch.int32)
-    labels = torch.tensor([[min(2163, vocab - 1), 1]] * batch, dtype=torch.int32)
-    img_index = torch.arange(batch, dtype=torch.int32)
-    return pixels, img_index.to(device), ids.to(device), labels.to(device)
+    pixels = synth_pixels(cfg, batch, g, device)
+    cap_len = torch.randint(8, 41, (batch,), generator=g) if ragged else None
+    ids = synth_prompts(cfg, batch, g, cap_len)
+    labels = torch.tensor([[min(2163, cfg.t5.vocab - 1), 1]] * batch, dtype=torch.int32)
+    return pixels, torch.arange(batch, dtype=torch.int32).to(device), ids.to(device), labels.to(device)
 
 
-def main():
+def length_buckets(lengths: torch.Tensor, batch: int):
+    """Sort pair indices by prompt length (stable) and cut into batches: every batch is padded only to ITS longest
+    prompt.  Returns a list of index tensors; concatenated they are a permutation of range(n)."""
+    order = torch.argsort(lengths, stable=True)
+    return [order[s: s + batch] for s in range(0, order.numel(), batch)]
+
+
+def make_jobs(args, cfg, rank, world, device):
+    """-> (jobs, info): jobs = [(pixels, img_index, ids, labels, dest_index or None)], one per step of this rank."""
+    B = args.batch
+    yes = [[min(2163, cfg.t5.vocab - 1), 1]]
+    if args.workload == "genai1600":
+        n_prompts, per = 1600, 6
+        g = torch.Generator().manual_seed(1600)
+        cap_prompt = torch.randint(8, 41, (n_prompts,), generator=g)
+        ids_prompt = synth_prompts(cfg, n_prompts, g, cap_prompt)
+        pair_prompt = torch.arange(n_prompts).repeat_interleave(per)          # pair i = prompt i // 6, image i % 6
+        n = n_prompts * per
+        buckets = length_buckets(cap_prompt[pair_prompt], B)
+        lo, hi = shard_range(len(buckets), rank, world)
+        jobs = []
+        for bi in range(lo, hi):
+            idx = buckets[bi]
+            gi = torch.Generator().manual_seed(16000 + bi)                   # images: a function of the bucket index
+            ids = ids_prompt[pair_prompt[idx]]
+            L = int((ids != 0).sum(1).max())
+            jobs.append((synth_pixels(cfg, idx.numel(), gi, device), torch.arange(idx.numel(), dtype=torch.int32, device=device),
+                         ids[:, :L].contiguous().to(device), torch.tensor(yes * idx.numel(), dtype=torch.int32, device=device),
+                         idx.to(device)))
+        return jobs, {"total_pairs": n, "name": f"GenAI-Bench-1600 stand-in: 1600 prompts x 6 images = 9600 pairs, caption 8-40 tok "
+                      f"(S_e 616-648), length-bucketed into batches of {B}", "scaling": "strong"}
+    if args.pairs > 0:
+        n = args.pairs
+        nblocks = (n + B - 1) // B
+        lo, hi = shard_range(nblocks, rank, world)
+        jobs = []
+        for bi in range(lo, hi):
+            m = min(B, n - bi * B)
+            px, ii, ids, lab = synth_batch(cfg, m, seed=1234 + bi, device=device)     # seed per GLOBAL block index
+            jobs.append((px, ii, ids, lab, torch.arange(bi * B, bi * B + m, device=device)))
+        return jobs, {"total_pairs": n, "name": f"{n} synthetic pairs in total (config-2 generator per global block of {B}), "
+                      f"contiguous blocks per rank", "scaling": "strong"}
+    px, ii, ids, lab = synth_batch(cfg, B, seed=1234 + rank, device=device, ragged=args.ragged)
+    return [(px, ii, ids, lab, None)] * args.steps, {
+        "total_pairs": B * args.steps * world, "scaling": "weak",
+        "name": f"batch={B} synthetic 224x224 + " + ("ragged 41-73-tok prompts (padded, masked)" if args.ragged else "32-tok prompts")
+                + " per GPU per step"}
+
+
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--model", default="clip-flant5-xl")
+    ap.add_argument("--model", default="clip-flant5-xxl", help="clip-flant5-xxl (the metric's model) | clip-flant5-xl | qwen2.5-vl-7b")
     ap.add_argument("--batch", type=int, default=256, help="pairs per GPU per step")
-    ap.add_argument("--cpu-pairs", type=int, default=2, help="pairs in the CPU-oracle sample (0 = skip)")
-    ap.add_argument("--ragged", action="store_true", help="SURVEY config-3 stand-in: variable-length prompts, padded + masked")
-    args = ap.parse_args()
+    ap.add_argument("--workload", default="synthetic", choices=["synthetic", "genai1600"])
+    ap.add_argument("--pairs", type=int, default=0, help="fixed total number of pairs over all ranks (BASELINE configs[3]: 100000)")
+    ap.add_argument("--cpu-pairs", type=int, default=1, help="pairs in the CPU reference sample (0 = skip the cpu_baseline leg)")
+    ap.add_argument("--cpu-emulation", action="store_true", help="also run the rounding-matched CPU oracle on pair 0 (~40 s at XXL)")
+    ap.add_argument("--cpu-reps", type=int, default=3, help="timed repetitions of the CPU reference (after 1 warm-up)")
+    ap.add_argument("--ragged", action="store_true", help="one batch of variable-length prompts, padded + masked (no bucketing)")
+    return ap.parse_args(argv)
+
+
+def main():
+    args = parse_args()
 
     if args.model.startswith("qwen"):
         # BASELINE.json configs[4] (Qwen2.5-VL-7B, 8-frame video): measured by tools/bench_qwen.py, one GPU
@@ -95,20 +190,33 @@ def main():
         import bench_qwen
         return bench_qwen.main()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: become the launcher -- one rank per GPU, rendezvous on 127.0.0.1
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        os.execv(sys.executable, cmd)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    if not torch.cuda.is_available():
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # Harness self-test hook (tests/test_bench_harness.py): VQS_BENCH_ENGINE_DOUBLE="module:Class" swaps the HIP engine
+    # for a test double so the launcher / sharding / gather / JSON logic runs on a box without GPUs.  Never set by the
+    # driver; the line it produces is labelled as not-a-measurement.
+    double = os.environ.get("VQS_BENCH_ENGINE_DOUBLE")
+    if not double and not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     # VQS_BENCH_BACKEND=gloo lets the N > 1 code path be exercised on a box with fewer GPUs than ranks (ranks share
     # devices, collectives go through host memory); the driver's runs use the default: nccl = RCCL, one GPU per rank.
-    backend = os.environ.get("VQS_BENCH_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(dev_index)
-    device = torch.device("cuda", dev_index)
-    coll_device = device if backend == "nccl" else torch.device("cpu")
+    backend = "gloo" if double else os.environ.get("VQS_BENCH_BACKEND", "nccl")
+    if double:
+        device = coll_device = torch.device("cpu")
+    else:
+        dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(dev_index)
+        device = torch.device("cuda", dev_index)
+        coll_device = device if backend == "nccl" else torch.device("cpu")
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
@@ -119,80 +227,120 @@ def main():
             dist_mod.init_process_group(backend=backend)
         dist = dist_mod
 
-    from t2v_metrics_amd.engine import VqsEngine
-
     cfg = get_config(args.model)
-    weights = make_seeded_weights(cfg, seed=0, device=device)
-    eng = VqsEngine(cfg, weights, device=device)
+    if double:
+        mod, cls = double.split(":")
+        eng = getattr(importlib.import_module(mod), cls)(cfg)
+        weights = None
+    else:
+        from t2v_metrics_amd.engine import VqsEngine
+        weights = make_seeded_weights(cfg, seed=0, device=device)
+        eng = VqsEngine(cfg, weights, device=device)
     B = args.batch
-    pixels, img_index, ids, labels = synth_batch(cfg, B, seed=1234 + rank, device=device, ragged=args.ragged)
-    L, T = ids.shape[1], labels.shape[1]
-    s_e = L - 1 + cfg.vision.n_patches
+    jobs, info = make_jobs(args, cfg, rank, world, device)
+    steps_local = len(jobs)
+    T = jobs[0][3].shape[1] if jobs else 2
 
-    def step():
-        feats = eng.encode_images(pixels)
-        return eng.score(feats, img_index, ids, labels)
+    def run(job):
+        pixels, img_index, ids, labels, _ = job
+        return eng.score(eng.encode_images(pixels), img_index, ids, labels)
 
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if device.type == "cuda":
+            torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    if jobs:
+        longest = max(jobs, key=lambda j: j[2].shape[1] * j[2].shape[0])   # sizes the workspaces once, outside the timed region
+        for _ in range(max(args.warmup, 1)):
+            run(longest)
     barrier()
     eng.profile(True)
     eng.profile_read(reset=True)
     t0 = time.perf_counter()
-    all_scores = []
-    for _ in range(args.steps):
-        lp, sc = step()
-        all_scores.append(sc)
-    local = torch.cat(all_scores) if all_scores else torch.zeros(0, device=device)
+    n_total = info["total_pairs"]
+    ordered = info["scaling"] == "strong"
+    local = torch.zeros(n_total if ordered else steps_local * B, device=device)
+    lp = None
+    for si, job in enumerate(jobs):
+        lp, sc = run(job)
+        if ordered:
+            local[job[4]] = sc                     # scatter back to input order (other ranks' slots stay 0)
+        else:
+            local[si * B: si * B + sc.numel()] = sc
+    ranks_seen = 1
     if dist is not None:
-        local = local.to(coll_device)
-        gathered = [torch.empty_like(local) for _ in range(world)]
-        dist.all_gather(gathered, local)            # the path's only exchange: scores to every rank
+        local_c = local.to(coll_device)
+        gathered = [torch.empty_like(local_c) for _ in range(world)]
+        dist.all_gather(gathered, local_c)          # the path's only exchange: scores to every rank
+        ranks_seen = len(gathered)
+        final = torch.stack(gathered).sum(0) if ordered else torch.cat(gathered)
+    else:
+        final = local
     barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed_local = time.perf_counter() - t0
     eng.profile(False)
     gemm_bytes = eng.profile_bytes()
     n_gemm, gemm_ms, gemm_flops = eng.profile_read(reset=True)
     if rank == 0 and os.environ.get("VQS_BENCH_REPORT"):
         print(eng.profile_report(), file=sys.stderr, flush=True)
 
-    t_el = torch.tensor([elapsed], device=coll_device, dtype=torch.float64)
+    pairs_local = sum(j[2].shape[0] for j in jobs)
+    t_el = torch.tensor([elapsed_local], device=coll_device, dtype=torch.float64)
+    per_rank = torch.tensor([pairs_local / elapsed_local if elapsed_local > 0 else 0.0], device=coll_device, dtype=torch.float64)
+    per_rank_list = [float(per_rank.item())]
     if dist is not None:
         dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
+        pr = [torch.empty_like(per_rank) for _ in range(world)]
+        dist.all_gather(pr, per_rank)
+        per_rank_list = [float(x.item()) for x in pr]
     elapsed = float(t_el.item())
-    total_pairs = B * args.steps * world
-    value = total_pairs / elapsed if elapsed > 0 and args.steps > 0 else 0.0
+    total_pairs = n_total if ordered else pairs_local * world
+    value = total_pairs / elapsed if elapsed > 0 and total_pairs > 0 else 0.0
+    steps = max(steps_local, 1)
+    if dist is not None:
+        st = torch.tensor([steps_local], device=coll_device)
+        dist.all_reduce(st, op=dist.ReduceOp.MAX)
+        steps = max(int(st.item()), 1)
 
     # real (unpadded) encoder lengths: padding the engine computes over is not algorithmic work
-    lens = ((ids != 0).sum(1) - 1 + cfg.vision.n_patches).tolist()
-    flops_pair = sum(cfg.flops_pair(int(l), T) for l in lens) / len(lens)
+    flops_sum, n_len = 0.0, 0
+    seen = set()
+    for j in jobs:
+        if id(j[2]) in seen:
+            continue
+        seen.add(id(j[2]))
+        lens = ((j[2] != 0).sum(1) - 1 + cfg.vision.n_patches).tolist()
+        flops_sum += sum(cfg.flops_pair(int(l), T) for l in lens)
+        n_len += len(lens)
+    flops_pair = flops_sum / max(n_len, 1)
+    s_e = (jobs[0][2].shape[1] - 1 + cfg.vision.n_patches) if jobs else 0
     out = {
-        "metric": "image-text pairs scored/sec (whole node), " + cfg.name,
+        "metric": METRIC + cfg.name,
         "value": value,
         "unit": "pairs/s",
         "n_gpus": world,
-        "steps": args.steps,
+        "steps": steps,
         "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / max(args.steps, 1),
+        "ms_per_step": 1e3 * elapsed / steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": info["scaling"],
         "vs_baseline": None,
         "dtype": "bf16",
-        "data": "synthetic (seeded 224x224 uint8 images resized to 336, seeded token ids, seeded random weights)",
-        "config": {"workload": f"{cfg.name} bf16, batch={B} synthetic 224x224 + "
-                               + ("ragged 41-73-tok prompts (padded, masked)" if args.ragged else "32-tok prompts") + " per GPU per step",
-                   "pairs_per_gpu_per_step": B, "encoder_len": s_e, "decoder_len": T,
+        "data": "synthetic (seeded 224x224 uint8 images resized to 336, seeded token ids, seeded random weights)"
+                if not double else "ENGINE DOUBLE -- harness self-test, not a measurement",
+        "config": {"workload": f"{cfg.name} bf16, {info['name']}",
+                   "pairs_per_gpu_per_step": B, "encoder_len": s_e, "decoder_len": T, "total_pairs": total_pairs,
                    "parallelism": f"replica x{world} (pairs sharded, RCCL all_gather of scores)"},
+        "ranks_seen": ranks_seen,
+        "per_rank_pairs_per_s": per_rank_list,
+        "scores_checksum": float(final.double().sum().item()),
         # FLOPs of the REFERENCE algorithm (SURVEY.md §8d formula).  The engine's reassociated decoder
         # cross-attention executes 4*S_e*D*I*layers fewer FLOPs per pair than that (same function);
         # "roofline" below is computed from the FLOPs the GEMM kernel really executed.
         "algorithmic_tflop_per_pair": flops_pair / 1e12,
-        "executed_gemm_tflop_per_pair": (gemm_flops / max(total_pairs // world, 1)) / 1e12 if n_gemm > 0 else None,
+        "executed_gemm_tflop_per_pair": (gemm_flops / max(pairs_local, 1)) / 1e12 if n_gemm > 0 else None,
         "model_tflops_per_gpu": value * flops_pair / 1e12 / world,
         "model_frac_of_mfma_peak": value * flops_pair / 1e12 / world / PEAK_BF16_TFLOPS,
     }
@@ -204,18 +352,19 @@ def main():
                            "traffic": None, "launches": n_gemm, "avg_launch_ms": gemm_ms / n_gemm,
                            "avg_launch_tflop": gemm_flops / n_gemm / 1e12,
                            "algorithmic_bytes_per_launch": gemm_bytes / n_gemm,
-                           "gemm_share_of_step_time": gemm_ms * 1e-3 / elapsed}
+                           "gemm_share_of_step_time": gemm_ms * 1e-3 / elapsed_local}
         # HBM-side bytes per GEMM launch: PMC counters cannot be read from inside the process; they come from the
-        # committed rocprofv3 --pmc passes over this same command (tools/gpu_pmc_bench.sh -> profiles/*gemm_traffic.json)
+        # committed rocprofv3 --pmc passes over this same command (tools/gpu_pmc_bench.sh -> profiles/gemm_traffic_*.json)
         tpath = os.path.join(ROOT, "profiles", "gemm_traffic_%s_b%d.json" % (cfg.name.replace("clip-flant5-", ""), B))
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and args.workload == "synthetic" and args.pairs == 0 and not args.ragged:
             with open(tpath) as f:
                 tj = json.load(f)
             out["roofline"]["traffic"] = tj["traffic_bytes_per_launch"]
             out["roofline"]["traffic_unit"] = "bytes per launch (HBM-side: 2 x FETCH_SIZE + WRITE_SIZE), from " + os.path.basename(tpath)
 
-    if rank == 0 and world == 1 and args.cpu_pairs > 0:
-        out["cpu_baseline"] = cpu_baseline(cfg, weights, pixels, img_index, ids, labels, args.cpu_pairs, lp)
+    if rank == 0 and world == 1 and args.cpu_pairs > 0 and not double and jobs:
+        out["cpu_baseline"] = cpu_baseline(cfg, weights, jobs[-1], min(args.cpu_pairs, jobs[-1][2].shape[0]), lp, args.cpu_reps,
+                                           args.cpu_emulation)
 
     if rank == 0:
         print(json.dumps(out), flush=True)
@@ -223,20 +372,60 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(cfg, weights, pixels, img_index, ids, labels, n_pairs, lp_gpu):
-    """Oracle (fp32 restatement of the reference's HF forward) on the host cores, first n_pairs pairs of the batch."""
+def cpu_baseline(cfg, weights, job, n_pairs, lp_gpu, reps, with_emulation=False):
+    """The reference's arithmetic on the host cores: HF modules cast to bf16 as mm_utils.py:228 does,
+    inference mode, all cores, 1 warm-up + `reps` timed repetitions on the first n_pairs pairs of the batch the GPU
+    scored last; beside it the fp32 port (oracle/clip_t5_oracle.py) on one pair = fp32 truth, and the |delta log P| table:
+    HIP vs truth, reference-as-shipped vs truth, HIP vs reference-as-shipped, rounding-matched CPU oracle vs truth."""
+    import warnings
+    warnings.filterwarnings("ignore")
     from oracle.clip_t5_oracle import Oracle
-    w_cpu = {k: v.cpu() for k, v in weights.items()}
-    orc = Oracle(cfg, w_cpu)
-    px = pixels[:n_pairs].float().cpu()
+    from oracle.hf_reference import HFReference
+    pixels, img_index, ids, labels, _ = job
+    px = pixels[:n_pairs].cpu()
     idx = torch.arange(n_pairs)
+    ids_c, lab_c = ids[:n_pairs].cpu().long(), labels[:n_pairs].cpu().long()
+    keep = int((ids_c != 0).sum(1).max())
+    ids_c = ids_c[:, :keep]
+    w_cpu = {k: v.cpu() for k, v in weights.items()}
+    ref = HFReference(cfg, w_cpu, torch.bfloat16)
+    times = []
+    for r in range(reps + 1):                       # repetition 0 = warm-up
+        t0 = time.perf_counter()
+        out_ref = ref.forward(px, idx, ids_c, lab_c, timed=True)
+        times.append(time.perf_counter() - t0)
+    timed = sorted(times[1:]) or times
+    med = timed[len(timed) // 2]
+    lp_ref = out_ref["label_logprobs"]
+    stage_s = dict(ref.stage_s)
+    del ref
+    # fp32 truth + the rounding-matched oracle on ONE pair (the fp32 port up-casts every weight per use: slow by design)
     t0 = time.perf_counter()
-    ref = orc.forward(px, idx, ids[:n_pairs].cpu().long(), labels[:n_pairs].cpu().long())
-    dt = time.perf_counter() - t0
-    dlp = (lp_gpu[:n_pairs].float().cpu() - ref["label_logprobs"]).abs().max().item()
-    return {"value": n_pairs / dt, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"first {n_pairs} pairs of the same batch, fp32 oracle, one pass ({dt:.1f} s)",
-            "host_cpus": os.cpu_count(), "max_abs_dlogp_hip_vs_oracle": dlp}
+    truth = Oracle(cfg, w_cpu).forward(px[:1].float(), idx[:1], ids_c[:1], lab_c[:1])["label_logprobs"]
+    t_port = time.perf_counter() - t0
+    emu = None
+    if with_emulation:
+        emu = Oracle(cfg, w_cpu, emulate="engine", acc=torch.float32).forward(px[:1].float(), idx[:1], ids_c[:1], lab_c[:1])["label_logprobs"]
+    lp_hip = lp_gpu[:n_pairs].float().cpu()
+    try:
+        cpu_model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        cpu_model = "unknown"
+    import transformers
+    return {"value": n_pairs / med, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "reference-hf-bf16",
+            "sample": f"first {n_pairs} pairs of the same batch; HF CLIPVisionModel + T5ForConditionalGeneration in bf16, inference mode; "
+                      f"1 warm-up + {len(timed)} timed repetitions, median {med:.2f} s (all: {', '.join('%.2f' % t for t in times)})",
+            "stage_seconds_last_rep": stage_s,
+            "host_cpus": os.cpu_count(), "cpu_model": cpu_model, "torch": torch.__version__, "transformers": transformers.__version__,
+            "port_fp32": {"value": 1.0 / t_port, "unit": "pairs/s", "kind": "port",
+                          "sample": f"oracle/clip_t5_oracle.py, fp32, one pair, one cold pass ({t_port:.1f} s)"},
+            "dlogp": {"pairs": n_pairs,
+                      "hip_vs_hf_bf16_max": (lp_hip - lp_ref).abs().max().item(),
+                      "hip_vs_fp32_truth_pair0": (lp_hip[:1] - truth).abs().max().item(),
+                      "hf_bf16_vs_fp32_truth_pair0": (lp_ref[:1] - truth).abs().max().item(),
+                      "rounding_matched_cpu_vs_fp32_truth_pair0": (emu - truth).abs().max().item() if emu is not None else None,
+                      "logp_hip_pair0": lp_hip[0].tolist(), "logp_fp32_truth_pair0": truth[0].tolist()},
+            "max_abs_dlogp_hip_vs_oracle": (lp_hip[:1] - truth).abs().max().item()}
 
 
 if __name__ == "__main__":

@@ -1,0 +1,64 @@
+"""bench.py's harness on CPU: `python bench.py --gpus 2` must launch its own two ranks (torch.distributed.run on
+127.0.0.1), shard the work, all_gather the scores (gloo here, RCCL on the GPU box) and print ONE JSON line whose
+result does not depend on the number of ranks.  The HIP engine is replaced by tests/bench_double.py through the
+harness self-test hook; nothing here is a measurement."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra, gpus):
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env["VQS_BENCH_ENGINE_DOUBLE"] = "tests.bench_double:DoubleEngine"
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--model", "tiny", "--batch", "8", "--cpu-pairs", "0"] + extra
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]           # exactly one JSON line (rank 0)
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(900)
+def test_gpus_2_self_launches_and_fixed_total_result_is_rank_count_invariant():
+    one = _run(["--pairs", "50"], 1)
+    two = _run(["--pairs", "50"], 2)
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["ranks_seen"] == 2
+    assert len(two["per_rank_pairs_per_s"]) == 2 and all(v > 0 for v in two["per_rank_pairs_per_s"])
+    assert one["config"]["total_pairs"] == two["config"]["total_pairs"] == 50
+    assert one["scaling"] == two["scaling"] == "strong"
+    # same 50 global pairs whatever the sharding: the gathered, input-ordered scores agree
+    assert abs(one["scores_checksum"] - two["scores_checksum"]) < 1e-6 * max(1.0, abs(one["scores_checksum"]))
+    assert "not a measurement" in two["data"]
+
+
+@pytest.mark.timeout(900)
+def test_weak_scaling_default_and_bucketed_workload_through_the_launcher():
+    weak = _run(["--steps", "3", "--warmup", "1"], 2)
+    assert weak["scaling"] == "weak" and weak["steps"] == 3 and weak["config"]["total_pairs"] == 2 * 3 * 8
+    assert weak["metric"].endswith("tiny") and weak["unit"] == "pairs/s" and weak["value"] > 0
+    g1 = _run(["--workload", "genai1600", "--batch", "512"], 1)
+    g2 = _run(["--workload", "genai1600", "--batch", "512"], 2)
+    assert g1["config"]["total_pairs"] == g2["config"]["total_pairs"] == 9600
+    assert abs(g1["scores_checksum"] - g2["scores_checksum"]) < 1e-6 * abs(g1["scores_checksum"])
+
+
+def test_length_buckets_are_a_permutation_with_minimal_padding():
+    sys.path.insert(0, ROOT)
+    import bench
+    g = torch.Generator().manual_seed(0)
+    lens = torch.randint(8, 41, (9600,), generator=g)
+    buckets = bench.length_buckets(lens, 256)
+    allidx = torch.cat(buckets)
+    assert torch.equal(torch.sort(allidx).values, torch.arange(9600))
+    waste = sum(int((lens[b].max() - lens[b]).sum()) for b in buckets)
+    unsorted_waste = sum(int((lens[s:s + 256].max() - lens[s:s + 256]).sum()) for s in range(0, 9600, 256))
+    assert waste <= 9600 and waste * 10 < unsorted_waste       # < 1 padded token per pair vs ~16 unsorted
