@@ -125,3 +125,26 @@ class HFReference:
         if timed:
             self.stage_s = {"vision+projector_s": t1 - t0, "t5_encoder+decoder+head_s": t2 - t1}
         return {"label_logprobs": lp, "scores": sc}
+
+
+class HFEngine:
+    """HFReference behind the engine interface of CLIPT5Model (encode_images / score), so the drop-in API can be driven
+    on the CPU by the reference's own arithmetic: VQAScore(device='cpu', engine=HFEngine(cfg, weights)).  Checker /
+    CPU-baseline only -- the product path constructs VqsEngine and has no CPU route."""
+
+    def __init__(self, cfg, weights, dtype=torch.bfloat16, attn=None):
+        self.ref = HFReference(cfg, weights, dtype, attn)
+        self.cfg = cfg
+        self.seconds = {"vision+projector": 0.0, "t5": 0.0}
+
+    def encode_images(self, pixels):
+        t0 = time.perf_counter()
+        out = self.ref.encode_images(pixels)
+        self.seconds["vision+projector"] += time.perf_counter() - t0
+        return out
+
+    def score(self, feats, img_index, input_ids, labels):
+        t0 = time.perf_counter()
+        out = self.ref.score(feats, img_index, input_ids, labels)
+        self.seconds["t5"] += time.perf_counter() - t0
+        return out

@@ -61,6 +61,31 @@ __device__ __forceinline__ float a_max3(float a, float b, float c) {
 #ifndef VQS_ATTN_ABLATE
 #define VQS_ATTN_ABLATE 0
 #endif
+// Phase de-synchronisation of the workgroups that share a CU (see attn_desync below): bit 0 = static wave priority by
+// workgroup class, bit 1 = class-dependent start delay.
+#ifndef VQS_ATTN_STAGGER
+#define VQS_ATTN_STAGGER 0
+#endif
+
+// The three workgroups resident on a CU run identical code; with equal priority the SIMD's oldest-first arbitration keeps
+// their waves in phase lock-step (all in their QK^T MFMA phase together, then all in their softmax VALU phase, then all in
+// PV), so the matrix pipe idles while the VALU pipe is oversubscribed and vice versa: measured one wave-tile per ~1 730
+// SIMD cycles = the SUM of its MFMA (640) and VALU/LDS (~1 100) issue time.  A static priority per workgroup class lets
+// the high-priority wave run at its own pace and the others fill the pipe it is not using, which makes the phases
+// complementary.  Workgroups c, c+1, c+2 of an XCD (blockIdx >> 3) land on one CU or on CUs 32 apart -- distinct classes
+// either way (32 mod 3 = 2).
+__device__ __forceinline__ void attn_desync() {
+#if VQS_ATTN_STAGGER
+    const int cls = __builtin_amdgcn_readfirstlane((int)((blockIdx.x >> 3) % 3u));
+#if (VQS_ATTN_STAGGER & 1)
+    if (cls == 1) __builtin_amdgcn_s_setprio(1);
+    if (cls == 2) __builtin_amdgcn_s_setprio(2);
+#endif
+#if (VQS_ATTN_STAGGER & 2)
+    for (int i = 0; i < cls; ++i) __builtin_amdgcn_s_sleep(8);       // 8 x 64 clocks per class step
+#endif
+#endif
+}
 
 static constexpr int KT = 64;            // keys per tile
 static constexpr int VT_LD = 136;        // bytes per V^T row (64 keys * 2 B + 8 B pad)
@@ -373,6 +398,7 @@ __global__ void __launch_bounds__(256) attn_fwd_dma_kernel(const AttnParams p) {
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hh = lane >> 5;
+    attn_desync();
     // XCD-aware work map (workgroup L runs on XCD L % 8): the q-blocks of one (sample, head) get consecutive slots of
     // ONE XCD, so its K/V tiles are fetched from HBM once and re-read from that XCD's L2 -- with the natural 3-D
     // grid the 5 q-blocks landed on 5 different XCDs and the PMC showed K/V crossing the fabric 5 times

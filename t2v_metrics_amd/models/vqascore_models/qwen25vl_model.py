@@ -1,11 +1,15 @@
 """Qwen2.5-VL VQAScore wrapper on the MI355X engine -- the plugin-interface counterpart of the reference's
 ``Qwen2VLModel`` (/root/reference/t2v_metrics/models/vqascore_models/qwen2vl_model.py:93-301) for ``qwen2.5-vl-7b``.
 
-Same recipe: prompt = chat template around one vision placeholder + ``question_template.format(text)``, one prefill,
-score = softmax(logits_of_the_first_generated_position / temperature)[first answer token]  (:222-289 with the default
-``max_new_tokens=1``).  What differs: samples are batched (the reference runs batch 1, :190), the prefill runs on
-libvqs_hip (include/vqs_qwen.h), frame resizing / patch flattening are restated here instead of going through
-``qwen_vl_utils`` + the HF processor (neither is installable offline).
+Same recipe: prompt = chat template around one vision placeholder + ``question_template.format(text)``, greedy
+generation of ``max_new_tokens`` tokens (default 1 = ONE prefill), score = geometric mean over the answer tokens of
+softmax(processed_scores / temperature)[answer token] read from the LAST positions of the generated scores, with the
+reference's trailing-special-token rule (:222-289).  "Processed" = what HF ``generate(output_scores=True)`` returns: the
+logits after the generation_config's repetition penalty over prompt + generated ids (read from the checkpoint's
+generation_config.json; 1.0 when absent, e.g. seeded weights).  What differs: samples are batched (the reference runs
+batch 1, :190), the prefill runs on libvqs_hip (include/vqs_qwen.h; no KV cache: step k re-runs the prefill over the
+prompt + k generated tokens), the softmax + gather run in the library's score head, frame resizing / patch flattening
+are restated here instead of going through ``qwen_vl_utils`` + the HF processor (neither is installable offline).
 
 Input support: ``.npy`` arrays ([H,W,3] image or [T,H,W,3] frames, as qwen2vl_model.py:145-155) and image files; video
 container files need decord/ffmpeg (absent) -> NotImplementedError.  Any frame size smart_resize produces is accepted
@@ -32,7 +36,7 @@ default_question_template = 'Does this figure show "{}"? Please answer Yes or No
 default_answer_template = 'Yes'
 OPENAI_CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
 OPENAI_CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
-VIDEO_MAX_PIXELS = 360 * 420                                                              # qwen2vl_model.py:142-144
+VIDEO_FILE_MAX_PIXELS = 360 * 420      # qwen2vl_model.py:141-144: ONLY for video container paths (not supported here)
 # qwen_vl_utils (not installable here) resizes BEFORE the HF processor (the reference then passes do_resize=False,
 # qwen2vl_model.py:208-216): its defaults are IMAGE_FACTOR = 28, MIN_PIXELS = 4*28*28, MAX_PIXELS = 16384*28*28
 # [RECALLED from qwen_vl_utils/vision_process.py]; frames given as a list go through the same per-image routine with the
@@ -71,6 +75,16 @@ def patchify(frames: torch.Tensor, patch: int = 14, merge: int = 2, temporal: in
     return x.reshape(t * h * w, C * temporal * patch * patch).contiguous(), (t, h, w)
 
 
+def read_repetition_penalty(checkpoint_dir: str) -> float:
+    """generation_config.json of the checkpoint directory (HF generate() applies it in greedy mode too); 1.0 if absent."""
+    import json
+    path = os.path.join(checkpoint_dir, "generation_config.json")
+    if not os.path.isfile(path):
+        return 1.0
+    with open(path) as f:
+        return float(json.load(f).get("repetition_penalty", 1.0))
+
+
 def chat_prompt(question: str, placeholder: str) -> str:
     """Qwen2.5-VL chat template, one user turn with one vision item followed by the text, generation prompt appended
     (what processor.apply_chat_template(messages, add_generation_prompt=True) renders, qwen2vl_model.py:196-200)."""
@@ -103,6 +117,7 @@ class Qwen25VLModel(VQAScoreModel):
 
     def load_model(self):
         self.cfg = self._cfg
+        self.repetition_penalty = 1.0
         if self._tokenizer_arg is not None:
             self.tokenizer = self._tokenizer_arg
         else:
@@ -125,11 +140,9 @@ class Qwen25VLModel(VQAScoreModel):
             path = self._checkpoint_dir()
             if not os.path.isdir(path):
                 raise FileNotFoundError(f"no checkpoint at {path} (no network here). Pass checkpoint=<local HF dir> or weights='seeded'.")
-            from safetensors.torch import load_file
-            weights = {}
-            for f in sorted(os.listdir(path)):
-                if f.endswith(".safetensors"):
-                    weights.update(load_file(os.path.join(path, f)))
+            from ...qwen.weights import load_qwen_checkpoint
+            weights = load_qwen_checkpoint(path)           # accepts the published (legacy) and the in-memory key layout
+            self.repetition_penalty = read_repetition_penalty(path)
         self.engine = QwenEngine(self.cfg, weights, device=dev)
 
     # ------------------------------------------------------------------ host-side preparation
@@ -154,16 +167,15 @@ class Qwen25VLModel(VQAScoreModel):
         return out
 
     def preprocess(self, item: Dict) -> Tuple[torch.Tensor, Tuple[int, int, int]]:
-        """Resize (smart_resize to multiples of 28; videos capped at 360*420 pixels as the reference does), rescale,
-        CLIP-normalise, flatten -> (patches fp32 [N, 1176], (t, h, w))."""
+        """Resize (smart_resize to multiples of 28), rescale, CLIP-normalise, flatten -> (patches fp32 [N, 1176], (t, h, w)).
+        Frame lists from a 4-D .npy carry NO max_pixels in the reference's message (qwen2vl_model.py:151-153; the
+        360*420 cap is set for container paths only, :141-144), so every frame goes through qwen_vl_utils' per-image
+        routine with its default MAX_PIXELS, exactly like a still image."""
         v = self.cfg.vision
         frames = item['frames']
         H, W = frames.shape[1:3]
         factor = v.patch * v.spatial_merge
-        if item['type'] == 'video':
-            rh, rw = smart_resize(H, W, factor=factor, min_pixels=QVU_MIN_PIXELS, max_pixels=VIDEO_MAX_PIXELS)
-        else:
-            rh, rw = smart_resize(H, W, factor=factor, min_pixels=QVU_MIN_PIXELS, max_pixels=QVU_MAX_PIXELS)
+        rh, rw = smart_resize(H, W, factor=factor, min_pixels=QVU_MIN_PIXELS, max_pixels=QVU_MAX_PIXELS)
         if (rh, rw) != (H, W):
             frames = np.stack([np.asarray(Image.fromarray(f).resize((rw, rh), Image.BICUBIC)) for f in frames])
         x = torch.from_numpy(np.ascontiguousarray(frames)).permute(0, 3, 1, 2).to(torch.float32) * (1.0 / 255.0)
@@ -182,12 +194,50 @@ class Qwen25VLModel(VQAScoreModel):
         return ids[:k] + [self.cfg.video_token_id] * n_tokens + ids[k + 1:]
 
     # ------------------------------------------------------------------ scoring
+    def _special_ids(self) -> List[int]:
+        tok = self.tokenizer
+        return [x for x in (getattr(tok, "eos_token_id", None), getattr(tok, "bos_token_id", None), getattr(tok, "pad_token_id", None))
+                if x is not None]
+
+    def _stop_ids(self) -> List[int]:
+        """ids that end HF generation: generation_config.eos_token_id ([<|im_end|>, <|endoftext|>] for the Instruct
+        checkpoints) when known, else the tokenizer's eos."""
+        extra = getattr(self, "_gen_eos_ids", None)
+        if extra:
+            return list(extra)
+        e = getattr(self.tokenizer, "eos_token_id", None)
+        return [] if e is None else [e]
+
+    def _processed_scores(self, logits: torch.Tensor, rows: List[List[int]]) -> torch.Tensor:
+        """HF RepetitionPenaltyLogitsProcessor over prompt + generated ids (generation/logits_process.py): a seen token's
+        score is divided by the penalty when positive and multiplied when negative.  Identity for penalty 1.0."""
+        pen = float(getattr(self, "repetition_penalty", 1.0))
+        if pen == 1.0:
+            return logits
+        out = logits.clone()
+        for k, r in enumerate(rows):
+            seen = torch.tensor(sorted(set(r)), dtype=torch.long, device=logits.device)
+            v = out[k, seen]
+            out[k, seen] = torch.where(v < 0, v * pen, v / pen)
+        return out
+
+    def _token_probs(self, scores: torch.Tensor, token_ids: torch.Tensor, temperature: float) -> torch.Tensor:
+        """softmax(scores / temperature)[token] per row, on the device: the library's fp32 log-softmax + gather
+        (vqs_score_head), not a [B, 152 064] softmax on the host."""
+        if hasattr(self.engine, "lib"):
+            from ... import engine as _eng
+            x = scores if temperature == 1.0 else scores / temperature
+            lp, _ = _eng.score_head(x.unsqueeze(1).contiguous(), token_ids.to(scores.device).reshape(-1, 1))
+            return lp[:, 0].exp().float().cpu()
+        p = torch.softmax(scores.float() / temperature, dim=-1)                 # engine doubles in the CPU tests
+        return p[torch.arange(p.shape[0]), token_ids.to(p.device)].cpu()
+
     @torch.no_grad()
     def forward(self, images: List[str], texts: List[str], fps=None, question_template: str = default_question_template,
                 answer_template: str = default_answer_template, max_new_tokens: int = 1, temperature: float = 1.0) -> torch.Tensor:
         assert len(images) == len(texts), "Number of images/videos and texts must match"
-        if max_new_tokens != 1:
-            raise NotImplementedError("the HIP path scores the first generated position only (max_new_tokens=1, the reference default)")
+        if max_new_tokens < 1:
+            raise ValueError("max_new_tokens must be >= 1")
         questions = [question_template.format(t) for t in texts]
         answers = [answer_template.format(t) for t in texts]
         items = self.load_images(images, fps)
@@ -199,6 +249,7 @@ class Qwen25VLModel(VQAScoreModel):
         else:
             prepared = [self.preprocess(it) for it in items]
         scores = torch.zeros(len(images), dtype=torch.float32)
+        specials, stops = self._special_ids(), self._stop_ids()
         # batch samples that share a grid (one vision call per group), at most max_batch at a time
         groups: Dict[Tuple[int, int, int], List[int]] = {}
         for i, (_, g) in enumerate(prepared):
@@ -210,19 +261,48 @@ class Qwen25VLModel(VQAScoreModel):
                 merged = self.engine.encode_vision(patches, [g] * len(chunk))
                 n_tok = g[0] * g[1] * g[2] // self.cfg.vision.merge_unit
                 rows = [self.build_ids(questions[i], items[i]['type'], n_tok) for i in chunk]
-                L = max(len(r) for r in rows)
-                ids = torch.zeros(len(rows), L, dtype=torch.long)
-                mask = torch.zeros(len(rows), L, dtype=torch.long)
-                for k, r in enumerate(rows):
-                    ids[k, : len(r)] = torch.tensor(r)
-                    mask[k, : len(r)] = 1
-                logits = self.engine.score_logits(merged, ids, mask, [g] * len(chunk)).float().cpu()
-                probs = torch.softmax(logits / temperature, dim=-1)                        # qwen2vl_model.py:160-167
+                a_ids = [list(self.tokenizer.encode(answers[i], add_special_tokens=False)) for i in chunk]
+                if any(len(a) < 1 for a in a_ids):
+                    raise ValueError("empty answer")
+                # ---- greedy generation (HF generate, do_sample=False): step t re-runs the prefill over prompt + t tokens;
+                # a sample stops at its first stop id, exactly as batch-1 generate does in the reference (:222-230)
+                step_scores: List[List[torch.Tensor]] = [[] for _ in chunk]       # processed scores per generated step
+                gen: List[List[int]] = [[] for _ in chunk]
+                live = list(range(len(chunk)))
+                for _step in range(max_new_tokens):
+                    cur = [rows[k] + gen[k] for k in live]
+                    L = max(len(r) for r in cur)
+                    ids = torch.zeros(len(cur), L, dtype=torch.long)
+                    mask = torch.zeros(len(cur), L, dtype=torch.long)
+                    for k, r in enumerate(cur):
+                        ids[k, : len(r)] = torch.tensor(r)
+                        mask[k, : len(r)] = 1
+                    sub = merged if len(live) == len(chunk) else merged.reshape(len(chunk), n_tok, -1)[live].reshape(len(live) * n_tok, -1)
+                    logits = self.engine.score_logits(sub, ids, mask, [g] * len(live))
+                    proc = self._processed_scores(logits, cur)
+                    nxt = proc.argmax(-1).cpu().tolist()
+                    still = []
+                    for k, sk in enumerate(live):
+                        step_scores[sk].append(proc[k])
+                        gen[sk].append(int(nxt[k]))
+                        if int(nxt[k]) not in stops:
+                            still.append(sk)
+                    live = still
+                    if not live:
+                        break
+                # ---- score the answer tokens from the LAST positions of the generated scores (:239-289)
                 for k, i in enumerate(chunk):
-                    a_ids = self.tokenizer.encode(answers[i], add_special_tokens=False)
-                    if len(a_ids) < 1:
-                        raise ValueError("empty answer")
-                    scores[i] = probs[k, a_ids[0]]          # max_new_tokens=1: only the first answer token is scored (:257-262)
+                    n_ans, offset = len(a_ids[k]), 0
+                    if gen[k][-1] in specials:
+                        n_ans = min(n_ans, len(step_scores[k]) - 1)
+                        offset = 1
+                        if n_ans <= 0:
+                            raise ValueError("No content tokens to score after removing special tokens")
+                    if len(step_scores[k]) < n_ans:
+                        n_ans = len(step_scores[k])
+                    pos = [len(step_scores[k]) - (n_ans - t + offset) for t in range(n_ans)]
+                    p = self._token_probs(torch.stack([step_scores[k][q] for q in pos]), torch.tensor(a_ids[k][:n_ans]), temperature)
+                    scores[i] = float(torch.prod(p.double()) ** (1.0 / n_ans))
         return scores
 
     def generate(self, *args, **kwargs):

@@ -67,3 +67,37 @@ def make_seeded_qwen_weights(cfg: Qwen25VLConfig, seed: int = 0, device="cpu", d
             x = x + 1.0
         out[name] = x.to(dtype).to(device)
     return out
+
+
+# --- mapping a published Qwen2.5-VL checkpoint onto the inventory -----------------------------------------------------
+# The safetensors shards of Qwen/Qwen2.5-VL-*-Instruct carry the pre-4.52 key layout (``visual.*``, ``model.layers.*``,
+# ``model.embed_tokens.weight``, ``model.norm.weight``, ``lm_head.weight``); HF renames them on load to the in-memory
+# names this inventory uses (transformers conversion_mapping for Qwen2_5_VLForConditionalGeneration:
+# ``^visual`` -> ``model.visual``, ``^model(?!\.(language_model|visual))`` -> ``model.language_model``).  Both layouts
+# are accepted.
+import re as _re
+
+_LEGACY_VISUAL = _re.compile(r"^visual\.")
+_LEGACY_TEXT = _re.compile(r"^model\.(?!language_model\.|visual\.)")
+
+
+def canonical_qwen_name(key: str) -> str:
+    if _LEGACY_VISUAL.match(key):
+        return "model." + key
+    if _LEGACY_TEXT.match(key):
+        return "model.language_model." + key[len("model."):]
+    return key
+
+
+def load_qwen_checkpoint(path: str) -> Dict[str, torch.Tensor]:
+    """Every ``*.safetensors`` shard of a local HF directory, keys canonicalised (legacy or in-memory layout)."""
+    import os
+    from safetensors.torch import load_file
+    out: Dict[str, torch.Tensor] = {}
+    for f in sorted(os.listdir(path)):
+        if f.endswith(".safetensors"):
+            for k, w in load_file(os.path.join(path, f)).items():
+                out[canonical_qwen_name(k)] = w
+    if not out:
+        raise FileNotFoundError(f"no *.safetensors under {path}")
+    return out

@@ -108,3 +108,102 @@ def test_forward_recipe_batching_and_errors(tmp_path):
     assert scorer.model.forward([str(odd)], ["x"]).shape == (1,)
     with pytest.raises(AssertionError):
         scorer.model.forward(paths[:2], texts[:1])
+
+
+def test_published_checkpoint_key_layout_is_accepted(tmp_path):
+    """The safetensors shards of Qwen/Qwen2.5-VL-*-Instruct use the legacy keys (visual.*, model.layers.*,
+    model.embed_tokens.weight, model.norm.weight); HF renames them on load.  Both layouts must map onto the inventory."""
+    from safetensors.torch import save_file
+    from t2v_metrics_amd.qwen.weights import canonical_qwen_name, load_qwen_checkpoint, qwen_weight_specs
+    cfg = get_qwen_config("qwen-tiny")
+    w = make_seeded_qwen_weights(cfg, seed=5, dtype=torch.bfloat16)
+
+    def legacy(k):
+        if k.startswith("model.visual."):
+            return k[len("model."):]
+        if k.startswith("model.language_model."):
+            return "model." + k[len("model.language_model."):]
+        return k
+
+    names = [n for n, _, _ in qwen_weight_specs(cfg)]
+    assert {canonical_qwen_name(legacy(n)) for n in names} == set(names) == {canonical_qwen_name(n) for n in names}
+    assert canonical_qwen_name("visual.blocks.0.attn.qkv.weight") == "model.visual.blocks.0.attn.qkv.weight"
+    assert canonical_qwen_name("model.layers.3.mlp.up_proj.weight") == "model.language_model.layers.3.mlp.up_proj.weight"
+    assert canonical_qwen_name("model.embed_tokens.weight") == "model.language_model.embed_tokens.weight"
+    assert canonical_qwen_name("model.norm.weight") == "model.language_model.norm.weight"
+    assert canonical_qwen_name("lm_head.weight") == "lm_head.weight"
+    items = sorted(w.items())
+    half = len(items) // 2
+    save_file({legacy(k): v.contiguous() for k, v in items[:half]}, str(tmp_path / "model-00001-of-00002.safetensors"))
+    save_file({legacy(k): v.contiguous() for k, v in items[half:]}, str(tmp_path / "model-00002-of-00002.safetensors"))
+    got = load_qwen_checkpoint(str(tmp_path))
+    assert set(got) == set(w) and all(torch.equal(got[k], w[k]) for k in w)
+
+
+def test_npy_frame_lists_are_not_capped_at_the_container_file_limit(tmp_path):
+    """qwen2vl_model.py:141-144 sets max_pixels = 360*420 for video FILE paths only; a 4-D .npy becomes a frame list
+    without max_pixels (:151-153), so a 448 x 672 clip keeps its grid (a capped one would be 308 x 476)."""
+    cfg = get_qwen_config("qwen-tiny")
+    m = Qwen25VLModel(model_name="qwen2.5-vl-7b", device="cpu", config=cfg, engine=object(), tokenizer=FakeQwenTokenizer(cfg.text.vocab))
+    p = tmp_path / "big.npy"
+    np.save(p, np.zeros((2, 448, 672, 3), dtype=np.uint8))
+    item = m.load_images([str(p)])[0]
+    assert item["type"] == "video"
+    _, grid = m.preprocess(item)
+    assert tuple(grid) == (1, 448 // 14, 672 // 14)
+    assert smart_resize(448, 672, max_pixels=360 * 420) == (308, 476)          # what the cap would have produced
+
+
+def test_multi_token_answers_processed_scores_and_eos_rule(tmp_path):
+    """max_new_tokens > 1: greedy generation, answer tokens scored at the LAST positions of the generated scores, geometric
+    mean (qwen2vl_model.py:265-289); repetition penalty applied to prompt + generated ids before the softmax (what HF
+    generate's output_scores holds); a generation that is only a special token raises like the reference (:252-256)."""
+    from oracle.qwen25vl_oracle import QwenOracle
+    cfg = get_qwen_config("qwen-tiny")
+    w = make_seeded_qwen_weights(cfg, seed=3, dtype=torch.bfloat16, lm_head_gain=4.0)
+    tok = FakeQwenTokenizer(cfg.text.vocab)
+    p = tmp_path / "img.npy"
+    np.save(p, np.random.RandomState(2).randint(0, 256, (112, 112, 3), dtype=np.uint8))
+    scorer = t2v.VQAScore(model="qwen2.5-vl-7b", device="cpu", config=cfg, engine=OracleQwenEngine(cfg, w), tokenizer=tok)
+    m = scorer.model
+    ans = "Yes indeed"
+    a = tok.encode(ans)
+    assert len(a) == 2
+    s2 = m.forward([str(p)], ["a red cube"], answer_template=ans, max_new_tokens=2)
+    # by hand with the oracle
+    item = m.load_images([str(p)])[0]
+    patches, grid = m.preprocess(item)
+    ids = m.build_ids(default_q("a red cube"), "image", grid[1] * grid[2] // 4)
+    o = QwenOracle(cfg, w)
+
+    def logits_of(seq):
+        t = torch.tensor([seq])
+        return o.forward(t, torch.ones_like(t), patches, [grid])[0]
+
+    l0 = logits_of(ids)
+    g0 = int(l0.argmax())
+    l1 = logits_of(ids + [g0])
+    want = (torch.softmax(l0, -1)[a[0]] * torch.softmax(l1, -1)[a[1]]).item() ** 0.5
+    assert abs(s2[0].item() - want) <= 1e-5 * max(want, 1e-3) + 1e-9
+    # a one-token budget truncates the answer to the tokens that were generated (:258-262)
+    s1 = m.forward([str(p)], ["a red cube"], answer_template=ans, max_new_tokens=1)
+    assert abs(s1[0].item() - torch.softmax(l0, -1)[a[0]].item()) <= 1e-6
+    # repetition penalty 1.3: the prompt's tokens are penalised before the softmax
+    m.repetition_penalty = 1.3
+    seen = torch.tensor(sorted(set(ids)))
+    lp = l0.clone()
+    lp[seen] = torch.where(lp[seen] < 0, lp[seen] * 1.3, lp[seen] / 1.3)
+    in_prompt = tok.encode("Yes")[0]                       # "Yes" occurs in the question template
+    assert in_prompt in ids
+    sp = m.forward([str(p)], ["a red cube"], max_new_tokens=1)
+    assert abs(sp[0].item() - torch.softmax(lp, -1)[in_prompt].item()) <= 1e-6 * max(1.0, sp[0].item()) + 1e-9
+    m.repetition_penalty = 1.0
+    # the generated token is the EOS: nothing left to score
+    tok.eos_token_id = g0
+    with pytest.raises(ValueError, match="No content tokens"):
+        m.forward([str(p)], ["a red cube"], max_new_tokens=1)
+
+
+def default_q(text):
+    from t2v_metrics_amd.models.vqascore_models.qwen25vl_model import default_question_template
+    return default_question_template.format(text)
