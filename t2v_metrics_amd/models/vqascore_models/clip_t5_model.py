@@ -58,7 +58,8 @@ class CLIPT5Model(VQAScoreModel):
 
     def __init__(self, model_name='clip-flant5-xxl', device='cuda', cache_dir=HF_CACHE_DIR, *, weights=None,
                  tokenizer=None, checkpoint: Optional[str] = None, config=None, max_pairs: int = 256,
-                 max_images: int = 256, seed: int = 0, engine=None, num_workers: Optional[int] = None):
+                 max_images: int = 256, seed: int = 0, engine=None, num_workers: Optional[int] = None,
+                 vision_tower: Optional[str] = None):
         """
         weights:    None -> load ``checkpoint`` (a local HF directory of safetensors); 'seeded' -> seeded random
                     weights at the exact architecture (benchmarks, tests); or a dict name -> tensor.
@@ -74,6 +75,7 @@ class CLIPT5Model(VQAScoreModel):
         self._weights_arg, self._tokenizer_arg, self._checkpoint = weights, tokenizer, checkpoint
         self._cfg = config if config is not None else get_config(CLIP_T5_MODELS[model_name]['config'])
         self._seed, self._engine_arg = seed, engine
+        self._vision_tower_dir = vision_tower
         self.num_workers = min(32, os.cpu_count() or 1) if num_workers is None else max(1, int(num_workers))
         self._pool = None
         self.max_pairs, self.max_images = int(max_pairs), int(max_images)
@@ -96,7 +98,7 @@ class CLIPT5Model(VQAScoreModel):
         elif self._weights_arg == 'seeded':
             weights = make_seeded_weights(self.cfg, seed=self._seed, device=dev)
         else:
-            weights = load_checkpoint_weights(self.cfg, self._read_checkpoint(), dev)
+            weights = load_checkpoint_weights(self.cfg, self._read_checkpoint(), dev, vision_state_dict=self._read_vision_tower())
         self.engine = VqsEngine(self.cfg, weights, device=dev)
 
     def _checkpoint_dir(self) -> str:
@@ -118,14 +120,19 @@ class CLIPT5Model(VQAScoreModel):
         if not os.path.isdir(path):
             raise FileNotFoundError(
                 f"no checkpoint at {path} (no network here). Pass checkpoint=<local HF dir> or weights='seeded'.")
-        from safetensors.torch import load_file
-        sd: Dict[str, torch.Tensor] = {}
-        for f in sorted(os.listdir(path)):
-            if f.endswith(".safetensors"):
-                sd.update(load_file(os.path.join(path, f)))
-        if not sd:
-            raise FileNotFoundError(f"no *.safetensors under {path}")
-        return sd
+        from ...weights import read_checkpoint_dir
+        return read_checkpoint_dir(path)
+
+    def _read_vision_tower(self) -> Optional[Dict[str, torch.Tensor]]:
+        """The CLIP tower's own directory, if the main checkpoint does not carry it (mm_utils.py:236-237): explicit
+        ``vision_tower=<dir>``, else <cache_dir>/clip-vit-large-patch14-336 when it exists."""
+        from ...weights import read_checkpoint_dir
+        path = self._vision_tower_dir or os.path.join(self.cache_dir, "clip-vit-large-patch14-336")
+        if os.path.isdir(path):
+            return read_checkpoint_dir(path)
+        if self._vision_tower_dir:
+            raise FileNotFoundError(f"no vision tower checkpoint at {path}")
+        return None
 
     # ------------------------------------------------------------------ host-side preparation
     def _executor(self):
@@ -224,7 +231,16 @@ class CLIPT5Model(VQAScoreModel):
         pending = pool.submit(self.load_images, chunks[0]) if (pool is not None and len(chunks) > 1) else None
         ids, lab = self.tokenize(questions, answers)
         idx = torch.as_tensor(list(pair_image), dtype=torch.int32)
-        # pairs are scored in order; prefix_max[k] = highest image index needed by pairs [0, k]
+        # Length bucketing: a batch is padded to ITS longest prompt and the engine computes over the padding, so pairs
+        # are scored in order of prompt length (stable: equal lengths keep arrival order, i.e. image order) and every
+        # batch's ids are cut to its own maximum; scores are scattered back to arrival order at the end.  With one
+        # image chunk the whole set is sorted; with several, sorting is per image chunk so that the streaming overlap
+        # (score a batch as soon as its images are encoded) survives.
+        plen = (ids != self.cfg.t5.pad_id).sum(1)
+        chunk_of_pair = idx.long() // self.max_images
+        order = torch.argsort(chunk_of_pair * (int(plen.max()) + 1) + plen, stable=True)
+        ids, lab, idx, plen = ids[order], lab[order], idx[order], plen[order]
+        # pairs are scored in (sorted) order; prefix_max[k] = highest image index needed by pairs [0, k]
         prefix_max = torch.cummax(idx, 0).values if n > 0 else idx
         feats, n_enc, next_pair = None, 0, 0
         scores, lps = [], []
@@ -245,13 +261,16 @@ class CLIPT5Model(VQAScoreModel):
                 e = min(n, next_pair + self.max_pairs)
                 if int(prefix_max[e - 1]) >= n_enc or (e - next_pair < self.max_pairs and not last):
                     break
-                lp, sc = self.engine.score(feats, idx[next_pair:e], ids[next_pair:e], lab[next_pair:e])
+                keep = int(plen[next_pair:e].max())
+                lp, sc = self.engine.score(feats, idx[next_pair:e], ids[next_pair:e, :keep].contiguous(), lab[next_pair:e])
                 scores.append(sc)
                 lps.append(lp)
                 next_pair = e
-        sc = torch.cat(scores).float().cpu()
+        inv = torch.empty_like(order)
+        inv[order] = torch.arange(n)
+        sc = torch.cat(scores).float().cpu()[inv]
         if return_logprobs:
-            return sc, torch.cat(lps).float().cpu()
+            return sc, torch.cat(lps).float().cpu()[inv]
         return sc
 
     def forward(self, images: List[str], texts: List[str], question_template: str = default_question_template,

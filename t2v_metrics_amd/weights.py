@@ -150,6 +150,27 @@ _CKPT_PREFIXES = (
 )
 
 
+def read_checkpoint_dir(path: str) -> Dict[str, torch.Tensor]:
+    """Every weight shard of a local HF directory: ``*.safetensors`` and/or ``pytorch_model*.bin`` (the published
+    zhiqiulin/clip-flant5-* repos ship .bin shards; layout [RECALLED], unverified offline).  .bin shards are read with
+    ``torch.load(weights_only=True, mmap=True)`` -- tensors only, no pickled code."""
+    import os
+    sd: Dict[str, torch.Tensor] = {}
+    names = sorted(os.listdir(path))
+    for f in names:
+        if f.endswith(".safetensors"):
+            from safetensors.torch import load_file
+            sd.update(load_file(os.path.join(path, f)))
+    for f in names:
+        if f.endswith(".bin") and f.startswith("pytorch_model"):
+            part = torch.load(os.path.join(path, f), map_location="cpu", weights_only=True, mmap=True)
+            for k, v in part.items():
+                sd.setdefault(k, v)
+    if not sd:
+        raise FileNotFoundError(f"no *.safetensors or pytorch_model*.bin under {path}")
+    return sd
+
+
 def canonical_name(ckpt_key: str) -> str:
     for src, dst in _CKPT_PREFIXES:
         if ckpt_key.startswith(src):
@@ -158,11 +179,14 @@ def canonical_name(ckpt_key: str) -> str:
 
 
 def load_checkpoint_weights(cfg: ClipT5Config, state_dict: Dict[str, torch.Tensor], device,
-                            dtype=torch.bfloat16) -> Dict[str, torch.Tensor]:
-    """Map a loaded ``state_dict`` (e.g. safetensors shards of a local HF dir) onto the
-    inventory; raises KeyError listing what is missing.  The whole model is cast to bf16,
-    as the reference does (mm_utils.py:228)."""
-    canon = {canonical_name(k): v for k, v in state_dict.items()}
+                            dtype=torch.bfloat16, vision_state_dict: Dict[str, torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+    """Map a loaded ``state_dict`` (shards of a local HF dir) onto the inventory; raises KeyError listing what is
+    missing.  ``vision_state_dict``: the CLIP tower when it lives in its own directory (the reference loads it
+    separately -- ``get_vision_tower().load_model()``, mm_utils.py:236-237 -- from openai/clip-vit-large-patch14-336,
+    keys ``vision_model.*``); tensors of the main checkpoint win on a clash.  The whole model is cast to bf16, as the
+    reference does (mm_utils.py:228)."""
+    canon = {canonical_name(k): v for k, v in (vision_state_dict or {}).items() if canonical_name(k).startswith("vision.")}
+    canon.update({canonical_name(k): v for k, v in state_dict.items()})
     out, missing = {}, []
     for name, shape, _ in weight_specs(cfg):
         if name not in canon:

@@ -199,10 +199,27 @@ def test_forward_grid_dedups_images_and_batches_pairs(tmp_path, images):
     assert eng.encode_calls == [(3, 3, 56, 56)]                 # 4 image slots, 3 distinct files, encoded once
     assert [c[0][0] for c in eng.score_calls] == [4, 4, 4]      # 12 pairs in chunks of max_pairs
     assert torch.equal(out[0], out[3])                          # same file -> same row
-    # row-major pair order: row i = image i
-    assert eng.score_calls[0][2] == [0, 0, 0, 1]
+    # pairs are scored in order of prompt length (stable; length bucketing), results come back row-major: row i = image i
+    assert eng.score_calls[0][2] == [0, 0, 1, 1]                # the two 2-word prompts of images 0 and 1 first
+    assert [c[0][1] for c in eng.score_calls] == sorted(c[0][1] for c in eng.score_calls)     # batch width grows
+    assert eng.score_calls[0][0][1] < eng.score_calls[-1][0][1]   # short prompts are not padded to the longest one
     single = s(images=images[1], texts=texts[2])
     assert single.shape == (1, 1) and torch.allclose(single[0, 0], out[1, 2])
+
+
+def test_scores_do_not_depend_on_arrival_order_or_batching(tmp_path, images):
+    """Length bucketing re-orders the pairs internally; every pair's score must come back in its own slot whatever the
+    order of the inputs, the batch size or the image chunking."""
+    texts = ["a", "b c d e f g", "h i", "j k l m", "n o p q r s t u", "v w x"]
+    s1, _ = make_scorer(tmp_path, max_pairs=256)
+    ref = s1(images=images[:3], texts=texts)
+    for mp, mi in ((4, 256), (5, 2), (1, 1)):
+        s2, eng = make_scorer(tmp_path, max_pairs=mp)
+        s2.model.max_images = mi
+        assert torch.allclose(s2(images=images[:3], texts=texts), ref)
+        perm = [4, 0, 5, 2, 1, 3]
+        out = s2(images=[images[2], images[0], images[1]], texts=[texts[k] for k in perm])
+        assert torch.allclose(out, ref[[2, 0, 1]][:, perm])
 
 
 def test_forward_kwargs_reach_the_model(tmp_path, images):

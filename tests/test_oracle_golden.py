@@ -129,3 +129,23 @@ def test_oracle_greedy_generate_matches_hf(name, golden_dir):
     assert torch.equal(toks, torch.from_numpy(z["tokens"]).long())
     assert torch.allclose(margins, torch.from_numpy(z["margins"]), atol=2e-3)
 
+
+
+@pytest.mark.parametrize("fixture", ["e2e_tiny_g1", "e2e_tiny_g4", "e2e_small_g1", "e2e_small_g4"])
+def test_hf_reference_builder_reproduces_the_fixtures(golden_dir, fixture):
+    """oracle/hf_reference.py (the reference's arithmetic assembled from the HF modules on the meta device; what
+    bench.py's cpu_baseline times and tools/config1_cpu.py drives) against the committed fixtures, which
+    oracle/make_golden.py generated from the same modules: fp32 and the reference's bf16 configuration."""
+    import warnings
+    warnings.filterwarnings("ignore")
+    from oracle.hf_reference import HFReference
+    g = np.load(os.path.join(golden_dir, fixture + ".npz"))
+    cfg = get_config(fixture.split("_")[1])
+    w = make_seeded_weights(cfg, seed=int(g["seed"]), device="cpu", lm_head_gain=float(g["gain"]))
+    pix = torch.from_numpy(g["pixels"]).to(torch.bfloat16)
+    idx, ids, labels = (torch.from_numpy(g[k]) for k in ("img_index", "ids", "labels"))
+    r32 = HFReference(cfg, w, torch.float32).forward(pix, idx, ids, labels)
+    r16 = HFReference(cfg, w, torch.bfloat16).forward(pix, idx, ids, labels)
+    assert (r32["label_logprobs"] - torch.from_numpy(g["logprobs_fp32"])).abs().max().item() <= 1e-5
+    assert (r32["scores"] - torch.from_numpy(g["scores_fp32"])).abs().max().item() <= 1e-6
+    assert (r16["label_logprobs"] - torch.from_numpy(g["logprobs_hf_bf16"])).abs().max().item() <= 1e-5
