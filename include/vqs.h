@@ -186,6 +186,17 @@ int vqs_norm_deferred(int32_t kind, float* d_x, const void* d_delta, const void*
 int vqs_score_head(const float* d_logits, int32_t ldl, int32_t V, const int32_t* d_labels, float* d_label_logprobs,
                    float* d_scores, int32_t B, int32_t T, void* stream);
 /* host-side bucket function used to build the bias tables (HF models/t5/modeling_t5.py:216-262) */
+/* Execution-form options of a handle; the defaults are what the engine ships with, the alternatives compute the same
+ * function and exist so that the parity tests can hold each form against the default and the oracle
+ * (tests/test_gpu_e2e.py).  The library reads NO environment variables.
+ *   "cross_mode"   1 (default) reassociated decoder cross-attention, 0 per-layer K|V projection (what HF executes)
+ *   "splitk"       1 (default) split-K for the decoder's skinny nn.Linear GEMMs, 0 single GEMMs
+ *   "norm_defer"   1 (default) deferred store of the fp32 stream in the norm kernels (bitwise equal), 0 store in every norm
+ *   "fused_norm"   0 (default) separate add+norm kernels, 1 residual update + RMSNorm operand in the o / wo GEMM epilogues
+ *   "gemm_variant" 3 (default) persistent kernels, 0 one tile per workgroup, 2 / 5 ping-pong schedule
+ * Returns VQS_ERR_INVALID for an unknown name or value. */
+int vqs_set_option(vqs_handle* h, const char* name, int32_t value);
+
 /* Stage tap (parity tests): register a caller-owned device buffer for a named intermediate of the NEXT passes; when a
  * pass produces it, it is copied there on the pass's stream (device to device, no synchronisation).  The workspace
  * buffers are reused layer after layer, so this is how a test reads EVERY layer's tensors and checks each launch

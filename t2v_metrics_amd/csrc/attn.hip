@@ -54,39 +54,6 @@ __device__ __forceinline__ float a_max3(float a, float b, float c) {
     return r;
 }
 
-// Lab-only ablations (tools/attn_lab.sh): 1 = no K/V staging after the first tile, 2 = no softmax math (P = S), 4 = no PV MFMAs
-#ifndef VQS_ATTN_PRIO
-#define VQS_ATTN_PRIO 0
-#endif
-#ifndef VQS_ATTN_ABLATE
-#define VQS_ATTN_ABLATE 0
-#endif
-// Phase de-synchronisation of the workgroups that share a CU (see attn_desync below): bit 0 = static wave priority by
-// workgroup class, bit 1 = class-dependent start delay.
-#ifndef VQS_ATTN_STAGGER
-#define VQS_ATTN_STAGGER 0
-#endif
-
-// The three workgroups resident on a CU run identical code; with equal priority the SIMD's oldest-first arbitration keeps
-// their waves in phase lock-step (all in their QK^T MFMA phase together, then all in their softmax VALU phase, then all in
-// PV), so the matrix pipe idles while the VALU pipe is oversubscribed and vice versa: measured one wave-tile per ~1 730
-// SIMD cycles = the SUM of its MFMA (640) and VALU/LDS (~1 100) issue time.  A static priority per workgroup class lets
-// the high-priority wave run at its own pace and the others fill the pipe it is not using, which makes the phases
-// complementary.  Workgroups c, c+1, c+2 of an XCD (blockIdx >> 3) land on one CU or on CUs 32 apart -- distinct classes
-// either way (32 mod 3 = 2).
-__device__ __forceinline__ void attn_desync() {
-#if VQS_ATTN_STAGGER
-    const int cls = __builtin_amdgcn_readfirstlane((int)((blockIdx.x >> 3) % 3u));
-#if (VQS_ATTN_STAGGER & 1)
-    if (cls == 1) __builtin_amdgcn_s_setprio(1);
-    if (cls == 2) __builtin_amdgcn_s_setprio(2);
-#endif
-#if (VQS_ATTN_STAGGER & 2)
-    for (int i = 0; i < cls; ++i) __builtin_amdgcn_s_sleep(8);       // 8 x 64 clocks per class step
-#endif
-#endif
-}
-
 static constexpr int KT = 64;            // keys per tile
 static constexpr int VT_LD = 136;        // bytes per V^T row (64 keys * 2 B + 8 B pad)
 static constexpr int K_LDS = KT * 128;   // 8192
@@ -122,231 +89,9 @@ __device__ __forceinline__ void fill_bias_copies(float* bias_s, const float* bt,
     }
 }
 
-template <bool HAS_BIAS>
-__global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* k_lds = smem;
-    char* vt_lds = smem + K_LDS;
-    float* bias_s = reinterpret_cast<float*>(smem + K_LDS + VT_LDS);
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int hh = lane >> 5;                 // lane half
-    // XCD-aware work map (workgroup L runs on XCD L % 8): the q-blocks of one (sample, head) get consecutive slots of
-    // ONE XCD, so its K/V tiles are fetched from HBM once and re-read from that XCD's L2 -- with the natural 3-D
-    // grid the 5 q-blocks landed on 5 different XCDs and the PMC showed K/V crossing the fabric 5 times
-    // (6.9 GB per T5-XL call, 4.6 TB/s: the kernel was fabric-bound).
-    const int S = p.S;
-    const int nqb = (S + 127) >> 7;
-    const int slot = blockIdx.x >> 3;
-    const int qb = slot % nqb;
-    const int g = (slot / nqb) * 8 + (blockIdx.x & 7);
-    if (g >= p.B * p.H) return;
-    const int b = g / p.H, h = g - b * p.H;
-    const size_t bh = (size_t)b * p.H + h;
-    const bf16_t* Q = p.q + bh * S * 64;
-    const bf16_t* K = p.k + bh * S * 64;
-    const bf16_t* V = p.v + bh * S * 64;
-    const int klen = p.key_len ? min(p.key_len[b], S) : S;
-    const int ntiles = (klen + KT - 1) / KT;
-
-    // softmax runs in the log2 domain (v_exp_f32 is 2^x): scores and bias are pre-multiplied by log2(e)
-    constexpr float LOG2E = 1.4426950408889634f;
-    // Four copies of the head's bias table, copy c shifted left by c entries, so that the 4 consecutive entries a lane
-    // needs (table index = key - query + S-1, any alignment) are one 16-B aligned ds_read_b128 in copy (index & 3).
-    // Copy stride = 4 (mod 16) chunks: the four copies of a chunk land on four different 16-B bank slots.
-    const int bias_cs = bias_copy_chunks(S);      // 16-B chunks per copy
-    if (HAS_BIAS) fill_bias_copies(bias_s, p.bias_table + (size_t)h * (2 * S - 1), 2 * S - 1, bias_cs * 4, tid);
-    const float sl2 = p.scale * LOG2E;
-
-    const int qrow = qb * 128 + wv * 32 + (lane & 31);
-    const int qrow_c = min(qrow, S - 1);
-    uint4 qf[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-        qf[ks] = *reinterpret_cast<const uint4*>(Q + (size_t)qrow_c * 64 + 16 * ks + 8 * hh);
-
-    // ---- staging assignments
-    // K: thread -> (key = tid>>3 (+32), chunk = tid&7), 16-B chunks, swizzled
-    const int sk_key = tid >> 3, sk_c = tid & 7;
-    // V: thread -> (key pair kp, d-chunk c); a 32-lane half covers 16 kp x 2 c  (conflict-free b32 writes)
-    const int sv_kp = (lane & 15) + 16 * (wv & 1);
-    const int sv_c = ((lane >> 4) & 3) + 4 * (wv >> 1);
-
-    uint4 kreg0, kreg1, vreg0, vreg1;
-    auto load_tile = [&](int kt) {
-        const int kb = kt * KT;
-        kreg0 = *reinterpret_cast<const uint4*>(K + (size_t)min(kb + sk_key, S - 1) * 64 + sk_c * 8);
-        kreg1 = *reinterpret_cast<const uint4*>(K + (size_t)min(kb + sk_key + 32, S - 1) * 64 + sk_c * 8);
-        vreg0 = *reinterpret_cast<const uint4*>(V + (size_t)min(kb + 2 * sv_kp, S - 1) * 64 + sv_c * 8);
-        vreg1 = *reinterpret_cast<const uint4*>(V + (size_t)min(kb + 2 * sv_kp + 1, S - 1) * 64 + sv_c * 8);
-    };
-    auto write_tile = [&]() {
-        *reinterpret_cast<uint4*>(k_lds + sk_key * 128 + ((sk_c ^ ((sk_key >> 1) & 7)) << 4)) = kreg0;
-        *reinterpret_cast<uint4*>(k_lds + (sk_key + 32) * 128 + ((sk_c ^ (((sk_key + 32) >> 1) & 7)) << 4)) = kreg1;
-        // dword j2 of a 16-B chunk holds d = 8c + 2*j2 (low half) and d + 1 (high half)
-#define VQS_VT_WRITE(J2, A, B)                                                                       \
-        {                                                                                            \
-            const uint32_t lo = ((A) & 0xffffu) | ((B) << 16);                                       \
-            const uint32_t hi = ((A) >> 16) | ((B) & 0xffff0000u);                                   \
-            const int d = sv_c * 8 + 2 * (J2);                                                       \
-            *reinterpret_cast<uint32_t*>(vt_lds + d * VT_LD + sv_kp * 4) = lo;                       \
-            *reinterpret_cast<uint32_t*>(vt_lds + (d + 1) * VT_LD + sv_kp * 4) = hi;                 \
-        }
-        VQS_VT_WRITE(0, vreg0.x, vreg1.x)
-        VQS_VT_WRITE(1, vreg0.y, vreg1.y)
-        VQS_VT_WRITE(2, vreg0.z, vreg1.z)
-        VQS_VT_WRITE(3, vreg0.w, vreg1.w)
-#undef VQS_VT_WRITE
-    };
-
-    f32x16 o[2];
-#pragma unroll
-    for (int df = 0; df < 2; ++df)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[df][r] = 0.0f;
-    float m_run = NEG_BIG, l_run = 0.0f;
-
-    const int swr = (lane >> 1) & 7;
-    const int jb = 4 * hh - qrow_c + (S - 1);                 // table index of (key kb + 0, this lane's query), kb = 0
-    const char* bias_rd = reinterpret_cast<const char*>(bias_s) + (jb & 3) * bias_cs * 16 + (jb & ~3) * 4;
-    const int k_rd = (lane & 31) * 128;
-    const int vt_rd = (lane & 31) * VT_LD + 8 * hh;
-
-    // (a two-stage LDS ring with one barrier per tile was measured 15 % SLOWER than this: 410 -> 346 TFLOP/s)
-    if (ntiles > 0) load_tile(0);
-    for (int kt = 0; kt < ntiles; ++kt) {
-        __syncthreads();                 // previous tile's LDS reads are done (also covers bias_s fill)
-        if (!(VQS_ATTN_ABLATE & 1) || kt == 0) {
-            write_tile();
-            if (kt + 1 < ntiles) load_tile(kt + 1);
-        }
-        __syncthreads();
-
-        // ---- S^T = K . Q^T   (i <-> key, j <-> query)
-        f32x16 s[2];
-#pragma unroll
-        for (int kf = 0; kf < 2; ++kf)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[kf][r] = 0.0f;
-        {
-            uint4 kfr[4][2];                 // all 8 fragments in flight before the first MFMA
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int kf = 0; kf < 2; ++kf)
-                    kfr[ks][kf] = *reinterpret_cast<const uint4*>(k_lds + kf * 4096 + k_rd + (((2 * ks + hh) ^ swr) << 4));
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int kf = 0; kf < 2; ++kf)
-                    s[kf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kfr[ks][kf]),
-                                                                    __builtin_bit_cast(bf16x8, qf[ks]), s[kf], 0, 0, 0);
-        }
-
-#if !(VQS_ATTN_ABLATE & 2)
-        // ---- scale + bias (+ mask on the ragged last tile), running max with deferred rescale
-        const int kb = kt * KT;
-        // element (kf, r) is key kb + kf*32 + (r&3) + 8*(r>>2) + 4*hh: table index = that - query + S-1
-        if (HAS_BIAS) {
-            const char* bp = bias_rd + kb * 4;
-#pragma unroll
-            for (int kf = 0; kf < 2; ++kf)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float4 bv = *reinterpret_cast<const float4*>(bp + kf * 128 + g * 32);
-                    s[kf][4 * g + 0] = fmaf(s[kf][4 * g + 0], sl2, bv.x);
-                    s[kf][4 * g + 1] = fmaf(s[kf][4 * g + 1], sl2, bv.y);
-                    s[kf][4 * g + 2] = fmaf(s[kf][4 * g + 2], sl2, bv.z);
-                    s[kf][4 * g + 3] = fmaf(s[kf][4 * g + 3], sl2, bv.w);
-                }
-        } else {
-#pragma unroll
-            for (int kf = 0; kf < 2; ++kf)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s[kf][r] *= sl2;
-        }
-        if (kb + KT > klen) {                       // wave-uniform: only the last tile of a sample is ragged
-#pragma unroll
-            for (int kf = 0; kf < 2; ++kf)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = kb + kf * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    if (key >= klen) s[kf][r] = NEG_BIG;
-                }
-        }
-#define VQS_SV(i) s[(i) >> 4][(i) & 15]
-        float mx = a_max3(VQS_SV(0), VQS_SV(1), VQS_SV(2));
-#pragma unroll
-        for (int i = 3; i < 31; i += 2) mx = a_max3(mx, VQS_SV(i), VQS_SV(i + 1));
-        mx = fmaxf(mx, VQS_SV(31));
-#undef VQS_SV
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        // keep the old running max while the new one is at most 2^RESCALE_THR above it (P stays <= 2^THR, exact in
-        // fp32/bf16 range); rescale O and l only when some row's max really jumps
-        if (__any(mx > m_run + RESCALE_THR)) {
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            m_run = m_new;
-            l_run *= alpha;
-#pragma unroll
-            for (int df = 0; df < 2; ++df)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[df][r] *= alpha;
-        }
-#pragma unroll
-        for (int kf = 0; kf < 2; ++kf)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pv = __builtin_amdgcn_exp2f(s[kf][r] - m_run);
-                s[kf][r] = pv;
-                l_run += pv;
-            }
-
+#ifdef VQS_LAB
+#include "lab/attn_regstaged.inc"
 #endif
-        // ---- O^T += V^T . P^T   (i <-> d, j <-> query, k-slot (half,j) <-> key 16t + 4*half + 8*(j>>2) + (j&3))
-#pragma unroll
-        for (int kf = 0; kf < 2; ++kf)
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                uint4 pb;
-                pb.x = a_pack2(s[kf][8 * t + 0], s[kf][8 * t + 1]);
-                pb.y = a_pack2(s[kf][8 * t + 2], s[kf][8 * t + 3]);
-                pb.z = a_pack2(s[kf][8 * t + 4], s[kf][8 * t + 5]);
-                pb.w = a_pack2(s[kf][8 * t + 6], s[kf][8 * t + 7]);
-#pragma unroll
-                for (int df = 0; df < 2; ++df) {
-                    const char* vp = vt_lds + df * 32 * VT_LD + vt_rd + (kf * 32 + 16 * t) * 2;
-                    const uint2 lo = *reinterpret_cast<const uint2*>(vp);
-                    const uint2 hi = *reinterpret_cast<const uint2*>(vp + 16);
-                    uint4 va;
-                    va.x = lo.x; va.y = lo.y; va.z = hi.x; va.w = hi.y;
-#if (VQS_ATTN_ABLATE & 4)
-                    asm volatile("" ::"v"(va.x), "v"(va.y), "v"(va.z), "v"(va.w), "v"(pb.x), "v"(pb.y), "v"(pb.z), "v"(pb.w));
-#else
-                    o[df] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, va),
-                                                                   __builtin_bit_cast(bf16x8, pb), o[df], 0, 0, 0);
-#endif
-                }
-            }
-    }
-
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
-    const float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
-    if (qrow < S) {
-        bf16_t* orow = p.out + ((size_t)b * S + qrow) * ((size_t)p.H * 64) + h * 64;
-#pragma unroll
-        for (int df = 0; df < 2; ++df)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                uint2 v;
-                v.x = a_pack2(o[df][4 * g + 0] * inv, o[df][4 * g + 1] * inv);
-                v.y = a_pack2(o[df][4 * g + 2] * inv, o[df][4 * g + 3] * inv);
-                *reinterpret_cast<uint2*>(orow + df * 32 + 8 * g + 4 * hh) = v;
-            }
-    }
-}
 
 // =====================================================================================================
 // attn_fwd_dma_kernel -- same math, same MFMA operand maps and the same softmax code as attn_fwd_kernel; what changes
@@ -398,7 +143,6 @@ __global__ void __launch_bounds__(256) attn_fwd_dma_kernel(const AttnParams p) {
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hh = lane >> 5;
-    attn_desync();
     // XCD-aware work map (workgroup L runs on XCD L % 8): the q-blocks of one (sample, head) get consecutive slots of
     // ONE XCD, so its K/V tiles are fetched from HBM once and re-read from that XCD's L2 -- with the natural 3-D
     // grid the 5 q-blocks landed on 5 different XCDs and the PMC showed K/V crossing the fabric 5 times
@@ -485,8 +229,8 @@ __global__ void __launch_bounds__(256) attn_fwd_dma_kernel(const AttnParams p) {
         const int st = kt & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of tile kt have landed
         __syncthreads();                                       // ... everybody's; stage st^1 is no longer read
-        if (kt + 1 < ntiles && !(VQS_ATTN_ABLATE & 1)) stage(kt + 1, st ^ 1);
-        const char* k_lds = smem + ((VQS_ATTN_ABLATE & 1) ? 0 : st) * ST_BYTES;
+        if (kt + 1 < ntiles) stage(kt + 1, st ^ 1);
+        const char* k_lds = smem + st * ST_BYTES;
 
         // ---- S^T = K . Q^T   (i <-> key, j <-> query)
         f32x16 s[2];
@@ -501,21 +245,14 @@ __global__ void __launch_bounds__(256) attn_fwd_dma_kernel(const AttnParams p) {
 #pragma unroll
                 for (int kf = 0; kf < 2; ++kf)
                     kfr[ks][kf] = *reinterpret_cast<const uint4*>(k_lds + kf * 4096 + k_rd + (((2 * ks + hh) ^ swr) << 4));
-#if VQS_ATTN_PRIO
-            __builtin_amdgcn_s_setprio(1);         // a wave in its MFMA phase goes ahead of waves in their softmax phase
-#endif
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
                 for (int kf = 0; kf < 2; ++kf)
                     s[kf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kfr[ks][kf]),
                                                                     __builtin_bit_cast(bf16x8, qf[ks]), s[kf], 0, 0, 0);
-#if VQS_ATTN_PRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
         }
 
-#if !(VQS_ATTN_ABLATE & 2)
         // ---- softmax numerators.  With a bias the scores move to the log2 domain first (t = s*c + bias, c = scale*log2 e,
         // one FMA) and p = 2^(t - m) is a subtract + v_exp_f32; without one the row max is taken on the raw scores
         // (c > 0) and p = 2^(s*c - m) is ONE FMA + v_exp_f32.  The row SUM is not accumulated here: the PV step
@@ -569,11 +306,7 @@ __global__ void __launch_bounds__(256) attn_fwd_dma_kernel(const AttnParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 s[kf][r] = __builtin_amdgcn_exp2f(HAS_BIAS ? s[kf][r] + neg_m : fmaf(s[kf][r], sl2, neg_m));
-#endif
         // ---- O^T += V^T . P^T   (i <-> d, j <-> query, k-slot (half,j) <-> key 16t + 4*half + 8*(j>>2) + (j&3))
-#if VQS_ATTN_PRIO
-        __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
         for (int kf = 0; kf < 2; ++kf)
 #pragma unroll
@@ -599,9 +332,6 @@ __global__ void __launch_bounds__(256) attn_fwd_dma_kernel(const AttnParams p) {
                                                                    __builtin_bit_cast(bf16x8, pb), o[df], 0, 0, 0);
                 }
             }
-#if VQS_ATTN_PRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
     }
 
     const float l_tot = osum[0];                  // all 32 rows of the ones-product are the same row sum
@@ -837,6 +567,7 @@ __global__ void __launch_bounds__(256) attn_fwd_hd_kernel(const AttnParams p) {
     }
 }
 
+#ifdef VQS_LAB
 static int attn_variant() {       // VQS_ATTN_VARIANT=0 selects the register-staged kernel (lab A/B); default = LDS-DMA kernel
     static int v = -1;
     if (v < 0) {
@@ -854,6 +585,10 @@ static size_t attn_lds_pad() {    // lab: VQS_ATTN_LDS_PAD=<bytes> inflates the 
     }
     return (size_t)v;
 }
+#else
+static constexpr int attn_variant() { return 1; }        // the shipped library holds the LDS-DMA kernel only
+static constexpr size_t attn_lds_pad() { return 0; }
+#endif
 
 template <typename KernelT>
 static hipError_t launch_attn_t(KernelT kern, const AttnParams& p, size_t lds, hipStream_t stream) {
@@ -881,10 +616,12 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
     if (p.hd != 0 && p.hd != 64) return hipErrorInvalidValue;
     if (p.causal || (p.Hkv > 0 && p.Hkv != p.H)) return hipErrorInvalidValue;
     const size_t bias_bytes = p.bias_table ? (size_t)bias_copy_chunks(p.S) * 64 : 0;
+#ifdef VQS_LAB
     if (attn_variant() == 0) {
         const size_t lds = K_LDS + VT_LDS + bias_bytes;
         return p.bias_table ? launch_attn_t(attn_fwd_kernel<true>, p, lds, stream) : launch_attn_t(attn_fwd_kernel<false>, p, lds, stream);
     }
+#endif
     const size_t lds = 2 * ST_BYTES + bias_bytes;
     return p.bias_table ? launch_attn_t(attn_fwd_dma_kernel<true>, p, lds, stream)
                         : launch_attn_t(attn_fwd_dma_kernel<false>, p, lds, stream);

@@ -54,38 +54,22 @@ __device__ __forceinline__ uint32_t e_pack2_hw(float a, float b) {   // v_cvt_pk
 }
 
 // The fp32 stream is touched once per norm and not again before gigabytes of other traffic have passed: its loads and
-// stores are non-temporal (VQS_NORM_NT bit 0 = loads, bit 1 = stores; in situ +0.4 % / 0 / +0.76 % for 1 / 2 / 3 against
-// cached accesses, profiles/r1_call88_ab_norm_nt.txt), which leaves L2 / Infinity Cache to the bf16 operands the GEMMs read
-// next.  Bit 2 (lab): also the last-use loads of the deltas.
-#ifndef VQS_NORM_NT
-#define VQS_NORM_NT 3
-#endif
+// stores are non-temporal (in situ +0.4 % for the loads alone, 0 for the stores alone, +0.76 % for both against cached
+// accesses, profiles/r1_call88_ab_norm_nt.txt), which leaves L2 / Infinity Cache to the bf16 operands the GEMMs read
+// next.  Making the deltas' last reads non-temporal as well measured nothing, so they stay plain loads.
 typedef float e_f4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 ld_stream(const float4* p) {
-#if (VQS_NORM_NT & 1)
     const e_f4v v = __builtin_nontemporal_load(reinterpret_cast<const e_f4v*>(p));
     return make_float4(v.x, v.y, v.z, v.w);
-#else
-    return *p;
-#endif
 }
 typedef unsigned int e_u2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint2 ld_delta_last(const uint2* p) {      // a delta's last reader
-#if (VQS_NORM_NT & 4)
-    const e_u2v v = __builtin_nontemporal_load(reinterpret_cast<const e_u2v*>(p));
-    return make_uint2(v.x, v.y);
-#else
     return *p;
-#endif
 }
 __device__ __forceinline__ void st_stream(float4* p, float4 v) {
-#if (VQS_NORM_NT & 2)
     e_f4v u;
     u.x = v.x; u.y = v.y; u.z = v.z; u.w = v.w;
     __builtin_nontemporal_store(u, reinterpret_cast<e_f4v*>(p));
-#else
-    *p = v;
-#endif
 }
 
 // KIND 0: RMSNorm (bsh unused); KIND 1: LayerNorm.

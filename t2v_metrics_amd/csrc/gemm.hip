@@ -21,20 +21,10 @@
 #include "vqs_kernels.h"
 #include <cstdlib>
 
-// Lab-only ablation switches (tools/gemm_lab.sh builds variants; the product build leaves this at 0):
-//   1 = no global->LDS staging after the first K-tile, 2 = no epilogue stores, 4 = fragments read from LDS once
-#ifndef VQS_ABLATE
-#define VQS_ABLATE 0
-#endif
-#ifndef VQS_PRIO_SPLIT
-#define VQS_PRIO_SPLIT 1
-#endif
-#ifndef VQS_DMA_BUFFER
-#define VQS_DMA_BUFFER 1
-#endif
-#ifndef VQS_DMA_SPLIT
-#define VQS_DMA_SPLIT 3   // 3 (default): four pieces in each of the first two k-steps (+2-5 % where operands stream from HBM); 0: two per k-step; 1: halves of the K-tile by wave row; 2: staggered among the MFMAs by wave column (0-2 equal within 2 %); 4: all eight in the first k-step
-#endif
+// Build flavours: the shipped library holds the kernels the engine launches (variant 0 one tile per workgroup, 2 / 5
+// ping-pong, 3 persistent with its schedule chosen by shape).  -DVQS_LAB (tools/lab builds only) adds the A/B forms kept
+// for the record -- the register-staged kernel (variant 1), the loader/consumer wave-specialised kernel (4), the forced
+// lock-step launch (7) and the VQS_L2_TOUCH environment switch.  Ablation builds of round 1 are in the git history.
 
 namespace vqs {
 
@@ -172,13 +162,6 @@ __global__ void __launch_bounds__(512) gemm_bf16_kernel(const GemmParams p) {
         }
     };
 
-    uint4 abl_af[4], abl_wf[2];
-    if constexpr ((VQS_ABLATE & 4) != 0) {
-#pragma unroll
-        for (int m = 0; m < 4; ++m) abl_af[m] = *reinterpret_cast<const uint4*>(p.A + (size_t)(lane + m * 64) * 8);
-#pragma unroll
-        for (int n = 0; n < 2; ++n) abl_wf[n] = *reinterpret_cast<const uint4*>(p.W + (size_t)(lane + n * 64) * 8);
-    }
     if constexpr (VAR == 2) {
         // ---- ping-pong schedule.  The two waves that share a SIMD (w and w+4, i.e. wr = 0 / 1) run one barrier
         // apart: while one group is in an MFMA segment (8 MFMAs = one k-step of 16) the other is in a load segment
@@ -242,22 +225,15 @@ __global__ void __launch_bounds__(512) gemm_bf16_kernel(const GemmParams p) {
     for (int t = 0; t < nt; ++t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                       // tile t landed everywhere; buffer (t+1)&1 no longer read
-        if ((t + 1 < nt) && !(VQS_ABLATE & 1)) stage((t + 1) & 1, t + 1);
-        const char* sb = lds + ((VQS_ABLATE & 1) ? 0 : (t & 1)) * STAGE_BYTES;
+        if (t + 1 < nt) stage((t + 1) & 1, t + 1);
+        const char* sb = lds + (t & 1) * STAGE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             uint4 af[4], wf[2];
-            if constexpr ((VQS_ABLATE & 4) != 0) {
 #pragma unroll
-                for (int m = 0; m < 4; ++m) af[m] = abl_af[m];
+            for (int m = 0; m < 4; ++m) af[m] = *reinterpret_cast<const uint4*>(sb + a_row + m * 4096 + koff[ks]);
 #pragma unroll
-                for (int n = 0; n < 2; ++n) wf[n] = abl_wf[n];
-            } else {
-#pragma unroll
-                for (int m = 0; m < 4; ++m) af[m] = *reinterpret_cast<const uint4*>(sb + a_row + m * 4096 + koff[ks]);
-#pragma unroll
-                for (int n = 0; n < 2; ++n) wf[n] = *reinterpret_cast<const uint4*>(sb + b_row + n * 4096 + koff[ks]);
-            }
+            for (int n = 0; n < 2; ++n) wf[n] = *reinterpret_cast<const uint4*>(sb + b_row + n * 4096 + koff[ks]);
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -267,16 +243,6 @@ __global__ void __launch_bounds__(512) gemm_bf16_kernel(const GemmParams p) {
         }
     }
     }
-    if constexpr ((VQS_ABLATE & 2) != 0) {
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[m][n][r]));
-        return;
-    }
-
     // ---- epilogue.  acc[m][n][r]: row = m0 + wr*128 + m*32 + (lane&31)
     //                               col = n0 + wc*64 + n*32 + 8*(r>>2) + 4*(lane>>5) + (r&3)
     const int hhalf = lane >> 5;
@@ -396,14 +362,6 @@ __global__ void __launch_bounds__(512) gemm_bf16_kernel(const GemmParams p) {
 __device__ __forceinline__ void st8(void* p, uint2 v) { *reinterpret_cast<uint2*>(p) = v; }
 __device__ __forceinline__ void st16(void* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
-#if (VQS_ABLATE & 32)
-__device__ unsigned long long* g_gemm_dbg = nullptr;   // [blocks][8 waves][8 counters], set by vqs_debug_set_gemm_timing
-#define TSTAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
-#define TACC(slot, a, b) tacc[slot] += (b) - (a)
-#else
-#define TSTAMP(var)
-#define TACC(slot, a, b)
-#endif
 
 
 // ----------------------------------------------------------------------------------------------------
@@ -798,7 +756,6 @@ __global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) 
 
     const int sw = ((w & 1) << 2) + (lane >> 4);
     const int gchunk = (lane & 7) ^ sw;
-#if VQS_DMA_BUFFER
     uint32_t pa[4], pb[4];          // byte offsets from the batch entry's base (every operand is < 4 GiB)
     v4i_t rsA, rsW;
     auto set_ptrs = [&](int m0, int n0, int bz) {
@@ -813,22 +770,6 @@ __global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) 
     };
 #define PGLDS_A(i, koffs, dst) bglds16(rsA, pa[i], (uint32_t)((koffs) * 2), (dst))
 #define PGLDS_W(i, koffs, dst) bglds16(rsW, pb[i], (uint32_t)((koffs) * 2), (dst))
-#else
-    const bf16_t* pa[4];
-    const bf16_t* pb[4];
-    auto set_ptrs = [&](int m0, int n0, int bz) {
-        const bf16_t* Ab = p.A + (size_t)bz * p.sA;
-        const bf16_t* Wb = p.W + (size_t)bz * p.sW;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = (i * 8 + w) * 8 + (lane >> 3);
-            pa[i] = Ab + (size_t)min(m0 + row, p.M - 1) * p.lda + gchunk * 8;
-            pb[i] = Wb + (size_t)min(n0 + row, p.N - 1) * p.ldw + gchunk * 8;
-        }
-    };
-#define PGLDS_A(i, koffs, dst) glds16(pa[i] + (koffs), (dst))
-#define PGLDS_W(i, koffs, dst) glds16(pb[i] + (koffs), (dst))
-#endif
     auto stage = [&](int s, int t) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -851,10 +792,6 @@ __global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) 
     tile_coords(pid, m0, n0, bz);
     set_ptrs(m0, n0, bz);
     stage(0, 0);
-#if (VQS_ABLATE & 32)
-    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
-#endif
     int buf = 0;
     bool counted = false;     // true: the only VMEM ops younger than the prefetched K-tile are a full epilogue's stores
     // TOUCH state (batch <= 1 only, enforced by the launcher)
@@ -897,7 +834,6 @@ __global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) 
         }
 
         for (int t = 0; t < nt; ++t) {
-            TSTAMP(ts0);
             if (t == 0 && counted) {
                 if constexpr (EpiStores<EPI>::value == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                 else if constexpr (EpiStores<EPI>::value == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
@@ -909,9 +845,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) 
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             did_touch = false;
-            TSTAMP(ts1);
             __builtin_amdgcn_s_barrier();
-            TSTAMP(ts2);
             // source of the stage that is filled during this K-tile: the next K-tile of this tile, or the first
             // K-tile of the next tile.  The 8 LDS-DMA pieces are issued two per k-step BETWEEN the MFMA groups:
             // issued back to back they cost 600-1700 cycles per wave (measured) during which the wave's matrix
@@ -928,8 +862,6 @@ __global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) 
             }
             const size_t koffs = (size_t)kn * BK;
             const uint32_t dst0 = lds_base + (buf ^ 1) * STAGE_BYTES + w * 1024;
-            TSTAMP(ts3);
-            TACC(0, ts0, ts1); TACC(1, ts1, ts2); TACC(2, ts2, ts3);
             const char* sb = lds + buf * STAGE_BYTES;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
@@ -969,46 +901,11 @@ __global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) 
                         }
                     }
                 }
-#if VQS_PRIO_SPLIT
                 // the older wave of a SIMD wins issue arbitration all the time (measured: its 32 MFMAs take ~2000
                 // cycles, the younger wave's ~2600, and the older half then idles at the barrier): hand the
                 // younger half (waves 4-7) priority for the first two k-steps of every K-tile
                 if (ks == 0 && wr == 1) __builtin_amdgcn_s_setprio(1);
                 if (ks == 2 && wr == 1) __builtin_amdgcn_s_setprio(0);
-#endif
-#if VQS_DMA_SPLIT == 2
-                // DMA issue staggered over the CU: wave column wc issues its A piece after its wc-th MFMA of this
-                // k-step and its W piece after the (wc+4)-th, so LDS-DMA requests reach the texture addresser one
-                // at a time instead of in 16-deep bursts (a queued DMA blocks the issuing wave, not just the TA)
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-#pragma unroll
-                    for (int n = 0; n < 2; ++n) {
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                            __builtin_bit_cast(bf16x8, wf[n]), __builtin_bit_cast(bf16x8, af[m]), acc[m][n], 0, 0, 0);
-                        const int idx = m * 2 + n;
-                        if (do_stage && idx == wc && !(VQS_ABLATE & 128)) PGLDS_A(ks, koffs, dst0 + ks * 8192);
-                        if (do_stage && idx == wc + 4 && !(VQS_ABLATE & 64)) PGLDS_W(ks, koffs, dst0 + ks * 8192 + W_OFF);
-                    }
-            }
-#else
-#if VQS_DMA_SPLIT == 1
-                if (do_stage && (ks >> 1) == wr) {
-                    const int i0 = (ks & 1) * 2;
-                    PGLDS_A(i0, koffs, dst0 + i0 * 8192);
-                    PGLDS_W(i0, koffs, dst0 + i0 * 8192 + W_OFF);
-                    PGLDS_A(i0 + 1, koffs, dst0 + (i0 + 1) * 8192);
-                    PGLDS_W(i0 + 1, koffs, dst0 + (i0 + 1) * 8192 + W_OFF);
-                }
-#elif VQS_DMA_SPLIT == 4
-                if (do_stage && ks == 0) {
-#pragma unroll
-                    for (int i0 = 0; i0 < 4; ++i0) {
-                        PGLDS_A(i0, koffs, dst0 + i0 * 8192);
-                        PGLDS_W(i0, koffs, dst0 + i0 * 8192 + W_OFF);
-                    }
-                }
-#elif VQS_DMA_SPLIT == 3
                 // all eight pieces in the first two k-steps: the last piece has >= 2 k-steps (~1 300 cycles) to land
                 // instead of one -- for operands streamed from HBM (the K = 1024 ViT shapes wait 350-900 cycles per K-tile)
                 if (do_stage && ks < 2) {
@@ -1018,12 +915,6 @@ __global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) 
                     PGLDS_A(i0 + 1, koffs, dst0 + (i0 + 1) * 8192);
                     PGLDS_W(i0 + 1, koffs, dst0 + (i0 + 1) * 8192 + W_OFF);
                 }
-#else
-                if (do_stage) {
-                    PGLDS_A(ks, koffs, dst0 + ks * 8192);
-                    PGLDS_W(ks, koffs, dst0 + ks * 8192 + W_OFF);
-                }
-#endif
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -1031,14 +922,8 @@ __global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) 
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                             __builtin_bit_cast(bf16x8, wf[n]), __builtin_bit_cast(bf16x8, af[m]), acc[m][n], 0, 0, 0);
             }
-#endif
             buf ^= 1;
-#if (VQS_ABLATE & 32)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            { TSTAMP(ts4); TACC(3, ts3, ts4); tacc[5] += 1; }
-#endif
         }
-        TSTAMP(te0);
 
         // ---------------- epilogue: C tile staged through the LDS stage that was just consumed, stored as whole rows.
         // (Storing straight from the accumulator layout touches 32 rows x 16 B per instruction and measured 10-20 K
@@ -1047,239 +932,22 @@ __global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) 
         __builtin_amdgcn_s_barrier();                       // every wave is done reading stage buf^1
         staged_epilogue<EPI>(p, acc, lds + (buf ^ 1) * STAGE_BYTES + w * 8192, m0, n0, bz, wr, wc, lane, full, rowred);
         counted = full;
-#if (VQS_ABLATE & 32)
-        { TSTAMP(te1); TACC(4, te0, te1); tacc[6] += 1; }
-#endif
         if (!has_next) break;
         pid = next_pid;
         m0 = nm0;
         n0 = nn0;
         bz = nbz;
     }
-#if (VQS_ABLATE & 32)
-    if (g_gemm_dbg != nullptr && lane == 0 && blockIdx.x < 64) {
-        tacc[7] = __builtin_amdgcn_s_memtime() - t_start;
-        for (int i = 0; i < 8; ++i) g_gemm_dbg[((size_t)blockIdx.x * 8 + w) * 8 + i] = tacc[i];
-    }
-#endif
 }
 
 
 #undef PGLDS_A
 #undef PGLDS_W
 
-// =====================================================================================================
-// Wave-specialised persistent variant (VAR 4): 12 waves per workgroup.  Waves 0-7 are CONSUMERS (ds_read_b128 +
-// MFMA + epilogue, the same 2x4 layout and LDS image as above); waves 8-11 are LOADERS, one per SIMD, that issue all
-// 64 LDS-DMA pieces of a K-tile (16 each) and do nothing else.  Motivation (tools/gemm_lab.sh): an LDS-DMA costs
-// the issuing wave 75-200 cycles during which it cannot feed the matrix pipe; with the DMA removed from the MFMA
-// waves the same loop ran 26-30 % faster.  3 waves per SIMD => at most 168 VGPRs per wave.
-// One s_barrier per K-tile for everybody: loaders wait for their own DMA (vmcnt(0)) before it, consumers never wait
-// on VMEM at all (their epilogue stores just drain).
-// =====================================================================================================
-template <int EPI>
-__device__ __forceinline__ void ws_epilogue(const GemmParams& p, f32x16 (&acc)[4][2], int m0, int n0, int bz, int wr, int wc,
-                                            int lane) {
-    const int hhalf = lane >> 5;
-    const int row_base = m0 + wr * 128 + (lane & 31);
-    const int col_base = n0 + wc * 64 + 4 * hhalf;
-    const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
-    if constexpr (EPI == EPI_GATED) {
-        const int oc_base = ((n0 + wc * 64) >> 1) + 4 * hhalf;
-        const int NO = p.N >> 1;
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int row = row_base + m * 32;
-            bf16_t* crow = reinterpret_cast<bf16_t*>(p.C) + (size_t)bz * p.sC + (size_t)row * p.ldc;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int oc = oc_base + 8 * g;
-                uint2 v;
-                v.x = pack2(act_gelu_new(acc[m][0][4 * g + 0]) * acc[m][1][4 * g + 0],
-                            act_gelu_new(acc[m][0][4 * g + 1]) * acc[m][1][4 * g + 1]);
-                v.y = pack2(act_gelu_new(acc[m][0][4 * g + 2]) * acc[m][1][4 * g + 2],
-                            act_gelu_new(acc[m][0][4 * g + 3]) * acc[m][1][4 * g + 3]);
-                if (full || (row < p.M && oc < NO)) *reinterpret_cast<uint2*>(crow + oc) = v;
-            }
-        }
-    } else {
-        bf16_t* head_base = nullptr;
-        if constexpr (EPI == EPI_HEADS) {
-            const int cw = min(n0 + wc * 64, p.N - 64);
-            const int which = cw / p.inner;
-            bf16_t* hp = which == 0 ? p.heads_out[0] : (which == 1 ? p.heads_out[1] : p.heads_out[2]);
-            head_base = hp + (size_t)((cw - which * p.inner) >> 6) * p.S * 64;
-        }
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int c = col_base + n * 32 + 8 * g;
-                float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
-                if (p.bias != nullptr && c < p.N) {
-                    const uint2 bv = *reinterpret_cast<const uint2*>(p.bias + c);
-                    b0 = bf2f((bf16_t)(bv.x & 0xffff)); b1 = bf2f((bf16_t)(bv.x >> 16));
-                    b2 = bf2f((bf16_t)(bv.y & 0xffff)); b3 = bf2f((bf16_t)(bv.y >> 16));
-                }
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const int row = row_base + m * 32;
-                    const bool ok = full || (row < p.M && c < p.N);
-                    float o0 = acc[m][n][4 * g + 0] + b0, o1 = acc[m][n][4 * g + 1] + b1;
-                    float o2 = acc[m][n][4 * g + 2] + b2, o3 = acc[m][n][4 * g + 3] + b3;
-                    if constexpr (EPI == EPI_BF16_QGELU) {
-                        o0 = act_quick_gelu(o0); o1 = act_quick_gelu(o1); o2 = act_quick_gelu(o2); o3 = act_quick_gelu(o3);
-                    }
-                    if constexpr (EPI == EPI_BF16_GELU) {
-                        o0 = act_gelu_erf(o0); o1 = act_gelu_erf(o1); o2 = act_gelu_erf(o2); o3 = act_gelu_erf(o3);
-                    }
-                    if constexpr (EPI == EPI_F32) {
-                        float* cp = reinterpret_cast<float*>(p.C) + (size_t)bz * p.sC + (size_t)row * p.ldc + c;
-                        if (ok) *reinterpret_cast<float4*>(cp) = make_float4(o0, o1, o2, o3);
-                    } else {
-                        uint2 v;
-                        v.x = pack2(o0, o1);
-                        v.y = pack2(o2, o3);
-                        bf16_t* dst;
-                        if constexpr (EPI == EPI_HEADS) {
-                            const int rowc = min(row, p.M - 1);
-                            const int hb = rowc / p.S, hs = rowc - hb * p.S;
-                            dst = head_base + ((size_t)hb * p.H * p.S + hs) * 64 + (c - (n0 + wc * 64));
-                        } else {
-                            dst = reinterpret_cast<bf16_t*>(p.C) + (size_t)bz * p.sC + (size_t)row * p.ldc + c;
-                        }
-                        if (ok) *reinterpret_cast<uint2*>(dst) = v;
-                    }
-                }
-            }
-    }
-}
+#ifdef VQS_LAB
+#include "lab/gemm_ws.inc"
+#endif
 
-template <int EPI>
-__global__ void __launch_bounds__(768) gemm_bf16_ws(const GemmParams p) {
-    __shared__ __attribute__((aligned(16))) char lds[2 * STAGE_BYTES];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
-    const int tiles_pb = tiles_m * tiles_n;
-    const int nwg = tiles_pb * (p.batch > 0 ? p.batch : 1);
-    const int nt = p.K / BK;
-
-    auto tile_coords = [&](int pid, int& m0, int& n0, int& bz) {
-        const int xcd = pid & 7, local = pid >> 3;
-        const int q = nwg >> 3, r = nwg & 7;
-        int t_lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
-        bz = t_lin / tiles_pb;
-        t_lin -= bz * tiles_pb;
-        const int GM = 8;
-        const int width = GM * tiles_n;
-        const int group = t_lin / width;
-        const int first_m = group * GM;
-        const int gsz = min(tiles_m - first_m, GM);
-        m0 = (first_m + (t_lin % width) % gsz) * BM;
-        n0 = ((t_lin % width) / gsz) * BN;
-    };
-
-    int pid = blockIdx.x;
-    if (pid >= nwg) return;
-
-    if (w >= 8) {
-        // ------------------------------------------------------------------ loader wave j: pieces p = j, j+4, ...
-        const int j = w - 8;
-        __builtin_amdgcn_s_setprio(3);     // DMA issue must not queue behind the consumers' instruction stream
-        const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)LDS_PTR(lds));
-        const int gchunk = (lane & 7) ^ (((j & 1) << 2) + (lane >> 4));     // (row>>1)&7 of the rows this lane stages
-        const bf16_t* pa[8];
-        const bf16_t* pb[8];
-        auto set_ptrs = [&](int m0, int n0, int bz) {
-            const bf16_t* Ab = p.A + (size_t)bz * p.sA;
-            const bf16_t* Wb = p.W + (size_t)bz * p.sW;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int row = (j + 4 * q) * 8 + (lane >> 3);
-                pa[q] = Ab + (size_t)min(m0 + row, p.M - 1) * p.lda + gchunk * 8;
-                pb[q] = Wb + (size_t)min(n0 + row, p.N - 1) * p.ldw + gchunk * 8;
-            }
-        };
-        auto stage = [&](int s, int t) {
-            const uint32_t d0 = lds_base + s * STAGE_BYTES + j * 1024;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                glds16(pa[q] + (size_t)t * BK, d0 + q * 4096);
-                glds16(pb[q] + (size_t)t * BK, d0 + q * 4096 + W_OFF);
-            }
-        };
-        int m0, n0, bz;
-        tile_coords(pid, m0, n0, bz);
-        set_ptrs(m0, n0, bz);
-        stage(0, 0);
-        int buf = 0;
-        while (true) {
-            const int next_pid = pid + gridDim.x;
-            const bool has_next = next_pid < nwg;
-            for (int t = 0; t < nt; ++t) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                if (t + 1 < nt) {
-                    stage(buf ^ 1, t + 1);
-                } else if (has_next) {
-                    tile_coords(next_pid, m0, n0, bz);
-                    set_ptrs(m0, n0, bz);
-                    stage(buf ^ 1, 0);
-                }
-                buf ^= 1;
-            }
-            if (!has_next) break;
-            pid = next_pid;
-        }
-        return;
-    }
-
-    // ---------------------------------------------------------------------- consumer waves
-    const int wr = w >> 2, wc = w & 3;
-    const int swr = (lane >> 1) & 7;
-    int koff[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) koff[ks] = (((ks * 2 + (lane >> 5)) ^ swr) << 4);
-    const int a_row = (wr * 128 + (lane & 31)) * 128;
-    const int b_row = W_OFF + (wc * 64 + (lane & 31)) * 128;
-    int buf = 0;
-    while (true) {
-        int m0, n0, bz;
-        tile_coords(pid, m0, n0, bz);
-        f32x16 acc[4][2];
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
-        for (int t = 0; t < nt; ++t) {
-            __builtin_amdgcn_s_barrier();
-            const char* sb = lds + buf * STAGE_BYTES;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                uint4 af[4], wf[2];
-#pragma unroll
-                for (int m = 0; m < 4; ++m) af[m] = *reinterpret_cast<const uint4*>(sb + a_row + m * 4096 + koff[ks]);
-#pragma unroll
-                for (int n = 0; n < 2; ++n) wf[n] = *reinterpret_cast<const uint4*>(sb + b_row + n * 4096 + koff[ks]);
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-#pragma unroll
-                    for (int n = 0; n < 2; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                            __builtin_bit_cast(bf16x8, wf[n]), __builtin_bit_cast(bf16x8, af[m]), acc[m][n], 0, 0, 0);
-            }
-            buf ^= 1;
-        }
-        ws_epilogue<EPI>(p, acc, m0, n0, bz, wr, wc, lane);
-        const int next_pid = pid + gridDim.x;
-        if (next_pid >= nwg) break;
-        pid = next_pid;
-    }
-}
 
 // =====================================================================================================
 // Persistent PING-PONG variant (VAR 5).  Same tile, LDS image, tile map and staged epilogue as the persistent kernel
@@ -1526,8 +1194,12 @@ __global__ void __launch_bounds__(512) gemm_bf16_pingpong(const GemmParams p) {
 // VQS_L2_TOUCH: 4 (default) = A-panel touch for N <= 2048; 3 = A and W panels for N <= 2048; 1 = A and W for every
 // lock-step launch; 0 = off
 static int l2_touch_mode() {
+#ifdef VQS_LAB
     static const int mode = [] { const char* e = std::getenv("VQS_L2_TOUCH"); return e ? std::atoi(e) : 4; }();
     return mode;
+#else
+    return 4;
+#endif
 }
 
 template <int EPI>
@@ -1546,8 +1218,10 @@ static hipError_t launch_epi(const GemmParams& p, int variant, hipStream_t strea
     } else
     if (variant == 0 || (EPI == EPI_HEADS && p.S < 8 && variant != 1 && variant != 2))   // the staged epilogue steps rows by 8 within a sample
         hipLaunchKernelGGL((gemm_bf16_kernel<EPI, 0>), grid, block, 0, stream, p);
+#ifdef VQS_LAB
     else if (variant == 1)
         hipLaunchKernelGGL((gemm_bf16_kernel<EPI, 1>), grid, block, 0, stream, p);
+#endif
     else if (variant == 2)
         hipLaunchKernelGGL((gemm_bf16_kernel<EPI, 2>), grid, block, 0, stream, p);
     else if (variant == 5 && EPI != EPI_F32_RESID) {
@@ -1556,12 +1230,14 @@ static hipError_t launch_epi(const GemmParams& p, int variant, hipStream_t strea
             dim3 pgrid(nwg < PERSISTENT_WGS ? nwg : PERSISTENT_WGS);
             hipLaunchKernelGGL((gemm_bf16_pingpong<EPI>), pgrid, block, 0, stream, p);
         }
+#ifdef VQS_LAB
     } else if (variant == 4 && EPI != EPI_F32_RESID) {
         if constexpr (EPI != EPI_F32_RESID) {
             const int nwg = tiles_m * tiles_n * (p.batch > 0 ? p.batch : 1);
             dim3 pgrid(nwg < PERSISTENT_WGS ? nwg : PERSISTENT_WGS);
             hipLaunchKernelGGL((gemm_bf16_ws<EPI>), pgrid, dim3(768), 0, stream, p);
         }
+#endif
     } else {
         if constexpr (EPI == EPI_F32_RESID) {
             // the in-epilogue fp32 read-modify-write does not fit the persistent kernel's register budget (it
@@ -1590,14 +1266,11 @@ static hipError_t launch_epi(const GemmParams& p, int variant, hipStream_t strea
     return hipGetLastError();
 }
 
-#if (VQS_ABLATE & 32)
-extern "C" int vqs_debug_set_gemm_timing(void* d_buf) {
-    unsigned long long* p = (unsigned long long*)d_buf;
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_dbg), &p, sizeof(p)) == hipSuccess ? 0 : -1;
-}
-#endif
 
 hipError_t launch_gemm(const GemmParams& p, int epilogue, int variant, hipStream_t stream) {
+#ifndef VQS_LAB
+    if (variant == 1 || variant == 4 || variant == 7) return hipErrorInvalidValue;     // lab-only forms (see the file header)
+#endif
     // N: a lane stores 4 consecutive columns; fp32 output may have a ragged N if ldc leaves room for the overhang
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K % BK) != 0) return hipErrorInvalidValue;
     if ((p.N % 8) != 0 && !(epilogue == EPI_F32 && p.ldc >= ((p.N + 3) & ~3) && p.bias == nullptr)) return hipErrorInvalidValue;

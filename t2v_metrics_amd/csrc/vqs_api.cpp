@@ -391,12 +391,27 @@ int vqs_create(const vqs_config* cfg, vqs_handle** out) {
         h->h_lut_bidir.push_back(vqs_relpos_bucket(-n, 1, c.rel_buckets, c.rel_max_distance));
         h->h_lut_causal.push_back(vqs_relpos_bucket(-n, 0, c.rel_buckets, c.rel_max_distance));
     }
+    h->gemm_variant = 3;   // persistent kernel, schedule chosen by shape (gemm.hip)
+#ifdef VQS_LAB
+    // lab builds only (tools/lab): in-situ A/B of the alternative forms through the environment
     if (const char* cm = std::getenv("VQS_CROSS_MODE")) h->cross_mode = std::atoi(cm);
     if (const char* sk = std::getenv("VQS_SPLITK")) h->splitk = std::atoi(sk);
     if (const char* fn = std::getenv("VQS_FUSED_NORM")) h->fused_norm = std::atoi(fn);
     if (const char* nd = std::getenv("VQS_NORM_DEFER")) h->norm_defer = std::atoi(nd);
-    const char* v = std::getenv("VQS_GEMM_VARIANT");
-    h->gemm_variant = v ? std::atoi(v) : 3;   // 3 = persistent kernel (gemm.hip)
+    if (const char* v = std::getenv("VQS_GEMM_VARIANT")) h->gemm_variant = std::atoi(v);
+#endif
+    return VQS_OK;
+}
+
+int vqs_set_option(vqs_handle* h, const char* name, int32_t value) {
+    if (!h || !name) return VQS_ERR_INVALID;
+    const std::string n(name);
+    if (n == "cross_mode" && (value == 0 || value == 1)) h->cross_mode = value;
+    else if (n == "splitk" && (value == 0 || value == 1)) h->splitk = value;
+    else if (n == "fused_norm" && (value == 0 || value == 1)) h->fused_norm = value;
+    else if (n == "norm_defer" && (value == 0 || value == 1)) h->norm_defer = value;
+    else if (n == "gemm_variant" && (value == 0 || value == 2 || value == 3 || value == 5)) h->gemm_variant = value;
+    else return fail(h, VQS_ERR_INVALID, "set_option: unknown option or value: " + n + "=" + std::to_string(value));
     return VQS_OK;
 }
 

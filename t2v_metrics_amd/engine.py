@@ -68,6 +68,7 @@ _SIGNATURES = {
     "vqs_norm_deferred": (_c_i32, [_c_i32, _c_vp, _c_vp, _c_vp, _c_i32, _c_vp, _c_vp, _c_vp, _c_i32, _c_i32, _c_f32, _c_vp]),
     "vqs_score_head": (_c_i32, [_c_vp, _c_i32, _c_i32, _c_vp, _c_vp, _c_vp, _c_i32, _c_i32, _c_vp]),
     "vqs_attention_lds_bytes": (ctypes.c_int64, [_c_i32, _c_i32, _c_i32]),
+    "vqs_set_option": (_c_i32, [_c_vp, ctypes.c_char_p, _c_i32]),
     "vqs_debug_tap": (_c_i32, [_c_vp, ctypes.c_char_p, _c_vp, ctypes.c_size_t]),
     "vqs_debug_heads_rows": (_c_i32, [_c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_vp]),
     "vqs_relpos_bucket": (_c_i32, [_c_i32, _c_i32, _c_i32, _c_i32]),
@@ -117,7 +118,9 @@ def make_vqs_config(cfg: ClipT5Config) -> VqsConfig:
 class VqsEngine:
     """One CLIP-FlanT5 replica on one GPU."""
 
-    def __init__(self, cfg: ClipT5Config, weights: Dict[str, torch.Tensor], device="cuda:0"):
+    def __init__(self, cfg: ClipT5Config, weights: Dict[str, torch.Tensor], device="cuda:0",
+                 options: Optional[Dict[str, int]] = None):
+        """options: execution-form switches of include/vqs.h vqs_set_option (parity tests A/B the alternative forms)."""
         self.lib = load_library()
         self.cfg = cfg
         self.device = torch.device(device)
@@ -132,6 +135,8 @@ class VqsEngine:
         self._ws: Optional[torch.Tensor] = None
         self._ws_shape = None
         self._ews: Optional[torch.Tensor] = None
+        for k, v in (options or {}).items():
+            self.set_option(k, v)
         self.bind(weights)
 
     # ------------------------------------------------------------------ helpers
@@ -273,6 +278,9 @@ class VqsEngine:
         if name == "flags":
             return self._ws[off: off + 4].view(torch.int32)
         raise VqsError(f"unknown stage {name}")
+
+    def set_option(self, name: str, value: int):
+        self._check(self.lib.vqs_set_option(self._h, name.encode(), int(value)), "vqs_set_option")
 
     def tap(self, name: Optional[str], dst: Optional[torch.Tensor] = None):
         """Register `dst` (device tensor, kept alive by the caller) to receive the named intermediate of the next passes

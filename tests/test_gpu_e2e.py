@@ -181,8 +181,8 @@ def test_low_sensitivity_regime_meets_1e3():
     eng.close()
 
 
-def test_reassociated_cross_attention_matches_direct_form(monkeypatch):
-    """VQS_CROSS_MODE=0 projects K|V of the encoder output per decoder layer (what HF executes); the default
+def test_reassociated_cross_attention_matches_direct_form():
+    """Option cross_mode=0 projects K|V of the encoder output per decoder layer (what HF executes); the default
     reassociates ((q Wk) E^T, (P E) Wv^T).  Same function: both must agree with the oracle and with each other."""
     from oracle.clip_t5_oracle import Oracle
     from t2v_metrics_amd.engine import VqsEngine
@@ -192,8 +192,7 @@ def test_reassociated_cross_attention_matches_direct_form(monkeypatch):
     ref = Oracle(cfg, w).forward(pix.float(), img_index, ids, labels)["label_logprobs"]
     out = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("VQS_CROSS_MODE", mode)
-        eng = VqsEngine(cfg, w, device="cuda:0")
+        eng = VqsEngine(cfg, w, device="cuda:0", options={"cross_mode": int(mode)})
         lp, _ = eng.score(eng.encode_images(pix.cuda()), img_index, ids, labels)
         torch.cuda.synchronize()
         out[mode] = lp.cpu()
@@ -204,9 +203,9 @@ def test_reassociated_cross_attention_matches_direct_form(monkeypatch):
     assert e0 <= 2 * LOGPROB_TOL_BF16 and e1 <= 2 * LOGPROB_TOL_BF16 and d01 <= 2 * LOGPROB_TOL_BF16, (e0, e1, d01)
 
 
-def test_decoder_split_k_matches_unsplit(monkeypatch):
+def test_decoder_split_k_matches_unsplit():
     """The decoder's skinny nn.Linear GEMMs run split-K (fp32 partial slices + a fixed-order reduction) by default;
-    VQS_SPLITK=0 runs them as single GEMMs.  Same function: both agree with the oracle and with each other, and the
+    option splitk=0 runs them as single GEMMs.  Same function: both agree with the oracle and with each other, and the
     split path is deterministic run to run (no atomics)."""
     import dataclasses
     from oracle.clip_t5_oracle import Oracle
@@ -219,8 +218,7 @@ def test_decoder_split_k_matches_unsplit(monkeypatch):
     ref = Oracle(cfg, w).forward(pix.float(), img_index, ids, labels)["label_logprobs"]
     out = {}
     for mode in ("0", "1", "1b"):
-        monkeypatch.setenv("VQS_SPLITK", mode[0])
-        eng = VqsEngine(cfg, w, device="cuda:0")
+        eng = VqsEngine(cfg, w, device="cuda:0", options={"splitk": int(mode[0])})
         lp, _ = eng.score(eng.encode_images(pix.cuda()), img_index, ids, labels)
         torch.cuda.synchronize()
         out[mode] = lp.cpu()
@@ -232,8 +230,8 @@ def test_decoder_split_k_matches_unsplit(monkeypatch):
     assert e0 <= 2 * LOGPROB_TOL_BF16 and e1 <= 2 * LOGPROB_TOL_BF16 and d01 <= 2 * LOGPROB_TOL_BF16, (e0, e1, d01)
 
 
-def test_fused_residual_rmsnorm_matches_separate_kernels(monkeypatch):
-    """VQS_FUSED_NORM=1: the T5 encoder's o / wo GEMM epilogues update the residual stream and hand the next RMSNorm's
+def test_fused_residual_rmsnorm_matches_separate_kernels():
+    """Option fused_norm=1: the T5 encoder's o / wo GEMM epilogues update the residual stream and hand the next RMSNorm's
     operand + row sums of squares to the consuming GEMM (no norm kernel).  Default (0): separate add+norm kernels.
     Same function: both agree with the oracle and with each other; the fused path is bitwise repeatable."""
     from oracle.clip_t5_oracle import Oracle
@@ -244,8 +242,7 @@ def test_fused_residual_rmsnorm_matches_separate_kernels(monkeypatch):
     ref = Oracle(cfg, w).forward(pix.float(), img_index, ids, labels)["label_logprobs"]
     out = {}
     for mode in ("0", "1", "1b"):
-        monkeypatch.setenv("VQS_FUSED_NORM", mode[0])
-        eng = VqsEngine(cfg, w, device="cuda:0")
+        eng = VqsEngine(cfg, w, device="cuda:0", options={"fused_norm": int(mode[0])})
         lp, _ = eng.score(eng.encode_images(pix.cuda()), img_index, ids, labels)
         torch.cuda.synchronize()
         out[mode] = lp.cpu()
@@ -257,9 +254,9 @@ def test_fused_residual_rmsnorm_matches_separate_kernels(monkeypatch):
     assert e0 <= 2 * LOGPROB_TOL_BF16 and e1 <= 2 * LOGPROB_TOL_BF16 and d01 <= 2 * LOGPROB_TOL_BF16, (e0, e1, d01)
 
 
-def test_deferred_stream_store_is_bitwise_the_stored_form(monkeypatch):
+def test_deferred_stream_store_is_bitwise_the_stored_form():
     """Default: the post-attention norm of a layer does not write the fp32 stream and the next pre-norm stores
-    (hidden + attention delta) + mlp delta (22 instead of 24 bytes per element and layer).  VQS_NORM_DEFER=0 stores in
+    (hidden + attention delta) + mlp delta (22 instead of 24 bytes per element and layer).  Option norm_defer=0 stores in
     every norm.  The fp32 additions are the same in the same order, so features, log-probs and scores must be bitwise
     equal (vision tower, T5 encoder; the decoder always stores)."""
     from t2v_metrics_amd.engine import VqsEngine
@@ -268,8 +265,7 @@ def test_deferred_stream_store_is_bitwise_the_stored_form(monkeypatch):
     pix, img_index, ids, labels = _inputs(cfg, 6, 3, 19, 2, seed=10)
     out = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("VQS_NORM_DEFER", mode)
-        eng = VqsEngine(cfg, w, device="cuda:0")
+        eng = VqsEngine(cfg, w, device="cuda:0", options={"norm_defer": int(mode)})
         feats = eng.encode_images(pix.cuda())
         lp, sc = eng.score(feats, img_index, ids, labels)
         torch.cuda.synchronize()

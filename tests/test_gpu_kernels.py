@@ -21,7 +21,7 @@ def eng():
 GEMM_SHAPES = [(256, 256, 64), (512, 768, 128), (300, 264, 192), (2065, 1024, 1024), (512, 1000, 256), (40, 64, 640)]
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [0, 2, 3, 5])       # the shipped kernels (1 / 4 / 7 exist in -DVQS_LAB builds only)
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
 def test_gemm_bf16_and_f32(eng, M, N, K, variant):
     A = randn_bf16(M, K, seed=1)
@@ -59,7 +59,7 @@ def test_gemm_persistent_many_tiles(eng, M, N, K, epi):
     bias = randn_bf16(N, seed=33)
     resid = torch.randn(M, N, device="cuda", generator=torch.Generator(device="cuda").manual_seed(34)) if epi == 4 else None
     ref = eng.gemm(A, W, epi, bias=bias, resid=resid, variant=0)
-    for variant in (3, 4, 5):
+    for variant in (3, 5):
         for _ in range(3):
             out = eng.gemm(A, W, epi, bias=bias, resid=resid, variant=variant)
             assert torch.equal(out, ref), describe(out, ref)
@@ -119,7 +119,7 @@ def test_gemm_gated(eng, M, F, K):
     w1 = randn_bf16(F, K, seed=7, scale=K ** -0.5)
     W = interleave_gate(w0, w1)
     ref = gelu_new(A.float() @ w0.float().t()) * (A.float() @ w1.float().t())
-    for variant in (0, 2, 3, 4, 5):
+    for variant in (0, 2, 3, 5):
         out = eng.gemm(A, W, 5, variant=variant)
         assert_close(out, ref, 2e-2, 1e-2, f"gemm gated {M}x{F}x{K} v{variant}")
 
@@ -131,7 +131,7 @@ def test_gemm_heads(eng, B, S, H, K, nsel):
     W = randn_bf16(nsel * I, K, seed=9, scale=K ** -0.5)
     bias = randn_bf16(nsel * I, seed=10)
     ref = (A.float() @ W.float().t() + bias.float()).reshape(B, S, nsel, H, 64).permute(2, 0, 3, 1, 4)
-    for variant in (0, 2, 3, 4, 5):
+    for variant in (0, 2, 3, 5):
         out = eng.gemm(A, W, 6, bias=bias, S=S, H=H, variant=variant)
         assert_close(out, ref, 2e-2, 1e-2, f"gemm heads v{variant}")
 

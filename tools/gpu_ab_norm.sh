@@ -1,4 +1,5 @@
 #!/bin/bash
+# (needs the lab build: make -C t2v_metrics_amd/csrc lab -- the shipped library reads no environment variables)
 # A/B of the deferred stream store (VQS_NORM_DEFER) on one box: GPU tests, then the bench with the store in every norm
 # and with the default, twice each and interleaved.  Output: gpurun_out/ab_norm.log
 bash tools/gpu_round.sh tests
@@ -7,7 +8,7 @@ grep -E "FAILED|ERROR" gpurun_out/pytest_gpu.log | head -10
 for rep in 1 2; do
   for mode in 0 1; do
     echo "VQS_NORM_DEFER=$mode rep $rep" >> gpurun_out/ab_norm.log
-    VQS_NORM_DEFER=$mode VQS_BENCH_REPORT=1 timeout 600 python bench.py --steps 4 --warmup 1 --cpu-pairs 0 >> gpurun_out/ab_norm.log 2> gpurun_out/ab_norm_report_${mode}.txt
+    VQS_LIB_PATH=build/lab/libvqs_hip_lab.so VQS_NORM_DEFER=$mode VQS_BENCH_REPORT=1 timeout 600 python bench.py --steps 4 --warmup 1 --cpu-pairs 0 >> gpurun_out/ab_norm.log 2> gpurun_out/ab_norm_report_${mode}.txt
   done
 done
 python - <<'PY'

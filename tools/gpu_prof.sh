@@ -1,22 +1,25 @@
 #!/bin/bash
-# rocprofv3 kernel trace + stats of the bench command; summaries land in gpurun_out/prof/.
-mkdir -p gpurun_out/prof
+# rocprofv3 kernel trace + stats of the bench command; summaries land in gpurun_out/prof_<xl|xxl>/.
+# MODEL=clip-flant5-xxl (default, the metric's model) | clip-flant5-xl
+MODEL=${MODEL:-clip-flant5-xxl}; TAG=${MODEL#clip-flant5-}; P=gpurun_out/prof_$TAG
+mkdir -p $P
 export PYTHONUNBUFFERED=1
 REPO=$(pwd)
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/prof -o bench -- python $REPO/bench.py --steps 3 --warmup 1 --cpu-pairs 0 > $REPO/gpurun_out/prof/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats -d $REPO/$P -o bench -- python $REPO/bench.py --model $MODEL --steps 3 --warmup 1 --cpu-pairs 0 > $REPO/$P/bench_under_rocprof.log 2>&1
 echo "rocprof exit $?"
 cd $REPO
-find gpurun_out/prof -type f | head -20
+
 # keep only the small summaries (kernel trace csv can be large)
-find gpurun_out/prof -name "*kernel_trace*" -size +20M -delete
-python tools/rocpd_summary.py gpurun_out/prof/bench_results.db gpurun_out/prof/summary "rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --cpu-pairs 0" > /dev/null 2>&1
-python - <<'PY'
-import sqlite3
-con = sqlite3.connect('gpurun_out/prof/bench_results.db')
+find $P -name "*kernel_trace*" -size +20M -delete
+python tools/rocpd_summary.py $P/bench_results.db $P/summary "rocprofv3 --kernel-trace --stats -- python bench.py --model $MODEL --steps 3 --warmup 1 --cpu-pairs 0" > /dev/null 2>&1
+python - $P <<'PY'
+import sqlite3, sys
+P = sys.argv[1]
+con = sqlite3.connect(P + '/bench_results.db')
 rows = con.execute("select name, grid_x, count(*), avg(duration), sum(duration) from kernels where name like '%vqs%' group by name, grid_x order by sum(duration) desc limit 40").fetchall()
-with open('gpurun_out/prof/by_grid.txt', 'w') as f:
+with open(P + '/by_grid.txt', 'w') as f:
     for r in rows:
         f.write(f"{r[0][:60]:60s} grid {r[1]:8d} n={r[2]:5d} avg {r[3]/1e3:9.1f} us total {r[4]/1e6:8.1f} ms\n")
 PY
-rm -f gpurun_out/prof/*.db
+rm -f $P/*.db
