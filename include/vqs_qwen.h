@@ -38,6 +38,13 @@ const char* vqs_qwen_last_error(const vqs_qwen_handle* h);
 
 /* Weights: HF state_dict names ("model.visual.blocks.0.attn.qkv.weight", ...), bf16, device, [out, in] row-major.  The
  * library packs fused / padded copies (heads padded to 128 lanes, gate|up interleaved, K padded to 64) into d_packed. */
+/* GEMM launch timing for the bench's roofline object (same contract as vqs_profile_* in vqs.h): when enabled, every GEMM
+ * launch of the following calls is bracketed by HIP events on the launch stream.  vqs_qwen_profile_read synchronises on
+ * them and returns the number of launches, their summed duration (ms), algorithmic FLOPs (2*M*N*K) and operand + result
+ * bytes.  The only entry point of this header that synchronises. */
+int vqs_qwen_profile_enable(vqs_qwen_handle* h, int32_t on);
+int vqs_qwen_profile_read(vqs_qwen_handle* h, double* gemm_ms, double* gemm_flops, double* gemm_bytes, int32_t reset);
+
 size_t vqs_qwen_packed_bytes(const vqs_qwen_handle* h);
 int vqs_qwen_bind_weights(vqs_qwen_handle* h, const vqs_weight_desc* descs, int32_t n, void* d_packed, size_t packed_bytes,
                           void* stream);

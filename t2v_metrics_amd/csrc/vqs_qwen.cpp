@@ -44,6 +44,11 @@ struct vqs_qwen_handle {
     const bf16_t* patch_w = nullptr;
     std::vector<const bf16_t*> v_qkv_w, v_qkv_b, v_proj_w, v_gu_w, v_gu_b, v_down_w;
     std::vector<const bf16_t*> t_qkv_w, t_qkv_b, t_o_w, t_gu_w, t_down_w;
+    // GEMM launch timing for bench roofline numbers (HIP events on the launch stream, as in vqs_api.cpp)
+    bool prof = false;
+    std::vector<hipEvent_t> ev;
+    size_t ev_used = 0;
+    double prof_flops = 0.0, prof_bytes = 0.0;
 };
 
 namespace {
@@ -121,7 +126,22 @@ int qgemm(vqs_qwen_handle* h, const GCall& g, hipStream_t st, const char* what) 
     p.S = g.S > 0 ? g.S : 1; p.H = g.H; p.inner = g.inner > 0 ? g.inner : 1;
     p.heads_out[0] = g.heads[0]; p.heads_out[1] = g.heads[1]; p.heads_out[2] = g.heads[2];
     p.hd = g.hd; p.inner_kv = g.inner_kv; p.Hkv = g.Hkv; p.gate_act = g.gate_act;
+    if (h->prof) {
+        while (h->ev.size() < h->ev_used + 2) {
+            hipEvent_t e;
+            QHIP(h, hipEventCreate(&e), "hipEventCreate");
+            h->ev.push_back(e);
+        }
+        QHIP(h, hipEventRecord(h->ev[h->ev_used], st), "hipEventRecord");
+    }
     QHIP(h, vqs::launch_gemm(p, g.epi, 3, st), std::string("gemm ") + what);
+    if (h->prof) {
+        QHIP(h, hipEventRecord(h->ev[h->ev_used + 1], st), "hipEventRecord");
+        h->ev_used += 2;
+        h->prof_flops += 2.0 * (double)g.M * (double)g.N * (double)g.K;
+        const double out_n = (g.epi == vqs::EPI_GATED) ? 0.5 * (double)g.N : (double)g.N;
+        h->prof_bytes += 2.0 * ((double)g.M + (double)g.N) * (double)g.K + ((g.epi == vqs::EPI_F32) ? 4.0 : 2.0) * (double)g.M * out_n;
+    }
     return VQS_OK;
 }
 
@@ -317,7 +337,34 @@ int vqs_qwen_create(const vqs_qwen_config* cfg, vqs_qwen_handle** out) {
     return VQS_OK;
 }
 
-void vqs_qwen_destroy(vqs_qwen_handle* h) { delete h; }
+void vqs_qwen_destroy(vqs_qwen_handle* h) {
+    if (!h) return;
+    for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+    delete h;
+}
+
+int vqs_qwen_profile_enable(vqs_qwen_handle* h, int32_t on) {
+    if (!h) return VQS_ERR_INVALID;
+    h->prof = on != 0;
+    return VQS_OK;
+}
+
+int vqs_qwen_profile_read(vqs_qwen_handle* h, double* gemm_ms, double* gemm_flops, double* gemm_bytes, int32_t reset) {
+    if (!h) return VQS_ERR_INVALID;
+    double ms = 0.0;
+    for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
+        QHIP(h, hipEventSynchronize(h->ev[i + 1]), "hipEventSynchronize");
+        float t = 0.f;
+        QHIP(h, hipEventElapsedTime(&t, h->ev[i], h->ev[i + 1]), "hipEventElapsedTime");
+        ms += t;
+    }
+    if (gemm_ms) *gemm_ms = ms;
+    if (gemm_flops) *gemm_flops = h->prof_flops;
+    if (gemm_bytes) *gemm_bytes = h->prof_bytes;
+    const int n = (int)(h->ev_used / 2);
+    if (reset) { h->ev_used = 0; h->prof_flops = 0.0; h->prof_bytes = 0.0; }
+    return n;
+}
 
 const char* vqs_qwen_last_error(const vqs_qwen_handle* h) { return h ? h->err.c_str() : "null handle"; }
 

@@ -29,6 +29,8 @@ _SIGS = {
     "vqs_qwen_vision_workspace_bytes": (_sz, [_vp, _i32, _i32]),
     "vqs_qwen_encode_vision": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
     "vqs_qwen_score_workspace_bytes": (_sz, [_vp, _i32, _i32]),
+    "vqs_qwen_profile_enable": (_i32, [_vp, _i32]),
+    "vqs_qwen_profile_read": (_i32, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), _i32]),
     "vqs_qwen_score": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _sz, _vp]),
 }
 
@@ -110,6 +112,17 @@ class QwenEngine:
                                                 t["sin"].data_ptr(), B, L, logits.data_ptr(), ws.data_ptr(), ws.numel(),
                                                 _stream_ptr()), "vqs_qwen_score")
             return logits
+
+    def profile(self, on: bool):
+        self._check(self.lib.vqs_qwen_profile_enable(self._h, 1 if on else 0), "vqs_qwen_profile_enable")
+
+    def profile_read(self, reset: bool = True):
+        """-> (launches, ms, flops, bytes) of the GEMM launches since the last reset (synchronises)."""
+        ms, fl, by = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_double(0)
+        n = self.lib.vqs_qwen_profile_read(self._h, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by), 1 if reset else 0)
+        if n < 0:
+            self._check(n, "vqs_qwen_profile_read")
+        return n, ms.value, fl.value, by.value
 
     def close(self):
         if getattr(self, "_h", None):

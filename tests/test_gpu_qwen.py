@@ -90,3 +90,40 @@ def test_qwen_drop_in_api_on_gpu(tmp_path):
     m = hip(images=paths[:2], texts=texts[:2])
     assert m.shape == (2, 2)
 
+
+
+def test_qwen_7b_full_size_one_sample_against_the_cpu_oracle():
+    """BASELINE.json configs[4] at the public 7B dimensions (vision 32 x 1280, LLM 28 x 3584, GQA 28/4, vocab 152 064): one
+    8-frame 336 x 448 sample (3 072 patches -> 768 vision tokens + 40 text tokens) through the HIP vision tower and prefill
+    against the fp32 oracle on the host (~1 min), on log P of the 5 most likely next tokens and of the bench's answer id.
+    Bound = bf16 operand noise, the criterion of the CLIP-FlanT5 row."""
+    from oracle.qwen25vl_oracle import QwenOracle
+    from t2v_metrics_amd.qwen.engine import QwenEngine
+    cfg = get_qwen_config("qwen2.5-vl-7b")
+    w = make_seeded_qwen_weights(cfg, seed=0, device="cuda:0")
+    eng = QwenEngine(cfg, w, device="cuda:0")
+    grid = (4, 24, 32)
+    n_patches = grid[0] * grid[1] * grid[2]
+    g = torch.Generator().manual_seed(77)
+    px = torch.randn(n_patches, cfg.vision.patch_dim, generator=g).to(torch.bfloat16)
+    n_merged = n_patches // cfg.vision.merge_unit
+    pre = torch.randint(10, 150000, (14,), generator=g)
+    post = torch.randint(10, 150000, (24,), generator=g)
+    ids = torch.cat([pre, torch.tensor([cfg.vision_start_token_id]), torch.full((n_merged,), cfg.video_token_id),
+                     torch.tensor([cfg.vision_end_token_id]), post])[None]
+    mask = torch.ones_like(ids)
+    logits = eng.score_logits(eng.encode_vision(px.cuda(), [grid]), ids, mask, [grid]).float().cpu()
+    torch.cuda.synchronize()
+    ref = QwenOracle(cfg, {k: v.cpu() for k, v in w.items()}).forward(ids, mask, px.float(), [grid])
+    lp, ref_lp = torch.log_softmax(logits, -1)[0], torch.log_softmax(ref, -1)[0]
+    toks = ref_lp.topk(5).indices.tolist() + [9454]
+    d = max(abs(lp[t].item() - ref_lp[t].item()) for t in toks)
+    import json
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_e2e.jsonl"), "a") as f:
+        f.write(json.dumps({"case": "fullsize/qwen2.5-vl-7b", "max_abs_dlogp_top5_and_answer": d,
+                            "logp_top1_fp32": ref_lp.max().item()}) + "\n")
+    assert d <= LOGPROB_TOL_BF16, d
+    assert lp.argmax().item() == ref_lp.argmax().item() or (ref_lp.topk(2).values[0] - ref_lp.topk(2).values[1]).item() < 2 * LOGPROB_TOL_BF16
+    eng.close()

@@ -64,11 +64,15 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    eng.profile(True)
+    eng.profile_read(reset=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         logits = step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    eng.profile(False)
+    n_gemm, gemm_ms, gemm_flops, gemm_bytes = eng.profile_read(reset=True)
     L = ids.shape[1]
     fl = flops_per_sample(cfg, n_patches, L)
     out = {"metric": "videos scored/sec, " + cfg.name, "value": B * args.steps / dt, "unit": "samples/s", "n_gpus": 1,
@@ -76,7 +80,15 @@ def main():
            "data": "synthetic (seeded patches, token ids, weights)",
            "config": {"workload": f"{cfg.name}, batch={B} x 8-frame 336x448 video (3072 patches -> 768 vision tokens) + 40 text tokens", "L": L},
            "algorithmic_tflop_per_sample": fl / 1e12, "model_tflops": B * args.steps / dt * fl / 1e12,
-           "model_frac_of_mfma_peak": B * args.steps / dt * fl / 1e12 / 2500.0, "init_s": t_init}
+           "model_frac_of_mfma_peak": B * args.steps / dt * fl / 1e12 / 2500.0, "init_s": t_init,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None}
+    if n_gemm > 0 and gemm_ms > 0:
+        ach = gemm_flops / (gemm_ms * 1e-3) / 1e12
+        out["roofline"] = {"kernel": "vqs::gemm_bf16_persistent / gemm_bf16_pingpong (every GEMM launch of the step; padded-head and "
+                                     "gate|up-interleaved shapes as executed)", "bound": "mfma", "achieved": ach, "peak": 2500.0,
+                           "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": None, "launches": n_gemm,
+                           "avg_launch_ms": gemm_ms / n_gemm, "algorithmic_bytes_per_launch": gemm_bytes / n_gemm,
+                           "gemm_share_of_step_time": gemm_ms * 1e-3 / dt}
     if args.cpu_samples > 0:
         from oracle.qwen25vl_oracle import QwenOracle
         n = args.cpu_samples
