@@ -106,10 +106,13 @@ int vqs_score(vqs_handle* h, const void* d_feats, const int32_t* d_img_index, co
               const int32_t* d_labels, int32_t B, int32_t L, int32_t T, float* d_label_logprobs, float* d_scores,
               void* d_ws, size_t ws_bytes, void* stream);
 
-/* Greedy decoding for `model.generate` (/root/reference/V_3.0_README.md:316-325; HF GenerationMixin greedy search over
- * T5ForConditionalGeneration, decoder_start_token_id = pad = 0): encoder once, then max_new (<= 16) decoder steps, each
- * appending argmax(logits) to d_tokens (int32 [B, max_new], device).  Every step is executed (no host sync); the caller
- * cuts each row at its first EOS (id 1).  Workspace: vqs_score_workspace_bytes(h, B, L, max_new). */
+/* Greedy decoding (the reference's `model.generate(images=, texts=)`, V_3.0_README.md:316-325 -> HF GenerationMixin greedy
+ * search of T5ForConditionalGeneration, decoder_start_token_id = pad = 0): encoder once, then max_new
+ * (<= VQS_MAX_NEW_TOKENS) incremental decoder steps over a self-attention K/V cache held in the workspace, each appending
+ * argmax(logits) to d_tokens (int32 [B, max_new], device).  Every step is executed (no host sync); the caller cuts each
+ * row at its first EOS (id 1).  Workspace: vqs_generate_workspace_bytes(h, B, L, max_new). */
+#define VQS_MAX_NEW_TOKENS 512
+size_t vqs_generate_workspace_bytes(const vqs_handle* h, int32_t B, int32_t L, int32_t max_new);
 int vqs_generate(vqs_handle* h, const void* d_feats, const int32_t* d_img_index, const int32_t* d_input_ids, int32_t B,
                  int32_t L, int32_t max_new, int32_t* d_tokens, void* d_ws, size_t ws_bytes, void* stream);
 

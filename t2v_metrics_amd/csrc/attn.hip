@@ -668,6 +668,8 @@ __global__ void __launch_bounds__(256) dec_attn_kernel(const DecAttnParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int h = blockIdx.x, b = blockIdx.y;
     const int klen = p.cross ? (p.key_len ? min(p.key_len[b], S) : S) : S;
+    const size_t kvb = p.kv_stride_b ? (size_t)p.kv_stride_b : (size_t)T * p.ldk;     // self form: sample stride of the K/V rows
+    const int bias_ld = p.bias_ld ? p.bias_ld : T;
 
     for (int i = tid; i < T * 64; i += 256) {
         const int t = i >> 6, d = i & 63;
@@ -678,7 +680,7 @@ __global__ void __launch_bounds__(256) dec_attn_kernel(const DecAttnParams p) {
     // ---- scores
     for (int j = tid; j < S; j += 256) {
         const bf16_t* krow = p.cross ? p.k + (((size_t)b * p.H + h) * S + j) * 64
-                                     : p.k + ((size_t)b * T + j) * p.ldk + h * 64;
+                                     : p.k + (size_t)b * kvb + (size_t)j * p.ldk + h * 64;
         float kv[64];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
@@ -698,8 +700,8 @@ __global__ void __launch_bounds__(256) dec_attn_kernel(const DecAttnParams p) {
             if (p.cross) {
                 masked = j >= klen;
             } else {
-                masked = j > t;                                    // causal
-                if (!masked && p.bias_table) a += p.bias_table[h * T + (t - j)];
+                masked = j > t + p.qpos0;                          // causal
+                if (!masked && p.bias_table) a += p.bias_table[h * bias_ld + (t + p.qpos0 - j)];
             }
             sc[(size_t)t * S + j] = masked ? NEG_BIG : a;
         }
@@ -729,7 +731,7 @@ __global__ void __launch_bounds__(256) dec_attn_kernel(const DecAttnParams p) {
 #pragma unroll 8
     for (int j = wv; j < S; j += 4) {
         const bf16_t* vrow = p.cross ? p.v + (((size_t)b * p.H + h) * S + j) * 64
-                                     : p.v + ((size_t)b * T + j) * p.ldk + h * 64;
+                                     : p.v + (size_t)b * kvb + (size_t)j * p.ldk + h * 64;
         const float vv = a_bf2f(vrow[lane]);
 #pragma unroll
         for (int t = 0; t < DEC_TMAX; ++t)

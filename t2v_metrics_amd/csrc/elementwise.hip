@@ -435,11 +435,11 @@ hipError_t launch_embed_splice(const int* ids, const int* sent_pos, const int* e
 // decoder_input_ids = shift_right(labels) (HF models/t5/modeling_t5.py:618-637); h = shared[id]
 __global__ void __launch_bounds__(256) decoder_embed_kernel(const int* __restrict__ labels, int ld_labels,
                                                             const bf16_t* __restrict__ shared, float* __restrict__ out,
-                                                            int T, int D, int vocab) {
+                                                            int T, int D, int vocab, int pos0) {
     const int b = blockIdx.y, t = blockIdx.x;
     int id = 0;                                          // decoder_start_token_id = pad = 0
-    if (t > 0) {
-        id = labels[(size_t)b * ld_labels + t - 1];
+    if (pos0 + t > 0) {
+        id = labels[(size_t)b * ld_labels + pos0 + t - 1];
         if (id == -100) id = 0;
         id = min(max(id, 0), vocab - 1);
     }
@@ -449,8 +449,8 @@ __global__ void __launch_bounds__(256) decoder_embed_kernel(const int* __restric
 }
 
 hipError_t launch_decoder_embed(const int* labels, int ld_labels, const bf16_t* shared, float* out, int B, int T, int D,
-                                int vocab, hipStream_t s) {
-    hipLaunchKernelGGL(decoder_embed_kernel, dim3(T, B), dim3(256), 0, s, labels, ld_labels, shared, out, T, D, vocab);
+                                int vocab, hipStream_t s, int pos0) {
+    hipLaunchKernelGGL(decoder_embed_kernel, dim3(T, B), dim3(256), 0, s, labels, ld_labels, shared, out, T, D, vocab, pos0);
     return hipGetLastError();
 }
 
@@ -530,7 +530,7 @@ hipError_t launch_reduce_slices(const float* part, int nslices, size_t n, bf16_t
 
 // Greedy step of vqs_generate: tokens[b, T-1] = argmax_v logits[(b*T + T-1), v] (lowest index on ties, as torch.argmax)
 __global__ void __launch_bounds__(256) argmax_append_kernel(const float* __restrict__ logits, int ldl, int V,
-                                                            int* __restrict__ tokens, int ld_tokens, int T) {
+                                                            int* __restrict__ tokens, int ld_tokens, int T, int dst_col) {
     __shared__ float s_val[256];
     __shared__ int s_idx[256];
     const int b = blockIdx.x;
@@ -555,12 +555,12 @@ __global__ void __launch_bounds__(256) argmax_append_kernel(const float* __restr
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) tokens[(size_t)b * ld_tokens + (T - 1)] = s_idx[0];
+    if (threadIdx.x == 0) tokens[(size_t)b * ld_tokens + dst_col] = s_idx[0];
 }
 
 hipError_t launch_argmax_append(const float* logits, int ldl, int V, int* tokens, int ld_tokens, int B, int T,
-                                hipStream_t s) {
-    hipLaunchKernelGGL(argmax_append_kernel, dim3(B), dim3(256), 0, s, logits, ldl, V, tokens, ld_tokens, T);
+                                hipStream_t s, int dst_col) {
+    hipLaunchKernelGGL(argmax_append_kernel, dim3(B), dim3(256), 0, s, logits, ldl, V, tokens, ld_tokens, T, dst_col < 0 ? T - 1 : dst_col);
     return hipGetLastError();
 }
 

@@ -130,11 +130,15 @@ struct ScoreWs {
     int S_pad;
     float* logits;
     int ldl;
+    bf16_t* kvcache;          // incremental decoding: [dec_layers][B][Tc][2I] (k | v of every decoded position), else nullptr
+    int Tc;
     size_t total;
 };
 
+// T = decoder rows per pair held at once; Tc > 0 additionally carves the self-attention K/V cache of vqs_generate for Tc
+// positions (the decoder buffers are then sized for T rows per step -- 1 -- and the bias table for Tc distances).
 ScoreWs carve_score(const vqs_handle* h, char* base, int B, int L, int T,
-                    std::unordered_map<std::string, size_t>* names = nullptr) {
+                    std::unordered_map<std::string, size_t>* names = nullptr, int Tc = 0) {
     const vqs_config& c = h->c;
     Carver cv{base, 0, names};
     ScoreWs w;
@@ -145,7 +149,7 @@ ScoreWs carve_score(const vqs_handle* h, char* base, int B, int L, int T,
     w.enc_len = cv.take<int>(B, "enc_len");
     w.flags = cv.take<int>(4, "flags");
     w.enc_table = cv.take<float>((size_t)H * (2 * S - 1));
-    w.dec_table = cv.take<float>((size_t)H * T);
+    w.dec_table = cv.take<float>((size_t)H * (T > Tc ? T : Tc));
     w.hidden = cv.take<float>(M * D, "enc_in");   // the fp32 residual stream; holds enc_in until layer 0 runs
     w.delta = cv.take<bf16_t>(M * D);            // bf16 sub-layer output waiting to be added by the next norm
     w.delta2 = cv.take<bf16_t>(M * D);           // second pending delta (deferred stream store, VQS_NORM_DEFER)
@@ -175,6 +179,8 @@ ScoreWs carve_score(const vqs_handle* h, char* base, int B, int L, int T,
     w.cctx = cv.take<bf16_t>(MT * H * D);
     w.ldl = c.vocab;
     w.logits = cv.take<float>(MT * w.ldl, "logits");
+    w.Tc = Tc;
+    w.kvcache = Tc > 0 ? cv.take<bf16_t>((size_t)c.dec_layers * B * Tc * 2 * I) : nullptr;
     w.total = align_up(cv.off);
     return w;
 }
@@ -794,8 +800,10 @@ static int dec_linear(vqs_handle* h, const bf16_t* A, const bf16_t* W, bf16_t* o
 
 // Decoder half: T teacher-forced rows per pair over the encoder output already in the workspace -> fp32 logits
 // [B*T, ldl].  d_labels[b*ld_labels + t] are the target ids (decoder input = shift_right, HF modeling_t5.py:618-637).
+// pos0 / cached (vqs_generate): the T rows are decoder positions pos0 .. pos0+T-1 of an incremental decode; their self
+// attention K/V rows are appended to w.kvcache and the queries attend to positions 0 .. pos0+T-1 of it (T = 1 per step).
 static int decoder_pass(vqs_handle* h, const ScoreWs& w, const int32_t* d_labels, int ld_labels, int B, int L, int T,
-                        hipStream_t st) {
+                        hipStream_t st, int pos0 = 0, bool cached = false) {
     const vqs_config& c = h->c;
     const int P = h->P, S = L - 1 + P;
     const int D = c.d_model, I = h->I, F = c.d_ff, H = c.n_heads, V = c.vocab;
@@ -806,9 +814,11 @@ static int decoder_pass(vqs_handle* h, const ScoreWs& w, const int32_t* d_labels
     float* scratch = reinterpret_cast<float*>(w.ff);          // the encoder's FFN buffer [B*S, F] bf16 is idle from here on
     const size_t scratch_bytes = (size_t)M * F * sizeof(bf16_t);
     GETW(dec_rel, "decoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight", (int64_t)c.rel_buckets * H);
-    HIPCHK(h, vqs::launch_relpos_table(dec_rel, h->lut_bidir, h->lut_causal, h->lut_len, c.rel_buckets, nullptr, H, S,
-                                       w.dec_table, T, st), "decoder bias table");
-    HIPCHK(h, vqs::launch_decoder_embed(d_labels, ld_labels, shared, w.dhid, B, T, D, V, st), "decoder embed");
+    const int TB = cached ? w.Tc : T;                          // row length of the decoder bias table
+    if (!cached || pos0 == 0)
+        HIPCHK(h, vqs::launch_relpos_table(dec_rel, h->lut_bidir, h->lut_causal, h->lut_len, c.rel_buckets, nullptr, H, S,
+                                           w.dec_table, TB, st), "decoder bias table");
+    HIPCHK(h, vqs::launch_decoder_embed(d_labels, ld_labels, shared, w.dhid, B, T, D, V, st, pos0), "decoder embed");
     TAP("dec", -1, "emb", w.dhid, (size_t)MT * D);
     const bf16_t* dpend = nullptr;
     for (int i = 0; i < c.dec_layers; ++i) {
@@ -826,7 +836,20 @@ static int decoder_pass(vqs_handle* h, const ScoreWs& w, const int32_t* d_labels
         TAP("dec", i, "xn0", w.dxn, (size_t)MT * D);
         RUN(dec_linear(h, w.dxn, h->dec_qkv[i], w.dqkv, MT, 3 * I, D, scratch, scratch_bytes, st, "dec self qkv"));
         TAP("dec", i, "qkv", w.dqkv, (size_t)MT * 3 * I);
-        {
+        if (cached) {
+            // append this step's k | v rows (columns I .. 3I of dqkv) to layer i's cache at position pos0, then attend over
+            // positions 0 .. pos0+T-1 of the cache
+            bf16_t* cl = w.kvcache + (size_t)i * B * w.Tc * 2 * I;
+            HIPCHK(h, hipMemcpy2DAsync(cl + (size_t)pos0 * 2 * I, (size_t)w.Tc * 2 * I * sizeof(bf16_t), w.dqkv + I,
+                                       (size_t)3 * I * sizeof(bf16_t), (size_t)2 * I * sizeof(bf16_t) * T, B,
+                                       hipMemcpyDeviceToDevice, st), "kv cache append");
+            vqs::DecAttnParams a{w.dqkv, cl, cl + I, w.dattn, w.dec_table, nullptr, B, H, T, pos0 + T, 3 * I, 2 * I, 0};
+            a.kv_stride_b = (long long)w.Tc * 2 * I;
+            a.qpos0 = pos0;
+            a.bias_ld = TB;
+            HIPCHK(h, vqs::launch_decoder_attention(a, st), "dec self attention (cached)");
+            TAP("dec", i, "sattn", w.dattn, (size_t)MT * I);
+        } else {
             vqs::DecAttnParams a{w.dqkv, w.dqkv + I, w.dqkv + 2 * I, w.dattn, w.dec_table, nullptr, B, H, T, T, 3 * I, 3 * I, 0};
             HIPCHK(h, vqs::launch_decoder_attention(a, st), "dec self attention");
             TAP("dec", i, "sattn", w.dattn, (size_t)MT * I);
@@ -936,25 +959,34 @@ int vqs_score(vqs_handle* h, const void* d_feats, const int32_t* d_img_index, co
 
 
 // Greedy decoding (the reference's `model.generate`, V_3.0_README.md:316-325; HF GenerationMixin greedy search with
-// T5's decoder_start_token_id = pad = 0): the encoder runs once, then step t re-runs the teacher-forced decoder over
-// the t+1 rows decoded so far (no KV cache: the decoder is ~4 % of a scoring pass and generation is off the hot path)
-// and appends argmax(logits[row t]).  No host synchronisation; all max_new steps are executed, the caller truncates
-// at the first EOS.  d_tokens: int32 [B, max_new].
+// T5's decoder_start_token_id = pad = 0): the encoder runs once, then step t decodes ONE new row per pair -- its
+// self-attention K/V are appended to a per-layer cache in the workspace and it attends to positions 0..t of it (the
+// cross-attention is the reassociated form over the encoder output, which needs no cache) -- and appends
+// argmax(logits).  No host synchronisation; all max_new steps are executed, the caller truncates at the first EOS.
+// d_tokens: int32 [B, max_new].
+size_t vqs_generate_workspace_bytes(const vqs_handle* h, int32_t B, int32_t L, int32_t max_new) {
+    if (!h || B <= 0 || L < 1 || max_new <= 0 || max_new > VQS_MAX_NEW_TOKENS) return 0;
+    return carve_score(h, nullptr, B, L, 1, nullptr, max_new).total;
+}
+
 int vqs_generate(vqs_handle* h, const void* d_feats, const int32_t* d_img_index, const int32_t* d_input_ids, int32_t B,
                  int32_t L, int32_t max_new, int32_t* d_tokens, void* d_ws, size_t ws_bytes, void* stream) {
     if (!h) return VQS_ERR_INVALID;
     if (!h->bound) return fail(h, VQS_ERR_STATE, "generate: weights not bound");
     if (!d_feats || !d_img_index || !d_input_ids || !d_tokens || !d_ws) return fail(h, VQS_ERR_INVALID, "generate: null argument");
-    if (B <= 0 || L < 1 || max_new <= 0 || max_new > 16) return fail(h, VQS_ERR_INVALID, "generate: need B>0, L>=1, 1<=max_new<=16");
+    if (B <= 0 || L < 1 || max_new <= 0 || max_new > VQS_MAX_NEW_TOKENS)
+        return fail(h, VQS_ERR_INVALID, "generate: need B>0, L>=1, 1<=max_new<=" + std::to_string(VQS_MAX_NEW_TOKENS));
     if (L - 1 > 2048) return fail(h, VQS_ERR_INVALID, "generate: prompt longer than CONTEXT_LEN (2048)");
-    const ScoreWs w = carve_score(h, (char*)d_ws, B, L, max_new);
-    if (ws_bytes < w.total) return fail(h, VQS_ERR_WORKSPACE, "generate: workspace too small (size it with vqs_score_workspace_bytes(B, L, max_new))");
+    if (h->cross_mode == 0) return fail(h, VQS_ERR_STATE, "generate: needs the reassociated cross-attention (option cross_mode=1)");
+    const ScoreWs w = carve_score(h, (char*)d_ws, B, L, 1, nullptr, max_new);
+    if (ws_bytes < w.total) return fail(h, VQS_ERR_WORKSPACE, "generate: workspace too small (size it with vqs_generate_workspace_bytes(B, L, max_new))");
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(h, hipMemsetAsync(d_tokens, 0, (size_t)B * max_new * sizeof(int32_t), st), "memset tokens");
     RUN(encoder_pass(h, w, d_feats, d_img_index, d_input_ids, B, L, st));
     for (int t = 0; t < max_new; ++t) {
-        RUN(decoder_pass(h, w, d_tokens, max_new, B, L, t + 1, st));
-        HIPCHK(h, vqs::launch_argmax_append(w.logits, w.ldl, h->c.vocab, d_tokens, max_new, B, t + 1, st), "argmax");
+        // one new decoder row per pair: position t, input = token t-1 (start token for t = 0), self-attention over the cache
+        RUN(decoder_pass(h, w, d_tokens, max_new, B, L, 1, st, t, true));
+        HIPCHK(h, vqs::launch_argmax_append(w.logits, w.ldl, h->c.vocab, d_tokens, max_new, B, 1, st, t), "argmax");
     }
     return VQS_OK;
 }

@@ -111,6 +111,10 @@ struct DecAttnParams {
     int B, H, T, S;           // S = number of keys (T for self)
     int ldq, ldk;
     int cross;
+    // incremental decoding over a K/V cache (self form only; 0 = the teacher-forced defaults)
+    long long kv_stride_b = 0;   // elements between the K/V rows of consecutive samples (default T * ldk)
+    int qpos0 = 0;               // decoder position of query row 0 (causal mask and bias use qpos0 + t - key)
+    int bias_ld = 0;             // row length of bias_table (default T)
 };
 hipError_t launch_decoder_attention(const DecAttnParams& p, hipStream_t stream);
 
@@ -138,13 +142,15 @@ hipError_t launch_embed_splice(const int* ids, const int* sent_pos, const int* e
                                const bf16_t* shared, const bf16_t* proj, float* out, int B, int L, int P, int D,
                                int vocab, hipStream_t s);
 // decoder_input_ids = shift_right(labels); h[b,t] = shared[id]  (fp32 out)
+// rows t = 0..T-1 hold decoder positions pos0 + t: id = labels[b, pos0 + t - 1] (start token for position 0)
 hipError_t launch_decoder_embed(const int* labels, int ld_labels, const bf16_t* shared, float* out, int B, int T, int D,
-                                int vocab, hipStream_t s);
+                                int vocab, hipStream_t s, int pos0 = 0);
 hipError_t launch_rope(bf16_t* x, const float* cs, const float* sn, int B, int H, int S, int hd, int half, hipStream_t s);
 hipError_t launch_rowss_to_rs(const float* rowss, int parts, int M, float invd, float eps, float* rs, hipStream_t s);
 hipError_t launch_reduce_slices(const float* part, int nslices, size_t n, bf16_t* out, hipStream_t s);
+// argmax of logits row (b*T + T-1) -> tokens[b, dst_col] (dst_col < 0: T-1)
 hipError_t launch_argmax_append(const float* logits, int ldl, int V, int* tokens, int ld_tokens, int B, int T,
-                                hipStream_t s);
+                                hipStream_t s, int dst_col = -1);
 // bias tables from the [buckets,H] bf16 embedding and a host-computed bucket LUT
 hipError_t launch_relpos_table(const bf16_t* rel_weight, const int* bucket_lut_bidir, const int* bucket_lut_causal,
                                int lut_len, int buckets, float* enc_table, int H, int S, float* dec_table, int T,

@@ -50,6 +50,7 @@ _SIGNATURES = {
     "vqs_score_workspace_bytes": (_c_sz, [_c_vp, _c_i32, _c_i32, _c_i32]),
     "vqs_score": (_c_i32, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i32, _c_i32, _c_i32, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),
     "vqs_workspace_offset": (_c_i64, [_c_vp, ctypes.c_char_p, _c_i32, _c_i32, _c_i32, ctypes.POINTER(_c_i64)]),
+    "vqs_generate_workspace_bytes": (_c_sz, [_c_vp, _c_i32, _c_i32, _c_i32]),
     "vqs_generate": (_c_i32, [_c_vp, _c_vp, _c_vp, _c_vp, _c_i32, _c_i32, _c_i32, _c_vp, _c_vp, _c_sz, _c_vp]),
     "vqs_profile_enable": (_c_i32, [_c_vp, _c_i32]),
     "vqs_profile_read": (_c_i32, [_c_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), _c_i32]),
@@ -227,7 +228,7 @@ class VqsEngine:
     def generate(self, feats: torch.Tensor, img_index: torch.Tensor, input_ids: torch.Tensor,
                  max_new_tokens: int = 16) -> torch.Tensor:
         """Greedy decoding -> int32 [B, max_new_tokens] on the device (every step executed; cut at the first EOS = 1 on
-        the host).  max_new_tokens <= 16."""
+        the host).  Incremental decoding over a K/V cache in the workspace; max_new_tokens <= 512."""
         with torch.cuda.device(self.device):
             B, L = input_ids.shape
             if img_index.shape[0] != B:
@@ -236,13 +237,13 @@ class VqsEngine:
             idx = img_index.to(device=self.device, dtype=torch.int32).contiguous()
             feats = feats.contiguous()
             tokens = torch.empty(B, max_new_tokens, dtype=torch.int32, device=self.device)
-            need = self.lib.vqs_score_workspace_bytes(self._h, B, L, max_new_tokens)
+            need = self.lib.vqs_generate_workspace_bytes(self._h, B, L, max_new_tokens)
             if need == 0:
                 raise VqsError(f"unsupported generate shape B={B} L={L} max_new_tokens={max_new_tokens}")
             if self._ws is None or self._ws.numel() < need:
                 self._ws = None
                 self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-            self._ws_shape = (B, L, max_new_tokens)
+            self._ws_shape = (B, L, 1)
             rc = self.lib.vqs_generate(self._h, feats.data_ptr(), idx.data_ptr(), ids.data_ptr(), B, L, max_new_tokens,
                                        tokens.data_ptr(), self._ws.data_ptr(), self._ws.numel(), _stream_ptr())
             self._check(rc, "vqs_generate")

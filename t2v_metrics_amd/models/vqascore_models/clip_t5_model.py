@@ -299,8 +299,8 @@ class CLIPT5Model(VQAScoreModel):
     def generate_ids(self, images: List[str], texts: List[str], max_new_tokens: int = 16) -> List[List[int]]:
         """Greedy decoding of one answer per (image, prompt) pair -> token ids, each cut after its first EOS."""
         assert len(images) == len(texts), "Number of images and texts must match"
-        if not 1 <= max_new_tokens <= 16:
-            raise ValueError("max_new_tokens must be in [1, 16] (the decoder kernels hold at most 16 rows per pair)")
+        if not 1 <= max_new_tokens <= 512:
+            raise ValueError("max_new_tokens must be in [1, 512]")
         uniq: Dict[str, int] = {}
         pair_image = [uniq.setdefault(str(p), len(uniq)) for p in images]
         paths = list(uniq.keys())
@@ -320,5 +320,5 @@ class CLIPT5Model(VQAScoreModel):
     def generate(self, images: List[str], texts: List[str], max_new_tokens: int = 16) -> List[str]:
         """The reference's ``model.generate(images=..., texts=...)`` (/root/reference/V_3.0_README.md:316-325): greedy
         decoding of a text answer per pair (HF GenerationMixin greedy search, decoder start = pad).  Runs on the HIP
-        engine: encoder once, then one teacher-forced decoder pass per new token."""
+        engine: encoder once, then one incremental decoder step per new token over a self-attention K/V cache."""
         return [self.tokenizer.decode(ids, skip_special_tokens=True) for ids in self.generate_ids(images, texts, max_new_tokens)]

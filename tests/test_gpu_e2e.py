@@ -164,6 +164,43 @@ def test_greedy_generate_matches_hf_fixture(golden_dir, fixture):
     eng.close()
 
 
+@pytest.mark.parametrize("name,B,L,max_new,seed,gain", [("tiny", 3, 10, 40, 31, 8.0), ("small", 3, 21, 24, 32, 16.0)])
+def test_long_greedy_generate_over_the_kv_cache_matches_the_oracle(name, B, L, max_new, seed, gain):
+    """vqs_generate decodes incrementally (one new row per step, self-attention over a K/V cache in the workspace) and is
+    no longer capped at 16 tokens: against the oracle's greedy loop (which recomputes every row every step and is pinned
+    token for token to HF generate on the g8 fixtures), ids must be identical up to the first step whose fp32 top-1/top-2
+    margin is below GEN_MARGIN; and the first 16 tokens must be what teacher-forced scoring of them arg-maxes to."""
+    GEN_MARGIN = 0.25
+    from oracle.clip_t5_oracle import Oracle
+    from t2v_metrics_amd.engine import VqsEngine
+    cfg = get_config(name)
+    w = make_seeded_weights(cfg, seed=seed, device="cpu", lm_head_gain=gain)
+    pix, img_index, ids, _ = _inputs(cfg, B, 2, L, 2, seed=200 + B)
+    ref, margins = Oracle(cfg, w).generate(pix.float(), img_index, ids, max_new, return_margins=True)
+    eng = VqsEngine(cfg, w, device="cuda:0")
+    feats = eng.encode_images(pix.cuda())
+    toks = eng.generate(feats, img_index, ids, max_new).cpu().long()
+    assert toks.shape == (B, max_new)
+    compared, longest = 0, 0
+    for b in range(B):
+        n = 0
+        for t in range(max_new):
+            if margins[b, t] < GEN_MARGIN:
+                break
+            assert toks[b, t] == ref[b, t], (b, t, toks[b].tolist(), ref[b].tolist(), margins[b].tolist())
+            n += 1
+        compared += n
+        longest = max(longest, n)
+    assert longest >= 20, f"longest compared run {longest}: the test must reach well past the old 16-token cap"
+    lp, _ = eng.score(feats, img_index, ids, toks[:, :16].to(torch.int32))
+    torch.cuda.synchronize()
+    tf = eng.stage("logits").float().cpu().argmax(-1)
+    agree = (tf == toks[:, :16]) | (margins[:, :16] < GEN_MARGIN)
+    assert bool(agree.all()), (tf.tolist(), toks[:, :16].tolist())
+    _record(f"generate-long-{name}", {"steps_compared": compared, "steps_total": B * max_new})
+    eng.close()
+
+
 def test_low_sensitivity_regime_meets_1e3():
     """With an unpeaked head (lm_head gain 0.02: logits ~ N(0, 0.02^2)) the literal north_star tolerance holds."""
     from oracle.clip_t5_oracle import Oracle

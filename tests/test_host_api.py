@@ -302,7 +302,7 @@ def test_generate_api(tmp_path, images):
     ids = s.model.generate_ids([images[0]], [texts[0]], max_new_tokens=4)
     assert 1 <= len(ids[0]) <= 4 and (1 not in ids[0][:-1])
     with pytest.raises(ValueError):
-        s.model.generate(images=[images[0]], texts=[texts[0]], max_new_tokens=17)
+        s.model.generate(images=[images[0]], texts=[texts[0]], max_new_tokens=513)
     with pytest.raises(AssertionError):
         s.model.generate(images=images[:2], texts=texts[:1])
 
