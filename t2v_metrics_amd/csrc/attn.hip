@@ -48,6 +48,17 @@ __device__ __forceinline__ uint32_t a_pack2(float a, float b) {   // v_cvt_pk_bf
 
 // v_max3_f32 without the IEEE-mode operand canonicalisation (v_max_f32 x, x) that fmaxf() costs per input:
 // the scores are finite by construction (masking uses NEG_BIG, not -inf)
+// max over the two half-waves (lane <-> lane ^ 32) without the LDS round trip of __shfl_xor (ds_bpermute_b32 + a
+// lgkmcnt(0) wait in the middle of every tile): gfx950's v_permlane32_swap exchanges lanes 32-63 of one register with
+// lanes 0-31 of another, so two copies of x hold {x[l], x[l^32]} afterwards.  Same value, no rounding involved.
+__device__ __forceinline__ float a_max_xhalf(float x) {
+    typedef unsigned a_v2u __attribute__((ext_vector_type(2)));
+    const a_v2u r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    float a = __uint_as_float(r[0]), b = __uint_as_float(r[1]), m;
+    asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(a), "v"(b));        // finite by construction: no canonicalising v_max x, x
+    return m;
+}
+
 __device__ __forceinline__ float a_max3(float a, float b, float c) {
     float r;
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
@@ -286,7 +297,7 @@ __global__ void __launch_bounds__(256) attn_fwd_dma_kernel(const AttnParams p) {
         for (int i = 3; i < 31; i += 2) mx = a_max3(mx, VQS_SV(i), VQS_SV(i + 1));
         mx = fmaxf(mx, VQS_SV(31));
 #undef VQS_SV
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        mx = a_max_xhalf(mx);
         if (!HAS_BIAS) mx *= sl2;                   // to the log2 domain (scale > 0)
         // keep the old running max while the new one is at most 2^RESCALE_THR above it; rescale only on a real jump
         if (__any(mx > m_run + RESCALE_THR)) {
@@ -504,7 +515,7 @@ __global__ void __launch_bounds__(256) attn_fwd_hd_kernel(const AttnParams p) {
         for (int i = 3; i < 31; i += 2) mx = a_max3(mx, VQS_SV(i), VQS_SV(i + 1));
         mx = fmaxf(mx, VQS_SV(31));
 #undef VQS_SV
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        mx = a_max_xhalf(mx);
         mx *= sl2;
         if (__any(mx > m_run + RESCALE_THR)) {
             const float m_new = fmaxf(m_run, mx);

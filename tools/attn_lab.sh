@@ -1,13 +1,9 @@
 #!/bin/bash
-# A/B the attention microbench: register-staged kernel (VQS_ATTN_VARIANT=0) vs LDS-DMA kernel (1), plus any lab
+# A/B the attention microbench: the shipped library, plus any lab
 # libraries under build/lab/ (ablations built with -DVQS_ATTN_ABLATE=n)
 mkdir -p gpurun_out; rm -f gpurun_out/attn_lab.txt
 echo "== product" >> gpurun_out/attn_lab.txt
 python tools/microbench.py --no-gemm 2>&1 | grep attention | cut -c1-150 >> gpurun_out/attn_lab.txt
-if [ -f build/lab/libvqs_hip_lab.so ]; then     # make -C t2v_metrics_amd/csrc lab: holds the register-staged predecessor
-  echo "== lab build, VQS_ATTN_VARIANT=0 (register-staged kernel)" >> gpurun_out/attn_lab.txt
-  VQS_LIB_PATH=build/lab/libvqs_hip_lab.so VQS_ATTN_VARIANT=0 python tools/microbench.py --no-gemm 2>&1 | grep attention | cut -c1-150 >> gpurun_out/attn_lab.txt
-fi
 for L in $(ls build/lab/libvqs_attn_*.so 2>/dev/null); do
   echo "== $L" >> gpurun_out/attn_lab.txt
   VQS_LIB_PATH=$L python tools/microbench.py --no-gemm 2>&1 | grep attention | cut -c1-150 >> gpurun_out/attn_lab.txt
