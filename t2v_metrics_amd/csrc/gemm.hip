@@ -545,23 +545,29 @@ __device__ __forceinline__ void staged_epilogue(const GemmParams& p, f32x16 (&ac
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     } else {
-        // bias of this lane's 2 x 4 column quads
-        float bia[2][4][4];
+        // bias of this lane's 2 x 4 column quads, added into the accumulators -- under a wave-uniform branch: no T5 linear
+        // has a bias, and adding 128 zeros per lane and tile was ~1 % of the o / wo / qkv GEMMs (nothing overlaps an epilogue)
+        if (p.bias != nullptr) {
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+            for (int n = 0; n < 2; ++n)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int c = col_w + n * 32 + 8 * g + 4 * hh;
-                if (p.bias != nullptr && c < p.N) {
-                    const uint2 bv = *reinterpret_cast<const uint2*>(p.bias + c);
-                    bia[n][g][0] = bf2f((bf16_t)(bv.x & 0xffff));
-                    bia[n][g][1] = bf2f((bf16_t)(bv.x >> 16));
-                    bia[n][g][2] = bf2f((bf16_t)(bv.y & 0xffff));
-                    bia[n][g][3] = bf2f((bf16_t)(bv.y >> 16));
-                } else {
-                    bia[n][g][0] = bia[n][g][1] = bia[n][g][2] = bia[n][g][3] = 0.0f;
+                for (int g = 0; g < 4; ++g) {
+                    const int c = col_w + n * 32 + 8 * g + 4 * hh;
+                    float b0 = 0.0f, b1 = 0.0f, b2 = 0.0f, b3 = 0.0f;
+                    if (c < p.N) {
+                        const uint2 bv = *reinterpret_cast<const uint2*>(p.bias + c);
+                        b0 = bf2f((bf16_t)(bv.x & 0xffff));
+                        b1 = bf2f((bf16_t)(bv.x >> 16));
+                        b2 = bf2f((bf16_t)(bv.y & 0xffff));
+                        b3 = bf2f((bf16_t)(bv.y >> 16));
+                    }
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        acc[m][n][4 * g + 0] += b0; acc[m][n][4 * g + 1] += b1;
+                        acc[m][n][4 * g + 2] += b2; acc[m][n][4 * g + 3] += b3;
+                    }
                 }
-            }
+        }
         if constexpr (EPI == EPI_F32 || EPI == EPI_F32_RESID) {
 #pragma unroll
             for (int m = 0; m < 4; ++m) {                     // 32 rows x 256 B per pass
@@ -570,8 +576,7 @@ __device__ __forceinline__ void staged_epilogue(const GemmParams& p, f32x16 (&ac
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const int ch = n * 8 + 2 * g + hh;    // 16-B chunk (4 fp32) within the 256-B row
-                        const float4 v = make_float4(acc[m][n][4 * g + 0] + bia[n][g][0], acc[m][n][4 * g + 1] + bia[n][g][1],
-                                                     acc[m][n][4 * g + 2] + bia[n][g][2], acc[m][n][4 * g + 3] + bia[n][g][3]);
+                        const float4 v = make_float4(acc[m][n][4 * g + 0], acc[m][n][4 * g + 1], acc[m][n][4 * g + 2], acc[m][n][4 * g + 3]);
                         *reinterpret_cast<float4*>(reg + lr * 256 + ((ch ^ (lr & 15)) << 4)) = v;
                     }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -627,7 +632,7 @@ __device__ __forceinline__ void staged_epilogue(const GemmParams& p, f32x16 (&ac
                         for (int g = 0; g < 4; ++g) {
                             float o[4];
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) o[e] = acc[m][n][4 * g + e] + bia[n][g][e];
+                            for (int e = 0; e < 4; ++e) o[e] = acc[m][n][4 * g + e];
                             if constexpr (EPI == EPI_BF16_QGELU) {
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) o[e] = act_quick_gelu(o[e]);
