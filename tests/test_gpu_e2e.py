@@ -328,6 +328,44 @@ def test_engine_matches_hf_golden_fixture(golden_dir):
     eng.close()
 
 
+def test_a_whole_pass_is_hip_graph_capturable_and_replays_bitwise():
+    """vqs_encode_images + vqs_score allocate nothing, never synchronise and read no host memory, so a pass can be captured
+    into a HIP graph (torch.cuda.CUDAGraph = hipGraph on ROCm) and replayed: same bits as the eager launches, also after the
+    inputs are overwritten in place (the graph holds pointers, not values)."""
+    from t2v_metrics_amd.engine import VqsEngine
+    cfg = get_config("small")
+    w = make_seeded_weights(cfg, seed=5, device="cpu")
+    pix, idx, ids, labels = _inputs(cfg, 5, 3, 14, 2, seed=9)
+    pix2, _, ids2, _ = _inputs(cfg, 5, 3, 14, 2, seed=10)
+    eng = VqsEngine(cfg, w, device="cuda:0")
+    d_pix, d_idx = pix.cuda(), idx.to("cuda", torch.int32)
+    d_ids, d_lab = ids.to("cuda", torch.int32).contiguous(), labels.to("cuda", torch.int32).contiguous()
+
+    def step():
+        return eng.score(eng.encode_images(d_pix), d_idx, d_ids, d_lab)
+
+    lp_a, sc_a = (t.clone() for t in step())
+    d_pix.copy_(pix2.cuda()); d_ids.copy_(ids2.to("cuda", torch.int32))
+    lp_b, sc_b = (t.clone() for t in step())
+    assert not torch.equal(lp_a, lp_b)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        lp_g, sc_g = step()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(lp_g, lp_b) and torch.equal(sc_g, sc_b)
+    d_pix.copy_(pix.cuda()); d_ids.copy_(ids.to("cuda", torch.int32))
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(lp_g, lp_a) and torch.equal(sc_g, sc_a)
+    eng.close()
+
+
 def test_dedup_and_reuse_of_image_features():
     """M x N grids score each image once: pairs that share an image give identical results to separate calls."""
     from t2v_metrics_amd.engine import VqsEngine
