@@ -71,7 +71,7 @@ def _record(name, payload):
         f.write(json.dumps({"case": name, **payload}) + "\n")
 
 
-def _one_pair_three_way(cfg, w, eng, tag, seed, emulate_regimes=("random-head", "planted-head")):
+def _one_pair_three_way(cfg, w, eng, tag, seed, emulate_regimes=("planted-head",), check_random=True):
     """HIP vs the fp32 oracle for one pair of the full-size model, with the rounding-matched oracle (the same arithmetic
     on the CPU) beside it as the calibrated noise level; random head (log P ~ -10.4, near-uniform) AND a peaked head: the lm_head rows of the two
     labels are replaced by 12 * x / |x|^2 with x the engine's own final decoder state at that step ("planted
@@ -85,6 +85,8 @@ def _one_pair_three_way(cfg, w, eng, tag, seed, emulate_regimes=("random-head", 
         for regime in ("random-head", "planted-head"):
             lp, sc = eng.score(eng.encode_images(pix.cuda()), idx, ids, labels)
             torch.cuda.synchronize()
+            if regime == "random-head" and not check_random:
+                continue                  # still ran the pass above: the planted direction comes from its decoder state
             if regime == "planted-head":
                 x = eng.stage("dec_out").float()[0]                   # [T, D]
                 head[2163] = (12.0 * x[0] / (x[0] @ x[0])).to(head.dtype)
@@ -122,7 +124,8 @@ def test_xxl_one_pair_three_way_random_and_peaked_head():
     w = make_seeded_weights(cfg, seed=0, device="cuda:0")
     eng = VqsEngine(cfg, w, device="cuda:0")
     try:
-        _one_pair_three_way(cfg, w, eng, "clip-flant5-xxl", seed=10, emulate_regimes=("planted-head",))
+        # the random-head regime at XXL is what bench.py's cpu_baseline.dlogp reports on every run; here: the peaked one
+        _one_pair_three_way(cfg, w, eng, "clip-flant5-xxl", seed=10, check_random=False)
     finally:
         eng.close()
         del w
