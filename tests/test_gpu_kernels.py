@@ -48,12 +48,13 @@ def test_gemm_bf16_and_f32(eng, M, N, K, variant):
 
 
 @pytest.mark.parametrize("M,N,K,epi", [(5000, 768, 256, 0), (70000, 512, 128, 4), (33000, 1024, 64, 3), (9000, 640, 192, 1),
-                                       (40000, 512, 320, 0), (33000, 1024, 256, 1), (70000, 2048, 512, 3)])
+                                       (40000, 512, 320, 0), (33000, 1024, 256, 1), (70000, 2048, 512, 3),
+                                       (20000, 4096, 8192, 0)])
 def test_gemm_persistent_many_tiles(eng, M, N, K, epi):
     """More tiles than workgroups: the persistent kernel's cross-tile pipeline (prefetch of the next tile's first
     K-tile, counted vmcnt behind the epilogue stores, edge tiles in the middle of a run) against variant 0, bitwise.
     The last three shapes (>= 256 tiles, K >= 256, N <= 2048) run the L2-touch form of the lock-step kernel, whose
-    prefetch crosses tile boundaries too."""
+    prefetch crosses tile boundaries too; the last one is the XXL wo rule (N = 4096, K >= 8192)."""
     A = randn_bf16(M, K, seed=31)
     W = randn_bf16(N, K, seed=32, scale=K ** -0.5)
     bias = randn_bf16(N, seed=33)
