@@ -48,7 +48,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 
-from .clip_t5_oracle import (IGNORE_INDEX, Oracle, gelu_erf, layer_norm, quick_gelu, shift_right, t5_rms_norm)
+from .clip_t5_oracle import Oracle, gelu_erf, layer_norm, quick_gelu, t5_rms_norm
 
 LOG2E = float(np.float32(1.4426950408889634))      # the kernels' constexpr float LOG2E
 NEG_BIG = -1.0e30                                  # attn.hip:69 (finite mask value)

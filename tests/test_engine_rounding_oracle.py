@@ -2,7 +2,6 @@
 the HIP path to at 1e-3: its structure (tiled online softmax with the deferred running max, reassociated
 cross-attention, fp32 stream with bf16 deltas) must be the SAME FUNCTION as the HF-pinned fp32 oracle -- identical to
 fp32 accuracy when the roundings are switched off -- and with the roundings on it must sit at the bf16 noise floor."""
-import os
 
 import numpy as np
 import pytest

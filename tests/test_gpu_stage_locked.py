@@ -13,7 +13,6 @@ per GEMM stage, so ANY two evaluations (the reference against itself included) d
 import json
 import os
 
-import numpy as np
 import pytest
 import torch
 

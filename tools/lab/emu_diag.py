@@ -2,7 +2,6 @@
 """Per-op check of the rounding-matched oracle against the HIP kernels (run on the GPU box): for every op the
 fraction of bf16 outputs that differ and the largest |difference|.  Expected: ~1e-4 fractions (fp32 summation order)."""
 import os, sys
-import numpy as np
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)

@@ -21,7 +21,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from oracle.clip_t5_engine_rounding import EngineRoundedOracle  # noqa: E402
-from oracle.clip_t5_oracle import Oracle  # noqa: E402
 from oracle.hf_reference import HFReference  # noqa: E402
 from t2v_metrics_amd.config import get_config  # noqa: E402
 from t2v_metrics_amd.weights import make_seeded_weights  # noqa: E402
