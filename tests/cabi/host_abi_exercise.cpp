@@ -1,0 +1,50 @@
+// Host-side exercise of the C ABI under AddressSanitizer + UBSan: everything that runs without touching a device
+// (creation, sizing, options, taps registration, error paths, integer helpers).  No GPU needed.
+#include "vqs.h"
+#include "vqs_qwen.h"
+#include <cassert>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+int main() {
+    vqs_config c;
+    memset(&c, 0, sizeof c);
+    c.vis_hidden = 1024; c.vis_layers_run = 23; c.vis_heads = 16; c.vis_mlp = 4096; c.vis_patch = 14; c.vis_image = 336; c.vis_ln_eps = 1e-5f;
+    c.d_model = 4096; c.n_heads = 64; c.d_kv = 64; c.d_ff = 10240; c.enc_layers = 24; c.dec_layers = 24; c.vocab = 32128;
+    c.rel_buckets = 32; c.rel_max_distance = 128; c.t5_ln_eps = 1e-6f;
+    vqs_handle* h = nullptr;
+    assert(vqs_create(&c, &h) == 0 && h);
+    assert(vqs_packed_bytes(h) > 0);
+    assert(vqs_encode_workspace_bytes(h, 256) > 0 && vqs_encode_workspace_bytes(h, 0) == 0);
+    assert(vqs_score_workspace_bytes(h, 256, 33, 2) > 0 && vqs_score_workspace_bytes(h, 0, 33, 2) == 0);
+    assert(vqs_generate_workspace_bytes(h, 4, 33, 64) > 0 && vqs_generate_workspace_bytes(h, 4, 33, 100000) == 0);
+    assert(vqs_set_option(h, "cross_mode", 0) == 0 && vqs_set_option(h, "cross_mode", 1) == 0);
+    assert(vqs_set_option(h, "cross_mode", 7) != 0 && vqs_set_option(h, "nonsense", 1) != 0 && vqs_set_option(h, nullptr, 1) != 0);
+    assert(strlen(vqs_last_error(h)) > 0);
+    int dummy = 0;
+    assert(vqs_debug_tap(h, "enc.3.xn0", &dummy, 4) == 0 && vqs_debug_tap(h, "enc.3.xn0", nullptr, 0) == 0 && vqs_debug_tap(h, nullptr, nullptr, 0) == 0);
+    int64_t ld = 0;
+    assert(vqs_workspace_offset(h, "logits", 4, 33, 2, &ld) >= 0 && ld == 32128);
+    assert(vqs_workspace_offset(h, "dec_out", 4, 33, 2, &ld) >= 0 && vqs_workspace_offset(h, "nope", 4, 33, 2, &ld) < 0);
+    assert(vqs_workspace_offset(h, "vit_hidden", 4, 0, 0, &ld) >= 0);
+    // calls that must fail cleanly before any device access
+    assert(vqs_score(h, &dummy, nullptr, nullptr, nullptr, 1, 33, 2, nullptr, nullptr, nullptr, 0, nullptr) != 0);
+    assert(vqs_encode_images(h, &dummy, 1, &dummy, &dummy, 16, nullptr) != 0);      // weights not bound
+    assert(vqs_bind_weights(h, nullptr, 0, nullptr, 0, nullptr) != 0);
+    for (int rel = -700; rel <= 700; ++rel) {
+        const int b = vqs_relpos_bucket(rel, 1, 32, 128), u = vqs_relpos_bucket(rel, 0, 32, 128);
+        assert(b >= 0 && b < 32 && u >= 0 && u < 32);
+    }
+    std::vector<int64_t> off(64);
+    assert(vqs_debug_heads_rows(5, 608, 64, 64, 64, off.data()) == 0 && vqs_debug_heads_rows(5, 7, 64, 64, 4, off.data()) != 0);
+    assert(vqs_attention_lds_bytes(608, 1, 64) > 0 && vqs_attention_lds_bytes(608, 1, 77) < 0);
+    vqs_destroy(h);
+    vqs_config bad = c;
+    bad.d_kv = 32;
+    vqs_handle* hb = nullptr;
+    assert(vqs_create(&bad, &hb) != 0);
+    vqs_destroy(hb);
+    assert(vqs_create(nullptr, &hb) != 0);
+    printf("host ABI exercise under ASan/UBSan: ok\n");
+    return 0;
+}
