@@ -137,7 +137,9 @@ const char* vqs_profile_report(vqs_handle* h);
 /* ---- single-kernel entry points (parity tests and micro-benchmarks call the kernels through these) ---- */
 /* epilogue: 0 bf16, 1 bf16+quick_gelu, 2 bf16+erf-gelu, 3 fp32, 4 fp32 + residual, 5 gated gelu_new (W rows
  * interleaved per 32: wi_0 block then wi_1 block; C is [M, N/2]), 6 head-major scatter (q/k/v = C, C+B*H*S*64, ...)
- * variant: 0 one tile per workgroup, 1 register-staged (A/B only), 2 ping-pong, 3 persistent (engine default) */
+ * variant (bits 0-7): 0 one tile per workgroup, 2 / 5 ping-pong, 3 persistent (engine default); bits 8-15 = gm, bits 16-23 = ns:
+ * the workgroup -> tile ORDER (groups of gm M-tiles x all N-tiles, N cut into ns column ranges walked one after the other;
+ * 0 = the default 8 / 1).  The order only permutes which workgroup computes a tile when: results are bitwise identical. */
 int vqs_gemm(const void* d_A, const void* d_W, void* d_C, const void* d_bias, const float* d_resid, int32_t M, int32_t N,
              int32_t K, int32_t lda, int32_t ldw, int32_t ldc, int32_t epilogue, int32_t S, int32_t H, int32_t variant,
              void* stream);
@@ -197,6 +199,8 @@ int vqs_score_head(const float* d_logits, int32_t ldl, int32_t V, const int32_t*
  *   "norm_defer"   1 (default) deferred store of the fp32 stream in the norm kernels (bitwise equal), 0 store in every norm
  *   "fused_norm"   0 (default) separate add+norm kernels, 1 residual update + RMSNorm operand in the o / wo GEMM epilogues
  *   "gemm_variant" 3 (default) persistent kernels, 0 one tile per workgroup, 2 / 5 ping-pong schedule
+ *   "tile_order:<N>x<K>"  value = gm | ns << 8: tile order (see vqs_gemm) of every GEMM of a pass whose weight is [N, K];
+ *                  0 removes the entry (back to the library's choice for that shape).  Bitwise-neutral.
  * Returns VQS_ERR_INVALID for an unknown name or value. */
 int vqs_set_option(vqs_handle* h, const char* name, int32_t value);
 
@@ -213,6 +217,11 @@ int vqs_debug_tap(vqs_handle* h, const char* name, void* d_dst, size_t bytes);
  * head-major epilogue (EPI_HEADS, the QKV projections' scatter -- HF modeling_t5.py:311-323 view/transpose) uses for the
  * rows row0 + 8k, k = 0..n-1, computed by the SAME inline functions as the kernel (one division, then steps).  S >= 8. */
 int vqs_debug_heads_rows(int32_t row0, int32_t S, int32_t hx, int32_t hdim, int32_t n, int64_t* off_out);
+/* Host-side test hook, no device access: the tile every workgroup slot of a persistent GEMM launch (grid workgroups, a multiple
+ * of 8) computes under tile order (gm, ns), by the SAME inline function as the kernels: out[4*i .. 4*i+3] = (slot, m0, n0, batch
+ * entry) for the M x N x batch problem, nwg = tiles entries.  Returns the resolved gm | ns << 8 (illegal ns falls back to 1) or a
+ * negative error. */
+int vqs_debug_tile_order(int32_t M, int32_t N, int32_t batch, int32_t gm, int32_t ns, int32_t grid, int32_t* out);
 /* Host-side arithmetic, no device access: dynamic LDS bytes vqs_attention / vqs_attention_hd request per workgroup for
  * sequence length S (hd 0 / 64 / 128).  The kernels' occupancy hangs on it (160 KiB of LDS per CU in 1 280-B granules);
  * -1 on bad arguments. */

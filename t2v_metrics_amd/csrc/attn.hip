@@ -79,14 +79,13 @@ __host__ __device__ __forceinline__ int bias_copy_chunks(int S) {
 
 // Table entry j goes to position j - c of copy c (c = 0..3).  Eight independent global loads per thread are in flight
 // before the first LDS store (a load-store-load chain costs a full L2 latency per 256 entries).
-__device__ __forceinline__ void fill_bias_copies(float* bias_s, const float* bt, int n, int cs4, int tid) {
-    constexpr float LOG2E = 1.4426950408889634f;
+__device__ __forceinline__ void fill_bias_copies(float* bias_s, const float* bt, int n, int cs4, int tid, float fac) {
     for (int base = 0; base < cs4 + 3; base += 2048) {
         float bv[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int j = base + tid + 256 * i;
-            bv[i] = j < n ? bt[j] * LOG2E : 0.0f;
+            bv[i] = j < n ? bt[j] * fac : 0.0f;
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -144,8 +143,13 @@ __device__ __forceinline__ a_v4i a_make_rsrc(const void* base) {
 }
 static constexpr int ST_BYTES = 16384;       // one stage: K 8 KiB + V 8 KiB
 
+// BIAS_ACC (compile-time form of the biased kernel): 1 = the position bias enters through the MFMA accumulators
+#ifndef VQS_ATTN_BIAS_ACC
+#define VQS_ATTN_BIAS_ACC 0
+#endif
 template <bool HAS_BIAS>
 __global__ void __launch_bounds__(256) attn_fwd_dma_kernel(const AttnParams p) {
+    constexpr bool BIAS_ACC = VQS_ATTN_BIAS_ACC != 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* bias_s = reinterpret_cast<float*>(smem + 2 * ST_BYTES);
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)A_LDS_PTR(smem));
@@ -174,7 +178,9 @@ __global__ void __launch_bounds__(256) attn_fwd_dma_kernel(const AttnParams p) {
 
     constexpr float LOG2E = 1.4426950408889634f;
     const int bias_cs = bias_copy_chunks(S);
-    if (HAS_BIAS) fill_bias_copies(bias_s, p.bias_table + (size_t)h * (2 * S - 1), 2 * S - 1, bias_cs * 4, tid);
+    // BIAS_ACC: the table holds bias / scale and is the INITIAL VALUE of the score accumulators (the matrix pipe adds it);
+    // otherwise it holds bias * log2 e and is added by an FMA per score after the product
+    if (HAS_BIAS) fill_bias_copies(bias_s, p.bias_table + (size_t)h * (2 * S - 1), 2 * S - 1, bias_cs * 4, tid, BIAS_ACC ? 1.0f / p.scale : LOG2E);
     const float sl2 = p.scale * LOG2E;
 
     const int qrow = qb * 128 + wv * 32 + (lane & 31);
@@ -244,11 +250,28 @@ __global__ void __launch_bounds__(256) attn_fwd_dma_kernel(const AttnParams p) {
         const char* k_lds = smem + st * ST_BYTES;
 
         // ---- S^T = K . Q^T   (i <-> key, j <-> query)
+        const int kb = kt * KT;
         f32x16 s[2];
+        if (HAS_BIAS && BIAS_ACC) {
+            // accumulators start at bias[key - query] / scale: eight ds_read_b128 straight into the C operand of the first
+            // MFMAs, no per-score add afterwards (the softmax below is then the bias-free form: ONE FMA + v_exp_f32 per score)
+            const char* bp = bias_rd + kb * 4;
 #pragma unroll
-        for (int kf = 0; kf < 2; ++kf)
+            for (int kf = 0; kf < 2; ++kf)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[kf][r] = 0.0f;
+                for (int g = 0; g < 4; ++g) {
+                    const float4 bv = *reinterpret_cast<const float4*>(bp + kf * 128 + g * 32);
+                    s[kf][4 * g + 0] = bv.x;
+                    s[kf][4 * g + 1] = bv.y;
+                    s[kf][4 * g + 2] = bv.z;
+                    s[kf][4 * g + 3] = bv.w;
+                }
+        } else {
+#pragma unroll
+            for (int kf = 0; kf < 2; ++kf)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kf][r] = 0.0f;
+        }
         {
             uint4 kfr[4][2];
 #pragma unroll
@@ -256,6 +279,9 @@ __global__ void __launch_bounds__(256) attn_fwd_dma_kernel(const AttnParams p) {
 #pragma unroll
                 for (int kf = 0; kf < 2; ++kf)
                     kfr[ks][kf] = *reinterpret_cast<const uint4*>(k_lds + kf * 4096 + k_rd + (((2 * ks + hh) ^ swr) << 4));
+            // all sixteen LDS reads of the tile (bias + K fragments) in flight before the first MFMA: left alone the scheduler
+            // reuses two fragment registers and waits lgkmcnt(0) in front of every MFMA pair
+            if (HAS_BIAS && BIAS_ACC) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -268,8 +294,8 @@ __global__ void __launch_bounds__(256) attn_fwd_dma_kernel(const AttnParams p) {
         // one FMA) and p = 2^(t - m) is a subtract + v_exp_f32; without one the row max is taken on the raw scores
         // (c > 0) and p = 2^(s*c - m) is ONE FMA + v_exp_f32.  The row SUM is not accumulated here: the PV step
         // below gets it from the matrix pipe (an all-ones A operand), which has slack while the VALU does not.
-        const int kb = kt * KT;
-        if (HAS_BIAS) {
+        constexpr bool LOG2_DOMAIN = HAS_BIAS && !BIAS_ACC;      // scores already hold s*c + bias*log2 e before the max
+        if (LOG2_DOMAIN) {
             const char* bp = bias_rd + kb * 4;
 #pragma unroll
             for (int kf = 0; kf < 2; ++kf)
@@ -298,7 +324,7 @@ __global__ void __launch_bounds__(256) attn_fwd_dma_kernel(const AttnParams p) {
         mx = fmaxf(mx, VQS_SV(31));
 #undef VQS_SV
         mx = a_max_xhalf(mx);
-        if (!HAS_BIAS) mx *= sl2;                   // to the log2 domain (scale > 0)
+        if (!LOG2_DOMAIN) mx *= sl2;                // to the log2 domain (scale > 0)
         // keep the old running max while the new one is at most 2^RESCALE_THR above it; rescale only on a real jump
         if (__any(mx > m_run + RESCALE_THR)) {
             const float m_new = fmaxf(m_run, mx);
@@ -316,7 +342,7 @@ __global__ void __launch_bounds__(256) attn_fwd_dma_kernel(const AttnParams p) {
         for (int kf = 0; kf < 2; ++kf)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                s[kf][r] = __builtin_amdgcn_exp2f(HAS_BIAS ? s[kf][r] + neg_m : fmaf(s[kf][r], sl2, neg_m));
+                s[kf][r] = __builtin_amdgcn_exp2f(LOG2_DOMAIN ? s[kf][r] + neg_m : fmaf(s[kf][r], sl2, neg_m));
         // ---- O^T += V^T . P^T   (i <-> d, j <-> query, k-slot (half,j) <-> key 16t + 4*half + 8*(j>>2) + (j&3))
 #pragma unroll
         for (int kf = 0; kf < 2; ++kf)

@@ -34,7 +34,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
-static constexpr int BM = 256, BN = 256, BK = 64;
+static constexpr int BM = GEMM_BM, BN = GEMM_BN, BK = 64;
 static constexpr int STAGE_BYTES = 65536;   // A 32 KiB + W 32 KiB
 static constexpr int W_OFF = 32768;
 static constexpr int PERSISTENT_WGS = 256;   // one 128-KiB-LDS workgroup per CU
@@ -91,22 +91,8 @@ __global__ void __launch_bounds__(512) gemm_bf16_kernel(const GemmParams p) {
 
     // ---- XCD-aware, grouped tile map (bijective for any tile count)
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
-    const int nwg = tiles_m * tiles_n;
-    int t_lin;
-    {
-        const int pid = blockIdx.x;
-        const int xcd = pid & 7, local = pid >> 3;
-        const int q = nwg >> 3, r = nwg & 7;
-        t_lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
-    }
-    const int GM = 8;
-    const int width = GM * tiles_n;
-    const int group = t_lin / width;
-    const int first_m = group * GM;
-    const int gsz = min(tiles_m - first_m, GM);
-    const int tm = first_m + (t_lin % width) % gsz;
-    const int tn = (t_lin % width) / gsz;
-    const int m0 = tm * BM, n0 = tn * BN;
+    int m0, n0, bz_unused;
+    tile_of_slot(blockIdx.x, tiles_m * tiles_n, tiles_m, tiles_n, p.tile_gm, p.tile_ns, m0, n0, bz_unused);
 
     // ---- staging addresses: wave w, instruction i covers LDS rows (i*8+w)*8 .. +7 (1 KiB, lane-linear)
     const int sw = ((w & 1) << 2) + (lane >> 4);   // = (row>>1)&7 of the row this lane stages
@@ -745,18 +731,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) 
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)LDS_PTR(lds));
 
     auto tile_coords = [&](int pid, int& m0, int& n0, int& bz) {
-        const int xcd = pid & 7, local = pid >> 3;
-        const int q = nwg >> 3, r = nwg & 7;
-        int t_lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
-        bz = t_lin / tiles_pb;                              // batched GEMM: consecutive tiles stay in one batch entry
-        t_lin -= bz * tiles_pb;
-        const int GM = 8;
-        const int width = GM * tiles_n;
-        const int group = t_lin / width;
-        const int first_m = group * GM;
-        const int gsz = min(tiles_m - first_m, GM);
-        m0 = (first_m + (t_lin % width) % gsz) * BM;
-        n0 = ((t_lin % width) / gsz) * BN;
+        tile_of_slot(pid, nwg, tiles_m, tiles_n, p.tile_gm, p.tile_ns, m0, n0, bz);
     };
 
     const int sw = ((w & 1) << 2) + (lane >> 4);
@@ -1001,18 +976,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_pingpong(const GemmParams p) {
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)LDS_PTR(lds));
 
     auto tile_coords = [&](int pid, int& m0, int& n0, int& bz) {
-        const int xcd = pid & 7, local = pid >> 3;
-        const int q = nwg >> 3, r = nwg & 7;
-        int t_lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
-        bz = t_lin / tiles_pb;
-        t_lin -= bz * tiles_pb;
-        const int GM = 8;
-        const int width = GM * tiles_n;
-        const int group = t_lin / width;
-        const int first_m = group * GM;
-        const int gsz = min(tiles_m - first_m, GM);
-        m0 = (first_m + (t_lin % width) % gsz) * BM;
-        n0 = ((t_lin % width) / gsz) * BN;
+        tile_of_slot(pid, nwg, tiles_m, tiles_n, p.tile_gm, p.tile_ns, m0, n0, bz);
     };
 
     // ---- staging stream.  Half-tile A_i = tile rows {c*128 + i*64 + 0..63}, W_j = rows {q*64 + j*32 + 0..31};
@@ -1274,7 +1238,9 @@ static hipError_t launch_epi(const GemmParams& p, int variant, hipStream_t strea
 }
 
 
-hipError_t launch_gemm(const GemmParams& p, int epilogue, int variant, hipStream_t stream) {
+hipError_t launch_gemm(const GemmParams& p_in, int epilogue, int variant, hipStream_t stream) {
+    GemmParams p = p_in;
+    resolve_tile_order(p, PERSISTENT_WGS);
 #ifndef VQS_LAB
     if (variant == 1 || variant == 4 || variant == 7) return hipErrorInvalidValue;     // lab-only forms (see the file header)
 #endif

@@ -57,6 +57,9 @@ struct vqs_handle {
     // stage taps (vqs_debug_tap): point name -> (caller buffer, capacity); the pass copies the named intermediate there
     struct Tap { void* dst; size_t cap; };
     std::unordered_map<std::string, Tap> taps;
+    // per-shape tile order of the big GEMMs (option "tile_order:<N>x<K>"): a permutation of the tile list, results unchanged
+    struct TileOrder { int N, K, gm, ns; };
+    std::vector<TileOrder> tile_orders;
 };
 
 namespace {
@@ -280,6 +283,8 @@ int run_gemm(vqs_handle* h, const GemmCall& g, hipStream_t st, const char* what)
     p.batch = g.batch; p.sA = g.sA; p.sW = g.sW; p.sC = g.sC;
     p.hres = g.hres; p.ldh = g.ldh; p.lnw = g.lnw; p.rowss_out = g.rowss_out;
     p.rowss_in = g.rowss_in; p.rowss_parts = g.rowss_parts; p.rs_invd = g.rs_invd; p.rs_eps = g.rs_eps;
+    for (const vqs_handle::TileOrder& t : h->tile_orders)
+        if (t.N == g.N && t.K == g.K) { p.tile_gm = t.gm; p.tile_ns = t.ns; }
     if (h->prof) {
         while (h->ev.size() < h->ev_used + 2) {
             hipEvent_t e;
@@ -346,6 +351,25 @@ int vqs_debug_heads_rows(int32_t row0, int32_t S, int32_t hx, int32_t hdim, int3
         vqs::heads_off_step8(S, hdim, wrap, hs, off);
     }
     return VQS_OK;
+}
+
+int vqs_debug_tile_order(int32_t M, int32_t N, int32_t batch, int32_t gm, int32_t ns, int32_t grid, int32_t* out) {
+    if (M <= 0 || N <= 0 || batch <= 0 || grid <= 0 || (grid & 7) != 0 || !out) return VQS_ERR_INVALID;
+    vqs::GemmParams p{};
+    p.M = M; p.N = N; p.batch = batch; p.tile_gm = gm; p.tile_ns = ns;
+    vqs::resolve_tile_order(p, grid);
+    const int tiles_m = (M + vqs::GEMM_BM - 1) / vqs::GEMM_BM, tiles_n = (N + vqs::GEMM_BN - 1) / vqs::GEMM_BN;
+    const int nwg = tiles_m * tiles_n * batch;
+    // the persistent kernels' walk: workgroup b takes slots b, b + grid, b + 2 grid, ... while slot < nwg
+    int k = 0;
+    for (int b = 0; b < grid; ++b)
+        for (int pid = b; pid < nwg; pid += grid) {
+            int m0, n0, bz;
+            vqs::tile_of_slot(pid, nwg, tiles_m, tiles_n, p.tile_gm, p.tile_ns, m0, n0, bz);
+            out[4 * k + 0] = pid; out[4 * k + 1] = m0; out[4 * k + 2] = n0; out[4 * k + 3] = bz;
+            ++k;
+        }
+    return k == nwg ? (p.tile_gm | (p.tile_ns << 8)) : VQS_ERR_INVALID;
 }
 
 int64_t vqs_attention_lds_bytes(int32_t S, int32_t has_bias, int32_t hd) {
@@ -417,6 +441,16 @@ int vqs_set_option(vqs_handle* h, const char* name, int32_t value) {
     else if (n == "fused_norm" && (value == 0 || value == 1)) h->fused_norm = value;
     else if (n == "norm_defer" && (value == 0 || value == 1)) h->norm_defer = value;
     else if (n == "gemm_variant" && (value == 0 || value == 2 || value == 3 || value == 5)) h->gemm_variant = value;
+    else if (n.rfind("tile_order:", 0) == 0) {
+        // "tile_order:<N>x<K>" = gm | ns << 8 for every GEMM of the pass with that (N, K); 0 removes the entry
+        int N = 0, K = 0;
+        const int gm = value & 0xff, ns = (value >> 8) & 0xff;
+        if (std::sscanf(n.c_str() + 11, "%dx%d", &N, &K) != 2 || N <= 0 || K <= 0 || value < 0 || (value >> 16) != 0 || (value != 0 && (gm < 1 || gm > 64 || ns > 8)))
+            return fail(h, VQS_ERR_INVALID, "set_option: bad tile order: " + n + "=" + std::to_string(value));
+        for (size_t i = 0; i < h->tile_orders.size(); ++i)
+            if (h->tile_orders[i].N == N && h->tile_orders[i].K == K) { h->tile_orders.erase(h->tile_orders.begin() + i); break; }
+        if (value != 0) h->tile_orders.push_back(vqs_handle::TileOrder{N, K, gm, ns});
+    }
     else return fail(h, VQS_ERR_INVALID, "set_option: unknown option or value: " + n + "=" + std::to_string(value));
     return VQS_OK;
 }
@@ -1089,7 +1123,9 @@ int vqs_gemm(const void* A, const void* W, void* C, const void* bias, const floa
     p.heads_out[0] = (bf16_t*)C;
     p.heads_out[1] = (bf16_t*)C + per;
     p.heads_out[2] = (bf16_t*)C + 2 * per;
-    return vqs::launch_gemm(p, epilogue, variant, (hipStream_t)stream) == hipSuccess ? VQS_OK : VQS_ERR_HIP;
+    p.tile_gm = (variant >> 8) & 0xff;     // bits 8-15 / 16-23 of `variant`: tile order (0 = default), see vqs.h
+    p.tile_ns = (variant >> 16) & 0xff;
+    return vqs::launch_gemm(p, epilogue, variant & 0xff, (hipStream_t)stream) == hipSuccess ? VQS_OK : VQS_ERR_HIP;
 }
 
 int vqs_attention(const void* q, const void* k, const void* v, void* out, const float* bias_table, const int32_t* key_len,

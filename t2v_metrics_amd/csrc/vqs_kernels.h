@@ -42,6 +42,9 @@ struct GemmParams {
     // batched GEMM (persistent variant only): entry z uses A + z*sA, W + z*sW, C + z*sC (strides in elements)
     int batch = 1;
     long long sA = 0, sW = 0, sC = 0;
+    // workgroup -> tile order (gemm.hip tile_of_slot): M-tiles per group and number of N column ranges; 0 = default (8, 1).
+    // A permutation of the tile list only -- results do not depend on it.
+    int tile_gm = 0, tile_ns = 0;
     // EPI_RESID_RMS (producer side of the fused residual + RMSNorm)
     float* hres = nullptr;           // [M, ldh] fp32 residual stream, read-modified-written
     int ldh = 0;
@@ -78,6 +81,60 @@ VQS_HD inline void heads_off_step8(int S, int hdim, long long wrap, int& hs, lon
         off += wrap;
     }
 }
+
+static constexpr int GEMM_BM = 256, GEMM_BN = 256;   // output tile of every GEMM kernel
+
+// ----------------------------------------------------------------------------------------------------
+// Workgroup slot -> output tile.  Slot `pid` runs on XCD pid % 8 (hardware round-robin), so each XCD is given a CONTIGUOUS run
+// of the tile order below and its 32 concurrent workgroups work on neighbouring tiles that share panels in that XCD's L2.
+// Order of the tiles of one batch entry: N is cut into `ns` column ranges walked one after the other IN TIME (every XCD does
+// its share of range 0, then of range 1, ...); inside a range, groups of `gm` M-tiles x all N-tiles of the range, M fastest.
+// gm = 8, ns = 1 is the map of rounds 1-2 (an 8 x 4 window of concurrent tiles per XCD).  (gm, ns) only permute WHICH
+// workgroup computes a tile WHEN: every tile's arithmetic is unchanged, results are bitwise identical for any choice
+// (test_gemm_tile_order_is_a_permutation, test_gemm_persistent_many_tiles).  What they steer is the working set that has to
+// stay in the 256 MB Infinity Cache while the chip sweeps W: 8 XCDs x (gm M-tiles x K) of A plus (N / ns x K) of W.
+// ns > 1 requires tiles_m * (tiles_n / ns) % 8 == 0 and tiles_n % ns == 0 (the launcher checks; no remainders to balance).
+// ----------------------------------------------------------------------------------------------------
+VQS_HD inline void tile_of_slot(int pid, int nwg, int tiles_m, int tiles_n, int gm, int ns, int& m0, int& n0, int& bz) {
+    const int xcd = pid & 7, local = pid >> 3;
+    const int tiles_pb = tiles_m * tiles_n;
+    int t_lin, n_lo = 0, cols = tiles_n;
+    if (ns > 1) {                                          // batch == 1, no remainders (launcher)
+        cols = tiles_n / ns;
+        const int per_xcd = (tiles_m * cols) >> 3;          // tiles of one range per XCD
+        const int part = local / per_xcd;
+        t_lin = xcd * per_xcd + (local - part * per_xcd);
+        n_lo = part * cols;
+        bz = 0;
+    } else {
+        const int q = nwg >> 3, r = nwg & 7;
+        t_lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+        bz = t_lin / tiles_pb;                              // batched GEMM: consecutive tiles stay in one batch entry
+        t_lin -= bz * tiles_pb;
+    }
+    const int width = gm * cols;
+    const int group = t_lin / width;
+    const int first_m = group * gm;
+    const int gsz = tiles_m - first_m < gm ? tiles_m - first_m : gm;
+    const int x = t_lin - group * width;
+    m0 = (first_m + x % gsz) * GEMM_BM;
+    n0 = (n_lo + x / gsz) * GEMM_BN;
+}
+
+
+// Tile order of a launch (see tile_of_slot): an explicit (tile_gm, tile_ns) of the caller is honoured where it is legal,
+// 0 selects the default.  ns > 1 needs equal column ranges and equal per-XCD shares (no remainders), one batch entry and
+// enough tiles for the persistent grid.
+inline void resolve_tile_order(GemmParams& p, int persistent_wgs) {
+    const int tiles_m = (p.M + GEMM_BM - 1) / GEMM_BM, tiles_n = (p.N + GEMM_BN - 1) / GEMM_BN;
+    int gm = p.tile_gm > 0 ? p.tile_gm : 8;
+    int ns = p.tile_ns > 0 ? p.tile_ns : 1;
+    if (gm > 64) gm = 64;
+    if (ns > 1 && (p.batch > 1 || (tiles_n % ns) != 0 || ((tiles_m * (tiles_n / ns)) & 7) != 0 || tiles_m * tiles_n < 8 * persistent_wgs)) ns = 1;
+    p.tile_gm = gm;
+    p.tile_ns = ns;
+}
+
 
 // variant 0 = direct-to-LDS (global_load_lds) staging; variant 1 = register-staged (debug / A-B)
 hipError_t launch_gemm(const GemmParams& p, int epilogue, int variant, hipStream_t stream);

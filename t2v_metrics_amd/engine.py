@@ -72,6 +72,7 @@ _SIGNATURES = {
     "vqs_set_option": (_c_i32, [_c_vp, ctypes.c_char_p, _c_i32]),
     "vqs_debug_tap": (_c_i32, [_c_vp, ctypes.c_char_p, _c_vp, ctypes.c_size_t]),
     "vqs_debug_heads_rows": (_c_i32, [_c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_vp]),
+    "vqs_debug_tile_order": (_c_i32, [_c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_vp]),
     "vqs_relpos_bucket": (_c_i32, [_c_i32, _c_i32, _c_i32, _c_i32]),
 }
 
@@ -314,8 +315,11 @@ class VqsEngine:
 
 
 # ---------------------------------------------------------------------- single-kernel wrappers (tests, microbench)
-def gemm(A, W, epilogue: int, bias=None, resid=None, out=None, S: int = 0, H: int = 0, variant: int = 0):
-    """C = epilogue(A @ W.T).  A [M,K] bf16, W [N,K] bf16.  See include/vqs.h for epilogue codes."""
+def gemm(A, W, epilogue: int, bias=None, resid=None, out=None, S: int = 0, H: int = 0, variant: int = 0, tile_order=None):
+    """C = epilogue(A @ W.T).  A [M,K] bf16, W [N,K] bf16.  See include/vqs.h for epilogue codes.
+    tile_order = (gm, ns): workgroup -> tile order of the launch (a permutation of the tile list; bitwise-neutral)."""
+    if tile_order is not None:
+        variant = (variant & 0xff) | (int(tile_order[0]) << 8) | (int(tile_order[1]) << 16)
     lib = load_library()
     M, K = A.shape
     N = W.shape[0]

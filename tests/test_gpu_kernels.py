@@ -71,6 +71,22 @@ def describe(out, ref):
     return describe_mismatch(out, ref, 0.0, 0.0, "persistent vs variant 0")
 
 
+@pytest.mark.parametrize("M,N,K,epi,S,H", [(16384 - 40, 8192, 128, 0, 0, 0), (16384, 8192, 192, 5, 0, 0), (608 * 27, 3 * 2048 + 2048, 128, 0, 0, 0),
+                                           (608 * 28, 3 * 2048, 128, 6, 608, 32), (40000, 512, 320, 0, 0, 0)])
+def test_gemm_tile_order_is_bitwise_neutral(eng, M, N, K, epi, S, H):
+    """The workgroup -> tile order (gm M-tiles per group, N cut into ns column ranges walked one after the other) permutes
+    which workgroup computes a tile when and nothing else: every order gives the bits of the default order and of the
+    one-tile-per-workgroup kernel -- persistent lock-step (incl. its L2-touch form on the last shape), ping-pong and
+    variant 0, full and ragged edges, plain / gated / head-major epilogues."""
+    A = randn_bf16(M, K, seed=61)
+    W = randn_bf16(N, K, seed=62, scale=K ** -0.5)
+    ref = eng.gemm(A, W, epi, S=S, H=H, variant=0)
+    for variant in (3, 5, 0):
+        for order in ((8, 1), (4, 1), (2, 1), (1, 1), (16, 1), (3, 1), (8, 2), (4, 2), (2, 4), (64, 4)):
+            out = eng.gemm(A, W, epi, S=S, H=H, variant=variant, tile_order=order)
+            assert torch.equal(out, ref), (variant, order, describe(out, ref))
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 512, 128), (1000, 768, 256), (70000, 512, 64)])
 @pytest.mark.parametrize("variant", [3, 5])
 def test_gemm_fused_residual_rmsnorm(eng, M, N, K, variant):

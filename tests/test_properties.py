@@ -173,3 +173,63 @@ def test_heads_epilogue_hook_rejects_short_sequences():
     lib = engine.load_library()
     out = np.empty(4, dtype=np.int64)
     assert lib.vqs_debug_heads_rows(0, 7, 2, 64, 4, out.ctypes.data_as(ctypes.c_void_p)) != 0      # S < 8 runs variant 0 instead
+
+
+# ------------------------------------------------------------------ workgroup -> tile order of the GEMM kernels (gemm.hip / vqs_kernels.h tile_of_slot)
+def _legacy_tile_map(M, N, batch):
+    """The map of rounds 1-2, restated: each XCD (slot % 8) owns a contiguous run of the tile list, walked in groups of
+    8 M-tiles x all N-tiles, M fastest."""
+    tm, tn = -(-M // 256), -(-N // 256)
+    nwg = tm * tn * batch
+    q, r = nwg >> 3, nwg & 7
+    out = {}
+    for pid in range(nwg):
+        xcd, local = pid & 7, pid >> 3
+        t = (xcd * (q + 1) if xcd < r else r * (q + 1) + (xcd - r) * q) + local
+        bz, t = divmod(t, tm * tn)
+        group, x = divmod(t, 8 * tn)
+        gsz = min(tm - group * 8, 8)
+        out[pid] = ((group * 8 + x % gsz) * 256, (x // gsz) * 256, bz)
+    return out
+
+
+@settings(max_examples=120, deadline=None)
+@given(tm=st.integers(1, 90), tn=st.integers(1, 40), batch=st.integers(1, 3), gm=st.sampled_from([0, 1, 2, 3, 4, 8, 16, 64]),
+       ns=st.sampled_from([0, 1, 2, 4, 5]), ragged=st.booleans())
+def test_gemm_tile_order_is_a_permutation(tm, tn, batch, gm, ns, ragged):
+    """Whatever (gm, ns) a caller asks for, the persistent walk visits every tile of every batch entry exactly once; (0, 0)
+    and (8, 1) are the map of rounds 1-2; an illegal ns (remainders, batched, too few tiles) falls back to 1."""
+    from t2v_metrics_amd import engine
+    lib = engine.load_library()
+    M, N = tm * 256 - (17 if ragged else 0), tn * 256 - (8 if ragged else 0)
+    nwg = tm * tn * batch
+    out = np.empty((nwg, 4), dtype=np.int32)
+    rc = lib.vqs_debug_tile_order(M, N, batch, gm, ns, 256, out.ctypes.data_as(ctypes.c_void_p))
+    assert rc > 0
+    rgm, rns = rc & 0xff, rc >> 8
+    assert rgm == (gm if gm else 8)
+    legal = ns > 1 and batch == 1 and tn % ns == 0 and (tm * (tn // ns)) % 8 == 0 and tm * tn >= 8 * 256
+    assert rns == (ns if legal else 1)
+    assert sorted(out[:, 0].tolist()) == list(range(nwg))                      # every slot once
+    tiles = {(int(m0), int(n0), int(bz)) for _, m0, n0, bz in out}
+    assert tiles == {(i * 256, j * 256, b) for i in range(tm) for j in range(tn) for b in range(batch)}
+    if rgm == 8 and rns == 1:
+        legacy = _legacy_tile_map(M, N, batch)
+        assert all(legacy[int(pid)] == (int(m0), int(n0), int(bz)) for pid, m0, n0, bz in out)
+
+
+def test_gemm_tile_order_column_ranges_are_walked_one_after_the_other():
+    """ns = 2 on the T5-XXL wi shape: every XCD finishes its share of the first half of N before any tile of the second."""
+    from t2v_metrics_amd import engine
+    lib = engine.load_library()
+    M, N = 155648, 20480
+    nwg = (M // 256) * (N // 256)
+    out = np.empty((nwg, 4), dtype=np.int32)
+    assert lib.vqs_debug_tile_order(M, N, 1, 4, 2, 256, out.ctypes.data_as(ctypes.c_void_p)) == (4 | 2 << 8)
+    order = out[np.argsort(out[:, 0], kind="stable")]                           # by slot = by time within an XCD
+    for xcd in range(8):
+        mine = order[order[:, 0] % 8 == xcd]
+        half = (mine[:, 2] >= N // 2).astype(int)
+        assert (np.diff(half) >= 0).all() and half.sum() * 2 == len(mine)
+        first = mine[:32]                                                        # the XCD's first 32 concurrent tiles: 4 M x 8 N
+        assert len(set(first[:, 1])) == 4 and len(set(first[:, 2])) == 8
