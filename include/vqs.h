@@ -218,10 +218,11 @@ int vqs_debug_tap(vqs_handle* h, const char* name, void* d_dst, size_t bytes);
  * rows row0 + 8k, k = 0..n-1, computed by the SAME inline functions as the kernel (one division, then steps).  S >= 8. */
 int vqs_debug_heads_rows(int32_t row0, int32_t S, int32_t hx, int32_t hdim, int32_t n, int64_t* off_out);
 /* Host-side test hook, no device access: the tile every workgroup slot of a persistent GEMM launch (grid workgroups, a multiple
- * of 8) computes under tile order (gm, ns), by the SAME inline function as the kernels: out[4*i .. 4*i+3] = (slot, m0, n0, batch
- * entry) for the M x N x batch problem, nwg = tiles entries.  Returns the resolved gm | ns << 8 (illegal ns falls back to 1) or a
- * negative error. */
-int vqs_debug_tile_order(int32_t M, int32_t N, int32_t batch, int32_t gm, int32_t ns, int32_t grid, int32_t* out);
+ * of 8) computes under tile order (gm, ns), by the SAME inline functions as the launcher and the kernels: out[4*i .. 4*i+3] =
+ * (slot, m0, n0, batch entry) for the M x N x K x batch problem, i < number of tiles.  gm = ns = 0 asks for the library's choice
+ * by shape (the Infinity-Cache working-set rule, vqs_kernels.h resolve_tile_order).  Returns the resolved gm | ns << 8 (an
+ * illegal ns falls back to 1) or a negative error. */
+int vqs_debug_tile_order(int32_t M, int32_t N, int32_t K, int32_t batch, int32_t gm, int32_t ns, int32_t grid, int32_t* out);
 /* Host-side arithmetic, no device access: dynamic LDS bytes vqs_attention / vqs_attention_hd request per workgroup for
  * sequence length S (hd 0 / 64 / 128).  The kernels' occupancy hangs on it (160 KiB of LDS per CU in 1 280-B granules);
  * -1 on bad arguments. */

@@ -345,6 +345,30 @@ __global__ void __launch_bounds__(512) gemm_bf16_kernel(const GemmParams p) {
 // stores of block m) so that no load ever has to wait behind a just-issued store.
 // Measured motivation (tools/gemm_lab.sh ablations, 155648x10240x2048): stores cost 19 %, staging+prologue 26 %.
 // =====================================================================================================
+// Row stores of the staged epilogue.  VQS_GEMM_NT_STORE (compile-time lab form): outputs of the big launches (>= 128 MB) leave
+// with the non-temporal hint -- they are gigabytes that the next kernel streams once, and the Infinity Cache is what the tile
+// order keeps the A / W panels in.
+#ifndef VQS_GEMM_NT_STORE
+#define VQS_GEMM_NT_STORE 0
+#endif
+typedef uint32_t g_u4v __attribute__((ext_vector_type(4)));
+typedef float g_f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st_row16(void* p, uint4 v, bool nt) {
+    if (VQS_GEMM_NT_STORE && nt) {
+        g_u4v u = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(u, reinterpret_cast<g_u4v*>(p));
+    } else {
+        *reinterpret_cast<uint4*>(p) = v;
+    }
+}
+__device__ __forceinline__ void st_row16f(void* p, float4 v, bool nt) {
+    if (VQS_GEMM_NT_STORE && nt) {
+        g_f4v u = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(u, reinterpret_cast<g_f4v*>(p));
+    } else {
+        *reinterpret_cast<float4*>(p) = v;
+    }
+}
 __device__ __forceinline__ void st8(void* p, uint2 v) { *reinterpret_cast<uint2*>(p) = v; }
 __device__ __forceinline__ void st16(void* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
@@ -361,6 +385,7 @@ template <int EPI>
 __device__ __forceinline__ void staged_epilogue(const GemmParams& p, f32x16 (&acc)[4][2], char* reg, int m0, int n0, int bz,
                                                 int wr, int wc, int lane, bool full, float* rowred) {
     const int hh = lane >> 5, lr = lane & 31;
+    const bool nt = VQS_GEMM_NT_STORE && (size_t)p.M * (size_t)p.N >= ((size_t)64 << 20);
     const int row_w = m0 + wr * 128;                 // first row of this wave's tile
     const int col_w = n0 + wc * 64;                  // first column
     if (p.rowss_in != nullptr) {
@@ -526,7 +551,7 @@ __device__ __forceinline__ void staged_epilogue(const GemmParams& p, f32x16 (&ac
                 const uint4 v = *reinterpret_cast<const uint4*>(reg + r * 64 + ((c ^ ((r >> 1) & 3)) << 4));
                 const int row = row_w + hm * 64 + r, oc = ocol_w + c * 8;
                 if (full || (row < p.M && oc < NO))
-                    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)bz * p.sC + (size_t)row * p.ldc + oc) = v;
+                    st_row16(reinterpret_cast<bf16_t*>(p.C) + (size_t)bz * p.sC + (size_t)row * p.ldc + oc, v, nt);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
@@ -577,7 +602,7 @@ __device__ __forceinline__ void staged_epilogue(const GemmParams& p, f32x16 (&ac
                             const float4 rv = *reinterpret_cast<const float4*>(p.resid + off);
                             v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
                         }
-                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + off) = v;
+                        st_row16f(reinterpret_cast<float*>(p.C) + off, v, nt);
                     }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -647,7 +672,7 @@ __device__ __forceinline__ void staged_epilogue(const GemmParams& p, f32x16 (&ac
                         } else {
                             dst = reinterpret_cast<bf16_t*>(p.C) + (size_t)bz * p.sC + (size_t)row * p.ldc + col;
                         }
-                        *reinterpret_cast<uint4*>(dst) = v;
+                        st_row16(dst, v, nt);
                     }
                     if constexpr (EPI == EPI_HEADS) heads_off_step8(p.S, hdim, off_wrap, hs_run, off_run);   // next row of this lane: + 8 (also across the hm passes)
                 }

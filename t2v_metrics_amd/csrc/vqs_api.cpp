@@ -353,10 +353,10 @@ int vqs_debug_heads_rows(int32_t row0, int32_t S, int32_t hx, int32_t hdim, int3
     return VQS_OK;
 }
 
-int vqs_debug_tile_order(int32_t M, int32_t N, int32_t batch, int32_t gm, int32_t ns, int32_t grid, int32_t* out) {
-    if (M <= 0 || N <= 0 || batch <= 0 || grid <= 0 || (grid & 7) != 0 || !out) return VQS_ERR_INVALID;
+int vqs_debug_tile_order(int32_t M, int32_t N, int32_t K, int32_t batch, int32_t gm, int32_t ns, int32_t grid, int32_t* out) {
+    if (M <= 0 || N <= 0 || K < 0 || batch <= 0 || grid <= 0 || (grid & 7) != 0 || !out) return VQS_ERR_INVALID;
     vqs::GemmParams p{};
-    p.M = M; p.N = N; p.batch = batch; p.tile_gm = gm; p.tile_ns = ns;
+    p.M = M; p.N = N; p.K = K; p.batch = batch; p.tile_gm = gm; p.tile_ns = ns;
     vqs::resolve_tile_order(p, grid);
     const int tiles_m = (M + vqs::GEMM_BM - 1) / vqs::GEMM_BM, tiles_n = (N + vqs::GEMM_BN - 1) / vqs::GEMM_BN;
     const int nwg = tiles_m * tiles_n * batch;

@@ -122,13 +122,28 @@ VQS_HD inline void tile_of_slot(int pid, int nwg, int tiles_m, int tiles_n, int 
 }
 
 
-// Tile order of a launch (see tile_of_slot): an explicit (tile_gm, tile_ns) of the caller is honoured where it is legal,
-// 0 selects the default.  ns > 1 needs equal column ranges and equal per-XCD shares (no remainders), one batch entry and
-// enough tiles for the persistent grid.
+// Tile order of a launch (see tile_of_slot): an explicit (tile_gm, tile_ns) of the caller is honoured where it is legal;
+// 0 selects the library's choice by shape.  That choice follows the working set the chip holds while it sweeps W --
+// 8 XCDs x (gm M-tiles x K) of A plus (N / ns x K) of W, in bf16 -- against the 256 MB Infinity Cache (measured, MI355X,
+// profiles/r2_call25_tile_order_*.jsonl: isolated sweeps of gm x ns per shape and an interleaved in-situ A/B, +1.0 % per XXL
+// step; 16-M-tile groups lose 10 % at every shape, the 16 x 2 window of concurrent tiles per XCD re-fetches more):
+//   * (8, 1) while the working set is <= 180 MB (every ViT and T5-XL shape but wo, T5-XXL o);
+//   * otherwise groups of 4 M-tiles (T5-XXL wi 302 -> 235 MB: +1.5 %, qkv 234 -> 167 MB: +1.5 %, T5-XL wo);
+//   * and N in two column ranges when even that leaves > 240 MB (T5-XXL wo, K = 10 240: 420 -> 210 MB, +3.6 %).
+// ns > 1 needs equal column ranges and equal per-XCD shares (no remainders), one batch entry and enough tiles for the
+// persistent grid; otherwise 1.
+inline double tile_order_working_set_mb(int N, int K, int gm, int ns) {
+    return (8.0 * gm * GEMM_BM * (double)K * 2.0 + ((double)N / ns) * (double)K * 2.0) / 1.0e6;
+}
 inline void resolve_tile_order(GemmParams& p, int persistent_wgs) {
     const int tiles_m = (p.M + GEMM_BM - 1) / GEMM_BM, tiles_n = (p.N + GEMM_BN - 1) / GEMM_BN;
-    int gm = p.tile_gm > 0 ? p.tile_gm : 8;
-    int ns = p.tile_ns > 0 ? p.tile_ns : 1;
+    int gm = p.tile_gm, ns = p.tile_ns;
+    if (gm <= 0 && ns <= 0 && p.batch <= 1 && tiles_m * tiles_n >= 8 * persistent_wgs) {      // the library's choice (big launches only)
+        gm = tile_order_working_set_mb(p.N, p.K, 8, 1) <= 180.0 ? 8 : 4;
+        ns = (gm == 4 && tile_order_working_set_mb(p.N, p.K, 4, 1) > 240.0) ? 2 : 1;
+    }
+    if (gm <= 0) gm = 8;
+    if (ns <= 0) ns = 1;
     if (gm > 64) gm = 64;
     if (ns > 1 && (p.batch > 1 || (tiles_n % ns) != 0 || ((tiles_m * (tiles_n / ns)) & 7) != 0 || tiles_m * tiles_n < 8 * persistent_wgs)) ns = 1;
     p.tile_gm = gm;

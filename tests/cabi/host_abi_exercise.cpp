@@ -38,6 +38,19 @@ int main() {
     std::vector<int64_t> off(64);
     assert(vqs_debug_heads_rows(5, 608, 64, 64, 64, off.data()) == 0 && vqs_debug_heads_rows(5, 7, 64, 64, 4, off.data()) != 0);
     assert(vqs_attention_lds_bytes(608, 1, 64) > 0 && vqs_attention_lds_bytes(608, 1, 77) < 0);
+    // tile order: option parsing (per-shape table, removal, malformed names / values) and the host walk of the tile map
+    assert(vqs_set_option(h, "tile_order:20480x4096", 4 | 2 << 8) == 0 && vqs_set_option(h, "tile_order:20480x4096", 2) == 0);
+    assert(vqs_set_option(h, "tile_order:20480x4096", 0) == 0 && vqs_set_option(h, "tile_order:4096x10240", 0) == 0);
+    assert(vqs_set_option(h, "tile_order:", 8) != 0 && vqs_set_option(h, "tile_order:12x", 8) != 0 && vqs_set_option(h, "tile_order:-4x64", 8) != 0);
+    assert(vqs_set_option(h, "tile_order:64x64", 65) != 0 && vqs_set_option(h, "tile_order:64x64", 1 << 16) != 0 && vqs_set_option(h, "tile_order:64x64", 8 | 9 << 8) != 0);
+    {
+        const int M = 155648, N = 20480, nwg = (M / 256) * (N / 256);
+        std::vector<int32_t> tiles(4 * (size_t)nwg);
+        assert(vqs_debug_tile_order(M, N, 4096, 1, 4, 2, 256, tiles.data()) == (4 | 2 << 8));
+        assert(vqs_debug_tile_order(M, N, 4096, 1, 0, 0, 256, tiles.data()) == (4 | 1 << 8));
+        assert(vqs_debug_tile_order(577 * 256, 1024, 1024, 1, 8, 2, 256, tiles.data()) == (8 | 1 << 8));     // 577 x 2 tiles per range: remainders -> ns = 1
+        assert(vqs_debug_tile_order(M, N, 4096, 1, 4, 2, 250, tiles.data()) < 0 && vqs_debug_tile_order(0, N, 4096, 1, 4, 2, 256, tiles.data()) < 0);
+    }
     vqs_destroy(h);
     vqs_config bad = c;
     bad.d_kv = 32;

@@ -204,10 +204,10 @@ def test_gemm_tile_order_is_a_permutation(tm, tn, batch, gm, ns, ragged):
     M, N = tm * 256 - (17 if ragged else 0), tn * 256 - (8 if ragged else 0)
     nwg = tm * tn * batch
     out = np.empty((nwg, 4), dtype=np.int32)
-    rc = lib.vqs_debug_tile_order(M, N, batch, gm, ns, 256, out.ctypes.data_as(ctypes.c_void_p))
+    rc = lib.vqs_debug_tile_order(M, N, 64, batch, gm, ns, 256, out.ctypes.data_as(ctypes.c_void_p))
     assert rc > 0
     rgm, rns = rc & 0xff, rc >> 8
-    assert rgm == (gm if gm else 8)
+    assert rgm == (gm if gm else 8)                    # K = 64: tiny working set, the library's own choice is (8, 1) too
     legal = ns > 1 and batch == 1 and tn % ns == 0 and (tm * (tn // ns)) % 8 == 0 and tm * tn >= 8 * 256
     assert rns == (ns if legal else 1)
     assert sorted(out[:, 0].tolist()) == list(range(nwg))                      # every slot once
@@ -225,7 +225,7 @@ def test_gemm_tile_order_column_ranges_are_walked_one_after_the_other():
     M, N = 155648, 20480
     nwg = (M // 256) * (N // 256)
     out = np.empty((nwg, 4), dtype=np.int32)
-    assert lib.vqs_debug_tile_order(M, N, 1, 4, 2, 256, out.ctypes.data_as(ctypes.c_void_p)) == (4 | 2 << 8)
+    assert lib.vqs_debug_tile_order(M, N, 4096, 1, 4, 2, 256, out.ctypes.data_as(ctypes.c_void_p)) == (4 | 2 << 8)
     order = out[np.argsort(out[:, 0], kind="stable")]                           # by slot = by time within an XCD
     for xcd in range(8):
         mine = order[order[:, 0] % 8 == xcd]
@@ -233,3 +233,20 @@ def test_gemm_tile_order_column_ranges_are_walked_one_after_the_other():
         assert (np.diff(half) >= 0).all() and half.sum() * 2 == len(mine)
         first = mine[:32]                                                        # the XCD's first 32 concurrent tiles: 4 M x 8 N
         assert len(set(first[:, 1])) == 4 and len(set(first[:, 2])) == 8
+
+
+@pytest.mark.parametrize("what,M,N,K,expect", [
+    ("t5-xxl wi", 155648, 20480, 4096, (4, 1)), ("t5-xxl wo", 155648, 4096, 10240, (4, 2)), ("t5-xxl qkv", 155648, 12288, 4096, (4, 1)),
+    ("t5-xxl o", 155648, 4096, 4096, (8, 1)), ("t5-xl wi", 155648, 10240, 2048, (8, 1)), ("t5-xl wo", 155648, 2048, 5120, (4, 1)),
+    ("t5-xl qkv", 155648, 6144, 2048, (8, 1)), ("vit fc1", 147712, 4096, 1024, (8, 1)), ("vit fc2", 147712, 1024, 4096, (8, 1)),
+    ("genai bucket wo, S_e 648", 256 * 648, 4096, 10240, (4, 2)), ("dec wi (512 rows: small launch)", 512, 20480, 4096, (8, 1))])
+def test_gemm_tile_order_library_choice_by_shape(what, M, N, K, expect):
+    """The library's own tile order (gm = ns = 0): groups of 8 M-tiles while 8 XCDs x (8 M-tiles x K) of A plus W stay under
+    180 MB of the 256 MB Infinity Cache, else groups of 4, and two column ranges when that still leaves > 240 MB --
+    the measured optimum of every path shape (profiles/r2_call25_tile_order_*.jsonl)."""
+    from t2v_metrics_amd import engine
+    lib = engine.load_library()
+    nwg = -(-M // 256) * -(-N // 256)
+    out = np.empty((nwg, 4), dtype=np.int32)
+    rc = lib.vqs_debug_tile_order(M, N, K, 1, 0, 0, 256, out.ctypes.data_as(ctypes.c_void_p))
+    assert (rc & 0xff, rc >> 8) == expect, what

@@ -118,7 +118,8 @@ def attention_ab(variant_lib, reps):
         torch.cuda.empty_cache()
 
 
-def in_situ(model, tuned, steps, rounds, variant_lib=None):
+def in_situ(model, configs, steps, rounds, variant_lib=None, tag="C"):
+    """configs: [(name, "product" | "variant", {(N, K): gm | ns << 8 or 0})]; run interleaved, `rounds` times, `steps` steps each."""
     cfg = get_config(model)
     dev = torch.device("cuda", 0)
     weights = make_seeded_weights(cfg, seed=0, device=dev)
@@ -129,10 +130,13 @@ def in_situ(model, tuned, steps, rounds, variant_lib=None):
         engine._lib = engine.load_library(variant_lib)
         engines["variant"] = engine.VqsEngine(cfg, weights, device=dev)
         engine._lib = saved
+    keys = set()
+    for _, _, o in configs:
+        keys |= set(o)
 
     def apply(eng, orders):
-        for (N, K), val in orders.items():
-            eng.set_option("tile_order:%dx%d" % (N, K), val)
+        for k in keys:
+            eng.set_option("tile_order:%dx%d" % k, orders.get(k, 0))
 
     def run(eng, n):
         eng.profile(True)
@@ -145,31 +149,23 @@ def in_situ(model, tuned, steps, rounds, variant_lib=None):
         dt = (time.perf_counter() - t0) / n
         eng.profile(False)
         ng, gms, gfl = eng.profile_read(reset=True)
-        rep = {l[:20].strip(): float(l.split("TFLOP/s")[1]) for l in eng.profile_report().splitlines() if "TFLOP/s" in l and ("enc " in l or "vit " in l)}
+        rep = {l[:20].strip(): float(l.split("TFLOP/s")[1]) for l in eng.profile_report().splitlines() if "TFLOP/s" in l}
         return dt, gfl / gms / 1e9 if gms > 0 else 0.0, rep, lp, sc
 
-    zero = {k: 0 for k in tuned}
-    configs = [("product/default", "product", zero), ("product/tuned", "product", tuned)]
-    if variant_lib:
-        configs += [("variant/default", "variant", zero), ("variant/tuned", "variant", tuned)]
-    for name, which, orders in configs[:1]:
-        apply(engines[which], orders)
-        run(engines[which], 1)                                   # warm-up, workspaces
-    if variant_lib:
-        run(engines["variant"], 1)
+    for e in engines.values():
+        run(e, 1)                                                # warm-up, workspaces
     ref = None
     for r in range(rounds):
         for name, which, orders in configs:
             apply(engines[which], orders)
             dt, tf, rep, lp, sc = run(engines[which], steps)
-            rec = {"part": "C", "model": model, "config": name, "round": r, "ms_per_step": round(dt * 1e3, 2), "pairs_per_s": round(256 / dt, 2),
+            rec = {"part": tag, "model": model, "config": name, "round": r, "ms_per_step": round(dt * 1e3, 2), "pairs_per_s": round(256 / dt, 2),
                    "gemm_tflops": round(tf, 1), "sites": rep}
-            if which == "product":
-                if ref is None:
-                    ref = (lp.clone(), sc.clone())
-                rec["bitwise_equal_to_default"] = bool(torch.equal(lp, ref[0]) and torch.equal(sc, ref[1]))
-            else:
-                rec["max_abs_dlogp_vs_product"] = (lp - ref[0]).abs().max().item()
+            if ref is None:
+                ref = (lp.clone(), sc.clone())
+            rec["bitwise_equal_to_first_config"] = bool(torch.equal(lp, ref[0]) and torch.equal(sc, ref[1]))
+            if not rec["bitwise_equal_to_first_config"]:
+                rec["max_abs_dlogp_vs_first_config"] = (lp - ref[0]).abs().max().item()
             emit(rec)
     for e in engines.values():
         e.close()
@@ -177,40 +173,37 @@ def in_situ(model, tuned, steps, rounds, variant_lib=None):
     torch.cuda.empty_cache()
 
 
+FORCE_8x1_XXL = {(20480, 4096): 8 | 1 << 8, (4096, 10240): 8 | 1 << 8, (12288, 4096): 8 | 1 << 8, (4096, 4096): 8 | 1 << 8}
+FORCE_8x1_XL = {(10240, 2048): 8 | 1 << 8, (2048, 5120): 8 | 1 << 8, (6144, 2048): 8 | 1 << 8, (2048, 2048): 8 | 1 << 8}
+FINE = [(8, 1), (3, 1), (4, 1), (5, 1), (6, 1), (3, 2), (4, 2), (5, 2), (6, 2), (4, 4)]
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--parts", default="A,C,B,D")
-    ap.add_argument("--variant-lib", default=os.path.join(ROOT, "build", "lab", "libvqs_attn_bias_acc.so"))
-    ap.add_argument("--min-gain", type=float, default=0.01)
+    ap.add_argument("--parts", default="H,N,F,X")
+    ap.add_argument("--variant-lib", default=os.path.join(ROOT, "build", "lab", "libvqs_gemm_nt_store.so"))
+    ap.add_argument("--attn-lib", default=os.path.join(ROOT, "build", "lab", "libvqs_attn_bias_acc.so"))
     a = ap.parse_args()
     parts = a.parts.split(",")
     emit({"part": "start", "device": torch.cuda.get_device_name(0), "parts": parts})
-    tuned_xxl, tuned_xl = {}, {}
-    if "A" in parts:
-        b = sweep(XXL, reps=3)
-        b.update(sweep(VIT, reps=5, orders=[(8, 1), (4, 1), (16, 1), (32, 1), (2, 1)]))
-        for (N, K), (cand, gain, _) in b.items():
-            if gain > a.min_gain and cand != "8x1":
-                gm, ns = map(int, cand.split("x"))
-                tuned_xxl[(N, K)] = gm | ns << 8
-        emit({"part": "A", "tuned_xxl": {"%dx%d" % k: v for k, v in tuned_xxl.items()}})
-    if "C" in parts:
-        if not tuned_xxl:                                        # nothing cleared the bar in isolation: still test the Infinity-Cache-fit guess
-            tuned_xxl = {(20480, 4096): 8 | 2 << 8, (4096, 10240): 2 | 1 << 8}
-        in_situ("clip-flant5-xxl", tuned_xxl, steps=3, rounds=2)
-    if "B" in parts and os.path.exists(a.variant_lib):
-        attention_ab(a.variant_lib, reps=5)
-    if "D" in parts and os.path.exists(a.variant_lib):
-        in_situ("clip-flant5-xxl", tuned_xxl, steps=3, rounds=2, variant_lib=a.variant_lib)
+    if "A" in parts:                                             # call 25: isolated sweep of the orders
+        sweep(XXL, reps=3)
+        sweep(VIT, reps=5, orders=[(8, 1), (4, 1), (16, 1), (32, 1), (2, 1)])
+    if "H" in parts:                                             # the library's choice by shape against the round-1/2 map, in situ
+        in_situ("clip-flant5-xxl", [("forced 8x1", "product", FORCE_8x1_XXL), ("library choice", "product", {})], steps=3, rounds=3, tag="H")
+    if "N" in parts and os.path.exists(a.variant_lib):           # a variant build against the product, both on the library's tile order
+        in_situ("clip-flant5-xxl", [("product", "product", {}), ("variant " + os.path.basename(a.variant_lib), "variant", {})], steps=3, rounds=3,
+                variant_lib=a.variant_lib, tag="N")
+    if "F" in parts:
+        sweep(XXL, reps=3, orders=FINE)
+        sweep([s for s in XL if "wo" in s[0]], reps=5, orders=FINE)
     if "X" in parts:
-        b = sweep(XL, reps=5)
-        for (N, K), (cand, gain, _) in b.items():
-            if gain > a.min_gain and cand != "8x1":
-                gm, ns = map(int, cand.split("x"))
-                tuned_xl[(N, K)] = gm | ns << 8
-        emit({"part": "A", "tuned_xl": {"%dx%d" % k: v for k, v in tuned_xl.items()}})
-        if tuned_xl:
-            in_situ("clip-flant5-xl", tuned_xl, steps=4, rounds=2)
+        in_situ("clip-flant5-xl", [("forced 8x1", "product", FORCE_8x1_XL), ("library choice", "product", {})], steps=4, rounds=3, tag="HX")
+        if os.path.exists(a.variant_lib):
+            in_situ("clip-flant5-xl", [("product", "product", {}), ("variant " + os.path.basename(a.variant_lib), "variant", {})], steps=4, rounds=2,
+                    variant_lib=a.variant_lib, tag="NX")
+    if "B" in parts and os.path.exists(a.attn_lib):
+        attention_ab(a.attn_lib, reps=5)
     emit({"part": "done"})
 
 
