@@ -345,16 +345,13 @@ __global__ void __launch_bounds__(512) gemm_bf16_kernel(const GemmParams p) {
 // stores of block m) so that no load ever has to wait behind a just-issued store.
 // Measured motivation (tools/gemm_lab.sh ablations, 155648x10240x2048): stores cost 19 %, staging+prologue 26 %.
 // =====================================================================================================
-// Row stores of the staged epilogue.  VQS_GEMM_NT_STORE (compile-time lab form): outputs of the big launches (>= 128 MB) leave
-// with the non-temporal hint -- they are gigabytes that the next kernel streams once, and the Infinity Cache is what the tile
-// order keeps the A / W panels in.
-#ifndef VQS_GEMM_NT_STORE
-#define VQS_GEMM_NT_STORE 0
-#endif
+// Row stores of the staged epilogue.  nt (GemmParams::nt_store): the result leaves with the non-temporal hint -- a multi-GB
+// output that the next kernel streams once should not push the A / W panels out of the Infinity Cache (the tile order is chosen
+// so that they stay there).  Same bytes to the same addresses: results do not depend on it.
 typedef uint32_t g_u4v __attribute__((ext_vector_type(4)));
 typedef float g_f4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void st_row16(void* p, uint4 v, bool nt) {
-    if (VQS_GEMM_NT_STORE && nt) {
+    if (nt) {
         g_u4v u = {v.x, v.y, v.z, v.w};
         __builtin_nontemporal_store(u, reinterpret_cast<g_u4v*>(p));
     } else {
@@ -362,7 +359,7 @@ __device__ __forceinline__ void st_row16(void* p, uint4 v, bool nt) {
     }
 }
 __device__ __forceinline__ void st_row16f(void* p, float4 v, bool nt) {
-    if (VQS_GEMM_NT_STORE && nt) {
+    if (nt) {
         g_f4v u = {v.x, v.y, v.z, v.w};
         __builtin_nontemporal_store(u, reinterpret_cast<g_f4v*>(p));
     } else {
@@ -385,7 +382,7 @@ template <int EPI>
 __device__ __forceinline__ void staged_epilogue(const GemmParams& p, f32x16 (&acc)[4][2], char* reg, int m0, int n0, int bz,
                                                 int wr, int wc, int lane, bool full, float* rowred) {
     const int hh = lane >> 5, lr = lane & 31;
-    const bool nt = VQS_GEMM_NT_STORE && (size_t)p.M * (size_t)p.N >= ((size_t)64 << 20);
+    const bool nt = p.nt_store != 0;
     const int row_w = m0 + wr * 128;                 // first row of this wave's tile
     const int col_w = n0 + wc * 64;                  // first column
     if (p.rowss_in != nullptr) {

@@ -60,6 +60,9 @@ struct vqs_handle {
     // per-shape tile order of the big GEMMs (option "tile_order:<N>x<K>"): a permutation of the tile list, results unchanged
     struct TileOrder { int N, K, gm, ns; };
     std::vector<TileOrder> tile_orders;
+    // per-shape non-temporal result stores (option "nt_store:<N>x<K>" = 1 on, 2 off; absent = the library's choice)
+    struct NtStore { int N, K, on; };
+    std::vector<NtStore> nt_stores;
 };
 
 namespace {
@@ -272,6 +275,7 @@ struct GemmCall {
     const float* rowss_in = nullptr;
     int rowss_parts = 0;
     float rs_invd = 0.0f, rs_eps = 0.0f;
+    int nt_store = 0;          // result rows leave with the non-temporal hint (call sites whose multi-GB output is streamed once)
 };
 
 int run_gemm(vqs_handle* h, const GemmCall& g, hipStream_t st, const char* what) {
@@ -285,6 +289,9 @@ int run_gemm(vqs_handle* h, const GemmCall& g, hipStream_t st, const char* what)
     p.rowss_in = g.rowss_in; p.rowss_parts = g.rowss_parts; p.rs_invd = g.rs_invd; p.rs_eps = g.rs_eps;
     for (const vqs_handle::TileOrder& t : h->tile_orders)
         if (t.N == g.N && t.K == g.K) { p.tile_gm = t.gm; p.tile_ns = t.ns; }
+    p.nt_store = g.nt_store;
+    for (const vqs_handle::NtStore& t : h->nt_stores)
+        if (t.N == g.N && t.K == g.K && g.M >= 4096) p.nt_store = t.on == 1;      // the big launches only (the decoder shares (N, K))
     if (h->prof) {
         while (h->ev.size() < h->ev_used + 2) {
             hipEvent_t e;
@@ -441,6 +448,16 @@ int vqs_set_option(vqs_handle* h, const char* name, int32_t value) {
     else if (n == "fused_norm" && (value == 0 || value == 1)) h->fused_norm = value;
     else if (n == "norm_defer" && (value == 0 || value == 1)) h->norm_defer = value;
     else if (n == "gemm_variant" && (value == 0 || value == 2 || value == 3 || value == 5)) h->gemm_variant = value;
+    else if (n.rfind("nt_store:", 0) == 0) {
+        // "nt_store:<N>x<K>" = 1: non-temporal result stores for every GEMM of the pass with that (N, K), 2: plain stores,
+        // 0: back to the library's choice for the call site
+        int N = 0, K = 0;
+        if (std::sscanf(n.c_str() + 9, "%dx%d", &N, &K) != 2 || N <= 0 || K <= 0 || value < 0 || value > 2)
+            return fail(h, VQS_ERR_INVALID, "set_option: bad nt_store: " + n + "=" + std::to_string(value));
+        for (size_t i = 0; i < h->nt_stores.size(); ++i)
+            if (h->nt_stores[i].N == N && h->nt_stores[i].K == K) { h->nt_stores.erase(h->nt_stores.begin() + i); break; }
+        if (value != 0) h->nt_stores.push_back(vqs_handle::NtStore{N, K, value});
+    }
     else if (n.rfind("tile_order:", 0) == 0) {
         // "tile_order:<N>x<K>" = gm | ns << 8 for every GEMM of the pass with that (N, K); 0 removes the entry
         int N = 0, K = 0;

@@ -45,6 +45,7 @@ struct GemmParams {
     // workgroup -> tile order (gemm.hip tile_of_slot): M-tiles per group and number of N column ranges; 0 = default (8, 1).
     // A permutation of the tile list only -- results do not depend on it.
     int tile_gm = 0, tile_ns = 0;
+    int nt_store = 0;        // persistent kernels: result rows leave with the non-temporal hint (same bytes; a cache-policy hint)
     // EPI_RESID_RMS (producer side of the fused residual + RMSNorm)
     float* hres = nullptr;           // [M, ldh] fp32 residual stream, read-modified-written
     int ldh = 0;
@@ -124,12 +125,14 @@ VQS_HD inline void tile_of_slot(int pid, int nwg, int tiles_m, int tiles_n, int 
 
 // Tile order of a launch (see tile_of_slot): an explicit (tile_gm, tile_ns) of the caller is honoured where it is legal;
 // 0 selects the library's choice by shape.  That choice follows the working set the chip holds while it sweeps W --
-// 8 XCDs x (gm M-tiles x K) of A plus (N / ns x K) of W, in bf16 -- against the 256 MB Infinity Cache (measured, MI355X,
-// profiles/r2_call25_tile_order_*.jsonl: isolated sweeps of gm x ns per shape and an interleaved in-situ A/B, +1.0 % per XXL
-// step; 16-M-tile groups lose 10 % at every shape, the 16 x 2 window of concurrent tiles per XCD re-fetches more):
-//   * (8, 1) while the working set is <= 180 MB (every ViT and T5-XL shape but wo, T5-XXL o);
-//   * otherwise groups of 4 M-tiles (T5-XXL wi 302 -> 235 MB: +1.5 %, qkv 234 -> 167 MB: +1.5 %, T5-XL wo);
-//   * and N in two column ranges when even that leaves > 240 MB (T5-XXL wo, K = 10 240: 420 -> 210 MB, +3.6 %).
+// 8 XCDs x (gm M-tiles x K) of A plus (N / ns x K) of W, in bf16 -- against the 256 MB Infinity Cache.  Measured on two
+// MI355X boxes (profiles/r2_call25_*.jsonl, r2_call26_*.jsonl: isolated sweeps of gm x ns per shape, interleaved in-situ A/B):
+//   * (8, 1), the map of rounds 1-2, while that working set is <= 180 MB: every ViT and T5-XL shape but wo, T5-XXL o;
+//   * otherwise groups of 4 M-tiles AND two column ranges -- T5-XXL wi (302 -> 151 MB) +1.1 / +1.8 %, qkv (235 -> 117 MB)
+//     +1.5 / +2.1 %, wo (K = 10 240: 420 -> 210 MB) +3.6 / +2.9 % in isolation; +0.4 ... +1.0 % per XXL step in situ;
+//   * one column range when N has fewer than 16 tiles (T5-XL wo, N = 2 048: (4, 1) +0.6 % in situ, (4, 2) -2 %).
+//   16-M-tile groups lose 10 % at every shape (a 16 x 2 window of concurrent tiles per XCD re-fetches more), 3 / 5 / 6-tile
+//   groups and four column ranges are never better than (4, 2).
 // ns > 1 needs equal column ranges and equal per-XCD shares (no remainders), one batch entry and enough tiles for the
 // persistent grid; otherwise 1.
 inline double tile_order_working_set_mb(int N, int K, int gm, int ns) {
@@ -140,7 +143,7 @@ inline void resolve_tile_order(GemmParams& p, int persistent_wgs) {
     int gm = p.tile_gm, ns = p.tile_ns;
     if (gm <= 0 && ns <= 0 && p.batch <= 1 && tiles_m * tiles_n >= 8 * persistent_wgs) {      // the library's choice (big launches only)
         gm = tile_order_working_set_mb(p.N, p.K, 8, 1) <= 180.0 ? 8 : 4;
-        ns = (gm == 4 && tile_order_working_set_mb(p.N, p.K, 4, 1) > 240.0) ? 2 : 1;
+        ns = (gm == 4 && tiles_n / 2 >= 8) ? 2 : 1;                 // a column range holds at least one 4 x 8 window's width
     }
     if (gm <= 0) gm = 8;
     if (ns <= 0) ns = 1;

@@ -47,7 +47,7 @@ int main() {
         const int M = 155648, N = 20480, nwg = (M / 256) * (N / 256);
         std::vector<int32_t> tiles(4 * (size_t)nwg);
         assert(vqs_debug_tile_order(M, N, 4096, 1, 4, 2, 256, tiles.data()) == (4 | 2 << 8));
-        assert(vqs_debug_tile_order(M, N, 4096, 1, 0, 0, 256, tiles.data()) == (4 | 1 << 8));
+        assert(vqs_debug_tile_order(M, N, 4096, 1, 0, 0, 256, tiles.data()) == (4 | 2 << 8));
         assert(vqs_debug_tile_order(577 * 256, 1024, 1024, 1, 8, 2, 256, tiles.data()) == (8 | 1 << 8));     // 577 x 2 tiles per range: remainders -> ns = 1
         assert(vqs_debug_tile_order(M, N, 4096, 1, 4, 2, 250, tiles.data()) < 0 && vqs_debug_tile_order(0, N, 4096, 1, 4, 2, 256, tiles.data()) < 0);
     }

@@ -236,7 +236,7 @@ def test_gemm_tile_order_column_ranges_are_walked_one_after_the_other():
 
 
 @pytest.mark.parametrize("what,M,N,K,expect", [
-    ("t5-xxl wi", 155648, 20480, 4096, (4, 1)), ("t5-xxl wo", 155648, 4096, 10240, (4, 2)), ("t5-xxl qkv", 155648, 12288, 4096, (4, 1)),
+    ("t5-xxl wi", 155648, 20480, 4096, (4, 2)), ("t5-xxl wo", 155648, 4096, 10240, (4, 2)), ("t5-xxl qkv", 155648, 12288, 4096, (4, 2)),
     ("t5-xxl o", 155648, 4096, 4096, (8, 1)), ("t5-xl wi", 155648, 10240, 2048, (8, 1)), ("t5-xl wo", 155648, 2048, 5120, (4, 1)),
     ("t5-xl qkv", 155648, 6144, 2048, (8, 1)), ("vit fc1", 147712, 4096, 1024, (8, 1)), ("vit fc2", 147712, 1024, 4096, (8, 1)),
     ("genai bucket wo, S_e 648", 256 * 648, 4096, 10240, (4, 2)), ("dec wi (512 rows: small launch)", 512, 20480, 4096, (8, 1))])

@@ -135,8 +135,8 @@ def in_situ(model, configs, steps, rounds, variant_lib=None, tag="C"):
         keys |= set(o)
 
     def apply(eng, orders):
-        for k in keys:
-            eng.set_option("tile_order:%dx%d" % k, orders.get(k, 0))
+        for k in keys:                                           # (N, K) = a tile order; a string = any other option name
+            eng.set_option(k if isinstance(k, str) else "tile_order:%dx%d" % k, orders.get(k, 0))
 
     def run(eng, n):
         eng.profile(True)
@@ -202,6 +202,17 @@ def main():
         if os.path.exists(a.variant_lib):
             in_situ("clip-flant5-xl", [("product", "product", {}), ("variant " + os.path.basename(a.variant_lib), "variant", {})], steps=4, rounds=2,
                     variant_lib=a.variant_lib, tag="NX")
+    if "S" in parts:                                             # non-temporal result stores, call site by call site, in situ
+        def nt(*sites):
+            return {"nt_store:%dx%d" % s: 1 for s in sites}
+        wo, qkv, o, wi, fc2 = (4096, 10240), (12288, 4096), (4096, 4096), (20480, 4096), (1024, 4096)
+        in_situ("clip-flant5-xxl", [("plain", "product", {}), ("nt wo", "product", nt(wo)), ("nt wo+qkv", "product", nt(wo, qkv)),
+                                    ("nt wo+qkv+o", "product", nt(wo, qkv, o)), ("nt wo+qkv+o+wi", "product", nt(wo, qkv, o, wi)),
+                                    ("nt wo+qkv+fc2", "product", nt(wo, qkv, fc2))], steps=3, rounds=3, tag="S")
+        wo, qkv, o, wi = (2048, 5120), (6144, 2048), (2048, 2048), (10240, 2048)
+        in_situ("clip-flant5-xl", [("plain", "product", {}), ("nt wo", "product", nt(wo)), ("nt wo+qkv", "product", nt(wo, qkv)),
+                                   ("nt wo+qkv+o", "product", nt(wo, qkv, o)), ("nt wo+qkv+o+wi", "product", nt(wo, qkv, o, wi))],
+                steps=4, rounds=3, tag="SX")
     if "B" in parts and os.path.exists(a.attn_lib):
         attention_ab(a.attn_lib, reps=5)
     emit({"part": "done"})
