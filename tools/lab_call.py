@@ -213,6 +213,24 @@ def main():
         in_situ("clip-flant5-xl", [("plain", "product", {}), ("nt wo", "product", nt(wo)), ("nt wo+qkv", "product", nt(wo, qkv)),
                                    ("nt wo+qkv+o", "product", nt(wo, qkv, o)), ("nt wo+qkv+o+wi", "product", nt(wo, qkv, o, wi))],
                 steps=4, rounds=3, tag="SX")
+    if "V" in parts:                                             # lock-step (launcher's rule) vs forced ping-pong schedule, ViT shapes
+        g = torch.Generator(device="cuda").manual_seed(0)
+        for tag, M, N, K, epi, S, H, has_bias in VIT + [("projector.0", 147456, 4096, 1024, 2, 0, 0, True)]:
+            A = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+            W = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(torch.bfloat16)
+            bias = torch.randn(N, device="cuda", generator=g).to(torch.bfloat16)
+            out = engine.gemm(A, W, epi, bias=bias, S=S, H=H, variant=3)
+            res = {}
+            for rnd in range(2):
+                for v in (3, 5):
+                    ms = time_ms(lambda: engine.gemm(A, W, epi, bias=bias, out=out, S=S, H=H, variant=v), 7)
+                    res.setdefault("variant%d" % v, []).append(round(2.0 * M * N * K / ms / 1e9, 1))
+            emit({"part": "V", "shape": tag, "N": N, "K": K, "tflops": res})
+            del A, W, out
+    if "BX" in parts and os.path.exists(a.attn_lib):             # attention bias-in-accumulator build, in situ at XL and XXL
+        for model, steps in (("clip-flant5-xl", 4), ("clip-flant5-xxl", 3)):
+            in_situ(model, [("product", "product", {}), ("variant " + os.path.basename(a.attn_lib), "variant", {})], steps=steps, rounds=3,
+                    variant_lib=a.attn_lib, tag="BX")
     if "B" in parts and os.path.exists(a.attn_lib):
         attention_ab(a.attn_lib, reps=5)
     emit({"part": "done"})
