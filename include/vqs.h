@@ -201,6 +201,8 @@ int vqs_score_head(const float* d_logits, int32_t ldl, int32_t V, const int32_t*
  *   "gemm_variant" 3 (default) persistent kernels, 0 one tile per workgroup, 2 / 5 ping-pong schedule
  *   "tile_order:<N>x<K>"  value = gm | ns << 8: tile order (see vqs_gemm) of every GEMM of a pass whose weight is [N, K];
  *                  0 removes the entry (back to the library's choice for that shape).  Bitwise-neutral.
+ *   "l2_touch:<N>x<K>"    1: the lock-step GEMM prefetches the A panel two K-tiles ahead into L2 for the big launches whose weight is
+ *                  [N, K], 2: it does not, 0: the library's rule by shape.  A hint: bitwise-neutral.
  *   "nt_store:<N>x<K>"    1: the results of every GEMM of a pass whose weight is [N, K] are stored with the non-temporal hint,
  *                  2: plain stores, 0: the library's choice for the call site.  A cache-policy hint: bitwise-neutral.
  * Returns VQS_ERR_INVALID for an unknown name or value. */

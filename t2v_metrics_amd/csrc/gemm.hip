@@ -1243,7 +1243,8 @@ static hipError_t launch_epi(const GemmParams& p, int variant, hipStream_t strea
             // XXL wo GEMM (N = 4096, K = 10240) -- its 8-M-tile A panels (42 MB per XCD, 336 MB per chip) overflow the
             // 256 MB Infinity Cache, so the re-reads come from HBM: +1.4 % with the touch (1 231 -> 1 248 TFLOP/s, A/B r2 call 21).
             const int tm = l2_touch_mode();
-            const bool touch = tm != 0 && p.batch <= 1 && nwg >= PERSISTENT_WGS && p.K >= 4 * BK && (tm == 1 || p.N <= 2048 || (p.N <= 4096 && p.K >= 8192));
+            const bool touch_ok = tm != 0 && p.batch <= 1 && nwg >= PERSISTENT_WGS && p.K >= 4 * BK;
+            const bool touch = touch_ok && (p.l2_touch == 1 || (p.l2_touch == 0 && (tm == 1 || p.N <= 2048 || (p.N <= 4096 && p.K >= 8192))));   // l2_touch: caller's override (1 on, 2 off)
             // schedule by shape: the ViT qkv (K = 1024, 2048 < N <= 3072) is 0-1 % faster on the ping-pong schedule; with
             // the touch the lock-step kernel wins on out_proj (+7 %).  All of them produce bitwise-identical results.
             if (variant != 7 && !touch && p.K <= 1024 && p.N <= 3072 && p.batch <= 1 && nwg >= PERSISTENT_WGS)   // 7 = lock-step forced (lab)

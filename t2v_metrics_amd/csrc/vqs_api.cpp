@@ -62,7 +62,7 @@ struct vqs_handle {
     std::vector<TileOrder> tile_orders;
     // per-shape non-temporal result stores (option "nt_store:<N>x<K>" = 1 on, 2 off; absent = the library's choice)
     struct NtStore { int N, K, on; };
-    std::vector<NtStore> nt_stores;
+    std::vector<NtStore> nt_stores, l2_touches;      // l2_touches: option "l2_touch:<N>x<K>" = 1 on, 2 off
 };
 
 namespace {
@@ -290,6 +290,8 @@ int run_gemm(vqs_handle* h, const GemmCall& g, hipStream_t st, const char* what)
     for (const vqs_handle::TileOrder& t : h->tile_orders)
         if (t.N == g.N && t.K == g.K) { p.tile_gm = t.gm; p.tile_ns = t.ns; }
     p.nt_store = g.nt_store;
+    for (const vqs_handle::NtStore& t : h->l2_touches)
+        if (t.N == g.N && t.K == g.K && g.M >= 4096) p.l2_touch = t.on;
     for (const vqs_handle::NtStore& t : h->nt_stores)
         if (t.N == g.N && t.K == g.K && g.M >= 4096) p.nt_store = t.on == 1;      // the big launches only (the decoder shares (N, K))
     if (h->prof) {
@@ -448,6 +450,15 @@ int vqs_set_option(vqs_handle* h, const char* name, int32_t value) {
     else if (n == "fused_norm" && (value == 0 || value == 1)) h->fused_norm = value;
     else if (n == "norm_defer" && (value == 0 || value == 1)) h->norm_defer = value;
     else if (n == "gemm_variant" && (value == 0 || value == 2 || value == 3 || value == 5)) h->gemm_variant = value;
+    else if (n.rfind("l2_touch:", 0) == 0) {
+        // "l2_touch:<N>x<K>" = 1: A-panel L2 prefetch in the lock-step GEMM for the big launches with that (N, K), 2: off, 0: by shape
+        int N = 0, K = 0;
+        if (std::sscanf(n.c_str() + 9, "%dx%d", &N, &K) != 2 || N <= 0 || K <= 0 || value < 0 || value > 2)
+            return fail(h, VQS_ERR_INVALID, "set_option: bad l2_touch: " + n + "=" + std::to_string(value));
+        for (size_t i = 0; i < h->l2_touches.size(); ++i)
+            if (h->l2_touches[i].N == N && h->l2_touches[i].K == K) { h->l2_touches.erase(h->l2_touches.begin() + i); break; }
+        if (value != 0) h->l2_touches.push_back(vqs_handle::NtStore{N, K, value});
+    }
     else if (n.rfind("nt_store:", 0) == 0) {
         // "nt_store:<N>x<K>" = 1: non-temporal result stores for every GEMM of the pass with that (N, K), 2: plain stores,
         // 0: back to the library's choice for the call site

@@ -45,6 +45,7 @@ struct GemmParams {
     // workgroup -> tile order (gemm.hip tile_of_slot): M-tiles per group and number of N column ranges; 0 = default (8, 1).
     // A permutation of the tile list only -- results do not depend on it.
     int tile_gm = 0, tile_ns = 0;
+    int l2_touch = 0;        // lock-step persistent kernel: L2 prefetch of the A panel two K-tiles ahead; 0 = by shape (gemm.hip), 1 on, 2 off (a hint)
     int nt_store = 0;        // persistent kernels: result rows leave with the non-temporal hint (same bytes; a cache-policy hint)
     // EPI_RESID_RMS (producer side of the fused residual + RMSNorm)
     float* hres = nullptr;           // [M, ldh] fp32 residual stream, read-modified-written

@@ -213,6 +213,27 @@ def main():
         in_situ("clip-flant5-xl", [("plain", "product", {}), ("nt wo", "product", nt(wo)), ("nt wo+qkv", "product", nt(wo, qkv)),
                                    ("nt wo+qkv+o", "product", nt(wo, qkv, o)), ("nt wo+qkv+o+wi", "product", nt(wo, qkv, o, wi))],
                 steps=4, rounds=3, tag="SX")
+    if "T" in parts:                                             # yardstick: this library vs torch.matmul (hipBLASLt) on the path's shapes
+        g = torch.Generator(device="cuda").manual_seed(0)
+        for tag, M, N, K, epi, S, H, has_bias in XXL + XL + VIT:
+            A = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+            W = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(torch.bfloat16)
+            out = engine.gemm(A, W, 0, variant=3)
+            ref = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+            res = {}
+            for rnd in range(2):
+                res.setdefault("vqs_plain_epilogue", []).append(round(2.0 * M * N * K / time_ms(lambda: engine.gemm(A, W, 0, out=out, variant=3), 5) / 1e9, 1))
+                res.setdefault("torch_matmul", []).append(round(2.0 * M * N * K / time_ms(lambda: torch.matmul(A, W.t(), out=ref), 5) / 1e9, 1))
+            emit({"part": "T", "shape": tag, "M": M, "N": N, "K": K, "tflops": res,
+                  "max_abs_diff": (out.float() - ref.float()).abs().max().item()})
+            del A, W, out, ref
+            torch.cuda.empty_cache()
+    if "L" in parts:                                             # A-panel L2 prefetch under the new tile order, site by site, in situ
+        wo, qkv, o, wi = (4096, 10240), (12288, 4096), (4096, 4096), (20480, 4096)
+        def opt(pairs):
+            return {"l2_touch:%dx%d" % s: v for s, v in pairs}
+        in_situ("clip-flant5-xxl", [("rule (wo on)", "product", {}), ("wo off", "product", opt([(wo, 2)])), ("wo on + o on", "product", opt([(o, 1)])),
+                                    ("wo on + qkv on", "product", opt([(qkv, 1)])), ("wo on + wi on", "product", opt([(wi, 1)]))], steps=3, rounds=3, tag="L")
     if "V" in parts:                                             # lock-step (launcher's rule) vs forced ping-pong schedule, ViT shapes
         g = torch.Generator(device="cuda").manual_seed(0)
         for tag, M, N, K, epi, S, H, has_bias in VIT + [("projector.0", 147456, 4096, 1024, 2, 0, 0, True)]:
