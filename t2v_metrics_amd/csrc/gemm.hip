@@ -20,6 +20,7 @@
 // M and N edges are handled by clamping source rows and predicating stores; K must be a multiple of 64.
 #include "vqs_kernels.h"
 #include <cstdlib>
+#include <type_traits>
 
 // Build flavours: the shipped library holds the kernels the engine launches (variant 0 one tile per workgroup, 2 / 5
 // ping-pong, 3 persistent with its schedule chosen by shape).  -DVQS_LAB (tools/lab builds only) adds the A/B forms kept
@@ -946,6 +947,274 @@ __global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) 
 #undef PGLDS_A
 #undef PGLDS_W
 
+// =====================================================================================================
+// WIDE variant (VAR 6): the same 256x256x64 tile, LDS image, LDS-DMA staging, tile order and staged epilogue -- computed by
+// FOUR waves of 128x128 (one per SIMD, 256 fp32 accumulators per lane) instead of eight of 128x64.
+//
+// Why: the 8-wave forms move, per k-step of 16 and workgroup, 8 x (128 + 64) x 16 x 2 B = 48 KiB of fragments out of LDS plus
+// 16 KiB of LDS-DMA in -- 64 KiB = 512 cycles of the CU's 128 B/clk LDS port, exactly the 512 cycles the matrix pipes need for
+// that k-step: the main loop sits on the LDS roofline at the same time as on the MFMA one (PMC: matrix pipe busy 70 % of SIMD
+// cycles), and the vendor library runs the path's shapes ~19 % faster on identical data (profiles/r2_call30_*: 1.50 vs 1.25
+// PFLOP/s).  A 128x128 wave tile reads 4 x (128 + 128) x 16 x 2 B = 32 KiB per k-step: LDS port 75 % busy at full MFMA rate.
+// Same MFMA instruction, same operand maps, same K order per output element => bitwise the results of every other form
+// (test_gemm_wide_...).  One wave per SIMD: latency is hidden inside the wave's own stream (fragments of k-step s+1 are read
+// while the 16 MFMAs of k-step s run), not by a partner wave.
+// =====================================================================================================
+// The 256 fp32 accumulators of a lane are exactly the 256 AGPRs a one-wave-per-SIMD kernel owns.  Left to the register
+// allocator (builtin MFMAs, or "+a" operands) some accumulator tuples end up in scratch: there is no slack to colour 16
+// aligned 16-register tuples next to anything else.  So the wide kernel names its accumulators itself: accumulator IDX lives
+// in a[16 IDX : 16 IDX + 15], the MFMA / zeroing / read-back statements below are the only code that touches AGPRs, and
+// every one of them lists its registers as clobbered so the compiler keeps nothing of its own there.
+typedef uint32_t g_frag_t __attribute__((ext_vector_type(4)));
+#define VQS_ACC_CASES(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
+template <int IDX>
+__device__ __forceinline__ void mfma_fixed(const uint4& a, const uint4& b) {
+    const g_frag_t av = {a.x, a.y, a.z, a.w}, bv = {b.x, b.y, b.z, b.w};
+    if constexpr (IDX == 0) asm volatile("v_mfma_f32_32x32x16_bf16 a[0:15], %0, %1, a[0:15]" ::"v"(av), "v"(bv) : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15");
+    else if constexpr (IDX == 1) asm volatile("v_mfma_f32_32x32x16_bf16 a[16:31], %0, %1, a[16:31]" ::"v"(av), "v"(bv) : "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31");
+    else if constexpr (IDX == 2) asm volatile("v_mfma_f32_32x32x16_bf16 a[32:47], %0, %1, a[32:47]" ::"v"(av), "v"(bv) : "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47");
+    else if constexpr (IDX == 3) asm volatile("v_mfma_f32_32x32x16_bf16 a[48:63], %0, %1, a[48:63]" ::"v"(av), "v"(bv) : "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63");
+    else if constexpr (IDX == 4) asm volatile("v_mfma_f32_32x32x16_bf16 a[64:79], %0, %1, a[64:79]" ::"v"(av), "v"(bv) : "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79");
+    else if constexpr (IDX == 5) asm volatile("v_mfma_f32_32x32x16_bf16 a[80:95], %0, %1, a[80:95]" ::"v"(av), "v"(bv) : "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95");
+    else if constexpr (IDX == 6) asm volatile("v_mfma_f32_32x32x16_bf16 a[96:111], %0, %1, a[96:111]" ::"v"(av), "v"(bv) : "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111");
+    else if constexpr (IDX == 7) asm volatile("v_mfma_f32_32x32x16_bf16 a[112:127], %0, %1, a[112:127]" ::"v"(av), "v"(bv) : "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127");
+    else if constexpr (IDX == 8) asm volatile("v_mfma_f32_32x32x16_bf16 a[128:143], %0, %1, a[128:143]" ::"v"(av), "v"(bv) : "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143");
+    else if constexpr (IDX == 9) asm volatile("v_mfma_f32_32x32x16_bf16 a[144:159], %0, %1, a[144:159]" ::"v"(av), "v"(bv) : "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159");
+    else if constexpr (IDX == 10) asm volatile("v_mfma_f32_32x32x16_bf16 a[160:175], %0, %1, a[160:175]" ::"v"(av), "v"(bv) : "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175");
+    else if constexpr (IDX == 11) asm volatile("v_mfma_f32_32x32x16_bf16 a[176:191], %0, %1, a[176:191]" ::"v"(av), "v"(bv) : "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191");
+    else if constexpr (IDX == 12) asm volatile("v_mfma_f32_32x32x16_bf16 a[192:207], %0, %1, a[192:207]" ::"v"(av), "v"(bv) : "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207");
+    else if constexpr (IDX == 13) asm volatile("v_mfma_f32_32x32x16_bf16 a[208:223], %0, %1, a[208:223]" ::"v"(av), "v"(bv) : "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223");
+    else if constexpr (IDX == 14) asm volatile("v_mfma_f32_32x32x16_bf16 a[224:239], %0, %1, a[224:239]" ::"v"(av), "v"(bv) : "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239");
+    else if constexpr (IDX == 15) asm volatile("v_mfma_f32_32x32x16_bf16 a[240:255], %0, %1, a[240:255]" ::"v"(av), "v"(bv) : "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255");
+}
+__device__ __forceinline__ void acc_zero_all() {
+    asm volatile("v_accvgpr_write_b32 a0, 0\n\tv_accvgpr_write_b32 a1, 0\n\tv_accvgpr_write_b32 a2, 0\n\tv_accvgpr_write_b32 a3, 0\n\tv_accvgpr_write_b32 a4, 0\n\tv_accvgpr_write_b32 a5, 0\n\tv_accvgpr_write_b32 a6, 0\n\tv_accvgpr_write_b32 a7, 0" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7");
+    asm volatile("v_accvgpr_write_b32 a8, 0\n\tv_accvgpr_write_b32 a9, 0\n\tv_accvgpr_write_b32 a10, 0\n\tv_accvgpr_write_b32 a11, 0\n\tv_accvgpr_write_b32 a12, 0\n\tv_accvgpr_write_b32 a13, 0\n\tv_accvgpr_write_b32 a14, 0\n\tv_accvgpr_write_b32 a15, 0" ::: "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15");
+    asm volatile("v_accvgpr_write_b32 a16, 0\n\tv_accvgpr_write_b32 a17, 0\n\tv_accvgpr_write_b32 a18, 0\n\tv_accvgpr_write_b32 a19, 0\n\tv_accvgpr_write_b32 a20, 0\n\tv_accvgpr_write_b32 a21, 0\n\tv_accvgpr_write_b32 a22, 0\n\tv_accvgpr_write_b32 a23, 0" ::: "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23");
+    asm volatile("v_accvgpr_write_b32 a24, 0\n\tv_accvgpr_write_b32 a25, 0\n\tv_accvgpr_write_b32 a26, 0\n\tv_accvgpr_write_b32 a27, 0\n\tv_accvgpr_write_b32 a28, 0\n\tv_accvgpr_write_b32 a29, 0\n\tv_accvgpr_write_b32 a30, 0\n\tv_accvgpr_write_b32 a31, 0" ::: "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31");
+    asm volatile("v_accvgpr_write_b32 a32, 0\n\tv_accvgpr_write_b32 a33, 0\n\tv_accvgpr_write_b32 a34, 0\n\tv_accvgpr_write_b32 a35, 0\n\tv_accvgpr_write_b32 a36, 0\n\tv_accvgpr_write_b32 a37, 0\n\tv_accvgpr_write_b32 a38, 0\n\tv_accvgpr_write_b32 a39, 0" ::: "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39");
+    asm volatile("v_accvgpr_write_b32 a40, 0\n\tv_accvgpr_write_b32 a41, 0\n\tv_accvgpr_write_b32 a42, 0\n\tv_accvgpr_write_b32 a43, 0\n\tv_accvgpr_write_b32 a44, 0\n\tv_accvgpr_write_b32 a45, 0\n\tv_accvgpr_write_b32 a46, 0\n\tv_accvgpr_write_b32 a47, 0" ::: "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47");
+    asm volatile("v_accvgpr_write_b32 a48, 0\n\tv_accvgpr_write_b32 a49, 0\n\tv_accvgpr_write_b32 a50, 0\n\tv_accvgpr_write_b32 a51, 0\n\tv_accvgpr_write_b32 a52, 0\n\tv_accvgpr_write_b32 a53, 0\n\tv_accvgpr_write_b32 a54, 0\n\tv_accvgpr_write_b32 a55, 0" ::: "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55");
+    asm volatile("v_accvgpr_write_b32 a56, 0\n\tv_accvgpr_write_b32 a57, 0\n\tv_accvgpr_write_b32 a58, 0\n\tv_accvgpr_write_b32 a59, 0\n\tv_accvgpr_write_b32 a60, 0\n\tv_accvgpr_write_b32 a61, 0\n\tv_accvgpr_write_b32 a62, 0\n\tv_accvgpr_write_b32 a63, 0" ::: "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63");
+    asm volatile("v_accvgpr_write_b32 a64, 0\n\tv_accvgpr_write_b32 a65, 0\n\tv_accvgpr_write_b32 a66, 0\n\tv_accvgpr_write_b32 a67, 0\n\tv_accvgpr_write_b32 a68, 0\n\tv_accvgpr_write_b32 a69, 0\n\tv_accvgpr_write_b32 a70, 0\n\tv_accvgpr_write_b32 a71, 0" ::: "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71");
+    asm volatile("v_accvgpr_write_b32 a72, 0\n\tv_accvgpr_write_b32 a73, 0\n\tv_accvgpr_write_b32 a74, 0\n\tv_accvgpr_write_b32 a75, 0\n\tv_accvgpr_write_b32 a76, 0\n\tv_accvgpr_write_b32 a77, 0\n\tv_accvgpr_write_b32 a78, 0\n\tv_accvgpr_write_b32 a79, 0" ::: "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79");
+    asm volatile("v_accvgpr_write_b32 a80, 0\n\tv_accvgpr_write_b32 a81, 0\n\tv_accvgpr_write_b32 a82, 0\n\tv_accvgpr_write_b32 a83, 0\n\tv_accvgpr_write_b32 a84, 0\n\tv_accvgpr_write_b32 a85, 0\n\tv_accvgpr_write_b32 a86, 0\n\tv_accvgpr_write_b32 a87, 0" ::: "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87");
+    asm volatile("v_accvgpr_write_b32 a88, 0\n\tv_accvgpr_write_b32 a89, 0\n\tv_accvgpr_write_b32 a90, 0\n\tv_accvgpr_write_b32 a91, 0\n\tv_accvgpr_write_b32 a92, 0\n\tv_accvgpr_write_b32 a93, 0\n\tv_accvgpr_write_b32 a94, 0\n\tv_accvgpr_write_b32 a95, 0" ::: "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95");
+    asm volatile("v_accvgpr_write_b32 a96, 0\n\tv_accvgpr_write_b32 a97, 0\n\tv_accvgpr_write_b32 a98, 0\n\tv_accvgpr_write_b32 a99, 0\n\tv_accvgpr_write_b32 a100, 0\n\tv_accvgpr_write_b32 a101, 0\n\tv_accvgpr_write_b32 a102, 0\n\tv_accvgpr_write_b32 a103, 0" ::: "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103");
+    asm volatile("v_accvgpr_write_b32 a104, 0\n\tv_accvgpr_write_b32 a105, 0\n\tv_accvgpr_write_b32 a106, 0\n\tv_accvgpr_write_b32 a107, 0\n\tv_accvgpr_write_b32 a108, 0\n\tv_accvgpr_write_b32 a109, 0\n\tv_accvgpr_write_b32 a110, 0\n\tv_accvgpr_write_b32 a111, 0" ::: "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111");
+    asm volatile("v_accvgpr_write_b32 a112, 0\n\tv_accvgpr_write_b32 a113, 0\n\tv_accvgpr_write_b32 a114, 0\n\tv_accvgpr_write_b32 a115, 0\n\tv_accvgpr_write_b32 a116, 0\n\tv_accvgpr_write_b32 a117, 0\n\tv_accvgpr_write_b32 a118, 0\n\tv_accvgpr_write_b32 a119, 0" ::: "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119");
+    asm volatile("v_accvgpr_write_b32 a120, 0\n\tv_accvgpr_write_b32 a121, 0\n\tv_accvgpr_write_b32 a122, 0\n\tv_accvgpr_write_b32 a123, 0\n\tv_accvgpr_write_b32 a124, 0\n\tv_accvgpr_write_b32 a125, 0\n\tv_accvgpr_write_b32 a126, 0\n\tv_accvgpr_write_b32 a127, 0" ::: "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127");
+    asm volatile("v_accvgpr_write_b32 a128, 0\n\tv_accvgpr_write_b32 a129, 0\n\tv_accvgpr_write_b32 a130, 0\n\tv_accvgpr_write_b32 a131, 0\n\tv_accvgpr_write_b32 a132, 0\n\tv_accvgpr_write_b32 a133, 0\n\tv_accvgpr_write_b32 a134, 0\n\tv_accvgpr_write_b32 a135, 0" ::: "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135");
+    asm volatile("v_accvgpr_write_b32 a136, 0\n\tv_accvgpr_write_b32 a137, 0\n\tv_accvgpr_write_b32 a138, 0\n\tv_accvgpr_write_b32 a139, 0\n\tv_accvgpr_write_b32 a140, 0\n\tv_accvgpr_write_b32 a141, 0\n\tv_accvgpr_write_b32 a142, 0\n\tv_accvgpr_write_b32 a143, 0" ::: "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143");
+    asm volatile("v_accvgpr_write_b32 a144, 0\n\tv_accvgpr_write_b32 a145, 0\n\tv_accvgpr_write_b32 a146, 0\n\tv_accvgpr_write_b32 a147, 0\n\tv_accvgpr_write_b32 a148, 0\n\tv_accvgpr_write_b32 a149, 0\n\tv_accvgpr_write_b32 a150, 0\n\tv_accvgpr_write_b32 a151, 0" ::: "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151");
+    asm volatile("v_accvgpr_write_b32 a152, 0\n\tv_accvgpr_write_b32 a153, 0\n\tv_accvgpr_write_b32 a154, 0\n\tv_accvgpr_write_b32 a155, 0\n\tv_accvgpr_write_b32 a156, 0\n\tv_accvgpr_write_b32 a157, 0\n\tv_accvgpr_write_b32 a158, 0\n\tv_accvgpr_write_b32 a159, 0" ::: "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159");
+    asm volatile("v_accvgpr_write_b32 a160, 0\n\tv_accvgpr_write_b32 a161, 0\n\tv_accvgpr_write_b32 a162, 0\n\tv_accvgpr_write_b32 a163, 0\n\tv_accvgpr_write_b32 a164, 0\n\tv_accvgpr_write_b32 a165, 0\n\tv_accvgpr_write_b32 a166, 0\n\tv_accvgpr_write_b32 a167, 0" ::: "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167");
+    asm volatile("v_accvgpr_write_b32 a168, 0\n\tv_accvgpr_write_b32 a169, 0\n\tv_accvgpr_write_b32 a170, 0\n\tv_accvgpr_write_b32 a171, 0\n\tv_accvgpr_write_b32 a172, 0\n\tv_accvgpr_write_b32 a173, 0\n\tv_accvgpr_write_b32 a174, 0\n\tv_accvgpr_write_b32 a175, 0" ::: "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175");
+    asm volatile("v_accvgpr_write_b32 a176, 0\n\tv_accvgpr_write_b32 a177, 0\n\tv_accvgpr_write_b32 a178, 0\n\tv_accvgpr_write_b32 a179, 0\n\tv_accvgpr_write_b32 a180, 0\n\tv_accvgpr_write_b32 a181, 0\n\tv_accvgpr_write_b32 a182, 0\n\tv_accvgpr_write_b32 a183, 0" ::: "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183");
+    asm volatile("v_accvgpr_write_b32 a184, 0\n\tv_accvgpr_write_b32 a185, 0\n\tv_accvgpr_write_b32 a186, 0\n\tv_accvgpr_write_b32 a187, 0\n\tv_accvgpr_write_b32 a188, 0\n\tv_accvgpr_write_b32 a189, 0\n\tv_accvgpr_write_b32 a190, 0\n\tv_accvgpr_write_b32 a191, 0" ::: "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191");
+    asm volatile("v_accvgpr_write_b32 a192, 0\n\tv_accvgpr_write_b32 a193, 0\n\tv_accvgpr_write_b32 a194, 0\n\tv_accvgpr_write_b32 a195, 0\n\tv_accvgpr_write_b32 a196, 0\n\tv_accvgpr_write_b32 a197, 0\n\tv_accvgpr_write_b32 a198, 0\n\tv_accvgpr_write_b32 a199, 0" ::: "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199");
+    asm volatile("v_accvgpr_write_b32 a200, 0\n\tv_accvgpr_write_b32 a201, 0\n\tv_accvgpr_write_b32 a202, 0\n\tv_accvgpr_write_b32 a203, 0\n\tv_accvgpr_write_b32 a204, 0\n\tv_accvgpr_write_b32 a205, 0\n\tv_accvgpr_write_b32 a206, 0\n\tv_accvgpr_write_b32 a207, 0" ::: "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207");
+    asm volatile("v_accvgpr_write_b32 a208, 0\n\tv_accvgpr_write_b32 a209, 0\n\tv_accvgpr_write_b32 a210, 0\n\tv_accvgpr_write_b32 a211, 0\n\tv_accvgpr_write_b32 a212, 0\n\tv_accvgpr_write_b32 a213, 0\n\tv_accvgpr_write_b32 a214, 0\n\tv_accvgpr_write_b32 a215, 0" ::: "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215");
+    asm volatile("v_accvgpr_write_b32 a216, 0\n\tv_accvgpr_write_b32 a217, 0\n\tv_accvgpr_write_b32 a218, 0\n\tv_accvgpr_write_b32 a219, 0\n\tv_accvgpr_write_b32 a220, 0\n\tv_accvgpr_write_b32 a221, 0\n\tv_accvgpr_write_b32 a222, 0\n\tv_accvgpr_write_b32 a223, 0" ::: "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223");
+    asm volatile("v_accvgpr_write_b32 a224, 0\n\tv_accvgpr_write_b32 a225, 0\n\tv_accvgpr_write_b32 a226, 0\n\tv_accvgpr_write_b32 a227, 0\n\tv_accvgpr_write_b32 a228, 0\n\tv_accvgpr_write_b32 a229, 0\n\tv_accvgpr_write_b32 a230, 0\n\tv_accvgpr_write_b32 a231, 0" ::: "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231");
+    asm volatile("v_accvgpr_write_b32 a232, 0\n\tv_accvgpr_write_b32 a233, 0\n\tv_accvgpr_write_b32 a234, 0\n\tv_accvgpr_write_b32 a235, 0\n\tv_accvgpr_write_b32 a236, 0\n\tv_accvgpr_write_b32 a237, 0\n\tv_accvgpr_write_b32 a238, 0\n\tv_accvgpr_write_b32 a239, 0" ::: "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239");
+    asm volatile("v_accvgpr_write_b32 a240, 0\n\tv_accvgpr_write_b32 a241, 0\n\tv_accvgpr_write_b32 a242, 0\n\tv_accvgpr_write_b32 a243, 0\n\tv_accvgpr_write_b32 a244, 0\n\tv_accvgpr_write_b32 a245, 0\n\tv_accvgpr_write_b32 a246, 0\n\tv_accvgpr_write_b32 a247, 0" ::: "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247");
+    asm volatile("v_accvgpr_write_b32 a248, 0\n\tv_accvgpr_write_b32 a249, 0\n\tv_accvgpr_write_b32 a250, 0\n\tv_accvgpr_write_b32 a251, 0\n\tv_accvgpr_write_b32 a252, 0\n\tv_accvgpr_write_b32 a253, 0\n\tv_accvgpr_write_b32 a254, 0\n\tv_accvgpr_write_b32 a255, 0" ::: "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255");
+}
+template <int IDX>
+__device__ __forceinline__ void acc_read(f32x16& out) {
+    float t[16];
+    if constexpr (IDX == 0) asm volatile("v_accvgpr_read_b32 %0, a0\n\tv_accvgpr_read_b32 %1, a1\n\tv_accvgpr_read_b32 %2, a2\n\tv_accvgpr_read_b32 %3, a3\n\tv_accvgpr_read_b32 %4, a4\n\tv_accvgpr_read_b32 %5, a5\n\tv_accvgpr_read_b32 %6, a6\n\tv_accvgpr_read_b32 %7, a7\n\tv_accvgpr_read_b32 %8, a8\n\tv_accvgpr_read_b32 %9, a9\n\tv_accvgpr_read_b32 %10, a10\n\tv_accvgpr_read_b32 %11, a11\n\tv_accvgpr_read_b32 %12, a12\n\tv_accvgpr_read_b32 %13, a13\n\tv_accvgpr_read_b32 %14, a14\n\tv_accvgpr_read_b32 %15, a15" : "=v"(t[0]), "=v"(t[1]), "=v"(t[2]), "=v"(t[3]), "=v"(t[4]), "=v"(t[5]), "=v"(t[6]), "=v"(t[7]), "=v"(t[8]), "=v"(t[9]), "=v"(t[10]), "=v"(t[11]), "=v"(t[12]), "=v"(t[13]), "=v"(t[14]), "=v"(t[15]));
+    else if constexpr (IDX == 1) asm volatile("v_accvgpr_read_b32 %0, a16\n\tv_accvgpr_read_b32 %1, a17\n\tv_accvgpr_read_b32 %2, a18\n\tv_accvgpr_read_b32 %3, a19\n\tv_accvgpr_read_b32 %4, a20\n\tv_accvgpr_read_b32 %5, a21\n\tv_accvgpr_read_b32 %6, a22\n\tv_accvgpr_read_b32 %7, a23\n\tv_accvgpr_read_b32 %8, a24\n\tv_accvgpr_read_b32 %9, a25\n\tv_accvgpr_read_b32 %10, a26\n\tv_accvgpr_read_b32 %11, a27\n\tv_accvgpr_read_b32 %12, a28\n\tv_accvgpr_read_b32 %13, a29\n\tv_accvgpr_read_b32 %14, a30\n\tv_accvgpr_read_b32 %15, a31" : "=v"(t[0]), "=v"(t[1]), "=v"(t[2]), "=v"(t[3]), "=v"(t[4]), "=v"(t[5]), "=v"(t[6]), "=v"(t[7]), "=v"(t[8]), "=v"(t[9]), "=v"(t[10]), "=v"(t[11]), "=v"(t[12]), "=v"(t[13]), "=v"(t[14]), "=v"(t[15]));
+    else if constexpr (IDX == 2) asm volatile("v_accvgpr_read_b32 %0, a32\n\tv_accvgpr_read_b32 %1, a33\n\tv_accvgpr_read_b32 %2, a34\n\tv_accvgpr_read_b32 %3, a35\n\tv_accvgpr_read_b32 %4, a36\n\tv_accvgpr_read_b32 %5, a37\n\tv_accvgpr_read_b32 %6, a38\n\tv_accvgpr_read_b32 %7, a39\n\tv_accvgpr_read_b32 %8, a40\n\tv_accvgpr_read_b32 %9, a41\n\tv_accvgpr_read_b32 %10, a42\n\tv_accvgpr_read_b32 %11, a43\n\tv_accvgpr_read_b32 %12, a44\n\tv_accvgpr_read_b32 %13, a45\n\tv_accvgpr_read_b32 %14, a46\n\tv_accvgpr_read_b32 %15, a47" : "=v"(t[0]), "=v"(t[1]), "=v"(t[2]), "=v"(t[3]), "=v"(t[4]), "=v"(t[5]), "=v"(t[6]), "=v"(t[7]), "=v"(t[8]), "=v"(t[9]), "=v"(t[10]), "=v"(t[11]), "=v"(t[12]), "=v"(t[13]), "=v"(t[14]), "=v"(t[15]));
+    else if constexpr (IDX == 3) asm volatile("v_accvgpr_read_b32 %0, a48\n\tv_accvgpr_read_b32 %1, a49\n\tv_accvgpr_read_b32 %2, a50\n\tv_accvgpr_read_b32 %3, a51\n\tv_accvgpr_read_b32 %4, a52\n\tv_accvgpr_read_b32 %5, a53\n\tv_accvgpr_read_b32 %6, a54\n\tv_accvgpr_read_b32 %7, a55\n\tv_accvgpr_read_b32 %8, a56\n\tv_accvgpr_read_b32 %9, a57\n\tv_accvgpr_read_b32 %10, a58\n\tv_accvgpr_read_b32 %11, a59\n\tv_accvgpr_read_b32 %12, a60\n\tv_accvgpr_read_b32 %13, a61\n\tv_accvgpr_read_b32 %14, a62\n\tv_accvgpr_read_b32 %15, a63" : "=v"(t[0]), "=v"(t[1]), "=v"(t[2]), "=v"(t[3]), "=v"(t[4]), "=v"(t[5]), "=v"(t[6]), "=v"(t[7]), "=v"(t[8]), "=v"(t[9]), "=v"(t[10]), "=v"(t[11]), "=v"(t[12]), "=v"(t[13]), "=v"(t[14]), "=v"(t[15]));
+    else if constexpr (IDX == 4) asm volatile("v_accvgpr_read_b32 %0, a64\n\tv_accvgpr_read_b32 %1, a65\n\tv_accvgpr_read_b32 %2, a66\n\tv_accvgpr_read_b32 %3, a67\n\tv_accvgpr_read_b32 %4, a68\n\tv_accvgpr_read_b32 %5, a69\n\tv_accvgpr_read_b32 %6, a70\n\tv_accvgpr_read_b32 %7, a71\n\tv_accvgpr_read_b32 %8, a72\n\tv_accvgpr_read_b32 %9, a73\n\tv_accvgpr_read_b32 %10, a74\n\tv_accvgpr_read_b32 %11, a75\n\tv_accvgpr_read_b32 %12, a76\n\tv_accvgpr_read_b32 %13, a77\n\tv_accvgpr_read_b32 %14, a78\n\tv_accvgpr_read_b32 %15, a79" : "=v"(t[0]), "=v"(t[1]), "=v"(t[2]), "=v"(t[3]), "=v"(t[4]), "=v"(t[5]), "=v"(t[6]), "=v"(t[7]), "=v"(t[8]), "=v"(t[9]), "=v"(t[10]), "=v"(t[11]), "=v"(t[12]), "=v"(t[13]), "=v"(t[14]), "=v"(t[15]));
+    else if constexpr (IDX == 5) asm volatile("v_accvgpr_read_b32 %0, a80\n\tv_accvgpr_read_b32 %1, a81\n\tv_accvgpr_read_b32 %2, a82\n\tv_accvgpr_read_b32 %3, a83\n\tv_accvgpr_read_b32 %4, a84\n\tv_accvgpr_read_b32 %5, a85\n\tv_accvgpr_read_b32 %6, a86\n\tv_accvgpr_read_b32 %7, a87\n\tv_accvgpr_read_b32 %8, a88\n\tv_accvgpr_read_b32 %9, a89\n\tv_accvgpr_read_b32 %10, a90\n\tv_accvgpr_read_b32 %11, a91\n\tv_accvgpr_read_b32 %12, a92\n\tv_accvgpr_read_b32 %13, a93\n\tv_accvgpr_read_b32 %14, a94\n\tv_accvgpr_read_b32 %15, a95" : "=v"(t[0]), "=v"(t[1]), "=v"(t[2]), "=v"(t[3]), "=v"(t[4]), "=v"(t[5]), "=v"(t[6]), "=v"(t[7]), "=v"(t[8]), "=v"(t[9]), "=v"(t[10]), "=v"(t[11]), "=v"(t[12]), "=v"(t[13]), "=v"(t[14]), "=v"(t[15]));
+    else if constexpr (IDX == 6) asm volatile("v_accvgpr_read_b32 %0, a96\n\tv_accvgpr_read_b32 %1, a97\n\tv_accvgpr_read_b32 %2, a98\n\tv_accvgpr_read_b32 %3, a99\n\tv_accvgpr_read_b32 %4, a100\n\tv_accvgpr_read_b32 %5, a101\n\tv_accvgpr_read_b32 %6, a102\n\tv_accvgpr_read_b32 %7, a103\n\tv_accvgpr_read_b32 %8, a104\n\tv_accvgpr_read_b32 %9, a105\n\tv_accvgpr_read_b32 %10, a106\n\tv_accvgpr_read_b32 %11, a107\n\tv_accvgpr_read_b32 %12, a108\n\tv_accvgpr_read_b32 %13, a109\n\tv_accvgpr_read_b32 %14, a110\n\tv_accvgpr_read_b32 %15, a111" : "=v"(t[0]), "=v"(t[1]), "=v"(t[2]), "=v"(t[3]), "=v"(t[4]), "=v"(t[5]), "=v"(t[6]), "=v"(t[7]), "=v"(t[8]), "=v"(t[9]), "=v"(t[10]), "=v"(t[11]), "=v"(t[12]), "=v"(t[13]), "=v"(t[14]), "=v"(t[15]));
+    else if constexpr (IDX == 7) asm volatile("v_accvgpr_read_b32 %0, a112\n\tv_accvgpr_read_b32 %1, a113\n\tv_accvgpr_read_b32 %2, a114\n\tv_accvgpr_read_b32 %3, a115\n\tv_accvgpr_read_b32 %4, a116\n\tv_accvgpr_read_b32 %5, a117\n\tv_accvgpr_read_b32 %6, a118\n\tv_accvgpr_read_b32 %7, a119\n\tv_accvgpr_read_b32 %8, a120\n\tv_accvgpr_read_b32 %9, a121\n\tv_accvgpr_read_b32 %10, a122\n\tv_accvgpr_read_b32 %11, a123\n\tv_accvgpr_read_b32 %12, a124\n\tv_accvgpr_read_b32 %13, a125\n\tv_accvgpr_read_b32 %14, a126\n\tv_accvgpr_read_b32 %15, a127" : "=v"(t[0]), "=v"(t[1]), "=v"(t[2]), "=v"(t[3]), "=v"(t[4]), "=v"(t[5]), "=v"(t[6]), "=v"(t[7]), "=v"(t[8]), "=v"(t[9]), "=v"(t[10]), "=v"(t[11]), "=v"(t[12]), "=v"(t[13]), "=v"(t[14]), "=v"(t[15]));
+    else if constexpr (IDX == 8) asm volatile("v_accvgpr_read_b32 %0, a128\n\tv_accvgpr_read_b32 %1, a129\n\tv_accvgpr_read_b32 %2, a130\n\tv_accvgpr_read_b32 %3, a131\n\tv_accvgpr_read_b32 %4, a132\n\tv_accvgpr_read_b32 %5, a133\n\tv_accvgpr_read_b32 %6, a134\n\tv_accvgpr_read_b32 %7, a135\n\tv_accvgpr_read_b32 %8, a136\n\tv_accvgpr_read_b32 %9, a137\n\tv_accvgpr_read_b32 %10, a138\n\tv_accvgpr_read_b32 %11, a139\n\tv_accvgpr_read_b32 %12, a140\n\tv_accvgpr_read_b32 %13, a141\n\tv_accvgpr_read_b32 %14, a142\n\tv_accvgpr_read_b32 %15, a143" : "=v"(t[0]), "=v"(t[1]), "=v"(t[2]), "=v"(t[3]), "=v"(t[4]), "=v"(t[5]), "=v"(t[6]), "=v"(t[7]), "=v"(t[8]), "=v"(t[9]), "=v"(t[10]), "=v"(t[11]), "=v"(t[12]), "=v"(t[13]), "=v"(t[14]), "=v"(t[15]));
+    else if constexpr (IDX == 9) asm volatile("v_accvgpr_read_b32 %0, a144\n\tv_accvgpr_read_b32 %1, a145\n\tv_accvgpr_read_b32 %2, a146\n\tv_accvgpr_read_b32 %3, a147\n\tv_accvgpr_read_b32 %4, a148\n\tv_accvgpr_read_b32 %5, a149\n\tv_accvgpr_read_b32 %6, a150\n\tv_accvgpr_read_b32 %7, a151\n\tv_accvgpr_read_b32 %8, a152\n\tv_accvgpr_read_b32 %9, a153\n\tv_accvgpr_read_b32 %10, a154\n\tv_accvgpr_read_b32 %11, a155\n\tv_accvgpr_read_b32 %12, a156\n\tv_accvgpr_read_b32 %13, a157\n\tv_accvgpr_read_b32 %14, a158\n\tv_accvgpr_read_b32 %15, a159" : "=v"(t[0]), "=v"(t[1]), "=v"(t[2]), "=v"(t[3]), "=v"(t[4]), "=v"(t[5]), "=v"(t[6]), "=v"(t[7]), "=v"(t[8]), "=v"(t[9]), "=v"(t[10]), "=v"(t[11]), "=v"(t[12]), "=v"(t[13]), "=v"(t[14]), "=v"(t[15]));
+    else if constexpr (IDX == 10) asm volatile("v_accvgpr_read_b32 %0, a160\n\tv_accvgpr_read_b32 %1, a161\n\tv_accvgpr_read_b32 %2, a162\n\tv_accvgpr_read_b32 %3, a163\n\tv_accvgpr_read_b32 %4, a164\n\tv_accvgpr_read_b32 %5, a165\n\tv_accvgpr_read_b32 %6, a166\n\tv_accvgpr_read_b32 %7, a167\n\tv_accvgpr_read_b32 %8, a168\n\tv_accvgpr_read_b32 %9, a169\n\tv_accvgpr_read_b32 %10, a170\n\tv_accvgpr_read_b32 %11, a171\n\tv_accvgpr_read_b32 %12, a172\n\tv_accvgpr_read_b32 %13, a173\n\tv_accvgpr_read_b32 %14, a174\n\tv_accvgpr_read_b32 %15, a175" : "=v"(t[0]), "=v"(t[1]), "=v"(t[2]), "=v"(t[3]), "=v"(t[4]), "=v"(t[5]), "=v"(t[6]), "=v"(t[7]), "=v"(t[8]), "=v"(t[9]), "=v"(t[10]), "=v"(t[11]), "=v"(t[12]), "=v"(t[13]), "=v"(t[14]), "=v"(t[15]));
+    else if constexpr (IDX == 11) asm volatile("v_accvgpr_read_b32 %0, a176\n\tv_accvgpr_read_b32 %1, a177\n\tv_accvgpr_read_b32 %2, a178\n\tv_accvgpr_read_b32 %3, a179\n\tv_accvgpr_read_b32 %4, a180\n\tv_accvgpr_read_b32 %5, a181\n\tv_accvgpr_read_b32 %6, a182\n\tv_accvgpr_read_b32 %7, a183\n\tv_accvgpr_read_b32 %8, a184\n\tv_accvgpr_read_b32 %9, a185\n\tv_accvgpr_read_b32 %10, a186\n\tv_accvgpr_read_b32 %11, a187\n\tv_accvgpr_read_b32 %12, a188\n\tv_accvgpr_read_b32 %13, a189\n\tv_accvgpr_read_b32 %14, a190\n\tv_accvgpr_read_b32 %15, a191" : "=v"(t[0]), "=v"(t[1]), "=v"(t[2]), "=v"(t[3]), "=v"(t[4]), "=v"(t[5]), "=v"(t[6]), "=v"(t[7]), "=v"(t[8]), "=v"(t[9]), "=v"(t[10]), "=v"(t[11]), "=v"(t[12]), "=v"(t[13]), "=v"(t[14]), "=v"(t[15]));
+    else if constexpr (IDX == 12) asm volatile("v_accvgpr_read_b32 %0, a192\n\tv_accvgpr_read_b32 %1, a193\n\tv_accvgpr_read_b32 %2, a194\n\tv_accvgpr_read_b32 %3, a195\n\tv_accvgpr_read_b32 %4, a196\n\tv_accvgpr_read_b32 %5, a197\n\tv_accvgpr_read_b32 %6, a198\n\tv_accvgpr_read_b32 %7, a199\n\tv_accvgpr_read_b32 %8, a200\n\tv_accvgpr_read_b32 %9, a201\n\tv_accvgpr_read_b32 %10, a202\n\tv_accvgpr_read_b32 %11, a203\n\tv_accvgpr_read_b32 %12, a204\n\tv_accvgpr_read_b32 %13, a205\n\tv_accvgpr_read_b32 %14, a206\n\tv_accvgpr_read_b32 %15, a207" : "=v"(t[0]), "=v"(t[1]), "=v"(t[2]), "=v"(t[3]), "=v"(t[4]), "=v"(t[5]), "=v"(t[6]), "=v"(t[7]), "=v"(t[8]), "=v"(t[9]), "=v"(t[10]), "=v"(t[11]), "=v"(t[12]), "=v"(t[13]), "=v"(t[14]), "=v"(t[15]));
+    else if constexpr (IDX == 13) asm volatile("v_accvgpr_read_b32 %0, a208\n\tv_accvgpr_read_b32 %1, a209\n\tv_accvgpr_read_b32 %2, a210\n\tv_accvgpr_read_b32 %3, a211\n\tv_accvgpr_read_b32 %4, a212\n\tv_accvgpr_read_b32 %5, a213\n\tv_accvgpr_read_b32 %6, a214\n\tv_accvgpr_read_b32 %7, a215\n\tv_accvgpr_read_b32 %8, a216\n\tv_accvgpr_read_b32 %9, a217\n\tv_accvgpr_read_b32 %10, a218\n\tv_accvgpr_read_b32 %11, a219\n\tv_accvgpr_read_b32 %12, a220\n\tv_accvgpr_read_b32 %13, a221\n\tv_accvgpr_read_b32 %14, a222\n\tv_accvgpr_read_b32 %15, a223" : "=v"(t[0]), "=v"(t[1]), "=v"(t[2]), "=v"(t[3]), "=v"(t[4]), "=v"(t[5]), "=v"(t[6]), "=v"(t[7]), "=v"(t[8]), "=v"(t[9]), "=v"(t[10]), "=v"(t[11]), "=v"(t[12]), "=v"(t[13]), "=v"(t[14]), "=v"(t[15]));
+    else if constexpr (IDX == 14) asm volatile("v_accvgpr_read_b32 %0, a224\n\tv_accvgpr_read_b32 %1, a225\n\tv_accvgpr_read_b32 %2, a226\n\tv_accvgpr_read_b32 %3, a227\n\tv_accvgpr_read_b32 %4, a228\n\tv_accvgpr_read_b32 %5, a229\n\tv_accvgpr_read_b32 %6, a230\n\tv_accvgpr_read_b32 %7, a231\n\tv_accvgpr_read_b32 %8, a232\n\tv_accvgpr_read_b32 %9, a233\n\tv_accvgpr_read_b32 %10, a234\n\tv_accvgpr_read_b32 %11, a235\n\tv_accvgpr_read_b32 %12, a236\n\tv_accvgpr_read_b32 %13, a237\n\tv_accvgpr_read_b32 %14, a238\n\tv_accvgpr_read_b32 %15, a239" : "=v"(t[0]), "=v"(t[1]), "=v"(t[2]), "=v"(t[3]), "=v"(t[4]), "=v"(t[5]), "=v"(t[6]), "=v"(t[7]), "=v"(t[8]), "=v"(t[9]), "=v"(t[10]), "=v"(t[11]), "=v"(t[12]), "=v"(t[13]), "=v"(t[14]), "=v"(t[15]));
+    else if constexpr (IDX == 15) asm volatile("v_accvgpr_read_b32 %0, a240\n\tv_accvgpr_read_b32 %1, a241\n\tv_accvgpr_read_b32 %2, a242\n\tv_accvgpr_read_b32 %3, a243\n\tv_accvgpr_read_b32 %4, a244\n\tv_accvgpr_read_b32 %5, a245\n\tv_accvgpr_read_b32 %6, a246\n\tv_accvgpr_read_b32 %7, a247\n\tv_accvgpr_read_b32 %8, a248\n\tv_accvgpr_read_b32 %9, a249\n\tv_accvgpr_read_b32 %10, a250\n\tv_accvgpr_read_b32 %11, a251\n\tv_accvgpr_read_b32 %12, a252\n\tv_accvgpr_read_b32 %13, a253\n\tv_accvgpr_read_b32 %14, a254\n\tv_accvgpr_read_b32 %15, a255" : "=v"(t[0]), "=v"(t[1]), "=v"(t[2]), "=v"(t[3]), "=v"(t[4]), "=v"(t[5]), "=v"(t[6]), "=v"(t[7]), "=v"(t[8]), "=v"(t[9]), "=v"(t[10]), "=v"(t[11]), "=v"(t[12]), "=v"(t[13]), "=v"(t[14]), "=v"(t[15]));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[r] = t[r];
+}
+
+template <int EPI>
+__global__ void __launch_bounds__(256) gemm_bf16_wide(const GemmParams p) {
+    static_assert(EPI != EPI_RESID_RMS && EPI != EPI_F32_RESID && EPI != EPI_F32, "not carried by the wide form (fp32 results: lm_head and split-K partials, small launches)");
+    __shared__ __attribute__((aligned(16))) char lds[2 * STAGE_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // 0..3, one wave per SIMD
+    const int wr = w >> 1, wc = w & 1;
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    const int nbatch = p.batch > 0 ? p.batch : 1;
+    const int nwg = tiles_m * tiles_n * nbatch;
+    const int nt = p.K / BK;
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)LDS_PTR(lds));
+
+    auto tile_coords = [&](int pid, int& m0, int& n0, int& bz) {
+        tile_of_slot(pid, nwg, tiles_m, tiles_n, p.tile_gm, p.tile_ns, m0, n0, bz);
+    };
+
+    // staging: piece q (8 rows x 128 B = 1 KiB) of the A / W image, q = 4 i + w, i = 0..7; (row >> 1) & 7 of the row a lane stages
+    // = ((q & 1) << 2) + (lane >> 4) = ((w & 1) << 2) + (lane >> 4), as in the 8-wave forms.  Byte offsets in 32 bits (every
+    // operand of a batch entry is < 4 GiB): sixteen VGPRs of loop-carried state, not sixteen 64-bit pairs.
+    const int sw = ((w & 1) << 2) + (lane >> 4);
+    const uint32_t gchunk_b = (uint32_t)(((lane & 7) ^ sw) << 4);
+    const uint32_t lda_b = (uint32_t)p.lda * 2u, ldw_b = (uint32_t)p.ldw * 2u;
+    uint32_t pa[8], pb[8];
+    v4i_t rsA, rsW;
+    auto set_ptrs = [&](int m0, int n0, int bz) {
+        rsA = make_rsrc(p.A + (size_t)bz * p.sA);
+        rsW = make_rsrc(p.W + (size_t)bz * p.sW);
+        const int r0 = w * 8 + (lane >> 3);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            pa[i] = (uint32_t)min(m0 + r0 + i * 32, p.M - 1) * lda_b + gchunk_b;
+            pb[i] = (uint32_t)min(n0 + r0 + i * 32, p.N - 1) * ldw_b + gchunk_b;
+        }
+    };
+    auto stage_all = [&](int s, int t) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t da = lds_base + s * STAGE_BYTES + (i * 4 + w) * 1024;
+            bglds16(rsA, pa[i], (uint32_t)(t * BK * 2), da);
+            bglds16(rsW, pb[i], (uint32_t)(t * BK * 2), da + W_OFF);
+        }
+    };
+
+    const int swr = (lane >> 1) & 7;
+    int koff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) koff[ks] = (((ks * 2 + (lane >> 5)) ^ swr) << 4);
+    const int a_row = (wr * 128 + (lane & 31)) * 128;
+    const int b_row = W_OFF + (wc * 128 + (lane & 31)) * 128;
+
+    int pid = blockIdx.x;
+    if (pid >= nwg) return;
+    int m0, n0, bz;
+    tile_coords(pid, m0, n0, bz);
+    set_ptrs(m0, n0, bz);
+    stage_all(0, 0);
+    int buf = 0;
+    bool counted = false;     // true: the only VMEM ops younger than the prefetched K-tile are a full epilogue's stores
+
+    while (true) {
+        // accumulator (half, m, n) = columns n0 + wc*128 + half*64 + n*32 ..., rows m0 + wr*128 + m*32 ... lives in AGPR tuple
+        // (half*4 + m)*2 + n (see mfma_fixed)
+        acc_zero_all();
+
+        const int next_pid = pid + gridDim.x;
+        const bool has_next = next_pid < nwg;
+        int nm0 = 0, nn0 = 0, nbz = 0;
+
+        // One K-tile = 4 k-steps of 8 fragment reads (ds_read_b128) + 16 MFMAs, software-pipelined by hand over two fragment
+        // register sets: the reads of k-step s+1 are issued BEFORE the MFMAs of k-step s (the MFMA statements are opaque to the
+        // scheduler, so the order below is the order in the binary; sched_barrier keeps the reads from sinking to their use).
+        // The K-tile boundary (wait for the own DMA pieces, barrier, first fragment reads of the next K-tile from the other
+        // stage) sits in the MIDDLE of the last k-step, in front of its last 8 MFMAs, so the LDS latency of those reads runs
+        // under 256 cycles of matrix work instead of an idle pipe.  STAGE: the sixteen LDS-DMA pieces of the next K-tile go out
+        // in the first two k-steps, two per row block of MFMAs.  LAST: last K-tile of an output tile (the epilogue follows; the
+        // next tile's first reads are issued after it).  Both compile-time: no branch between MFMA groups.
+        uint4 fa[2][4], fw[2][4];
+        auto read_frags = [&](int set, const char* sbase, int ks) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) fa[set][m] = *reinterpret_cast<const uint4*>(sbase + a_row + m * 4096 + koff[ks]);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) fw[set][n] = *reinterpret_cast<const uint4*>(sbase + b_row + n * 4096 + koff[ks]);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+#define VQS_ROWBLOCK(SET, M, DMA_I)                                                    \
+    mfma_fixed<(0 * 4 + (M)) * 2 + 0>(fw[SET][0], fa[SET][M]);                         \
+    mfma_fixed<(0 * 4 + (M)) * 2 + 1>(fw[SET][1], fa[SET][M]);                         \
+    mfma_fixed<(1 * 4 + (M)) * 2 + 0>(fw[SET][2], fa[SET][M]);                         \
+    mfma_fixed<(1 * 4 + (M)) * 2 + 1>(fw[SET][3], fa[SET][M]);                         \
+    if (STAGE && (DMA_I) >= 0) {                                                       \
+        bglds16(rsA, pa[(DMA_I) & 7], koffs2, dst0 + ((DMA_I) & 7) * 4096);            \
+        bglds16(rsW, pb[(DMA_I) & 7], koffs2, dst0 + ((DMA_I) & 7) * 4096 + W_OFF);    \
+    }
+        auto ktile = [&](auto stage_tag, auto last_tag, uint32_t koffs2) {
+            constexpr bool STAGE = decltype(stage_tag)::value;
+            constexpr bool LAST = decltype(last_tag)::value;
+            const uint32_t dst0 = lds_base + (buf ^ 1) * STAGE_BYTES + w * 1024;
+            const char* sb = lds + buf * STAGE_BYTES;
+            const char* sn = lds + (buf ^ 1) * STAGE_BYTES;
+            read_frags(1, sb, 1);
+            VQS_ROWBLOCK(0, 0, 0) VQS_ROWBLOCK(0, 1, 1) VQS_ROWBLOCK(0, 2, 2) VQS_ROWBLOCK(0, 3, 3)
+            read_frags(0, sb, 2);
+            VQS_ROWBLOCK(1, 0, 4) VQS_ROWBLOCK(1, 1, 5) VQS_ROWBLOCK(1, 2, 6) VQS_ROWBLOCK(1, 3, 7)
+            read_frags(1, sb, 3);
+            VQS_ROWBLOCK(0, 0, -1) VQS_ROWBLOCK(0, 1, -1) VQS_ROWBLOCK(0, 2, -1) VQS_ROWBLOCK(0, 3, -1)
+            VQS_ROWBLOCK(1, 0, -1) VQS_ROWBLOCK(1, 1, -1)
+            if (!LAST) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own pieces of the next K-tile (issued >= 2 k-steps ago)
+                __builtin_amdgcn_s_barrier();                      // everybody's; and nobody reads stage `buf` any more
+                read_frags(0, sn, 0);
+            }
+            VQS_ROWBLOCK(1, 2, -1) VQS_ROWBLOCK(1, 3, -1)
+            buf ^= 1;
+        };
+
+        // top of an output tile: the prefetched first K-tile has landed (behind a counted epilogue: all but its stores)
+        if (counted) {
+            constexpr int NST = 2 * EpiStores<EPI>::value;       // two 64-column halves per wave
+            if constexpr (NST == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if constexpr (NST == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(63)" ::: "memory");   // the counter has 6 bits: 63 = "at most all but one store"
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        read_frags(0, lds + buf * STAGE_BYTES, 0);
+
+        for (int t = 0; t < nt; ++t) {
+            if (t + 1 < nt) {
+                ktile(std::true_type{}, std::false_type{}, (uint32_t)((t + 1) * BK * 2));
+            } else if (has_next) {
+                tile_coords(next_pid, nm0, nn0, nbz);
+                set_ptrs(nm0, nn0, nbz);
+                ktile(std::true_type{}, std::true_type{}, 0u);
+            } else {
+                ktile(std::false_type{}, std::true_type{}, 0u);
+            }
+        }
+#undef VQS_ROWBLOCK
+
+        const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
+        // the MFMAs are opaque to the compiler's hazard recogniser: 18 wait states between the last one and the first
+        // v_accvgpr_read of its result (16-pass XDL write -> VALU read)
+        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+        __builtin_amdgcn_s_barrier();                       // every wave is done reading stage buf^1
+        char* reg = lds + (buf ^ 1) * STAGE_BYTES + w * 16384;
+        {
+            f32x16 c[4][2];
+            acc_read<0>(c[0][0]); acc_read<1>(c[0][1]); acc_read<2>(c[1][0]); acc_read<3>(c[1][1]);
+            acc_read<4>(c[2][0]); acc_read<5>(c[2][1]); acc_read<6>(c[3][0]); acc_read<7>(c[3][1]);
+            staged_epilogue<EPI>(p, c, reg, m0, n0, bz, wr, 2 * wc, lane, full, nullptr);
+        }
+        {
+            f32x16 c[4][2];
+            acc_read<8>(c[0][0]); acc_read<9>(c[0][1]); acc_read<10>(c[1][0]); acc_read<11>(c[1][1]);
+            acc_read<12>(c[2][0]); acc_read<13>(c[2][1]); acc_read<14>(c[3][0]); acc_read<15>(c[3][1]);
+            staged_epilogue<EPI>(p, c, reg + 8192, m0, n0, bz, wr, 2 * wc + 1, lane, full, nullptr);
+        }
+        counted = full;
+        if (!has_next) break;
+        pid = next_pid;
+        m0 = nm0;
+        n0 = nn0;
+        bz = nbz;
+    }
+}
+
+
 #ifdef VQS_LAB
 #include "lab/gemm_ws.inc"
 #endif
@@ -1215,7 +1484,11 @@ static hipError_t launch_epi(const GemmParams& p, int variant, hipStream_t strea
 #endif
     else if (variant == 2)
         hipLaunchKernelGGL((gemm_bf16_kernel<EPI, 2>), grid, block, 0, stream, p);
-    else if (variant == 5 && EPI != EPI_F32_RESID) {
+    else if (variant == 6 && EPI != EPI_F32_RESID && EPI != EPI_F32 && p.batch <= 1 && tiles_m * tiles_n >= PERSISTENT_WGS) {
+        // wide form: bf16-result epilogues of the big launches; everything else of a variant-6 pass runs the default forms below
+        if constexpr (EPI != EPI_F32_RESID && EPI != EPI_F32)
+            hipLaunchKernelGGL((gemm_bf16_wide<EPI>), dim3(PERSISTENT_WGS), dim3(256), 0, stream, p);
+    } else if (variant == 5 && EPI != EPI_F32_RESID) {
         if constexpr (EPI != EPI_F32_RESID) {
             const int nwg = tiles_m * tiles_n * (p.batch > 0 ? p.batch : 1);
             dim3 pgrid(nwg < PERSISTENT_WGS ? nwg : PERSISTENT_WGS);
@@ -1270,12 +1543,12 @@ hipError_t launch_gemm(const GemmParams& p_in, int epilogue, int variant, hipStr
     // N: a lane stores 4 consecutive columns; fp32 output may have a ragged N if ldc leaves room for the overhang
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K % BK) != 0) return hipErrorInvalidValue;
     if ((p.N % 8) != 0 && !(epilogue == EPI_F32 && p.ldc >= ((p.N + 3) & ~3) && p.bias == nullptr)) return hipErrorInvalidValue;
-    if (p.batch > 1 && ((variant != 3 && variant != 4 && variant != 5 && variant != 7) || epilogue == EPI_HEADS || epilogue == EPI_F32_RESID)) return hipErrorInvalidValue;
+    if (p.batch > 1 && ((variant != 3 && variant != 4 && variant != 5 && variant != 6 && variant != 7) || epilogue == EPI_HEADS || epilogue == EPI_F32_RESID)) return hipErrorInvalidValue;
     if ((p.lda % 8) != 0 || (p.ldw % 8) != 0) return hipErrorInvalidValue;
     if ((p.hd > 64 || p.inner_kv > 0 || p.Hkv > 0 || p.gate_act != 0 || (epilogue == EPI_GATED && p.bias != nullptr)) &&
-        variant != 3 && variant != 5 && variant != 7)
+        variant != 3 && variant != 5 && variant != 6 && variant != 7)
         return hipErrorInvalidValue;   // generalised HEADS / GATED epilogues live in the persistent kernels only
-    if (p.rowss_in != nullptr && (p.rowss_parts < 0 || (variant != 3 && variant != 5 && variant != 7) || epilogue == EPI_F32_RESID))
+    if (p.rowss_in != nullptr && (p.rowss_parts < 0 || (variant != 3 && variant != 5 && variant != 6 && variant != 7) || epilogue == EPI_F32_RESID))
         return hipErrorInvalidValue;   // the row scale lives in the persistent kernels' staged epilogue only
     switch (epilogue) {
         case EPI_BF16: return launch_epi<EPI_BF16>(p, variant, stream);

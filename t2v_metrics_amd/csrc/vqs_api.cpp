@@ -449,7 +449,7 @@ int vqs_set_option(vqs_handle* h, const char* name, int32_t value) {
     else if (n == "splitk" && (value == 0 || value == 1)) h->splitk = value;
     else if (n == "fused_norm" && (value == 0 || value == 1)) h->fused_norm = value;
     else if (n == "norm_defer" && (value == 0 || value == 1)) h->norm_defer = value;
-    else if (n == "gemm_variant" && (value == 0 || value == 2 || value == 3 || value == 5)) h->gemm_variant = value;
+    else if (n == "gemm_variant" && (value == 0 || value == 2 || value == 3 || value == 5 || value == 6)) h->gemm_variant = value;
     else if (n.rfind("l2_touch:", 0) == 0) {
         // "l2_touch:<N>x<K>" = 1: A-panel L2 prefetch in the lock-step GEMM for the big launches with that (N, K), 2: off, 0: by shape
         int N = 0, K = 0;
@@ -734,7 +734,7 @@ static int encoder_pass(vqs_handle* h, const ScoreWs& w, const void* d_feats, co
     // the consuming qkv / wi GEMM scales its accumulator rows by 1/rms.  Bit-exact repeatable and parity-tested, but the
     // read-modify-write epilogue costs the producer GEMMs +0.55 ms per launch against 0.64 ms for the norm kernel it
     // removes (+1 % end to end, and it lowers the GEMM's own roofline fraction): kept as a lab path.
-    const bool fused = h->fused_norm != 0 && (h->gemm_variant == 3 || h->gemm_variant == 5 || h->gemm_variant == 7);
+    const bool fused = h->fused_norm != 0 && (h->gemm_variant == 3 || h->gemm_variant == 5 || h->gemm_variant == 7);   // not the wide form (6)
     const int parts = (D + 255) / 256;
     bool scaled = false;          // w.xn holds an un-normalised operand whose row sums are in w.rowss
     const bf16_t* pend = nullptr;

@@ -43,7 +43,8 @@ def _kernels(src):
             return int(re.search(r"\.%s:\s+(\d+)" % name, entry).group(1))
         out[re.search(r"\.name:\s+(\S+)", entry).group(1)] = {
             "lds": field("group_segment_fixed_size"), "scratch": field("private_segment_fixed_size"),
-            "vgpr": field("vgpr_count"), "vgpr_spill": field("vgpr_spill_count"), "wg": field("max_flat_workgroup_size")}
+            "vgpr": field("vgpr_count"), "vgpr_spill": field("vgpr_spill_count"), "wg": field("max_flat_workgroup_size"),
+            "agpr": int(entry.split()[0])}
     assert out, "no kernel metadata found in " + asm
     return out
 
@@ -82,12 +83,21 @@ def test_attention_lds_budget_keeps_its_occupancy():
 
 
 def test_gemm_kernels_own_the_cu():
-    """One 512-thread GEMM workgroup per CU by construction: two 64-KiB stages (+ the 2-KiB touch sink / row-reduction
-    scratch of the variants that have one) leave no room for a second, and the persistent grid is sized for that."""
+    """One GEMM workgroup per CU by construction: two 64-KiB stages (+ the 2-KiB touch sink / row-reduction scratch of the
+    variants that have one) leave no room for a second, and the persistent grid is sized for that.  The 8-wave forms are
+    512 threads (two waves per SIMD, <= 256 registers per lane); the wide form is 256 threads -- ONE wave per SIMD, whose 256
+    fp32 accumulators per lane are the whole AGPR file (hand-allocated, gemm.hip mfma_fixed) next to <= 256 VGPRs."""
+    wide = 0
     for name, k in _kernels("gemm.hip").items():
         if "gemm_bf16" in name:
             assert 2 * 65536 <= k["lds"] <= 2 * 65536 + 8192, (name, k)
-            assert _resident(k["lds"], 0) == 1 and k["wg"] == 512 or "gemm_bf16_ws" in name, (name, k)
+            assert _resident(k["lds"], 0) == 1, (name, k)
+            if "gemm_bf16_wide" in name:
+                wide += 1
+                assert k["wg"] == 256 and k["agpr"] == 256 and k["vgpr"] <= 512, (name, k)
+            else:
+                assert k["wg"] == 512 or "gemm_bf16_ws" in name, (name, k)
+    assert wide == 5, "wide form: epilogues bf16, quick_gelu, erf-GELU, gated, head-major"
 
 
 def test_shipped_library_has_no_lab_code_and_reads_no_environment():

@@ -60,7 +60,7 @@ def test_gemm_persistent_many_tiles(eng, M, N, K, epi):
     bias = randn_bf16(N, seed=33)
     resid = torch.randn(M, N, device="cuda", generator=torch.Generator(device="cuda").manual_seed(34)) if epi == 4 else None
     ref = eng.gemm(A, W, epi, bias=bias, resid=resid, variant=0)
-    for variant in (3, 5):
+    for variant in (3, 5, 6):          # 6 = the four-wave 128x128 form (fp32-result epilogues run the default form under it)
         for _ in range(3):
             out = eng.gemm(A, W, epi, bias=bias, resid=resid, variant=variant)
             assert torch.equal(out, ref), describe(out, ref)
@@ -81,10 +81,38 @@ def test_gemm_tile_order_is_bitwise_neutral(eng, M, N, K, epi, S, H):
     A = randn_bf16(M, K, seed=61)
     W = randn_bf16(N, K, seed=62, scale=K ** -0.5)
     ref = eng.gemm(A, W, epi, S=S, H=H, variant=0)
-    for variant in (3, 5, 0):
+    for variant in (3, 5, 6, 0):
         for order in ((8, 1), (4, 1), (2, 1), (1, 1), (16, 1), (3, 1), (8, 2), (4, 2), (2, 4), (64, 4)):
             out = eng.gemm(A, W, epi, S=S, H=H, variant=variant, tile_order=order)
             assert torch.equal(out, ref), (variant, order, describe(out, ref))
+
+
+@pytest.mark.parametrize("M,N,K,epi,S,H", [
+    (33000, 2048, 64, 0, 0, 0),            # one K-tile per output tile: every K-tile is a tile's first AND last
+    (33000 - 7, 2048 - 8, 128, 0, 0, 0),   # ragged M and N edges in the middle of a workgroup's run
+    (20000, 4096, 1024, 1, 0, 0),          # quick_gelu + bias (ViT fc1)
+    (147456 // 4, 2048, 1024, 2, 0, 0),    # erf-GELU + bias (projector)
+    (16384, 8192, 256, 5, 0, 0),           # gated gelu_new over interleaved wi_0 / wi_1 blocks
+    (608 * 40, 3 * 1024, 192, 6, 608, 16), # head-major scatter, sample boundaries inside tiles
+    (577 * 64, 3 * 1024, 128, 6, 577, 16), # ... with the ViT's odd sequence length
+    (131072, 512, 2048, 0, 0, 0)])         # long K, many tiles per workgroup
+def test_gemm_wide_form_is_bitwise_the_other_forms(eng, M, N, K, epi, S, H):
+    """gemm_bf16_wide (variant 6): the same 256x256x64 tiles computed by four waves of 128x128 with the accumulators in
+    hand-allocated AGPRs and a hand-pipelined K loop.  Same MFMA instruction, operand maps and K order per output element:
+    bit for bit the one-tile-per-workgroup kernel (variant 0) and the 8-wave persistent kernel, on every epilogue it
+    carries, with ragged edges, repeated (no dependence on what the previous launch left in LDS / registers)."""
+    A = randn_bf16(M, K, seed=71)
+    W = randn_bf16(N, K, seed=72, scale=K ** -0.5)
+    bias = randn_bf16(N, seed=73) if epi in (0, 1, 2, 6) else None
+    ref = eng.gemm(A, W, epi, bias=bias, S=S, H=H, variant=0)
+    assert torch.equal(eng.gemm(A, W, epi, bias=bias, S=S, H=H, variant=3), ref)
+    for _ in range(3):
+        out = eng.gemm(A, W, epi, bias=bias, S=S, H=H, variant=6)
+        assert torch.equal(out, ref), describe(out, ref)
+    if epi in (0, 1, 2):                   # and against fp32 torch, so that the three forms cannot be wrong together
+        full = A.float() @ W.float().t() + bias.float()
+        full = quick_gelu(full) if epi == 1 else (gelu_erf(full) if epi == 2 else full)
+        assert_close(out, full, 2e-2, 1e-2, "wide form vs fp32")
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 512, 128), (1000, 768, 256), (70000, 512, 64)])

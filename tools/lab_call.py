@@ -234,6 +234,30 @@ def main():
             return {"l2_touch:%dx%d" % s: v for s, v in pairs}
         in_situ("clip-flant5-xxl", [("rule (wo on)", "product", {}), ("wo off", "product", opt([(wo, 2)])), ("wo on + o on", "product", opt([(o, 1)])),
                                     ("wo on + qkv on", "product", opt([(qkv, 1)])), ("wo on + wi on", "product", opt([(wi, 1)]))], steps=3, rounds=3, tag="L")
+    if "W" in parts:                                             # the four-wave 128x128 GEMM form (variant 6) vs the 8-wave default and hipBLASLt
+        g = torch.Generator(device="cuda").manual_seed(0)
+        for tag, M, N, K, epi, S, H, has_bias in XXL + XL + VIT:
+            A = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+            W = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(torch.bfloat16)
+            bias = torch.randn(N, device="cuda", generator=g).to(torch.bfloat16) if has_bias else None
+            out3 = engine.gemm(A, W, epi, bias=bias, S=S, H=H, variant=3)
+            out6 = engine.gemm(A, W, epi, bias=bias, S=S, H=H, variant=6)
+            same = bool(torch.equal(out3, out6))
+            ref = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+            res = {}
+            for rnd in range(2):
+                for v, o in ((3, out3), (6, out6)):
+                    ms = time_ms(lambda: engine.gemm(A, W, epi, bias=bias, out=o, S=S, H=H, variant=v), 5)
+                    res.setdefault("variant%d" % v, []).append(round(2.0 * M * N * K / ms / 1e9, 1))
+                res.setdefault("torch_matmul_no_epilogue", []).append(round(2.0 * M * N * K / time_ms(lambda: torch.matmul(A, W.t(), out=ref), 5) / 1e9, 1))
+            emit({"part": "W", "shape": tag, "N": N, "K": K, "epilogue": epi, "tflops": res, "bitwise_equal_3_vs_6": same})
+            del A, W, out3, out6, ref
+            torch.cuda.empty_cache()
+    if "WI" in parts:                                            # ... in situ
+        in_situ("clip-flant5-xxl", [("8-wave forms (variant 3)", "product", {"gemm_variant": 3}), ("wide form (variant 6)", "product", {"gemm_variant": 6})],
+                steps=3, rounds=3, tag="WI")
+        in_situ("clip-flant5-xl", [("8-wave forms (variant 3)", "product", {"gemm_variant": 3}), ("wide form (variant 6)", "product", {"gemm_variant": 6})],
+                steps=4, rounds=2, tag="WIX")
     if "V" in parts:                                             # lock-step (launcher's rule) vs forced ping-pong schedule, ViT shapes
         g = torch.Generator(device="cuda").manual_seed(0)
         for tag, M, N, K, epi, S, H, has_bias in VIT + [("projector.0", 147456, 4096, 1024, 2, 0, 0, True)]:
