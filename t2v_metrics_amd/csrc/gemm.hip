@@ -987,6 +987,27 @@ __device__ __forceinline__ void mfma_fixed(const uint4& a, const uint4& b) {
     else if constexpr (IDX == 14) asm volatile("v_mfma_f32_32x32x16_bf16 a[224:239], %0, %1, a[224:239]" ::"v"(av), "v"(bv) : "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239");
     else if constexpr (IDX == 15) asm volatile("v_mfma_f32_32x32x16_bf16 a[240:255], %0, %1, a[240:255]" ::"v"(av), "v"(bv) : "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255");
 }
+// first k-step of an output tile: C = 0 as an inline constant (no 256 v_accvgpr_write per tile)
+template <int IDX>
+__device__ __forceinline__ void mfma_fixed_zero(const uint4& a, const uint4& b) {
+    const g_frag_t av = {a.x, a.y, a.z, a.w}, bv = {b.x, b.y, b.z, b.w};
+    if constexpr (IDX == 0) asm volatile("v_mfma_f32_32x32x16_bf16 a[0:15], %0, %1, 0" ::"v"(av), "v"(bv) : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15");
+    else if constexpr (IDX == 1) asm volatile("v_mfma_f32_32x32x16_bf16 a[16:31], %0, %1, 0" ::"v"(av), "v"(bv) : "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31");
+    else if constexpr (IDX == 2) asm volatile("v_mfma_f32_32x32x16_bf16 a[32:47], %0, %1, 0" ::"v"(av), "v"(bv) : "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47");
+    else if constexpr (IDX == 3) asm volatile("v_mfma_f32_32x32x16_bf16 a[48:63], %0, %1, 0" ::"v"(av), "v"(bv) : "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63");
+    else if constexpr (IDX == 4) asm volatile("v_mfma_f32_32x32x16_bf16 a[64:79], %0, %1, 0" ::"v"(av), "v"(bv) : "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79");
+    else if constexpr (IDX == 5) asm volatile("v_mfma_f32_32x32x16_bf16 a[80:95], %0, %1, 0" ::"v"(av), "v"(bv) : "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95");
+    else if constexpr (IDX == 6) asm volatile("v_mfma_f32_32x32x16_bf16 a[96:111], %0, %1, 0" ::"v"(av), "v"(bv) : "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111");
+    else if constexpr (IDX == 7) asm volatile("v_mfma_f32_32x32x16_bf16 a[112:127], %0, %1, 0" ::"v"(av), "v"(bv) : "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127");
+    else if constexpr (IDX == 8) asm volatile("v_mfma_f32_32x32x16_bf16 a[128:143], %0, %1, 0" ::"v"(av), "v"(bv) : "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143");
+    else if constexpr (IDX == 9) asm volatile("v_mfma_f32_32x32x16_bf16 a[144:159], %0, %1, 0" ::"v"(av), "v"(bv) : "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159");
+    else if constexpr (IDX == 10) asm volatile("v_mfma_f32_32x32x16_bf16 a[160:175], %0, %1, 0" ::"v"(av), "v"(bv) : "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175");
+    else if constexpr (IDX == 11) asm volatile("v_mfma_f32_32x32x16_bf16 a[176:191], %0, %1, 0" ::"v"(av), "v"(bv) : "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191");
+    else if constexpr (IDX == 12) asm volatile("v_mfma_f32_32x32x16_bf16 a[192:207], %0, %1, 0" ::"v"(av), "v"(bv) : "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207");
+    else if constexpr (IDX == 13) asm volatile("v_mfma_f32_32x32x16_bf16 a[208:223], %0, %1, 0" ::"v"(av), "v"(bv) : "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223");
+    else if constexpr (IDX == 14) asm volatile("v_mfma_f32_32x32x16_bf16 a[224:239], %0, %1, 0" ::"v"(av), "v"(bv) : "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239");
+    else if constexpr (IDX == 15) asm volatile("v_mfma_f32_32x32x16_bf16 a[240:255], %0, %1, 0" ::"v"(av), "v"(bv) : "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255");
+}
 __device__ __forceinline__ void acc_zero_all() {
     asm volatile("v_accvgpr_write_b32 a0, 0\n\tv_accvgpr_write_b32 a1, 0\n\tv_accvgpr_write_b32 a2, 0\n\tv_accvgpr_write_b32 a3, 0\n\tv_accvgpr_write_b32 a4, 0\n\tv_accvgpr_write_b32 a5, 0\n\tv_accvgpr_write_b32 a6, 0\n\tv_accvgpr_write_b32 a7, 0" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7");
     asm volatile("v_accvgpr_write_b32 a8, 0\n\tv_accvgpr_write_b32 a9, 0\n\tv_accvgpr_write_b32 a10, 0\n\tv_accvgpr_write_b32 a11, 0\n\tv_accvgpr_write_b32 a12, 0\n\tv_accvgpr_write_b32 a13, 0\n\tv_accvgpr_write_b32 a14, 0\n\tv_accvgpr_write_b32 a15, 0" ::: "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15");
@@ -1108,57 +1129,150 @@ __global__ void __launch_bounds__(256) gemm_bf16_wide(const GemmParams p) {
 
     while (true) {
         // accumulator (half, m, n) = columns n0 + wc*128 + half*64 + n*32 ..., rows m0 + wr*128 + m*32 ... lives in AGPR tuple
-        // (half*4 + m)*2 + n (see mfma_fixed)
-        acc_zero_all();
+        // (half*4 + m)*2 + n (see mfma_fixed); zeroed by the C = 0 form of the first k-step's MFMAs
 
         const int next_pid = pid + gridDim.x;
         const bool has_next = next_pid < nwg;
         int nm0 = 0, nn0 = 0, nbz = 0;
 
-        // One K-tile = 4 k-steps of 8 fragment reads (ds_read_b128) + 16 MFMAs, software-pipelined by hand over two fragment
-        // register sets: the reads of k-step s+1 are issued BEFORE the MFMAs of k-step s (the MFMA statements are opaque to the
-        // scheduler, so the order below is the order in the binary; sched_barrier keeps the reads from sinking to their use).
-        // The K-tile boundary (wait for the own DMA pieces, barrier, first fragment reads of the next K-tile from the other
-        // stage) sits in the MIDDLE of the last k-step, in front of its last 8 MFMAs, so the LDS latency of those reads runs
-        // under 256 cycles of matrix work instead of an idle pipe.  STAGE: the sixteen LDS-DMA pieces of the next K-tile go out
-        // in the first two k-steps, two per row block of MFMAs.  LAST: last K-tile of an output tile (the epilogue follows; the
-        // next tile's first reads are issued after it).  Both compile-time: no branch between MFMA groups.
+        // One K-tile = 4 k-steps of 16 MFMAs, the instruction stream written out by hand (the MFMA statements are opaque to the
+        // scheduler, sched_barrier pins every LDS read where it stands): ONE wave per SIMD means one instruction per issue
+        // slot, and an MFMA leaves seven free slots in its 32-cycle shadow -- so never more than one LDS read or one LDS-DMA piece
+        // between two MFMAs.
+        //   k-steps 0..2: MFMA j of the current fragment set is followed (j < 8) by read j of the NEXT k-step's set;
+        //   k-steps 0, 1: MFMA j >= 8 is followed by one of the sixteen LDS-DMA pieces of the next K-tile (STAGE);
+        //   k-step 3: after its first 8 MFMAs the K-tile boundary (own DMA pieces landed, barrier), then MFMAs 8..15 each
+        //             followed by a read of the next K-tile's first set from the other stage (not LAST: the epilogue follows).
+        //   FIRST: first K-tile of an output tile, its k-step 0 writes the accumulators with C = 0.
+        // Read order A0 W0 W1 W2 W3 A1 A2 A3 = the order the next k-step's first MFMAs need them.
         uint4 fa[2][4], fw[2][4];
-        auto read_frags = [&](int set, const char* sbase, int ks) {
-#pragma unroll
-            for (int m = 0; m < 4; ++m) fa[set][m] = *reinterpret_cast<const uint4*>(sbase + a_row + m * 4096 + koff[ks]);
-#pragma unroll
-            for (int n = 0; n < 4; ++n) fw[set][n] = *reinterpret_cast<const uint4*>(sbase + b_row + n * 4096 + koff[ks]);
-            __builtin_amdgcn_sched_barrier(0);
-        };
-#define VQS_ROWBLOCK(SET, M, DMA_I)                                                    \
-    mfma_fixed<(0 * 4 + (M)) * 2 + 0>(fw[SET][0], fa[SET][M]);                         \
-    mfma_fixed<(0 * 4 + (M)) * 2 + 1>(fw[SET][1], fa[SET][M]);                         \
-    mfma_fixed<(1 * 4 + (M)) * 2 + 0>(fw[SET][2], fa[SET][M]);                         \
-    mfma_fixed<(1 * 4 + (M)) * 2 + 1>(fw[SET][3], fa[SET][M]);                         \
-    if (STAGE && (DMA_I) >= 0) {                                                       \
-        bglds16(rsA, pa[(DMA_I) & 7], koffs2, dst0 + ((DMA_I) & 7) * 4096);            \
-        bglds16(rsW, pb[(DMA_I) & 7], koffs2, dst0 + ((DMA_I) & 7) * 4096 + W_OFF);    \
-    }
-        auto ktile = [&](auto stage_tag, auto last_tag, uint32_t koffs2) {
+        auto ktile = [&](auto stage_tag, auto last_tag, auto first_tag, uint32_t koffs2) {
             constexpr bool STAGE = decltype(stage_tag)::value;
             constexpr bool LAST = decltype(last_tag)::value;
+            constexpr bool FIRST = decltype(first_tag)::value;
             const uint32_t dst0 = lds_base + (buf ^ 1) * STAGE_BYTES + w * 1024;
             const char* sb = lds + buf * STAGE_BYTES;
             const char* sn = lds + (buf ^ 1) * STAGE_BYTES;
-            read_frags(1, sb, 1);
-            VQS_ROWBLOCK(0, 0, 0) VQS_ROWBLOCK(0, 1, 1) VQS_ROWBLOCK(0, 2, 2) VQS_ROWBLOCK(0, 3, 3)
-            read_frags(0, sb, 2);
-            VQS_ROWBLOCK(1, 0, 4) VQS_ROWBLOCK(1, 1, 5) VQS_ROWBLOCK(1, 2, 6) VQS_ROWBLOCK(1, 3, 7)
-            read_frags(1, sb, 3);
-            VQS_ROWBLOCK(0, 0, -1) VQS_ROWBLOCK(0, 1, -1) VQS_ROWBLOCK(0, 2, -1) VQS_ROWBLOCK(0, 3, -1)
-            VQS_ROWBLOCK(1, 0, -1) VQS_ROWBLOCK(1, 1, -1)
-            if (!LAST) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own pieces of the next K-tile (issued >= 2 k-steps ago)
+            // ---- k-step 0 (fragment set 0)
+            if constexpr (FIRST) mfma_fixed_zero<0>(fw[0][0], fa[0][0]); else mfma_fixed<0>(fw[0][0], fa[0][0]);
+            fa[1][0] = *reinterpret_cast<const uint4*>(sb + a_row + 0 * 4096 + koff[1]); __builtin_amdgcn_sched_barrier(0);
+            if constexpr (FIRST) mfma_fixed_zero<1>(fw[0][1], fa[0][0]); else mfma_fixed<1>(fw[0][1], fa[0][0]);
+            fw[1][0] = *reinterpret_cast<const uint4*>(sb + b_row + 0 * 4096 + koff[1]); __builtin_amdgcn_sched_barrier(0);
+            if constexpr (FIRST) mfma_fixed_zero<8>(fw[0][2], fa[0][0]); else mfma_fixed<8>(fw[0][2], fa[0][0]);
+            fw[1][1] = *reinterpret_cast<const uint4*>(sb + b_row + 1 * 4096 + koff[1]); __builtin_amdgcn_sched_barrier(0);
+            if constexpr (FIRST) mfma_fixed_zero<9>(fw[0][3], fa[0][0]); else mfma_fixed<9>(fw[0][3], fa[0][0]);
+            fw[1][2] = *reinterpret_cast<const uint4*>(sb + b_row + 2 * 4096 + koff[1]); __builtin_amdgcn_sched_barrier(0);
+            if constexpr (FIRST) mfma_fixed_zero<2>(fw[0][0], fa[0][1]); else mfma_fixed<2>(fw[0][0], fa[0][1]);
+            fw[1][3] = *reinterpret_cast<const uint4*>(sb + b_row + 3 * 4096 + koff[1]); __builtin_amdgcn_sched_barrier(0);
+            if constexpr (FIRST) mfma_fixed_zero<3>(fw[0][1], fa[0][1]); else mfma_fixed<3>(fw[0][1], fa[0][1]);
+            fa[1][1] = *reinterpret_cast<const uint4*>(sb + a_row + 1 * 4096 + koff[1]); __builtin_amdgcn_sched_barrier(0);
+            if constexpr (FIRST) mfma_fixed_zero<10>(fw[0][2], fa[0][1]); else mfma_fixed<10>(fw[0][2], fa[0][1]);
+            fa[1][2] = *reinterpret_cast<const uint4*>(sb + a_row + 2 * 4096 + koff[1]); __builtin_amdgcn_sched_barrier(0);
+            if constexpr (FIRST) mfma_fixed_zero<11>(fw[0][3], fa[0][1]); else mfma_fixed<11>(fw[0][3], fa[0][1]);
+            fa[1][3] = *reinterpret_cast<const uint4*>(sb + a_row + 3 * 4096 + koff[1]); __builtin_amdgcn_sched_barrier(0);
+            if constexpr (FIRST) mfma_fixed_zero<4>(fw[0][0], fa[0][2]); else mfma_fixed<4>(fw[0][0], fa[0][2]);
+            if constexpr (STAGE) bglds16(rsA, pa[0], koffs2, dst0 + 0 * 4096);
+            if constexpr (FIRST) mfma_fixed_zero<5>(fw[0][1], fa[0][2]); else mfma_fixed<5>(fw[0][1], fa[0][2]);
+            if constexpr (STAGE) bglds16(rsW, pb[0], koffs2, dst0 + 0 * 4096 + W_OFF);
+            if constexpr (FIRST) mfma_fixed_zero<12>(fw[0][2], fa[0][2]); else mfma_fixed<12>(fw[0][2], fa[0][2]);
+            if constexpr (STAGE) bglds16(rsA, pa[1], koffs2, dst0 + 1 * 4096);
+            if constexpr (FIRST) mfma_fixed_zero<13>(fw[0][3], fa[0][2]); else mfma_fixed<13>(fw[0][3], fa[0][2]);
+            if constexpr (STAGE) bglds16(rsW, pb[1], koffs2, dst0 + 1 * 4096 + W_OFF);
+            if constexpr (FIRST) mfma_fixed_zero<6>(fw[0][0], fa[0][3]); else mfma_fixed<6>(fw[0][0], fa[0][3]);
+            if constexpr (STAGE) bglds16(rsA, pa[2], koffs2, dst0 + 2 * 4096);
+            if constexpr (FIRST) mfma_fixed_zero<7>(fw[0][1], fa[0][3]); else mfma_fixed<7>(fw[0][1], fa[0][3]);
+            if constexpr (STAGE) bglds16(rsW, pb[2], koffs2, dst0 + 2 * 4096 + W_OFF);
+            if constexpr (FIRST) mfma_fixed_zero<14>(fw[0][2], fa[0][3]); else mfma_fixed<14>(fw[0][2], fa[0][3]);
+            if constexpr (STAGE) bglds16(rsA, pa[3], koffs2, dst0 + 3 * 4096);
+            if constexpr (FIRST) mfma_fixed_zero<15>(fw[0][3], fa[0][3]); else mfma_fixed<15>(fw[0][3], fa[0][3]);
+            if constexpr (STAGE) bglds16(rsW, pb[3], koffs2, dst0 + 3 * 4096 + W_OFF);
+            // ---- k-step 1 (fragment set 1)
+            mfma_fixed<0>(fw[1][0], fa[1][0]);
+            fa[0][0] = *reinterpret_cast<const uint4*>(sb + a_row + 0 * 4096 + koff[2]); __builtin_amdgcn_sched_barrier(0);
+            mfma_fixed<1>(fw[1][1], fa[1][0]);
+            fw[0][0] = *reinterpret_cast<const uint4*>(sb + b_row + 0 * 4096 + koff[2]); __builtin_amdgcn_sched_barrier(0);
+            mfma_fixed<8>(fw[1][2], fa[1][0]);
+            fw[0][1] = *reinterpret_cast<const uint4*>(sb + b_row + 1 * 4096 + koff[2]); __builtin_amdgcn_sched_barrier(0);
+            mfma_fixed<9>(fw[1][3], fa[1][0]);
+            fw[0][2] = *reinterpret_cast<const uint4*>(sb + b_row + 2 * 4096 + koff[2]); __builtin_amdgcn_sched_barrier(0);
+            mfma_fixed<2>(fw[1][0], fa[1][1]);
+            fw[0][3] = *reinterpret_cast<const uint4*>(sb + b_row + 3 * 4096 + koff[2]); __builtin_amdgcn_sched_barrier(0);
+            mfma_fixed<3>(fw[1][1], fa[1][1]);
+            fa[0][1] = *reinterpret_cast<const uint4*>(sb + a_row + 1 * 4096 + koff[2]); __builtin_amdgcn_sched_barrier(0);
+            mfma_fixed<10>(fw[1][2], fa[1][1]);
+            fa[0][2] = *reinterpret_cast<const uint4*>(sb + a_row + 2 * 4096 + koff[2]); __builtin_amdgcn_sched_barrier(0);
+            mfma_fixed<11>(fw[1][3], fa[1][1]);
+            fa[0][3] = *reinterpret_cast<const uint4*>(sb + a_row + 3 * 4096 + koff[2]); __builtin_amdgcn_sched_barrier(0);
+            mfma_fixed<4>(fw[1][0], fa[1][2]);
+            if constexpr (STAGE) bglds16(rsA, pa[4], koffs2, dst0 + 4 * 4096);
+            mfma_fixed<5>(fw[1][1], fa[1][2]);
+            if constexpr (STAGE) bglds16(rsW, pb[4], koffs2, dst0 + 4 * 4096 + W_OFF);
+            mfma_fixed<12>(fw[1][2], fa[1][2]);
+            if constexpr (STAGE) bglds16(rsA, pa[5], koffs2, dst0 + 5 * 4096);
+            mfma_fixed<13>(fw[1][3], fa[1][2]);
+            if constexpr (STAGE) bglds16(rsW, pb[5], koffs2, dst0 + 5 * 4096 + W_OFF);
+            mfma_fixed<6>(fw[1][0], fa[1][3]);
+            if constexpr (STAGE) bglds16(rsA, pa[6], koffs2, dst0 + 6 * 4096);
+            mfma_fixed<7>(fw[1][1], fa[1][3]);
+            if constexpr (STAGE) bglds16(rsW, pb[6], koffs2, dst0 + 6 * 4096 + W_OFF);
+            mfma_fixed<14>(fw[1][2], fa[1][3]);
+            if constexpr (STAGE) bglds16(rsA, pa[7], koffs2, dst0 + 7 * 4096);
+            mfma_fixed<15>(fw[1][3], fa[1][3]);
+            if constexpr (STAGE) bglds16(rsW, pb[7], koffs2, dst0 + 7 * 4096 + W_OFF);
+            // ---- k-step 2 (fragment set 0)
+            mfma_fixed<0>(fw[0][0], fa[0][0]);
+            fa[1][0] = *reinterpret_cast<const uint4*>(sb + a_row + 0 * 4096 + koff[3]); __builtin_amdgcn_sched_barrier(0);
+            mfma_fixed<1>(fw[0][1], fa[0][0]);
+            fw[1][0] = *reinterpret_cast<const uint4*>(sb + b_row + 0 * 4096 + koff[3]); __builtin_amdgcn_sched_barrier(0);
+            mfma_fixed<8>(fw[0][2], fa[0][0]);
+            fw[1][1] = *reinterpret_cast<const uint4*>(sb + b_row + 1 * 4096 + koff[3]); __builtin_amdgcn_sched_barrier(0);
+            mfma_fixed<9>(fw[0][3], fa[0][0]);
+            fw[1][2] = *reinterpret_cast<const uint4*>(sb + b_row + 2 * 4096 + koff[3]); __builtin_amdgcn_sched_barrier(0);
+            mfma_fixed<2>(fw[0][0], fa[0][1]);
+            fw[1][3] = *reinterpret_cast<const uint4*>(sb + b_row + 3 * 4096 + koff[3]); __builtin_amdgcn_sched_barrier(0);
+            mfma_fixed<3>(fw[0][1], fa[0][1]);
+            fa[1][1] = *reinterpret_cast<const uint4*>(sb + a_row + 1 * 4096 + koff[3]); __builtin_amdgcn_sched_barrier(0);
+            mfma_fixed<10>(fw[0][2], fa[0][1]);
+            fa[1][2] = *reinterpret_cast<const uint4*>(sb + a_row + 2 * 4096 + koff[3]); __builtin_amdgcn_sched_barrier(0);
+            mfma_fixed<11>(fw[0][3], fa[0][1]);
+            fa[1][3] = *reinterpret_cast<const uint4*>(sb + a_row + 3 * 4096 + koff[3]); __builtin_amdgcn_sched_barrier(0);
+            mfma_fixed<4>(fw[0][0], fa[0][2]);
+            mfma_fixed<5>(fw[0][1], fa[0][2]);
+            mfma_fixed<12>(fw[0][2], fa[0][2]);
+            mfma_fixed<13>(fw[0][3], fa[0][2]);
+            mfma_fixed<6>(fw[0][0], fa[0][3]);
+            mfma_fixed<7>(fw[0][1], fa[0][3]);
+            mfma_fixed<14>(fw[0][2], fa[0][3]);
+            mfma_fixed<15>(fw[0][3], fa[0][3]);
+            // ---- k-step 3 (fragment set 1)
+            mfma_fixed<0>(fw[1][0], fa[1][0]);
+            mfma_fixed<1>(fw[1][1], fa[1][0]);
+            mfma_fixed<8>(fw[1][2], fa[1][0]);
+            mfma_fixed<9>(fw[1][3], fa[1][0]);
+            mfma_fixed<2>(fw[1][0], fa[1][1]);
+            mfma_fixed<3>(fw[1][1], fa[1][1]);
+            mfma_fixed<10>(fw[1][2], fa[1][1]);
+            mfma_fixed<11>(fw[1][3], fa[1][1]);
+            if constexpr (!LAST) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own pieces of the next K-tile (issued >= 1.5 k-steps ago)
                 __builtin_amdgcn_s_barrier();                      // everybody's; and nobody reads stage `buf` any more
-                read_frags(0, sn, 0);
             }
-            VQS_ROWBLOCK(1, 2, -1) VQS_ROWBLOCK(1, 3, -1)
+            mfma_fixed<4>(fw[1][0], fa[1][2]);
+            if constexpr (!LAST) { fa[0][0] = *reinterpret_cast<const uint4*>(sn + a_row + 0 * 4096 + koff[0]); __builtin_amdgcn_sched_barrier(0); }
+            mfma_fixed<5>(fw[1][1], fa[1][2]);
+            if constexpr (!LAST) { fw[0][0] = *reinterpret_cast<const uint4*>(sn + b_row + 0 * 4096 + koff[0]); __builtin_amdgcn_sched_barrier(0); }
+            mfma_fixed<12>(fw[1][2], fa[1][2]);
+            if constexpr (!LAST) { fw[0][1] = *reinterpret_cast<const uint4*>(sn + b_row + 1 * 4096 + koff[0]); __builtin_amdgcn_sched_barrier(0); }
+            mfma_fixed<13>(fw[1][3], fa[1][2]);
+            if constexpr (!LAST) { fw[0][2] = *reinterpret_cast<const uint4*>(sn + b_row + 2 * 4096 + koff[0]); __builtin_amdgcn_sched_barrier(0); }
+            mfma_fixed<6>(fw[1][0], fa[1][3]);
+            if constexpr (!LAST) { fw[0][3] = *reinterpret_cast<const uint4*>(sn + b_row + 3 * 4096 + koff[0]); __builtin_amdgcn_sched_barrier(0); }
+            mfma_fixed<7>(fw[1][1], fa[1][3]);
+            if constexpr (!LAST) { fa[0][1] = *reinterpret_cast<const uint4*>(sn + a_row + 1 * 4096 + koff[0]); __builtin_amdgcn_sched_barrier(0); }
+            mfma_fixed<14>(fw[1][2], fa[1][3]);
+            if constexpr (!LAST) { fa[0][2] = *reinterpret_cast<const uint4*>(sn + a_row + 2 * 4096 + koff[0]); __builtin_amdgcn_sched_barrier(0); }
+            mfma_fixed<15>(fw[1][3], fa[1][3]);
+            if constexpr (!LAST) { fa[0][3] = *reinterpret_cast<const uint4*>(sn + a_row + 3 * 4096 + koff[0]); __builtin_amdgcn_sched_barrier(0); }
             buf ^= 1;
         };
 
@@ -1172,20 +1286,35 @@ __global__ void __launch_bounds__(256) gemm_bf16_wide(const GemmParams p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
-        read_frags(0, lds + buf * STAGE_BYTES, 0);
+        {
+            const char* s0 = lds + buf * STAGE_BYTES;
+            fa[0][0] = *reinterpret_cast<const uint4*>(s0 + a_row + 0 * 4096 + koff[0]); __builtin_amdgcn_sched_barrier(0);
+            fw[0][0] = *reinterpret_cast<const uint4*>(s0 + b_row + 0 * 4096 + koff[0]); __builtin_amdgcn_sched_barrier(0);
+            fw[0][1] = *reinterpret_cast<const uint4*>(s0 + b_row + 1 * 4096 + koff[0]); __builtin_amdgcn_sched_barrier(0);
+            fw[0][2] = *reinterpret_cast<const uint4*>(s0 + b_row + 2 * 4096 + koff[0]); __builtin_amdgcn_sched_barrier(0);
+            fw[0][3] = *reinterpret_cast<const uint4*>(s0 + b_row + 3 * 4096 + koff[0]); __builtin_amdgcn_sched_barrier(0);
+            fa[0][1] = *reinterpret_cast<const uint4*>(s0 + a_row + 1 * 4096 + koff[0]); __builtin_amdgcn_sched_barrier(0);
+            fa[0][2] = *reinterpret_cast<const uint4*>(s0 + a_row + 2 * 4096 + koff[0]); __builtin_amdgcn_sched_barrier(0);
+            fa[0][3] = *reinterpret_cast<const uint4*>(s0 + a_row + 3 * 4096 + koff[0]); __builtin_amdgcn_sched_barrier(0);
+        }
 
+        constexpr std::true_type YES{};
+        constexpr std::false_type NO{};
         for (int t = 0; t < nt; ++t) {
+            const bool first = (t == 0);
             if (t + 1 < nt) {
-                ktile(std::true_type{}, std::false_type{}, (uint32_t)((t + 1) * BK * 2));
+                if (first) ktile(YES, NO, YES, (uint32_t)((t + 1) * BK * 2));
+                else ktile(YES, NO, NO, (uint32_t)((t + 1) * BK * 2));
             } else if (has_next) {
                 tile_coords(next_pid, nm0, nn0, nbz);
                 set_ptrs(nm0, nn0, nbz);
-                ktile(std::true_type{}, std::true_type{}, 0u);
+                if (first) ktile(YES, YES, YES, 0u);
+                else ktile(YES, YES, NO, 0u);
             } else {
-                ktile(std::false_type{}, std::true_type{}, 0u);
+                if (first) ktile(NO, YES, YES, 0u);
+                else ktile(NO, YES, NO, 0u);
             }
         }
-#undef VQS_ROWBLOCK
 
         const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
         // the MFMAs are opaque to the compiler's hazard recogniser: 18 wait states between the last one and the first
