@@ -1091,10 +1091,8 @@ __global__ void __launch_bounds__(256) gemm_bf16_wide(const GemmParams p) {
     const uint32_t gchunk_b = (uint32_t)(((lane & 7) ^ sw) << 4);
     const uint32_t lda_b = (uint32_t)p.lda * 2u, ldw_b = (uint32_t)p.ldw * 2u;
     uint32_t pa[8], pb[8];
-    v4i_t rsA, rsW;
-    auto set_ptrs = [&](int m0, int n0, int bz) {
-        rsA = make_rsrc(p.A + (size_t)bz * p.sA);
-        rsW = make_rsrc(p.W + (size_t)bz * p.sW);
+    const v4i_t rsA = make_rsrc(p.A), rsW = make_rsrc(p.W);      // one batch entry (launcher): loop-invariant SGPR descriptors
+    auto set_ptrs = [&](int m0, int n0, int) {
         const int r0 = w * 8 + (lane >> 3);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {

@@ -255,7 +255,8 @@ def main():
             torch.cuda.empty_cache()
     if "WI" in parts:                                            # ... in situ
         in_situ("clip-flant5-xxl", [("8-wave forms (variant 3)", "product", {"gemm_variant": 3}), ("wide form (variant 6)", "product", {"gemm_variant": 6})],
-                steps=3, rounds=3, tag="WI")
+                steps=3, rounds=2, tag="WI")
+    if "WIX" in parts:
         in_situ("clip-flant5-xl", [("8-wave forms (variant 3)", "product", {"gemm_variant": 3}), ("wide form (variant 6)", "product", {"gemm_variant": 6})],
                 steps=4, rounds=2, tag="WIX")
     if "V" in parts:                                             # lock-step (launcher's rule) vs forced ping-pong schedule, ViT shapes
