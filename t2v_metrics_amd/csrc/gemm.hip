@@ -1065,6 +1065,10 @@ __device__ __forceinline__ void acc_read(f32x16& out) {
     for (int r = 0; r < 16; ++r) out[r] = t[r];
 }
 
+// VQS_WIDE_ABL (timing ablations, lab builds only; results are then garbage): 1 = no LDS-DMA in the K loop, 2 = no fragment reads
+#ifndef VQS_WIDE_ABL
+#define VQS_WIDE_ABL 0
+#endif
 template <int EPI>
 __global__ void __launch_bounds__(256) gemm_bf16_wide(const GemmParams p) {
     static_assert(EPI != EPI_RESID_RMS && EPI != EPI_F32_RESID && EPI != EPI_F32, "not carried by the wide form (fp32 results: lm_head and split-K partials, small launches)");
@@ -1153,87 +1157,87 @@ __global__ void __launch_bounds__(256) gemm_bf16_wide(const GemmParams p) {
             const char* sn = lds + (buf ^ 1) * STAGE_BYTES;
             // ---- k-step 0 (fragment set 0)
             if constexpr (FIRST) mfma_fixed_zero<0>(fw[0][0], fa[0][0]); else mfma_fixed<0>(fw[0][0], fa[0][0]);
-            fa[1][0] = *reinterpret_cast<const uint4*>(sb + a_row + 0 * 4096 + koff[1]); __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(VQS_WIDE_ABL & 2)) { fa[1][0] = *reinterpret_cast<const uint4*>(sb + a_row + 0 * 4096 + koff[1]); } __builtin_amdgcn_sched_barrier(0);
             if constexpr (FIRST) mfma_fixed_zero<1>(fw[0][1], fa[0][0]); else mfma_fixed<1>(fw[0][1], fa[0][0]);
-            fw[1][0] = *reinterpret_cast<const uint4*>(sb + b_row + 0 * 4096 + koff[1]); __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(VQS_WIDE_ABL & 2)) { fw[1][0] = *reinterpret_cast<const uint4*>(sb + b_row + 0 * 4096 + koff[1]); } __builtin_amdgcn_sched_barrier(0);
             if constexpr (FIRST) mfma_fixed_zero<8>(fw[0][2], fa[0][0]); else mfma_fixed<8>(fw[0][2], fa[0][0]);
-            fw[1][1] = *reinterpret_cast<const uint4*>(sb + b_row + 1 * 4096 + koff[1]); __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(VQS_WIDE_ABL & 2)) { fw[1][1] = *reinterpret_cast<const uint4*>(sb + b_row + 1 * 4096 + koff[1]); } __builtin_amdgcn_sched_barrier(0);
             if constexpr (FIRST) mfma_fixed_zero<9>(fw[0][3], fa[0][0]); else mfma_fixed<9>(fw[0][3], fa[0][0]);
-            fw[1][2] = *reinterpret_cast<const uint4*>(sb + b_row + 2 * 4096 + koff[1]); __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(VQS_WIDE_ABL & 2)) { fw[1][2] = *reinterpret_cast<const uint4*>(sb + b_row + 2 * 4096 + koff[1]); } __builtin_amdgcn_sched_barrier(0);
             if constexpr (FIRST) mfma_fixed_zero<2>(fw[0][0], fa[0][1]); else mfma_fixed<2>(fw[0][0], fa[0][1]);
-            fw[1][3] = *reinterpret_cast<const uint4*>(sb + b_row + 3 * 4096 + koff[1]); __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(VQS_WIDE_ABL & 2)) { fw[1][3] = *reinterpret_cast<const uint4*>(sb + b_row + 3 * 4096 + koff[1]); } __builtin_amdgcn_sched_barrier(0);
             if constexpr (FIRST) mfma_fixed_zero<3>(fw[0][1], fa[0][1]); else mfma_fixed<3>(fw[0][1], fa[0][1]);
-            fa[1][1] = *reinterpret_cast<const uint4*>(sb + a_row + 1 * 4096 + koff[1]); __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(VQS_WIDE_ABL & 2)) { fa[1][1] = *reinterpret_cast<const uint4*>(sb + a_row + 1 * 4096 + koff[1]); } __builtin_amdgcn_sched_barrier(0);
             if constexpr (FIRST) mfma_fixed_zero<10>(fw[0][2], fa[0][1]); else mfma_fixed<10>(fw[0][2], fa[0][1]);
-            fa[1][2] = *reinterpret_cast<const uint4*>(sb + a_row + 2 * 4096 + koff[1]); __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(VQS_WIDE_ABL & 2)) { fa[1][2] = *reinterpret_cast<const uint4*>(sb + a_row + 2 * 4096 + koff[1]); } __builtin_amdgcn_sched_barrier(0);
             if constexpr (FIRST) mfma_fixed_zero<11>(fw[0][3], fa[0][1]); else mfma_fixed<11>(fw[0][3], fa[0][1]);
-            fa[1][3] = *reinterpret_cast<const uint4*>(sb + a_row + 3 * 4096 + koff[1]); __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(VQS_WIDE_ABL & 2)) { fa[1][3] = *reinterpret_cast<const uint4*>(sb + a_row + 3 * 4096 + koff[1]); } __builtin_amdgcn_sched_barrier(0);
             if constexpr (FIRST) mfma_fixed_zero<4>(fw[0][0], fa[0][2]); else mfma_fixed<4>(fw[0][0], fa[0][2]);
-            if constexpr (STAGE) bglds16(rsA, pa[0], koffs2, dst0 + 0 * 4096);
+            if constexpr (STAGE && !(VQS_WIDE_ABL & 1)) bglds16(rsA, pa[0], koffs2, dst0 + 0 * 4096);
             if constexpr (FIRST) mfma_fixed_zero<5>(fw[0][1], fa[0][2]); else mfma_fixed<5>(fw[0][1], fa[0][2]);
-            if constexpr (STAGE) bglds16(rsW, pb[0], koffs2, dst0 + 0 * 4096 + W_OFF);
+            if constexpr (STAGE && !(VQS_WIDE_ABL & 1)) bglds16(rsW, pb[0], koffs2, dst0 + 0 * 4096 + W_OFF);
             if constexpr (FIRST) mfma_fixed_zero<12>(fw[0][2], fa[0][2]); else mfma_fixed<12>(fw[0][2], fa[0][2]);
-            if constexpr (STAGE) bglds16(rsA, pa[1], koffs2, dst0 + 1 * 4096);
+            if constexpr (STAGE && !(VQS_WIDE_ABL & 1)) bglds16(rsA, pa[1], koffs2, dst0 + 1 * 4096);
             if constexpr (FIRST) mfma_fixed_zero<13>(fw[0][3], fa[0][2]); else mfma_fixed<13>(fw[0][3], fa[0][2]);
-            if constexpr (STAGE) bglds16(rsW, pb[1], koffs2, dst0 + 1 * 4096 + W_OFF);
+            if constexpr (STAGE && !(VQS_WIDE_ABL & 1)) bglds16(rsW, pb[1], koffs2, dst0 + 1 * 4096 + W_OFF);
             if constexpr (FIRST) mfma_fixed_zero<6>(fw[0][0], fa[0][3]); else mfma_fixed<6>(fw[0][0], fa[0][3]);
-            if constexpr (STAGE) bglds16(rsA, pa[2], koffs2, dst0 + 2 * 4096);
+            if constexpr (STAGE && !(VQS_WIDE_ABL & 1)) bglds16(rsA, pa[2], koffs2, dst0 + 2 * 4096);
             if constexpr (FIRST) mfma_fixed_zero<7>(fw[0][1], fa[0][3]); else mfma_fixed<7>(fw[0][1], fa[0][3]);
-            if constexpr (STAGE) bglds16(rsW, pb[2], koffs2, dst0 + 2 * 4096 + W_OFF);
+            if constexpr (STAGE && !(VQS_WIDE_ABL & 1)) bglds16(rsW, pb[2], koffs2, dst0 + 2 * 4096 + W_OFF);
             if constexpr (FIRST) mfma_fixed_zero<14>(fw[0][2], fa[0][3]); else mfma_fixed<14>(fw[0][2], fa[0][3]);
-            if constexpr (STAGE) bglds16(rsA, pa[3], koffs2, dst0 + 3 * 4096);
+            if constexpr (STAGE && !(VQS_WIDE_ABL & 1)) bglds16(rsA, pa[3], koffs2, dst0 + 3 * 4096);
             if constexpr (FIRST) mfma_fixed_zero<15>(fw[0][3], fa[0][3]); else mfma_fixed<15>(fw[0][3], fa[0][3]);
-            if constexpr (STAGE) bglds16(rsW, pb[3], koffs2, dst0 + 3 * 4096 + W_OFF);
+            if constexpr (STAGE && !(VQS_WIDE_ABL & 1)) bglds16(rsW, pb[3], koffs2, dst0 + 3 * 4096 + W_OFF);
             // ---- k-step 1 (fragment set 1)
             mfma_fixed<0>(fw[1][0], fa[1][0]);
-            fa[0][0] = *reinterpret_cast<const uint4*>(sb + a_row + 0 * 4096 + koff[2]); __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(VQS_WIDE_ABL & 2)) { fa[0][0] = *reinterpret_cast<const uint4*>(sb + a_row + 0 * 4096 + koff[2]); } __builtin_amdgcn_sched_barrier(0);
             mfma_fixed<1>(fw[1][1], fa[1][0]);
-            fw[0][0] = *reinterpret_cast<const uint4*>(sb + b_row + 0 * 4096 + koff[2]); __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(VQS_WIDE_ABL & 2)) { fw[0][0] = *reinterpret_cast<const uint4*>(sb + b_row + 0 * 4096 + koff[2]); } __builtin_amdgcn_sched_barrier(0);
             mfma_fixed<8>(fw[1][2], fa[1][0]);
-            fw[0][1] = *reinterpret_cast<const uint4*>(sb + b_row + 1 * 4096 + koff[2]); __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(VQS_WIDE_ABL & 2)) { fw[0][1] = *reinterpret_cast<const uint4*>(sb + b_row + 1 * 4096 + koff[2]); } __builtin_amdgcn_sched_barrier(0);
             mfma_fixed<9>(fw[1][3], fa[1][0]);
-            fw[0][2] = *reinterpret_cast<const uint4*>(sb + b_row + 2 * 4096 + koff[2]); __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(VQS_WIDE_ABL & 2)) { fw[0][2] = *reinterpret_cast<const uint4*>(sb + b_row + 2 * 4096 + koff[2]); } __builtin_amdgcn_sched_barrier(0);
             mfma_fixed<2>(fw[1][0], fa[1][1]);
-            fw[0][3] = *reinterpret_cast<const uint4*>(sb + b_row + 3 * 4096 + koff[2]); __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(VQS_WIDE_ABL & 2)) { fw[0][3] = *reinterpret_cast<const uint4*>(sb + b_row + 3 * 4096 + koff[2]); } __builtin_amdgcn_sched_barrier(0);
             mfma_fixed<3>(fw[1][1], fa[1][1]);
-            fa[0][1] = *reinterpret_cast<const uint4*>(sb + a_row + 1 * 4096 + koff[2]); __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(VQS_WIDE_ABL & 2)) { fa[0][1] = *reinterpret_cast<const uint4*>(sb + a_row + 1 * 4096 + koff[2]); } __builtin_amdgcn_sched_barrier(0);
             mfma_fixed<10>(fw[1][2], fa[1][1]);
-            fa[0][2] = *reinterpret_cast<const uint4*>(sb + a_row + 2 * 4096 + koff[2]); __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(VQS_WIDE_ABL & 2)) { fa[0][2] = *reinterpret_cast<const uint4*>(sb + a_row + 2 * 4096 + koff[2]); } __builtin_amdgcn_sched_barrier(0);
             mfma_fixed<11>(fw[1][3], fa[1][1]);
-            fa[0][3] = *reinterpret_cast<const uint4*>(sb + a_row + 3 * 4096 + koff[2]); __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(VQS_WIDE_ABL & 2)) { fa[0][3] = *reinterpret_cast<const uint4*>(sb + a_row + 3 * 4096 + koff[2]); } __builtin_amdgcn_sched_barrier(0);
             mfma_fixed<4>(fw[1][0], fa[1][2]);
-            if constexpr (STAGE) bglds16(rsA, pa[4], koffs2, dst0 + 4 * 4096);
+            if constexpr (STAGE && !(VQS_WIDE_ABL & 1)) bglds16(rsA, pa[4], koffs2, dst0 + 4 * 4096);
             mfma_fixed<5>(fw[1][1], fa[1][2]);
-            if constexpr (STAGE) bglds16(rsW, pb[4], koffs2, dst0 + 4 * 4096 + W_OFF);
+            if constexpr (STAGE && !(VQS_WIDE_ABL & 1)) bglds16(rsW, pb[4], koffs2, dst0 + 4 * 4096 + W_OFF);
             mfma_fixed<12>(fw[1][2], fa[1][2]);
-            if constexpr (STAGE) bglds16(rsA, pa[5], koffs2, dst0 + 5 * 4096);
+            if constexpr (STAGE && !(VQS_WIDE_ABL & 1)) bglds16(rsA, pa[5], koffs2, dst0 + 5 * 4096);
             mfma_fixed<13>(fw[1][3], fa[1][2]);
-            if constexpr (STAGE) bglds16(rsW, pb[5], koffs2, dst0 + 5 * 4096 + W_OFF);
+            if constexpr (STAGE && !(VQS_WIDE_ABL & 1)) bglds16(rsW, pb[5], koffs2, dst0 + 5 * 4096 + W_OFF);
             mfma_fixed<6>(fw[1][0], fa[1][3]);
-            if constexpr (STAGE) bglds16(rsA, pa[6], koffs2, dst0 + 6 * 4096);
+            if constexpr (STAGE && !(VQS_WIDE_ABL & 1)) bglds16(rsA, pa[6], koffs2, dst0 + 6 * 4096);
             mfma_fixed<7>(fw[1][1], fa[1][3]);
-            if constexpr (STAGE) bglds16(rsW, pb[6], koffs2, dst0 + 6 * 4096 + W_OFF);
+            if constexpr (STAGE && !(VQS_WIDE_ABL & 1)) bglds16(rsW, pb[6], koffs2, dst0 + 6 * 4096 + W_OFF);
             mfma_fixed<14>(fw[1][2], fa[1][3]);
-            if constexpr (STAGE) bglds16(rsA, pa[7], koffs2, dst0 + 7 * 4096);
+            if constexpr (STAGE && !(VQS_WIDE_ABL & 1)) bglds16(rsA, pa[7], koffs2, dst0 + 7 * 4096);
             mfma_fixed<15>(fw[1][3], fa[1][3]);
-            if constexpr (STAGE) bglds16(rsW, pb[7], koffs2, dst0 + 7 * 4096 + W_OFF);
+            if constexpr (STAGE && !(VQS_WIDE_ABL & 1)) bglds16(rsW, pb[7], koffs2, dst0 + 7 * 4096 + W_OFF);
             // ---- k-step 2 (fragment set 0)
             mfma_fixed<0>(fw[0][0], fa[0][0]);
-            fa[1][0] = *reinterpret_cast<const uint4*>(sb + a_row + 0 * 4096 + koff[3]); __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(VQS_WIDE_ABL & 2)) { fa[1][0] = *reinterpret_cast<const uint4*>(sb + a_row + 0 * 4096 + koff[3]); } __builtin_amdgcn_sched_barrier(0);
             mfma_fixed<1>(fw[0][1], fa[0][0]);
-            fw[1][0] = *reinterpret_cast<const uint4*>(sb + b_row + 0 * 4096 + koff[3]); __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(VQS_WIDE_ABL & 2)) { fw[1][0] = *reinterpret_cast<const uint4*>(sb + b_row + 0 * 4096 + koff[3]); } __builtin_amdgcn_sched_barrier(0);
             mfma_fixed<8>(fw[0][2], fa[0][0]);
-            fw[1][1] = *reinterpret_cast<const uint4*>(sb + b_row + 1 * 4096 + koff[3]); __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(VQS_WIDE_ABL & 2)) { fw[1][1] = *reinterpret_cast<const uint4*>(sb + b_row + 1 * 4096 + koff[3]); } __builtin_amdgcn_sched_barrier(0);
             mfma_fixed<9>(fw[0][3], fa[0][0]);
-            fw[1][2] = *reinterpret_cast<const uint4*>(sb + b_row + 2 * 4096 + koff[3]); __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(VQS_WIDE_ABL & 2)) { fw[1][2] = *reinterpret_cast<const uint4*>(sb + b_row + 2 * 4096 + koff[3]); } __builtin_amdgcn_sched_barrier(0);
             mfma_fixed<2>(fw[0][0], fa[0][1]);
-            fw[1][3] = *reinterpret_cast<const uint4*>(sb + b_row + 3 * 4096 + koff[3]); __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(VQS_WIDE_ABL & 2)) { fw[1][3] = *reinterpret_cast<const uint4*>(sb + b_row + 3 * 4096 + koff[3]); } __builtin_amdgcn_sched_barrier(0);
             mfma_fixed<3>(fw[0][1], fa[0][1]);
-            fa[1][1] = *reinterpret_cast<const uint4*>(sb + a_row + 1 * 4096 + koff[3]); __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(VQS_WIDE_ABL & 2)) { fa[1][1] = *reinterpret_cast<const uint4*>(sb + a_row + 1 * 4096 + koff[3]); } __builtin_amdgcn_sched_barrier(0);
             mfma_fixed<10>(fw[0][2], fa[0][1]);
-            fa[1][2] = *reinterpret_cast<const uint4*>(sb + a_row + 2 * 4096 + koff[3]); __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(VQS_WIDE_ABL & 2)) { fa[1][2] = *reinterpret_cast<const uint4*>(sb + a_row + 2 * 4096 + koff[3]); } __builtin_amdgcn_sched_barrier(0);
             mfma_fixed<11>(fw[0][3], fa[0][1]);
-            fa[1][3] = *reinterpret_cast<const uint4*>(sb + a_row + 3 * 4096 + koff[3]); __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(VQS_WIDE_ABL & 2)) { fa[1][3] = *reinterpret_cast<const uint4*>(sb + a_row + 3 * 4096 + koff[3]); } __builtin_amdgcn_sched_barrier(0);
             mfma_fixed<4>(fw[0][0], fa[0][2]);
             mfma_fixed<5>(fw[0][1], fa[0][2]);
             mfma_fixed<12>(fw[0][2], fa[0][2]);
@@ -1256,21 +1260,21 @@ __global__ void __launch_bounds__(256) gemm_bf16_wide(const GemmParams p) {
                 __builtin_amdgcn_s_barrier();                      // everybody's; and nobody reads stage `buf` any more
             }
             mfma_fixed<4>(fw[1][0], fa[1][2]);
-            if constexpr (!LAST) { fa[0][0] = *reinterpret_cast<const uint4*>(sn + a_row + 0 * 4096 + koff[0]); __builtin_amdgcn_sched_barrier(0); }
+            if constexpr (!LAST) { if constexpr (!(VQS_WIDE_ABL & 2)) { fa[0][0] = *reinterpret_cast<const uint4*>(sn + a_row + 0 * 4096 + koff[0]); } __builtin_amdgcn_sched_barrier(0); }
             mfma_fixed<5>(fw[1][1], fa[1][2]);
-            if constexpr (!LAST) { fw[0][0] = *reinterpret_cast<const uint4*>(sn + b_row + 0 * 4096 + koff[0]); __builtin_amdgcn_sched_barrier(0); }
+            if constexpr (!LAST) { if constexpr (!(VQS_WIDE_ABL & 2)) { fw[0][0] = *reinterpret_cast<const uint4*>(sn + b_row + 0 * 4096 + koff[0]); } __builtin_amdgcn_sched_barrier(0); }
             mfma_fixed<12>(fw[1][2], fa[1][2]);
-            if constexpr (!LAST) { fw[0][1] = *reinterpret_cast<const uint4*>(sn + b_row + 1 * 4096 + koff[0]); __builtin_amdgcn_sched_barrier(0); }
+            if constexpr (!LAST) { if constexpr (!(VQS_WIDE_ABL & 2)) { fw[0][1] = *reinterpret_cast<const uint4*>(sn + b_row + 1 * 4096 + koff[0]); } __builtin_amdgcn_sched_barrier(0); }
             mfma_fixed<13>(fw[1][3], fa[1][2]);
-            if constexpr (!LAST) { fw[0][2] = *reinterpret_cast<const uint4*>(sn + b_row + 2 * 4096 + koff[0]); __builtin_amdgcn_sched_barrier(0); }
+            if constexpr (!LAST) { if constexpr (!(VQS_WIDE_ABL & 2)) { fw[0][2] = *reinterpret_cast<const uint4*>(sn + b_row + 2 * 4096 + koff[0]); } __builtin_amdgcn_sched_barrier(0); }
             mfma_fixed<6>(fw[1][0], fa[1][3]);
-            if constexpr (!LAST) { fw[0][3] = *reinterpret_cast<const uint4*>(sn + b_row + 3 * 4096 + koff[0]); __builtin_amdgcn_sched_barrier(0); }
+            if constexpr (!LAST) { if constexpr (!(VQS_WIDE_ABL & 2)) { fw[0][3] = *reinterpret_cast<const uint4*>(sn + b_row + 3 * 4096 + koff[0]); } __builtin_amdgcn_sched_barrier(0); }
             mfma_fixed<7>(fw[1][1], fa[1][3]);
-            if constexpr (!LAST) { fa[0][1] = *reinterpret_cast<const uint4*>(sn + a_row + 1 * 4096 + koff[0]); __builtin_amdgcn_sched_barrier(0); }
+            if constexpr (!LAST) { if constexpr (!(VQS_WIDE_ABL & 2)) { fa[0][1] = *reinterpret_cast<const uint4*>(sn + a_row + 1 * 4096 + koff[0]); } __builtin_amdgcn_sched_barrier(0); }
             mfma_fixed<14>(fw[1][2], fa[1][3]);
-            if constexpr (!LAST) { fa[0][2] = *reinterpret_cast<const uint4*>(sn + a_row + 2 * 4096 + koff[0]); __builtin_amdgcn_sched_barrier(0); }
+            if constexpr (!LAST) { if constexpr (!(VQS_WIDE_ABL & 2)) { fa[0][2] = *reinterpret_cast<const uint4*>(sn + a_row + 2 * 4096 + koff[0]); } __builtin_amdgcn_sched_barrier(0); }
             mfma_fixed<15>(fw[1][3], fa[1][3]);
-            if constexpr (!LAST) { fa[0][3] = *reinterpret_cast<const uint4*>(sn + a_row + 3 * 4096 + koff[0]); __builtin_amdgcn_sched_barrier(0); }
+            if constexpr (!LAST) { if constexpr (!(VQS_WIDE_ABL & 2)) { fa[0][3] = *reinterpret_cast<const uint4*>(sn + a_row + 3 * 4096 + koff[0]); } __builtin_amdgcn_sched_barrier(0); }
             buf ^= 1;
         };
 
@@ -1286,14 +1290,14 @@ __global__ void __launch_bounds__(256) gemm_bf16_wide(const GemmParams p) {
         __builtin_amdgcn_s_barrier();
         {
             const char* s0 = lds + buf * STAGE_BYTES;
-            fa[0][0] = *reinterpret_cast<const uint4*>(s0 + a_row + 0 * 4096 + koff[0]); __builtin_amdgcn_sched_barrier(0);
-            fw[0][0] = *reinterpret_cast<const uint4*>(s0 + b_row + 0 * 4096 + koff[0]); __builtin_amdgcn_sched_barrier(0);
-            fw[0][1] = *reinterpret_cast<const uint4*>(s0 + b_row + 1 * 4096 + koff[0]); __builtin_amdgcn_sched_barrier(0);
-            fw[0][2] = *reinterpret_cast<const uint4*>(s0 + b_row + 2 * 4096 + koff[0]); __builtin_amdgcn_sched_barrier(0);
-            fw[0][3] = *reinterpret_cast<const uint4*>(s0 + b_row + 3 * 4096 + koff[0]); __builtin_amdgcn_sched_barrier(0);
-            fa[0][1] = *reinterpret_cast<const uint4*>(s0 + a_row + 1 * 4096 + koff[0]); __builtin_amdgcn_sched_barrier(0);
-            fa[0][2] = *reinterpret_cast<const uint4*>(s0 + a_row + 2 * 4096 + koff[0]); __builtin_amdgcn_sched_barrier(0);
-            fa[0][3] = *reinterpret_cast<const uint4*>(s0 + a_row + 3 * 4096 + koff[0]); __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(VQS_WIDE_ABL & 2)) { fa[0][0] = *reinterpret_cast<const uint4*>(s0 + a_row + 0 * 4096 + koff[0]); } __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(VQS_WIDE_ABL & 2)) { fw[0][0] = *reinterpret_cast<const uint4*>(s0 + b_row + 0 * 4096 + koff[0]); } __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(VQS_WIDE_ABL & 2)) { fw[0][1] = *reinterpret_cast<const uint4*>(s0 + b_row + 1 * 4096 + koff[0]); } __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(VQS_WIDE_ABL & 2)) { fw[0][2] = *reinterpret_cast<const uint4*>(s0 + b_row + 2 * 4096 + koff[0]); } __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(VQS_WIDE_ABL & 2)) { fw[0][3] = *reinterpret_cast<const uint4*>(s0 + b_row + 3 * 4096 + koff[0]); } __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(VQS_WIDE_ABL & 2)) { fa[0][1] = *reinterpret_cast<const uint4*>(s0 + a_row + 1 * 4096 + koff[0]); } __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(VQS_WIDE_ABL & 2)) { fa[0][2] = *reinterpret_cast<const uint4*>(s0 + a_row + 2 * 4096 + koff[0]); } __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(VQS_WIDE_ABL & 2)) { fa[0][3] = *reinterpret_cast<const uint4*>(s0 + a_row + 3 * 4096 + koff[0]); } __builtin_amdgcn_sched_barrier(0);
         }
 
         constexpr std::true_type YES{};

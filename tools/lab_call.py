@@ -259,6 +259,22 @@ def main():
     if "WIX" in parts:
         in_situ("clip-flant5-xl", [("8-wave forms (variant 3)", "product", {"gemm_variant": 3}), ("wide form (variant 6)", "product", {"gemm_variant": 6})],
                 steps=4, rounds=2, tag="WIX")
+    if "WA" in parts:                                            # timing ablations of the wide form (lab builds; results are garbage by design)
+        g = torch.Generator(device="cuda").manual_seed(0)
+        libs = [("product", engine.load_library())] + [(n, engine.load_library(os.path.join(ROOT, "build", "lab", "libvqs_%s.so" % n)))
+                                                       for n in ("wide_abl1", "wide_abl2", "wide_abl3") if os.path.exists(os.path.join(ROOT, "build", "lab", "libvqs_%s.so" % n))]
+        for tag, M, N, K, epi, S, H, has_bias in [XXL[0], XXL[3], VIT[1]]:
+            A = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+            W = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(torch.bfloat16)
+            out = engine.gemm(A, W, 0, variant=3)
+            res = {}
+            for name, lib in libs:
+                for v in ((3, 6) if name == "product" else (6,)):
+                    def call(lib=lib, v=v):
+                        lib.vqs_gemm(A.data_ptr(), W.data_ptr(), out.data_ptr(), None, None, M, N, K, K, K, N, 0, 0, 0, v, torch.cuda.current_stream().cuda_stream)
+                    res["%s v%d" % (name, v)] = [round(2.0 * M * N * K / time_ms(call, 5) / 1e9, 1) for _ in range(2)]
+            emit({"part": "WA", "shape": tag, "tflops_plain_epilogue": res})
+            del A, W, out
     if "V" in parts:                                             # lock-step (launcher's rule) vs forced ping-pong schedule, ViT shapes
         g = torch.Generator(device="cuda").manual_seed(0)
         for tag, M, N, K, epi, S, H, has_bias in VIT + [("projector.0", 147456, 4096, 1024, 2, 0, 0, True)]:
