@@ -259,6 +259,40 @@ def main():
     if "WIX" in parts:
         in_situ("clip-flant5-xl", [("8-wave forms (variant 3)", "product", {"gemm_variant": 3}), ("wide form (variant 6)", "product", {"gemm_variant": 6})],
                 steps=4, rounds=2, tag="WIX")
+    if "R" in parts:                                             # ring form (variant 8, lab library: VQS_LIB_PATH=build/lab/libvqs_hip_lab.so): bitwise check, then rate
+        from tests.gpu_util import randn_bf16
+        bad = []
+        for M, N, K, epi, S, H in [(33000, 2048, 64, 0, 0, 0), (33000 - 7, 2048 - 8, 128, 0, 0, 0), (20000, 4096, 1024, 1, 0, 0), (147456 // 4, 2048, 1024, 2, 0, 0),
+                                   (16384, 8192, 256, 5, 0, 0), (608 * 40, 3 * 1024, 192, 6, 608, 16), (577 * 64, 3 * 1024, 128, 6, 577, 16), (131072, 512, 2048, 0, 0, 0),
+                                   (70000, 512, 64, 0, 0, 0), (256 * 300 + 1, 256, 320, 0, 0, 0)]:
+            A = randn_bf16(M, K, seed=81)
+            W = randn_bf16(N, K, seed=82, scale=K ** -0.5)
+            bias = randn_bf16(N, seed=83) if epi in (0, 1, 2, 6) else None
+            ref = engine.gemm(A, W, epi, bias=bias, S=S, H=H, variant=0)
+            for rep in range(3):
+                for order in (None, (4, 2), (2, 1)):
+                    out = engine.gemm(A, W, epi, bias=bias, S=S, H=H, variant=8, tile_order=order)
+                    if not torch.equal(out, ref):
+                        d = (out.float() - ref.float()).abs()
+                        bad.append({"shape": [M, N, K, epi], "rep": rep, "order": order, "max_abs_diff": d.max().item(), "frac": (d > 0).float().mean().item()})
+            del A, W, ref
+        emit({"part": "R", "bitwise_check": "ok" if not bad else "MISMATCH", "mismatches": bad[:8]})
+        g = torch.Generator(device="cuda").manual_seed(0)
+        for tag, M, N, K, epi, S, H, has_bias in XXL + XL + VIT:
+            A = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+            W = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(torch.bfloat16)
+            bias = torch.randn(N, device="cuda", generator=g).to(torch.bfloat16) if has_bias else None
+            outs = {v: engine.gemm(A, W, epi, bias=bias, S=S, H=H, variant=v) for v in (3, 6, 8)}
+            ref = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+            res = {}
+            for rnd in range(2):
+                for v, o in outs.items():
+                    ms = time_ms(lambda: engine.gemm(A, W, epi, bias=bias, out=o, S=S, H=H, variant=v), 5)
+                    res.setdefault("variant%d" % v, []).append(round(2.0 * M * N * K / ms / 1e9, 1))
+                res.setdefault("torch_matmul_no_epilogue", []).append(round(2.0 * M * N * K / time_ms(lambda: torch.matmul(A, W.t(), out=ref), 5) / 1e9, 1))
+            emit({"part": "R", "shape": tag, "N": N, "K": K, "epilogue": epi, "tflops": res, "bitwise_equal_3_6_8": bool(torch.equal(outs[3], outs[6]) and torch.equal(outs[3], outs[8]))})
+            del A, W, outs, ref
+            torch.cuda.empty_cache()
     if "WA" in parts:                                            # timing ablations of the wide form (lab builds; results are garbage by design)
         g = torch.Generator(device="cuda").manual_seed(0)
         libs = [("product", engine.load_library())] + [(n, engine.load_library(os.path.join(ROOT, "build", "lab", "libvqs_%s.so" % n)))
