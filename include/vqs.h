@@ -137,7 +137,7 @@ const char* vqs_profile_report(vqs_handle* h);
 /* ---- single-kernel entry points (parity tests and micro-benchmarks call the kernels through these) ---- */
 /* epilogue: 0 bf16, 1 bf16+quick_gelu, 2 bf16+erf-gelu, 3 fp32, 4 fp32 + residual, 5 gated gelu_new (W rows
  * interleaved per 32: wi_0 block then wi_1 block; C is [M, N/2]), 6 head-major scatter (q/k/v = C, C+B*H*S*64, ...)
- * variant (bits 0-7): 0 one tile per workgroup, 2 / 5 ping-pong, 3 persistent (engine default); bits 8-15 = gm, bits 16-23 = ns:
+ * variant (bits 0-7): 0 one tile per workgroup, 2 / 5 ping-pong, 3 persistent (engine default), 6 four-wave wide form; bits 8-15 = gm, bits 16-23 = ns:
  * the workgroup -> tile ORDER (groups of gm M-tiles x all N-tiles, N cut into ns column ranges walked one after the other;
  * 0 = the default 8 / 1).  The order only permutes which workgroup computes a tile when: results are bitwise identical. */
 int vqs_gemm(const void* d_A, const void* d_W, void* d_C, const void* d_bias, const float* d_resid, int32_t M, int32_t N,
@@ -198,7 +198,8 @@ int vqs_score_head(const float* d_logits, int32_t ldl, int32_t V, const int32_t*
  *   "splitk"       1 (default) split-K for the decoder's skinny nn.Linear GEMMs, 0 single GEMMs
  *   "norm_defer"   1 (default) deferred store of the fp32 stream in the norm kernels (bitwise equal), 0 store in every norm
  *   "fused_norm"   0 (default) separate add+norm kernels, 1 residual update + RMSNorm operand in the o / wo GEMM epilogues
- *   "gemm_variant" 3 (default) persistent kernels, 0 one tile per workgroup, 2 / 5 ping-pong schedule
+ *   "gemm_variant" 3 (default) persistent 8-wave kernels, 0 one tile per workgroup, 2 / 5 ping-pong schedule, 6 the four-wave
+ *                  128x128 form for the big bf16-result launches (everything else of the pass runs the default forms); all bitwise equal
  *   "tile_order:<N>x<K>"  value = gm | ns << 8: tile order (see vqs_gemm) of every GEMM of a pass whose weight is [N, K];
  *                  0 removes the entry (back to the library's choice for that shape).  Bitwise-neutral.
  *   "l2_touch:<N>x<K>"    1: the lock-step GEMM prefetches the A panel two K-tiles ahead into L2 for the big launches whose weight is
