@@ -1065,6 +1065,7 @@ __device__ __forceinline__ void acc_read(f32x16& out) {
     for (int r = 0; r < 16; ++r) out[r] = t[r];
 }
 
+__host__ __device__ constexpr int wide_acc_idx(int j) { return ((((j) & 3) >> 1) * 4 + ((j) >> 2)) * 2 + ((j) & 1); }   // MFMA j of a k-step -> AGPR tuple
 // VQS_WIDE_ABL (timing ablations, lab builds only; results are then garbage): 1 = no LDS-DMA in the K loop, 2 = no fragment reads
 #ifndef VQS_WIDE_ABL
 #define VQS_WIDE_ABL 0
@@ -1148,6 +1149,32 @@ __global__ void __launch_bounds__(256) gemm_bf16_wide(const GemmParams p) {
         //   FIRST: first K-tile of an output tile, its k-step 0 writes the accumulators with C = 0.
         // Read order A0 W0 W1 W2 W3 A1 A2 A3 = the order the next k-step's first MFMAs need them.
         uint4 fa[2][4], fw[2][4];
+        // read R of k-step KS of the K-tile at SBASE into fragment set ST (order A0 W0 W1 W2 W3 A1 A2 A3); sched_barrier pins it
+#define WD_RDA(ST, M, SBASE, KS) if constexpr (!(VQS_WIDE_ABL & 2)) { fa[ST][M] = *reinterpret_cast<const uint4*>((SBASE) + a_row + (M) * 4096 + koff[KS]); } __builtin_amdgcn_sched_barrier(0)
+#define WD_RDW(ST, N, SBASE, KS) if constexpr (!(VQS_WIDE_ABL & 2)) { fw[ST][N] = *reinterpret_cast<const uint4*>((SBASE) + b_row + (N) * 4096 + koff[KS]); } __builtin_amdgcn_sched_barrier(0)
+#define WD_RD_0(ST, SBASE, KS) WD_RDA(ST, 0, SBASE, KS)
+#define WD_RD_1(ST, SBASE, KS) WD_RDW(ST, 0, SBASE, KS)
+#define WD_RD_2(ST, SBASE, KS) WD_RDW(ST, 1, SBASE, KS)
+#define WD_RD_3(ST, SBASE, KS) WD_RDW(ST, 2, SBASE, KS)
+#define WD_RD_4(ST, SBASE, KS) WD_RDW(ST, 3, SBASE, KS)
+#define WD_RD_5(ST, SBASE, KS) WD_RDA(ST, 1, SBASE, KS)
+#define WD_RD_6(ST, SBASE, KS) WD_RDA(ST, 2, SBASE, KS)
+#define WD_RD_7(ST, SBASE, KS) WD_RDA(ST, 3, SBASE, KS)
+#define WD_RD(ST, R, SBASE, KS) WD_RD_##R(ST, SBASE, KS)
+        // MFMA J of a k-step on set ST: row block J >> 2, column block J & 3 -> accumulator wide_acc_idx(J); ZERO: the C = 0 form
+#define WD_MFMA(ST, J, ZERO)                                                                                  \
+    do {                                                                                                      \
+        if constexpr (ZERO) mfma_fixed_zero<wide_acc_idx(J)>(fw[ST][(J) & 3], fa[ST][(J) >> 2]);              \
+        else mfma_fixed<wide_acc_idx(J)>(fw[ST][(J) & 3], fa[ST][(J) >> 2]);                                  \
+    } while (0)
+        // LDS-DMA instruction D = 0..15 of the next K-tile: even -> A piece D / 2, odd -> W piece D / 2
+#define WD_DMA(D)                                                                                             \
+    do {                                                                                                      \
+        if constexpr (STAGE && !(VQS_WIDE_ABL & 1)) {                                                         \
+            if (((D) & 1) == 0) bglds16(rsA, pa[(D) >> 1], koffs2, dst0 + ((D) >> 1) * 4096);                 \
+            else bglds16(rsW, pb[(D) >> 1], koffs2, dst0 + ((D) >> 1) * 4096 + W_OFF);                        \
+        }                                                                                                     \
+    } while (0)
         auto ktile = [&](auto stage_tag, auto last_tag, auto first_tag, uint32_t koffs2) {
             constexpr bool STAGE = decltype(stage_tag)::value;
             constexpr bool LAST = decltype(last_tag)::value;
@@ -1155,126 +1182,38 @@ __global__ void __launch_bounds__(256) gemm_bf16_wide(const GemmParams p) {
             const uint32_t dst0 = lds_base + (buf ^ 1) * STAGE_BYTES + w * 1024;
             const char* sb = lds + buf * STAGE_BYTES;
             const char* sn = lds + (buf ^ 1) * STAGE_BYTES;
-            // ---- k-step 0 (fragment set 0)
-            if constexpr (FIRST) mfma_fixed_zero<0>(fw[0][0], fa[0][0]); else mfma_fixed<0>(fw[0][0], fa[0][0]);
-            if constexpr (!(VQS_WIDE_ABL & 2)) { fa[1][0] = *reinterpret_cast<const uint4*>(sb + a_row + 0 * 4096 + koff[1]); } __builtin_amdgcn_sched_barrier(0);
-            if constexpr (FIRST) mfma_fixed_zero<1>(fw[0][1], fa[0][0]); else mfma_fixed<1>(fw[0][1], fa[0][0]);
-            if constexpr (!(VQS_WIDE_ABL & 2)) { fw[1][0] = *reinterpret_cast<const uint4*>(sb + b_row + 0 * 4096 + koff[1]); } __builtin_amdgcn_sched_barrier(0);
-            if constexpr (FIRST) mfma_fixed_zero<8>(fw[0][2], fa[0][0]); else mfma_fixed<8>(fw[0][2], fa[0][0]);
-            if constexpr (!(VQS_WIDE_ABL & 2)) { fw[1][1] = *reinterpret_cast<const uint4*>(sb + b_row + 1 * 4096 + koff[1]); } __builtin_amdgcn_sched_barrier(0);
-            if constexpr (FIRST) mfma_fixed_zero<9>(fw[0][3], fa[0][0]); else mfma_fixed<9>(fw[0][3], fa[0][0]);
-            if constexpr (!(VQS_WIDE_ABL & 2)) { fw[1][2] = *reinterpret_cast<const uint4*>(sb + b_row + 2 * 4096 + koff[1]); } __builtin_amdgcn_sched_barrier(0);
-            if constexpr (FIRST) mfma_fixed_zero<2>(fw[0][0], fa[0][1]); else mfma_fixed<2>(fw[0][0], fa[0][1]);
-            if constexpr (!(VQS_WIDE_ABL & 2)) { fw[1][3] = *reinterpret_cast<const uint4*>(sb + b_row + 3 * 4096 + koff[1]); } __builtin_amdgcn_sched_barrier(0);
-            if constexpr (FIRST) mfma_fixed_zero<3>(fw[0][1], fa[0][1]); else mfma_fixed<3>(fw[0][1], fa[0][1]);
-            if constexpr (!(VQS_WIDE_ABL & 2)) { fa[1][1] = *reinterpret_cast<const uint4*>(sb + a_row + 1 * 4096 + koff[1]); } __builtin_amdgcn_sched_barrier(0);
-            if constexpr (FIRST) mfma_fixed_zero<10>(fw[0][2], fa[0][1]); else mfma_fixed<10>(fw[0][2], fa[0][1]);
-            if constexpr (!(VQS_WIDE_ABL & 2)) { fa[1][2] = *reinterpret_cast<const uint4*>(sb + a_row + 2 * 4096 + koff[1]); } __builtin_amdgcn_sched_barrier(0);
-            if constexpr (FIRST) mfma_fixed_zero<11>(fw[0][3], fa[0][1]); else mfma_fixed<11>(fw[0][3], fa[0][1]);
-            if constexpr (!(VQS_WIDE_ABL & 2)) { fa[1][3] = *reinterpret_cast<const uint4*>(sb + a_row + 3 * 4096 + koff[1]); } __builtin_amdgcn_sched_barrier(0);
-            if constexpr (FIRST) mfma_fixed_zero<4>(fw[0][0], fa[0][2]); else mfma_fixed<4>(fw[0][0], fa[0][2]);
-            if constexpr (STAGE && !(VQS_WIDE_ABL & 1)) bglds16(rsA, pa[0], koffs2, dst0 + 0 * 4096);
-            if constexpr (FIRST) mfma_fixed_zero<5>(fw[0][1], fa[0][2]); else mfma_fixed<5>(fw[0][1], fa[0][2]);
-            if constexpr (STAGE && !(VQS_WIDE_ABL & 1)) bglds16(rsW, pb[0], koffs2, dst0 + 0 * 4096 + W_OFF);
-            if constexpr (FIRST) mfma_fixed_zero<12>(fw[0][2], fa[0][2]); else mfma_fixed<12>(fw[0][2], fa[0][2]);
-            if constexpr (STAGE && !(VQS_WIDE_ABL & 1)) bglds16(rsA, pa[1], koffs2, dst0 + 1 * 4096);
-            if constexpr (FIRST) mfma_fixed_zero<13>(fw[0][3], fa[0][2]); else mfma_fixed<13>(fw[0][3], fa[0][2]);
-            if constexpr (STAGE && !(VQS_WIDE_ABL & 1)) bglds16(rsW, pb[1], koffs2, dst0 + 1 * 4096 + W_OFF);
-            if constexpr (FIRST) mfma_fixed_zero<6>(fw[0][0], fa[0][3]); else mfma_fixed<6>(fw[0][0], fa[0][3]);
-            if constexpr (STAGE && !(VQS_WIDE_ABL & 1)) bglds16(rsA, pa[2], koffs2, dst0 + 2 * 4096);
-            if constexpr (FIRST) mfma_fixed_zero<7>(fw[0][1], fa[0][3]); else mfma_fixed<7>(fw[0][1], fa[0][3]);
-            if constexpr (STAGE && !(VQS_WIDE_ABL & 1)) bglds16(rsW, pb[2], koffs2, dst0 + 2 * 4096 + W_OFF);
-            if constexpr (FIRST) mfma_fixed_zero<14>(fw[0][2], fa[0][3]); else mfma_fixed<14>(fw[0][2], fa[0][3]);
-            if constexpr (STAGE && !(VQS_WIDE_ABL & 1)) bglds16(rsA, pa[3], koffs2, dst0 + 3 * 4096);
-            if constexpr (FIRST) mfma_fixed_zero<15>(fw[0][3], fa[0][3]); else mfma_fixed<15>(fw[0][3], fa[0][3]);
-            if constexpr (STAGE && !(VQS_WIDE_ABL & 1)) bglds16(rsW, pb[3], koffs2, dst0 + 3 * 4096 + W_OFF);
-            // ---- k-step 1 (fragment set 1)
-            mfma_fixed<0>(fw[1][0], fa[1][0]);
-            if constexpr (!(VQS_WIDE_ABL & 2)) { fa[0][0] = *reinterpret_cast<const uint4*>(sb + a_row + 0 * 4096 + koff[2]); } __builtin_amdgcn_sched_barrier(0);
-            mfma_fixed<1>(fw[1][1], fa[1][0]);
-            if constexpr (!(VQS_WIDE_ABL & 2)) { fw[0][0] = *reinterpret_cast<const uint4*>(sb + b_row + 0 * 4096 + koff[2]); } __builtin_amdgcn_sched_barrier(0);
-            mfma_fixed<8>(fw[1][2], fa[1][0]);
-            if constexpr (!(VQS_WIDE_ABL & 2)) { fw[0][1] = *reinterpret_cast<const uint4*>(sb + b_row + 1 * 4096 + koff[2]); } __builtin_amdgcn_sched_barrier(0);
-            mfma_fixed<9>(fw[1][3], fa[1][0]);
-            if constexpr (!(VQS_WIDE_ABL & 2)) { fw[0][2] = *reinterpret_cast<const uint4*>(sb + b_row + 2 * 4096 + koff[2]); } __builtin_amdgcn_sched_barrier(0);
-            mfma_fixed<2>(fw[1][0], fa[1][1]);
-            if constexpr (!(VQS_WIDE_ABL & 2)) { fw[0][3] = *reinterpret_cast<const uint4*>(sb + b_row + 3 * 4096 + koff[2]); } __builtin_amdgcn_sched_barrier(0);
-            mfma_fixed<3>(fw[1][1], fa[1][1]);
-            if constexpr (!(VQS_WIDE_ABL & 2)) { fa[0][1] = *reinterpret_cast<const uint4*>(sb + a_row + 1 * 4096 + koff[2]); } __builtin_amdgcn_sched_barrier(0);
-            mfma_fixed<10>(fw[1][2], fa[1][1]);
-            if constexpr (!(VQS_WIDE_ABL & 2)) { fa[0][2] = *reinterpret_cast<const uint4*>(sb + a_row + 2 * 4096 + koff[2]); } __builtin_amdgcn_sched_barrier(0);
-            mfma_fixed<11>(fw[1][3], fa[1][1]);
-            if constexpr (!(VQS_WIDE_ABL & 2)) { fa[0][3] = *reinterpret_cast<const uint4*>(sb + a_row + 3 * 4096 + koff[2]); } __builtin_amdgcn_sched_barrier(0);
-            mfma_fixed<4>(fw[1][0], fa[1][2]);
-            if constexpr (STAGE && !(VQS_WIDE_ABL & 1)) bglds16(rsA, pa[4], koffs2, dst0 + 4 * 4096);
-            mfma_fixed<5>(fw[1][1], fa[1][2]);
-            if constexpr (STAGE && !(VQS_WIDE_ABL & 1)) bglds16(rsW, pb[4], koffs2, dst0 + 4 * 4096 + W_OFF);
-            mfma_fixed<12>(fw[1][2], fa[1][2]);
-            if constexpr (STAGE && !(VQS_WIDE_ABL & 1)) bglds16(rsA, pa[5], koffs2, dst0 + 5 * 4096);
-            mfma_fixed<13>(fw[1][3], fa[1][2]);
-            if constexpr (STAGE && !(VQS_WIDE_ABL & 1)) bglds16(rsW, pb[5], koffs2, dst0 + 5 * 4096 + W_OFF);
-            mfma_fixed<6>(fw[1][0], fa[1][3]);
-            if constexpr (STAGE && !(VQS_WIDE_ABL & 1)) bglds16(rsA, pa[6], koffs2, dst0 + 6 * 4096);
-            mfma_fixed<7>(fw[1][1], fa[1][3]);
-            if constexpr (STAGE && !(VQS_WIDE_ABL & 1)) bglds16(rsW, pb[6], koffs2, dst0 + 6 * 4096 + W_OFF);
-            mfma_fixed<14>(fw[1][2], fa[1][3]);
-            if constexpr (STAGE && !(VQS_WIDE_ABL & 1)) bglds16(rsA, pa[7], koffs2, dst0 + 7 * 4096);
-            mfma_fixed<15>(fw[1][3], fa[1][3]);
-            if constexpr (STAGE && !(VQS_WIDE_ABL & 1)) bglds16(rsW, pb[7], koffs2, dst0 + 7 * 4096 + W_OFF);
-            // ---- k-step 2 (fragment set 0)
-            mfma_fixed<0>(fw[0][0], fa[0][0]);
-            if constexpr (!(VQS_WIDE_ABL & 2)) { fa[1][0] = *reinterpret_cast<const uint4*>(sb + a_row + 0 * 4096 + koff[3]); } __builtin_amdgcn_sched_barrier(0);
-            mfma_fixed<1>(fw[0][1], fa[0][0]);
-            if constexpr (!(VQS_WIDE_ABL & 2)) { fw[1][0] = *reinterpret_cast<const uint4*>(sb + b_row + 0 * 4096 + koff[3]); } __builtin_amdgcn_sched_barrier(0);
-            mfma_fixed<8>(fw[0][2], fa[0][0]);
-            if constexpr (!(VQS_WIDE_ABL & 2)) { fw[1][1] = *reinterpret_cast<const uint4*>(sb + b_row + 1 * 4096 + koff[3]); } __builtin_amdgcn_sched_barrier(0);
-            mfma_fixed<9>(fw[0][3], fa[0][0]);
-            if constexpr (!(VQS_WIDE_ABL & 2)) { fw[1][2] = *reinterpret_cast<const uint4*>(sb + b_row + 2 * 4096 + koff[3]); } __builtin_amdgcn_sched_barrier(0);
-            mfma_fixed<2>(fw[0][0], fa[0][1]);
-            if constexpr (!(VQS_WIDE_ABL & 2)) { fw[1][3] = *reinterpret_cast<const uint4*>(sb + b_row + 3 * 4096 + koff[3]); } __builtin_amdgcn_sched_barrier(0);
-            mfma_fixed<3>(fw[0][1], fa[0][1]);
-            if constexpr (!(VQS_WIDE_ABL & 2)) { fa[1][1] = *reinterpret_cast<const uint4*>(sb + a_row + 1 * 4096 + koff[3]); } __builtin_amdgcn_sched_barrier(0);
-            mfma_fixed<10>(fw[0][2], fa[0][1]);
-            if constexpr (!(VQS_WIDE_ABL & 2)) { fa[1][2] = *reinterpret_cast<const uint4*>(sb + a_row + 2 * 4096 + koff[3]); } __builtin_amdgcn_sched_barrier(0);
-            mfma_fixed<11>(fw[0][3], fa[0][1]);
-            if constexpr (!(VQS_WIDE_ABL & 2)) { fa[1][3] = *reinterpret_cast<const uint4*>(sb + a_row + 3 * 4096 + koff[3]); } __builtin_amdgcn_sched_barrier(0);
-            mfma_fixed<4>(fw[0][0], fa[0][2]);
-            mfma_fixed<5>(fw[0][1], fa[0][2]);
-            mfma_fixed<12>(fw[0][2], fa[0][2]);
-            mfma_fixed<13>(fw[0][3], fa[0][2]);
-            mfma_fixed<6>(fw[0][0], fa[0][3]);
-            mfma_fixed<7>(fw[0][1], fa[0][3]);
-            mfma_fixed<14>(fw[0][2], fa[0][3]);
-            mfma_fixed<15>(fw[0][3], fa[0][3]);
-            // ---- k-step 3 (fragment set 1)
-            mfma_fixed<0>(fw[1][0], fa[1][0]);
-            mfma_fixed<1>(fw[1][1], fa[1][0]);
-            mfma_fixed<8>(fw[1][2], fa[1][0]);
-            mfma_fixed<9>(fw[1][3], fa[1][0]);
-            mfma_fixed<2>(fw[1][0], fa[1][1]);
-            mfma_fixed<3>(fw[1][1], fa[1][1]);
-            mfma_fixed<10>(fw[1][2], fa[1][1]);
-            mfma_fixed<11>(fw[1][3], fa[1][1]);
+            // ---- k-step 0 (set 0): reads of k-step 1 -> set 1, then DMA instructions 0..7
+#define WD_A(J) WD_MFMA(0, J, FIRST); WD_RD(1, J, sb, 1);
+#define WD_B(J, D) WD_MFMA(0, J, FIRST); WD_DMA(D);
+            WD_A(0) WD_A(1) WD_A(2) WD_A(3) WD_A(4) WD_A(5) WD_A(6) WD_A(7)
+            WD_B(8, 0) WD_B(9, 1) WD_B(10, 2) WD_B(11, 3) WD_B(12, 4) WD_B(13, 5) WD_B(14, 6) WD_B(15, 7)
+#undef WD_A
+#undef WD_B
+            // ---- k-step 1 (set 1): reads of k-step 2 -> set 0, then DMA instructions 8..15
+#define WD_A(J) WD_MFMA(1, J, false); WD_RD(0, J, sb, 2);
+#define WD_B(J, D) WD_MFMA(1, J, false); WD_DMA(D);
+            WD_A(0) WD_A(1) WD_A(2) WD_A(3) WD_A(4) WD_A(5) WD_A(6) WD_A(7)
+            WD_B(8, 8) WD_B(9, 9) WD_B(10, 10) WD_B(11, 11) WD_B(12, 12) WD_B(13, 13) WD_B(14, 14) WD_B(15, 15)
+#undef WD_A
+#undef WD_B
+            // ---- k-step 2 (set 0): reads of k-step 3 -> set 1
+#define WD_A(J) WD_MFMA(0, J, false); WD_RD(1, J, sb, 3);
+#define WD_B(J) WD_MFMA(0, J, false);
+            WD_A(0) WD_A(1) WD_A(2) WD_A(3) WD_A(4) WD_A(5) WD_A(6) WD_A(7)
+            WD_B(8) WD_B(9) WD_B(10) WD_B(11) WD_B(12) WD_B(13) WD_B(14) WD_B(15)
+#undef WD_A
+#undef WD_B
+            // ---- k-step 3 (set 1): 8 MFMAs, the K-tile boundary, 8 MFMAs each followed by a read of the next K-tile's set 0
+#define WD_A(J) WD_MFMA(1, J, false);
+#define WD_B(J, R) WD_MFMA(1, J, false); if constexpr (!LAST) { WD_RD(0, R, sn, 0); }
+            WD_A(0) WD_A(1) WD_A(2) WD_A(3) WD_A(4) WD_A(5) WD_A(6) WD_A(7)
             if constexpr (!LAST) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own pieces of the next K-tile (issued >= 1.5 k-steps ago)
                 __builtin_amdgcn_s_barrier();                      // everybody's; and nobody reads stage `buf` any more
             }
-            mfma_fixed<4>(fw[1][0], fa[1][2]);
-            if constexpr (!LAST) { if constexpr (!(VQS_WIDE_ABL & 2)) { fa[0][0] = *reinterpret_cast<const uint4*>(sn + a_row + 0 * 4096 + koff[0]); } __builtin_amdgcn_sched_barrier(0); }
-            mfma_fixed<5>(fw[1][1], fa[1][2]);
-            if constexpr (!LAST) { if constexpr (!(VQS_WIDE_ABL & 2)) { fw[0][0] = *reinterpret_cast<const uint4*>(sn + b_row + 0 * 4096 + koff[0]); } __builtin_amdgcn_sched_barrier(0); }
-            mfma_fixed<12>(fw[1][2], fa[1][2]);
-            if constexpr (!LAST) { if constexpr (!(VQS_WIDE_ABL & 2)) { fw[0][1] = *reinterpret_cast<const uint4*>(sn + b_row + 1 * 4096 + koff[0]); } __builtin_amdgcn_sched_barrier(0); }
-            mfma_fixed<13>(fw[1][3], fa[1][2]);
-            if constexpr (!LAST) { if constexpr (!(VQS_WIDE_ABL & 2)) { fw[0][2] = *reinterpret_cast<const uint4*>(sn + b_row + 2 * 4096 + koff[0]); } __builtin_amdgcn_sched_barrier(0); }
-            mfma_fixed<6>(fw[1][0], fa[1][3]);
-            if constexpr (!LAST) { if constexpr (!(VQS_WIDE_ABL & 2)) { fw[0][3] = *reinterpret_cast<const uint4*>(sn + b_row + 3 * 4096 + koff[0]); } __builtin_amdgcn_sched_barrier(0); }
-            mfma_fixed<7>(fw[1][1], fa[1][3]);
-            if constexpr (!LAST) { if constexpr (!(VQS_WIDE_ABL & 2)) { fa[0][1] = *reinterpret_cast<const uint4*>(sn + a_row + 1 * 4096 + koff[0]); } __builtin_amdgcn_sched_barrier(0); }
-            mfma_fixed<14>(fw[1][2], fa[1][3]);
-            if constexpr (!LAST) { if constexpr (!(VQS_WIDE_ABL & 2)) { fa[0][2] = *reinterpret_cast<const uint4*>(sn + a_row + 2 * 4096 + koff[0]); } __builtin_amdgcn_sched_barrier(0); }
-            mfma_fixed<15>(fw[1][3], fa[1][3]);
-            if constexpr (!LAST) { if constexpr (!(VQS_WIDE_ABL & 2)) { fa[0][3] = *reinterpret_cast<const uint4*>(sn + a_row + 3 * 4096 + koff[0]); } __builtin_amdgcn_sched_barrier(0); }
+            WD_B(8, 0) WD_B(9, 1) WD_B(10, 2) WD_B(11, 3) WD_B(12, 4) WD_B(13, 5) WD_B(14, 6) WD_B(15, 7)
+#undef WD_A
+#undef WD_B
             buf ^= 1;
         };
 
@@ -1290,14 +1229,8 @@ __global__ void __launch_bounds__(256) gemm_bf16_wide(const GemmParams p) {
         __builtin_amdgcn_s_barrier();
         {
             const char* s0 = lds + buf * STAGE_BYTES;
-            if constexpr (!(VQS_WIDE_ABL & 2)) { fa[0][0] = *reinterpret_cast<const uint4*>(s0 + a_row + 0 * 4096 + koff[0]); } __builtin_amdgcn_sched_barrier(0);
-            if constexpr (!(VQS_WIDE_ABL & 2)) { fw[0][0] = *reinterpret_cast<const uint4*>(s0 + b_row + 0 * 4096 + koff[0]); } __builtin_amdgcn_sched_barrier(0);
-            if constexpr (!(VQS_WIDE_ABL & 2)) { fw[0][1] = *reinterpret_cast<const uint4*>(s0 + b_row + 1 * 4096 + koff[0]); } __builtin_amdgcn_sched_barrier(0);
-            if constexpr (!(VQS_WIDE_ABL & 2)) { fw[0][2] = *reinterpret_cast<const uint4*>(s0 + b_row + 2 * 4096 + koff[0]); } __builtin_amdgcn_sched_barrier(0);
-            if constexpr (!(VQS_WIDE_ABL & 2)) { fw[0][3] = *reinterpret_cast<const uint4*>(s0 + b_row + 3 * 4096 + koff[0]); } __builtin_amdgcn_sched_barrier(0);
-            if constexpr (!(VQS_WIDE_ABL & 2)) { fa[0][1] = *reinterpret_cast<const uint4*>(s0 + a_row + 1 * 4096 + koff[0]); } __builtin_amdgcn_sched_barrier(0);
-            if constexpr (!(VQS_WIDE_ABL & 2)) { fa[0][2] = *reinterpret_cast<const uint4*>(s0 + a_row + 2 * 4096 + koff[0]); } __builtin_amdgcn_sched_barrier(0);
-            if constexpr (!(VQS_WIDE_ABL & 2)) { fa[0][3] = *reinterpret_cast<const uint4*>(s0 + a_row + 3 * 4096 + koff[0]); } __builtin_amdgcn_sched_barrier(0);
+            WD_RD(0, 0, s0, 0); WD_RD(0, 1, s0, 0); WD_RD(0, 2, s0, 0); WD_RD(0, 3, s0, 0);
+            WD_RD(0, 4, s0, 0); WD_RD(0, 5, s0, 0); WD_RD(0, 6, s0, 0); WD_RD(0, 7, s0, 0);
         }
 
         constexpr std::true_type YES{};
@@ -1317,6 +1250,20 @@ __global__ void __launch_bounds__(256) gemm_bf16_wide(const GemmParams p) {
                 else ktile(NO, YES, NO, 0u);
             }
         }
+
+#undef WD_RD
+#undef WD_RD_0
+#undef WD_RD_1
+#undef WD_RD_2
+#undef WD_RD_3
+#undef WD_RD_4
+#undef WD_RD_5
+#undef WD_RD_6
+#undef WD_RD_7
+#undef WD_RDA
+#undef WD_RDW
+#undef WD_MFMA
+#undef WD_DMA
 
         const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
         // the MFMAs are opaque to the compiler's hazard recogniser: 18 wait states between the last one and the first
