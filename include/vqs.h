@@ -139,7 +139,9 @@ const char* vqs_profile_report(vqs_handle* h);
  * interleaved per 32: wi_0 block then wi_1 block; C is [M, N/2]), 6 head-major scatter (q/k/v = C, C+B*H*S*64, ...)
  * variant (bits 0-7): 0 one tile per workgroup, 2 / 5 ping-pong, 3 persistent (engine default), 6 four-wave wide form; bits 8-15 = gm, bits 16-23 = ns:
  * the workgroup -> tile ORDER (groups of gm M-tiles x all N-tiles, N cut into ns column ranges walked one after the other;
- * 0 = the default 8 / 1).  The order only permutes which workgroup computes a tile when: results are bitwise identical. */
+ * 0 = the library's choice by shape).  The order only permutes which workgroup computes a tile when: results are bitwise
+ * identical.  Bit 24: result rows leave with the non-temporal hint; bits 25-26: A-panel L2 prefetch of the lock-step kernel
+ * (0 by shape, 1 on, 2 off) -- cache-policy hints, bitwise-neutral as well. */
 int vqs_gemm(const void* d_A, const void* d_W, void* d_C, const void* d_bias, const float* d_resid, int32_t M, int32_t N,
              int32_t K, int32_t lda, int32_t ldw, int32_t ldc, int32_t epilogue, int32_t S, int32_t H, int32_t variant,
              void* stream);

@@ -1153,6 +1153,8 @@ int vqs_gemm(const void* A, const void* W, void* C, const void* bias, const floa
     p.heads_out[2] = (bf16_t*)C + 2 * per;
     p.tile_gm = (variant >> 8) & 0xff;     // bits 8-15 / 16-23 of `variant`: tile order (0 = default), see vqs.h
     p.tile_ns = (variant >> 16) & 0xff;
+    p.nt_store = (variant >> 24) & 1;      // bit 24: non-temporal result stores; bits 25-26: A-panel L2 touch (0 by shape, 1 on, 2 off)
+    p.l2_touch = (variant >> 25) & 3;
     return vqs::launch_gemm(p, epilogue, variant & 0xff, (hipStream_t)stream) == hipSuccess ? VQS_OK : VQS_ERR_HIP;
 }
 

@@ -315,11 +315,14 @@ class VqsEngine:
 
 
 # ---------------------------------------------------------------------- single-kernel wrappers (tests, microbench)
-def gemm(A, W, epilogue: int, bias=None, resid=None, out=None, S: int = 0, H: int = 0, variant: int = 0, tile_order=None):
+def gemm(A, W, epilogue: int, bias=None, resid=None, out=None, S: int = 0, H: int = 0, variant: int = 0, tile_order=None,
+         nt_store: bool = False, l2_touch: int = 0):
     """C = epilogue(A @ W.T).  A [M,K] bf16, W [N,K] bf16.  See include/vqs.h for epilogue codes.
-    tile_order = (gm, ns): workgroup -> tile order of the launch (a permutation of the tile list; bitwise-neutral)."""
+    tile_order = (gm, ns): workgroup -> tile order of the launch (a permutation of the tile list); nt_store: non-temporal result
+    stores; l2_touch: 1 / 2 = A-panel L2 prefetch on / off (0: by shape).  All three are bitwise-neutral."""
     if tile_order is not None:
         variant = (variant & 0xff) | (int(tile_order[0]) << 8) | (int(tile_order[1]) << 16)
+    variant |= (1 << 24 if nt_store else 0) | ((int(l2_touch) & 3) << 25)
     lib = load_library()
     M, K = A.shape
     N = W.shape[0]

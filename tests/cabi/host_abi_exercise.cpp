@@ -43,6 +43,10 @@ int main() {
     assert(vqs_set_option(h, "tile_order:20480x4096", 0) == 0 && vqs_set_option(h, "tile_order:4096x10240", 0) == 0);
     assert(vqs_set_option(h, "tile_order:", 8) != 0 && vqs_set_option(h, "tile_order:12x", 8) != 0 && vqs_set_option(h, "tile_order:-4x64", 8) != 0);
     assert(vqs_set_option(h, "tile_order:64x64", 65) != 0 && vqs_set_option(h, "tile_order:64x64", 1 << 16) != 0 && vqs_set_option(h, "tile_order:64x64", 8 | 9 << 8) != 0);
+    assert(vqs_set_option(h, "nt_store:4096x10240", 1) == 0 && vqs_set_option(h, "nt_store:4096x10240", 2) == 0 && vqs_set_option(h, "nt_store:4096x10240", 0) == 0);
+    assert(vqs_set_option(h, "nt_store:4096x10240", 3) != 0 && vqs_set_option(h, "nt_store:x", 1) != 0);
+    assert(vqs_set_option(h, "l2_touch:12288x4096", 1) == 0 && vqs_set_option(h, "l2_touch:12288x4096", 0) == 0 && vqs_set_option(h, "l2_touch:12288x4096", 5) != 0);
+    assert(vqs_set_option(h, "gemm_variant", 6) == 0 && vqs_set_option(h, "gemm_variant", 3) == 0 && vqs_set_option(h, "gemm_variant", 8) != 0);
     {
         const int M = 155648, N = 20480, nwg = (M / 256) * (N / 256);
         std::vector<int32_t> tiles(4 * (size_t)nwg);

@@ -85,6 +85,9 @@ def test_gemm_tile_order_is_bitwise_neutral(eng, M, N, K, epi, S, H):
         for order in ((8, 1), (4, 1), (2, 1), (1, 1), (16, 1), (3, 1), (8, 2), (4, 2), (2, 4), (64, 4)):
             out = eng.gemm(A, W, epi, S=S, H=H, variant=variant, tile_order=order)
             assert torch.equal(out, ref), (variant, order, describe(out, ref))
+        for nt, touch in ((True, 0), (False, 1), (False, 2), (True, 1)):      # the other two cache-policy hints of a launch
+            out = eng.gemm(A, W, epi, S=S, H=H, variant=variant, nt_store=nt, l2_touch=touch)
+            assert torch.equal(out, ref), (variant, nt, touch, describe(out, ref))
 
 
 @pytest.mark.parametrize("M,N,K,epi,S,H", [
