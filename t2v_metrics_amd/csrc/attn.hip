@@ -143,6 +143,29 @@ __device__ __forceinline__ a_v4i a_make_rsrc(const void* base) {
 }
 static constexpr int ST_BYTES = 16384;       // one stage: K 8 KiB + V 8 KiB
 
+// VQS_ATTN_TIMING (lab builds only: make variant NAME=attn_timing VFLAGS=-DVQS_ATTN_TIMING=1): per-phase s_memtime cycle totals of
+// the LDS-DMA kernel, summed over all waves into a device buffer registered with vqs_lab_set_attn_timing (8 x int64:
+// [0] wait for the staged tile + barrier, [1] K reads + QK^T MFMAs (+ bias), [2] mask / max / rescale branch, [3] exp + pack + V
+// reads + PV MFMAs, [4] prologue (bias table fill, Q load), [5] epilogue, [6] wave-tiles, [7] waves).  Each probe is an
+// s_memtime + s_waitcnt lgkmcnt(0): it perturbs what it measures (the waits drain the LDS reads in flight), so read the split,
+// not the total.
+#ifndef VQS_ATTN_TIMING
+#define VQS_ATTN_TIMING 0
+#endif
+#if VQS_ATTN_TIMING
+__device__ unsigned long long* g_attn_timing = nullptr;
+__device__ __forceinline__ unsigned long long a_now() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+#define A_T(var) const unsigned long long var = a_now()
+#define A_ACC(slot, t1, t0) t_acc[slot] += (t1) - (t0)
+#else
+#define A_T(var)
+#define A_ACC(slot, t1, t0)
+#endif
+
 // BIAS_ACC (compile-time form of the biased kernel): 1 = the position bias enters through the MFMA accumulators
 #ifndef VQS_ATTN_BIAS_ACC
 #define VQS_ATTN_BIAS_ACC 0
@@ -158,6 +181,11 @@ __global__ void __launch_bounds__(256) attn_fwd_dma_kernel(const AttnParams p) {
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hh = lane >> 5;
+#if VQS_ATTN_TIMING
+    unsigned long long t_acc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long t_tiles = 0;
+#endif
+    A_T(t_start);
     // XCD-aware work map (workgroup L runs on XCD L % 8): the q-blocks of one (sample, head) get consecutive slots of
     // ONE XCD, so its K/V tiles are fetched from HBM once and re-read from that XCD's L2 -- with the natural 3-D
     // grid the 5 q-blocks landed on 5 different XCDs and the PMC showed K/V crossing the fabric 5 times
@@ -242,12 +270,17 @@ __global__ void __launch_bounds__(256) attn_fwd_dma_kernel(const AttnParams p) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[ks].x), "+v"(qf[ks].y), "+v"(qf[ks].z), "+v"(qf[ks].w));
     if (ntiles > 0) stage(0, 0);
+    A_T(t_pro);
+    A_ACC(4, t_pro, t_start);
     for (int kt = 0; kt < ntiles; ++kt) {
         const int st = kt & 1;
+        A_T(t0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of tile kt have landed
         __syncthreads();                                       // ... everybody's; stage st^1 is no longer read
         if (kt + 1 < ntiles) stage(kt + 1, st ^ 1);
         const char* k_lds = smem + st * ST_BYTES;
+        A_T(t1);
+        A_ACC(0, t1, t0);
 
         // ---- S^T = K . Q^T   (i <-> key, j <-> query)
         const int kb = kt * KT;
@@ -308,6 +341,11 @@ __global__ void __launch_bounds__(256) attn_fwd_dma_kernel(const AttnParams p) {
                     s[kf][4 * g + 3] = fmaf(s[kf][4 * g + 3], sl2, bv.w);
                 }
         }
+#if VQS_ATTN_TIMING
+        asm volatile("" : "+v"(s[0][0]), "+v"(s[1][15]));      // the scores exist before the clock is read
+#endif
+        A_T(t2);
+        A_ACC(1, t2, t1);
         if (kb + KT > klen) {                       // wave-uniform: only the last tile of a sample is ragged
 #pragma unroll
             for (int kf = 0; kf < 2; ++kf)
@@ -338,6 +376,11 @@ __global__ void __launch_bounds__(256) attn_fwd_dma_kernel(const AttnParams p) {
             }
         }
         const float neg_m = -m_run;
+#if VQS_ATTN_TIMING
+        asm volatile("" : "+v"(o[0][0]), "+v"(osum[0]));
+#endif
+        A_T(t3);
+        A_ACC(2, t3, t2);
 #pragma unroll
         for (int kf = 0; kf < 2; ++kf)
 #pragma unroll
@@ -369,7 +412,16 @@ __global__ void __launch_bounds__(256) attn_fwd_dma_kernel(const AttnParams p) {
                                                                    __builtin_bit_cast(bf16x8, pb), o[df], 0, 0, 0);
                 }
             }
+#if VQS_ATTN_TIMING
+        asm volatile("" : "+v"(o[0][0]), "+v"(o[1][15]), "+v"(osum[0]));
+        {
+            A_T(t4);
+            A_ACC(3, t4, t3);
+            ++t_tiles;
+        }
+#endif
     }
+    A_T(t_loop_end);
 
     const float l_tot = osum[0];                  // all 32 rows of the ones-product are the same row sum
     const float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
@@ -385,7 +437,22 @@ __global__ void __launch_bounds__(256) attn_fwd_dma_kernel(const AttnParams p) {
                 *reinterpret_cast<uint2*>(orow + df * 32 + 8 * g + 4 * hh) = v;
             }
     }
+#if VQS_ATTN_TIMING
+    {
+        A_T(t_end);
+        A_ACC(5, t_end, t_loop_end);
+        if (g_attn_timing != nullptr && lane == 0) {
+            for (int i = 0; i < 6; ++i) atomicAdd(g_attn_timing + i, t_acc[i]);
+            atomicAdd(g_attn_timing + 6, t_tiles);
+            atomicAdd(g_attn_timing + 7, 1ull);
+        }
+    }
+#endif
 }
+
+#if VQS_ATTN_TIMING
+hipError_t lab_set_attn_timing(unsigned long long* d_buf) { return hipMemcpyToSymbol(HIP_SYMBOL(g_attn_timing), &d_buf, sizeof(d_buf)); }
+#endif
 
 
 // =====================================================================================================

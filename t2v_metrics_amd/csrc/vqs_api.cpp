@@ -27,6 +27,10 @@ struct WEntry {
     int64_t numel;
 };
 
+#if defined(VQS_ATTN_TIMING) && VQS_ATTN_TIMING
+namespace vqs { hipError_t lab_set_attn_timing(unsigned long long* d_buf); }   // attn.hip, timing build only
+#endif
+
 struct vqs_handle {
     vqs_config c;
     std::string err;
@@ -380,6 +384,11 @@ int vqs_debug_tile_order(int32_t M, int32_t N, int32_t K, int32_t batch, int32_t
         }
     return k == nwg ? (p.tile_gm | (p.tile_ns << 8)) : VQS_ERR_INVALID;
 }
+
+#if defined(VQS_ATTN_TIMING) && VQS_ATTN_TIMING
+// lab builds only (make variant NAME=attn_timing VFLAGS=-DVQS_ATTN_TIMING=1): d_buf = 8 x uint64 on the device, zeroed by the caller
+int vqs_lab_set_attn_timing(void* d_buf) { return vqs::lab_set_attn_timing((unsigned long long*)d_buf) == hipSuccess ? VQS_OK : VQS_ERR_HIP; }
+#endif
 
 int64_t vqs_attention_lds_bytes(int32_t S, int32_t has_bias, int32_t hd) {
     if (S <= 0 || (hd != 0 && hd != 64 && hd != 128)) return -1;

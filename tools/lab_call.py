@@ -293,6 +293,32 @@ def main():
             emit({"part": "R", "shape": tag, "N": N, "K": K, "epilogue": epi, "tflops": res, "bitwise_equal_3_6_8": bool(torch.equal(outs[3], outs[6]) and torch.equal(outs[3], outs[8]))})
             del A, W, outs, ref
             torch.cuda.empty_cache()
+    if "AT" in parts:                                            # per-phase cycle split of the self-attention kernel (timing build)
+        import ctypes
+        path = os.path.join(ROOT, "build", "lab", "libvqs_attn_timing.so")
+        lib = engine.load_library(path)
+        lib.vqs_lab_set_attn_timing.argtypes = [ctypes.c_void_p]
+        g = torch.Generator(device="cuda").manual_seed(5)
+        names = ["wait+barrier+stage", "K reads + QK^T (+bias)", "mask / max / rescale", "exp + pack + V reads + PV", "prologue", "epilogue"]
+        for tag, B, H, S, scale, with_bias in (("t5-xxl", 256, 64, 608, 1.0, True), ("t5-xl", 256, 32, 608, 1.0, True), ("vit", 256, 16, 577, 0.125, False)):
+            q, k, v = [torch.randn(B, H, S, 64, device="cuda", generator=g).to(torch.bfloat16) for _ in range(3)]
+            bias = (torch.randn(H, 2 * S - 1, device="cuda", generator=g) * 2.0).contiguous() if with_bias else None
+            o = torch.empty(B * S, H * 64, dtype=torch.bfloat16, device="cuda")
+            buf = torch.zeros(8, dtype=torch.int64, device="cuda")
+            assert lib.vqs_lab_set_attn_timing(buf.data_ptr()) == 0
+
+            def call():
+                assert lib.vqs_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), None if bias is None else bias.data_ptr(), None,
+                                         B, H, S, scale, torch.cuda.current_stream().cuda_stream) == 0
+            call()
+            torch.cuda.synchronize()
+            buf.zero_()
+            ms = time_ms(call, 3)                                 # 1 warm + 3 timed launches = 4 launches in the counters
+            t = buf.cpu().tolist()
+            waves, tiles = max(t[7], 1), max(t[6], 1)
+            emit({"part": "AT", "shape": tag, "ms_per_call_with_probes": ms, "cycles_per_wave_tile": {n: round(t[i] / tiles, 1) for i, n in enumerate(names[:4])},
+                  "cycles_per_wave": {n: round(t[4 + i] / waves, 1) for i, n in enumerate(names[4:])}, "wave_tiles": tiles, "waves": waves})
+            assert lib.vqs_lab_set_attn_timing(None) == 0
     if "WA" in parts:                                            # timing ablations of the wide form (lab builds; results are garbage by design)
         g = torch.Generator(device="cuda").manual_seed(0)
         libs = [("product", engine.load_library())] + [(n, engine.load_library(os.path.join(ROOT, "build", "lab", "libvqs_%s.so" % n)))
