@@ -30,6 +30,9 @@ struct WEntry {
 #if defined(VQS_ATTN_TIMING) && VQS_ATTN_TIMING
 namespace vqs { hipError_t lab_set_attn_timing(unsigned long long* d_buf); }   // attn.hip, timing build only
 #endif
+#if defined(VQS_LAB) && defined(VQS_RING_TIMING) && VQS_RING_TIMING
+namespace vqs { hipError_t lab_set_ring_timing(unsigned long long* d_buf); }   // lab/gemm_ring.inc, timing build only
+#endif
 
 struct vqs_handle {
     vqs_config c;
@@ -388,6 +391,11 @@ int vqs_debug_tile_order(int32_t M, int32_t N, int32_t K, int32_t batch, int32_t
 #if defined(VQS_ATTN_TIMING) && VQS_ATTN_TIMING
 // lab builds only (make variant NAME=attn_timing VFLAGS=-DVQS_ATTN_TIMING=1): d_buf = 8 x uint64 on the device, zeroed by the caller
 int vqs_lab_set_attn_timing(void* d_buf) { return vqs::lab_set_attn_timing((unsigned long long*)d_buf) == hipSuccess ? VQS_OK : VQS_ERR_HIP; }
+#endif
+
+#if defined(VQS_LAB) && defined(VQS_RING_TIMING) && VQS_RING_TIMING
+// lab timing build only (make lab LABFLAGS=-DVQS_RING_TIMING=1): d_buf = 8 x uint64 on the device, zeroed by the caller
+int vqs_lab_set_ring_timing(void* d_buf) { return vqs::lab_set_ring_timing((unsigned long long*)d_buf) == hipSuccess ? VQS_OK : VQS_ERR_HIP; }
 #endif
 
 int64_t vqs_attention_lds_bytes(int32_t S, int32_t has_bias, int32_t hd) {

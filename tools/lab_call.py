@@ -293,6 +293,30 @@ def main():
             emit({"part": "R", "shape": tag, "N": N, "K": K, "epilogue": epi, "tflops": res, "bitwise_equal_3_6_8": bool(torch.equal(outs[3], outs[6]) and torch.equal(outs[3], outs[8]))})
             del A, W, outs, ref
             torch.cuda.empty_cache()
+    if "RT" in parts:                                            # where the ring form's cycles go (lab timing build: make lab LABDIR=../../build/lab_timing LABFLAGS=-DVQS_RING_TIMING=1)
+        import ctypes
+        lib = engine.load_library(os.path.join(ROOT, "build", "lab_timing", "libvqs_hip_lab.so"))
+        lib.vqs_lab_set_ring_timing.argtypes = [ctypes.c_void_p]
+        g = torch.Generator(device="cuda").manual_seed(0)
+        for tag, M, N, K, epi, S, H, has_bias in [XXL[0], XXL[1], XXL[3], VIT[0], VIT[1]]:
+            A = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+            W = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(torch.bfloat16)
+            out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+            buf = torch.zeros(8, dtype=torch.int64, device="cuda")
+            assert lib.vqs_lab_set_ring_timing(buf.data_ptr()) == 0
+
+            def call():
+                assert lib.vqs_gemm(A.data_ptr(), W.data_ptr(), out.data_ptr(), None, None, M, N, K, K, K, N, 0, 0, 0, 8, torch.cuda.current_stream().cuda_stream) == 0
+            call()
+            torch.cuda.synchronize()
+            buf.zero_()
+            ms = time_ms(call, 3)
+            t = buf.cpu().tolist()
+            waves, bnd, tiles = max(t[6], 1), max(t[4], 1), max(t[5], 1)
+            emit({"part": "RT", "shape": tag, "tflops_with_probes": round(2.0 * M * N * K / ms / 1e9, 1), "cycles_per_boundary": {"vmcnt wait": round(t[0] / bnd, 1), "barrier": round(t[1] / bnd, 1)},
+                  "cycles_per_tile": {"epilogue incl. its stores": round(t[2] / tiles, 1), "whole tile": round(t[3] / tiles, 1), "mfma floor": K // 32 * 1024}, "waves": waves})
+            assert lib.vqs_lab_set_ring_timing(None) == 0
+            del A, W, out
     if "AT" in parts:                                            # per-phase cycle split of the self-attention kernel (timing build)
         import ctypes
         path = os.path.join(ROOT, "build", "lab", "libvqs_attn_timing.so")
