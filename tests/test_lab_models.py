@@ -24,7 +24,8 @@ def test_lds_images_and_accumulator_map():
 
 
 def test_ring_vmcnt_protocol_covers_the_slice_read_next():
-    assert "432 schedules" in _model().check_ring_protocol()
+    assert "432 schedules" in _model().check_ring_protocol(4)
+    assert "432 schedules" in _model().check_ring_protocol(3)
 
 
 def test_the_models_formulas_are_the_kernels():
@@ -37,6 +38,6 @@ def test_the_models_formulas_are_the_kernels():
         assert needle in wide, needle
     for needle in ["const uint32_t gch_b = (uint32_t)(((lane & 3) ^ ((lane >> 4) & 3)) << 4);", "const int fsw = (lane >> 2) & 3;",
                    "koff[ks] = (((ks * 2 + (lane >> 5)) ^ fsw) << 4);", "const int a_row = (wr * 128 + (lane & 31)) * 64;",
-                   "const int r0 = w * 16 + (lane >> 2);", "sync_extra = full ? 3 : 0;", 'asm volatile("s_waitcnt vmcnt(16)" ::: "memory");']:
+                   "const int r0 = w * 16 + (lane >> 2);", "sync_extra = full ? RING_AHEAD : 0;", "constexpr int YOUNGER = 8 * (RING_AHEAD - 1);"]:
         assert needle in ring, needle
     assert len(re.findall(r"stream_piece\(D\)", ring)) == 1 and "RK_B(15, 7)" in ring

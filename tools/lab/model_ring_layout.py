@@ -78,13 +78,15 @@ if __name__ == "__main__":
         print(f())
 
 
-def check_ring_protocol():
-    """Replay of the ring form's VMEM issue order and slice-boundary waits for one wave (control flow of gemm_bf16_ring): at every
-    boundary the `s_waitcnt vmcnt(N)` used must be <= the number of VMEM operations issued AFTER the last LDS-DMA piece of the slice
-    that is read next (VMEM retires in order: then that slice has landed), for every slices-per-tile count, number of tiles per
-    workgroup, full / partial tile pattern and epilogue store count; and the slot a piece is written to must not be read any more."""
+def check_ring_protocol(slots=4):
+    """Replay of the ring form's VMEM issue order and slice-boundary waits for one wave (control flow of gemm_bf16_ring, ring of
+    `slots` slices, LDS-DMA slots - 1 slices ahead): at every boundary the `s_waitcnt vmcnt(N)` used must be <= the number of VMEM
+    operations issued AFTER the last LDS-DMA piece of the slice that is read next (VMEM retires in order: then that slice has
+    landed), for every slices-per-tile count, number of tiles per workgroup, full / partial tile pattern and epilogue store
+    count; and a piece must only be written to the slot of a slice whose reads are over."""
     import random
     rng = random.Random(0)
+    ahead = slots - 1
     checked = 0
     for ns in (2, 3, 4, 5, 8, 64):
         for ntiles in (1, 2, 3, 5):
@@ -98,14 +100,14 @@ def check_ring_protocol():
                         nonlocal s_g
                         log.extend([("dma", s_g)] * 8)
                         s_g += 1
-                    for _ in range(3):
+                    for _ in range(ahead):
                         if s_g < total:
                             issue()
                     c_g, counted, sync_extra = 0, False, 0
                     def need(slice_idx, n_imm):
                         last = max(i for i, op in enumerate(log) if op == ("dma", slice_idx))
                         younger = len(log) - 1 - last
-                        assert n_imm <= younger or n_imm == 0, (ns, ntiles, nst, slice_idx, n_imm, younger)
+                        assert n_imm <= younger or n_imm == 0, (slots, ns, ntiles, nst, slice_idx, n_imm, younger)
                     def boundary_wait():
                         nonlocal sync_extra
                         if s_g >= total:                         # !s_valid
@@ -113,8 +115,8 @@ def check_ring_protocol():
                             return 0
                         if sync_extra > 0:
                             sync_extra -= 1
-                            return min(16 + nst, 63)
-                        return 16
+                            return min(8 * (ahead - 1) + nst, 63)
+                        return 8 * (ahead - 1)
                     for t in range(ntiles):
                         if counted:
                             n = boundary_wait()
@@ -122,8 +124,8 @@ def check_ring_protocol():
                             n, sync_extra = 0, 0
                         need(c_g, n)
                         for k in range(ns):
-                            if s_g < total:                      # k-step 0 of slice c_g issues stream slice c_g + 3 into slot (c_g + 3) & 3
-                                assert s_g == c_g + 3 and (s_g & 3) == ((c_g - 1) & 3)
+                            if s_g < total:                      # k-step 0 of slice c_g issues stream slice c_g + ahead into the slot of slice c_g - 1
+                                assert s_g == c_g + ahead and (s_g % slots) == ((c_g - 1) % slots)
                                 issue()
                             if k + 1 < ns:
                                 need(c_g + 1, boundary_wait())
@@ -131,11 +133,12 @@ def check_ring_protocol():
                         stores = nst if full[t] else rng.randrange(0, nst)
                         log.extend([("st", t)] * stores)
                         counted = full[t]
-                        sync_extra = 3 if full[t] else 0
+                        sync_extra = ahead if full[t] else 0
                     assert c_g == total and s_g == total
                     checked += 1
-    return "ring protocol: %d schedules replayed, every boundary wait covers the slice read next" % checked
+    return "ring protocol (%d slots): %d schedules replayed, every boundary wait covers the slice read next" % (slots, checked)
 
 
 if __name__ == "__main__":
-    print(check_ring_protocol())
+    print(check_ring_protocol(4))
+    print(check_ring_protocol(3))
