@@ -174,6 +174,9 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-emulation", action="store_true", help="also run the rounding-matched CPU oracle on pair 0 (~40 s at XXL)")
     ap.add_argument("--cpu-reps", type=int, default=3, help="timed repetitions of the CPU reference (after 1 warm-up)")
     ap.add_argument("--ragged", action="store_true", help="one batch of variable-length prompts, padded + masked (no bucketing)")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="execution-form option of include/vqs.h vqs_set_option (e.g. gemm_variant=6, tile_order:20480x4096=520); "
+                         "every form computes the same function -- for A/B runs, recorded in config.options")
     return ap.parse_args(argv)
 
 
@@ -235,7 +238,11 @@ def main():
     else:
         from t2v_metrics_amd.engine import VqsEngine
         weights = make_seeded_weights(cfg, seed=0, device=device)
-        eng = VqsEngine(cfg, weights, device=device)
+        options = {}
+        for item in args.opt:
+            name, _, value = item.partition("=")
+            options[name] = int(value)
+        eng = VqsEngine(cfg, weights, device=device, options=options)
     B = args.batch
     jobs, info = make_jobs(args, cfg, rank, world, device)
     steps_local = len(jobs)
@@ -332,7 +339,8 @@ def main():
                 if not double else "ENGINE DOUBLE -- harness self-test, not a measurement",
         "config": {"workload": f"{cfg.name} bf16, {info['name']}",
                    "pairs_per_gpu_per_step": B, "encoder_len": s_e, "decoder_len": T, "total_pairs": total_pairs,
-                   "parallelism": f"replica x{world} (pairs sharded, RCCL all_gather of scores)"},
+                   "parallelism": f"replica x{world} (pairs sharded, RCCL all_gather of scores)",
+                   **({"options": args.opt} if args.opt else {})},
         "ranks_seen": ranks_seen,
         "per_rank_pairs_per_s": per_rank_list,
         "scores_checksum": float(final.double().sum().item()),
