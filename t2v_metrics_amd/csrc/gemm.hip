@@ -1070,8 +1070,14 @@ __host__ __device__ constexpr int wide_acc_idx(int j) { return ((((j) & 3) >> 1)
 #ifndef VQS_WIDE_ABL
 #define VQS_WIDE_ABL 0
 #endif
-template <int EPI>
+// TOUCH = 1 (lab build, variant 9; not yet run on a GPU): waves 0 / 1 pull the cache lines of the A / W rows this workgroup is
+// responsible for -- its 1 / sharers part of the panels the XCD's window of concurrent tiles shares -- TWO K-tiles ahead into L2
+// with one dword LDS-DMA each per K-tile (into a sink nobody reads), so that the real staging DMA, issued one K-tile ahead, hits
+// L2 instead of waiting out the ~1 850-cycle far latency (the same hint the lock-step kernel uses for HBM-streamed panels; here
+// it addresses the form's whole problem).  The touch is the youngest VMEM op at the K-tile boundary: vmcnt(1) lets it fly.
+template <int EPI, int TOUCH = 0>
 __global__ void __launch_bounds__(256) gemm_bf16_wide(const GemmParams p) {
+    __shared__ __attribute__((aligned(16))) char wide_touch_sink[TOUCH != 0 ? 1024 : 16];
     static_assert(EPI != EPI_RESID_RMS && EPI != EPI_F32_RESID && EPI != EPI_F32, "not carried by the wide form (fp32 results: lm_head and split-K partials, small launches)");
     __shared__ __attribute__((aligned(16))) char lds[2 * STAGE_BYTES];
 
@@ -1130,6 +1136,24 @@ __global__ void __launch_bounds__(256) gemm_bf16_wide(const GemmParams p) {
     int buf = 0;
     bool counted = false;     // true: the only VMEM ops younger than the prefetched K-tile are a full epilogue's stores
 
+    // TOUCH state: wave 0 touches A rows, wave 1 W rows.  A window of 32 concurrent tiles per XCD is gm M-tiles x 32 / gm N-tiles:
+    // an A panel has 32 / gm sharers (this workgroup takes 8 gm of its 256 rows, picked by its N-tile index), a W panel gm sharers
+    const bool touch_wave = TOUCH != 0 && w < 2 && nt >= 2;
+    const v4i_t rsT = make_rsrc(w == 0 ? (const void*)p.A : (const void*)p.W);
+    const uint32_t touch_dst = (uint32_t)(uintptr_t)LDS_PTR(wide_touch_sink) + w * 256;
+    auto touch_off = [&](int tm0, int tn0) -> uint32_t {
+        const int gmr = p.tile_gm > 0 ? (p.tile_gm > 32 ? 32 : p.tile_gm) : 8;
+        if (w == 0) {
+            const int sharers = 32 / gmr > 0 ? 32 / gmr : 1, rows = 256 / sharers;
+            const int row = min(tm0 + rows * ((tn0 / BN) % sharers) + (lane % rows), p.M - 1);
+            return (uint32_t)row * lda_b;
+        }
+        const int rows = 256 / gmr;
+        const int row = min(tn0 + rows * ((tm0 / BM) % gmr) + (lane % rows), p.N - 1);
+        return (uint32_t)row * ldw_b;
+    };
+    uint32_t t_cur = 0, t_nxt = 0;
+
     while (true) {
         // accumulator (half, m, n) = columns n0 + wc*128 + half*64 + n*32 ..., rows m0 + wr*128 + m*32 ... lives in AGPR tuple
         // (half*4 + m)*2 + n (see mfma_fixed); zeroed by the C = 0 form of the first k-step's MFMAs
@@ -1137,6 +1161,16 @@ __global__ void __launch_bounds__(256) gemm_bf16_wide(const GemmParams p) {
         const int next_pid = pid + gridDim.x;
         const bool has_next = next_pid < nwg;
         int nm0 = 0, nn0 = 0, nbz = 0;
+        if constexpr (TOUCH != 0) {
+            if (touch_wave) {
+                t_cur = touch_off(m0, n0);
+                if (has_next) {
+                    int xm0, xn0, xbz;
+                    tile_coords(next_pid, xm0, xn0, xbz);
+                    t_nxt = touch_off(xm0, xn0);
+                }
+            }
+        }
 
         // One K-tile = 4 k-steps of 16 MFMAs, the instruction stream written out by hand (the MFMA statements are opaque to the
         // scheduler, sched_barrier pins every LDS read where it stands): ONE wave per SIMD means one instruction per issue
@@ -1175,7 +1209,7 @@ __global__ void __launch_bounds__(256) gemm_bf16_wide(const GemmParams p) {
             else bglds16(rsW, pb[(D) >> 1], koffs2, dst0 + ((D) >> 1) * 4096 + W_OFF);                        \
         }                                                                                                     \
     } while (0)
-        auto ktile = [&](auto stage_tag, auto last_tag, auto first_tag, uint32_t koffs2) {
+        auto ktile = [&](auto stage_tag, auto last_tag, auto first_tag, uint32_t koffs2, bool do_touch, uint32_t touch_voff, uint32_t touch_koff) {
             constexpr bool STAGE = decltype(stage_tag)::value;
             constexpr bool LAST = decltype(last_tag)::value;
             constexpr bool FIRST = decltype(first_tag)::value;
@@ -1200,7 +1234,11 @@ __global__ void __launch_bounds__(256) gemm_bf16_wide(const GemmParams p) {
 #define WD_A(J) WD_MFMA(0, J, false); WD_RD(1, J, sb, 3);
 #define WD_B(J) WD_MFMA(0, J, false);
             WD_A(0) WD_A(1) WD_A(2) WD_A(3) WD_A(4) WD_A(5) WD_A(6) WD_A(7)
-            WD_B(8) WD_B(9) WD_B(10) WD_B(11) WD_B(12) WD_B(13) WD_B(14) WD_B(15)
+            WD_B(8)
+            if constexpr (TOUCH != 0) {                            // after every real piece of this K-tile: the youngest VMEM op at the boundary
+                if (do_touch) bglds4s(rsT, touch_voff, touch_koff, touch_dst);
+            }
+            WD_B(9) WD_B(10) WD_B(11) WD_B(12) WD_B(13) WD_B(14) WD_B(15)
 #undef WD_A
 #undef WD_B
             // ---- k-step 3 (set 1): 8 MFMAs, the K-tile boundary, 8 MFMAs each followed by a read of the next K-tile's set 0
@@ -1208,7 +1246,8 @@ __global__ void __launch_bounds__(256) gemm_bf16_wide(const GemmParams p) {
 #define WD_B(J, R) WD_MFMA(1, J, false); if constexpr (!LAST) { WD_RD(0, R, sn, 0); }
             WD_A(0) WD_A(1) WD_A(2) WD_A(3) WD_A(4) WD_A(5) WD_A(6) WD_A(7)
             if constexpr (!LAST) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own pieces of the next K-tile (issued >= 1.5 k-steps ago)
+                if (TOUCH != 0 && do_touch) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");   // ... all but this K-tile's touch
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own pieces of the next K-tile (issued >= 1.5 k-steps ago)
                 __builtin_amdgcn_s_barrier();                      // everybody's; and nobody reads stage `buf` any more
             }
             WD_B(8, 0) WD_B(9, 1) WD_B(10, 2) WD_B(11, 3) WD_B(12, 4) WD_B(13, 5) WD_B(14, 6) WD_B(15, 7)
@@ -1237,17 +1276,33 @@ __global__ void __launch_bounds__(256) gemm_bf16_wide(const GemmParams p) {
         constexpr std::false_type NO{};
         for (int t = 0; t < nt; ++t) {
             const bool first = (t == 0);
+            // touch target: K-tile t + 2 of this tile, or K-tile t + 2 - nt of the next one
+            bool do_touch = false;
+            uint32_t tv = 0, tk = 0;
+            if constexpr (TOUCH != 0) {
+                if (touch_wave) {
+                    int kt2 = t + 2;
+                    tv = t_cur;
+                    do_touch = true;
+                    if (kt2 >= nt) {
+                        kt2 -= nt;
+                        tv = t_nxt;
+                        do_touch = has_next;
+                    }
+                    tk = (uint32_t)(kt2 * BK * 2);
+                }
+            }
             if (t + 1 < nt) {
-                if (first) ktile(YES, NO, YES, (uint32_t)((t + 1) * BK * 2));
-                else ktile(YES, NO, NO, (uint32_t)((t + 1) * BK * 2));
+                if (first) ktile(YES, NO, YES, (uint32_t)((t + 1) * BK * 2), do_touch, tv, tk);
+                else ktile(YES, NO, NO, (uint32_t)((t + 1) * BK * 2), do_touch, tv, tk);
             } else if (has_next) {
                 tile_coords(next_pid, nm0, nn0, nbz);
                 set_ptrs(nm0, nn0, nbz);
-                if (first) ktile(YES, YES, YES, 0u);
-                else ktile(YES, YES, NO, 0u);
+                if (first) ktile(YES, YES, YES, 0u, do_touch, tv, tk);
+                else ktile(YES, YES, NO, 0u, do_touch, tv, tk);
             } else {
-                if (first) ktile(NO, YES, YES, 0u);
-                else ktile(NO, YES, NO, 0u);
+                if (first) ktile(NO, YES, YES, 0u, do_touch, tv, tk);
+                else ktile(NO, YES, NO, 0u, do_touch, tv, tk);
             }
         }
 
@@ -1571,6 +1626,9 @@ static hipError_t launch_epi(const GemmParams& p, int variant, hipStream_t strea
         if constexpr (EPI != EPI_F32_RESID && EPI != EPI_F32)
             hipLaunchKernelGGL((gemm_bf16_wide<EPI>), dim3(PERSISTENT_WGS), dim3(256), 0, stream, p);
 #ifdef VQS_LAB
+    } else if (variant == 9 && EPI != EPI_F32_RESID && EPI != EPI_F32 && p.batch <= 1 && tiles_m * tiles_n >= PERSISTENT_WGS) {
+        if constexpr (EPI != EPI_F32_RESID && EPI != EPI_F32)
+            hipLaunchKernelGGL((gemm_bf16_wide<EPI, 1>), dim3(PERSISTENT_WGS), dim3(256), 0, stream, p);
     } else if (variant == 8 && EPI != EPI_F32_RESID && EPI != EPI_F32 && p.batch <= 1 && tiles_m * tiles_n >= PERSISTENT_WGS) {
         if constexpr (EPI != EPI_F32_RESID && EPI != EPI_F32)
             hipLaunchKernelGGL((gemm_bf16_ring<EPI>), dim3(PERSISTENT_WGS), dim3(256), 0, stream, p);
@@ -1625,17 +1683,17 @@ hipError_t launch_gemm(const GemmParams& p_in, int epilogue, int variant, hipStr
     GemmParams p = p_in;
     resolve_tile_order(p, PERSISTENT_WGS);
 #ifndef VQS_LAB
-    if (variant == 1 || variant == 4 || variant == 7 || variant == 8) return hipErrorInvalidValue;     // lab-only forms (see the file header)
+    if (variant == 1 || variant == 4 || variant == 7 || variant == 8 || variant == 9) return hipErrorInvalidValue;     // lab-only forms (see the file header)
 #endif
     // N: a lane stores 4 consecutive columns; fp32 output may have a ragged N if ldc leaves room for the overhang
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K % BK) != 0) return hipErrorInvalidValue;
     if ((p.N % 8) != 0 && !(epilogue == EPI_F32 && p.ldc >= ((p.N + 3) & ~3) && p.bias == nullptr)) return hipErrorInvalidValue;
-    if (p.batch > 1 && ((variant != 3 && variant != 4 && variant != 5 && variant != 6 && variant != 7 && variant != 8) || epilogue == EPI_HEADS || epilogue == EPI_F32_RESID)) return hipErrorInvalidValue;
+    if (p.batch > 1 && ((variant != 3 && variant != 4 && variant != 5 && variant != 6 && variant != 7 && variant != 8 && variant != 9) || epilogue == EPI_HEADS || epilogue == EPI_F32_RESID)) return hipErrorInvalidValue;
     if ((p.lda % 8) != 0 || (p.ldw % 8) != 0) return hipErrorInvalidValue;
     if ((p.hd > 64 || p.inner_kv > 0 || p.Hkv > 0 || p.gate_act != 0 || (epilogue == EPI_GATED && p.bias != nullptr)) &&
-        variant != 3 && variant != 5 && variant != 6 && variant != 7 && variant != 8)
+        variant != 3 && variant != 5 && variant != 6 && variant != 7 && variant != 8 && variant != 9)
         return hipErrorInvalidValue;   // generalised HEADS / GATED epilogues live in the persistent kernels only
-    if (p.rowss_in != nullptr && (p.rowss_parts < 0 || (variant != 3 && variant != 5 && variant != 6 && variant != 7 && variant != 8) || epilogue == EPI_F32_RESID))
+    if (p.rowss_in != nullptr && (p.rowss_parts < 0 || (variant != 3 && variant != 5 && variant != 6 && variant != 7 && variant != 8 && variant != 9) || epilogue == EPI_F32_RESID))
         return hipErrorInvalidValue;   // the row scale lives in the persistent kernels' staged epilogue only
     switch (epilogue) {
         case EPI_BF16: return launch_epi<EPI_BF16>(p, variant, stream);
