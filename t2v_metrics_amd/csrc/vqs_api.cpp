@@ -467,6 +467,9 @@ int vqs_set_option(vqs_handle* h, const char* name, int32_t value) {
     else if (n == "fused_norm" && (value == 0 || value == 1)) h->fused_norm = value;
     else if (n == "norm_defer" && (value == 0 || value == 1)) h->norm_defer = value;
     else if (n == "gemm_variant" && (value == 0 || value == 2 || value == 3 || value == 5 || value == 6)) h->gemm_variant = value;
+#ifdef VQS_LAB
+    else if (n == "gemm_variant" && (value == 7 || value == 8 || value == 9)) h->gemm_variant = value;     // lab forms: forced lock-step, ring, wide + touch
+#endif
     else if (n.rfind("l2_touch:", 0) == 0) {
         // "l2_touch:<N>x<K>" = 1: A-panel L2 prefetch in the lock-step GEMM for the big launches with that (N, K), 2: off, 0: by shape
         int N = 0, K = 0;

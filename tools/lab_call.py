@@ -256,6 +256,10 @@ def main():
     if "WI" in parts:                                            # ... in situ
         in_situ("clip-flant5-xxl", [("8-wave forms (variant 3)", "product", {"gemm_variant": 3}), ("wide form (variant 6)", "product", {"gemm_variant": 6})],
                 steps=3, rounds=2, tag="WI")
+    if "RI" in parts:                                            # lab library (VQS_LIB_PATH): ring (8) and wide + touch (9) forms in situ against the default
+        in_situ("clip-flant5-xxl", [("8-wave forms (variant 3)", "product", {"gemm_variant": 3}), ("ring form (variant 8)", "product", {"gemm_variant": 8}),
+                                    ("wide + L2 touch (variant 9)", "product", {"gemm_variant": 9}), ("wide form (variant 6)", "product", {"gemm_variant": 6})],
+                steps=3, rounds=2, tag="RI")
     if "WIX" in parts:
         in_situ("clip-flant5-xl", [("8-wave forms (variant 3)", "product", {"gemm_variant": 3}), ("wide form (variant 6)", "product", {"gemm_variant": 6})],
                 steps=4, rounds=2, tag="WIX")
