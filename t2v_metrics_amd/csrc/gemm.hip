@@ -1246,6 +1246,9 @@ __global__ void __launch_bounds__(256) gemm_bf16_wide(const GemmParams p) {
 #define WD_B(J, R) WD_MFMA(1, J, false); if constexpr (!LAST) { WD_RD(0, R, sn, 0); }
             WD_A(0) WD_A(1) WD_A(2) WD_A(3) WD_A(4) WD_A(5) WD_A(6) WD_A(7)
             if constexpr (!LAST) {
+                // WAR on stage `buf`: its last fragment reads (issued a k-step ago) are retired before the barrier after which
+                // another wave restages it (cdna_hip_programming.md: "1 phase after when an lgkmcnt ... retired those reads")
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (TOUCH != 0 && do_touch) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");   // ... all but this K-tile's touch
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own pieces of the next K-tile (issued >= 1.5 k-steps ago)
                 __builtin_amdgcn_s_barrier();                      // everybody's; and nobody reads stage `buf` any more
