@@ -1158,7 +1158,9 @@ int vqs_gemm_rms(const void* A, const void* W, void* C, float* hres, const void*
     p.heads_out[2] = (bf16_t*)C + 2 * per;
     p.hres = hres; p.ldh = N; p.lnw = (const bf16_t*)lnw; p.rowss_out = rowss_out;
     p.rowss_in = rowss_in; p.rowss_parts = rowss_parts; p.rs_invd = rs_invd; p.rs_eps = rs_eps;
-    return vqs::launch_gemm(p, epilogue, variant, (hipStream_t)stream) == hipSuccess ? VQS_OK : VQS_ERR_HIP;
+    p.tile_gm = (variant >> 8) & 0xff;     // same layout of the variant word as vqs_gemm
+    p.tile_ns = (variant >> 16) & 0xff;
+    return vqs::launch_gemm(p, epilogue, variant & 0xff, (hipStream_t)stream) == hipSuccess ? VQS_OK : VQS_ERR_HIP;
 }
 
 int vqs_gemm(const void* A, const void* W, void* C, const void* bias, const float* resid, int32_t M, int32_t N, int32_t K,
