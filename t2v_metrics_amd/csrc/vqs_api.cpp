@@ -470,34 +470,30 @@ int vqs_set_option(vqs_handle* h, const char* name, int32_t value) {
 #ifdef VQS_LAB
     else if (n == "gemm_variant" && (value == 7 || value == 8 || value == 9)) h->gemm_variant = value;     // lab forms: forced lock-step, ring, wide + touch
 #endif
-    else if (n.rfind("l2_touch:", 0) == 0) {
-        // "l2_touch:<N>x<K>" = 1: A-panel L2 prefetch in the lock-step GEMM for the big launches with that (N, K), 2: off, 0: by shape
-        int N = 0, K = 0;
-        if (std::sscanf(n.c_str() + 9, "%dx%d", &N, &K) != 2 || N <= 0 || K <= 0 || value < 0 || value > 2)
-            return fail(h, VQS_ERR_INVALID, "set_option: bad l2_touch: " + n + "=" + std::to_string(value));
-        for (size_t i = 0; i < h->l2_touches.size(); ++i)
-            if (h->l2_touches[i].N == N && h->l2_touches[i].K == K) { h->l2_touches.erase(h->l2_touches.begin() + i); break; }
-        if (value != 0) h->l2_touches.push_back(vqs_handle::NtStore{N, K, value});
-    }
-    else if (n.rfind("nt_store:", 0) == 0) {
-        // "nt_store:<N>x<K>" = 1: non-temporal result stores for every GEMM of the pass with that (N, K), 2: plain stores,
-        // 0: back to the library's choice for the call site
-        int N = 0, K = 0;
-        if (std::sscanf(n.c_str() + 9, "%dx%d", &N, &K) != 2 || N <= 0 || K <= 0 || value < 0 || value > 2)
-            return fail(h, VQS_ERR_INVALID, "set_option: bad nt_store: " + n + "=" + std::to_string(value));
-        for (size_t i = 0; i < h->nt_stores.size(); ++i)
-            if (h->nt_stores[i].N == N && h->nt_stores[i].K == K) { h->nt_stores.erase(h->nt_stores.begin() + i); break; }
-        if (value != 0) h->nt_stores.push_back(vqs_handle::NtStore{N, K, value});
-    }
-    else if (n.rfind("tile_order:", 0) == 0) {
-        // "tile_order:<N>x<K>" = gm | ns << 8 for every GEMM of the pass with that (N, K); 0 removes the entry
+    else if (n.rfind("l2_touch:", 0) == 0 || n.rfind("nt_store:", 0) == 0 || n.rfind("tile_order:", 0) == 0) {
+        // per weight shape [N, K], for the big launches of a pass; 0 removes the entry = the library's choice.  All three are
+        // bitwise-neutral cache-policy knobs:
+        //   "l2_touch:<N>x<K>"   1: A-panel L2 prefetch in the lock-step GEMM, 2: off
+        //   "nt_store:<N>x<K>"   1: non-temporal result stores, 2: plain stores
+        //   "tile_order:<N>x<K>" gm | ns << 8
+        const bool order = n[0] == 't';
+        const size_t colon = n.find(':');
         int N = 0, K = 0;
         const int gm = value & 0xff, ns = (value >> 8) & 0xff;
-        if (std::sscanf(n.c_str() + 11, "%dx%d", &N, &K) != 2 || N <= 0 || K <= 0 || value < 0 || (value >> 16) != 0 || (value != 0 && (gm < 1 || gm > 64 || ns > 8)))
-            return fail(h, VQS_ERR_INVALID, "set_option: bad tile order: " + n + "=" + std::to_string(value));
-        for (size_t i = 0; i < h->tile_orders.size(); ++i)
-            if (h->tile_orders[i].N == N && h->tile_orders[i].K == K) { h->tile_orders.erase(h->tile_orders.begin() + i); break; }
-        if (value != 0) h->tile_orders.push_back(vqs_handle::TileOrder{N, K, gm, ns});
+        const bool value_ok = order ? (value >= 0 && (value >> 16) == 0 && (value == 0 || (gm >= 1 && gm <= 64 && ns <= 8))) : (value >= 0 && value <= 2);
+        if (std::sscanf(n.c_str() + colon + 1, "%dx%d", &N, &K) != 2 || N <= 0 || K <= 0 || !value_ok)
+            return fail(h, VQS_ERR_INVALID, "set_option: bad " + n.substr(0, colon) + ": " + n + "=" + std::to_string(value));
+        if (order) {
+            auto& v = h->tile_orders;
+            for (size_t i = 0; i < v.size(); ++i)
+                if (v[i].N == N && v[i].K == K) { v.erase(v.begin() + i); break; }
+            if (value != 0) v.push_back(vqs_handle::TileOrder{N, K, gm, ns});
+        } else {
+            auto& v = n[0] == 'l' ? h->l2_touches : h->nt_stores;
+            for (size_t i = 0; i < v.size(); ++i)
+                if (v[i].N == N && v[i].K == K) { v.erase(v.begin() + i); break; }
+            if (value != 0) v.push_back(vqs_handle::NtStore{N, K, value});
+        }
     }
     else return fail(h, VQS_ERR_INVALID, "set_option: unknown option or value: " + n + "=" + std::to_string(value));
     return VQS_OK;
