@@ -202,34 +202,12 @@ int vqs_score_head(const float* d_logits, int32_t ldl, int32_t V, const int32_t*
  *   "fused_norm"   0 (default) separate add+norm kernels, 1 residual update + RMSNorm operand in the o / wo GEMM epilogues
  *   "gemm_variant" 3 (default) persistent 8-wave kernels, 0 one tile per workgroup, 2 / 5 ping-pong schedule, 6 the four-wave
  *                  128x128 form for the big bf16-result launches (everything else of the pass runs the default forms); all bitwise equal
- *   "tile_order:<N>x<K>"  value = gm | ns << 8: tile order (see vqs_gemm) of every GEMM of a pass whose weight is [N, K];
- *                  0 removes the entry (back to the library's choice for that shape).  Bitwise-neutral.
- *   "l2_touch:<N>x<K>"    1: the lock-step GEMM prefetches the A panel two K-tiles ahead into L2 for the big launches whose weight is
- *                  [N, K], 2: it does not, 0: the library's rule by shape.  A hint: bitwise-neutral.
- *   "nt_store:<N>x<K>"    1: the results of every GEMM of a pass whose weight is [N, K] are stored with the non-temporal hint,
- *                  2: plain stores, 0: the library's choice for the call site.  A cache-policy hint: bitwise-neutral.
+ *   per-shape cache-policy names ("tile_order:", "l2_touch:", "nt_store:"): lab switches, see include/vqs_debug.h
  * Returns VQS_ERR_INVALID for an unknown name or value. */
 int vqs_set_option(vqs_handle* h, const char* name, int32_t value);
 
-/* Stage tap (parity tests): register a caller-owned device buffer for a named intermediate of the NEXT passes; when a
- * pass produces it, it is copied there on the pass's stream (device to device, no synchronisation).  The workspace
- * buffers are reused layer after layer, so this is how a test reads EVERY layer's tensors and checks each launch
- * against the oracle on the engine's own inputs (tests/test_gpu_stage_locked.py).  Names: "<stack>.<layer>.<what>" or
- * "<stack>.<what>": vit.{patch_out,h0,feat_in,pmid}; vit.<i>.{xn0,q,k,v,attn,d_attn,xn1,mid,d_mlp};
- * enc.emb; enc.<i>.{xn0,q,k,v,attn,d_attn,xn1,ff,d_ff}; dec.emb; dec.<i>.{xn0,qkv,sattn,d_self,xn1,cq,cqk,cscores,cprobs,cctx,
- * cattn,d_cross,xn2,ff,d_ff}.  bytes = capacity of d_dst (a pass fails with VQS_ERR_WORKSPACE if it is too small);
- * name == NULL clears every tap, d_dst == NULL removes one.  With no tap registered a pass pays one empty() test. */
-int vqs_debug_tap(vqs_handle* h, const char* name, void* d_dst, size_t bytes);
-/* Host-side test hook, no device access: the element offsets into a head-major [B, hx, S, hdim] tensor that the GEMM's
- * head-major epilogue (EPI_HEADS, the QKV projections' scatter -- HF modeling_t5.py:311-323 view/transpose) uses for the
- * rows row0 + 8k, k = 0..n-1, computed by the SAME inline functions as the kernel (one division, then steps).  S >= 8. */
-int vqs_debug_heads_rows(int32_t row0, int32_t S, int32_t hx, int32_t hdim, int32_t n, int64_t* off_out);
-/* Host-side test hook, no device access: the tile every workgroup slot of a persistent GEMM launch (grid workgroups, a multiple
- * of 8) computes under tile order (gm, ns), by the SAME inline functions as the launcher and the kernels: out[4*i .. 4*i+3] =
- * (slot, m0, n0, batch entry) for the M x N x K x batch problem, i < number of tiles.  gm = ns = 0 asks for the library's choice
- * by shape (the Infinity-Cache working-set rule, vqs_kernels.h resolve_tile_order).  Returns the resolved gm | ns << 8 (an
- * illegal ns falls back to 1) or a negative error. */
-int vqs_debug_tile_order(int32_t M, int32_t N, int32_t K, int32_t batch, int32_t gm, int32_t ns, int32_t grid, int32_t* out);
+/* Test hooks (stage taps, host-side restatements of the kernels' index arithmetic) and the cache-policy / execution-form lab
+ * switches of vqs_set_option are declared and documented in include/vqs_debug.h -- not part of the drop-in boundary. */
 /* Host-side arithmetic, no device access: dynamic LDS bytes vqs_attention / vqs_attention_hd request per workgroup for
  * sequence length S (hd 0 / 64 / 128).  The kernels' occupancy hangs on it (160 KiB of LDS per CU in 1 280-B granules);
  * -1 on bad arguments. */

@@ -166,7 +166,14 @@ class EngineRoundedOracle(Oracle):
         else:
             n = d.numel()
             ref_abs = float(e.abs().max())
-        self.report[name] = {"frac_diff": float((d > 0).sum()) / max(n, 1), "max_abs": float(d.max()), "ref_absmax": ref_abs, "n": n}
+        # per-element measure: the difference in units of the element's OWN bf16 ulp (2^(exponent - 7) of the larger of the two
+        # values) plus an absolute floor of 2^-18 of the tensor's top value -- the fp32 summation noise a result that cancels to
+        # nearly nothing still carries.  An absmax-relative bound alone lets a defect confined to small elements through.
+        big = torch.maximum(y.abs(), e.abs())
+        own_ulp = torch.ldexp(torch.ones_like(big), torch.frexp(big).exponent - 8)
+        own = d / (own_ulp + ref_abs * 2.0 ** -18 + 1e-37)
+        self.report[name] = {"frac_diff": float((d > 0).sum()) / max(n, 1), "max_abs": float(d.max()), "ref_absmax": ref_abs, "n": n,
+                             "max_own_ulps": float(own.max()), "frac_over_1_own_ulp": float((own > 1.0).sum()) / max(n, 1)}
         return e
 
     # ---------------------------------------------------------------------------------------------- helpers

@@ -6,6 +6,7 @@
 // No device allocation, no stream synchronisation, no CPU fallback: if a launch fails the call
 // returns VQS_ERR_HIP and the message says which one.
 #include "../../include/vqs.h"
+#include "../../include/vqs_debug.h"
 #include "vqs_kernels.h"
 
 #include <hip/hip_runtime.h>
@@ -64,6 +65,9 @@ struct vqs_handle {
     // stage taps (vqs_debug_tap): point name -> (caller buffer, capacity); the pass copies the named intermediate there
     struct Tap { void* dst; size_t cap; };
     std::unordered_map<std::string, Tap> taps;
+    // tap window (vqs_debug_tap_window): taps copy outer entries [tap_first, tap_first + tap_count) of tap_outer (pairs of the
+    // running T5 pass / images of the running vision pass; set by the pass); tap_count == 0: whole tensors
+    int tap_first = 0, tap_count = 0, tap_outer = 0;
     // per-shape tile order of the big GEMMs (option "tile_order:<N>x<K>"): a permutation of the tile list, results unchanged
     struct TileOrder { int N, K, gm, ns; };
     std::vector<TileOrder> tile_orders;
@@ -338,6 +342,14 @@ int tap(vqs_handle* h, const char* stack, int layer, const char* what, const voi
     const std::string name = layer >= 0 ? std::string(stack) + "." + std::to_string(layer) + "." + what : std::string(stack) + "." + what;
     auto it = h->taps.find(name);
     if (it == h->taps.end()) return VQS_OK;
+    if (h->tap_count > 0) {        // every intermediate is outer-entry-major: the window is one contiguous byte range of it
+        if (h->tap_outer <= 0 || h->tap_first + h->tap_count > h->tap_outer || bytes % (size_t)h->tap_outer != 0)
+            return fail(h, VQS_ERR_INVALID, "tap " + name + ": window [" + std::to_string(h->tap_first) + ", +" + std::to_string(h->tap_count) +
+                                            ") does not fit " + std::to_string(h->tap_outer) + " outer entries");
+        const size_t per = bytes / (size_t)h->tap_outer;
+        src = static_cast<const char*>(src) + per * (size_t)h->tap_first;
+        bytes = per * (size_t)h->tap_count;
+    }
     if (it->second.cap < bytes) return fail(h, VQS_ERR_WORKSPACE, "tap " + name + ": buffer too small (" + std::to_string(bytes) + " bytes needed)");
     HIPCHK(h, hipMemcpyAsync(it->second.dst, src, bytes, hipMemcpyDeviceToDevice, st), "tap copy");
     return VQS_OK;
@@ -353,6 +365,13 @@ int vqs_debug_tap(vqs_handle* h, const char* name, void* d_dst, size_t bytes) {
     if (!name) { h->taps.clear(); return VQS_OK; }
     if (!d_dst || bytes == 0) { h->taps.erase(name); return VQS_OK; }
     h->taps[name] = vqs_handle::Tap{d_dst, bytes};
+    return VQS_OK;
+}
+
+int vqs_debug_tap_window(vqs_handle* h, int32_t first, int32_t count) {
+    if (!h || first < 0 || count < 0) return VQS_ERR_INVALID;
+    h->tap_first = count > 0 ? first : 0;
+    h->tap_count = count;
     return VQS_OK;
 }
 
@@ -607,6 +626,7 @@ int vqs_encode_images(vqs_handle* h, const void* d_pixels, int32_t N, void* d_fe
     hipStream_t st = (hipStream_t)stream;
     const int hid = c.vis_hidden, P = h->P, Sv = h->Sv, mlp = c.vis_mlp, D = c.d_model;
     const int NP = N * P, NS = N * Sv;
+    h->tap_outer = N;
 
     GETW(cls, "vision.embeddings.class_embedding", hid);
     GETW(pos, "vision.embeddings.position_embedding.weight", (int64_t)Sv * hid);
@@ -733,6 +753,7 @@ static int encoder_pass(vqs_handle* h, const ScoreWs& w, const void* d_feats, co
     const int D = c.d_model, I = h->I, F = c.d_ff, H = c.n_heads, V = c.vocab;
     const int M = B * S, MT = B * T;
     (void)P; (void)M; (void)MT; (void)F; (void)I; (void)V;
+    h->tap_outer = B;
     GETW(shared, "shared.weight", (int64_t)V * D);
     GETW(enc_rel, "encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight", (int64_t)c.rel_buckets * H);
 
@@ -854,10 +875,15 @@ static int encoder_pass(vqs_handle* h, const ScoreWs& w, const void* d_feats, co
 // workgroup leaves 16-80 of 256 CUs busy, each walking the whole K (56-133 us per launch at XL for 8-21 MB of weights).
 // Split-K: the same persistent kernel run as a batched GEMM whose batch entries are K-slices (operand pointers advance
 // by K/s columns, fp32 partial tiles go to `scratch`), then one pass sums the s slices in a fixed order into bf16 --
-// deterministic (no atomics).  s = the largest divisor of K/64 with tiles*s <= 256 CUs and >= 4 K-tiles per slice.
+// deterministic (no atomics).  s = the largest divisor of K/64 with 2 * N-tiles * s <= 256 CUs and >= 4 K-tiles per slice:
+// a function of the WEIGHT's shape only.  The slicing fixes the order in which a row's fp32 partial sums are added, so it must
+// not depend on how many rows the launch has -- a pair's score in a 256-pair batch (MT = 512, two M-tiles) has to be bit-equal
+// to its score in a 4-pair batch (reference contract: independent cells, score.py:104-106; round 2 derived s from the tile
+// count of the launch, which made the decoder's bits depend on ceil(MT / 256)).  Two M-tiles are assumed because that is the
+// bench batch; a single M-tile then runs on half the CUs it could use (small-batch latency, not the metric).
 static int dec_linear(vqs_handle* h, const bf16_t* A, const bf16_t* W, bf16_t* out, int MT, int N, int K, float* scratch,
                       size_t scratch_bytes, hipStream_t st, const char* what) {
-    const int tiles = ((MT + 255) / 256) * ((N + 255) / 256);
+    const int tiles = 2 * ((N + 255) / 256);
     const int nt = K / 64;
     int sk = 1;
     if (h->splitk && MT <= 1024 && (K % 64) == 0 && (N % 8) == 0)
@@ -887,6 +913,7 @@ static int decoder_pass(vqs_handle* h, const ScoreWs& w, const int32_t* d_labels
     const int D = c.d_model, I = h->I, F = c.d_ff, H = c.n_heads, V = c.vocab;
     const int M = B * S, MT = B * T;
     (void)P; (void)M; (void)MT; (void)F; (void)I; (void)V;
+    h->tap_outer = B;
     // ---------------- decoder (teacher forced, T rows per pair)
     GETW(shared, "shared.weight", (int64_t)V * D);
     float* scratch = reinterpret_cast<float*>(w.ff);          // the encoder's FFN buffer [B*S, F] bf16 is idle from here on

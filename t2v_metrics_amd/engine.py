@@ -71,6 +71,7 @@ _SIGNATURES = {
     "vqs_attention_lds_bytes": (ctypes.c_int64, [_c_i32, _c_i32, _c_i32]),
     "vqs_set_option": (_c_i32, [_c_vp, ctypes.c_char_p, _c_i32]),
     "vqs_debug_tap": (_c_i32, [_c_vp, ctypes.c_char_p, _c_vp, ctypes.c_size_t]),
+    "vqs_debug_tap_window": (_c_i32, [_c_vp, _c_i32, _c_i32]),
     "vqs_debug_heads_rows": (_c_i32, [_c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_vp]),
     "vqs_debug_tile_order": (_c_i32, [_c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_vp]),
     "vqs_relpos_bucket": (_c_i32, [_c_i32, _c_i32, _c_i32, _c_i32]),
@@ -292,6 +293,11 @@ class VqsEngine:
             return
         nbytes = 0 if dst is None else dst.numel() * dst.element_size()
         self._check(self.lib.vqs_debug_tap(self._h, name.encode(), _ptr(dst), nbytes), "vqs_debug_tap")
+
+    def tap_window(self, first: int = 0, count: int = 0):
+        """Restrict the taps to `count` consecutive pairs (T5 stacks) / images (vision tower) starting at `first`
+        (vqs_debug_tap_window); count 0 = whole tensors."""
+        self._check(self.lib.vqs_debug_tap_window(self._h, int(first), int(count)), "vqs_debug_tap_window")
 
     def profile(self, on: bool):
         self._check(self.lib.vqs_profile_enable(self._h, 1 if on else 0), "vqs_profile_enable")

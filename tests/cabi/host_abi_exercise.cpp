@@ -1,6 +1,7 @@
 // Host-side exercise of the C ABI under AddressSanitizer + UBSan: everything that runs without touching a device
 // (creation, sizing, options, taps registration, error paths, integer helpers).  No GPU needed.
 #include "vqs.h"
+#include "vqs_debug.h"
 #include "vqs_qwen.h"
 #include <cassert>
 #include <cstdio>

@@ -16,11 +16,15 @@ def _declared_symbols(header="vqs.h"):
 def test_library_loads_and_exports_header_symbols():
     from t2v_metrics_amd import engine
     lib = engine.load_library()
-    declared = _declared_symbols()
-    assert len(declared) >= 15
+    boundary, hooks = _declared_symbols(), _declared_symbols("vqs_debug.h")
+    assert len(boundary) >= 15
+    # the drop-in boundary carries no test hook or lab switch; those live in include/vqs_debug.h
+    assert not [n for n in boundary if n.startswith(("vqs_debug_", "vqs_lab_"))], boundary
+    assert hooks and all(n.startswith("vqs_debug_") for n in hooks), hooks
+    declared = sorted(set(boundary) | set(hooks))
     for name in declared:
-        assert hasattr(lib, name), f"{name} declared in include/vqs.h but not exported"
-    assert set(declared) == set(engine.exported_symbols()), "engine.py signatures out of sync with include/vqs.h"
+        assert hasattr(lib, name), f"{name} declared in include/vqs.h / vqs_debug.h but not exported"
+    assert set(declared) == set(engine.exported_symbols()), "engine.py signatures out of sync with include/vqs.h + vqs_debug.h"
 
 
 def test_qwen_header_symbols_are_exported_and_bound():

@@ -71,44 +71,85 @@ def _record(name, payload):
         f.write(json.dumps({"case": name, **payload}) + "\n")
 
 
-def _one_pair_three_way(cfg, w, eng, tag, seed, emulate_regimes=("planted-head",), check_random=True):
-    """HIP vs the fp32 oracle for one pair of the full-size model, with the rounding-matched oracle (the same arithmetic
-    on the CPU) beside it as the calibrated noise level; random head (log P ~ -10.4, near-uniform) AND a peaked head: the lm_head rows of the two
-    labels are replaced by 12 * x / |x|^2 with x the engine's own final decoder state at that step ("planted
-    direction", SURVEY.md section 7), which puts P(label) at 0.2-0.8 -- the regime a real checkpoint scores in."""
+def _label_logprobs(dec_out, head, labels, acc=torch.float32):
+    """fp32 label log-probs of an lm_head [V, D] over a final decoder state [B, T, D] (the head is the only thing the regimes
+    below change, and the decoder input -- shift_right(labels) -- does not depend on it: one oracle pass serves them all)."""
+    logits = (dec_out.to(acc) @ head.to(acc).t()).float()
+    return torch.log_softmax(logits, -1).gather(-1, labels.long().unsqueeze(-1)).squeeze(-1)
+
+
+def _one_pair_three_way(cfg, w, eng, tag, seed, check_random=True):
+    """HIP vs the fp32 oracle for one pair of the full-size model, with the rounding-matched oracle (the engine's arithmetic on
+    the CPU, free-running) beside it as the calibrated noise level.  Four heads over the same pass:
+      random-head     the seeded lm_head: log P ~ -10.4 (near-uniform over 32 128 tokens);
+      planted-self    lm_head rows of the two labels := 12 x / |x|^2 with x the ENGINE's own final decoder state ("planted
+                      direction"): P(label) 0.2-0.8, the regime a real checkpoint scores in -- and the
+                      label logit is first-order insensitive to upstream error by construction (VERDICT r2, weak 1);
+      planted-oracle  the same with x taken from the FP32 ORACLE's decoder state: the direction is independent of the engine;
+                      the state sits behind an RMSNorm, so an upstream relative error eps moves the logit by 12 eps^2 / 2;
+      planted-tilted  direction at atan(3) ~ 72 degrees from the oracle's state (x + 3 |x| r, r a seeded unit vector orthogonal
+                      to x), gain such that the fp32 logit is 12: first-order sensitive -- the logit moves by 12 * 3 * (the
+                      state's relative error along r, ~ its norm-wise error / sqrt(D) for a direction drawn at random).  Held
+                      to the calibrated noise level and recorded for DESIGN.md, like the random head.
+    north_star's 1e-3 is asserted in the two planted regimes where it is well defined."""
     from oracle.clip_t5_oracle import Oracle
     pix, idx, ids, labels = _batch(cfg, 1, 1, 33, seed=seed)
     head = w["lm_head.weight"]
     saved = head[[2163, 1]].clone()
+    w_cpu = {k: v.cpu() for k, v in w.items()}
+    ref = Oracle(cfg, w_cpu).forward(pix.float(), idx, ids, labels, return_stages=True)
+    emu = Oracle(cfg, w_cpu, emulate="engine").forward(pix.float(), idx, ids, labels, return_stages=True)   # ~40 s at XXL
+    head_cpu = w_cpu["lm_head.weight"].float().clone()
+    del w_cpu
+    x_ref = ref["dec_out"].float()[0]                                            # [T, D]
     out = {}
     try:
-        for regime in ("random-head", "planted-head"):
-            lp, sc = eng.score(eng.encode_images(pix.cuda()), idx, ids, labels)
-            torch.cuda.synchronize()
+        lp, sc = eng.score(eng.encode_images(pix.cuda()), idx, ids, labels)
+        torch.cuda.synchronize()
+        x_eng = eng.stage("dec_out").float()[0].cpu()
+        g = torch.Generator().manual_seed(seed + 1000)
+        regimes = {"random-head": None, "planted-self": x_eng, "planted-oracle": x_ref}
+        tilt = []
+        for t in range(2):
+            r = torch.randn(x_ref.shape[1], generator=g)
+            r = r - (r @ x_ref[t]) / (x_ref[t] @ x_ref[t]) * x_ref[t]
+            tilt.append(x_ref[t] + 3.0 * x_ref[t].norm() * r / r.norm())
+        regimes["planted-tilted"] = torch.stack(tilt)
+        for regime, xdir in regimes.items():
             if regime == "random-head" and not check_random:
-                continue                  # still ran the pass above: the planted direction comes from its decoder state
-            if regime == "planted-head":
-                x = eng.stage("dec_out").float()[0]                   # [T, D]
-                head[2163] = (12.0 * x[0] / (x[0] @ x[0])).to(head.dtype)
-                head[1] = (12.0 * x[1] / (x[1] @ x[1])).to(head.dtype)
+                continue
+            hc = head_cpu.clone()
+            if xdir is not None:
+                for t, row in enumerate((2163, 1)):
+                    v = 12.0 * xdir[t] / (xdir[t] @ x_ref[t])                    # fp32 logit of the label = 12 (planted-self: ~12)
+                    head[row] = v.to(head.dtype).to(head.device)
+                    hc[row] = v.to(head.dtype).float()
                 lp, sc = eng.score(eng.encode_images(pix.cuda()), idx, ids, labels)     # lm_head is read in place
                 torch.cuda.synchronize()
-            w_cpu = {k: v.cpu() for k, v in w.items()}
-            ref = Oracle(cfg, w_cpu).forward(pix.float(), idx, ids, labels)
-            out[regime] = {"logp_hip": lp.cpu().tolist(), "logp_fp32": ref["label_logprobs"].tolist(),
-                           "dlogp_vs_fp32": (lp.cpu() - ref["label_logprobs"]).abs().max().item(), "rounding_matched_vs_fp32": 0.0}
-            if regime in emulate_regimes:          # the same arithmetic on the CPU = the calibrated noise level (~40 s at XXL)
-                emu = Oracle(cfg, w_cpu, emulate="engine").forward(pix.float(), idx, ids, labels)
-                out[regime]["dlogp_vs_rounding_matched"] = (lp.cpu() - emu["label_logprobs"]).abs().max().item()
-                out[regime]["rounding_matched_vs_fp32"] = (emu["label_logprobs"] - ref["label_logprobs"]).abs().max().item()
-            del w_cpu
+            lp_ref = _label_logprobs(ref["dec_out"].float(), hc, labels)
+            lp_emu = _label_logprobs(emu["dec_out"].float(), hc, labels, acc=torch.float64)
+            out[regime] = {"logp_hip": lp.cpu().tolist(), "logp_fp32": lp_ref.tolist(),
+                           "dlogp_vs_fp32": (lp.cpu() - lp_ref).abs().max().item(),
+                           "dlogp_vs_rounding_matched": (lp.cpu() - lp_emu).abs().max().item(),
+                           "rounding_matched_vs_fp32": (lp_emu - lp_ref).abs().max().item()}
+            head[[2163, 1]] = saved
     finally:
         head[[2163, 1]] = saved
+    rel = ((x_eng - x_ref).norm(dim=-1) / x_ref.norm(dim=-1)).max().item()
+    out["decoder_state_relative_error_vs_fp32"] = rel
     _record("fullsize/" + tag, out)
-    assert out["planted-head"]["logp_fp32"][0][0] > -3.0, out           # the planted regime really is peaked
-    for regime, o in out.items():
-        # bf16 operand noise, calibrated by what the same arithmetic shows on the CPU
-        assert o["dlogp_vs_fp32"] <= max(2.5e-2, 3.0 * o["rounding_matched_vs_fp32"]), (regime, out)
+    for regime in ("planted-self", "planted-oracle", "planted-tilted"):
+        assert out[regime]["logp_fp32"][0][0] > -3.0, out                        # the planted regimes really are peaked
+    # north_star's literal tolerance, where it is well defined: peaked head, direction = the decoder state (engine's or oracle's)
+    assert out["planted-self"]["dlogp_vs_fp32"] <= 1e-3, out
+    assert out["planted-oracle"]["dlogp_vs_fp32"] <= 1e-3, out
+    # first-order sensitive regimes: bf16 operand noise (DESIGN.md section 4), calibrated by what the same arithmetic shows on
+    # the CPU, under an absolute ceiling (the emulator must not be able to widen the gate without limit -- ADVICE r2)
+    for regime in ("random-head", "planted-tilted"):
+        if regime in out:
+            o = out[regime]
+            assert o["dlogp_vs_fp32"] <= min(max(2.5e-2, 3.0 * o["rounding_matched_vs_fp32"]), 5e-2), (regime, out)
+    assert rel <= 0.05, rel
 
 
 def test_xl_one_pair_three_way_random_and_peaked_head(xl):
@@ -124,8 +165,7 @@ def test_xxl_one_pair_three_way_random_and_peaked_head():
     w = make_seeded_weights(cfg, seed=0, device="cuda:0")
     eng = VqsEngine(cfg, w, device="cuda:0")
     try:
-        # the random-head regime at XXL is what bench.py's cpu_baseline.dlogp reports on every run; here: the peaked one
-        _one_pair_three_way(cfg, w, eng, "clip-flant5-xxl", seed=10, check_random=False)
+        _one_pair_three_way(cfg, w, eng, "clip-flant5-xxl", seed=10)
     finally:
         eng.close()
         del w

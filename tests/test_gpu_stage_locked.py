@@ -26,34 +26,57 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ATTENTION_TAPS = ("attn", "sattn", "cctx", "cattn")
 
 
-def run_stage_locked(cfg, w, eng, pix, idx, ids, labels, tag):
+def run_stage_locked(cfg, w, eng, pix, idx, ids, labels, tag, window=None):
+    """window = (first, count): the pass runs on the WHOLE batch, the taps and the oracle cover pairs first .. first+count-1
+    (vqs_debug_tap_window; their images must be rows first .. of `pix` in order) -- the stage-locked check of a few sampled
+    pairs inside a batch too large to tap whole (the benchmarked 256-pair XXL batch)."""
     from oracle.clip_t5_oracle import Oracle
     w_cpu = {k: v.cpu() for k, v in w.items()}
     emu = Oracle(cfg, w_cpu, emulate="engine")
     B, L = ids.shape
     T = labels.shape[1]
-    shapes = emu.tap_shapes(pix.shape[0], B, L, T)
+    if window is None:
+        first, cnt, n_img_t = 0, B, pix.shape[0]
+    else:
+        first, cnt = window
+        n_img_t = cnt
+        assert idx[first:first + cnt].tolist() == list(range(first, first + cnt)), "window pairs must use images first.. in order"
+    shapes = emu.tap_shapes(n_img_t, cnt, L, T)
     bufs = {n: torch.empty(shape, dtype=dt, device="cuda") for n, (shape, dt) in shapes.items()}
     for n, t in bufs.items():
         eng.tap(n, t)
+    if window is not None:
+        eng.tap_window(first, cnt)
     try:
         feats = eng.encode_images(pix.cuda())
         lp, sc = eng.score(feats, idx, ids, labels)
         torch.cuda.synchronize()
     finally:
         eng.tap(None)
+        eng.tap_window(0, 0)
     taps = {n: t.cpu() for n, t in bufs.items()}
-    taps.update(proj=feats.cpu(), enc_out=eng.stage("enc_out").cpu(), dec_out=eng.stage("dec_out").cpu(),
-                logits=eng.stage("logits").cpu())
+    S = L - 1 + cfg.vision.n_patches
+    sl = slice(first, first + cnt)
+    enc_out = eng.stage("enc_out").reshape(B, S, -1)[sl].reshape(cnt * S, -1)
+    dec_out = eng.stage("dec_out").reshape(B, T, -1)[sl].reshape(cnt * T, -1)
+    logits = eng.stage("logits").reshape(B, T, -1)[sl].reshape(cnt * T, -1)
+    taps.update(proj=feats[first:first + n_img_t].cpu() if window is not None else feats.cpu(), enc_out=enc_out.cpu(), dec_out=dec_out.cpu(),
+                logits=logits.cpu())
     del bufs
-    report, lp_from_engine_logits = emu.forward_locked(taps, pix.float(), idx, ids, labels)
+    if window is None:
+        pix_o, idx_o = pix, idx
+    else:
+        pix_o, idx_o = pix[sl], torch.arange(cnt, dtype=idx.dtype)
+    report, lp_from_engine_logits = emu.forward_locked(taps, pix_o.float().cpu(), idx_o.cpu(), ids[sl].cpu(), labels[sl].cpu())
+    lp = lp[sl]
     # ---- summary for profiles/
     worst = {}
     for n, r in report.items():
         kind = n.split(".")[-1]
-        a = worst.setdefault(n.split(".")[0] + "." + kind, {"frac_diff": 0.0, "max_abs_over_ref": 0.0, "taps": 0})
+        a = worst.setdefault(n.split(".")[0] + "." + kind, {"frac_diff": 0.0, "max_abs_over_ref": 0.0, "max_own_ulps": 0.0, "taps": 0})
         a["frac_diff"] = max(a["frac_diff"], r["frac_diff"])
         a["max_abs_over_ref"] = max(a["max_abs_over_ref"], r["max_abs"] / max(r["ref_absmax"], 1e-30))
+        a["max_own_ulps"] = max(a["max_own_ulps"], r["max_own_ulps"])
         a["taps"] += 1
     d_lp = (lp.cpu() - lp_from_engine_logits).abs().max().item()
     out = os.path.join(ROOT, "gpurun_out")
@@ -71,6 +94,12 @@ def run_stage_locked(cfg, w, eng, pix, idx, ids, labels, tag):
         else:
             ulps = 2.0 if kind in ATTENTION_TAPS else 1.0
             ok = r["frac_diff"] <= 5e-3 and rel <= ulps * 2.0 ** -7 * 1.001
+            # per element: a launch whose inputs are not re-rounded inside it (GEMM + epilogue, norm) differs from the oracle by
+            # at most ONE ulp of the element's own binade (+ the fp32-summation floor, see _emit) -- a defect confined to
+            # small-magnitude elements fails here although it passes the absmax-relative bound.  The attention kernels round P
+            # internally: a flipped P moves an output by 2^-8 p |v| whatever the output's own size, so they keep the bound above.
+            if kind not in ATTENTION_TAPS and kind != "cprobs":
+                ok = ok and r["max_own_ulps"] <= 1.001
         if not ok:
             bad.append((n, r))
     assert not bad, f"{len(bad)} of {len(report)} launch outputs off: {bad[:6]}"
