@@ -1360,6 +1360,8 @@ __global__ void __launch_bounds__(256) gemm_bf16_wide(const GemmParams p) {
 #include "lab/gemm_ring.inc"
 #endif
 
+#include "gemm_quad.inc"
+
 // =====================================================================================================
 // Persistent PING-PONG variant (VAR 5).  Same tile, LDS image, tile map and staged epilogue as the persistent kernel
 // above; what changes is WHO feeds the matrix pipe WHEN.  The two waves that share a SIMD (w and w+4, wave row
@@ -1624,7 +1626,11 @@ static hipError_t launch_epi(const GemmParams& p, int variant, hipStream_t strea
 #endif
     else if (variant == 2)
         hipLaunchKernelGGL((gemm_bf16_kernel<EPI, 2>), grid, block, 0, stream, p);
-    else if (variant == 6 && EPI != EPI_F32_RESID && EPI != EPI_F32 && p.batch <= 1 && tiles_m * tiles_n >= PERSISTENT_WGS) {
+    else if (variant == 10 && EPI != EPI_F32_RESID && EPI != EPI_F32 && p.batch <= 1 && tiles_m * tiles_n >= PERSISTENT_WGS && p.K >= 4 * BK) {
+        // quad form: bf16-result epilogues of the big launches; everything else of a variant-10 pass runs the default forms below
+        if constexpr (EPI != EPI_F32_RESID && EPI != EPI_F32)
+            hipLaunchKernelGGL((gemm_bf16_quad<EPI>), dim3(PERSISTENT_WGS), dim3(256), 0, stream, p);
+    } else if (variant == 6 && EPI != EPI_F32_RESID && EPI != EPI_F32 && p.batch <= 1 && tiles_m * tiles_n >= PERSISTENT_WGS) {
         // wide form: bf16-result epilogues of the big launches; everything else of a variant-6 pass runs the default forms below
         if constexpr (EPI != EPI_F32_RESID && EPI != EPI_F32)
             hipLaunchKernelGGL((gemm_bf16_wide<EPI>), dim3(PERSISTENT_WGS), dim3(256), 0, stream, p);
@@ -1691,12 +1697,12 @@ hipError_t launch_gemm(const GemmParams& p_in, int epilogue, int variant, hipStr
     // N: a lane stores 4 consecutive columns; fp32 output may have a ragged N if ldc leaves room for the overhang
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K % BK) != 0) return hipErrorInvalidValue;
     if ((p.N % 8) != 0 && !(epilogue == EPI_F32 && p.ldc >= ((p.N + 3) & ~3) && p.bias == nullptr)) return hipErrorInvalidValue;
-    if (p.batch > 1 && ((variant != 3 && variant != 4 && variant != 5 && variant != 6 && variant != 7 && variant != 8 && variant != 9) || epilogue == EPI_HEADS || epilogue == EPI_F32_RESID)) return hipErrorInvalidValue;
+    if (p.batch > 1 && ((variant != 3 && variant != 4 && variant != 5 && variant != 6 && variant != 7 && variant != 8 && variant != 9 && variant != 10) || epilogue == EPI_HEADS || epilogue == EPI_F32_RESID)) return hipErrorInvalidValue;
     if ((p.lda % 8) != 0 || (p.ldw % 8) != 0) return hipErrorInvalidValue;
     if ((p.hd > 64 || p.inner_kv > 0 || p.Hkv > 0 || p.gate_act != 0 || (epilogue == EPI_GATED && p.bias != nullptr)) &&
-        variant != 3 && variant != 5 && variant != 6 && variant != 7 && variant != 8 && variant != 9)
+        variant != 3 && variant != 5 && variant != 6 && variant != 7 && variant != 8 && variant != 9 && variant != 10)
         return hipErrorInvalidValue;   // generalised HEADS / GATED epilogues live in the persistent kernels only
-    if (p.rowss_in != nullptr && (p.rowss_parts < 0 || (variant != 3 && variant != 5 && variant != 6 && variant != 7 && variant != 8 && variant != 9) || epilogue == EPI_F32_RESID))
+    if (p.rowss_in != nullptr && (p.rowss_parts < 0 || (variant != 3 && variant != 5 && variant != 6 && variant != 7 && variant != 8 && variant != 9 && variant != 10) || epilogue == EPI_F32_RESID))
         return hipErrorInvalidValue;   // the row scale lives in the persistent kernels' staged epilogue only
     switch (epilogue) {
         case EPI_BF16: return launch_epi<EPI_BF16>(p, variant, stream);
