@@ -947,6 +947,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) 
 #undef PGLDS_A
 #undef PGLDS_W
 
+#ifdef VQS_LAB   // the wide form lost to the 8-wave forms by 8-10 % (round 2) and to the quad form by 25-35 %: lab builds only
 // =====================================================================================================
 // WIDE variant (VAR 6): the same 256x256x64 tile, LDS image, LDS-DMA staging, tile order and staged epilogue -- computed by
 // FOUR waves of 128x128 (one per SIMD, 256 fp32 accumulators per lane) instead of eight of 128x64.
@@ -1351,6 +1352,8 @@ __global__ void __launch_bounds__(256) gemm_bf16_wide(const GemmParams p) {
 }
 
 
+#endif   // VQS_LAB (wide form)
+
 #ifdef VQS_LAB
 #include "lab/gemm_ws.inc"
 #endif
@@ -1604,10 +1607,27 @@ static int l2_touch_mode() {
 #endif
 }
 
+// Which launches the quad form carries: a function of the epilogue and the WEIGHT's shape only (never of M).
+template <int EPI>
+static bool quad_eligible(const GemmParams& p) {
+    if constexpr (!(EPI == EPI_BF16 || EPI == EPI_BF16_QGELU || EPI == EPI_BF16_GELU || EPI == EPI_GATED || EPI == EPI_HEADS)) return false;
+    if (p.batch > 1 || p.K < 2 * BK || p.rowss_in != nullptr) return false;
+    if constexpr (EPI == EPI_GATED) {
+        if ((p.N % 64) != 0) return false;
+    }
+    if constexpr (EPI == EPI_HEADS) {
+        // a wave's 128 columns must lie inside ONE of the q / k / v tensors (one head count per block); rows step by 4 within a sample
+        const int ikv = p.inner_kv > 0 ? p.inner_kv : p.inner;
+        if (p.S < 8 || (p.inner % 128) != 0 || (ikv % 128) != 0) return false;
+    }
+    return true;
+}
+
 template <int EPI>
 static hipError_t launch_epi(const GemmParams& p, int variant, hipStream_t stream) {
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
     dim3 grid(tiles_m * tiles_n), block(512);
+    // variant 11 = the 8-wave forms by the round-1/2 shape rule for every launch (A/B against the quad form; below it is variant 3)
     if constexpr (EPI == EPI_RESID_RMS) {
         // only the persistent kernels carry this epilogue (LDS-staged, needs the cross-wave row reduction)
         const int nwg = tiles_m * tiles_n;
@@ -1626,15 +1646,18 @@ static hipError_t launch_epi(const GemmParams& p, int variant, hipStream_t strea
 #endif
     else if (variant == 2)
         hipLaunchKernelGGL((gemm_bf16_kernel<EPI, 2>), grid, block, 0, stream, p);
-    else if (variant == 10 && EPI != EPI_F32_RESID && EPI != EPI_F32 && p.batch <= 1 && tiles_m * tiles_n >= PERSISTENT_WGS && p.K >= 4 * BK) {
-        // quad form: bf16-result epilogues of the big launches; everything else of a variant-10 pass runs the default forms below
-        if constexpr (EPI != EPI_F32_RESID && EPI != EPI_F32)
-            hipLaunchKernelGGL((gemm_bf16_quad<EPI>), dim3(PERSISTENT_WGS), dim3(256), 0, stream, p);
+    else if ((variant == 3 || variant == 10) && quad_eligible<EPI>(p)) {
+        // quad form (gemm_quad.inc): every bf16-result launch of a call site, WHATEVER its M -- the form's k-order differs from the
+        // 8-wave forms' in the last ulp, so a weight must not change form with the batch size (a pair's bits are batch-invariant)
+        if constexpr (EPI == EPI_BF16 || EPI == EPI_BF16_QGELU || EPI == EPI_BF16_GELU || EPI == EPI_GATED || EPI == EPI_HEADS) {
+            const int nwg = tiles_m * tiles_n;
+            hipLaunchKernelGGL((gemm_bf16_quad<EPI>), dim3(nwg < PERSISTENT_WGS ? nwg : PERSISTENT_WGS), dim3(256), 0, stream, p);
+        }
+#ifdef VQS_LAB
     } else if (variant == 6 && EPI != EPI_F32_RESID && EPI != EPI_F32 && p.batch <= 1 && tiles_m * tiles_n >= PERSISTENT_WGS) {
         // wide form: bf16-result epilogues of the big launches; everything else of a variant-6 pass runs the default forms below
         if constexpr (EPI != EPI_F32_RESID && EPI != EPI_F32)
             hipLaunchKernelGGL((gemm_bf16_wide<EPI>), dim3(PERSISTENT_WGS), dim3(256), 0, stream, p);
-#ifdef VQS_LAB
     } else if (variant == 9 && EPI != EPI_F32_RESID && EPI != EPI_F32 && p.batch <= 1 && tiles_m * tiles_n >= PERSISTENT_WGS) {
         if constexpr (EPI != EPI_F32_RESID && EPI != EPI_F32)
             hipLaunchKernelGGL((gemm_bf16_wide<EPI, 1>), dim3(PERSISTENT_WGS), dim3(256), 0, stream, p);
@@ -1692,17 +1715,17 @@ hipError_t launch_gemm(const GemmParams& p_in, int epilogue, int variant, hipStr
     GemmParams p = p_in;
     resolve_tile_order(p, PERSISTENT_WGS);
 #ifndef VQS_LAB
-    if (variant == 1 || variant == 4 || variant == 7 || variant == 8 || variant == 9) return hipErrorInvalidValue;     // lab-only forms (see the file header)
+    if (variant == 1 || variant == 4 || variant == 6 || variant == 7 || variant == 8 || variant == 9) return hipErrorInvalidValue;     // lab-only forms (see the file header)
 #endif
     // N: a lane stores 4 consecutive columns; fp32 output may have a ragged N if ldc leaves room for the overhang
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K % BK) != 0) return hipErrorInvalidValue;
     if ((p.N % 8) != 0 && !(epilogue == EPI_F32 && p.ldc >= ((p.N + 3) & ~3) && p.bias == nullptr)) return hipErrorInvalidValue;
-    if (p.batch > 1 && ((variant != 3 && variant != 4 && variant != 5 && variant != 6 && variant != 7 && variant != 8 && variant != 9 && variant != 10) || epilogue == EPI_HEADS || epilogue == EPI_F32_RESID)) return hipErrorInvalidValue;
+    if (p.batch > 1 && ((variant != 3 && variant != 4 && variant != 5 && variant != 6 && variant != 7 && variant != 8 && variant != 9 && variant != 10 && variant != 11) || epilogue == EPI_HEADS || epilogue == EPI_F32_RESID)) return hipErrorInvalidValue;
     if ((p.lda % 8) != 0 || (p.ldw % 8) != 0) return hipErrorInvalidValue;
     if ((p.hd > 64 || p.inner_kv > 0 || p.Hkv > 0 || p.gate_act != 0 || (epilogue == EPI_GATED && p.bias != nullptr)) &&
-        variant != 3 && variant != 5 && variant != 6 && variant != 7 && variant != 8 && variant != 9 && variant != 10)
+        variant != 3 && variant != 5 && variant != 6 && variant != 7 && variant != 8 && variant != 9 && variant != 10 && variant != 11)
         return hipErrorInvalidValue;   // generalised HEADS / GATED epilogues live in the persistent kernels only
-    if (p.rowss_in != nullptr && (p.rowss_parts < 0 || (variant != 3 && variant != 5 && variant != 6 && variant != 7 && variant != 8 && variant != 9 && variant != 10) || epilogue == EPI_F32_RESID))
+    if (p.rowss_in != nullptr && (p.rowss_parts < 0 || (variant != 3 && variant != 5 && variant != 6 && variant != 7 && variant != 8 && variant != 9 && variant != 10 && variant != 11) || epilogue == EPI_F32_RESID))
         return hipErrorInvalidValue;   // the row scale lives in the persistent kernels' staged epilogue only
     switch (epilogue) {
         case EPI_BF16: return launch_epi<EPI_BF16>(p, variant, stream);

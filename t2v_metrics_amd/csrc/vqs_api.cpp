@@ -485,9 +485,9 @@ int vqs_set_option(vqs_handle* h, const char* name, int32_t value) {
     else if (n == "splitk" && (value == 0 || value == 1)) h->splitk = value;
     else if (n == "fused_norm" && (value == 0 || value == 1)) h->fused_norm = value;
     else if (n == "norm_defer" && (value == 0 || value == 1)) h->norm_defer = value;
-    else if (n == "gemm_variant" && (value == 0 || value == 2 || value == 3 || value == 5 || value == 6)) h->gemm_variant = value;
+    else if (n == "gemm_variant" && (value == 0 || value == 2 || value == 3 || value == 5 || value == 11)) h->gemm_variant = value;
 #ifdef VQS_LAB
-    else if (n == "gemm_variant" && (value == 7 || value == 8 || value == 9)) h->gemm_variant = value;     // lab forms: forced lock-step, ring, wide + touch
+    else if (n == "gemm_variant" && (value == 6 || value == 7 || value == 8 || value == 9)) h->gemm_variant = value;     // lab forms: wide, forced lock-step, ring, wide + touch
 #endif
     else if (n.rfind("l2_touch:", 0) == 0 || n.rfind("nt_store:", 0) == 0 || n.rfind("tile_order:", 0) == 0) {
         // per weight shape [N, K], for the big launches of a pass; 0 removes the entry = the library's choice.  All three are
@@ -771,7 +771,7 @@ static int encoder_pass(vqs_handle* h, const ScoreWs& w, const void* d_feats, co
     // the consuming qkv / wi GEMM scales its accumulator rows by 1/rms.  Bit-exact repeatable and parity-tested, but the
     // read-modify-write epilogue costs the producer GEMMs +0.55 ms per launch against 0.64 ms for the norm kernel it
     // removes (+1 % end to end, and it lowers the GEMM's own roofline fraction): kept as a lab path.
-    const bool fused = h->fused_norm != 0 && (h->gemm_variant == 3 || h->gemm_variant == 5 || h->gemm_variant == 7);   // not the wide form (6)
+    const bool fused = h->fused_norm != 0 && (h->gemm_variant == 11 || h->gemm_variant == 5 || h->gemm_variant == 7);   // the 8-wave forms carry the fused epilogue (lab path), not the quad form
     const int parts = (D + 255) / 256;
     bool scaled = false;          // w.xn holds an un-normalised operand whose row sums are in w.rowss
     const bf16_t* pend = nullptr;

@@ -18,6 +18,7 @@ def main():
     nocheck = {sys.argv[i + 1] for i, a in enumerate(sys.argv) if a == "--no-check"}
     variants = [int(sys.argv[i + 1]) for i, a in enumerate(sys.argv) if a == "--variant"] or [8]
     shapes = XXL + [VIT[1], VIT[0]] if "--all" not in sys.argv else XXL + XL + VIT
+    tol = "--tol" in sys.argv
     libs = []
     for a in args:
         name, path = a.split("=", 1)
@@ -36,22 +37,41 @@ def main():
         if name in nocheck:
             continue
         bad = []
-        for M, N, K, epi in [(33000, 2048, 64, 0), (33000 - 7, 2048 - 8, 128, 0), (20000, 4096, 1024, 1), (16384, 8192, 256, 5), (131072, 512, 2048, 0),
-                             (256 * 300 + 1, 256, 320, 0), (70000, 512, 64, 0)]:
+        stats = []
+        for M, N, K, epi in [(33000, 2048, 128, 0), (33000 - 7, 2048 - 8, 128, 0), (20000, 4096, 1024, 1), (16384, 8192, 256, 5), (131072, 512, 2048, 0),
+                             (256 * 300 + 1, 256, 320, 0), (70000, 512, 192, 2), (300, 264, 192, 0), (40, 64, 640, 0)]:
             A = randn_bf16(M, K, seed=81)
             W = randn_bf16(N, K, seed=82, scale=K ** -0.5)
-            bias = randn_bf16(N, seed=83) if epi in (0, 1) else None
+            bias = randn_bf16(N, seed=83) if epi in (0, 1, 2) else None
             NO = N // 2 if epi == 5 else N
             ref = torch.empty(M, NO, dtype=torch.bfloat16, device="cuda")
             gemm(lib, A, W, ref, bias, M, N, K, epi, 0, 0, 0)
             for v in variants:
+                first = None
                 for rep in range(3):
                     out = torch.full((M, NO), float("nan"), dtype=torch.bfloat16, device="cuda")
                     gemm(lib, A, W, out, bias, M, N, K, epi, 0, 0, v)
-                    if not torch.equal(out, ref):
+                    if first is None:
+                        first = out
+                    elif not torch.equal(out, first):
+                        bad.append({"variant": v, "shape": [M, N, K, epi], "rep": rep, "what": "not repeatable"})
+                    if tol:
+                        o, r = out.float(), ref.float()
+                        d = (o - r).abs()
+                        big = torch.maximum(o.abs(), r.abs())
+                        ulp = torch.ldexp(torch.ones_like(big), torch.frexp(big).exponent - 8)
+                        own = (d / ulp).max().item() if torch.isfinite(d).all() else float("inf")
+                        frac = (d > 0).float().mean().item()
+                        if rep == 0:
+                            stats.append({"shape": [M, N, K, epi], "frac_diff": round(frac, 6), "max_own_ulps": own})
+                        if not (own <= 1.0 and frac <= 0.02):
+                            bad.append({"variant": v, "shape": [M, N, K, epi], "rep": rep, "max_own_ulps": own, "frac": frac,
+                                        "nan": int(torch.isnan(o).sum())})
+                    elif not torch.equal(out, ref):
                         d = (out.float() - ref.float()).abs()
                         bad.append({"variant": v, "shape": [M, N, K, epi], "rep": rep, "max_abs_diff": d.max().item(), "frac": (d > 0).float().mean().item()})
-        emit({"part": "R2", "lib": name, "bitwise_check_vs_variant0": "ok" if not bad else "MISMATCH", "mismatches": bad[:6]})
+        emit({"part": "R2", "lib": name, "check_vs_variant0": ("<= 1 bf16 ulp" if tol else "bitwise"), "result": "ok" if not bad else "MISMATCH",
+              "mismatches": bad[:6], "stats": stats})
     g = torch.Generator(device="cuda").manual_seed(0)
     for tag, M, N, K, epi, S, H, has_bias in shapes:
         A = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
@@ -59,7 +79,7 @@ def main():
         out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
         res = {}
         for rnd in range(2):
-            res.setdefault("product v3", []).append(round(2.0 * M * N * K / time_ms(lambda: gemm(libs[0][1], A, W, out, None, M, N, K, 0, 0, 0, 3), 5) / 1e9, 1))
+            res.setdefault("8-wave v11", []).append(round(2.0 * M * N * K / time_ms(lambda: gemm(libs[0][1], A, W, out, None, M, N, K, 0, 0, 0, 11), 5) / 1e9, 1))
             for name, lib in libs:
                 for v in variants:
                     ms = time_ms(lambda: gemm(lib, A, W, out, None, M, N, K, 0, 0, 0, v), 5)
