@@ -771,7 +771,7 @@ static int encoder_pass(vqs_handle* h, const ScoreWs& w, const void* d_feats, co
     // the consuming qkv / wi GEMM scales its accumulator rows by 1/rms.  Bit-exact repeatable and parity-tested, but the
     // read-modify-write epilogue costs the producer GEMMs +0.55 ms per launch against 0.64 ms for the norm kernel it
     // removes (+1 % end to end, and it lowers the GEMM's own roofline fraction): kept as a lab path.
-    const bool fused = h->fused_norm != 0 && (h->gemm_variant == 11 || h->gemm_variant == 5 || h->gemm_variant == 7);   // the 8-wave forms carry the fused epilogue (lab path), not the quad form
+    const bool fused = h->fused_norm != 0 && (h->gemm_variant == 3 || h->gemm_variant == 11 || h->gemm_variant == 5 || h->gemm_variant == 7);   // the fused epilogue's launches are not quad-eligible: they run the 8-wave forms
     const int parts = (D + 255) / 256;
     bool scaled = false;          // w.xn holds an un-normalised operand whose row sums are in w.rowss
     const bf16_t* pend = nullptr;

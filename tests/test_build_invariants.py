@@ -23,7 +23,7 @@ pytestmark = pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipc
 
 
 def _kernels(src):
-    deps = [os.path.join(CSRC, src), os.path.join(CSRC, "vqs_kernels.h")]
+    deps = [os.path.join(CSRC, src), os.path.join(CSRC, "vqs_kernels.h")] + ([os.path.join(CSRC, "gemm_quad.inc")] if src == "gemm.hip" else [])
     key = "_".join("%d-%d" % (os.path.getsize(d), int(os.path.getmtime(d))) for d in deps)
     out_dir = os.path.join(ROOT, "build", "isa")
     os.makedirs(out_dir, exist_ok=True)
@@ -46,12 +46,15 @@ def _kernels(src):
             "vgpr": field("vgpr_count"), "vgpr_spill": field("vgpr_spill_count"), "wg": field("max_flat_workgroup_size"),
             "agpr": int(entry.split()[0])}
     assert out, "no kernel metadata found in " + asm
+    out["__asm__"] = text
     return out
 
 
 @pytest.mark.parametrize("src", ["gemm.hip", "attn.hip", "elementwise.hip"])
 def test_no_kernel_spills_or_exceeds_the_cu(src):
     for name, k in _kernels(src).items():
+        if name == "__asm__":
+            continue
         assert k["vgpr_spill"] == 0 and k["scratch"] == 0, (name, k)
         assert k["lds"] <= LDS_PER_CU, (name, k)
         # a 512-thread workgroup is two waves per SIMD: at most 256 registers per lane each
@@ -67,6 +70,7 @@ def test_attention_lds_budget_keeps_its_occupancy():
     from t2v_metrics_amd import engine
     lib = engine.load_library()
     ks = _kernels("attn.hip")
+    ks = {n: k for n, k in ks.items() if n != "__asm__"}
     dma = {n: k for n, k in ks.items() if "attn_fwd_dma_kernel" in n}
     hd = {n: k for n, k in ks.items() if "attn_fwd_hd_kernel" in n}
     assert len(dma) == 2 and len(hd) == 2
@@ -84,28 +88,63 @@ def test_attention_lds_budget_keeps_its_occupancy():
 
 def test_gemm_kernels_own_the_cu():
     """One GEMM workgroup per CU by construction: two 64-KiB stages (+ the 2-KiB touch sink / row-reduction scratch of the
-    variants that have one) leave no room for a second, and the persistent grid is sized for that.  The 8-wave forms are
-    512 threads (two waves per SIMD, <= 256 registers per lane); the wide form is 256 threads -- ONE wave per SIMD, whose 256
-    fp32 accumulators per lane are the whole AGPR file (hand-allocated, gemm.hip mfma_fixed) next to <= 256 VGPRs."""
-    wide = 0
-    for name, k in _kernels("gemm.hip").items():
-        if "gemm_bf16" in name:
+    variants that have one, + 32 KiB of epilogue scratch in the quad form = all 160 KiB) leave no room for a second, and the
+    persistent grid is sized for that.  The 8-wave forms are 512 threads (two waves per SIMD, <= 256 registers per lane); the
+    quad form is 256 threads -- ONE wave per SIMD, whose 256 fp32 accumulators per lane are the whole AGPR file."""
+    quad = 0
+    ks = _kernels("gemm.hip")
+    for name, k in ks.items():
+        if name == "__asm__" or "gemm_bf16" not in name:
+            continue
+        assert _resident(k["lds"], 0) == 1, (name, k)
+        if "gemm_bf16_quad" in name:
+            quad += 1
+            assert k["lds"] == 2 * 65536 + 32768 and k["wg"] == 256 and k["vgpr"] <= 512, (name, k)
+        else:
             assert 2 * 65536 <= k["lds"] <= 2 * 65536 + 8192, (name, k)
-            assert _resident(k["lds"], 0) == 1, (name, k)
-            if "gemm_bf16_wide" in name:
-                wide += 1
-                assert k["wg"] == 256 and k["agpr"] == 256 and k["vgpr"] <= 512, (name, k)
-            else:
-                assert k["wg"] == 512 or "gemm_bf16_ws" in name, (name, k)
-    assert wide == 5, "wide form: epilogues bf16, quick_gelu, erf-GELU, gated, head-major"
+            assert k["wg"] == 512, (name, k)
+    assert quad == 5, "quad form: epilogues bf16, quick_gelu, erf-GELU, gated, head-major"
+
+
+def test_quad_form_keeps_the_compiler_out_of_its_accumulators():
+    """gemm_bf16_quad names its 256 accumulator registers itself (a[4 Q : 4 Q + 3] per 16 x 16 block, gemm_quad.inc) in asm
+    statements the register allocator cannot see into.  That is sound only while the compiler puts nothing of its own
+    into AGPRs -- no fragment, no spill slot, no copy (one draft of the form had `ds_read_b128 a[0:3], ...` in a cold path:
+    silent corruption of an accumulator).  Checked on the ISA of every instantiation: the kernel descriptor reserves exactly
+    256 AGPRs behind the VGPRs, an AGPR appears only as the C/D operand of a v_mfma or the source of a v_accvgpr_read, there is
+    no v_accvgpr_write / scratch access, and the K loop's instruction mix is the scheduled one."""
+    text = _kernels("gemm.hip")["__asm__"]
+    found = 0
+    for m in re.finditer(r"^(_ZN3vqs14gemm_bf16_quadILi(\d+)EEEvNS_10GemmParamsE):[^\n]*\n(.*?)^\.Lfunc_end", text, flags=re.S | re.M):
+        found += 1
+        name, body = m.group(1), m.group(3)
+        desc = text[text.index(".amdhsa_kernel " + name):]
+        desc = desc[:desc.index(".end_amdhsa_kernel")]
+        nxt = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", desc).group(1))
+        acc = int(re.search(r"\.amdhsa_accum_offset (\d+)", desc).group(1))
+        assert nxt - acc == 256 and acc <= 256, (name, nxt, acc)
+        code = [l.split(";")[0].strip() for l in body.splitlines()]
+        code = [l for l in code if l and not l.startswith((".", ";")) and not l.endswith(":")]
+        agpr = re.compile(r"\ba(\[\d+(:\d+)?\]|\d+)\b")
+        bad = [l for l in code if agpr.search(l) and not l.startswith(("v_mfma_f32_16x16x32_bf16", "v_accvgpr_read_b32"))]
+        assert not bad, (name, bad[:5])
+        assert not [l for l in code if l.startswith(("v_accvgpr_write", "scratch_", "v_accvgpr_mov"))], name
+        for l in code:
+            if l.startswith("v_mfma"):
+                ops = [o.strip() for o in l.split(None, 1)[1].split(",")]
+                assert ops[0].startswith("a[") and ops[1].startswith("v[") and ops[2].startswith("v[") and (ops[3] == "0" or ops[3] == ops[0]), l
+        n_mfma = sum(l.startswith("v_mfma") for l in code)
+        assert n_mfma == 3 * 128, (name, n_mfma)                    # FIRST / MID / LAST K-tile bodies, nothing unrolled twice
+        assert sum(" lds" in l and l.startswith("buffer_load_dwordx4") for l in code) == 3 * 16 + 2 * 16, name   # + the two K-tiles of the prologue
+    assert found == 5
 
 
 def test_shipped_library_has_no_lab_code_and_reads_no_environment():
     """Hygiene of libvqs_hip.so: the A/B forms kept for the record (wave-specialised GEMM, register-staged GEMM and
     attention) are compiled only under -DVQS_LAB (make lab -> build/lab/, never loaded by the package), and the product
     library does not import getenv: execution forms are chosen through vqs_set_option, not through the environment."""
-    names = set(_kernels("gemm.hip")) | set(_kernels("attn.hip"))
-    assert not [n for n in names if "gemm_bf16_ws" in n or "attn_fwd_kernel" in n], names
+    names = (set(_kernels("gemm.hip")) | set(_kernels("attn.hip"))) - {"__asm__"}
+    assert not [n for n in names if "gemm_bf16_ws" in n or "attn_fwd_kernel" in n or "gemm_bf16_wide" in n or "gemm_bf16_ring" in n], names
     assert not [n for n in names if re.search(r"gemm_bf16_kernelILi\d+ELi1EE", n)], "register-staged GEMM (variant 1) instantiated"
     assert any("gemm_bf16_persistent" in n for n in names) and any("attn_fwd_dma_kernel" in n for n in names)
     lib = os.path.join(ROOT, "t2v_metrics_amd", "libvqs_hip.so")

@@ -21,7 +21,8 @@ def eng():
 GEMM_SHAPES = [(256, 256, 64), (512, 768, 128), (300, 264, 192), (2065, 1024, 1024), (512, 1000, 256), (40, 64, 640)]
 
 
-@pytest.mark.parametrize("variant", [0, 2, 3, 5])       # the shipped kernels (1 / 4 / 7 exist in -DVQS_LAB builds only)
+@pytest.mark.parametrize("variant", [0, 2, 3, 5, 11])   # the shipped kernels (3 = the library's rule: the quad form wherever it is eligible;
+                                                        # 11 = the 8-wave forms by shape; 1 / 4 / 6-9 exist in -DVQS_LAB builds only)
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
 def test_gemm_bf16_and_f32(eng, M, N, K, variant):
     A = randn_bf16(M, K, seed=1)
@@ -60,7 +61,7 @@ def test_gemm_persistent_many_tiles(eng, M, N, K, epi):
     bias = randn_bf16(N, seed=33)
     resid = torch.randn(M, N, device="cuda", generator=torch.Generator(device="cuda").manual_seed(34)) if epi == 4 else None
     ref = eng.gemm(A, W, epi, bias=bias, resid=resid, variant=0)
-    for variant in (3, 5, 6):          # 6 = the four-wave 128x128 form (fp32-result epilogues run the default form under it)
+    for variant in (3, 5, 11):         # 3 = the quad form for the bf16-result epilogues (16x16x32 MFMAs: the same bits), 11 = the 8-wave rule
         for _ in range(3):
             out = eng.gemm(A, W, epi, bias=bias, resid=resid, variant=variant)
             assert torch.equal(out, ref), describe(out, ref)
@@ -81,7 +82,7 @@ def test_gemm_tile_order_is_bitwise_neutral(eng, M, N, K, epi, S, H):
     A = randn_bf16(M, K, seed=61)
     W = randn_bf16(N, K, seed=62, scale=K ** -0.5)
     ref = eng.gemm(A, W, epi, S=S, H=H, variant=0)
-    for variant in (3, 5, 6, 0):
+    for variant in (3, 5, 11, 0):
         for order in ((8, 1), (4, 1), (2, 1), (1, 1), (16, 1), (3, 1), (8, 2), (4, 2), (2, 4), (64, 4)):
             out = eng.gemm(A, W, epi, S=S, H=H, variant=variant, tile_order=order)
             assert torch.equal(out, ref), (variant, order, describe(out, ref))
@@ -99,23 +100,25 @@ def test_gemm_tile_order_is_bitwise_neutral(eng, M, N, K, epi, S, H):
     (608 * 40, 3 * 1024, 192, 6, 608, 16), # head-major scatter, sample boundaries inside tiles
     (577 * 64, 3 * 1024, 128, 6, 577, 16), # ... with the ViT's odd sequence length
     (131072, 512, 2048, 0, 0, 0)])         # long K, many tiles per workgroup
-def test_gemm_wide_form_is_bitwise_the_other_forms(eng, M, N, K, epi, S, H):
-    """gemm_bf16_wide (variant 6): the same 256x256x64 tiles computed by four waves of 128x128 with the accumulators in
-    hand-allocated AGPRs and a hand-pipelined K loop.  Same MFMA instruction, operand maps and K order per output element:
-    bit for bit the one-tile-per-workgroup kernel (variant 0) and the 8-wave persistent kernel, on every epilogue it
-    carries, with ragged edges, repeated (no dependence on what the previous launch left in LDS / registers)."""
+def test_gemm_quad_form_is_bitwise_the_other_forms(eng, M, N, K, epi, S, H):
+    """gemm_bf16_quad (the library's default for bf16-result launches, variant 3): 256x256x64 tiles computed by four waves of
+    128x128 on v_mfma_f32_16x16x32_bf16 with the accumulators in hand-named AGPRs, a table-scheduled K loop and the
+    stream two K-tiles ahead through range-checked descriptors.  A 16x16x32 MFMA adds a step's 32 products in the same order
+    as two 32x32x16 MFMAs do: bit for bit the one-tile-per-workgroup kernel (variant 0) and the 8-wave persistent kernels
+    (variant 11), on every epilogue it carries, with ragged edges (rows beyond M / N come back as zeros from the descriptor's
+    range check instead of clamped copies), repeated (no dependence on what the previous launch left in LDS / registers)."""
     A = randn_bf16(M, K, seed=71)
     W = randn_bf16(N, K, seed=72, scale=K ** -0.5)
     bias = randn_bf16(N, seed=73) if epi in (0, 1, 2, 6) else None
     ref = eng.gemm(A, W, epi, bias=bias, S=S, H=H, variant=0)
-    assert torch.equal(eng.gemm(A, W, epi, bias=bias, S=S, H=H, variant=3), ref)
+    assert torch.equal(eng.gemm(A, W, epi, bias=bias, S=S, H=H, variant=11), ref)
     for _ in range(3):
-        out = eng.gemm(A, W, epi, bias=bias, S=S, H=H, variant=6)
+        out = eng.gemm(A, W, epi, bias=bias, S=S, H=H, variant=3)
         assert torch.equal(out, ref), describe(out, ref)
     if epi in (0, 1, 2):                   # and against fp32 torch, so that the three forms cannot be wrong together
         full = A.float() @ W.float().t() + bias.float()
         full = quick_gelu(full) if epi == 1 else (gelu_erf(full) if epi == 2 else full)
-        assert_close(out, full, 2e-2, 1e-2, "wide form vs fp32")
+        assert_close(out, full, 2e-2, 1e-2, "quad form vs fp32")
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 512, 128), (1000, 768, 256), (70000, 512, 64)])
