@@ -27,6 +27,14 @@ int vqs_debug_heads_rows(int32_t row0, int32_t S, int32_t hx, int32_t hdim, int3
  * by shape (the Infinity-Cache working-set rule, vqs_kernels.h resolve_tile_order).  Returns the resolved gm | ns << 8 (an
  * illegal ns falls back to 1) or a negative error. */
 int vqs_debug_tile_order(int32_t M, int32_t N, int32_t K, int32_t batch, int32_t gm, int32_t ns, int32_t grid, int32_t* out);
+/* Host-side test hook, no device access: the kernel family a vqs_gemm launch of this shape resolves to, by the launcher's own
+ * function (gemm.hip gemm_form): 10 = the quad form (four waves, 16x16x32 MFMAs; operand offsets relative to the output tile, no
+ * size limit), 3 = an 8-wave persistent kernel (32-bit byte offsets into a batch entry's operands), 0 = one tile per workgroup
+ * (64-bit pointers), -1 = not launchable.  Two properties the tests pin: the form of a bf16-result launch is a function of the
+ * epilogue and the WEIGHT's shape only, never of M (a pair's bits must not depend on its batch), and an operand of 4 GiB or more
+ * per batch entry never reaches a 32-bit kernel (it falls back to family 0 where that computes the same function, else -1). */
+int vqs_debug_gemm_form(int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t epilogue, int32_t batch, int32_t variant,
+                        int32_t S, int32_t inner, int32_t inner_kv);
 /* Tap window: taps copy only the rows of `count` consecutive outer entries starting at `first` -- pairs for the T5 stacks
  * (rows [first*S, (first+count)*S) of an [B*S, W] tensor, the same fraction of a head-major [B, H, S, 64] or a [B*T, W] one),
  * images for the vision tower (so the window's pairs must reference images first .. first+count-1 in order, as the bench

@@ -1608,26 +1608,44 @@ static int l2_touch_mode() {
 }
 
 // Which launches the quad form carries: a function of the epilogue and the WEIGHT's shape only (never of M).
-template <int EPI>
-static bool quad_eligible(const GemmParams& p) {
-    if constexpr (!(EPI == EPI_BF16 || EPI == EPI_BF16_QGELU || EPI == EPI_BF16_GELU || EPI == EPI_GATED || EPI == EPI_HEADS)) return false;
+static bool quad_eligible_rt(const GemmParams& p, int epi) {
+    if (!(epi == EPI_BF16 || epi == EPI_BF16_QGELU || epi == EPI_BF16_GELU || epi == EPI_GATED || epi == EPI_HEADS)) return false;
     if (p.batch > 1 || p.K < 2 * BK || p.rowss_in != nullptr) return false;
-    if constexpr (EPI == EPI_GATED) {
-        if ((p.N % 64) != 0) return false;
-    }
-    if constexpr (EPI == EPI_HEADS) {
+    if (epi == EPI_GATED && (p.N % 64) != 0) return false;
+    if (epi == EPI_HEADS) {
         // a wave's 128 columns must lie inside ONE of the q / k / v tensors (one head count per block); rows step by 4 within a sample
         const int ikv = p.inner_kv > 0 ? p.inner_kv : p.inner;
         if (p.S < 8 || (p.inner % 128) != 0 || (ikv % 128) != 0) return false;
     }
     return true;
 }
+template <int EPI>
+static bool quad_eligible(const GemmParams& p) { return quad_eligible_rt(p, EPI); }
+// Kernel family a launch resolves to (host arithmetic, shared with the test hook vqs_debug_gemm_form): 10 quad form, 0 one tile per
+// workgroup (64-bit pointers), 3 an 8-wave persistent / ping-pong kernel or a lab form (32-bit byte offsets into a batch entry's
+// operands), -1 not launchable.  The 32-bit forms refuse operands of 4 GiB or more per batch entry; a plain single-entry launch
+// then falls back to the one-tile-per-workgroup kernel (same bits), anything else is an error -- never a wrapped offset.
+int gemm_form(const GemmParams& p, int epilogue, int variant) {
+    if (epilogue == EPI_RESID_RMS) variant = variant == 5 ? 5 : 3;
+    const bool plain_v0 = !(p.hd > 64 || p.inner_kv > 0 || p.Hkv > 0 || p.gate_act != 0 || (epilogue == EPI_GATED && p.bias != nullptr) || p.rowss_in != nullptr) &&
+                          p.batch <= 1 && epilogue != EPI_RESID_RMS;
+    if (variant == 0 || variant == 2 || variant == 1) return plain_v0 ? 0 : -1;
+    if (epilogue == EPI_HEADS && p.S < 8) return plain_v0 ? 0 : -1;
+    if ((variant == 3 || variant == 10) && quad_eligible_rt(p, epilogue)) return 10;
+    if (epilogue == EPI_F32_RESID) return p.batch <= 1 ? 0 : -1;
+    const bool fit = (uint64_t)p.M * (uint64_t)p.lda * 2ull < (1ull << 32) && (uint64_t)p.N * (uint64_t)p.ldw * 2ull < (1ull << 32);
+    if (fit) return 3;
+    return plain_v0 ? 0 : -1;
+}
 
 template <int EPI>
-static hipError_t launch_epi(const GemmParams& p, int variant, hipStream_t stream) {
+static hipError_t launch_epi(const GemmParams& p, int variant, hipStream_t stream) {   // NOLINT(variant is resolved below)
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
     dim3 grid(tiles_m * tiles_n), block(512);
     // variant 11 = the 8-wave forms by the round-1/2 shape rule for every launch (A/B against the quad form; below it is variant 3)
+    const int form = gemm_form(p, EPI, variant);
+    if (form < 0) return hipErrorInvalidValue;
+    if (form == 0 && variant != 2 && variant != 1) variant = 0;      // incl. the fallback of a >= 4 GiB operand from the 32-bit forms
     if constexpr (EPI == EPI_RESID_RMS) {
         // only the persistent kernels carry this epilogue (LDS-staged, needs the cross-wave row reduction)
         const int nwg = tiles_m * tiles_n;
@@ -1646,7 +1664,7 @@ static hipError_t launch_epi(const GemmParams& p, int variant, hipStream_t strea
 #endif
     else if (variant == 2)
         hipLaunchKernelGGL((gemm_bf16_kernel<EPI, 2>), grid, block, 0, stream, p);
-    else if ((variant == 3 || variant == 10) && quad_eligible<EPI>(p)) {
+    else if (form == 10) {
         // quad form (gemm_quad.inc): every bf16-result launch of a call site, WHATEVER its M -- the form's k-order differs from the
         // 8-wave forms' in the last ulp, so a weight must not change form with the batch size (a pair's bits are batch-invariant)
         if constexpr (EPI == EPI_BF16 || EPI == EPI_BF16_QGELU || EPI == EPI_BF16_GELU || EPI == EPI_GATED || EPI == EPI_HEADS) {

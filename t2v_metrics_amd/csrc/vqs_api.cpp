@@ -375,6 +375,15 @@ int vqs_debug_tap_window(vqs_handle* h, int32_t first, int32_t count) {
     return VQS_OK;
 }
 
+int vqs_debug_gemm_form(int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t epilogue, int32_t batch, int32_t variant,
+                        int32_t S, int32_t inner, int32_t inner_kv) {
+    if (M <= 0 || N <= 0 || K <= 0 || epilogue < 0 || epilogue >= vqs::EPI_COUNT) return -1;
+    vqs::GemmParams p{};
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = N; p.batch = batch > 0 ? batch : 1;
+    p.S = S; p.inner = inner; p.inner_kv = inner_kv;
+    return vqs::gemm_form(p, epilogue, variant & 0xff);
+}
+
 int vqs_debug_heads_rows(int32_t row0, int32_t S, int32_t hx, int32_t hdim, int32_t n, int64_t* off_out) {
     if (row0 < 0 || S < 8 || hx <= 0 || hdim <= 0 || n <= 0 || !off_out) return VQS_ERR_INVALID;
     int hs;

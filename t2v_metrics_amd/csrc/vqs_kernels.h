@@ -156,6 +156,7 @@ inline void resolve_tile_order(GemmParams& p, int persistent_wgs) {
 
 
 // variant 0 = direct-to-LDS (global_load_lds) staging; variant 1 = register-staged (debug / A-B)
+int gemm_form(const GemmParams& p, int epilogue, int variant);   // kernel family a launch resolves to (gemm.hip), host arithmetic
 hipError_t launch_gemm(const GemmParams& p, int epilogue, int variant, hipStream_t stream);
 
 // ---------------------------------------------------------------- attention (attn.hip)

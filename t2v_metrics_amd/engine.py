@@ -72,6 +72,7 @@ _SIGNATURES = {
     "vqs_set_option": (_c_i32, [_c_vp, ctypes.c_char_p, _c_i32]),
     "vqs_debug_tap": (_c_i32, [_c_vp, ctypes.c_char_p, _c_vp, ctypes.c_size_t]),
     "vqs_debug_tap_window": (_c_i32, [_c_vp, _c_i32, _c_i32]),
+    "vqs_debug_gemm_form": (_c_i32, [_c_i32] * 11),
     "vqs_debug_heads_rows": (_c_i32, [_c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_vp]),
     "vqs_debug_tile_order": (_c_i32, [_c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_vp]),
     "vqs_relpos_bucket": (_c_i32, [_c_i32, _c_i32, _c_i32, _c_i32]),

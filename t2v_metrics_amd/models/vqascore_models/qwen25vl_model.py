@@ -75,14 +75,23 @@ def patchify(frames: torch.Tensor, patch: int = 14, merge: int = 2, temporal: in
     return x.reshape(t * h * w, C * temporal * patch * patch).contiguous(), (t, h, w)
 
 
-def read_repetition_penalty(checkpoint_dir: str) -> float:
-    """generation_config.json of the checkpoint directory (HF generate() applies it in greedy mode too); 1.0 if absent."""
+def read_generation_config(checkpoint_dir: str):
+    """(repetition_penalty, eos ids) from generation_config.json of the checkpoint directory: HF generate() applies the
+    penalty in greedy mode too and stops at ANY of generation_config.eos_token_id (an int or a list -- [<|im_end|>,
+    <|endoftext|>] for the Instruct checkpoints), not only at the tokenizer's eos.  (1.0, []) if the file is absent."""
     import json
     path = os.path.join(checkpoint_dir, "generation_config.json")
     if not os.path.isfile(path):
-        return 1.0
+        return 1.0, []
     with open(path) as f:
-        return float(json.load(f).get("repetition_penalty", 1.0))
+        g = json.load(f)
+    eos = g.get("eos_token_id", [])
+    eos = [int(eos)] if isinstance(eos, int) else [int(e) for e in (eos or [])]
+    return float(g.get("repetition_penalty", 1.0)), eos
+
+
+def read_repetition_penalty(checkpoint_dir: str) -> float:
+    return read_generation_config(checkpoint_dir)[0]
 
 
 def chat_prompt(question: str, placeholder: str) -> str:
@@ -118,6 +127,7 @@ class Qwen25VLModel(VQAScoreModel):
     def load_model(self):
         self.cfg = self._cfg
         self.repetition_penalty = 1.0
+        self._gen_eos_ids = []
         if self._tokenizer_arg is not None:
             self.tokenizer = self._tokenizer_arg
         else:
@@ -142,7 +152,7 @@ class Qwen25VLModel(VQAScoreModel):
                 raise FileNotFoundError(f"no checkpoint at {path} (no network here). Pass checkpoint=<local HF dir> or weights='seeded'.")
             from ...qwen.weights import load_qwen_checkpoint
             weights = load_qwen_checkpoint(path)           # accepts the published (legacy) and the in-memory key layout
-            self.repetition_penalty = read_repetition_penalty(path)
+            self.repetition_penalty, self._gen_eos_ids = read_generation_config(path)
         self.engine = QwenEngine(self.cfg, weights, device=dev)
 
     # ------------------------------------------------------------------ host-side preparation
@@ -227,7 +237,8 @@ class Qwen25VLModel(VQAScoreModel):
         if hasattr(self.engine, "lib"):
             from ... import engine as _eng
             x = scores if temperature == 1.0 else scores / temperature
-            lp, _ = _eng.score_head(x.unsqueeze(1).contiguous(), token_ids.to(scores.device).reshape(-1, 1))
+            with torch.cuda.device(scores.device):          # the kernel launches on the current device's stream
+                lp, _ = _eng.score_head(x.unsqueeze(1).contiguous(), token_ids.to(scores.device).reshape(-1, 1))
             return lp[:, 0].exp().float().cpu()
         p = torch.softmax(scores.float() / temperature, dim=-1)                 # engine doubles in the CPU tests
         return p[torch.arange(p.shape[0]), token_ids.to(p.device)].cpu()

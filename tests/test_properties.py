@@ -250,3 +250,36 @@ def test_gemm_tile_order_library_choice_by_shape(what, M, N, K, expect):
     out = np.empty((nwg, 4), dtype=np.int32)
     rc = lib.vqs_debug_tile_order(M, N, K, 1, 0, 0, 256, out.ctypes.data_as(ctypes.c_void_p))
     assert (rc & 0xff, rc >> 8) == expect, what
+
+
+# ---------------------------------------------------------------------------------------------- GEMM form resolution
+def _form(M, N, K, epi, batch=1, variant=3, lda=None, ldw=None, S=0, inner=0, inner_kv=0):
+    from t2v_metrics_amd import engine
+    return engine.load_library().vqs_debug_gemm_form(M, N, K, lda or K, ldw or K, epi, batch, variant, S, inner, inner_kv)
+
+
+@given(st.integers(1, 400000), st.sampled_from([(20480, 4096, 5), (4096, 10240, 0), (12288, 4096, 6), (4096, 1024, 1), (1024, 4096, 0),
+                                                (4096, 1024, 2), (3072, 1024, 6), (32128, 4096, 3), (2048, 64, 0)]))
+def test_gemm_form_depends_on_the_weight_never_on_the_row_count(M, shape):
+    """A pair's bits must not depend on the batch it is scored in (reference contract: independent cells, score.py:104-106):
+    the kernel family of a call site is a function of the epilogue and the weight's shape -- for every M the same."""
+    N, K, epi = shape
+    S, inner = (608, N // 3) if epi == 6 else (0, 0)
+    f = _form(M, N, K, epi, S=S, inner=inner)
+    assert f == _form(7, N, K, epi, S=S, inner=inner) == _form(155648, N, K, epi, S=S, inner=inner)
+    assert f == (10 if epi in (0, 1, 2, 5, 6) and K >= 128 else 3)
+
+
+def test_gemm_operands_of_4_gib_never_reach_a_32_bit_kernel():
+    """the 8-wave kernels address a batch entry's operands with 32-bit byte offsets; the XXL wo GEMM's A operand is
+    3.19 GB at 256 pairs and S = 608, 4.3 GB at 345 pairs.  The quad form has no such limit (tile-relative offsets, 64-bit
+    descriptor base); what still runs on the 8-wave kernels falls back to the one-tile-per-workgroup kernel or is refused."""
+    big_m = 400000                                          # x 10 240 x 2 B = 8.2 GB
+    assert _form(big_m, 4096, 10240, 0) == 10               # bf16 result: quad form, any size
+    assert _form(big_m, 4096, 10240, 0, variant=11) == 0    # the 8-wave rule: falls back to 64-bit pointers (same bits)
+    assert _form(big_m, 4096, 10240, 3) == 0                # fp32 result
+    assert _form(big_m, 4096, 10240, 3, batch=2) == -1      # batched entries exist in the 32-bit kernels only: refused, not wrapped
+    assert _form(big_m, 4096, 10240, 7) == -1               # fused residual + RMSNorm epilogue likewise
+    assert _form(155648, 4096, 10240, 3) == 3 and _form(155648, 4096, 10240, 3, batch=2) == 3     # 3.19 GB: fits
+    assert _form(209715, 4096, 10240, 3) == 3 and _form(209716, 4096, 10240, 3) == 0              # the boundary: M * lda * 2 < 2^32
+    assert _form(512, 32128, 4096, 3, lda=4096, ldw=4096 * 17) == 0                                  # a strided W operand counts with its stride

@@ -202,6 +202,23 @@ def test_multi_token_answers_processed_scores_and_eos_rule(tmp_path):
     tok.eos_token_id = g0
     with pytest.raises(ValueError, match="No content tokens"):
         m.forward([str(p)], ["a red cube"], max_new_tokens=1)
+    # ... and so is ANY id of generation_config.eos_token_id (HF generate stops at each of them), not only the tokenizer's eos
+    tok.eos_token_id = cfg.text.vocab - 1
+    assert g0 != tok.eos_token_id
+    m.forward([str(p)], ["a red cube"], max_new_tokens=1)
+    m._gen_eos_ids = [cfg.text.vocab - 2, g0]
+    with pytest.raises(ValueError, match="No content tokens"):
+        m.forward([str(p)], ["a red cube"], max_new_tokens=1)
+
+
+def test_generation_config_eos_ids_and_penalty_are_read_from_the_checkpoint_dir(tmp_path):
+    import json
+    from t2v_metrics_amd.models.vqascore_models.qwen25vl_model import read_generation_config
+    assert read_generation_config(str(tmp_path)) == (1.0, [])
+    (tmp_path / "generation_config.json").write_text(json.dumps({"eos_token_id": [151645, 151643], "repetition_penalty": 1.05, "do_sample": True}))
+    assert read_generation_config(str(tmp_path)) == (1.05, [151645, 151643])
+    (tmp_path / "generation_config.json").write_text(json.dumps({"eos_token_id": 151645}))
+    assert read_generation_config(str(tmp_path)) == (1.0, [151645])
 
 
 def default_q(text):

@@ -1,4 +1,4 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-.}"
 mkdir -p gpurun_out; rm -f gpurun_out/lab_call.jsonl
-timeout 300 python tools/lab_ring2.py quad16=t2v_metrics_amd/libvqs_hip.so order1=build/lab/libvqs_quad_order1.so --variant 3 --tol > gpurun_out/lab_quad.log 2>&1; echo "quad exit $?"; tail -16 gpurun_out/lab_quad.log | cut -c1-900
+timeout 300 python tools/lab_ring2.py quad16=t2v_metrics_amd/libvqs_hip.so --variant 3 --tol --all > gpurun_out/lab_quad.log 2>&1; echo "quad exit $?"; tail -16 gpurun_out/lab_quad.log | cut -c1-900
