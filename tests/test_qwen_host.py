@@ -202,13 +202,15 @@ def test_multi_token_answers_processed_scores_and_eos_rule(tmp_path):
     tok.eos_token_id = g0
     with pytest.raises(ValueError, match="No content tokens"):
         m.forward([str(p)], ["a red cube"], max_new_tokens=1)
-    # ... and so is ANY id of generation_config.eos_token_id (HF generate stops at each of them), not only the tokenizer's eos
+    # HF generate STOPS at any id of generation_config.eos_token_id, not only at the tokenizer's eos (the special-token rule above
+    # is the tokenizer's, as in the reference :239-244): with g0 among them a 2-token budget yields one score, and the answer is
+    # truncated to it (:258-262) exactly as with a 1-token budget
     tok.eos_token_id = cfg.text.vocab - 1
     assert g0 != tok.eos_token_id
-    m.forward([str(p)], ["a red cube"], max_new_tokens=1)
+    assert abs(m.forward([str(p)], ["a red cube"], answer_template=ans, max_new_tokens=2)[0].item() - s2[0].item()) <= 1e-7
     m._gen_eos_ids = [cfg.text.vocab - 2, g0]
-    with pytest.raises(ValueError, match="No content tokens"):
-        m.forward([str(p)], ["a red cube"], max_new_tokens=1)
+    stopped = m.forward([str(p)], ["a red cube"], answer_template=ans, max_new_tokens=2)
+    assert abs(stopped[0].item() - s1[0].item()) <= 1e-7 and abs(s1[0].item() - s2[0].item()) > 1e-6
 
 
 def test_generation_config_eos_ids_and_penalty_are_read_from_the_checkpoint_dir(tmp_path):
