@@ -10,7 +10,10 @@ meaningful -- wall time, per-stage time and fp32-vs-bf16 |delta| are.  Two drive
   reference semantics  Score.forward as written (score.py:104-106): per image, model.forward([img]*N, texts) -- the
                        image is decoded, preprocessed and encoded N times per row;
   this repo's API      t2v_metrics_amd.VQAScore(device='cpu', engine=HFEngine) -> forward_grid: unique images once.
-Runs only where /root/reference exists (the build container).  Output: profiles/r2_config1_cpu_xl_4x4.json"""
+Where /root/reference does not exist (the GPU box), the four images are seeded stand-ins of the SAME file formats and sizes
+(1024x1024 PNG, 256x256 JPEG, two 1024x1024 JPEGs) and the captions are the four README strings restated below, so that
+`run(...)` is callable from bench.py's cpu_baseline leg ("timed on the host cores of the same box").
+Output of the CLI: profiles/r3_config1_cpu_<model>_4x4.json"""
 import json
 import os
 import sys
@@ -30,7 +33,12 @@ from t2v_metrics_amd.config import get_config  # noqa: E402
 from t2v_metrics_amd.weights import make_seeded_weights  # noqa: E402
 
 IMAGES = ["DALLE3.png", "DeepFloyd.jpg", "Midjourney.jpg", "SDXL.jpg"]
+IMAGE_SIZES = [(1024, 1024), (256, 256), (1024, 1024), (1024, 1024)]      # of the reference's files, in that order
 README_LINES = (178, 179, 122, 123)
+CAPTIONS = ["The brown dog chases the black dog around the tree.",           # V_3.0_README.md:178,179,122,123
+            "Two cats sit at the window, the blue one intently watching the rain, the red one curled up asleep.",
+            "someone talks on the phone angrily while another person sits happily",
+            "someone talks on the phone happily while another person sits angrily"]
 
 
 class WordHashTokenizer:
@@ -48,6 +56,8 @@ class WordHashTokenizer:
 
 
 def readme_captions():
+    if not os.path.exists("/root/reference/V_3.0_README.md"):
+        return list(CAPTIONS)
     lines = open("/root/reference/V_3.0_README.md").read().splitlines()
     caps = []
     import re
@@ -56,17 +66,35 @@ def readme_captions():
     return caps
 
 
-def main():
-    model = sys.argv[1] if len(sys.argv) > 1 else "clip-flant5-xl"
-    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+def image_paths():
+    """the reference's four images where they exist; else seeded stand-ins of the same formats and sizes in a temp directory"""
+    real = [os.path.join("/root/reference/images/0", f) for f in IMAGES]
+    if all(os.path.exists(p) for p in real):
+        return real, "the reference's images/0"
+    import tempfile
+    import numpy as np
+    from PIL import Image
+    tmp = tempfile.mkdtemp(prefix="vqs_config0_")
+    out = []
+    rng = np.random.RandomState(0)
+    for name, (w_, h_) in zip(IMAGES, IMAGE_SIZES):
+        small = rng.randint(0, 256, (h_ // 16, w_ // 16, 3), dtype=np.uint8)
+        im = Image.fromarray(small).resize((w_, h_), Image.BICUBIC)
+        p = os.path.join(tmp, name)
+        im.save(p)
+        out.append(p)
+    return out, "seeded stand-ins of the reference's image formats and sizes (/root/reference is absent on this box)"
+
+
+def run(model="clip-flant5-xl", reps=3, dtypes=(torch.bfloat16, torch.float32), weights=None, verbose=True):
     cfg = get_config(model)
-    paths = [os.path.join("/root/reference/images/0", f) for f in IMAGES]
+    paths, image_note = image_paths()
     texts = readme_captions()
     t0 = time.perf_counter()
-    w = make_seeded_weights(cfg, seed=0, device="cpu")
+    w = weights if weights is not None else make_seeded_weights(cfg, seed=0, device="cpu")
     t_w = time.perf_counter() - t0
     tok = WordHashTokenizer(cfg.t5.vocab)
-    out = {"config": "BASELINE.json configs[0]: %s on CPU, 4 images x 4 prompts (16 pairs)" % model, "images": paths, "texts": texts,
+    out = {"config": "BASELINE.json configs[0]: %s on CPU, 4 images x 4 prompts (16 pairs)" % model, "images": image_note, "texts": texts,
            "nproc": os.cpu_count(), "torch_threads": torch.get_num_threads(), "torch": torch.__version__,
            "cpu_model": [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0],
            "weights": f"seeded random, bf16, generated in {t_w:.0f} s", "tokenizer": "word-hash stand-in (no spiece.model offline)", "runs": {}}
@@ -74,7 +102,7 @@ def main():
     out["transformers"] = transformers.__version__
     scores = {}
     for dtype, tag in ((torch.bfloat16, "bf16 (reference as shipped)"), (torch.float32, "fp32 (same weights, fp32 arithmetic)")):
-        if dtype == torch.float32 and model.endswith("xxl"):
+        if dtype not in dtypes or (dtype == torch.float32 and model.endswith("xxl")):
             continue
         eng = HFEngine(cfg, w, dtype)
         scorer = t2v.VQAScore(model="clip-flant5-xl", device="cpu", cache_dir="/tmp/none", config=cfg, tokenizer=tok, engine=eng)
@@ -117,12 +145,20 @@ def main():
         run["max_rel_diff_grid_vs_row_loop"] = float(((grid.cpu() - grid_ref).abs() / grid_ref).max())
         scores[tag] = grid.cpu()
         out["runs"][tag] = run
-        print(tag, json.dumps(run)[:400], flush=True)
+        if verbose:
+            print(tag, json.dumps(run)[:400], flush=True)
         del eng, scorer
     if len(scores) == 2:
         a, b = scores["bf16 (reference as shipped)"], scores["fp32 (same weights, fp32 arithmetic)"]
         out["bf16_vs_fp32_max_abs_dlog_score"] = float((a.log() - b.log()).abs().max())
-    dst = os.path.join(ROOT, "profiles", "r2_config1_cpu_%s_4x4.json" % model.replace("clip-flant5-", ""))
+    return out
+
+
+def main():
+    model = sys.argv[1] if len(sys.argv) > 1 else "clip-flant5-xl"
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    out = run(model, reps)
+    dst = os.path.join(ROOT, "profiles", "r3_config1_cpu_%s_4x4.json" % model.replace("clip-flant5-", ""))
     with open(dst, "w") as f:
         json.dump(out, f, indent=1)
     print("wrote", dst)

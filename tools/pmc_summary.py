@@ -41,6 +41,13 @@ if cnt["FETCH_SIZE"] and cnt["WRITE_SIZE"]:
            "kernels": "vqs::gemm_bf16_* (all GEMM launches of the run)", "launches_per_pass": cnt["FETCH_SIZE"],
            "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write, "traffic_bytes_per_launch": fetch + write,
            "corrections": "FETCH_SIZE KiB x 1024 x 2 (gfx950 128-B requests tallied at 64 B); WRITE_SIZE KiB x 1024 as reported"}
+    try:                                    # stamp with the kernel sources the counters were taken on (bench.py checks it)
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        out["csrc_sha256_16"] = bench.csrc_hash()
+    except Exception as e:
+        out["csrc_sha256_16"] = None
+        print("no source stamp:", e)
     with open(os.path.join(d, "gemm_traffic.json"), "w") as f:
         json.dump(out, f, indent=1)
     print("gemm traffic per launch: fetch %.1f MB + write %.1f MB" % (fetch / 1e6, write / 1e6))
