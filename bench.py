@@ -286,9 +286,27 @@ def main():
         device = torch.device("cuda", dev_index)
         coll_device = device if backend == "nccl" else torch.device("cpu")
     dist = None
-    if world > 1:
+    # VQS_BENCH_FORCE_DIST=1: take the multi-rank branch with ONE rank -- init_process_group("nccl", device_id=...), the device-side
+    # all_gather / all_reduce / barrier and destroy_process_group run on a single MI355X (tests/test_gpu_rccl_single_rank.py); the
+    # 1/2/4/8-GPU curve itself is the driver's to measure.
+    force_dist = os.environ.get("VQS_BENCH_FORCE_DIST") == "1" and not double
+    if world > 1 or force_dist:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+        # one rank per GPU: keep the rank's host threads on the cores next to its device (first touch of pinned buffers, the image
+        # thread pool): cores are split evenly by local rank unless the launcher already restricted the affinity
+        try:
+            cores = sorted(os.sched_getaffinity(0))
+            nloc = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+            if nloc > 1 and len(cores) >= 2 * nloc and os.environ.get("VQS_BENCH_NO_AFFINITY") != "1":
+                per = len(cores) // nloc
+                os.sched_setaffinity(0, cores[local_rank * per:(local_rank + 1) * per])
+        except (AttributeError, OSError):
+            pass
         if backend == "nccl":
             dist_mod.init_process_group(backend="nccl", device_id=device)
         else:
@@ -407,6 +425,7 @@ def main():
                    "parallelism": f"replica x{world} (pairs sharded, RCCL all_gather of scores)",
                    **({"options": args.opt} if args.opt else {})},
         "ranks_seen": ranks_seen,
+        "collective": (backend + (" (RCCL over xGMI)" if backend == "nccl" else "")) if dist is not None else None,
         "per_rank_pairs_per_s": per_rank_list,
         "scores_checksum": float(final.double().sum().item()),
         # FLOPs of the REFERENCE algorithm (SURVEY.md §8d formula).  The engine's reassociated decoder
