@@ -237,7 +237,7 @@ def parse_args(argv=None):
                     "xl,genai1600,qwen,pipeline,config0; auto = all of them for the default single-GPU XXL run, none otherwise; none = off")
     ap.add_argument("--buckets", type=int, default=0, help="genai1600: time only this many length buckets, evenly spaced over the sorted workload (0 = all 38)")
     ap.add_argument("--cpu-emulation", action="store_true", help="also run the rounding-matched CPU oracle on pair 0 (~40 s at XXL)")
-    ap.add_argument("--cpu-reps", type=int, default=2, help="timed repetitions of the CPU reference (after 1 warm-up)")
+    ap.add_argument("--cpu-reps", type=int, default=1, help="timed repetitions of the CPU reference (after 1 warm-up; a 4-pair XXL pass is ~45 s)")
     ap.add_argument("--ragged", action="store_true", help="one batch of variable-length prompts, padded + masked (no bucketing)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="execution-form option of include/vqs.h vqs_set_option (e.g. gemm_variant=6, tile_order:20480x4096=520); "
@@ -465,26 +465,34 @@ def main():
     legs = [] if args.also == "none" else ([k for k in ("xl", "genai1600", "qwen", "pipeline", "config0")] if args.also == "auto" else args.also.split(","))
     if args.also == "auto" and not default_run:
         legs = []
-    also, leg_thread = {}, None
+    also, config0 = {}, None
     if rank == 0 and world == 1 and not double and legs:
+        # Order matters for what each leg measures: the XL and GenAI legs are GPU-bound (a few hundred launches per step) and run in
+        # their own processes WHILE the host cores time configs[0]; the Qwen leg (launch-bound on the host: 37.6 instead of 66 videos/s
+        # next to a 128-thread CPU job, profiles/r3_call17_*) and the PNG pipeline (uses the host cores itself) run alone; the CPU
+        # reference of the cpu_baseline leg runs last, alone.
         import threading
-        gpu_legs = [k for k in legs if k in ("xl", "genai1600", "qwen")]
+        phase_a = [k for k in legs if k in ("xl", "genai1600")]
 
-        def run_gpu_legs():                                 # the GPU-only legs run while the host cores time the CPU reference
-            for k in gpu_legs:
+        def run_phase_a():
+            for k in phase_a:
                 also[k] = run_also_leg(k)
-        leg_thread = threading.Thread(target=run_gpu_legs)
-        leg_thread.start()
+        th = threading.Thread(target=run_phase_a)
+        th.start()
+        if "config0" in legs and args.cpu_pairs > 0:
+            config0 = run_config0()
+        th.join()
+        for k in ("qwen", "pipeline"):
+            if k in legs:
+                also[k] = run_also_leg(k)
 
     failed = None
     if rank == 0 and world == 1 and args.cpu_pairs > 0 and not double and jobs:
         out["cpu_baseline"] = cpu_baseline(cfg, weights, jobs[-1], min(args.cpu_pairs, jobs[-1][2].shape[0]), lp, args.cpu_reps,
-                                           args.cpu_emulation, with_config0="config0" in legs)
+                                           args.cpu_emulation)
+        if config0 is not None:
+            out["cpu_baseline"]["config0"] = config0
         failed = out["cpu_baseline"]["dlogp"].get("violation")
-    if leg_thread is not None:
-        leg_thread.join()
-    if rank == 0 and world == 1 and not double and "pipeline" in legs:
-        also["pipeline"] = run_also_leg("pipeline")         # uses the host cores itself: after the CPU reference
     if also:
         out["also"] = also
 
@@ -497,14 +505,30 @@ def main():
         sys.exit(3)
 
 
-def cpu_baseline(cfg, weights, job, n_pairs, lp_gpu, reps, with_emulation=False, with_config0=False):
+def run_config0():
+    """BASELINE configs[0] on THIS box's host cores: clip-flant5-xl, 4 images x 4 prompts, the reference's row loop (score.py:104-106:
+    N-fold image work per row), HF modules in bf16 as mm_utils.py:228 casts them; one pass (a pass is ~60 s on 128 threads of the GPU
+    box's 2 x EPYC 9575F -- slower than the 8-vCPU build container's 15.6 s: oneDNN's bf16 kernels do not scale over the sockets)."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import config1_cpu
+        t0 = time.perf_counter()
+        c0 = config1_cpu.run("clip-flant5-xl", reps=0, dtypes=(torch.bfloat16,), verbose=False, api_pass=False)
+        r = c0["runs"]["bf16 (reference as shipped)"]["reference_semantics"]
+        return {"what": c0["config"] + "; HF modules in bf16 on this box's host cores, one cold pass; images: " + c0["images"],
+                "value": r["pairs_per_s"], "unit": "pairs/s", "wall_s": r["wall_s_median_after_warmup"], "stages_s": r["stages_last_rep"],
+                "cores": c0["torch_threads"], "host_cpus": c0["nproc"], "wall_s_incl_weights": round(time.perf_counter() - t0, 1)}
+    except Exception as e:                                  # noqa: BLE001 -- reported, not raised
+        return {"error": repr(e)[:300]}
+
+
+def cpu_baseline(cfg, weights, job, n_pairs, lp_gpu, reps, with_emulation=False):
     """The reference's arithmetic on the host cores: HF modules cast to bf16 as mm_utils.py:228 does,
     inference mode, all cores, 1 warm-up + `reps` timed repetitions on the first n_pairs pairs (one batch) of the batch the
     GPU scored last; beside it the fp32 port (oracle/clip_t5_oracle.py) on the same pairs = fp32 truth, and the per-pair
     |delta log P| table: HIP vs truth, reference-as-shipped vs truth, HIP vs reference-as-shipped.  `violation` is set (and
     bench.py exits non-zero after printing its line) when the HIP path is not at least as close to fp32 truth as the reference's
-    own bf16 path on this sample, or leaves the end-to-end bound the GPU tests assert (2.5e-2).  with_config0: BASELINE
-    configs[0] (clip-flant5-xl, 4 images x 4 prompts, the reference's row loop) timed on THIS box's host cores too."""
+    own bf16 path on this sample, or leaves the end-to-end bound the GPU tests assert (2.5e-2)."""
     import warnings
     warnings.filterwarnings("ignore")
     from oracle.clip_t5_oracle import Oracle
@@ -569,21 +593,6 @@ def cpu_baseline(cfg, weights, job, n_pairs, lp_gpu, reps, with_emulation=False,
                      "violation": violation},
            "max_abs_dlogp_hip_vs_oracle": float(hip_pair.max())}
     del w_cpu
-    if with_config0:
-        try:
-            sys.path.insert(0, os.path.join(ROOT, "tools"))
-            import config1_cpu
-            t0 = time.perf_counter()
-            c0 = config1_cpu.run("clip-flant5-xl", reps=1, dtypes=(torch.bfloat16,), verbose=False)
-            r = c0["runs"]["bf16 (reference as shipped)"]
-            out["config0"] = {"what": c0["config"] + "; HF modules in bf16 on this box's host cores; images: " + c0["images"],
-                              "reference_semantics_pairs_per_s": r["reference_semantics"]["pairs_per_s"],
-                              "reference_semantics_wall_s": r["reference_semantics"]["wall_s_median_after_warmup"],
-                              "reference_semantics_stages_s": r["reference_semantics"]["stages_last_rep"],
-                              "this_repo_api_pairs_per_s": r["this_repo_api_forward_grid"]["pairs_per_s"],
-                              "cores": c0["torch_threads"], "wall_s_incl_weights": round(time.perf_counter() - t0, 1)}
-        except Exception as e:                              # noqa: BLE001 -- reported, not raised
-            out["config0"] = {"error": repr(e)[:300]}
     return out
 
 
