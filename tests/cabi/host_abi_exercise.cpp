@@ -24,6 +24,10 @@ int main() {
     assert(strlen(vqs_last_error(h)) > 0);
     int dummy = 0;
     assert(vqs_debug_tap(h, "enc.3.xn0", &dummy, 4) == 0 && vqs_debug_tap(h, "enc.3.xn0", nullptr, 0) == 0 && vqs_debug_tap(h, nullptr, nullptr, 0) == 0);
+    assert(vqs_debug_tap_window(h, 3, 2) == 0 && vqs_debug_tap_window(h, 0, 0) == 0 && vqs_debug_tap_window(h, -1, 2) != 0);
+    // GEMM form resolution (host arithmetic): the quad form for bf16 results whatever M, the 32-bit kernels refuse >= 4 GiB operands
+    assert(vqs_debug_gemm_form(155648, 20480, 4096, 4096, 4096, 5, 1, 3, 0, 0, 0) == 10 && vqs_debug_gemm_form(2, 20480, 4096, 4096, 4096, 5, 1, 3, 0, 0, 0) == 10);
+    assert(vqs_debug_gemm_form(400000, 4096, 10240, 10240, 10240, 3, 1, 3, 0, 0, 0) == 0 && vqs_debug_gemm_form(400000, 4096, 10240, 10240, 10240, 3, 2, 3, 0, 0, 0) == -1);
     int64_t ld = 0;
     assert(vqs_workspace_offset(h, "logits", 4, 33, 2, &ld) >= 0 && ld == 32128);
     assert(vqs_workspace_offset(h, "dec_out", 4, 33, 2, &ld) >= 0 && vqs_workspace_offset(h, "nope", 4, 33, 2, &ld) < 0);
@@ -47,7 +51,7 @@ int main() {
     assert(vqs_set_option(h, "nt_store:4096x10240", 1) == 0 && vqs_set_option(h, "nt_store:4096x10240", 2) == 0 && vqs_set_option(h, "nt_store:4096x10240", 0) == 0);
     assert(vqs_set_option(h, "nt_store:4096x10240", 3) != 0 && vqs_set_option(h, "nt_store:x", 1) != 0);
     assert(vqs_set_option(h, "l2_touch:12288x4096", 1) == 0 && vqs_set_option(h, "l2_touch:12288x4096", 0) == 0 && vqs_set_option(h, "l2_touch:12288x4096", 5) != 0);
-    assert(vqs_set_option(h, "gemm_variant", 6) == 0 && vqs_set_option(h, "gemm_variant", 3) == 0 && vqs_set_option(h, "gemm_variant", 8) != 0);
+    assert(vqs_set_option(h, "gemm_variant", 11) == 0 && vqs_set_option(h, "gemm_variant", 3) == 0 && vqs_set_option(h, "gemm_variant", 6) != 0 && vqs_set_option(h, "gemm_variant", 8) != 0);
     {
         const int M = 155648, N = 20480, nwg = (M / 256) * (N / 256);
         std::vector<int32_t> tiles(4 * (size_t)nwg);
