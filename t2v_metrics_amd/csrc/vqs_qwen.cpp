@@ -49,6 +49,9 @@ struct vqs_qwen_handle {
     std::vector<hipEvent_t> ev;
     size_t ev_used = 0;
     double prof_flops = 0.0, prof_bytes = 0.0;
+    // stage taps (vqs_qwen_debug_tap): point name -> (caller buffer, capacity); a pass copies the named intermediate there
+    struct Tap { void* dst; size_t cap; };
+    std::unordered_map<std::string, Tap> taps;
 };
 
 namespace {
@@ -68,6 +71,20 @@ int qfail(vqs_qwen_handle* h, int code, const std::string& msg) {
         int _r = (expr);             \
         if (_r != VQS_OK) return _r; \
     } while (0)
+
+// Copy an intermediate to a caller buffer registered with vqs_qwen_debug_tap (in-stream, device to device): the workspace buffers
+// are reused block after block, so this is how tests/test_gpu_qwen.py checks EVERY launch of a pass against the rounding-matched
+// oracle on the engine's own inputs.  One empty() test when nothing is registered.
+int qtap(vqs_qwen_handle* h, const char* stack, int layer, const char* what, const void* src, size_t bytes, hipStream_t st) {
+    if (h->taps.empty()) return VQS_OK;
+    const std::string name = layer >= 0 ? std::string(stack) + "." + std::to_string(layer) + "." + what : std::string(stack) + "." + what;
+    auto it = h->taps.find(name);
+    if (it == h->taps.end()) return VQS_OK;
+    if (it->second.cap < bytes) return qfail(h, VQS_ERR_WORKSPACE, "tap " + name + ": buffer too small (" + std::to_string(bytes) + " bytes needed)");
+    QHIP(h, hipMemcpyAsync(it->second.dst, src, bytes, hipMemcpyDeviceToDevice, st), "tap copy");
+    return VQS_OK;
+}
+#define QTAP(stack, layer, what, ptr, elems) QRUN(qtap(h, stack, layer, what, ptr, (size_t)(elems) * sizeof(*(ptr)), st))
 
 int get_w(vqs_qwen_handle* h, const std::string& name, int64_t numel, const bf16_t** out) {
     auto it = h->w.find(name);
@@ -366,6 +383,14 @@ int vqs_qwen_profile_read(vqs_qwen_handle* h, double* gemm_ms, double* gemm_flop
     return n;
 }
 
+int vqs_qwen_debug_tap(vqs_qwen_handle* h, const char* name, void* d_dst, size_t bytes) {
+    if (!h) return VQS_ERR_INVALID;
+    if (!name) { h->taps.clear(); return VQS_OK; }
+    if (!d_dst || bytes == 0) { h->taps.erase(name); return VQS_OK; }
+    h->taps[name] = vqs_qwen_handle::Tap{d_dst, bytes};
+    return VQS_OK;
+}
+
 const char* vqs_qwen_last_error(const vqs_qwen_handle* h) { return h ? h->err.c_str() : "null handle"; }
 
 size_t vqs_qwen_packed_bytes(const vqs_qwen_handle* h) {
@@ -446,6 +471,7 @@ int vqs_qwen_encode_vision(vqs_qwen_handle* h, const void* d_patches, int32_t N,
         g.M = N; g.N = VH; g.K = h->v_kpatch; g.lda = h->v_kpatch; g.ldw = h->v_kpatch; g.ldc = VH; g.epi = vqs::EPI_F32;
         QRUN(qgemm(h, g, st, "patch embed"));
     }
+    QTAP("vis", -1, "pre", w.pre, (size_t)N * VH);
     QHIP(h, vqs::launch_gather_rows_f32(w.pre, d_row_map, w.hidden, Np, VH, st), "window permutation");
     QHIP(h, hipMemsetAsync(w.ff, 0, (size_t)Np * h->v_ffld * sizeof(bf16_t), st), "clear ff padding");
 
@@ -461,6 +487,8 @@ int vqs_qwen_encode_vision(vqs_qwen_handle* h, const void* d_patches, int32_t N,
         // deferred store: norm2 normalises hidden + attention delta without writing the stream; the next norm1 (or the
         // merger norm) stores (hidden + attention delta) + mlp delta -- same fp32 sums, 22 instead of 24 B per element
         QHIP(h, vqs::launch_rmsnorm(w.hidden, pend_attn ? pend_attn : pend, n1, w.xn, Np, VH, c.v_eps, st, pend_attn ? pend : nullptr), "vision norm1");
+        QTAP("vis", i, "h", w.hidden, (size_t)Np * VH);          // the fp32 stream this block starts from (norm1 stored it)
+        QTAP("vis", i, "xn0", w.xn, (size_t)Np * VH);
         // window blocks run on the padded windowed layout (every window = win_len slots, d_win_valid of them real);
         // full-attention blocks on a frame-compact copy (original patch order), scattered back afterwards
         const bf16_t* xin = w.xn;
@@ -480,11 +508,15 @@ int vqs_qwen_encode_vision(vqs_qwen_handle* h, const void* d_patches, int32_t N,
         }
         QHIP(h, vqs::launch_rope(w.q, full ? d_cos_f : d_cos_w, full ? d_sin_f : d_sin_w, Bseg, VNH, S, HDP, h->v_hd / 2, st), "vision rope q");
         QHIP(h, vqs::launch_rope(w.k, full ? d_cos_f : d_cos_w, full ? d_sin_f : d_sin_w, Bseg, VNH, S, HDP, h->v_hd / 2, st), "vision rope k");
+        QTAP("vis", i, "q", w.q, (size_t)rows * VPK);            // after the rotary embedding, head-major [Bseg, heads, S, 128]
+        QTAP("vis", i, "k", w.k, (size_t)rows * VPK);
+        QTAP("vis", i, "v", w.v, (size_t)rows * VPK);
         {
             vqs::AttnParams a{w.q, w.k, w.v, w.attn, nullptr, full ? nullptr : d_win_valid, Bseg, VNH, S, scale};
             a.hd = HDP;
             QHIP(h, vqs::launch_attention(a, st), "vision attention");
         }
+        QTAP("vis", i, "attn", w.attn, (size_t)rows * VPK);
         {
             GCall g{w.attn, h->v_proj_w[i], full ? (void*)w.dc : (void*)w.delta};
             g.bias = pb;
@@ -493,7 +525,9 @@ int vqs_qwen_encode_vision(vqs_qwen_handle* h, const void* d_patches, int32_t N,
         }
         if (full)
             QHIP(h, vqs::launch_gather_rows_bf16(w.dc, nullptr, d_row_map, w.delta, Np, VH, VH, VH, st), "scatter frame rows back");
+        QTAP("vis", i, "d_attn", w.delta, (size_t)Np * VH);
         QHIP(h, vqs::launch_rmsnorm(w.hidden, w.delta, n2, w.xn, Np, VH, c.v_eps, st, nullptr, false), "vision norm2");
+        QTAP("vis", i, "xn1", w.xn, (size_t)Np * VH);
         pend_attn = w.delta;
         {
             GCall g{w.xn, h->v_gu_w[i], w.ff};
@@ -501,6 +535,7 @@ int vqs_qwen_encode_vision(vqs_qwen_handle* h, const void* d_patches, int32_t N,
             g.M = Np; g.N = 2 * h->v_mlp_p; g.K = VH; g.lda = VH; g.ldw = VH; g.ldc = h->v_ffld; g.epi = vqs::EPI_GATED; g.gate_act = 1;
             QRUN(qgemm(h, g, st, "vision gate|up"));
         }
+        QTAP("vis", i, "ff", w.ff, (size_t)Np * h->v_ffld);
         {
             GCall g{w.ff, h->v_down_w[i], w.delta2};
             g.bias = db;
@@ -508,6 +543,7 @@ int vqs_qwen_encode_vision(vqs_qwen_handle* h, const void* d_patches, int32_t N,
             QRUN(qgemm(h, g, st, "vision down"));
             pend = w.delta2;
         }
+        QTAP("vis", i, "d_mlp", w.delta2, (size_t)Np * VH);
     }
     // merger: RMSNorm, the 4 patches of a cell (consecutive rows in the windowed layout) concatenated, Linear-GELU-Linear,
     // then original cell order (padding cells are simply never gathered)
@@ -518,6 +554,8 @@ int vqs_qwen_encode_vision(vqs_qwen_handle* h, const void* d_patches, int32_t N,
     QW(m2b, "model.visual.merger.mlp.2.bias", c.v_out_hidden);
     const int NCp = Np / c.v_merge_unit;
     QHIP(h, vqs::launch_rmsnorm(w.hidden, pend_attn ? pend_attn : pend, lnq, w.xn, Np, VH, 1e-6f, st, pend_attn ? pend : nullptr), "merger norm");
+    QTAP("vis", -1, "h_out", w.hidden, (size_t)Np * VH);
+    QTAP("vis", -1, "xnm", w.xn, (size_t)Np * VH);
     {
         GCall g{w.xn, m0w, w.mid};
         g.bias = m0b;
@@ -525,6 +563,7 @@ int vqs_qwen_encode_vision(vqs_qwen_handle* h, const void* d_patches, int32_t N,
         g.epi = vqs::EPI_BF16_GELU;
         QRUN(qgemm(h, g, st, "merger mlp.0"));
     }
+    QTAP("vis", -1, "mid", w.mid, (size_t)NCp * h->merge_hidden);
     {
         GCall g{w.mid, m2w, w.merged_w};
         g.bias = m2b;
@@ -532,6 +571,7 @@ int vqs_qwen_encode_vision(vqs_qwen_handle* h, const void* d_patches, int32_t N,
         g.epi = vqs::EPI_BF16;
         QRUN(qgemm(h, g, st, "merger mlp.2"));
     }
+    QTAP("vis", -1, "merged_w", w.merged_w, (size_t)NCp * c.v_out_hidden);
     QHIP(h, vqs::launch_gather_rows_bf16(w.merged_w, nullptr, d_cell_inv, (bf16_t*)d_merged, NC, c.v_out_hidden, c.v_out_hidden,
                                           c.v_out_hidden, st), "undo window permutation");
     return VQS_OK;
@@ -559,6 +599,7 @@ int vqs_qwen_score(vqs_qwen_handle* h, const void* d_merged, const int32_t* d_in
     QW(embed, "model.language_model.embed_tokens.weight", (int64_t)c.t_vocab * TH);
     QHIP(h, vqs::launch_qwen_embed(d_input_ids, d_vis_slot, embed, (const bf16_t*)d_merged, w.hidden, M, TH, c.t_vocab, st), "embed + splice");
     QHIP(h, hipMemsetAsync(w.ff, 0, (size_t)M * h->t_ffld * sizeof(bf16_t), st), "clear ff padding");
+    QTAP("txt", -1, "emb", w.hidden, (size_t)M * TH);
 
     const bf16_t* pend = nullptr;
     const bf16_t* pend_attn = nullptr;   // attention delta the fp32 stream has not absorbed yet
@@ -567,6 +608,8 @@ int vqs_qwen_score(vqs_qwen_handle* h, const void* d_merged, const int32_t* d_in
         QW(ln1, p + "input_layernorm.weight", TH);
         QW(ln2, p + "post_attention_layernorm.weight", TH);
         QHIP(h, vqs::launch_rmsnorm(w.hidden, pend_attn ? pend_attn : pend, ln1, w.xn, M, TH, c.t_eps, st, pend_attn ? pend : nullptr), "input_layernorm");
+        QTAP("txt", i, "h", w.hidden, (size_t)M * TH);            // the fp32 stream this layer starts from (input_layernorm stored it)
+        QTAP("txt", i, "xn0", w.xn, (size_t)M * TH);
         {
             GCall g{w.xn, h->t_qkv_w[i], nullptr};
             g.bias = h->t_qkv_b[i];
@@ -577,33 +620,43 @@ int vqs_qwen_score(vqs_qwen_handle* h, const void* d_merged, const int32_t* d_in
         }
         QHIP(h, vqs::launch_rope(w.q, d_cos, d_sin, B, c.t_heads, L, HDP, h->t_hd / 2, st), "rope q");
         QHIP(h, vqs::launch_rope(w.k, d_cos, d_sin, B, c.t_kv_heads, L, HDP, h->t_hd / 2, st), "rope k");
+        QTAP("txt", i, "q", w.q, (size_t)M * IQ);                 // after the rotary embedding, head-major [B, heads, L, 128]
+        QTAP("txt", i, "k", w.k, (size_t)M * IKV);
+        QTAP("txt", i, "v", w.v, (size_t)M * IKV);
         {
             vqs::AttnParams a{w.q, w.k, w.v, w.attn, nullptr, d_seq_len, B, c.t_heads, L, scale};
             a.hd = HDP; a.Hkv = c.t_kv_heads; a.causal = 1;
             QHIP(h, vqs::launch_attention(a, st), "attention");
         }
+        QTAP("txt", i, "attn", w.attn, (size_t)M * IQ);
         {
             GCall g{w.attn, h->t_o_w[i], w.delta};
             g.M = M; g.N = TH; g.K = IQ; g.lda = IQ; g.ldw = IQ; g.ldc = TH; g.epi = vqs::EPI_BF16;
             QRUN(qgemm(h, g, st, "o_proj"));
         }
+        QTAP("txt", i, "d_attn", w.delta, (size_t)M * TH);
         QHIP(h, vqs::launch_rmsnorm(w.hidden, w.delta, ln2, w.xn, M, TH, c.t_eps, st, nullptr, false), "post_attention_layernorm");
+        QTAP("txt", i, "xn1", w.xn, (size_t)M * TH);
         pend_attn = w.delta;
         {
             GCall g{w.xn, h->t_gu_w[i], w.ff};
             g.M = M; g.N = 2 * h->t_mlp_p; g.K = TH; g.lda = TH; g.ldw = TH; g.ldc = h->t_ffld; g.epi = vqs::EPI_GATED; g.gate_act = 1;
             QRUN(qgemm(h, g, st, "gate|up"));
         }
+        QTAP("txt", i, "ff", w.ff, (size_t)M * h->t_ffld);
         {
             GCall g{w.ff, h->t_down_w[i], w.delta2};
             g.M = M; g.N = TH; g.K = h->t_ffld; g.lda = h->t_ffld; g.ldw = h->t_ffld; g.ldc = TH; g.epi = vqs::EPI_BF16;
             QRUN(qgemm(h, g, st, "down_proj"));
             pend = w.delta2;
         }
+        QTAP("txt", i, "d_mlp", w.delta2, (size_t)M * TH);
     }
     QW(fin, "model.language_model.norm.weight", TH);
     QW(head, "lm_head.weight", (int64_t)c.t_vocab * TH);
     QHIP(h, vqs::launch_rmsnorm(w.hidden, pend_attn ? pend_attn : pend, fin, w.xn, M, TH, c.t_eps, st, pend_attn ? pend : nullptr), "final norm");
+    QTAP("txt", -1, "h_out", w.hidden, (size_t)M * TH);
+    QTAP("txt", -1, "xnf", w.xn, (size_t)M * TH);
     QHIP(h, vqs::launch_gather_rows_bf16(w.xn, nullptr, d_last_row, w.last, B, TH, TH, TH, st), "last positions");
     {
         GCall g{w.last, head, d_logits};

@@ -31,6 +31,7 @@ _SIGS = {
     "vqs_qwen_score_workspace_bytes": (_sz, [_vp, _i32, _i32]),
     "vqs_qwen_profile_enable": (_i32, [_vp, _i32]),
     "vqs_qwen_profile_read": (_i32, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), _i32]),
+    "vqs_qwen_debug_tap": (_i32, [_vp, ctypes.c_char_p, _vp, _sz]),
     "vqs_qwen_score": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _sz, _vp]),
 }
 
@@ -112,6 +113,14 @@ class QwenEngine:
                                                 t["sin"].data_ptr(), B, L, logits.data_ptr(), ws.data_ptr(), ws.numel(),
                                                 _stream_ptr()), "vqs_qwen_score")
             return logits
+
+    def tap(self, name, dst: torch.Tensor = None):
+        """Register `dst` (device tensor, kept alive by the caller) for the named intermediate of the next passes
+        (vqs_qwen_debug_tap); name None clears all taps."""
+        if name is None:
+            self._check(self.lib.vqs_qwen_debug_tap(self._h, None, None, 0), "vqs_qwen_debug_tap")
+            return
+        self._check(self.lib.vqs_qwen_debug_tap(self._h, name.encode(), dst.data_ptr(), dst.numel() * dst.element_size()), "vqs_qwen_debug_tap")
 
     def profile(self, on: bool):
         self._check(self.lib.vqs_qwen_profile_enable(self._h, 1 if on else 0), "vqs_qwen_profile_enable")
