@@ -77,9 +77,9 @@ int vqs_qwen_score(vqs_qwen_handle* h, const void* d_merged, const int32_t* d_in
                    int32_t L, float* d_logits, void* d_ws, size_t ws_bytes, void* stream);
 
 /* Test hook (not part of the drop-in boundary): register a caller-owned device buffer for a named intermediate of the NEXT passes;
- * when a pass produces it, it is copied there on the pass's stream.  Names: vis.pre, vis.<i>.{h,xn0,q,k,v,attn,d_attn,xn1,ff,d_mlp},
- * vis.{h_out,xnm,mid,merged_w}; txt.emb, txt.<i>.{h,xn0,q,k,v,attn,d_attn,xn1,ff,d_mlp}, txt.{h_out,xnf} -- tensors in the ENGINE's
- * layouts (padded windowed rows, 128-lane heads, q / k after the rotary embedding, padded ff width).  name == NULL clears every tap.
+ * when a pass produces it, it is copied there on the pass's stream.  Names: vis.pre, vis.<i>.{h,xn0,q0,k0,q,k,v,attn,d_attn,xn1,ff,d_mlp},
+ * vis.{h_out,xnm,mid,merged_w}; txt.emb, txt.<i>.{h,xn0,q0,k0,q,k,v,attn,d_attn,xn1,ff,d_mlp}, txt.{h_out,xnf} -- tensors in the ENGINE's
+ * layouts (padded windowed rows, 128-lane heads, q0 / k0 before and q / k after the rotary embedding, padded ff width).  name == NULL clears every tap.
  * tests/test_gpu_qwen.py checks every launch of a pass against the rounding-matched oracle through it. */
 int vqs_qwen_debug_tap(vqs_qwen_handle* h, const char* name, void* d_dst, size_t bytes);
 

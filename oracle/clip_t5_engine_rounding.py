@@ -74,10 +74,12 @@ def gelu_new_sigmoid(x: torch.Tensor) -> torch.Tensor:
     return x * torch.sigmoid(u2)
 
 
-def tiled_attention(q, k, v, scale: float, bias_table=None, key_len=None, round_fn=bf16_round, acc=torch.float64):
-    """attn_fwd_dma_kernel<HAS_BIAS> (attn.hip:366-595) restated on the CPU.
+def tiled_attention(q, k, v, scale: float, bias_table=None, key_len=None, round_fn=bf16_round, acc=torch.float64, causal=False):
+    """attn_fwd_dma_kernel<HAS_BIAS> (attn.hip:366-595) and attn_fwd_hd_kernel<128, CAUSAL> (attn.hip:468-672; same tiles,
+    same softmax, key > query masked when ``causal``) restated on the CPU.  A tile the causal kernel skips for a 128-query
+    block is a tile whose scores are all masked there: it moves neither the running max nor the sums, so masking is enough.
 
-    q, k, v: [B, H, S, 64] fp32 tensors holding bf16 values.  bias_table: [H, 2S-1] fp32, entry (key - query + S - 1),
+    q, k, v: [B, H, S, d] fp32 tensors holding bf16 values.  bias_table: [H, 2S-1] fp32, entry (key - query + S - 1),
     natural-log units (the kernel multiplies by log2e when it fills its LDS copies).  key_len: [B] or None.
     Returns [B, S, H*64] fp32 holding bf16 values (``round_fn`` applied)."""
     B, H, S, d = q.shape
@@ -91,6 +93,7 @@ def tiled_attention(q, k, v, scale: float, bias_table=None, key_len=None, round_
         t_all = None
     klen = torch.full((B,), S, dtype=torch.long) if key_len is None else key_len.clamp(max=S).long()
     keymask = torch.arange(S)[None, :] >= klen[:, None]                              # [B,S] True = masked
+    cmask = (torch.arange(S)[None, :] > torch.arange(S)[:, None]) if causal else None  # [query, key] True = masked
     G = (S + WAVE_ROWS - 1) // WAVE_ROWS
     pad = G * WAVE_ROWS - S
 
@@ -101,6 +104,8 @@ def tiled_attention(q, k, v, scale: float, bias_table=None, key_len=None, round_
     for kt in range(ntiles):
         kb, ke = kt * KT, min(kt * KT + KT, S)
         km = keymask[:, None, None, kb:ke]
+        if cmask is not None:
+            km = km | cmask[None, None, :, kb:ke]
         if t_all is not None:
             t = t_all[..., kb:ke].masked_fill(km, NEG_BIG)
             mx = t.max(-1).values
@@ -134,6 +139,27 @@ def tiled_attention(q, k, v, scale: float, bias_table=None, key_len=None, round_
     return out.transpose(1, 2).reshape(B, S, H * d)
 
 
+def compare_tap(y: torch.Tensor, e: torch.Tensor, valid: torch.Tensor | None = None) -> dict:
+    """Distance of an oracle result `y` from the engine's tensor `e` of the same launch (both fp32, same shape), over the
+    `valid` elements if given.  Per-element measure: the difference in units of the element's OWN bf16 ulp (2^(exponent - 7)
+    of the larger of the two values) plus an absolute floor of 2^-18 of the tensor's top value -- the fp32 summation noise a
+    result that cancels to nearly nothing still carries.  An absmax-relative bound alone lets a defect confined to small
+    elements through."""
+    d = (y - e).abs()
+    if valid is not None:
+        d = torch.where(valid.expand_as(d), d, torch.zeros_like(d))
+        n = int(valid.expand_as(d).sum())
+        ref_abs = float(torch.where(valid.expand_as(e), e.abs(), torch.zeros_like(e)).max())
+    else:
+        n = d.numel()
+        ref_abs = float(e.abs().max())
+    big = torch.maximum(y.abs(), e.abs())
+    own_ulp = torch.ldexp(torch.ones_like(big), torch.frexp(big).exponent - 8)
+    own = d / (own_ulp + ref_abs * 2.0 ** -18 + 1e-37)
+    return {"frac_diff": float((d > 0).sum()) / max(n, 1), "max_abs": float(d.max()), "ref_absmax": ref_abs, "n": n,
+            "max_own_ulps": float(own.max()), "frac_over_1_own_ulp": float((own > 1.0).sum()) / max(n, 1)}
+
+
 class EngineRoundedOracle(Oracle):
     """See the module docstring.  ``round_fn`` = identity turns every rounding off (used to pin this class against
     ``Oracle``); ``acc`` is the dtype matrix products are accumulated in."""
@@ -158,22 +184,7 @@ class EngineRoundedOracle(Oracle):
             raise KeyError(f"stage-locked run needs the engine tap {name!r}")
         e = self.locked[name].detach().to("cpu", torch.float32)
         e = e.reshape(-1)[: y.numel()].reshape(y.shape) if e.numel() >= y.numel() and e.shape != y.shape else e
-        d = (y - e).abs()
-        if valid is not None:
-            d = torch.where(valid.expand_as(d), d, torch.zeros_like(d))
-            n = int(valid.expand_as(d).sum())
-            ref_abs = float(torch.where(valid.expand_as(e), e.abs(), torch.zeros_like(e)).max())
-        else:
-            n = d.numel()
-            ref_abs = float(e.abs().max())
-        # per-element measure: the difference in units of the element's OWN bf16 ulp (2^(exponent - 7) of the larger of the two
-        # values) plus an absolute floor of 2^-18 of the tensor's top value -- the fp32 summation noise a result that cancels to
-        # nearly nothing still carries.  An absmax-relative bound alone lets a defect confined to small elements through.
-        big = torch.maximum(y.abs(), e.abs())
-        own_ulp = torch.ldexp(torch.ones_like(big), torch.frexp(big).exponent - 8)
-        own = d / (own_ulp + ref_abs * 2.0 ** -18 + 1e-37)
-        self.report[name] = {"frac_diff": float((d > 0).sum()) / max(n, 1), "max_abs": float(d.max()), "ref_absmax": ref_abs, "n": n,
-                             "max_own_ulps": float(own.max()), "frac_over_1_own_ulp": float((own > 1.0).sum()) / max(n, 1)}
+        self.report[name] = compare_tap(y, e, valid)
         return e
 
     # ---------------------------------------------------------------------------------------------- helpers

@@ -506,6 +506,8 @@ int vqs_qwen_encode_vision(vqs_qwen_handle* h, const void* d_patches, int32_t N,
             g.heads[0] = w.q; g.heads[1] = w.k; g.heads[2] = w.v;
             QRUN(qgemm(h, g, st, "vision qkv"));
         }
+        QTAP("vis", i, "q0", w.q, (size_t)rows * VPK);           // projection output, before the rotary embedding
+        QTAP("vis", i, "k0", w.k, (size_t)rows * VPK);
         QHIP(h, vqs::launch_rope(w.q, full ? d_cos_f : d_cos_w, full ? d_sin_f : d_sin_w, Bseg, VNH, S, HDP, h->v_hd / 2, st), "vision rope q");
         QHIP(h, vqs::launch_rope(w.k, full ? d_cos_f : d_cos_w, full ? d_sin_f : d_sin_w, Bseg, VNH, S, HDP, h->v_hd / 2, st), "vision rope k");
         QTAP("vis", i, "q", w.q, (size_t)rows * VPK);            // after the rotary embedding, head-major [Bseg, heads, S, 128]
@@ -618,6 +620,8 @@ int vqs_qwen_score(vqs_qwen_handle* h, const void* d_merged, const int32_t* d_in
             g.heads[0] = w.q; g.heads[1] = w.k; g.heads[2] = w.v;
             QRUN(qgemm(h, g, st, "qkv"));
         }
+        QTAP("txt", i, "q0", w.q, (size_t)M * IQ);                // projection output, before the rotary embedding
+        QTAP("txt", i, "k0", w.k, (size_t)M * IKV);
         QHIP(h, vqs::launch_rope(w.q, d_cos, d_sin, B, c.t_heads, L, HDP, h->t_hd / 2, st), "rope q");
         QHIP(h, vqs::launch_rope(w.k, d_cos, d_sin, B, c.t_kv_heads, L, HDP, h->t_hd / 2, st), "rope k");
         QTAP("txt", i, "q", w.q, (size_t)M * IQ);                 // after the rotary embedding, head-major [B, heads, L, 128]

@@ -56,6 +56,102 @@ def test_qwen_path_matches_hf_fixture(golden_dir, name, fixture):
     eng.close()
 
 
+ATTENTION_TAPS = ("attn",)
+
+
+def _stage_locked(tag, cfg, w, eng, px, grid, ids, mask, grids, vis_layers=None, txt_layers=None, acc=torch.float64, merged=None):
+    """Every launch of one vqs_qwen_encode_vision call (grid `grid`, patches `px`) and one vqs_qwen_score call against
+    oracle/qwen25vl_engine_rounding.py evaluated on the ENGINE's own inputs of that launch (vqs_qwen_debug_tap).  Asserted per
+    launch output: fp32 tensors within 2e-5 of their top value; bf16 tensors within ONE ulp of the element's own binade, at most
+    0.5 % of the elements different at all (attention: two ulps of the tensor's top value -- P is rounded inside the kernel)."""
+    import json
+    from oracle.qwen25vl_engine_rounding import FP32_TAPS, QwenEngineRounded, text_tap_shapes, vision_tap_shapes
+    from t2v_metrics_amd.qwen.layout import text_layout, vision_layout
+    emu = QwenEngineRounded(cfg, {k: v.cpu() for k, v in w.items()}, acc=acc)
+    reports = {}
+    if px is not None:
+        lay = vision_layout(cfg, [grid])
+        shapes = vision_tap_shapes(cfg, lay, vis_layers)
+        bufs = {n: torch.zeros(sh, dtype=dt, device="cuda") for n, (sh, dt) in shapes.items()}
+        for n, b in bufs.items():
+            eng.tap(n, b)
+        out = eng.encode_vision(px, [grid])
+        torch.cuda.synchronize()
+        eng.tap(None)
+        taps = {n: b.cpu() for n, b in bufs.items()}
+        taps["vis.merged"] = out.cpu()
+        del bufs
+        rep = emu.vision_locked(taps, px.float().cpu(), lay, layers=vis_layers)
+        # a block behind a skipped one starts from the engine's stream unchecked: only those names may be absent
+        assert all(n.endswith(".h") or n.endswith("h_out") for n in set(shapes) - set(rep)) and "vis.merged" in rep, set(shapes) - set(rep)
+        assert vis_layers is not None or len(rep) == len(shapes) + 1
+        reports.update(rep)
+    if ids is not None:
+        B, L = ids.shape
+        lay = text_layout(cfg, ids, mask, grids)
+        shapes = text_tap_shapes(cfg, B, L, txt_layers)
+        bufs = {n: torch.zeros(sh, dtype=dt, device="cuda") for n, (sh, dt) in shapes.items()}
+        for n, b in bufs.items():
+            eng.tap(n, b)
+        logits = eng.score_logits(merged, ids, mask, grids)
+        torch.cuda.synchronize()
+        eng.tap(None)
+        taps = {n: b.cpu() for n, b in bufs.items()}
+        taps["txt.logits"] = logits.cpu()
+        del bufs
+        rep = emu.text_locked(taps, merged.float().cpu(), ids, lay, layers=txt_layers)
+        assert all(n.endswith(".h") or n.endswith("h_out") for n in set(shapes) - set(rep)) and "txt.logits" in rep, set(shapes) - set(rep)
+        assert txt_layers is not None or len(rep) == len(shapes) + 1
+        reports.update(rep)
+    worst, bad = {}, []
+    for n, r in reports.items():
+        kind = n.split(".")[-1]
+        rel = r["max_abs"] / max(r["ref_absmax"], 1e-30)
+        a = worst.setdefault(n.split(".")[0] + "." + kind, {"frac_diff": 0.0, "max_abs_over_ref": 0.0, "max_own_ulps": 0.0, "taps": 0})
+        a["frac_diff"], a["max_abs_over_ref"] = max(a["frac_diff"], r["frac_diff"]), max(a["max_abs_over_ref"], rel)
+        a["max_own_ulps"], a["taps"] = max(a["max_own_ulps"], r["max_own_ulps"]), a["taps"] + 1
+        if kind in FP32_TAPS:
+            ok = rel <= 2e-5
+        elif kind in ATTENTION_TAPS:
+            ok = r["frac_diff"] <= 5e-3 and rel <= 2.0 * 2.0 ** -7 * 1.001
+        else:
+            ok = r["frac_diff"] <= 5e-3 and r["max_own_ulps"] <= 1.001
+        ok = ok and r.get("pad_nonzero", 0) == 0
+        if not ok:
+            bad.append((n, r))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "stage_locked.jsonl"), "a") as f:
+        f.write(json.dumps({"case": tag, "launch_outputs_checked": len(reports), "worst_by_kind": worst}) + "\n")
+    assert not bad, f"{len(bad)} of {len(reports)} launch outputs off: {bad[:6]}"
+    return reports
+
+
+@pytest.mark.parametrize("name,fixture", [("qwen-tiny", "qwen_tiny"), ("qwen-small", "qwen_small"), ("qwen-tiny", "qwen_tiny_ragged")])
+def test_qwen_every_launch_stage_locked(golden_dir, name, fixture):
+    """The Qwen2.5-VL row held to the CLIP-FlanT5 row's standard: every launch of the vision tower (one call per video: window
+    and full-attention blocks, partial windows, 32- / 80-lane heads padded to 128) and of the batched right-padded prefill
+    (grouped-query causal attention, M-RoPE) bit-checked against the rounding-matched oracle on the engine's own inputs."""
+    from t2v_metrics_amd.qwen.engine import QwenEngine
+    z = np.load(os.path.join(golden_dir, fixture + ".npz"))
+    cfg = get_qwen_config(name)
+    w = make_seeded_qwen_weights(cfg, seed=int(z["seed"]), dtype=torch.bfloat16, lm_head_gain=float(z["gain"]))
+    eng = QwenEngine(cfg, w)
+    grids = [tuple(int(x) for x in g) for g in z["grids"]]
+    ids, mask = torch.from_numpy(z["input_ids"]), torch.from_numpy(z["attention_mask"])
+    px = torch.from_numpy(z["pixel_values"]).to(torch.bfloat16)
+    merged, off, n_checked = [], 0, 0
+    for vi, g in enumerate(grids):
+        n = g[0] * g[1] * g[2]
+        n_checked += len(_stage_locked(f"qwen/{fixture}/video{vi}", cfg, w, eng, px[off: off + n].cuda(), g, None, None, None))
+        merged.append(eng.encode_vision(px[off: off + n].cuda(), [g]))
+        off += n
+    merged = torch.cat(merged)
+    n_checked += len(_stage_locked(f"qwen/{fixture}/prefill", cfg, w, eng, None, None, ids, mask, grids, merged=merged))
+    assert n_checked == len(grids) * (12 * cfg.vision.depth + 6) + 12 * cfg.text.layers + 4
+    eng.close()
+
+
 def test_qwen_errors_are_reported():
     from t2v_metrics_amd.engine import VqsError
     from t2v_metrics_amd.qwen.engine import QwenEngine
@@ -112,8 +208,14 @@ def test_qwen_7b_full_size_one_sample_against_the_cpu_oracle():
     ids = torch.cat([pre, torch.tensor([cfg.vision_start_token_id]), torch.full((n_merged,), cfg.video_token_id),
                      torch.tensor([cfg.vision_end_token_id]), post])[None]
     mask = torch.ones_like(ids)
-    logits = eng.score_logits(eng.encode_vision(px.cuda(), [grid]), ids, mask, [grid]).float().cpu()
+    merged_dev = eng.encode_vision(px.cuda(), [grid])
+    logits = eng.score_logits(merged_dev, ids, mask, [grid]).float().cpu()
     torch.cuda.synchronize()
+    # launch-level check at the public dimensions (80-lane tower heads, 3420-wide tower MLP, 28/4 grouped-query heads): first /
+    # full-attention / last tower blocks and first / middle / last decoder layers, each launch on the engine's own inputs
+    # (fp32 accumulation on the host: same <= 1 ulp criterion, ~4x cheaper than fp64 at this size)
+    _stage_locked("qwen/fullsize-7b", cfg, w, eng, px.cuda(), grid, ids, mask, [grid], vis_layers=[0, 7, 31], txt_layers=[0, 13, 27],
+                  acc=torch.float32, merged=merged_dev)
     ref = QwenOracle(cfg, {k: v.cpu() for k, v in w.items()}).forward(ids, mask, px.float(), [grid])
     lp, ref_lp = torch.log_softmax(logits, -1)[0], torch.log_softmax(ref, -1)[0]
     toks = ref_lp.topk(5).indices.tolist() + [9454]

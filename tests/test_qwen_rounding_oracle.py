@@ -1,0 +1,98 @@
+"""Pins oracle/qwen25vl_engine_rounding.py (the rounding-matched restatement of the Qwen2.5-VL row in the HIP engine's
+layouts) against oracle/qwen25vl_oracle.py (pinned to the HF modules by test_qwen_oracle_golden.py): with every rounding
+switched off the two must agree to fp32 accuracy -- on grids with and without partial attention windows, with 32-, 80- and
+128-lane heads, grouped-query heads and ragged (right-padded) batches."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.qwen25vl_engine_rounding import QwenEngineRounded, _identity, text_tap_names, vision_tap_names
+from oracle.qwen25vl_oracle import QwenOracle
+from t2v_metrics_amd.qwen import get_qwen_config
+from t2v_metrics_amd.qwen.layout import text_layout, vision_layout
+from t2v_metrics_amd.qwen.weights import make_seeded_qwen_weights
+
+
+def _case(golden_dir, name, fixture):
+    z = np.load(os.path.join(golden_dir, fixture + ".npz"))
+    cfg = get_qwen_config(name)
+    w = make_seeded_qwen_weights(cfg, seed=int(z["seed"]), dtype=torch.bfloat16, lm_head_gain=float(z["gain"]))
+    grids = [tuple(int(x) for x in g) for g in z["grids"]]
+    return cfg, w, grids, torch.from_numpy(z["input_ids"]), torch.from_numpy(z["attention_mask"]), torch.from_numpy(z["pixel_values"])
+
+
+def _run(o, cfg, grids, ids, mask, px, record=None):
+    merged, off = [], 0
+    for g in grids:
+        n = g[0] * g[1] * g[2]
+        merged.append(o.vision_tower(px[off: off + n], vision_layout(cfg, [g])))
+        off += n
+    merged = torch.cat(merged)
+    return merged, o.text_logits(merged, ids, text_layout(cfg, ids, mask, grids))
+
+
+@pytest.mark.parametrize("name,fixture", [("qwen-tiny", "qwen_tiny"), ("qwen-small", "qwen_small"), ("qwen-tiny", "qwen_tiny_ragged")])
+def test_roundings_off_reproduces_the_fp32_oracle(golden_dir, name, fixture):
+    cfg, w, grids, ids, mask, px = _case(golden_dir, name, fixture)
+    with torch.no_grad():
+        merged, logits = _run(QwenEngineRounded(cfg, w, round_fn=_identity), cfg, grids, ids, mask, px)
+    ref = QwenOracle(cfg, w).forward(ids, mask, px, grids, return_stages=True)
+    assert (merged - ref["merged"]).abs().max().item() <= 2e-5 * max(1.0, ref["merged"].abs().max().item())
+    assert (logits - ref["logits"]).abs().max().item() <= 5e-5 * max(1.0, ref["logits"].abs().max().item())
+
+
+@pytest.mark.parametrize("name,fixture", [("qwen-tiny", "qwen_tiny_ragged"), ("qwen-small", "qwen_small")])
+def test_rounded_pass_sits_at_the_bf16_noise_floor(golden_dir, name, fixture):
+    cfg, w, grids, ids, mask, px = _case(golden_dir, name, fixture)
+    with torch.no_grad():
+        _, logits = _run(QwenEngineRounded(cfg, w), cfg, grids, ids, mask, px)
+    ref = QwenOracle(cfg, w).forward(ids, mask, px, grids)
+    lp, ref_lp = torch.log_softmax(logits, -1), torch.log_softmax(ref, -1)
+    top = ref_lp.argmax(-1)[:, None]
+    d = (lp.gather(-1, top) - ref_lp.gather(-1, top)).abs().max().item()
+    assert 0 < d <= 5e-2, d
+
+
+def test_stage_locked_mode_is_exact_on_its_own_record(golden_dir):
+    """A free-running pass recorded and replayed as the 'engine' must report zero differences everywhere, with every tap
+    name the GPU tests register present -- the plumbing of the stage-locked check, including the layer subset."""
+    cfg, w, grids, ids, mask, px = _case(golden_dir, "qwen-tiny", "qwen_tiny_ragged")
+    o = QwenEngineRounded(cfg, w)
+    g = grids[0]
+    n = g[0] * g[1] * g[2]
+    lay = vision_layout(cfg, [g])
+    o.record = {}
+    with torch.no_grad():
+        o.vision_tower(px[:n], lay)
+    rec = dict(o.record)
+    o.record = None
+    assert set(vision_tap_names(cfg)) <= set(rec)
+    # the engine's ff rows are wider than mlp (zero padding): emulate that
+    for i in range(cfg.vision.depth):
+        rec[f"vis.{i}.ff"] = torch.nn.functional.pad(rec[f"vis.{i}.ff"], (0, 32))
+    rep = o.vision_locked(rec, px[:n], lay)
+    assert set(vision_tap_names(cfg)) <= set(rep)
+    assert all(r["frac_diff"] == 0.0 and r["pad_nonzero"] == 0 for r in rep.values()), {k: r for k, r in rep.items() if r["frac_diff"]}
+    sub = {k: v for k, v in rec.items() if k in set(vision_tap_names(cfg, [1, 3])) | {"vis.merged"}}
+    rep = o.vision_locked(sub, px[:n], lay, layers=[1, 3])
+    assert "vis.1.attn" in rep and "vis.0.attn" not in rep and all(r["frac_diff"] == 0.0 for r in rep.values())
+    # a planted defect is seen at its launch (and at the launch that consumes the changed tensor), nowhere else
+    bad = dict(rec)
+    bad["vis.2.attn"] = rec["vis.2.attn"] * 1.02
+    rep = o.vision_locked(bad, px[:n], lay)
+    assert rep["vis.2.attn"]["max_own_ulps"] > 1.5 and rep["vis.2.d_attn"]["frac_diff"] > 0.5
+    assert all(r["frac_diff"] == 0.0 for k, r in rep.items() if k not in ("vis.2.attn", "vis.2.d_attn"))
+    # text stack
+    merged = torch.cat([QwenEngineRounded(cfg, w).vision_tower(px[o_: o_ + gg[0] * gg[1] * gg[2]], vision_layout(cfg, [gg]))
+                        for o_, gg in zip(np.cumsum([0] + [a * b * c for a, b, c in grids[:-1]]).tolist(), grids)])
+    tl = text_layout(cfg, ids, mask, grids)
+    o.record = {}
+    with torch.no_grad():
+        o.text_logits(merged, ids, tl)
+    rec = dict(o.record)
+    o.record = None
+    assert set(text_tap_names(cfg)) <= set(rec)
+    rep = o.text_locked(rec, merged, ids, tl)
+    assert set(text_tap_names(cfg)) | {"txt.logits"} <= set(rep) and all(r["frac_diff"] == 0.0 for r in rep.values())
