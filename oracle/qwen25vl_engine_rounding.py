@@ -43,6 +43,14 @@ from .clip_t5_engine_rounding import bf16_round, compare_tap, tiled_attention
 HDP = 128          # lanes per head in the engine's Q / K / V / attention tensors (vqs_qwen.cpp)
 
 
+def vision_heads_compact(cfg) -> bool:
+    """vqs_qwen.cpp v_compact: tower heads narrower than 128 lanes with whole 128-column q | k | v ranges (7B: 16 x 80) keep the
+    checkpoint's qkv / proj tensors -- Q / K / V still sit in 128-lane slots, but the attention output leaves compact
+    ``[rows, heads * head_dim]``."""
+    v = cfg.vision
+    return v.head_dim < HDP and v.head_dim % 8 == 0 and v.hidden % 128 == 0
+
+
 def _identity(x: torch.Tensor) -> torch.Tensor:
     return x.to(torch.float32)
 
@@ -173,8 +181,11 @@ class QwenEngineRounded:
             q = self._emit(t + "q", self._rope(q0, cos, sin, hd))
             k = self._emit(t + "k", self._rope(k0, cos, sin, hd))
             a = tiled_attention(q, k, val, scale, key_len=klen, round_fn=r, acc=self.acc).reshape(rows, H * HDP)
-            a = self._emit(t + "attn", a)
-            d = r(self._lin(self._unpad_heads(a, H, hd), p + "attn.proj.weight", p + "attn.proj.bias"))
+            if vision_heads_compact(self.cfg):
+                a = self._emit(t + "attn", self._unpad_heads(a, H, hd))
+            else:
+                a = self._unpad_heads(self._emit(t + "attn", a), H, hd)
+            d = r(self._lin(a, p + "attn.proj.weight", p + "attn.proj.bias"))
             if full:
                 d = torch.where(real[:, None], d[row_map.clamp(min=0)], torch.zeros(1, VH))   # scatter back, zero padding rows
             d_attn = self._emit(t + "d_attn", d)
@@ -276,7 +287,7 @@ def vision_tap_shapes(cfg, lay, layers: Optional[Sequence[int]] = None):
         rows, S = (N, lay["frame_len"]) if i in v.fullatt_blocks else (Np, lay["win_len"])
         hs = ((rows // S, H, S, HDP), b16)
         out.update({f"vis.{i}.h": ((Np, VH), f32), f"vis.{i}.xn0": ((Np, VH), b16), f"vis.{i}.q0": hs, f"vis.{i}.k0": hs, f"vis.{i}.q": hs,
-                    f"vis.{i}.k": hs, f"vis.{i}.v": hs, f"vis.{i}.attn": ((rows, H * HDP), b16), f"vis.{i}.d_attn": ((Np, VH), b16),
+                    f"vis.{i}.k": hs, f"vis.{i}.v": hs, f"vis.{i}.attn": ((rows, VH if vision_heads_compact(cfg) else H * HDP), b16), f"vis.{i}.d_attn": ((Np, VH), b16),
                     f"vis.{i}.xn1": ((Np, VH), b16), f"vis.{i}.ff": ((Np, _ffld(v.mlp)), b16), f"vis.{i}.d_mlp": ((Np, VH), b16)})
     ncp = Np // v.merge_unit
     out.update({"vis.h_out": ((Np, VH), f32), "vis.xnm": ((Np, VH), b16), "vis.mid": ((ncp, v.merge_unit * VH), b16),

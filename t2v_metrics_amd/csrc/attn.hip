@@ -658,7 +658,8 @@ __global__ void __launch_bounds__(256) attn_fwd_hd_kernel(const AttnParams p) {
     const float l_tot = osum[0];
     const float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
     if (qrow < S) {
-        bf16_t* orow = p.out + ((size_t)b * S + qrow) * ((size_t)p.H * HD) + h * HD;
+        const int ohd = p.out_hd > 0 ? p.out_hd : HD;        // lanes of the head that leave (a multiple of 4)
+        bf16_t* orow = p.out + ((size_t)b * S + qrow) * ((size_t)p.H * ohd) + h * ohd;
 #pragma unroll
         for (int df = 0; df < DF; ++df)
 #pragma unroll
@@ -666,7 +667,7 @@ __global__ void __launch_bounds__(256) attn_fwd_hd_kernel(const AttnParams p) {
                 uint2 v;
                 v.x = a_pack2(o[df][4 * gq + 0] * inv, o[df][4 * gq + 1] * inv);
                 v.y = a_pack2(o[df][4 * gq + 2] * inv, o[df][4 * gq + 3] * inv);
-                *reinterpret_cast<uint2*>(orow + df * 32 + 8 * gq + 4 * hh) = v;
+                if (df * 32 + 8 * gq + 4 * hh < ohd) *reinterpret_cast<uint2*>(orow + df * 32 + 8 * gq + 4 * hh) = v;
             }
     }
 }
@@ -713,11 +714,12 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
     if (p.hd == 128) {
         const int Hkv = p.Hkv > 0 ? p.Hkv : p.H;
         if (p.bias_table != nullptr || Hkv <= 0 || (p.H % Hkv) != 0) return hipErrorInvalidValue;
+        if (p.out_hd < 0 || p.out_hd > 128 || (p.out_hd & 3)) return hipErrorInvalidValue;
         const size_t lds = 2 * 2 * (size_t)KT * 128 * 2;            // two stages of K + V tiles
         return p.causal ? launch_attn_t(attn_fwd_hd_kernel<128, true>, p, lds, stream)
                         : launch_attn_t(attn_fwd_hd_kernel<128, false>, p, lds, stream);
     }
-    if (p.hd != 0 && p.hd != 64) return hipErrorInvalidValue;
+    if ((p.hd != 0 && p.hd != 64) || p.out_hd != 0) return hipErrorInvalidValue;
     if (p.causal || (p.Hkv > 0 && p.Hkv != p.H)) return hipErrorInvalidValue;
     const size_t bias_bytes = p.bias_table ? (size_t)bias_copy_chunks(p.S) * 64 : 0;
 #ifdef VQS_LAB

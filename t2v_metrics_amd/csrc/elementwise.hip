@@ -516,6 +516,49 @@ __global__ void __launch_bounds__(256) rope_grid_kernel(bf16_t* __restrict__ x, 
     *reinterpret_cast<uint32_t*>(xr + half + 2 * ip) = e_pack2_hw(b0 * c.x + a0 * sv.x, b1 * c.y + a1 * sv.y);
 }
 
+// Q and K of one layer in ONE launch, 16-byte accesses: thread = (8-lane chunk c of the first half, position), it rotates lanes
+// [8c, 8c+8) against [half + 8c, half + 8c + 8) -- same fp32 expressions as rope_kernel, element for element.  blockIdx.y walks the
+// Hq query heads, then the Hk key heads.  The 4-byte kernels above move 16 B per thread and are issue-bound at half the HBM rate.
+__global__ void __launch_bounds__(256) rope_qk_kernel(bf16_t* __restrict__ q, bf16_t* __restrict__ k, const float* __restrict__ cs,
+                                                      const float* __restrict__ sn, int Hq, int Hk, int S, int hd, int half) {
+    const int c = threadIdx.x, s_ = blockIdx.x * 32 + threadIdx.y;
+    if (c >= (half >> 3) || s_ >= S) return;
+    const int hy = blockIdx.y, b = blockIdx.z;
+    const bool isq = hy < Hq;
+    const int h = isq ? hy : hy - Hq, H = isq ? Hq : Hk;
+    bf16_t* xr = (isq ? q : k) + (((size_t)b * H + h) * S + s_) * hd;
+    const size_t tok = (size_t)b * S + s_;
+    const uint4 lo = *reinterpret_cast<const uint4*>(xr + 8 * c);
+    const uint4 hi = *reinterpret_cast<const uint4*>(xr + half + 8 * c);
+    const float4 c0 = *reinterpret_cast<const float4*>(cs + tok * half + 8 * c), c1 = *reinterpret_cast<const float4*>(cs + tok * half + 8 * c + 4);
+    const float4 s0 = *reinterpret_cast<const float4*>(sn + tok * half + 8 * c), s1 = *reinterpret_cast<const float4*>(sn + tok * half + 8 * c + 4);
+    const uint32_t lw[4] = {lo.x, lo.y, lo.z, lo.w}, hw[4] = {hi.x, hi.y, hi.z, hi.w};
+    const float cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w}, ss[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+    uint32_t ol[4], oh[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float a0 = e_bf2f((bf16_t)(lw[j] & 0xffff)), a1 = e_bf2f((bf16_t)(lw[j] >> 16));
+        const float b0 = e_bf2f((bf16_t)(hw[j] & 0xffff)), b1 = e_bf2f((bf16_t)(hw[j] >> 16));
+        ol[j] = e_pack2_hw(a0 * cc[2 * j] - b0 * ss[2 * j], a1 * cc[2 * j + 1] - b1 * ss[2 * j + 1]);
+        oh[j] = e_pack2_hw(b0 * cc[2 * j] + a0 * ss[2 * j], b1 * cc[2 * j + 1] + a1 * ss[2 * j + 1]);
+    }
+    *reinterpret_cast<uint4*>(xr + 8 * c) = make_uint4(ol[0], ol[1], ol[2], ol[3]);
+    *reinterpret_cast<uint4*>(xr + half + 8 * c) = make_uint4(oh[0], oh[1], oh[2], oh[3]);
+}
+
+hipError_t launch_rope(bf16_t* x, const float* cs, const float* sn, int B, int H, int S, int hd, int half, hipStream_t s);
+hipError_t launch_rope_qk(bf16_t* q, bf16_t* k, const float* cs, const float* sn, int B, int Hq, int Hk, int S, int hd, int half,
+                          hipStream_t s) {
+    if ((half & 1) || 2 * half > hd || (hd & 1)) return hipErrorInvalidValue;
+    if ((half & 7) == 0 && (hd & 7) == 0 && half <= 64 && B <= 65535 && Hq + Hk <= 65535) {
+        hipLaunchKernelGGL(rope_qk_kernel, dim3((unsigned)((S + 31) / 32), (unsigned)(Hq + Hk), (unsigned)B), dim3(8, 32), 0, s, q, k, cs,
+                           sn, Hq, Hk, S, hd, half);
+        return hipGetLastError();
+    }
+    const hipError_t e = launch_rope(q, cs, sn, B, Hq, S, hd, half, s);
+    return e != hipSuccess ? e : launch_rope(k, cs, sn, B, Hk, S, hd, half, s);
+}
+
 hipError_t launch_rope(bf16_t* x, const float* cs, const float* sn, int B, int H, int S, int hd, int half, hipStream_t s) {
     if ((half & 1) || 2 * half > hd || (hd & 1)) return hipErrorInvalidValue;
     if (half <= 64 && B <= 65535 && H <= 65535) {

@@ -1616,6 +1616,7 @@ static bool quad_eligible_rt(const GemmParams& p, int epi) {
         // a wave's 128 columns must lie inside ONE of the q / k / v tensors (one head count per block); rows step by 4 within a sample
         const int ikv = p.inner_kv > 0 ? p.inner_kv : p.inner;
         if (p.S < 8 || (p.inner % 128) != 0 || (ikv % 128) != 0) return false;
+        if (p.hd_src > 0 && ((p.hd_src % 8) != 0 || p.hd_src > (p.hd > 0 ? p.hd : 64))) return false;
     }
     return true;
 }
@@ -1627,11 +1628,12 @@ static bool quad_eligible(const GemmParams& p) { return quad_eligible_rt(p, EPI)
 // then falls back to the one-tile-per-workgroup kernel (same bits), anything else is an error -- never a wrapped offset.
 int gemm_form(const GemmParams& p, int epilogue, int variant) {
     if (epilogue == EPI_RESID_RMS) variant = variant == 5 ? 5 : 3;
-    const bool plain_v0 = !(p.hd > 64 || p.inner_kv > 0 || p.Hkv > 0 || p.gate_act != 0 || (epilogue == EPI_GATED && p.bias != nullptr) || p.rowss_in != nullptr) &&
+    const bool plain_v0 = !(p.hd > 64 || p.hd_src > 0 || p.inner_kv > 0 || p.Hkv > 0 || p.gate_act != 0 || (epilogue == EPI_GATED && p.bias != nullptr) || p.rowss_in != nullptr) &&
                           p.batch <= 1 && epilogue != EPI_RESID_RMS;
     if (variant == 0 || variant == 2 || variant == 1) return plain_v0 ? 0 : -1;
     if (epilogue == EPI_HEADS && p.S < 8) return plain_v0 ? 0 : -1;
     if ((variant == 3 || variant == 10) && quad_eligible_rt(p, epilogue)) return 10;
+    if (epilogue == EPI_HEADS && p.hd_src > 0 && p.hd_src != (p.hd > 0 ? p.hd : 64)) return -1;   // narrow heads in wide slots: quad form only
     if (epilogue == EPI_F32_RESID) return p.batch <= 1 ? 0 : -1;
     const bool fit = (uint64_t)p.M * (uint64_t)p.lda * 2ull < (1ull << 32) && (uint64_t)p.N * (uint64_t)p.ldw * 2ull < (1ull << 32);
     if (fit) return 3;

@@ -35,6 +35,9 @@ struct GemmParams {
     int S, H, inner;
     bf16_t* heads_out[3];
     int hd = 0;              // head width (0 = 64); 128 for Qwen2.5-VL
+    int hd_src = 0;          // columns per head in the GEMM's N when narrower than hd (0 = hd): the product's heads are written into
+                             // the first hd_src lanes of hd-lane slots (the caller keeps the other lanes zero); inner / inner_kv count
+                             // GEMM columns.  Quad form only.
     int inner_kv = 0;        // width of the k and of the v column ranges (0 = inner); grouped-query models
     int Hkv = 0;             // heads of the k / v tensors (0 = H)
     // EPI_GATED
@@ -173,6 +176,8 @@ struct AttnParams {
     int hd = 0;               // 0 / 64: the kernels above
     int Hkv = 0;              // key/value heads (0 = H); query head h reads head h / (H / Hkv)
     int causal = 0;           // key <= query
+    int out_hd = 0;           // hd = 128 only: lanes of a head written to `out`, which is then [B*S, H*out_hd] (0 = hd); the Qwen2.5-VL
+                              // tower's 80-lane heads leave compact so that the proj GEMM contracts over 1280, not 2048
 };
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream);
 size_t attention_lds_bytes(int S, bool has_bias, int hd);   // dynamic LDS request of that launch (host-side arithmetic)
@@ -223,6 +228,9 @@ hipError_t launch_embed_splice(const int* ids, const int* sent_pos, const int* e
 hipError_t launch_decoder_embed(const int* labels, int ld_labels, const bf16_t* shared, float* out, int B, int T, int D,
                                 int vocab, hipStream_t s, int pos0 = 0);
 hipError_t launch_rope(bf16_t* x, const float* cs, const float* sn, int B, int H, int S, int hd, int half, hipStream_t s);
+// q [B, Hq, S, hd] and k [B, Hk, S, hd] in one launch (16-byte accesses when half % 8 == 0; otherwise two launch_rope calls)
+hipError_t launch_rope_qk(bf16_t* q, bf16_t* k, const float* cs, const float* sn, int B, int Hq, int Hk, int S, int hd, int half,
+                          hipStream_t s);
 hipError_t launch_rowss_to_rs(const float* rowss, int parts, int M, float invd, float eps, float* rs, hipStream_t s);
 hipError_t launch_reduce_slices(const float* part, int nslices, size_t n, bf16_t* out, hipStream_t s);
 // argmax of logits row (b*T + T-1) -> tokens[b, dst_col] (dst_col < 0: T-1)

@@ -36,6 +36,11 @@ struct vqs_qwen_handle {
     std::string err;
     std::unordered_map<std::string, WEnt> w;
     bool bound = false;
+    // tower heads narrower than 128 lanes whose q | k | v ranges are whole 128-column blocks (7B: 16 x 80): the qkv product keeps its
+    // 3 x hidden columns (the GEMM scatters every head into the first v_hd lanes of a 128-lane slot, the other lanes are zeroed once
+    // per call), attention writes its output compact and proj contracts over hidden -- 37.5 % fewer flops in both GEMMs at 80 lanes.
+    // Otherwise weights are packed with every head padded to 128 rows / columns.
+    bool v_compact = false;
     int v_hd = 0, t_hd = 0, v_kpatch = 0, v_mlp_p = 0, v_ffld = 0, t_mlp_p = 0, t_ffld = 0, t_iq = 0, t_ikv = 0, merge_hidden = 0;
     // host copies of the packing maps (must outlive the async uploads)
     std::vector<int> m_vheads, m_theads, m_tkv, m_vgate, m_tgate;
@@ -132,7 +137,7 @@ struct GCall {
     void* C;
     const bf16_t* bias = nullptr;
     int M = 0, N = 0, K = 0, lda = 0, ldw = 0, ldc = 0, epi = 0;
-    int S = 0, H = 0, inner = 0, hd = 0, inner_kv = 0, Hkv = 0, gate_act = 0;
+    int S = 0, H = 0, inner = 0, hd = 0, inner_kv = 0, Hkv = 0, gate_act = 0, hd_src = 0;
     bf16_t* heads[3] = {nullptr, nullptr, nullptr};
 };
 
@@ -142,7 +147,7 @@ int qgemm(vqs_qwen_handle* h, const GCall& g, hipStream_t st, const char* what) 
     p.M = g.M; p.N = g.N; p.K = g.K; p.lda = g.lda; p.ldw = g.ldw; p.ldc = g.ldc;
     p.S = g.S > 0 ? g.S : 1; p.H = g.H; p.inner = g.inner > 0 ? g.inner : 1;
     p.heads_out[0] = g.heads[0]; p.heads_out[1] = g.heads[1]; p.heads_out[2] = g.heads[2];
-    p.hd = g.hd; p.inner_kv = g.inner_kv; p.Hkv = g.Hkv; p.gate_act = g.gate_act;
+    p.hd = g.hd; p.inner_kv = g.inner_kv; p.Hkv = g.Hkv; p.gate_act = g.gate_act; p.hd_src = g.hd_src;
     if (h->prof) {
         while (h->ev.size() < h->ev_used + 2) {
             hipEvent_t e;
@@ -201,9 +206,10 @@ int pack(vqs_qwen_handle* h, char* base, size_t* total, hipStream_t st) {
     }
     for (int i = 0; i < c.v_depth; ++i) {
         const std::string p = "model.visual.blocks." + std::to_string(i) + ".";
-        bf16_t* qkv = cv.take<bf16_t>((size_t)3 * VPK * VH);
-        bf16_t* qkvb = cv.take<bf16_t>((size_t)3 * VPK);
-        bf16_t* proj = cv.take<bf16_t>((size_t)VH * VPK);
+        const bool cp = h->v_compact;            // compact heads: the checkpoint's qkv / proj tensors are used where they lie
+        bf16_t* qkv = cp ? nullptr : cv.take<bf16_t>((size_t)3 * VPK * VH);
+        bf16_t* qkvb = cp ? nullptr : cv.take<bf16_t>((size_t)3 * VPK);
+        bf16_t* proj = cp ? nullptr : cv.take<bf16_t>((size_t)VH * VPK);
         bf16_t* gu = cv.take<bf16_t>((size_t)2 * h->v_mlp_p * VH);
         bf16_t* gub = cv.take<bf16_t>((size_t)2 * h->v_mlp_p);
         bf16_t* down = cv.take<bf16_t>((size_t)VH * h->v_ffld);
@@ -216,13 +222,14 @@ int pack(vqs_qwen_handle* h, char* base, size_t* total, hipStream_t st) {
         QW(wu, p + "mlp.up_proj.weight", (int64_t)c.v_mlp * VH);
         QW(bu, p + "mlp.up_proj.bias", c.v_mlp);
         QW(wd, p + "mlp.down_proj.weight", (int64_t)VH * c.v_mlp);
-        for (int which = 0; which < 3; ++which) {   // q | k | v row ranges, every head padded to 128 rows
+        for (int which = 0; which < 3 && !cp; ++which) {   // q | k | v row ranges, every head padded to 128 rows
             QHIP(h, vqs::launch_gather_rows_bf16(wqkv + (size_t)which * VH * VH, nullptr, h->d_vheads, qkv + (size_t)which * VPK * VH,
                                                   VPK, VH, VH, VH, st), "pack vision qkv");
             QHIP(h, vqs::launch_gather_rows_bf16(bqkv + (size_t)which * VH, nullptr, h->d_vheads, qkvb + (size_t)which * VPK, VPK, 1, 1, 1, st),
                  "pack vision qkv bias");
         }
-        QHIP(h, vqs::launch_gather_cols_bf16(wproj, h->d_vheads, proj, VH, VH, VPK, st), "pack vision proj");
+        if (!cp) QHIP(h, vqs::launch_gather_cols_bf16(wproj, h->d_vheads, proj, VH, VH, VPK, st), "pack vision proj");
+        if (cp) { qkv = const_cast<bf16_t*>(wqkv); qkvb = const_cast<bf16_t*>(bqkv); proj = const_cast<bf16_t*>(wproj); }
         QHIP(h, vqs::launch_gather_rows_bf16(wg, wu, h->d_vgate, gu, 2 * h->v_mlp_p, VH, VH, VH, st), "pack vision gate|up");
         QHIP(h, vqs::launch_gather_rows_bf16(bg, bu, h->d_vgate, gub, 2 * h->v_mlp_p, 1, 1, 1, st), "pack vision gate|up bias");
         QHIP(h, vqs::launch_gather_rows_bf16(wd, nullptr, nullptr, down, VH, c.v_mlp, c.v_mlp, h->v_ffld, st), "pack vision down");
@@ -345,6 +352,7 @@ int vqs_qwen_create(const vqs_qwen_config* cfg, vqs_qwen_handle** out) {
     h->t_iq = c.t_heads * HDP;
     h->t_ikv = c.t_kv_heads * HDP;
     h->merge_hidden = c.v_hidden * c.v_merge_unit;
+    h->v_compact = h->v_hd < HDP && (h->v_hd % 8) == 0 && (c.v_hidden % 128) == 0;
     h->m_vheads = head_pad_map(c.v_heads, h->v_hd);
     h->m_theads = head_pad_map(c.t_heads, h->t_hd);
     h->m_tkv = head_pad_map(c.t_kv_heads, h->t_hd);
@@ -474,6 +482,10 @@ int vqs_qwen_encode_vision(vqs_qwen_handle* h, const void* d_patches, int32_t N,
     QTAP("vis", -1, "pre", w.pre, (size_t)N * VH);
     QHIP(h, vqs::launch_gather_rows_f32(w.pre, d_row_map, w.hidden, Np, VH, st), "window permutation");
     QHIP(h, hipMemsetAsync(w.ff, 0, (size_t)Np * h->v_ffld * sizeof(bf16_t), st), "clear ff padding");
+    const bool cp = h->v_compact;
+    const int VAK = cp ? VH : VPK;       // width of the attention output = K of the proj GEMM
+    if (cp)   // lanes [v_hd, 128) of every head slot: written by nobody, read by the attention kernel (q | k | v are contiguous)
+        QHIP(h, hipMemsetAsync(w.q, 0, (size_t)((char*)w.attn - (char*)w.q), st), "clear head padding");
 
     const bf16_t* pend = nullptr;
     const bf16_t* pend_attn = nullptr;   // attention delta the fp32 stream has not absorbed yet
@@ -501,28 +513,27 @@ int vqs_qwen_encode_vision(vqs_qwen_handle* h, const void* d_patches, int32_t N,
         {
             GCall g{xin, h->v_qkv_w[i], nullptr};
             g.bias = h->v_qkv_b[i];
-            g.M = rows; g.N = 3 * VPK; g.K = VH; g.lda = VH; g.ldw = VH; g.epi = vqs::EPI_HEADS;
-            g.S = S; g.H = VNH; g.inner = VPK; g.hd = HDP;
+            g.M = rows; g.N = cp ? 3 * VH : 3 * VPK; g.K = VH; g.lda = VH; g.ldw = VH; g.epi = vqs::EPI_HEADS;
+            g.S = S; g.H = VNH; g.inner = cp ? VH : VPK; g.hd = HDP; g.hd_src = cp ? h->v_hd : 0;
             g.heads[0] = w.q; g.heads[1] = w.k; g.heads[2] = w.v;
             QRUN(qgemm(h, g, st, "vision qkv"));
         }
         QTAP("vis", i, "q0", w.q, (size_t)rows * VPK);           // projection output, before the rotary embedding
         QTAP("vis", i, "k0", w.k, (size_t)rows * VPK);
-        QHIP(h, vqs::launch_rope(w.q, full ? d_cos_f : d_cos_w, full ? d_sin_f : d_sin_w, Bseg, VNH, S, HDP, h->v_hd / 2, st), "vision rope q");
-        QHIP(h, vqs::launch_rope(w.k, full ? d_cos_f : d_cos_w, full ? d_sin_f : d_sin_w, Bseg, VNH, S, HDP, h->v_hd / 2, st), "vision rope k");
+        QHIP(h, vqs::launch_rope_qk(w.q, w.k, full ? d_cos_f : d_cos_w, full ? d_sin_f : d_sin_w, Bseg, VNH, VNH, S, HDP, h->v_hd / 2, st), "vision rope");
         QTAP("vis", i, "q", w.q, (size_t)rows * VPK);            // after the rotary embedding, head-major [Bseg, heads, S, 128]
         QTAP("vis", i, "k", w.k, (size_t)rows * VPK);
         QTAP("vis", i, "v", w.v, (size_t)rows * VPK);
         {
             vqs::AttnParams a{w.q, w.k, w.v, w.attn, nullptr, full ? nullptr : d_win_valid, Bseg, VNH, S, scale};
-            a.hd = HDP;
+            a.hd = HDP; a.out_hd = cp ? h->v_hd : 0;
             QHIP(h, vqs::launch_attention(a, st), "vision attention");
         }
-        QTAP("vis", i, "attn", w.attn, (size_t)rows * VPK);
+        QTAP("vis", i, "attn", w.attn, (size_t)rows * VAK);
         {
             GCall g{w.attn, h->v_proj_w[i], full ? (void*)w.dc : (void*)w.delta};
             g.bias = pb;
-            g.M = rows; g.N = VH; g.K = VPK; g.lda = VPK; g.ldw = VPK; g.ldc = VH; g.epi = vqs::EPI_BF16;
+            g.M = rows; g.N = VH; g.K = VAK; g.lda = VAK; g.ldw = VAK; g.ldc = VH; g.epi = vqs::EPI_BF16;
             QRUN(qgemm(h, g, st, "vision proj"));
         }
         if (full)
@@ -622,8 +633,7 @@ int vqs_qwen_score(vqs_qwen_handle* h, const void* d_merged, const int32_t* d_in
         }
         QTAP("txt", i, "q0", w.q, (size_t)M * IQ);                // projection output, before the rotary embedding
         QTAP("txt", i, "k0", w.k, (size_t)M * IKV);
-        QHIP(h, vqs::launch_rope(w.q, d_cos, d_sin, B, c.t_heads, L, HDP, h->t_hd / 2, st), "rope q");
-        QHIP(h, vqs::launch_rope(w.k, d_cos, d_sin, B, c.t_kv_heads, L, HDP, h->t_hd / 2, st), "rope k");
+        QHIP(h, vqs::launch_rope_qk(w.q, w.k, d_cos, d_sin, B, c.t_heads, c.t_kv_heads, L, HDP, h->t_hd / 2, st), "rope");
         QTAP("txt", i, "q", w.q, (size_t)M * IQ);                 // after the rotary embedding, head-major [B, heads, L, 128]
         QTAP("txt", i, "k", w.k, (size_t)M * IKV);
         QTAP("txt", i, "v", w.v, (size_t)M * IKV);

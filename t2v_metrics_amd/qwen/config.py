@@ -79,7 +79,13 @@ QWEN_SMALL = Qwen25VLConfig(
     text=QwenTextConfig(vocab=1024, hidden=256, layers=3, heads=2, kv_heads=1, mlp=384, mrope_section=(16, 24, 24)),
     image_token_id=4, video_token_id=5, vision_start_token_id=6, vision_end_token_id=7,
 )
-_CONFIGS = {c.name: c for c in (QWEN25_VL_7B, QWEN_TINY, QWEN_SMALL)}
+QWEN_SMALL_C80 = Qwen25VLConfig(
+    name="qwen-small-c80",          # the 7B tower's head geometry in small: 80-wide heads whose q | k | v ranges are whole 128-column blocks
+    vision=QwenVisionConfig(depth=4, hidden=640, heads=8, mlp=712, window=112, fullatt_blocks=(1, 3), out_hidden=256),
+    text=QwenTextConfig(vocab=1024, hidden=256, layers=2, heads=2, kv_heads=1, mlp=384, mrope_section=(16, 24, 24)),
+    image_token_id=4, video_token_id=5, vision_start_token_id=6, vision_end_token_id=7,
+)
+_CONFIGS = {c.name: c for c in (QWEN25_VL_7B, QWEN_TINY, QWEN_SMALL, QWEN_SMALL_C80)}
 
 
 def get_qwen_config(name: str) -> Qwen25VLConfig:

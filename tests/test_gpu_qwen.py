@@ -11,9 +11,29 @@ from t2v_metrics_amd.qwen.weights import make_seeded_qwen_weights
 
 pytestmark = pytest.mark.gpu
 
-# bf16 operands against fp32 arithmetic: same criterion as the CLIP-FlanT5 row: |d log P(answer)| within the
-# bf16 noise floor measured there
+# End-to-end criterion of the CLIP-FlanT5 row (tests/test_gpu_fullsize.py): the engine differs from fp32 arithmetic by
+# the bf16 operand noise of the pass.  That floor is MEASURED per case by the rounding-matched oracle run free on the host (same
+# roundings, different summation order): |d log P| of the engine against the fp32 oracle must stay within max(2.5e-2, 3 x that floor),
+# never above the absolute ceiling 5e-2 -- while the kernel arithmetic itself is held to <= 1 bf16 ulp per launch by the stage-locked
+# tests below.
 LOGPROB_TOL_BF16 = 2.5e-2
+LOGPROB_CEILING = 5e-2
+
+
+def _calibrated_bound(cfg, w, grids, ids, mask, px, ref_lp, toks):
+    """max(2.5e-2, 3 x |free-running rounding-matched oracle - fp32 oracle|) capped at the ceiling, over the tokens `toks` [B, k]."""
+    from oracle.qwen25vl_engine_rounding import QwenEngineRounded
+    from t2v_metrics_amd.qwen.layout import text_layout, vision_layout
+    emu = QwenEngineRounded(cfg, {k: v.cpu() for k, v in w.items()})
+    with torch.no_grad():
+        merged, off = [], 0
+        for g in grids:
+            n = g[0] * g[1] * g[2]
+            merged.append(emu.vision_tower(px[off: off + n].to(torch.bfloat16).float(), vision_layout(cfg, [g])))
+            off += n
+        lp = torch.log_softmax(emu.text_logits(torch.cat(merged), ids, text_layout(cfg, ids, mask, grids)), -1)
+    floor = (lp.gather(-1, toks) - ref_lp.gather(-1, toks)).abs().max().item()
+    return min(max(LOGPROB_TOL_BF16, 3.0 * floor), LOGPROB_CEILING), floor
 
 
 @pytest.mark.parametrize("name,fixture", [("qwen-tiny", "qwen_tiny"), ("qwen-small", "qwen_small"), ("qwen-tiny", "qwen_tiny_ragged")])
@@ -36,23 +56,59 @@ def test_qwen_path_matches_hf_fixture(golden_dir, name, fixture):
     merged = torch.cat(merged)
     torch.cuda.synchronize()
     ref_merged = torch.from_numpy(z["merged"])
+    # merged vision tokens: 4-8 blocks of bf16 operand noise on an fp32 reference (per launch they are held to 1 ulp, below)
     err = (merged.float().cpu() - ref_merged).abs().max().item()
-    assert err <= 0.06 * max(1.0, ref_merged.abs().max().item()), f"merged vision tokens off by {err}"
+    assert err <= 2.0 ** -5 * max(1.0, ref_merged.abs().max().item()), f"merged vision tokens off by {err}"
     # language model: batched, right-padded
     logits = eng.score_logits(merged, ids, mask, grids).float().cpu()
     ref_logits = torch.from_numpy(z["logits"])
     lp, ref_lp = torch.log_softmax(logits, -1), torch.log_softmax(ref_logits, -1)
-    top = ref_lp.argmax(-1)
-    for b in range(ids.shape[0]):
-        # the answer ids the reference would look at: compare the log-probabilities of the 5 most likely tokens
-        for tok in ref_lp[b].topk(5).indices.tolist():
-            assert abs(lp[b, tok].item() - ref_lp[b, tok].item()) <= 4 * LOGPROB_TOL_BF16, (b, tok, lp[b, tok].item(), ref_lp[b, tok].item())
-    assert (lp.gather(-1, top[:, None]) - ref_lp.gather(-1, top[:, None])).abs().max().item() <= 2 * LOGPROB_TOL_BF16
-    # oracle agrees with the fixture (pinned on the CPU suite) -- here: the HIP path agrees with the oracle on a fresh batch
-    o = QwenOracle(cfg, w)
-    o_logits = o.forward(ids, mask, px, grids)
-    d = (torch.log_softmax(o_logits, -1) - lp).gather(-1, top[:, None]).abs().max().item()
-    assert d <= 2 * LOGPROB_TOL_BF16
+    # the answer ids the reference would look at: the log-probabilities of the 5 most likely tokens of every sample, against the HF
+    # fixture and against the fp32 oracle, within the calibrated bf16 floor of this case
+    top5 = ref_lp.topk(5).indices
+    bound, floor = _calibrated_bound(cfg, w, grids, ids, mask, px, ref_lp, top5)
+    d_fix = (lp.gather(-1, top5) - ref_lp.gather(-1, top5)).abs().max().item()
+    o_lp = torch.log_softmax(QwenOracle(cfg, w).forward(ids, mask, px, grids), -1)
+    d_orc = (lp.gather(-1, top5) - o_lp.gather(-1, top5)).abs().max().item()
+    _record({"case": f"qwen/{fixture}", "max_abs_dlogp_top5_vs_hf_fixture": d_fix, "max_abs_dlogp_top5_vs_fp32_oracle": d_orc,
+             "bf16_floor_rounding_matched_vs_fp32": floor, "bound": bound})
+    assert d_fix <= bound and d_orc <= bound, (d_fix, d_orc, bound, floor)
+    eng.close()
+
+
+def _record(row):
+    import json
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_e2e.jsonl"), "a") as f:
+        f.write(json.dumps(row) + "\n")
+
+
+def test_qwen_compact_tower_heads_stage_locked_and_end_to_end():
+    """The 7B tower's head geometry at a size the host oracle finishes in seconds (qwen-small-c80: 8 heads x 80 lanes = 5 whole
+    128-column blocks): the qkv product keeps 3 x hidden columns and scatters every head into a 128-lane slot, attention writes its
+    output compact, proj contracts over hidden.  Every launch stage-locked, and the pass against the fp32 oracle."""
+    from oracle.qwen25vl_oracle import QwenOracle
+    from t2v_metrics_amd.qwen.engine import QwenEngine
+    from tests.test_qwen_rounding_oracle import C80_GRIDS, synthetic_case
+    cfg, w, grids, ids, mask, px = synthetic_case("qwen-small-c80", C80_GRIDS)
+    eng = QwenEngine(cfg, w)
+    pxb = px.to(torch.bfloat16)
+    merged, off = [], 0
+    for vi, g in enumerate(grids):
+        n = g[0] * g[1] * g[2]
+        _stage_locked(f"qwen/small-c80/video{vi}", cfg, w, eng, pxb[off: off + n].cuda(), g, None, None, None)
+        merged.append(eng.encode_vision(pxb[off: off + n].cuda(), [g]))
+        off += n
+    merged = torch.cat(merged)
+    _stage_locked("qwen/small-c80/prefill", cfg, w, eng, None, None, ids, mask, grids, merged=merged)
+    lp = torch.log_softmax(eng.score_logits(merged, ids, mask, grids).float().cpu(), -1)
+    ref_lp = torch.log_softmax(QwenOracle(cfg, w).forward(ids, mask, px, grids), -1)
+    top5 = ref_lp.topk(5).indices
+    bound, floor = _calibrated_bound(cfg, w, grids, ids, mask, px, ref_lp, top5)
+    d = (lp.gather(-1, top5) - ref_lp.gather(-1, top5)).abs().max().item()
+    _record({"case": "qwen/small-c80", "max_abs_dlogp_top5_vs_fp32_oracle": d, "bf16_floor_rounding_matched_vs_fp32": floor, "bound": bound})
+    assert d <= bound, (d, bound, floor)
     eng.close()
 
 

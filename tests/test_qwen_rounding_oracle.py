@@ -23,6 +23,28 @@ def _case(golden_dir, name, fixture):
     return cfg, w, grids, torch.from_numpy(z["input_ids"]), torch.from_numpy(z["attention_mask"]), torch.from_numpy(z["pixel_values"])
 
 
+def synthetic_case(name, grids, seed=5, n_text=(6, 9), gain=4.0):
+    """A seeded batch for a configuration without an HF fixture (one video per sample, right-padded ids)."""
+    cfg = get_qwen_config(name)
+    w = make_seeded_qwen_weights(cfg, seed=seed, dtype=torch.bfloat16, lm_head_gain=gain)
+    g = torch.Generator().manual_seed(seed)
+    px = torch.randn(sum(a * b * c for a, b, c in grids), cfg.vision.patch_dim, generator=g).to(torch.bfloat16).float()
+    rows = []
+    for i, gr in enumerate(grids):
+        n_merged = gr[0] * gr[1] * gr[2] // cfg.vision.merge_unit
+        pre = torch.randint(10, cfg.text.vocab, (n_text[0] + i,), generator=g)
+        post = torch.randint(10, cfg.text.vocab, (n_text[1] + 2 * i,), generator=g)
+        rows.append(torch.cat([pre, torch.tensor([cfg.vision_start_token_id]), torch.full((n_merged,), cfg.video_token_id),
+                               torch.tensor([cfg.vision_end_token_id]), post]))
+    L = max(len(r) for r in rows)
+    ids = torch.stack([torch.nn.functional.pad(r, (0, L - len(r))) for r in rows])
+    mask = torch.stack([torch.nn.functional.pad(torch.ones(len(r), dtype=torch.long), (0, L - len(r))) for r in rows])
+    return cfg, w, list(grids), ids, mask, px
+
+
+C80_GRIDS = [(2, 12, 20), (2, 16, 16)]        # partial windows in the first, whole ones in the second
+
+
 def _run(o, cfg, grids, ids, mask, px, record=None):
     merged, off = [], 0
     for g in grids:
@@ -36,6 +58,18 @@ def _run(o, cfg, grids, ids, mask, px, record=None):
 @pytest.mark.parametrize("name,fixture", [("qwen-tiny", "qwen_tiny"), ("qwen-small", "qwen_small"), ("qwen-tiny", "qwen_tiny_ragged")])
 def test_roundings_off_reproduces_the_fp32_oracle(golden_dir, name, fixture):
     cfg, w, grids, ids, mask, px = _case(golden_dir, name, fixture)
+    with torch.no_grad():
+        merged, logits = _run(QwenEngineRounded(cfg, w, round_fn=_identity), cfg, grids, ids, mask, px)
+    ref = QwenOracle(cfg, w).forward(ids, mask, px, grids, return_stages=True)
+    assert (merged - ref["merged"]).abs().max().item() <= 2e-5 * max(1.0, ref["merged"].abs().max().item())
+    assert (logits - ref["logits"]).abs().max().item() <= 5e-5 * max(1.0, ref["logits"].abs().max().item())
+
+
+def test_roundings_off_reproduces_the_fp32_oracle_compact_heads():
+    """The 7B tower's head geometry (80-lane heads kept compact in the qkv product and the attention output)."""
+    from oracle.qwen25vl_engine_rounding import vision_heads_compact
+    cfg, w, grids, ids, mask, px = synthetic_case("qwen-small-c80", C80_GRIDS)
+    assert vision_heads_compact(cfg) and vision_heads_compact(get_qwen_config("qwen2.5-vl-7b")) and not vision_heads_compact(get_qwen_config("qwen-small"))
     with torch.no_grad():
         merged, logits = _run(QwenEngineRounded(cfg, w, round_fn=_identity), cfg, grids, ids, mask, px)
     ref = QwenOracle(cfg, w).forward(ids, mask, px, grids, return_stages=True)
