@@ -83,6 +83,11 @@ int vqs_qwen_score(vqs_qwen_handle* h, const void* d_merged, const int32_t* d_in
  * tests/test_gpu_qwen.py checks every launch of a pass against the rounding-matched oracle through it. */
 int vqs_qwen_debug_tap(vqs_qwen_handle* h, const char* name, void* d_dst, size_t bytes);
 
+/* Test hook: "x_pitch" = row pitch (elements, a multiple of 64, >= hidden) of the language model's normalised activations and packed
+ * gate|up weight rows; the library's choice is hidden for hidden <= 2048 and the next power of two >= 4096 above that.
+ * Must be called before vqs_qwen_bind_weights.  Results do not depend on it. */
+int vqs_qwen_debug_option(vqs_qwen_handle* h, const char* name, int64_t value);
+
 #ifdef __cplusplus
 }
 #endif

@@ -77,7 +77,7 @@ template <int NV, int KIND, int ADD, bool OUT_F32>
 __global__ void __launch_bounds__(256) norm_rows_reg_kernel(float* __restrict__ x, const bf16_t* __restrict__ delta,
                                                             const bf16_t* __restrict__ delta2,
                                                             const bf16_t* __restrict__ w, const bf16_t* __restrict__ bsh,
-                                                            void* __restrict__ out, int M, float eps) {
+                                                            void* __restrict__ out, int M, float eps, int out_ld) {
     constexpr int D = NV * 256;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -137,12 +137,12 @@ __global__ void __launch_bounds__(256) norm_rows_reg_kernel(float* __restrict__ 
         const float o0 = (v[j].x - mu) * rs * wv.x + bv.x, o1 = (v[j].y - mu) * rs * wv.y + bv.y;
         const float o2 = (v[j].z - mu) * rs * wv.z + bv.z, o3 = (v[j].w - mu) * rs * wv.w + bv.w;
         if (OUT_F32) {
-            reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)row * D)[i] = make_float4(o0, o1, o2, o3);
+            reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)row * out_ld)[i] = make_float4(o0, o1, o2, o3);
         } else {
             uint2 o;
             o.x = e_pack2_hw(o0, o1);
             o.y = e_pack2_hw(o2, o3);
-            reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(out) + (size_t)row * D)[i] = o;
+            reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(out) + (size_t)row * out_ld)[i] = o;
         }
     }
 }
@@ -152,7 +152,7 @@ template <int KIND, int ADD, bool OUT_F32>
 __global__ void __launch_bounds__(256) norm_rows_loop_kernel(float* __restrict__ x, const bf16_t* __restrict__ delta,
                                                              const bf16_t* __restrict__ delta2,
                                                              const bf16_t* __restrict__ w, const bf16_t* __restrict__ bsh,
-                                                             void* __restrict__ out, int M, int D, float eps) {
+                                                             void* __restrict__ out, int M, int D, float eps, int out_ld) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= M) return;
@@ -207,32 +207,35 @@ __global__ void __launch_bounds__(256) norm_rows_loop_kernel(float* __restrict__
         const float o0 = (v.x - mu) * rs * wv.x + bv.x, o1 = (v.y - mu) * rs * wv.y + bv.y;
         const float o2 = (v.z - mu) * rs * wv.z + bv.z, o3 = (v.w - mu) * rs * wv.w + bv.w;
         if (OUT_F32) {
-            reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)row * D)[i] = make_float4(o0, o1, o2, o3);
+            reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)row * out_ld)[i] = make_float4(o0, o1, o2, o3);
         } else {
             uint2 o;
             o.x = e_pack2_hw(o0, o1);
             o.y = e_pack2_hw(o2, o3);
-            reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(out) + (size_t)row * D)[i] = o;
+            reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(out) + (size_t)row * out_ld)[i] = o;
         }
     }
 }
 
+// out_ld: row pitch of `out` in elements (0 = D; a multiple of 4).  The stream x and the deltas are always dense.
 template <int KIND, int ADD, bool OUT_F32>
 static hipError_t launch_norm_t(float* x, const bf16_t* delta, const bf16_t* delta2, const bf16_t* w, const bf16_t* b, void* out,
-                                int M, int D, float eps, hipStream_t s) {
+                                int M, int D, float eps, hipStream_t s, int out_ld = 0) {
     const dim3 grid((M + 3) / 4), block(256);
+    if (out_ld <= 0) out_ld = D;
+    if (out_ld < D || (out_ld & 3)) return hipErrorInvalidValue;
     if (D == 1024)
-        hipLaunchKernelGGL((norm_rows_reg_kernel<4, KIND, ADD, OUT_F32>), grid, block, 0, s, x, delta, delta2, w, b, out, M, eps);
+        hipLaunchKernelGGL((norm_rows_reg_kernel<4, KIND, ADD, OUT_F32>), grid, block, 0, s, x, delta, delta2, w, b, out, M, eps, out_ld);
     else if (D == 2048)
-        hipLaunchKernelGGL((norm_rows_reg_kernel<8, KIND, ADD, OUT_F32>), grid, block, 0, s, x, delta, delta2, w, b, out, M, eps);
+        hipLaunchKernelGGL((norm_rows_reg_kernel<8, KIND, ADD, OUT_F32>), grid, block, 0, s, x, delta, delta2, w, b, out, M, eps, out_ld);
     else if (D == 4096)
-        hipLaunchKernelGGL((norm_rows_reg_kernel<16, KIND, ADD, OUT_F32>), grid, block, 0, s, x, delta, delta2, w, b, out, M, eps);
+        hipLaunchKernelGGL((norm_rows_reg_kernel<16, KIND, ADD, OUT_F32>), grid, block, 0, s, x, delta, delta2, w, b, out, M, eps, out_ld);
     else if (D == 1280)     // Qwen2.5-VL vision tower
-        hipLaunchKernelGGL((norm_rows_reg_kernel<5, KIND, ADD, OUT_F32>), grid, block, 0, s, x, delta, delta2, w, b, out, M, eps);
+        hipLaunchKernelGGL((norm_rows_reg_kernel<5, KIND, ADD, OUT_F32>), grid, block, 0, s, x, delta, delta2, w, b, out, M, eps, out_ld);
     else if (D == 3584)     // Qwen2.5-VL-7B language model
-        hipLaunchKernelGGL((norm_rows_reg_kernel<14, KIND, ADD, OUT_F32>), grid, block, 0, s, x, delta, delta2, w, b, out, M, eps);
+        hipLaunchKernelGGL((norm_rows_reg_kernel<14, KIND, ADD, OUT_F32>), grid, block, 0, s, x, delta, delta2, w, b, out, M, eps, out_ld);
     else
-        hipLaunchKernelGGL((norm_rows_loop_kernel<KIND, ADD, OUT_F32>), grid, block, 0, s, x, delta, delta2, w, b, out, M, D, eps);
+        hipLaunchKernelGGL((norm_rows_loop_kernel<KIND, ADD, OUT_F32>), grid, block, 0, s, x, delta, delta2, w, b, out, M, D, eps, out_ld);
     return hipGetLastError();
 }
 
@@ -244,13 +247,13 @@ static int norm_add_mode(const bf16_t* delta, const bf16_t* delta2, bool store_x
 }
 
 hipError_t launch_rmsnorm(float* x, const bf16_t* delta, const bf16_t* w, bf16_t* out, int M, int D, float eps,
-                          hipStream_t s, const bf16_t* delta2, bool store_x) {
+                          hipStream_t s, const bf16_t* delta2, bool store_x, int out_ld) {
     if (D % 4) return hipErrorInvalidValue;
     switch (norm_add_mode(delta, delta2, store_x)) {
-        case 0: return launch_norm_t<0, 0, false>(x, delta, delta2, w, nullptr, out, M, D, eps, s);
-        case 1: return launch_norm_t<0, 1, false>(x, delta, delta2, w, nullptr, out, M, D, eps, s);
-        case 2: return launch_norm_t<0, 2, false>(x, delta, delta2, w, nullptr, out, M, D, eps, s);
-        case 3: return launch_norm_t<0, 3, false>(x, delta, delta2, w, nullptr, out, M, D, eps, s);
+        case 0: return launch_norm_t<0, 0, false>(x, delta, delta2, w, nullptr, out, M, D, eps, s, out_ld);
+        case 1: return launch_norm_t<0, 1, false>(x, delta, delta2, w, nullptr, out, M, D, eps, s, out_ld);
+        case 2: return launch_norm_t<0, 2, false>(x, delta, delta2, w, nullptr, out, M, D, eps, s, out_ld);
+        case 3: return launch_norm_t<0, 3, false>(x, delta, delta2, w, nullptr, out, M, D, eps, s, out_ld);
         default: return hipErrorInvalidValue;
     }
 }

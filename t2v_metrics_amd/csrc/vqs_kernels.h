@@ -205,7 +205,7 @@ hipError_t launch_decoder_attention(const DecAttnParams& p, hipStream_t stream);
 // delta2 / store_x select the deferred-store forms (elementwise.hip): (delta, store_x=false) normalises x + delta without
 // writing the stream; (delta, delta2) stores x = (x + delta) + delta2.
 hipError_t launch_rmsnorm(float* x, const bf16_t* delta, const bf16_t* w, bf16_t* out, int M, int D, float eps,
-                          hipStream_t s, const bf16_t* delta2 = nullptr, bool store_x = true);
+                          hipStream_t s, const bf16_t* delta2 = nullptr, bool store_x = true, int out_ld = 0);   // out_ld: row pitch of out (0 = D)
 hipError_t launch_layernorm(float* x, const bf16_t* delta, const bf16_t* w, const bf16_t* b, void* out, int out_f32, int M,
                             int D, float eps, hipStream_t s, const bf16_t* delta2 = nullptr, bool store_x = true);
 // pixels bf16 [N,3,IMG,IMG] -> rows [N*G*G, Kpad] in (c,ky,kx) order, zero padded

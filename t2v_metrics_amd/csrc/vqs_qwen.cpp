@@ -41,6 +41,11 @@ struct vqs_qwen_handle {
     // per call), attention writes its output compact and proj contracts over hidden -- 37.5 % fewer flops in both GEMMs at 80 lanes.
     // Otherwise weights are packed with every head padded to 128 rows / columns.
     bool v_compact = false;
+    // Row pitch (elements) of the language model's normalised activations and of its packed gate|up weight rows.  Measured
+    // (profiles/r3_call28_qwen_gemm_pitch.jsonl): the 51712 x 37888 x 3584 gate|up GEMM runs at 1.25 PFLOP/s with both operands at
+    // their natural 7 KiB pitch and at 1.37 with 8 KiB rows; the other launches do not care.  Rows of 2^k bytes once the hidden
+    // size is past 4 KiB; vqs_qwen_debug_option("x_pitch") overrides it before the weights are bound (tests at small sizes).
+    int t_xld = 0;
     int v_hd = 0, t_hd = 0, v_kpatch = 0, v_mlp_p = 0, v_ffld = 0, t_mlp_p = 0, t_ffld = 0, t_iq = 0, t_ikv = 0, merge_hidden = 0;
     // host copies of the packing maps (must outlive the async uploads)
     std::vector<int> m_vheads, m_theads, m_tkv, m_vgate, m_tgate;
@@ -87,6 +92,19 @@ int qtap(vqs_qwen_handle* h, const char* stack, int layer, const char* what, con
     if (it == h->taps.end()) return VQS_OK;
     if (it->second.cap < bytes) return qfail(h, VQS_ERR_WORKSPACE, "tap " + name + ": buffer too small (" + std::to_string(bytes) + " bytes needed)");
     QHIP(h, hipMemcpyAsync(it->second.dst, src, bytes, hipMemcpyDeviceToDevice, st), "tap copy");
+    return VQS_OK;
+}
+// the same for a tensor whose rows sit at a pitch: the tap receives the dense [rows, width] tensor
+int qtap2d(vqs_qwen_handle* h, const char* stack, int layer, const char* what, const bf16_t* src, int width, int rows, int pitch, hipStream_t st) {
+    if (h->taps.empty()) return VQS_OK;
+    if (pitch == width) return qtap(h, stack, layer, what, src, (size_t)rows * width * sizeof(bf16_t), st);
+    const std::string name = layer >= 0 ? std::string(stack) + "." + std::to_string(layer) + "." + what : std::string(stack) + "." + what;
+    auto it = h->taps.find(name);
+    if (it == h->taps.end()) return VQS_OK;
+    const size_t bytes = (size_t)rows * width * sizeof(bf16_t);
+    if (it->second.cap < bytes) return qfail(h, VQS_ERR_WORKSPACE, "tap " + name + ": buffer too small (" + std::to_string(bytes) + " bytes needed)");
+    QHIP(h, hipMemcpy2DAsync(it->second.dst, (size_t)width * sizeof(bf16_t), src, (size_t)pitch * sizeof(bf16_t), (size_t)width * sizeof(bf16_t),
+                             (size_t)rows, hipMemcpyDeviceToDevice, st), "tap copy");
     return VQS_OK;
 }
 #define QTAP(stack, layer, what, ptr, elems) QRUN(qtap(h, stack, layer, what, ptr, (size_t)(elems) * sizeof(*(ptr)), st))
@@ -242,7 +260,7 @@ int pack(vqs_qwen_handle* h, char* base, size_t* total, hipStream_t st) {
         bf16_t* qkv = cv.take<bf16_t>((size_t)QN * TH);
         bf16_t* qkvb = cv.take<bf16_t>((size_t)QN);
         bf16_t* ow = cv.take<bf16_t>((size_t)TH * IQ);
-        bf16_t* gu = cv.take<bf16_t>((size_t)2 * h->t_mlp_p * TH);
+        bf16_t* gu = cv.take<bf16_t>((size_t)2 * h->t_mlp_p * h->t_xld);
         bf16_t* down = cv.take<bf16_t>((size_t)TH * h->t_ffld);
         if (!base) continue;
         const int64_t qn = (int64_t)c.t_heads * thd, kn = (int64_t)c.t_kv_heads * thd;
@@ -263,7 +281,7 @@ int pack(vqs_qwen_handle* h, char* base, size_t* total, hipStream_t st) {
         QHIP(h, vqs::launch_gather_rows_bf16(bk, nullptr, h->d_tkv, qkvb + IQ, IKV, 1, 1, 1, st), "pack k bias");
         QHIP(h, vqs::launch_gather_rows_bf16(bv, nullptr, h->d_tkv, qkvb + IQ + IKV, IKV, 1, 1, 1, st), "pack v bias");
         QHIP(h, vqs::launch_gather_cols_bf16(wo, h->d_theads, ow, TH, (int)qn, IQ, st), "pack o");
-        QHIP(h, vqs::launch_gather_rows_bf16(wg, wu, h->d_tgate, gu, 2 * h->t_mlp_p, TH, TH, TH, st), "pack gate|up");
+        QHIP(h, vqs::launch_gather_rows_bf16(wg, wu, h->d_tgate, gu, 2 * h->t_mlp_p, TH, TH, h->t_xld, st), "pack gate|up");
         QHIP(h, vqs::launch_gather_rows_bf16(wd, nullptr, nullptr, down, TH, c.t_mlp, c.t_mlp, h->t_ffld, st), "pack down");
         h->t_qkv_w[i] = qkv; h->t_qkv_b[i] = qkvb; h->t_o_w[i] = ow; h->t_gu_w[i] = gu; h->t_down_w[i] = down;
     }
@@ -312,7 +330,7 @@ TxtWs carve_text(const vqs_qwen_handle* h, char* base, int B, int L) {
     TxtWs w{};
     const size_t M = (size_t)B * L;
     w.hidden = cv.take<float>(M * c.t_hidden);
-    w.xn = cv.take<bf16_t>(M * c.t_hidden);
+    w.xn = cv.take<bf16_t>(M * h->t_xld);
     w.delta = cv.take<bf16_t>(M * c.t_hidden);
     w.delta2 = cv.take<bf16_t>(M * c.t_hidden);
     w.q = cv.take<bf16_t>(M * h->t_iq);
@@ -352,6 +370,12 @@ int vqs_qwen_create(const vqs_qwen_config* cfg, vqs_qwen_handle** out) {
     h->t_iq = c.t_heads * HDP;
     h->t_ikv = c.t_kv_heads * HDP;
     h->merge_hidden = c.v_hidden * c.v_merge_unit;
+    h->t_xld = c.t_hidden;
+    if (c.t_hidden > 2048) {
+        int p2 = 4096;
+        while (p2 < c.t_hidden) p2 *= 2;
+        h->t_xld = p2;
+    }
     h->v_compact = h->v_hd < HDP && (h->v_hd % 8) == 0 && (c.v_hidden % 128) == 0;
     h->m_vheads = head_pad_map(c.v_heads, h->v_hd);
     h->m_theads = head_pad_map(c.t_heads, h->t_hd);
@@ -389,6 +413,18 @@ int vqs_qwen_profile_read(vqs_qwen_handle* h, double* gemm_ms, double* gemm_flop
     const int n = (int)(h->ev_used / 2);
     if (reset) { h->ev_used = 0; h->prof_flops = 0.0; h->prof_bytes = 0.0; }
     return n;
+}
+
+int vqs_qwen_debug_option(vqs_qwen_handle* h, const char* name, int64_t value) {
+    if (!h || !name) return VQS_ERR_INVALID;
+    if (std::string(name) == "x_pitch") {        // before vqs_qwen_bind_weights: the packed gate|up rows carry the pitch
+        if (h->bound) return qfail(h, VQS_ERR_STATE, "x_pitch must be set before the weights are bound");
+        if (value < h->c.t_hidden || (value % 64) != 0 || value > 8 * (int64_t)h->c.t_hidden + 4096)
+            return qfail(h, VQS_ERR_INVALID, "x_pitch: a multiple of 64 elements, >= hidden");
+        h->t_xld = (int)value;
+        return VQS_OK;
+    }
+    return qfail(h, VQS_ERR_INVALID, std::string("unknown option ") + name);
 }
 
 int vqs_qwen_debug_tap(vqs_qwen_handle* h, const char* name, void* d_dst, size_t bytes) {
@@ -607,7 +643,7 @@ int vqs_qwen_score(vqs_qwen_handle* h, const void* d_merged, const int32_t* d_in
     const TxtWs w = carve_text(h, (char*)d_ws, B, L);
     if (ws_bytes < w.total) return qfail(h, VQS_ERR_WORKSPACE, "score: workspace too small");
     hipStream_t st = (hipStream_t)stream;
-    const int TH = c.t_hidden, M = B * L, IQ = h->t_iq, IKV = h->t_ikv;
+    const int TH = c.t_hidden, M = B * L, IQ = h->t_iq, IKV = h->t_ikv, XLD = h->t_xld;
     const float scale = 1.0f / sqrtf((float)h->t_hd);
     QW(embed, "model.language_model.embed_tokens.weight", (int64_t)c.t_vocab * TH);
     QHIP(h, vqs::launch_qwen_embed(d_input_ids, d_vis_slot, embed, (const bf16_t*)d_merged, w.hidden, M, TH, c.t_vocab, st), "embed + splice");
@@ -620,13 +656,13 @@ int vqs_qwen_score(vqs_qwen_handle* h, const void* d_merged, const int32_t* d_in
         const std::string p = "model.language_model.layers." + std::to_string(i) + ".";
         QW(ln1, p + "input_layernorm.weight", TH);
         QW(ln2, p + "post_attention_layernorm.weight", TH);
-        QHIP(h, vqs::launch_rmsnorm(w.hidden, pend_attn ? pend_attn : pend, ln1, w.xn, M, TH, c.t_eps, st, pend_attn ? pend : nullptr), "input_layernorm");
+        QHIP(h, vqs::launch_rmsnorm(w.hidden, pend_attn ? pend_attn : pend, ln1, w.xn, M, TH, c.t_eps, st, pend_attn ? pend : nullptr, true, XLD), "input_layernorm");
         QTAP("txt", i, "h", w.hidden, (size_t)M * TH);            // the fp32 stream this layer starts from (input_layernorm stored it)
-        QTAP("txt", i, "xn0", w.xn, (size_t)M * TH);
+        QRUN(qtap2d(h, "txt", i, "xn0", w.xn, TH, M, XLD, st));
         {
             GCall g{w.xn, h->t_qkv_w[i], nullptr};
             g.bias = h->t_qkv_b[i];
-            g.M = M; g.N = IQ + 2 * IKV; g.K = TH; g.lda = TH; g.ldw = TH; g.epi = vqs::EPI_HEADS;
+            g.M = M; g.N = IQ + 2 * IKV; g.K = TH; g.lda = XLD; g.ldw = TH; g.epi = vqs::EPI_HEADS;
             g.S = L; g.H = c.t_heads; g.inner = IQ; g.hd = HDP; g.inner_kv = IKV; g.Hkv = c.t_kv_heads;
             g.heads[0] = w.q; g.heads[1] = w.k; g.heads[2] = w.v;
             QRUN(qgemm(h, g, st, "qkv"));
@@ -649,12 +685,12 @@ int vqs_qwen_score(vqs_qwen_handle* h, const void* d_merged, const int32_t* d_in
             QRUN(qgemm(h, g, st, "o_proj"));
         }
         QTAP("txt", i, "d_attn", w.delta, (size_t)M * TH);
-        QHIP(h, vqs::launch_rmsnorm(w.hidden, w.delta, ln2, w.xn, M, TH, c.t_eps, st, nullptr, false), "post_attention_layernorm");
-        QTAP("txt", i, "xn1", w.xn, (size_t)M * TH);
+        QHIP(h, vqs::launch_rmsnorm(w.hidden, w.delta, ln2, w.xn, M, TH, c.t_eps, st, nullptr, false, XLD), "post_attention_layernorm");
+        QRUN(qtap2d(h, "txt", i, "xn1", w.xn, TH, M, XLD, st));
         pend_attn = w.delta;
         {
             GCall g{w.xn, h->t_gu_w[i], w.ff};
-            g.M = M; g.N = 2 * h->t_mlp_p; g.K = TH; g.lda = TH; g.ldw = TH; g.ldc = h->t_ffld; g.epi = vqs::EPI_GATED; g.gate_act = 1;
+            g.M = M; g.N = 2 * h->t_mlp_p; g.K = TH; g.lda = XLD; g.ldw = XLD; g.ldc = h->t_ffld; g.epi = vqs::EPI_GATED; g.gate_act = 1;
             QRUN(qgemm(h, g, st, "gate|up"));
         }
         QTAP("txt", i, "ff", w.ff, (size_t)M * h->t_ffld);
@@ -668,10 +704,10 @@ int vqs_qwen_score(vqs_qwen_handle* h, const void* d_merged, const int32_t* d_in
     }
     QW(fin, "model.language_model.norm.weight", TH);
     QW(head, "lm_head.weight", (int64_t)c.t_vocab * TH);
-    QHIP(h, vqs::launch_rmsnorm(w.hidden, pend_attn ? pend_attn : pend, fin, w.xn, M, TH, c.t_eps, st, pend_attn ? pend : nullptr), "final norm");
+    QHIP(h, vqs::launch_rmsnorm(w.hidden, pend_attn ? pend_attn : pend, fin, w.xn, M, TH, c.t_eps, st, pend_attn ? pend : nullptr, true, XLD), "final norm");
     QTAP("txt", -1, "h_out", w.hidden, (size_t)M * TH);
-    QTAP("txt", -1, "xnf", w.xn, (size_t)M * TH);
-    QHIP(h, vqs::launch_gather_rows_bf16(w.xn, nullptr, d_last_row, w.last, B, TH, TH, TH, st), "last positions");
+    QRUN(qtap2d(h, "txt", -1, "xnf", w.xn, TH, M, XLD, st));
+    QHIP(h, vqs::launch_gather_rows_bf16(w.xn, nullptr, d_last_row, w.last, B, TH, XLD, TH, st), "last positions");
     {
         GCall g{w.last, head, d_logits};
         g.M = B; g.N = c.t_vocab; g.K = TH; g.lda = TH; g.ldw = TH; g.ldc = c.t_vocab; g.epi = vqs::EPI_F32;

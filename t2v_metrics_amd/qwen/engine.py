@@ -32,12 +32,13 @@ _SIGS = {
     "vqs_qwen_profile_enable": (_i32, [_vp, _i32]),
     "vqs_qwen_profile_read": (_i32, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), _i32]),
     "vqs_qwen_debug_tap": (_i32, [_vp, ctypes.c_char_p, _vp, _sz]),
+    "vqs_qwen_debug_option": (_i32, [_vp, ctypes.c_char_p, ctypes.c_int64]),
     "vqs_qwen_score": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _sz, _vp]),
 }
 
 
 class QwenEngine:
-    def __init__(self, cfg: Qwen25VLConfig, weights: Dict[str, torch.Tensor], device="cuda:0"):
+    def __init__(self, cfg: Qwen25VLConfig, weights: Dict[str, torch.Tensor], device="cuda:0", x_pitch: int = None):
         if not torch.cuda.is_available():
             raise VqsError("the Qwen2.5-VL HIP path needs an MI355X (no CPU fallback)")
         self.lib = load_library()
@@ -56,6 +57,8 @@ class QwenEngine:
         if rc != 0:
             raise VqsError(f"vqs_qwen_create failed ({rc}): unsupported configuration")
         self._h = h
+        if x_pitch is not None:          # test hook (include/vqs_qwen.h): row pitch of the normalised activations / gate|up weight rows
+            self._check(self.lib.vqs_qwen_debug_option(self._h, b"x_pitch", int(x_pitch)), "vqs_qwen_debug_option")
         with torch.cuda.device(self.device):
             self._weights = {k: w.to(self.device, torch.bfloat16).contiguous() for k, w in weights.items()}
             descs = (VqsWeightDesc * len(self._weights))(*[VqsWeightDesc(k.encode(), w.data_ptr(), w.numel())

@@ -92,7 +92,9 @@ def test_qwen_compact_tower_heads_stage_locked_and_end_to_end():
     from t2v_metrics_amd.qwen.engine import QwenEngine
     from tests.test_qwen_rounding_oracle import C80_GRIDS, synthetic_case
     cfg, w, grids, ids, mask, px = synthetic_case("qwen-small-c80", C80_GRIDS)
-    eng = QwenEngine(cfg, w)
+    # x_pitch: the 7B path keeps the language model's normalised activations and gate|up weight rows at an 8 KiB pitch (hidden 3584
+    # -> 4096); here the same code path at hidden 256 -> 320
+    eng = QwenEngine(cfg, w, x_pitch=320)
     pxb = px.to(torch.bfloat16)
     merged, off = [], 0
     for vi, g in enumerate(grids):
