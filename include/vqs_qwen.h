@@ -8,6 +8,7 @@
  *                              attention blocks with 2-D RoPE, patch merger)
  *   vqs_qwen_score          <- get_placeholder_mask/masked_scatter :1094-1232, Qwen2_5_VLTextModel.forward :790-873,
  *                              lm_head on the last position (= scores[0] of generate)
+ *   vqs_qwen_prefill/decode <- the same forward with past_key_values (Qwen2_5_VLAttention.forward :653-717), one position per call
  * Same conventions as include/vqs.h: plain device pointers, caller-owned buffers, no allocation, no stream sync, 0 or a
  * negative VQS_ERR_* code, message via vqs_qwen_last_error.  Integer layout work (window permutation, rotary tables from
  * the 3-D positions, placeholder slots) is the caller's: t2v_metrics_amd/qwen/layout.py builds those arrays. */
@@ -37,7 +38,8 @@ void vqs_qwen_destroy(vqs_qwen_handle* h);
 const char* vqs_qwen_last_error(const vqs_qwen_handle* h);
 
 /* Weights: HF state_dict names ("model.visual.blocks.0.attn.qkv.weight", ...), bf16, device, [out, in] row-major.  The
- * library packs fused / padded copies (heads padded to 128 lanes, gate|up interleaved, K padded to 64) into d_packed. */
+ * library packs fused / padded copies (language-model heads padded to 128 lanes, gate|up interleaved, K padded to 64) into d_packed
+ * and reads the other tensors where they lie: the descs' device pointers must stay valid for the handle's lifetime. */
 /* GEMM launch timing for the bench's roofline object (same contract as vqs_profile_* in vqs.h): when enabled, every GEMM
  * launch of the following calls is bracketed by HIP events on the launch stream.  vqs_qwen_profile_read synchronises on
  * them and returns the number of launches, their summed duration (ms), algorithmic FLOPs (2*M*N*K) and operand + result
@@ -75,6 +77,22 @@ size_t vqs_qwen_score_workspace_bytes(const vqs_qwen_handle* h, int32_t B, int32
 int vqs_qwen_score(vqs_qwen_handle* h, const void* d_merged, const int32_t* d_input_ids, const int32_t* d_vis_slot,
                    const int32_t* d_seq_len, const int32_t* d_last_row, const float* d_cos, const float* d_sin, int32_t B,
                    int32_t L, float* d_logits, void* d_ws, size_t ws_bytes, void* stream);
+
+/* Generation beyond the first token (the reference's forward with max_new_tokens > 1, qwen2vl_model.py:222-230, and generate(),
+ * :495-563, run HF generate with its KV cache): vqs_qwen_prefill is vqs_qwen_score that also keeps every layer's K (after the rotary
+ * embedding) and V in a caller-owned cache; vqs_qwen_decode runs ONE further position per sample against it.
+ *   d_kv         bf16, vqs_qwen_kv_bytes(B, Lmax): per layer K then V, each [B, t_kv_heads, Lmax, 128]; Lmax >= L + steps to come
+ *   decode: d_ids int32 [B] the token entering each sample, d_len int32 [B] its index in the sample's sequence (= tokens cached so
+ *   far; the caller advances it), d_cos / d_sin fp32 [B, head_dim/2] rotary table of that position (all three M-RoPE axes equal
+ *   max(prompt position) + 1 + step, HF get_rope_index rope_deltas); d_logits fp32 [B, t_vocab] of the new position.
+ * Samples that have stopped may be fed any token: rows are independent. */
+size_t vqs_qwen_kv_bytes(const vqs_qwen_handle* h, int32_t B, int32_t Lmax);
+int vqs_qwen_prefill(vqs_qwen_handle* h, const void* d_merged, const int32_t* d_input_ids, const int32_t* d_vis_slot,
+                     const int32_t* d_seq_len, const int32_t* d_last_row, const float* d_cos, const float* d_sin, int32_t B,
+                     int32_t L, float* d_logits, void* d_ws, size_t ws_bytes, void* d_kv, size_t kv_bytes, int32_t Lmax, void* stream);
+size_t vqs_qwen_decode_workspace_bytes(const vqs_qwen_handle* h, int32_t B);
+int vqs_qwen_decode(vqs_qwen_handle* h, const int32_t* d_ids, const int32_t* d_len, const float* d_cos, const float* d_sin, int32_t B,
+                    int32_t Lmax, void* d_kv, size_t kv_bytes, float* d_logits, void* d_ws, size_t ws_bytes, void* stream);
 
 /* Test hook (not part of the drop-in boundary): register a caller-owned device buffer for a named intermediate of the NEXT passes;
  * when a pass produces it, it is copied there on the pass's stream.  Names: vis.pre, vis.<i>.{h,xn0,q0,k0,q,k,v,attn,d_attn,xn1,ff,d_mlp},

@@ -1,0 +1,149 @@
+// Greedy-decoding step of the Qwen2.5-VL language model against a KV cache (include/vqs_qwen.h vqs_qwen_decode): the two kernels
+// a one-token step needs besides the GEMMs and norms of the prefill.  Replaces, for max_new_tokens > 1 and free-form generation
+// (/root/reference/t2v_metrics/models/vqascore_models/qwen2vl_model.py:222-230, :495-563), HF generate's cached forward
+// (Qwen2_5_VLAttention.forward with past_key_values, modeling_qwen2_5_vl.py:653-717): K after RoPE and V are appended at the
+// sample's current length and the new query attends over [0, length].
+// Both kernels are HBM-bound row streams (a step reads every cached K / V row of the layer once): 16-byte accesses per lane, fp32
+// arithmetic, no matrix pipe -- one query row per (sample, head) is 1/128 of an MFMA tile.
+#include "vqs_kernels.h"
+
+namespace vqs {
+
+namespace {
+__device__ __forceinline__ float d_bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+typedef __attribute__((ext_vector_type(2))) __bf16 d_bf16x2;
+__device__ __forceinline__ bf16_t d_f2bf(float f) {           // v_cvt_pk_bf16_f32, RNE
+    d_bf16x2 v;
+    v[0] = (__bf16)f;
+    v[1] = (__bf16)0.0f;
+    return (bf16_t)(__builtin_bit_cast(uint32_t, v) & 0xffff);
+}
+}  // namespace
+
+// qkv [B, (Hq + 2 Hkv) * hd] = bf16(x W^T + b) of the new token, heads in hd-lane slots (q heads, then k heads, then v heads).
+// Block (head slot, sample), 64 threads: rotates q and k by the new position's table (x[i] <- x[i] c[i] - x[i+half] s[i],
+// x[i+half] <- x[i+half] c[i] + x[i] s[i], i < half; lanes >= 2 half are the heads' zero padding), writes q dense [B, Hq * hd] and
+// k / v into the cache rows [b, head, len[b], :] of this layer.
+__global__ void __launch_bounds__(64) qwen_decode_rope_append_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ cs,
+                                                                     const float* __restrict__ sn, const int* __restrict__ len,
+                                                                     bf16_t* __restrict__ q_out, bf16_t* __restrict__ kc,
+                                                                     bf16_t* __restrict__ vc, int Hq, int Hkv, int hd, int half, int Lmax) {
+    const int slot = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+    const int QN = (Hq + 2 * Hkv) * hd;
+    const bf16_t* src = qkv + (size_t)b * QN + (size_t)slot * hd;
+    const int pos = len[b];
+    bf16_t* dst;
+    bool rot = true;
+    if (slot < Hq) {
+        dst = q_out + ((size_t)b * Hq + slot) * hd;
+    } else if (slot < Hq + Hkv) {
+        dst = kc + (((size_t)b * Hkv + (slot - Hq)) * Lmax + pos) * hd;
+    } else {
+        dst = vc + (((size_t)b * Hkv + (slot - Hq - Hkv)) * Lmax + pos) * hd;
+        rot = false;
+    }
+    if (rot) {
+        if (t < half) {
+            const float a = d_bf2f(src[t]), c2 = d_bf2f(src[t + half]);
+            const float c = cs[(size_t)b * half + t], s = sn[(size_t)b * half + t];
+            dst[t] = d_f2bf(a * c - c2 * s);
+            dst[t + half] = d_f2bf(c2 * c + a * s);
+        }
+        for (int d = 2 * half + t; d < hd; d += 64) dst[d] = src[d];
+    } else {
+        for (int d = t; d < hd; d += 64) dst[d] = src[d];
+    }
+}
+
+hipError_t launch_qwen_decode_rope_append(const bf16_t* qkv, const float* cs, const float* sn, const int* len, bf16_t* q_out, bf16_t* kc,
+                                          bf16_t* vc, int B, int Hq, int Hkv, int hd, int half, int Lmax, hipStream_t s) {
+    if (B <= 0 || Hq <= 0 || Hkv <= 0 || half <= 0 || half > 64 || 2 * half > hd || B > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(qwen_decode_rope_append_kernel, dim3((unsigned)(Hq + 2 * Hkv), (unsigned)B), dim3(64), 0, s, qkv, cs, sn, len, q_out,
+                       kc, vc, Hq, Hkv, hd, half, Lmax);
+    return hipGetLastError();
+}
+
+// One query row per (sample, query head) over the cached keys [0, len[b]] of its key/value head (h / (Hq / Hkv)); hd = 128.
+// Block (head, sample), 256 threads.  Scores: thread j takes keys j, j + 256, ...: fp32 dot of the 256-byte K row with q (LDS,
+// fp32) -> t_j = s_j * scale in LDS.  m = max t; p_j = exp(t_j - m), fp32, NOT rounded (a one-row softmax has no matrix-pipe operand
+// to round for); l = sum p.  Output: wave w takes keys w, w + 4, ...; lane i the lanes 2i, 2i + 1 (one coalesced 256-byte V row per
+// wave and key), the four partial rows are added in wave order, divided by l, rounded to bf16.  Dynamic LDS: (len + 1) floats.
+__global__ void __launch_bounds__(256) qwen_decode_attn_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc,
+                                                               const bf16_t* __restrict__ vc, const int* __restrict__ len,
+                                                               bf16_t* __restrict__ out, int Hq, int Hkv, int Lmax, float scale) {
+    constexpr int HD = 128;
+    extern __shared__ __attribute__((aligned(16))) float d_smem[];
+    __shared__ float qs[HD];
+    __shared__ float red[4];
+    __shared__ float part[4][HD];
+    const int h = blockIdx.x, b = blockIdx.y, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int hk = h / (Hq / Hkv);
+    const int n = len[b] + 1;
+    const bf16_t* K = kc + ((size_t)b * Hkv + hk) * Lmax * HD;
+    const bf16_t* V = vc + ((size_t)b * Hkv + hk) * Lmax * HD;
+    if (t < HD) qs[t] = d_bf2f(q[((size_t)b * Hq + h) * HD + t]);
+    __syncthreads();
+    float mx = -3.0e38f;
+    for (int j = t; j < n; j += 256) {
+        const uint4* kr = reinterpret_cast<const uint4*>(K + (size_t)j * HD);
+        float acc = 0.0f;
+#pragma unroll
+        for (int c = 0; c < HD / 8; ++c) {
+            const uint4 u = kr[c];
+            const uint32_t w4[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc = fmaf(__uint_as_float(w4[e] << 16), qs[8 * c + 2 * e], acc);
+                acc = fmaf(__uint_as_float(w4[e] & 0xffff0000u), qs[8 * c + 2 * e + 1], acc);
+            }
+        }
+        const float tj = acc * scale;
+        d_smem[j] = tj;
+        mx = fmaxf(mx, tj);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    if (lane == 0) red[wv] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float ls = 0.0f;
+    for (int j = t; j < n; j += 256) {
+        const float p = __expf(d_smem[j] - mx);
+        d_smem[j] = p;
+        ls += p;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ls += __shfl_xor(ls, off);
+    if (lane == 0) red[wv] = ls;
+    __syncthreads();
+    const float l = (red[0] + red[1]) + (red[2] + red[3]);
+    float o0 = 0.0f, o1 = 0.0f;
+    for (int j = wv; j < n; j += 4) {
+        const uint32_t u = reinterpret_cast<const uint32_t*>(V + (size_t)j * HD)[lane];
+        const float p = d_smem[j];
+        o0 = fmaf(p, __uint_as_float(u << 16), o0);
+        o1 = fmaf(p, __uint_as_float(u & 0xffff0000u), o1);
+    }
+    part[wv][2 * lane] = o0;
+    part[wv][2 * lane + 1] = o1;
+    __syncthreads();
+    if (t < HD) {
+        const float o = ((part[0][t] + part[1][t]) + (part[2][t] + part[3][t])) / l;
+        out[((size_t)b * Hq + h) * HD + t] = d_f2bf(o);
+    }
+}
+
+hipError_t launch_qwen_decode_attn(const bf16_t* q, const bf16_t* kc, const bf16_t* vc, const int* len, bf16_t* out, int B, int Hq,
+                                   int Hkv, int Lmax, float scale, hipStream_t s) {
+    if (B <= 0 || Hq <= 0 || Hkv <= 0 || (Hq % Hkv) != 0 || Lmax <= 0 || Lmax > 36864 || B > 65535) return hipErrorInvalidValue;
+    const size_t lds = (size_t)Lmax * sizeof(float);
+    if (lds > 48 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(qwen_decode_attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(qwen_decode_attn_kernel, dim3((unsigned)Hq, (unsigned)B), dim3(256), lds, s, q, kc, vc, len, out, Hq, Hkv, Lmax, scale);
+    return hipGetLastError();
+}
+
+}  // namespace vqs

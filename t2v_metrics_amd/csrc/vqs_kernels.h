@@ -229,6 +229,11 @@ hipError_t launch_decoder_embed(const int* labels, int ld_labels, const bf16_t* 
                                 int vocab, hipStream_t s, int pos0 = 0);
 hipError_t launch_rope(bf16_t* x, const float* cs, const float* sn, int B, int H, int S, int hd, int half, hipStream_t s);
 // q [B, Hq, S, hd] and k [B, Hk, S, hd] in one launch (16-byte accesses when half % 8 == 0; otherwise two launch_rope calls)
+// greedy-decoding step of the Qwen2.5-VL language model (qwen_decode.hip): rotate + append the new token's q / k / v, one-row attention
+hipError_t launch_qwen_decode_rope_append(const bf16_t* qkv, const float* cs, const float* sn, const int* len, bf16_t* q_out, bf16_t* kc,
+                                          bf16_t* vc, int B, int Hq, int Hkv, int hd, int half, int Lmax, hipStream_t s);
+hipError_t launch_qwen_decode_attn(const bf16_t* q, const bf16_t* kc, const bf16_t* vc, const int* len, bf16_t* out, int B, int Hq,
+                                   int Hkv, int Lmax, float scale, hipStream_t s);
 hipError_t launch_rope_qk(bf16_t* q, bf16_t* k, const float* cs, const float* sn, int B, int Hq, int Hk, int S, int hd, int half,
                           hipStream_t s);
 hipError_t launch_rowss_to_rs(const float* rowss, int parts, int M, float invd, float eps, float* rs, hipStream_t s);

@@ -631,9 +631,16 @@ size_t vqs_qwen_score_workspace_bytes(const vqs_qwen_handle* h, int32_t B, int32
     return carve_text(h, nullptr, B, L).total;
 }
 
-int vqs_qwen_score(vqs_qwen_handle* h, const void* d_merged, const int32_t* d_input_ids, const int32_t* d_vis_slot,
-                   const int32_t* d_seq_len, const int32_t* d_last_row, const float* d_cos, const float* d_sin, int32_t B,
-                   int32_t L, float* d_logits, void* d_ws, size_t ws_bytes, void* stream) {
+}  // extern "C"
+
+namespace {
+// KV cache: layer i holds K at slab 2i and V at slab 2i + 1, each [B, kv_heads, Lmax, 128] bf16 (K after the rotary embedding)
+inline size_t kv_slab(const vqs_qwen_handle* h, int B, int Lmax) { return (size_t)B * h->c.t_kv_heads * (size_t)Lmax * HDP; }
+
+// vqs_qwen_score / vqs_qwen_prefill: d_kv != nullptr also keeps every layer's K and V
+int score_impl(vqs_qwen_handle* h, const void* d_merged, const int32_t* d_input_ids, const int32_t* d_vis_slot,
+               const int32_t* d_seq_len, const int32_t* d_last_row, const float* d_cos, const float* d_sin, int32_t B,
+               int32_t L, float* d_logits, void* d_ws, size_t ws_bytes, void* stream, void* d_kv, int32_t Lmax) {
     if (!h) return VQS_ERR_INVALID;
     if (!h->bound) return qfail(h, VQS_ERR_STATE, "score: weights not bound");
     if (!d_merged || !d_input_ids || !d_vis_slot || !d_seq_len || !d_last_row || !d_cos || !d_sin || !d_logits || !d_ws)
@@ -673,6 +680,13 @@ int vqs_qwen_score(vqs_qwen_handle* h, const void* d_merged, const int32_t* d_in
         QTAP("txt", i, "q", w.q, (size_t)M * IQ);                 // after the rotary embedding, head-major [B, heads, L, 128]
         QTAP("txt", i, "k", w.k, (size_t)M * IKV);
         QTAP("txt", i, "v", w.v, (size_t)M * IKV);
+        if (d_kv) {   // rows [b, head, 0 .. L) of the cache slabs (pitch Lmax positions)
+            bf16_t* kc = (bf16_t*)d_kv + (size_t)(2 * i) * kv_slab(h, B, Lmax);
+            bf16_t* vc = kc + kv_slab(h, B, Lmax);
+            const size_t wb = (size_t)L * HDP * sizeof(bf16_t), pb = (size_t)Lmax * HDP * sizeof(bf16_t), nr = (size_t)B * c.t_kv_heads;
+            QHIP(h, hipMemcpy2DAsync(kc, pb, w.k, wb, wb, nr, hipMemcpyDeviceToDevice, st), "keep K");
+            QHIP(h, hipMemcpy2DAsync(vc, pb, w.v, wb, wb, nr, hipMemcpyDeviceToDevice, st), "keep V");
+        }
         {
             vqs::AttnParams a{w.q, w.k, w.v, w.attn, nullptr, d_seq_len, B, c.t_heads, L, scale};
             a.hd = HDP; a.Hkv = c.t_kv_heads; a.causal = 1;
@@ -711,6 +725,124 @@ int vqs_qwen_score(vqs_qwen_handle* h, const void* d_merged, const int32_t* d_in
     {
         GCall g{w.last, head, d_logits};
         g.M = B; g.N = c.t_vocab; g.K = TH; g.lda = TH; g.ldw = TH; g.ldc = c.t_vocab; g.epi = vqs::EPI_F32;
+        QRUN(qgemm(h, g, st, "lm_head"));
+    }
+    return VQS_OK;
+}
+
+struct DecWs {
+    float* hidden;
+    bf16_t *xn, *delta, *delta2, *qkv, *q, *attn, *ff;
+    int* neg1;
+    size_t total;
+};
+DecWs carve_decode(const vqs_qwen_handle* h, char* base, int B) {
+    const vqs_qwen_config& c = h->c;
+    Carver cv{base};
+    DecWs w{};
+    const size_t b = (size_t)B;
+    w.hidden = cv.take<float>(b * c.t_hidden);
+    w.xn = cv.take<bf16_t>(b * h->t_xld);
+    w.delta = cv.take<bf16_t>(b * c.t_hidden);
+    w.delta2 = cv.take<bf16_t>(b * c.t_hidden);
+    w.qkv = cv.take<bf16_t>(b * (h->t_iq + 2 * h->t_ikv));
+    w.q = cv.take<bf16_t>(b * h->t_iq);
+    w.attn = cv.take<bf16_t>(b * h->t_iq);
+    w.ff = cv.take<bf16_t>(b * h->t_ffld);
+    w.neg1 = cv.take<int>(b);
+    w.total = align_up(cv.off);
+    return w;
+}
+}  // namespace
+
+extern "C" {
+
+int vqs_qwen_score(vqs_qwen_handle* h, const void* d_merged, const int32_t* d_input_ids, const int32_t* d_vis_slot,
+                   const int32_t* d_seq_len, const int32_t* d_last_row, const float* d_cos, const float* d_sin, int32_t B,
+                   int32_t L, float* d_logits, void* d_ws, size_t ws_bytes, void* stream) {
+    return score_impl(h, d_merged, d_input_ids, d_vis_slot, d_seq_len, d_last_row, d_cos, d_sin, B, L, d_logits, d_ws, ws_bytes, stream,
+                      nullptr, 0);
+}
+
+size_t vqs_qwen_kv_bytes(const vqs_qwen_handle* h, int32_t B, int32_t Lmax) {
+    if (!h || B <= 0 || Lmax <= 0) return 0;
+    return (size_t)2 * h->c.t_layers * kv_slab(h, B, Lmax) * sizeof(bf16_t);
+}
+
+int vqs_qwen_prefill(vqs_qwen_handle* h, const void* d_merged, const int32_t* d_input_ids, const int32_t* d_vis_slot,
+                     const int32_t* d_seq_len, const int32_t* d_last_row, const float* d_cos, const float* d_sin, int32_t B,
+                     int32_t L, float* d_logits, void* d_ws, size_t ws_bytes, void* d_kv, size_t kv_bytes, int32_t Lmax, void* stream) {
+    if (!h) return VQS_ERR_INVALID;
+    if (!d_kv || Lmax < L || kv_bytes < vqs_qwen_kv_bytes(h, B, Lmax)) return qfail(h, VQS_ERR_WORKSPACE, "prefill: KV cache missing or too small");
+    return score_impl(h, d_merged, d_input_ids, d_vis_slot, d_seq_len, d_last_row, d_cos, d_sin, B, L, d_logits, d_ws, ws_bytes, stream, d_kv,
+                      Lmax);
+}
+
+size_t vqs_qwen_decode_workspace_bytes(const vqs_qwen_handle* h, int32_t B) {
+    if (!h || B <= 0) return 0;
+    return carve_decode(h, nullptr, B).total;
+}
+
+int vqs_qwen_decode(vqs_qwen_handle* h, const int32_t* d_ids, const int32_t* d_len, const float* d_cos, const float* d_sin, int32_t B,
+                    int32_t Lmax, void* d_kv, size_t kv_bytes, float* d_logits, void* d_ws, size_t ws_bytes, void* stream) {
+    if (!h) return VQS_ERR_INVALID;
+    if (!h->bound) return qfail(h, VQS_ERR_STATE, "decode: weights not bound");
+    if (!d_ids || !d_len || !d_cos || !d_sin || !d_kv || !d_logits || !d_ws) return qfail(h, VQS_ERR_INVALID, "decode: null argument");
+    if (B <= 0 || Lmax <= 0) return qfail(h, VQS_ERR_INVALID, "decode: need B > 0, Lmax > 0");
+    if (kv_bytes < vqs_qwen_kv_bytes(h, B, Lmax)) return qfail(h, VQS_ERR_WORKSPACE, "decode: KV cache too small");
+    const vqs_qwen_config& c = h->c;
+    const DecWs w = carve_decode(h, (char*)d_ws, B);
+    if (ws_bytes < w.total) return qfail(h, VQS_ERR_WORKSPACE, "decode: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int TH = c.t_hidden, IQ = h->t_iq, IKV = h->t_ikv, XLD = h->t_xld, QN = IQ + 2 * IKV;
+    const float scale = 1.0f / sqrtf((float)h->t_hd);
+    QW(embed, "model.language_model.embed_tokens.weight", (int64_t)c.t_vocab * TH);
+    QHIP(h, hipMemsetAsync(w.neg1, 0xff, (size_t)B * sizeof(int), st), "no placeholder rows");
+    QHIP(h, vqs::launch_qwen_embed(d_ids, w.neg1, embed, embed, w.hidden, B, TH, c.t_vocab, st), "embed");
+    QHIP(h, hipMemsetAsync(w.ff, 0, (size_t)B * h->t_ffld * sizeof(bf16_t), st), "clear ff padding");
+    const bf16_t* pend = nullptr;
+    const bf16_t* pend_attn = nullptr;
+    for (int i = 0; i < c.t_layers; ++i) {
+        const std::string p = "model.language_model.layers." + std::to_string(i) + ".";
+        QW(ln1, p + "input_layernorm.weight", TH);
+        QW(ln2, p + "post_attention_layernorm.weight", TH);
+        bf16_t* kc = (bf16_t*)d_kv + (size_t)(2 * i) * kv_slab(h, B, Lmax);
+        bf16_t* vc = kc + kv_slab(h, B, Lmax);
+        QHIP(h, vqs::launch_rmsnorm(w.hidden, pend_attn ? pend_attn : pend, ln1, w.xn, B, TH, c.t_eps, st, pend_attn ? pend : nullptr, true, XLD), "input_layernorm");
+        {   // one position per sample: head-major [B, heads, 1, 128] IS token-major [B, heads * 128]
+            GCall g{w.xn, h->t_qkv_w[i], w.qkv};
+            g.bias = h->t_qkv_b[i];
+            g.M = B; g.N = QN; g.K = TH; g.lda = XLD; g.ldw = TH; g.ldc = QN; g.epi = vqs::EPI_BF16;
+            QRUN(qgemm(h, g, st, "decode qkv"));
+        }
+        QHIP(h, vqs::launch_qwen_decode_rope_append(w.qkv, d_cos, d_sin, d_len, w.q, kc, vc, B, c.t_heads, c.t_kv_heads, HDP, h->t_hd / 2, Lmax, st),
+             "decode rope + append");
+        QHIP(h, vqs::launch_qwen_decode_attn(w.q, kc, vc, d_len, w.attn, B, c.t_heads, c.t_kv_heads, Lmax, scale, st), "decode attention");
+        {
+            GCall g{w.attn, h->t_o_w[i], w.delta};
+            g.M = B; g.N = TH; g.K = IQ; g.lda = IQ; g.ldw = IQ; g.ldc = TH; g.epi = vqs::EPI_BF16;
+            QRUN(qgemm(h, g, st, "decode o_proj"));
+        }
+        QHIP(h, vqs::launch_rmsnorm(w.hidden, w.delta, ln2, w.xn, B, TH, c.t_eps, st, nullptr, false, XLD), "post_attention_layernorm");
+        pend_attn = w.delta;
+        {
+            GCall g{w.xn, h->t_gu_w[i], w.ff};
+            g.M = B; g.N = 2 * h->t_mlp_p; g.K = TH; g.lda = XLD; g.ldw = XLD; g.ldc = h->t_ffld; g.epi = vqs::EPI_GATED; g.gate_act = 1;
+            QRUN(qgemm(h, g, st, "decode gate|up"));
+        }
+        {
+            GCall g{w.ff, h->t_down_w[i], w.delta2};
+            g.M = B; g.N = TH; g.K = h->t_ffld; g.lda = h->t_ffld; g.ldw = h->t_ffld; g.ldc = TH; g.epi = vqs::EPI_BF16;
+            QRUN(qgemm(h, g, st, "decode down_proj"));
+            pend = w.delta2;
+        }
+    }
+    QW(fin, "model.language_model.norm.weight", TH);
+    QW(head, "lm_head.weight", (int64_t)c.t_vocab * TH);
+    QHIP(h, vqs::launch_rmsnorm(w.hidden, pend_attn ? pend_attn : pend, fin, w.xn, B, TH, c.t_eps, st, pend_attn ? pend : nullptr, true, XLD), "final norm");
+    {
+        GCall g{w.xn, head, d_logits};
+        g.M = B; g.N = c.t_vocab; g.K = TH; g.lda = XLD; g.ldw = TH; g.ldc = c.t_vocab; g.epi = vqs::EPI_F32;
         QRUN(qgemm(h, g, st, "lm_head"));
     }
     return VQS_OK;

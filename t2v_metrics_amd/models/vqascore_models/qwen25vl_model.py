@@ -275,32 +275,10 @@ class Qwen25VLModel(VQAScoreModel):
                 a_ids = [list(self.tokenizer.encode(answers[i], add_special_tokens=False)) for i in chunk]
                 if any(len(a) < 1 for a in a_ids):
                     raise ValueError("empty answer")
-                # ---- greedy generation (HF generate, do_sample=False): step t re-runs the prefill over prompt + t tokens;
-                # a sample stops at its first stop id, exactly as batch-1 generate does in the reference (:222-230)
-                step_scores: List[List[torch.Tensor]] = [[] for _ in chunk]       # processed scores per generated step
-                gen: List[List[int]] = [[] for _ in chunk]
-                live = list(range(len(chunk)))
-                for _step in range(max_new_tokens):
-                    cur = [rows[k] + gen[k] for k in live]
-                    L = max(len(r) for r in cur)
-                    ids = torch.zeros(len(cur), L, dtype=torch.long)
-                    mask = torch.zeros(len(cur), L, dtype=torch.long)
-                    for k, r in enumerate(cur):
-                        ids[k, : len(r)] = torch.tensor(r)
-                        mask[k, : len(r)] = 1
-                    sub = merged if len(live) == len(chunk) else merged.reshape(len(chunk), n_tok, -1)[live].reshape(len(live) * n_tok, -1)
-                    logits = self.engine.score_logits(sub, ids, mask, [g] * len(live))
-                    proc = self._processed_scores(logits, cur)
-                    nxt = proc.argmax(-1).cpu().tolist()
-                    still = []
-                    for k, sk in enumerate(live):
-                        step_scores[sk].append(proc[k])
-                        gen[sk].append(int(nxt[k]))
-                        if int(nxt[k]) not in stops:
-                            still.append(sk)
-                    live = still
-                    if not live:
-                        break
+                # ---- greedy generation (HF generate, do_sample=False): ONE prefill that keeps the KV cache, then one cached
+                # position per further token; a sample stops at its first stop id, exactly as batch-1 generate does in the
+                # reference (:222-230) -- its later rows are computed and ignored (rows are independent)
+                step_scores, gen = self._greedy(merged, rows, [g] * len(chunk), max_new_tokens, stops)
                 # ---- score the answer tokens from the LAST positions of the generated scores (:239-289)
                 for k, i in enumerate(chunk):
                     n_ans, offset = len(a_ids[k]), 0
@@ -316,5 +294,71 @@ class Qwen25VLModel(VQAScoreModel):
                     scores[i] = float(torch.prod(p.double()) ** (1.0 / n_ans))
         return scores
 
-    def generate(self, *args, **kwargs):
-        raise NotImplementedError("free-form generation is not part of the MI355X Qwen2.5-VL path yet (scoring only)")
+    def _greedy(self, merged, rows: List[List[int]], grids, max_new_tokens: int, stops: List[int], pick=None):
+        """Shared generation loop: prompt rows (token id lists, one video run each) -> (per-sample list of processed score rows,
+        per-sample generated ids).  `pick(proc) -> next ids` defaults to argmax (do_sample=False)."""
+        n = len(rows)
+        L = max(len(r) for r in rows)
+        ids = torch.zeros(n, L, dtype=torch.long)
+        mask = torch.zeros(n, L, dtype=torch.long)
+        for k, r in enumerate(rows):
+            ids[k, : len(r)] = torch.tensor(r)
+            mask[k, : len(r)] = 1
+        step_scores: List[List[torch.Tensor]] = [[] for _ in rows]
+        gen: List[List[int]] = [[] for _ in rows]
+        done = [False] * n
+        state = None
+        if max_new_tokens == 1:
+            logits = self.engine.score_logits(merged, ids, mask, grids)
+        else:
+            logits, state = self.engine.prefill(merged, ids, mask, grids, max_new_tokens)
+        for step in range(max_new_tokens):
+            if step > 0:
+                logits = self.engine.decode(state, torch.tensor([gen[k][-1] for k in range(n)], dtype=torch.long))
+            proc = self._processed_scores(logits, [rows[k] + gen[k] for k in range(n)])
+            nxt = (proc.argmax(-1) if pick is None else pick(proc)).cpu().tolist()
+            for k in range(n):
+                if done[k]:
+                    continue
+                step_scores[k].append(proc[k])
+                gen[k].append(int(nxt[k]))
+                done[k] = int(nxt[k]) in stops
+            if all(done):
+                break
+        return step_scores, gen
+
+    @torch.no_grad()
+    def generate(self, images: List[str], texts: List[str], fps=None, max_new_tokens: int = 2048, temperature: float = 0.0,
+                 do_sample: bool = None, top_p: float = 0.9) -> List[str]:
+        """Free-form answers (qwen2vl_model.py:495-563): the text is the whole user turn; greedy unless temperature > 0, then
+        HF's temperature + nucleus sampling (TemperatureLogitsWarper, TopPLogitsWarper: the smallest set of tokens whose
+        probability reaches top_p is kept).  Decoded with skip_special_tokens=True and stripped."""
+        assert len(images) == len(texts), "Number of paths and texts must match"
+        if do_sample is None:
+            do_sample = temperature > 0
+        items = self.load_images(images, fps)
+        prepared = [self.preprocess(it) for it in items]
+        pick = None
+        if do_sample and temperature > 0:
+            def pick(proc):
+                lp = torch.log_softmax(proc.float() / temperature, -1)
+                srt, idx = lp.sort(-1, descending=False)
+                drop = srt.exp().cumsum(-1) <= (1.0 - top_p)          # HF TopPLogitsWarper: remove the low tail, keep >= 1 token
+                drop[..., -1] = False
+                lp = lp.masked_fill(torch.zeros_like(drop).scatter(-1, idx, drop), float("-inf"))
+                return torch.multinomial(torch.softmax(lp, -1), 1)[:, 0]
+        stops = self._stop_ids()
+        out = [""] * len(images)
+        groups: Dict[Tuple[int, int, int], List[int]] = {}
+        for i, (_, g) in enumerate(prepared):
+            groups.setdefault(g, []).append(i)
+        for g, idxs in groups.items():
+            for s in range(0, len(idxs), self.max_batch):
+                chunk = idxs[s: s + self.max_batch]
+                merged = self.engine.encode_vision(torch.cat([prepared[i][0] for i in chunk]), [g] * len(chunk))
+                n_tok = g[0] * g[1] * g[2] // self.cfg.vision.merge_unit
+                rows = [self.build_ids(texts[i], items[i]['type'], n_tok) for i in chunk]
+                _, gen = self._greedy(merged, rows, [g] * len(chunk), max_new_tokens, stops, pick)
+                for k, i in enumerate(chunk):
+                    out[i] = self.tokenizer.decode(gen[k], skip_special_tokens=True).strip()
+        return out

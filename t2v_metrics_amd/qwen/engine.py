@@ -31,6 +31,10 @@ _SIGS = {
     "vqs_qwen_score_workspace_bytes": (_sz, [_vp, _i32, _i32]),
     "vqs_qwen_profile_enable": (_i32, [_vp, _i32]),
     "vqs_qwen_profile_read": (_i32, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), _i32]),
+    "vqs_qwen_kv_bytes": (_sz, [_vp, _i32, _i32]),
+    "vqs_qwen_prefill": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _sz, _vp, _sz, _i32, _vp]),
+    "vqs_qwen_decode_workspace_bytes": (_sz, [_vp, _i32]),
+    "vqs_qwen_decode": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _sz, _vp, _vp, _sz, _vp]),
     "vqs_qwen_debug_tap": (_i32, [_vp, ctypes.c_char_p, _vp, _sz]),
     "vqs_qwen_debug_option": (_i32, [_vp, ctypes.c_char_p, ctypes.c_int64]),
     "vqs_qwen_score": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _sz, _vp]),
@@ -115,6 +119,51 @@ class QwenEngine:
                                                 t["seq_len"].data_ptr(), t["last_row"].data_ptr(), t["cos"].data_ptr(),
                                                 t["sin"].data_ptr(), B, L, logits.data_ptr(), ws.data_ptr(), ws.numel(),
                                                 _stream_ptr()), "vqs_qwen_score")
+            return logits
+
+    def prefill(self, merged: torch.Tensor, input_ids: torch.Tensor, attention_mask: torch.Tensor,
+                grids: Sequence[Tuple[int, int, int]], max_new_tokens: int):
+        """score_logits that also keeps the KV cache for `max_new_tokens - 1` further positions.
+        -> (fp32 [B, vocab] logits of the last prompt position, state for decode())."""
+        lay = text_layout(self.cfg, input_ids.cpu(), attention_mask.cpu(), grids)
+        with torch.cuda.device(self.device):
+            dev = self.device
+            B, L = input_ids.shape
+            Lmax = L + max(int(max_new_tokens) - 1, 0)
+            ids = input_ids.to(dev, torch.int32).contiguous()
+            t = {k: lay[k].to(dev) for k in ("vis_slot", "seq_len", "last_row", "cos", "sin")}
+            logits = torch.empty(B, self.cfg.text.vocab, dtype=torch.float32, device=dev)
+            kv = torch.empty(self.lib.vqs_qwen_kv_bytes(self._h, B, Lmax), dtype=torch.uint8, device=dev)
+            ws = self._workspace(self.lib.vqs_qwen_score_workspace_bytes(self._h, B, L))
+            self._check(self.lib.vqs_qwen_prefill(self._h, merged.contiguous().data_ptr(), ids.data_ptr(), t["vis_slot"].data_ptr(),
+                                                  t["seq_len"].data_ptr(), t["last_row"].data_ptr(), t["cos"].data_ptr(),
+                                                  t["sin"].data_ptr(), B, L, logits.data_ptr(), ws.data_ptr(), ws.numel(), kv.data_ptr(),
+                                                  kv.numel(), Lmax, _stream_ptr()), "vqs_qwen_prefill")
+            state = {"kv": kv, "len": t["seq_len"].clone(), "Lmax": Lmax, "B": B, "pos": lay["next_pos"].clone(), "steps": 0}
+            return logits, state
+
+    def decode(self, state, token_ids: torch.Tensor) -> torch.Tensor:
+        """One further position per sample: token_ids long [B] (the tokens just generated; anything for stopped samples)
+        -> fp32 [B, vocab] logits of that position.  Advances `state`."""
+        from .layout import decode_tables
+        B = state["B"]
+        if int(state["len"].max()) >= state["Lmax"]:
+            raise VqsError("KV cache is full: prefill(..., max_new_tokens) sized it")
+        cos, sin = decode_tables(self.cfg, state["pos"])
+        with torch.cuda.device(self.device):
+            dev = self.device
+            ids = token_ids.to(dev, torch.int32).contiguous()
+            cos, sin = cos.to(dev), sin.to(dev)
+            logits = torch.empty(B, self.cfg.text.vocab, dtype=torch.float32, device=dev)
+            need = self.lib.vqs_qwen_decode_workspace_bytes(self._h, B)
+            if state.get("ws") is None or state["ws"].numel() < need:
+                state["ws"] = torch.empty(need, dtype=torch.uint8, device=dev)
+            self._check(self.lib.vqs_qwen_decode(self._h, ids.data_ptr(), state["len"].data_ptr(), cos.data_ptr(), sin.data_ptr(), B,
+                                                 state["Lmax"], state["kv"].data_ptr(), state["kv"].numel(), logits.data_ptr(),
+                                                 state["ws"].data_ptr(), state["ws"].numel(), _stream_ptr()), "vqs_qwen_decode")
+            state["len"] += 1
+            state["pos"] = state["pos"] + 1
+            state["steps"] += 1
             return logits
 
     def tap(self, name, dst: torch.Tensor = None):

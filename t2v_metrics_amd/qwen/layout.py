@@ -107,5 +107,16 @@ def text_layout(cfg: Qwen25VLConfig, input_ids: torch.Tensor, attention_mask: to
     sec = list(t_.mrope_section)
     ang = torch.cat([m[i % 3] for i, m in enumerate(freqs.split(sec, dim=-1))], dim=-1).reshape(B * L, hd // 2)
     last_row = torch.arange(B) * L + seq_len - 1
+    # position of the first generated token: HF decodes at cache_position + rope_delta, rope_delta = max(position) + 1 - length
+    # (get_rope_index), i.e. all three axes at max over the prompt's positions + 1 (+ step)
+    next_pos = torch.stack([pos[:, b, : int(seq_len[b])].max() + 1 for b in range(B)])
     return {"vis_slot": vis_slot.to(torch.int32), "seq_len": seq_len.to(torch.int32), "last_row": last_row.to(torch.int32),
-            "cos": ang.cos().contiguous(), "sin": ang.sin().contiguous(), "position_ids": pos}
+            "cos": ang.cos().contiguous(), "sin": ang.sin().contiguous(), "position_ids": pos, "next_pos": next_pos}
+
+
+def decode_tables(cfg: Qwen25VLConfig, positions: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """positions long [B] (the same on all three M-RoPE axes: generated tokens are text) -> cos, sin fp32 [B, head_dim/2]."""
+    hd = cfg.text.head_dim
+    inv_freq = 1.0 / (cfg.text.rope_theta ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
+    ang = positions[:, None].float() * inv_freq
+    return ang.cos().contiguous(), ang.sin().contiguous()

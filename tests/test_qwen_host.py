@@ -27,6 +27,10 @@ class FakeQwenTokenizer:
             text = text.replace(s, f" {s} ")
         return [SPECIALS[w] if w in SPECIALS else 10 + zlib.crc32(w.encode()) % (self.vocab - 10) for w in text.split()]
 
+    def decode(self, ids, skip_special_tokens=True):
+        special = set(SPECIALS.values())
+        return " ".join(f"t{int(i)}" for i in ids if not (skip_special_tokens and int(i) in special))
+
 
 class OracleQwenEngine:
     def __init__(self, cfg, weights):
@@ -51,6 +55,41 @@ class OracleQwenEngine:
             hid = o.text_model(emb, pos, attention_mask)
             last = attention_mask.long().sum(-1) - 1
             return hid[torch.arange(hid.shape[0]), last] @ o._w("lm_head.weight").t()
+
+    # generation with a "cache": the double re-runs the fp32 forward over prompt + tokens so far, the generated tokens at the
+    # positions HF's cached decode uses (max prompt position + 1 + step on all three axes)
+    def prefill(self, merged, input_ids, attention_mask, grids, max_new_tokens):
+        state = {"merged": merged, "ids": input_ids.clone(), "mask": attention_mask.clone(), "grids": grids, "new": [], "steps": 0}
+        self.prefills = getattr(self, "prefills", 0) + 1
+        return self.score_logits(merged, input_ids, attention_mask, grids), state
+
+    def decode(self, state, token_ids):
+        from oracle.qwen25vl_oracle import mrope_position_ids
+        o, c = self.o, self.cfg
+        state["new"].append(token_ids.clone())
+        state["steps"] += 1
+        ids0, mask0 = state["ids"], state["mask"]
+        B, L = ids0.shape
+        t = len(state["new"])
+        n = mask0.long().sum(-1)
+        ids = torch.zeros(B, L + t, dtype=torch.long)
+        mask = torch.zeros(B, L + t, dtype=torch.long)
+        pos0 = mrope_position_ids(ids0, mask0, c.image_token_id, c.video_token_id, [], state["grids"], c.vision.spatial_merge,
+                                  c.vision.tokens_per_second)
+        pos = torch.zeros(3, B, L + t, dtype=torch.long)
+        for b in range(B):
+            nb = int(n[b])
+            ids[b, :nb] = ids0[b, :nb]
+            ids[b, nb: nb + t] = torch.stack([x[b] for x in state["new"]])
+            mask[b, : nb + t] = 1
+            pos[:, b, :nb] = pos0[:, b, :nb]
+            pos[:, b, nb: nb + t] = pos0[:, b, :nb].max() + 1 + torch.arange(t)
+        with torch.no_grad():
+            emb = o._w("model.language_model.embed_tokens.weight")[ids]
+            m = (ids == c.video_token_id) & mask.bool()
+            emb = emb.masked_scatter(m[..., None].expand_as(emb), state["merged"].float())
+            hid = o.text_model(emb, pos, mask)
+            return hid[torch.arange(B), mask.long().sum(-1) - 1] @ o._w("lm_head.weight").t()
 
 
 def test_patchify_and_smart_resize_match_hf():
@@ -226,3 +265,44 @@ def test_generation_config_eos_ids_and_penalty_are_read_from_the_checkpoint_dir(
 def default_q(text):
     from t2v_metrics_amd.models.vqascore_models.qwen25vl_model import default_question_template
     return default_question_template.format(text)
+
+
+def test_generation_is_one_prefill_plus_cached_steps_and_generate_returns_text(tmp_path):
+    """max_new_tokens > 1 and generate() (qwen2vl_model.py:222-230, :495-563) run ONE prefill per batch and one cached position per
+    further token; greedy tokens equal the ones a prefill over prompt + tokens-so-far picks; generate() decodes them without the
+    specials; sampling (temperature > 0) draws from the nucleus only."""
+    cfg = get_qwen_config("qwen-tiny")
+    w = make_seeded_qwen_weights(cfg, seed=3, dtype=torch.bfloat16, lm_head_gain=4.0)
+    tok = FakeQwenTokenizer(cfg.text.vocab)
+    paths = []
+    for i, shape in enumerate([(112, 112, 3), (112, 112, 3), (2, 112, 168, 3)]):
+        p = tmp_path / f"x{i}.npy"
+        np.save(p, np.random.RandomState(i).randint(0, 256, shape, dtype=np.uint8))
+        paths.append(str(p))
+    eng = OracleQwenEngine(cfg, w)
+    m = t2v.VQAScore(model="qwen2.5-vl-7b", device="cpu", config=cfg, engine=eng, tokenizer=tok).model
+    m._gen_eos_ids = []                                    # never stop early: every sample runs the 4 steps
+    texts = ["what is shown", "describe the picture please", "what happens"]
+    out = m.generate(paths, texts, max_new_tokens=4)
+    assert eng.prefills == 2 and len(out) == 3            # two grids -> two batches, one prefill each
+    assert all(len(o.split()) <= 4 and all(t.startswith("t") for t in o.split()) for o in out)
+    # by hand: re-prefill greedy over prompt + generated tokens
+    item = m.load_images([paths[2]])[0]
+    patches, grid = m.preprocess(item)
+    merged = eng.encode_vision(patches, [grid])
+    row = m.build_ids(texts[2], "video", grid[0] * grid[1] * grid[2] // 4)
+    got = []
+    for _ in range(4):
+        ids = torch.tensor([row + got])
+        got.append(int(eng.score_logits(merged, ids, torch.ones_like(ids), [grid]).argmax(-1)))
+    assert out[2] == tok.decode(got)
+    # nucleus sampling: with top_p -> 0 only the most likely token survives, so sampling equals greedy
+    torch.manual_seed(0)
+    assert m.generate(paths[2:], texts[2:], max_new_tokens=3, temperature=0.7, top_p=1e-6) == [tok.decode(got[:3])]
+    torch.manual_seed(0)
+    sampled = m.generate(paths[2:], texts[2:], max_new_tokens=3, temperature=5.0, top_p=0.95)
+    assert len(sampled[0].split()) <= 3
+    # stop ids end a sample; its text excludes the special
+    first = got[0]
+    m._gen_eos_ids = [first]
+    assert m.generate(paths[2:], texts[2:], max_new_tokens=4) == [tok.decode([first])]

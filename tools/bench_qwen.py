@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--cpu-samples", type=int, default=0)
+    ap.add_argument("--decode-steps", type=int, default=0, help="also time N cached decode steps behind one prefill (KV cache)")
     args = ap.parse_args()
     from t2v_metrics_amd.qwen.engine import QwenEngine
     cfg = get_qwen_config(args.model)
@@ -89,6 +90,27 @@ def main():
                            "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": None, "launches": n_gemm,
                            "avg_launch_ms": gemm_ms / n_gemm, "algorithmic_bytes_per_launch": gemm_bytes / n_gemm,
                            "gemm_share_of_step_time": gemm_ms * 1e-3 / dt}
+    if args.decode_steps > 0:
+        # generation beyond the first token: one prefill that keeps the KV cache, then one cached position per step.  A decode step
+        # streams every language-model weight once (2 B x 7.07e9 parameters) and the cached K / V rows: HBM-bound.
+        n = args.decode_steps
+        merged = eng.encode_vision(px, grids)
+        lg, state = eng.prefill(merged, ids, mask, grids, n + 2)
+        tok = lg.argmax(-1)
+        eng.decode(state, tok)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            tok = eng.decode(state, tok).argmax(-1)
+        torch.cuda.synchronize()
+        dtd = (time.perf_counter() - t0) / n
+        t_ = cfg.text
+        wbytes = 2.0 * (t_.layers * (t_.hidden * (t_.heads + 2 * t_.kv_heads) * t_.head_dim + t_.hidden * t_.heads * t_.head_dim + 3 * t_.hidden * t_.mlp)
+                        + t_.vocab * t_.hidden)
+        kvbytes = 2.0 * 2 * t_.layers * B * t_.kv_heads * (L + n / 2) * 128
+        out["decode"] = {"ms_per_step": 1e3 * dtd, "tokens_per_s": B / dtd, "batch": B, "steps": n,
+                         "hbm_bound": {"weight_bytes": wbytes, "kv_bytes": kvbytes, "achieved_GBps": (wbytes + kvbytes) / dtd / 1e9, "peak_GBps": 8000.0,
+                                       "frac": (wbytes + kvbytes) / dtd / 8e12}}
     if args.cpu_samples > 0:
         from oracle.qwen25vl_oracle import QwenOracle
         n = args.cpu_samples
