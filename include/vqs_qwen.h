@@ -96,7 +96,8 @@ int vqs_qwen_decode(vqs_qwen_handle* h, const int32_t* d_ids, const int32_t* d_l
 
 /* Test hook (not part of the drop-in boundary): register a caller-owned device buffer for a named intermediate of the NEXT passes;
  * when a pass produces it, it is copied there on the pass's stream.  Names: vis.pre, vis.<i>.{h,xn0,q0,k0,q,k,v,attn,d_attn,xn1,ff,d_mlp},
- * vis.{h_out,xnm,mid,merged_w}; txt.emb, txt.<i>.{h,xn0,q0,k0,q,k,v,attn,d_attn,xn1,ff,d_mlp}, txt.{h_out,xnf} -- tensors in the ENGINE's
+ * vis.{h_out,xnm,mid,merged_w}; txt.emb, txt.<i>.{h,xn0,q0,k0,q,k,v,attn,d_attn,xn1,ff,d_mlp}, txt.{h_out,xnf}; of vqs_qwen_decode:
+ * dec.emb, dec.<i>.{h,xn0,qkv,q,attn,d_attn,xn1,ff,d_mlp}, dec.{h_out,xnf} -- tensors in the ENGINE's
  * layouts (padded windowed rows, 128-lane heads, q0 / k0 before and q / k after the rotary embedding, padded ff width).  name == NULL clears every tap.
  * tests/test_gpu_qwen.py checks every launch of a pass against the rounding-matched oracle through it. */
 int vqs_qwen_debug_tap(vqs_qwen_handle* h, const char* name, void* d_dst, size_t bytes);

@@ -243,6 +243,68 @@ class QwenEngineRounded:
         last = xn[lay["last_row"].long()]
         return self._emit("txt.logits", self._lin(last, "lm_head.weight"))
 
+    def text_decode(self, token_ids: torch.Tensor, kc, vc, length: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
+        """vqs_qwen_decode (vqs_qwen.cpp; kernels in qwen_decode.hip): ONE further position per sample against the KV cache.
+        token_ids long [B]; kc / vc: per layer [B, kv_heads, Lmax, 128] fp32 holding bf16 values; length long [B] = index of the new
+        position; cos / sin [B, head_dim/2].  Free-running: the new K / V rows are written into kc / vc.  Stage-locked: kc / vc are the
+        ENGINE's cache after the step -- its new rows are compared with the oracle's ("dec.<i>.k_row" / "v_row") and used.
+        One-row attention: fp32 scores * scale, p = exp(t - max) NOT rounded, sum(p v) / sum(p) -> bf16 (qwen_decode_attn_kernel)."""
+        t_ = self.cfg.text
+        r = self.r
+        B = token_ids.shape[0]
+        TH, H, Hkv, hd = t_.hidden, t_.heads, t_.kv_heads, t_.head_dim
+        scale, rep = hd ** -0.5, H // Hkv
+        bi = torch.arange(B)
+        h = self._emit("dec.emb", r(self.w["model.language_model.embed_tokens.weight"])[token_ids.long().clamp(0, t_.vocab - 1)])
+        d_attn = d_mlp = None
+        for i in range(t_.layers):
+            p, t = f"model.language_model.layers.{i}.", f"dec.{i}."
+            if not self._want(i):
+                h = None
+                continue
+            h = self._stream(t + "h", h, d_attn, d_mlp, (B, TH), first=(i == 0))
+            xn = self._emit(t + "xn0", self._norm(h, p + "input_layernorm.weight", t_.rms_eps))
+            parts = [self._heads(self._lin(xn, p + f"self_attn.{n}_proj.weight", p + f"self_attn.{n}_proj.bias"), B, 1, nh, hd).reshape(B, nh * HDP)
+                     for n, nh in (("q", H), ("k", Hkv), ("v", Hkv))]
+            qkv = self._emit(t + "qkv", torch.cat(parts, dim=1))
+            q0 = qkv[:, : H * HDP].reshape(B, H, 1, HDP)
+            k0 = qkv[:, H * HDP: (H + Hkv) * HDP].reshape(B, Hkv, 1, HDP)
+            v0 = qkv[:, (H + Hkv) * HDP:].reshape(B, Hkv, HDP)
+            q = self._emit(t + "q", self._rope(q0, cos, sin, hd).reshape(B, H * HDP)).reshape(B, H, HDP)
+            k_new = self._rope(k0, cos, sin, hd).reshape(B, Hkv, HDP)
+            if self.locked is None:
+                kc[i][bi, :, length.long()] = k_new
+                vc[i][bi, :, length.long()] = v0
+            else:
+                self.report[t + "k_row"] = compare_tap(k_new, kc[i][bi, :, length.long()])
+                self.report[t + "v_row"] = compare_tap(v0, vc[i][bi, :, length.long()])
+            a = torch.zeros(B, H, HDP)
+            for b in range(B):
+                n = int(length[b]) + 1
+                K = kc[i][b, :, :n].repeat_interleave(rep, dim=0).to(self.acc)                    # [H, n, 128]
+                V = vc[i][b, :, :n].repeat_interleave(rep, dim=0).to(self.acc)
+                sc = torch.einsum("hd,hnd->hn", q[b].to(self.acc), K).float() * scale
+                pr = torch.exp(sc - sc.max(-1, keepdim=True).values)
+                a[b] = (torch.einsum("hn,hnd->hd", pr.to(self.acc), V).float() / pr.to(self.acc).sum(-1, keepdim=True).float())
+            a = self._emit(t + "attn", r(a).reshape(B, H * HDP))
+            d_attn = self._emit(t + "d_attn", r(self._lin(self._unpad_heads(a, H, hd), p + "self_attn.o_proj.weight")))
+            xn = self._emit(t + "xn1", self._norm(h + d_attn, p + "post_attention_layernorm.weight", t_.rms_eps))
+            g = self._lin(xn, p + "mlp.gate_proj.weight")
+            u = self._lin(xn, p + "mlp.up_proj.weight")
+            ff = self._emit(t + "ff", r(g * torch.sigmoid(g) * u), cols=t_.mlp)
+            d_mlp = self._emit(t + "d_mlp", r(self._lin(ff, p + "mlp.down_proj.weight")))
+        h = self._stream("dec.h_out", h, d_attn, d_mlp, (B, TH))
+        xn = self._emit("dec.xnf", self._norm(h, "model.language_model.norm.weight", t_.rms_eps))
+        return self._emit("dec.logits", self._lin(xn, "lm_head.weight"))
+
+    def decode_locked(self, taps, token_ids, kc, vc, length, cos, sin, layers: Optional[Sequence[int]] = None) -> Dict[str, dict]:
+        """Stage-locked check of one vqs_qwen_decode call; kc / vc = the engine's cache after the call, "dec.logits" its output."""
+        self.locked, self.layers, self.report = taps, (None if layers is None else set(layers)), {}
+        with torch.no_grad():
+            self.text_decode(token_ids, kc, vc, length, cos, sin)
+        self.locked = None
+        return self.report
+
     # ------------------------------------------------------------------------------------------------ whole passes
     def forward(self, pixel_values: torch.Tensor, vis_lay: Dict[str, torch.Tensor], input_ids: torch.Tensor,
                 txt_lay: Dict[str, torch.Tensor]) -> torch.Tensor:
@@ -307,6 +369,20 @@ def text_tap_shapes(cfg, B: int, L: int, layers: Optional[Sequence[int]] = None)
                     f"txt.{i}.k": hk, f"txt.{i}.v": hk, f"txt.{i}.attn": ((M, t.heads * HDP), b16), f"txt.{i}.d_attn": ((M, TH), b16),
                     f"txt.{i}.xn1": ((M, TH), b16), f"txt.{i}.ff": ((M, _ffld(t.mlp)), b16), f"txt.{i}.d_mlp": ((M, TH), b16)})
     out.update({"txt.h_out": ((M, TH), f32), "txt.xnf": ((M, TH), b16)})
+    return out
+
+
+def decode_tap_shapes(cfg, B: int, layers: Optional[Sequence[int]] = None):
+    """{tap name: (shape, dtype)} of one vqs_qwen_decode call."""
+    t = cfg.text
+    TH, IQ, QN = t.hidden, t.heads * HDP, (t.heads + 2 * t.kv_heads) * HDP
+    f32, b16 = torch.float32, torch.bfloat16
+    out = {"dec.emb": ((B, TH), f32)}
+    for i in (range(t.layers) if layers is None else layers):
+        out.update({f"dec.{i}.h": ((B, TH), f32), f"dec.{i}.xn0": ((B, TH), b16), f"dec.{i}.qkv": ((B, QN), b16), f"dec.{i}.q": ((B, IQ), b16),
+                    f"dec.{i}.attn": ((B, IQ), b16), f"dec.{i}.d_attn": ((B, TH), b16), f"dec.{i}.xn1": ((B, TH), b16),
+                    f"dec.{i}.ff": ((B, _ffld(t.mlp)), b16), f"dec.{i}.d_mlp": ((B, TH), b16)})
+    out.update({"dec.h_out": ((B, TH), f32), "dec.xnf": ((B, TH), b16)})
     return out
 
 

@@ -800,6 +800,7 @@ int vqs_qwen_decode(vqs_qwen_handle* h, const int32_t* d_ids, const int32_t* d_l
     QHIP(h, hipMemsetAsync(w.neg1, 0xff, (size_t)B * sizeof(int), st), "no placeholder rows");
     QHIP(h, vqs::launch_qwen_embed(d_ids, w.neg1, embed, embed, w.hidden, B, TH, c.t_vocab, st), "embed");
     QHIP(h, hipMemsetAsync(w.ff, 0, (size_t)B * h->t_ffld * sizeof(bf16_t), st), "clear ff padding");
+    QTAP("dec", -1, "emb", w.hidden, (size_t)B * TH);
     const bf16_t* pend = nullptr;
     const bf16_t* pend_attn = nullptr;
     for (int i = 0; i < c.t_layers; ++i) {
@@ -809,37 +810,48 @@ int vqs_qwen_decode(vqs_qwen_handle* h, const int32_t* d_ids, const int32_t* d_l
         bf16_t* kc = (bf16_t*)d_kv + (size_t)(2 * i) * kv_slab(h, B, Lmax);
         bf16_t* vc = kc + kv_slab(h, B, Lmax);
         QHIP(h, vqs::launch_rmsnorm(w.hidden, pend_attn ? pend_attn : pend, ln1, w.xn, B, TH, c.t_eps, st, pend_attn ? pend : nullptr, true, XLD), "input_layernorm");
+        QTAP("dec", i, "h", w.hidden, (size_t)B * TH);
+        QRUN(qtap2d(h, "dec", i, "xn0", w.xn, TH, B, XLD, st));
         {   // one position per sample: head-major [B, heads, 1, 128] IS token-major [B, heads * 128]
             GCall g{w.xn, h->t_qkv_w[i], w.qkv};
             g.bias = h->t_qkv_b[i];
             g.M = B; g.N = QN; g.K = TH; g.lda = XLD; g.ldw = TH; g.ldc = QN; g.epi = vqs::EPI_BF16;
             QRUN(qgemm(h, g, st, "decode qkv"));
         }
+        QTAP("dec", i, "qkv", w.qkv, (size_t)B * QN);
         QHIP(h, vqs::launch_qwen_decode_rope_append(w.qkv, d_cos, d_sin, d_len, w.q, kc, vc, B, c.t_heads, c.t_kv_heads, HDP, h->t_hd / 2, Lmax, st),
              "decode rope + append");
+        QTAP("dec", i, "q", w.q, (size_t)B * IQ);
         QHIP(h, vqs::launch_qwen_decode_attn(w.q, kc, vc, d_len, w.attn, B, c.t_heads, c.t_kv_heads, Lmax, scale, st), "decode attention");
+        QTAP("dec", i, "attn", w.attn, (size_t)B * IQ);
         {
             GCall g{w.attn, h->t_o_w[i], w.delta};
             g.M = B; g.N = TH; g.K = IQ; g.lda = IQ; g.ldw = IQ; g.ldc = TH; g.epi = vqs::EPI_BF16;
             QRUN(qgemm(h, g, st, "decode o_proj"));
         }
+        QTAP("dec", i, "d_attn", w.delta, (size_t)B * TH);
         QHIP(h, vqs::launch_rmsnorm(w.hidden, w.delta, ln2, w.xn, B, TH, c.t_eps, st, nullptr, false, XLD), "post_attention_layernorm");
+        QRUN(qtap2d(h, "dec", i, "xn1", w.xn, TH, B, XLD, st));
         pend_attn = w.delta;
         {
             GCall g{w.xn, h->t_gu_w[i], w.ff};
             g.M = B; g.N = 2 * h->t_mlp_p; g.K = TH; g.lda = XLD; g.ldw = XLD; g.ldc = h->t_ffld; g.epi = vqs::EPI_GATED; g.gate_act = 1;
             QRUN(qgemm(h, g, st, "decode gate|up"));
         }
+        QTAP("dec", i, "ff", w.ff, (size_t)B * h->t_ffld);
         {
             GCall g{w.ff, h->t_down_w[i], w.delta2};
             g.M = B; g.N = TH; g.K = h->t_ffld; g.lda = h->t_ffld; g.ldw = h->t_ffld; g.ldc = TH; g.epi = vqs::EPI_BF16;
             QRUN(qgemm(h, g, st, "decode down_proj"));
             pend = w.delta2;
         }
+        QTAP("dec", i, "d_mlp", w.delta2, (size_t)B * TH);
     }
     QW(fin, "model.language_model.norm.weight", TH);
     QW(head, "lm_head.weight", (int64_t)c.t_vocab * TH);
     QHIP(h, vqs::launch_rmsnorm(w.hidden, pend_attn ? pend_attn : pend, fin, w.xn, B, TH, c.t_eps, st, pend_attn ? pend : nullptr, true, XLD), "final norm");
+    QTAP("dec", -1, "h_out", w.hidden, (size_t)B * TH);
+    QRUN(qtap2d(h, "dec", -1, "xnf", w.xn, TH, B, XLD, st));
     {
         GCall g{w.xn, head, d_logits};
         g.M = B; g.N = c.t_vocab; g.K = TH; g.lda = XLD; g.ldw = TH; g.ldc = c.t_vocab; g.epi = vqs::EPI_F32;

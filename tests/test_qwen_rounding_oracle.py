@@ -130,3 +130,38 @@ def test_stage_locked_mode_is_exact_on_its_own_record(golden_dir):
     assert set(text_tap_names(cfg)) <= set(rec)
     rep = o.text_locked(rec, merged, ids, tl)
     assert set(text_tap_names(cfg)) | {"txt.logits"} <= set(rep) and all(r["frac_diff"] == 0.0 for r in rep.values())
+
+
+def test_decode_step_with_roundings_off_equals_a_forward_over_the_longer_sequence():
+    """text_decode against the KV cache of a (recorded) prefill, roundings off, must reproduce the fp32 oracle run over prompt + the
+    new tokens at HF's decode positions -- pins the cache indexing, the grouped-query one-row attention and the position rule."""
+    from t2v_metrics_amd.qwen.layout import decode_tables
+    from tests.test_qwen_host import OracleQwenEngine
+    cfg, w, grids, ids, mask, px = synthetic_case("qwen-tiny", [(2, 8, 8), (2, 8, 12)], seed=9, n_text=(5, 4))
+    o = QwenEngineRounded(cfg, w, round_fn=_identity)
+    ref = OracleQwenEngine(cfg, w)
+    with torch.no_grad():
+        merged = torch.cat([o.vision_tower(px[a: a + n], vision_layout(cfg, [g]))
+                            for a, n, g in [(0, 128, grids[0]), (128, 192, grids[1])]])
+        lay = text_layout(cfg, ids, mask, grids)
+        o.record = {}
+        o.text_logits(merged, ids, lay)
+        rec, o.record = o.record, None
+    B, L = ids.shape
+    steps, Lmax = 2, L + 2
+    t_ = cfg.text
+    kc = [torch.zeros(B, t_.kv_heads, Lmax, 128) for _ in range(t_.layers)]
+    vc = [torch.zeros(B, t_.kv_heads, Lmax, 128) for _ in range(t_.layers)]
+    for i in range(t_.layers):
+        kc[i][:, :, :L] = rec[f"txt.{i}.k"]
+        vc[i][:, :, :L] = rec[f"txt.{i}.v"]
+    _, r_state = ref.prefill(merged, ids, mask, grids, steps + 1)
+    length, pos = lay["seq_len"].long().clone(), lay["next_pos"].clone()
+    forced = torch.randint(10, t_.vocab, (steps, B), generator=torch.Generator().manual_seed(1))
+    for t in range(steps):
+        cos, sin = decode_tables(cfg, pos)
+        with torch.no_grad():
+            lg = o.text_decode(forced[t], kc, vc, length, cos, sin)
+        want = ref.decode(r_state, forced[t])
+        assert (lg - want).abs().max().item() <= 5e-5 * max(1.0, want.abs().max().item()), t
+        length, pos = length + 1, pos + 1
