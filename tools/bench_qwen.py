@@ -85,8 +85,8 @@ def main():
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None}
     if n_gemm > 0 and gemm_ms > 0:
         ach = gemm_flops / (gemm_ms * 1e-3) / 1e12
-        out["roofline"] = {"kernel": "vqs::gemm_bf16_quad + gemm_bf16_persistent (every GEMM launch of the step; padded-head and "
-                                     "gate|up-interleaved shapes as executed)", "bound": "mfma", "achieved": ach, "peak": 2500.0,
+        out["roofline"] = {"kernel": "vqs::gemm_bf16_quad + gemm_bf16_persistent (every GEMM launch of the step; "
+                                     "gate|up-interleaved shapes as executed; language-model heads padded to 128 lanes)", "bound": "mfma", "achieved": ach, "peak": 2500.0,
                            "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": None, "launches": n_gemm,
                            "avg_launch_ms": gemm_ms / n_gemm, "algorithmic_bytes_per_launch": gemm_bytes / n_gemm,
                            "gemm_share_of_step_time": gemm_ms * 1e-3 / dt}
