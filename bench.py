@@ -573,7 +573,8 @@ def cpu_baseline(cfg, weights, job, n_pairs, lp_gpu, reps, with_emulation=False)
     elif float(hip_pair.mean()) > float(ref_pair.mean()):
         violation = "mean |dlogP| vs fp32 truth: HIP %.3e > reference-as-shipped (HF bf16) %.3e" % (float(hip_pair.mean()), float(ref_pair.mean()))
     import transformers
-    out = {"value": n_pairs / med, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "reference-hf-bf16",
+    out = {"value": n_pairs / med, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "reference",
+           "kind_detail": "reference as shipped: the HF modules its CLIP-FlanT5 wrapper calls, bf16, on the host cores (oracle/hf_reference.py)",
            "sample": f"first {n_pairs} pairs of the same batch as ONE batch; HF CLIPVisionModel + T5ForConditionalGeneration in bf16, inference mode; "
                      f"1 warm-up + {len(timed)} timed repetitions, median {med:.2f} s (all: {', '.join('%.2f' % t for t in times)})",
            "stage_seconds_last_rep": stage_s,
