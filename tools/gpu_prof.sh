@@ -6,13 +6,13 @@ mkdir -p $P
 export PYTHONUNBUFFERED=1
 REPO=$(pwd)
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $REPO/$P -o bench -- python $REPO/bench.py --model $MODEL --steps 3 --warmup 1 --cpu-pairs 0 > $REPO/$P/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats -d $REPO/$P -o bench -- python $REPO/bench.py --model $MODEL --steps 3 --warmup 1 --cpu-pairs 0 --also none > $REPO/$P/bench_under_rocprof.log 2>&1
 echo "rocprof exit $?"
 cd $REPO
 
 # keep only the small summaries (kernel trace csv can be large)
 find $P -name "*kernel_trace*" -size +20M -delete
-python tools/rocpd_summary.py $P/bench_results.db $P/summary "rocprofv3 --kernel-trace --stats -- python bench.py --model $MODEL --steps 3 --warmup 1 --cpu-pairs 0" > /dev/null 2>&1
+python tools/rocpd_summary.py $P/bench_results.db $P/summary "rocprofv3 --kernel-trace --stats -- python bench.py --model $MODEL --steps 3 --warmup 1 --cpu-pairs 0 --also none" > /dev/null 2>&1
 python - $P <<'PY'
 import sqlite3, sys
 P = sys.argv[1]
