@@ -50,7 +50,7 @@ def _kernels(src):
     return out
 
 
-@pytest.mark.parametrize("src", ["gemm.hip", "attn.hip", "elementwise.hip"])
+@pytest.mark.parametrize("src", ["gemm.hip", "attn.hip", "elementwise.hip", "qwen_decode.hip"])
 def test_no_kernel_spills_or_exceeds_the_cu(src):
     for name, k in _kernels(src).items():
         if name == "__asm__":
@@ -59,6 +59,17 @@ def test_no_kernel_spills_or_exceeds_the_cu(src):
         assert k["lds"] <= LDS_PER_CU, (name, k)
         # a 512-thread workgroup is two waves per SIMD: at most 256 registers per lane each
         assert k["vgpr"] <= (256 if k["wg"] > 256 else 512), (name, k)
+
+
+def test_decode_attention_fits_its_largest_cache_in_lds():
+    """qwen_decode_attn_kernel keeps one fp32 score per cached position in dynamic LDS next to its static q / partial-row buffers:
+    the launcher's Lmax limit (36 864 positions) must fit the CU together with them."""
+    ks = _kernels("qwen_decode.hip")
+    k = [v for n, v in ks.items() if "qwen_decode_attn_kernel" in n]
+    assert len(k) == 1
+    assert k[0]["lds"] + 36864 * 4 <= LDS_PER_CU, k[0]
+    src = open(os.path.join(CSRC, "qwen_decode.hip")).read()
+    assert "Lmax > 36864" in src
 
 
 def _resident(static_lds, dynamic_lds):

@@ -19,7 +19,7 @@ pytestmark = pytest.mark.skipif(not (os.path.exists(HIPCC) and os.path.exists(CL
 
 
 def test_host_abi_under_asan_and_ubsan():
-    dev_objs = [os.path.join(OBJ, f) for f in ("gemm.hip.o", "attn.hip.o", "elementwise.hip.o")]
+    dev_objs = [os.path.join(OBJ, f) for f in ("gemm.hip.o", "attn.hip.o", "elementwise.hip.o", "qwen_decode.hip.o")]
     if not all(os.path.exists(o) for o in dev_objs):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "t2v_metrics_amd", "csrc"), "-j4"], stdout=subprocess.DEVNULL)
     out = os.path.join(ROOT, "build", "asan")
