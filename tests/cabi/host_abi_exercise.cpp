@@ -67,6 +67,32 @@ int main() {
     assert(vqs_create(&bad, &hb) != 0);
     vqs_destroy(hb);
     assert(vqs_create(nullptr, &hb) != 0);
+    {   // Qwen2.5-VL row: sizes, options and the calls that must fail cleanly before any device access
+        vqs_qwen_config q;
+        memset(&q, 0, sizeof q);
+        q.v_depth = 32; q.v_hidden = 1280; q.v_heads = 16; q.v_mlp = 3420; q.v_patch_dim = 1176; q.v_merge_unit = 4; q.v_out_hidden = 3584;
+        q.v_fullatt_mask = (1 << 7) | (1 << 15) | (1 << 23) | (int32_t)(1u << 31); q.v_eps = 1e-6f;
+        q.t_vocab = 152064; q.t_hidden = 3584; q.t_layers = 28; q.t_heads = 28; q.t_kv_heads = 4; q.t_mlp = 18944; q.t_eps = 1e-6f;
+        vqs_qwen_handle* qh = nullptr;
+        assert(vqs_qwen_create(&q, &qh) == 0 && qh);
+        assert(vqs_qwen_packed_bytes(qh) > 0);
+        assert(vqs_qwen_vision_workspace_bytes(qh, 3072, 3072) > 0 && vqs_qwen_vision_workspace_bytes(qh, 3071, 3072) == 0);
+        assert(vqs_qwen_score_workspace_bytes(qh, 64, 808) > 0 && vqs_qwen_score_workspace_bytes(qh, 0, 808) == 0);
+        // KV cache: 28 layers x (K, V) x [B, 4, Lmax, 128] bf16
+        assert(vqs_qwen_kv_bytes(qh, 64, 816) == (size_t)2 * 28 * 64 * 4 * 816 * 128 * 2 && vqs_qwen_kv_bytes(qh, 0, 816) == 0);
+        assert(vqs_qwen_decode_workspace_bytes(qh, 64) > 0 && vqs_qwen_decode_workspace_bytes(qh, 0) == 0);
+        assert(vqs_qwen_debug_option(qh, "x_pitch", 4096) == 0 && vqs_qwen_debug_option(qh, "x_pitch", 3584) == 0);
+        assert(vqs_qwen_debug_option(qh, "x_pitch", 3000) != 0 && vqs_qwen_debug_option(qh, "x_pitch", 3600) != 0 && vqs_qwen_debug_option(qh, "nope", 1) != 0);
+        assert(strlen(vqs_qwen_last_error(qh)) > 0);
+        assert(vqs_qwen_debug_tap(qh, "txt.3.xn0", &dummy, 4) == 0 && vqs_qwen_debug_tap(qh, nullptr, nullptr, 0) == 0);
+        assert(vqs_qwen_decode(qh, &dummy, &dummy, nullptr, nullptr, 1, 16, &dummy, 1 << 20, nullptr, &dummy, 1 << 20, nullptr) != 0);   // not bound
+        assert(vqs_qwen_prefill(qh, &dummy, &dummy, &dummy, &dummy, &dummy, nullptr, nullptr, 1, 16, nullptr, &dummy, 16, nullptr, 0, 16, nullptr) != 0);
+        assert(vqs_qwen_prefill(qh, &dummy, &dummy, &dummy, &dummy, &dummy, nullptr, nullptr, 1, 16, nullptr, &dummy, 16, &dummy, 16, 8, nullptr) != 0);   // Lmax < L
+        assert(vqs_qwen_score(qh, &dummy, &dummy, &dummy, &dummy, &dummy, nullptr, nullptr, 1, 16, nullptr, &dummy, 16, nullptr) != 0);
+        vqs_qwen_destroy(qh);
+        q.t_heads = 27;        // hidden not divisible by heads
+        assert(vqs_qwen_create(&q, &qh) != 0);
+    }
     printf("host ABI exercise under ASan/UBSan: ok\n");
     return 0;
 }
