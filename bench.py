@@ -353,8 +353,15 @@ def main():
     ordered = info["scaling"] == "strong"
     local = torch.zeros(n_total if ordered else steps_local * B, device=device)
     lp = None
+    # per-step device time (HIP events on the launch stream, recorded without synchronising; read after the closing barrier): shows
+    # whether a long run drifts -- sustained board power -- or the box is simply slower
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(jobs) + 1)] if device.type == "cuda" else None
+    if step_ev:
+        step_ev[0].record()
     for si, job in enumerate(jobs):
         lp, sc = run(job)
+        if step_ev:
+            step_ev[si + 1].record()
         if ordered:
             local[job[4]] = sc                     # scatter back to input order (other ranks' slots stay 0)
         else:
@@ -370,6 +377,7 @@ def main():
         final = local
     barrier()
     elapsed_local = time.perf_counter() - t0
+    step_ms = [round(step_ev[i].elapsed_time(step_ev[i + 1]), 2) for i in range(len(jobs))] if step_ev else None
     eng.profile(False)
     gemm_bytes = eng.profile_bytes()
     n_gemm, gemm_ms, gemm_flops = eng.profile_read(reset=True)
@@ -427,6 +435,7 @@ def main():
         "ranks_seen": ranks_seen,
         "collective": (backend + (" (RCCL over xGMI)" if backend == "nccl" else "")) if dist is not None else None,
         "per_rank_pairs_per_s": per_rank_list,
+        "step_ms_rank0": step_ms,
         "scores_checksum": float(final.double().sum().item()),
         # FLOPs of the REFERENCE algorithm (SURVEY.md §8d formula).  The engine's reassociated decoder
         # cross-attention executes 4*S_e*D*I*layers fewer FLOPs per pair than that (same function);
