@@ -83,8 +83,8 @@ int vqs_qwen_score(vqs_qwen_handle* h, const void* d_merged, const int32_t* d_in
  * embedding) and V in a caller-owned cache; vqs_qwen_decode runs ONE further position per sample against it.
  *   d_kv         bf16, vqs_qwen_kv_bytes(B, Lmax): per layer K then V, each [B, t_kv_heads, Lmax, 128]; Lmax >= L + steps to come
  *   decode: d_ids int32 [B] the token entering each sample, d_len int32 [B] its index in the sample's sequence (= tokens cached so
- *   far; the caller advances it), d_cos / d_sin fp32 [B, head_dim/2] rotary table of that position (all three M-RoPE axes equal
- *   max(prompt position) + 1 + step, HF get_rope_index rope_deltas); d_logits fp32 [B, t_vocab] of the new position.
+ *   far; the caller advances it), d_cos / d_sin fp32 [B, head_dim/2] rotary table of that position (each M-RoPE axis at the prompt's
+ *   last position + 1 + step, as HF generate advances position_ids); d_logits fp32 [B, t_vocab] of the new position.
  * Samples that have stopped may be fed any token: rows are independent. */
 size_t vqs_qwen_kv_bytes(const vqs_qwen_handle* h, int32_t B, int32_t Lmax);
 int vqs_qwen_prefill(vqs_qwen_handle* h, const void* d_merged, const int32_t* d_input_ids, const int32_t* d_vis_slot,

@@ -309,6 +309,54 @@ def golden_qwen(name: str, seed: int, grids, text_lens, gain: float, tag: str = 
     print(path, os.path.getsize(path) // 1024, "KiB", "logits range", float(torch.stack(logits_all).min()), float(torch.stack(logits_all).max()))
 
 
+def golden_qwen_generate(name: str, seed: int, grids, text_lens, gain: float, steps: int, tag: str):
+    """HF generate WITH its KV cache, greedy, `steps` tokens per sample (batch 1 each, as the reference runs it,
+    qwen2vl_model.py:222-230): stores the prompt, the pixels, the generated ids and the scores of every step.  Pins what
+    vqs_qwen_prefill / vqs_qwen_decode must reproduce: the cached forward and the position of a generated token (cache position +
+    rope_delta, get_rope_index) -- including a video whose temporal positions run past its spatial ones, where that rule and
+    "continue behind the last text token" differ."""
+    from t2v_metrics_amd.qwen import get_qwen_config
+    from t2v_metrics_amd.qwen.weights import make_seeded_qwen_weights
+    cfg = get_qwen_config(name)
+    w = make_seeded_qwen_weights(cfg, seed=seed, dtype=torch.bfloat16, lm_head_gain=gain)
+    m = build_hf_qwen(cfg, w)
+    g = torch.Generator().manual_seed(seed + 5)
+    v = cfg.vision
+    pix, ids_rows, gen_ids, gen_scores, pos_max = [], [], [], [], []
+    for (t, h, wd), (n_pre, n_post) in zip(grids, text_lens):
+        n_patches = t * h * wd
+        pv = torch.randn(n_patches, v.patch_dim, generator=g).to(torch.bfloat16).float()
+        n_merged = n_patches // v.merge_unit
+        pre = torch.randint(10, cfg.text.vocab, (n_pre,), generator=g)
+        post = torch.randint(10, cfg.text.vocab, (n_post,), generator=g)
+        ids = torch.cat([pre, torch.tensor([cfg.vision_start_token_id]), torch.full((n_merged,), cfg.video_token_id),
+                         torch.tensor([cfg.vision_end_token_id]), post])[None]
+        mm_type = torch.where(ids == cfg.video_token_id, 2, 0)
+        with torch.no_grad():
+            m.model.rope_deltas = None
+            gen = m.generate(input_ids=ids, attention_mask=torch.ones_like(ids), pixel_values_videos=pv, mm_token_type_ids=mm_type,
+                             video_grid_thw=torch.tensor([[t, h, wd]]), max_new_tokens=steps, min_new_tokens=steps, do_sample=False,
+                             output_scores=True, return_dict_in_generate=True, use_cache=True)
+            m.model.rope_deltas = None
+            pos, _ = m.model.get_rope_index(ids, mm_token_type_ids=mm_type, video_grid_thw=torch.tensor([[t, h, wd]]),
+                                            attention_mask=torch.ones_like(ids))
+        assert len(gen.scores) == steps
+        pix.append(pv); ids_rows.append(ids[0]); gen_ids.append(gen.sequences[0, ids.shape[1]:])
+        gen_scores.append(torch.stack([sc[0].float() for sc in gen.scores])); pos_max.append(int(pos.max()))
+    B, L = len(grids), max(len(r) for r in ids_rows)
+    ids_pad = torch.zeros(B, L, dtype=torch.long)
+    mask = torch.zeros(B, L, dtype=torch.long)
+    for b, r in enumerate(ids_rows):
+        ids_pad[b, : len(r)] = r
+        mask[b, : len(r)] = 1
+    path = os.path.join(GOLDEN, f"qwen_{name.split('-')[-1]}{tag}.npz")
+    np.savez_compressed(path, seed=seed, gain=gain, grids=np.asarray(grids), input_ids=ids_pad.numpy(), attention_mask=mask.numpy(),
+                        pixel_values=torch.cat(pix).numpy(), gen_ids=torch.stack(gen_ids).numpy(), gen_scores=torch.stack(gen_scores).numpy(),
+                        prompt_position_max=np.asarray(pos_max))
+    print(path, os.path.getsize(path) // 1024, "KiB", "generated", torch.stack(gen_ids).tolist(), "max prompt positions", pos_max,
+          "prompt lengths", [len(r) for r in ids_rows])
+
+
 def golden_preprocess():
     """HF CLIPImageProcessor (PIL backend here: no torchvision) on seeded images at a small target size."""
     from PIL import Image
@@ -342,3 +390,7 @@ if __name__ == "__main__":
     golden_qwen("qwen-tiny", seed=51, grids=[(2, 8, 8), (1, 4, 12), (3, 12, 8)], text_lens=[(3, 4), (5, 2), (2, 6)], gain=4.0)
     golden_qwen("qwen-small", seed=52, grids=[(2, 8, 16), (2, 16, 8)], text_lens=[(4, 5), (3, 7)], gain=4.0)
     golden_qwen("qwen-tiny", seed=53, grids=[(2, 6, 10), (1, 10, 6), (2, 6, 10)], text_lens=[(3, 4), (5, 2), (2, 3)], gain=4.0, tag="_ragged")
+    # generation with HF's KV cache; the second video is long and narrow: 8 temporal patches x 2 tokens/s run to position 14 while the
+    # spatial axes advance the cursor by 2
+    golden_qwen_generate("qwen-tiny", seed=54, grids=[(2, 8, 8), (8, 4, 4), (1, 4, 12)], text_lens=[(3, 4), (2, 3), (5, 2)], gain=4.0,
+                         steps=4, tag="_gen4")

@@ -107,16 +107,19 @@ def text_layout(cfg: Qwen25VLConfig, input_ids: torch.Tensor, attention_mask: to
     sec = list(t_.mrope_section)
     ang = torch.cat([m[i % 3] for i, m in enumerate(freqs.split(sec, dim=-1))], dim=-1).reshape(B * L, hd // 2)
     last_row = torch.arange(B) * L + seq_len - 1
-    # position of the first generated token: HF decodes at cache_position + rope_delta, rope_delta = max(position) + 1 - length
-    # (get_rope_index), i.e. all three axes at max over the prompt's positions + 1 (+ step)
-    next_pos = torch.stack([pos[:, b, : int(seq_len[b])].max() + 1 for b in range(B)])
+    # position of the first generated token: HF generate advances the prompt's LAST position by one on each axis per new token
+    # (GenerationMixin updates position_ids incrementally; pinned by tests/golden/qwen_tiny_gen4.npz, whose long narrow video
+    # separates this rule from "max prompt position + 1", the rope_deltas formula the cached forward would use on its own)
+    next_pos = torch.stack([pos[:, b, int(seq_len[b]) - 1] + 1 for b in range(B)], dim=1)          # [3, B]
     return {"vis_slot": vis_slot.to(torch.int32), "seq_len": seq_len.to(torch.int32), "last_row": last_row.to(torch.int32),
             "cos": ang.cos().contiguous(), "sin": ang.sin().contiguous(), "position_ids": pos, "next_pos": next_pos}
 
 
 def decode_tables(cfg: Qwen25VLConfig, positions: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-    """positions long [B] (the same on all three M-RoPE axes: generated tokens are text) -> cos, sin fp32 [B, head_dim/2]."""
+    """positions long [3, B] (t, h, w axes of the new token; equal when the prompt ends in text) -> cos, sin fp32 [B, head_dim/2],
+    M-RoPE sections applied as in text_layout."""
     hd = cfg.text.head_dim
     inv_freq = 1.0 / (cfg.text.rope_theta ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
-    ang = positions[:, None].float() * inv_freq
+    freqs = positions[..., None].float() * inv_freq                                  # [3, B, hd/2]
+    ang = torch.cat([m[i % 3] for i, m in enumerate(freqs.split(list(cfg.text.mrope_section), dim=-1))], dim=-1)
     return ang.cos().contiguous(), ang.sin().contiguous()

@@ -57,7 +57,7 @@ class OracleQwenEngine:
             return hid[torch.arange(hid.shape[0]), last] @ o._w("lm_head.weight").t()
 
     # generation with a "cache": the double re-runs the fp32 forward over prompt + tokens so far, the generated tokens at the
-    # positions HF's cached decode uses (max prompt position + 1 + step on all three axes)
+    # positions HF generate uses (the prompt's last position + 1 + step on each axis)
     def prefill(self, merged, input_ids, attention_mask, grids, max_new_tokens):
         state = {"merged": merged, "ids": input_ids.clone(), "mask": attention_mask.clone(), "grids": grids, "new": [], "steps": 0}
         self.prefills = getattr(self, "prefills", 0) + 1
@@ -83,7 +83,7 @@ class OracleQwenEngine:
             ids[b, nb: nb + t] = torch.stack([x[b] for x in state["new"]])
             mask[b, : nb + t] = 1
             pos[:, b, :nb] = pos0[:, b, :nb]
-            pos[:, b, nb: nb + t] = pos0[:, b, :nb].max() + 1 + torch.arange(t)
+            pos[:, b, nb: nb + t] = (pos0[:, b, nb - 1] + 1)[:, None] + torch.arange(t)[None]
         with torch.no_grad():
             emb = o._w("model.language_model.embed_tokens.weight")[ids]
             m = (ids == c.video_token_id) & mask.bool()
@@ -306,3 +306,40 @@ def test_generation_is_one_prefill_plus_cached_steps_and_generate_returns_text(t
     first = got[0]
     m._gen_eos_ids = [first]
     assert m.generate(paths[2:], texts[2:], max_new_tokens=4) == [tok.decode([first])]
+
+
+def test_cached_generation_matches_hf_generate_fixture(golden_dir):
+    """tests/golden/qwen_tiny_gen4.npz = HF generate(use_cache=True, do_sample=False, 4 tokens) per sample, made by
+    oracle/make_golden.py::golden_qwen_generate.  The fp32 double's prefill + decode (the semantics vqs_qwen_prefill / vqs_qwen_decode
+    are stage-locked to) must give HF's scores at every step on the ragged batch -- which pins the position rule of generated tokens
+    (the prompt's last position + 1 + step on each axis, what HF generate does): sample 1 is a long narrow video whose temporal
+    positions (up to 17) run far past its last text token (position 8), where "max prompt position + 1" -- the rope_deltas formula --
+    would rotate the new token differently (it misses HF's scores by 1.4 there)."""
+    import os
+    from t2v_metrics_amd.qwen.layout import text_layout
+    z = np.load(os.path.join(golden_dir, "qwen_tiny_gen4.npz"))
+    cfg = get_qwen_config("qwen-tiny")
+    w = make_seeded_qwen_weights(cfg, seed=int(z["seed"]), dtype=torch.bfloat16, lm_head_gain=float(z["gain"]))
+    grids = [tuple(int(x) for x in g) for g in z["grids"]]
+    ids, mask = torch.from_numpy(z["input_ids"]), torch.from_numpy(z["attention_mask"])
+    px = torch.from_numpy(z["pixel_values"])
+    want, want_ids = torch.from_numpy(z["gen_scores"]), torch.from_numpy(z["gen_ids"])          # [B, steps, vocab], [B, steps]
+    lay = text_layout(cfg, ids, mask, grids)
+    n1 = int(mask[1].sum())                                      # the long video: the decode position is NOT "max prompt position + 1"
+    assert lay["next_pos"][:, 1].tolist() == [9, 9, 9] and int(z["prompt_position_max"][1]) + 1 == 18
+    assert lay["next_pos"][:, 1].tolist() == (lay["position_ids"][:, 1, n1 - 1] + 1).tolist()
+    eng = OracleQwenEngine(cfg, w)
+    merged, off = [], 0
+    for g in grids:
+        n = g[0] * g[1] * g[2]
+        merged.append(eng.encode_vision(px[off: off + n], [g]))
+        off += n
+    merged = torch.cat(merged)
+    steps = want.shape[1]
+    logits, state = eng.prefill(merged, ids, mask, grids, steps)
+    scale = max(1.0, want.abs().max().item())
+    for t in range(steps):
+        assert (logits - want[:, t]).abs().max().item() <= 5e-4 * scale, t
+        assert logits.argmax(-1).tolist() == want_ids[:, t].tolist()
+        if t + 1 < steps:
+            logits = eng.decode(state, want_ids[:, t])
