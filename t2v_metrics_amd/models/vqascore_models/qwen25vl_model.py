@@ -294,6 +294,16 @@ class Qwen25VLModel(VQAScoreModel):
                     scores[i] = float(torch.prod(p.double()) ** (1.0 / n_ans))
         return scores
 
+    @staticmethod
+    def _warp(scores: torch.Tensor, temperature: float, top_p: float) -> torch.Tensor:
+        """HF TemperatureLogitsWarper then TopPLogitsWarper (generation/logits_process.py): scores / temperature; sorted ascending,
+        the low tail whose cumulative probability is <= 1 - top_p is set to -inf, the most likely token always stays."""
+        x = scores.float() / temperature
+        srt, idx = x.sort(-1, descending=False)
+        drop = torch.softmax(srt, -1).cumsum(-1) <= (1.0 - top_p)
+        drop[..., -1:] = False
+        return x.masked_fill(torch.zeros_like(drop).scatter(-1, idx, drop), float("-inf"))
+
     def _greedy(self, merged, rows: List[List[int]], grids, max_new_tokens: int, stops: List[int], pick=None):
         """Shared generation loop: prompt rows (token id lists, one video run each) -> (per-sample list of processed score rows,
         per-sample generated ids).  `pick(proc) -> next ids` defaults to argmax (do_sample=False)."""
@@ -341,12 +351,7 @@ class Qwen25VLModel(VQAScoreModel):
         pick = None
         if do_sample and temperature > 0:
             def pick(proc):
-                lp = torch.log_softmax(proc.float() / temperature, -1)
-                srt, idx = lp.sort(-1, descending=False)
-                drop = srt.exp().cumsum(-1) <= (1.0 - top_p)          # HF TopPLogitsWarper: remove the low tail, keep >= 1 token
-                drop[..., -1] = False
-                lp = lp.masked_fill(torch.zeros_like(drop).scatter(-1, idx, drop), float("-inf"))
-                return torch.multinomial(torch.softmax(lp, -1), 1)[:, 0]
+                return torch.multinomial(torch.softmax(self._warp(proc, temperature, top_p), -1), 1)[:, 0]
         stops = self._stop_ids()
         out = [""] * len(images)
         groups: Dict[Tuple[int, int, int], List[int]] = {}

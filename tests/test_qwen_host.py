@@ -343,3 +343,21 @@ def test_cached_generation_matches_hf_generate_fixture(golden_dir):
         assert logits.argmax(-1).tolist() == want_ids[:, t].tolist()
         if t + 1 < steps:
             logits = eng.decode(state, want_ids[:, t])
+
+
+def test_logits_processing_equals_hf_processors():
+    """The wrapper's repetition penalty and temperature + nucleus filter against HF's own processors on random scores."""
+    lp = pytest.importorskip("transformers.generation.logits_process")
+    g = torch.Generator().manual_seed(3)
+    scores = torch.randn(5, 300, generator=g) * 3
+    rows = [torch.randint(0, 300, (int(n),), generator=g).tolist() for n in (7, 40, 1, 120, 12)]
+    cfg = get_qwen_config("qwen-tiny")
+    m = Qwen25VLModel(model_name="qwen2.5-vl-7b", device="cpu", config=cfg, engine=object(), tokenizer=FakeQwenTokenizer(cfg.text.vocab))
+    m.repetition_penalty = 1.05
+    want = torch.stack([lp.RepetitionPenaltyLogitsProcessor(1.05)(torch.tensor([r]), scores[k: k + 1].clone())[0] for k, r in enumerate(rows)])
+    assert torch.equal(m._processed_scores(scores, rows), want)
+    for temperature, top_p in ((0.7, 0.9), (1.3, 0.5), (1.0, 0.999), (2.0, 1e-6)):
+        ref = lp.TopPLogitsWarper(top_p)(None, lp.TemperatureLogitsWarper(temperature)(None, scores.clone()))
+        got = Qwen25VLModel._warp(scores, temperature, top_p)
+        assert torch.equal(torch.isinf(got), torch.isinf(ref)) and torch.allclose(got[~torch.isinf(got)], ref[~torch.isinf(ref)])
+    assert int((~torch.isinf(Qwen25VLModel._warp(scores, 2.0, 1e-6))).sum()) == scores.shape[0]      # only the top token survives
