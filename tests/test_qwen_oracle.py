@@ -74,3 +74,53 @@ def test_host_layout_matches_hf(golden_dir, name):
             blk = rm[wi * vl["win_len"]: (wi + 1) * vl["win_len"]]
             assert bool((blk[:nv] >= 0).all()) and bool((blk[nv:] < 0).all())
 
+
+
+def test_layout_equals_hf_index_functions_on_random_grids():
+    """Bit-exact integer work against HF's own functions (the installed transformers, tiny model on the CPU), over random grids with
+    and without partial windows and random prompts: window permutation + window lengths (get_window_index), 2-D rotary positions of
+    the tower (rot_pos_emb), 3-D M-RoPE positions of the prompt (get_rope_index) -- for the oracle's restatements and for
+    t2v_metrics_amd/qwen/layout.py, the arrays the HIP path is fed."""
+    pytest.importorskip("transformers")
+    from oracle.make_golden import build_hf_qwen
+    from oracle.qwen25vl_oracle import frame_seqlens, mrope_position_ids, vision_position_ids, vision_window_index
+    from t2v_metrics_amd.qwen.layout import text_layout, vision_layout
+    cfg = get_qwen_config("qwen-tiny")
+    w = make_seeded_qwen_weights(cfg, seed=1, dtype=torch.bfloat16)
+    m = build_hf_qwen(cfg, w)
+    v = cfg.vision
+    rng = np.random.RandomState(7)
+    for trial in range(25):
+        t, gh, gw = int(rng.randint(1, 9)), int(rng.randint(1, 12)), int(rng.randint(1, 12))
+        g = (t, gh * v.spatial_merge, gw * v.spatial_merge)
+        thw = torch.tensor([list(g)])
+        hf_idx, hf_cu = m.model.visual.get_window_index(thw)
+        hf_cu = torch.unique_consecutive(torch.tensor(hf_cu)).tolist()
+        widx, cu = vision_window_index([g], v.spatial_merge, v.window, v.patch)
+        assert torch.equal(widx, torch.as_tensor(hf_idx).long()) and list(cu) == hf_cu, g
+        vl = vision_layout(cfg, [g])
+        cells = vl["row_map"].long().view(-1, v.merge_unit)[:, 0]
+        assert torch.equal(cells[cells >= 0] // v.merge_unit, torch.as_tensor(hf_idx).long()), g
+        assert vl["win_valid"].tolist() == [b - a for a, b in zip(hf_cu[:-1], hf_cu[1:])]
+        assert frame_seqlens([g]) == [i * g[1] * g[2] for i in range(t + 1)]
+        # tower rotary table: HF rot_pos_emb gives the angles [N, head_dim/2] in the ORIGINAL patch order
+        hf_rot = m.model.visual.rot_pos_emb(thw).float()
+        assert torch.allclose(torch.cos(hf_rot), vl["cos_f"], atol=1e-6) and torch.allclose(torch.sin(hf_rot), vl["sin_f"], atol=1e-6), g
+        pid = vision_position_ids([g], v.spatial_merge)
+        dim = v.head_dim // 2
+        inv_freq = 1.0 / (10000.0 ** (torch.arange(0, dim, 2, dtype=torch.float32) / dim))
+        assert torch.allclose((pid.unsqueeze(-1).float() * inv_freq).flatten(1), hf_rot, atol=1e-6)
+        # prompt positions
+        n_merged = t * gh * gw
+        pre = torch.randint(10, cfg.text.vocab, (int(rng.randint(0, 6)),))
+        post = torch.randint(10, cfg.text.vocab, (int(rng.randint(1, 7)),))
+        ids = torch.cat([pre, torch.tensor([cfg.vision_start_token_id]), torch.full((n_merged,), cfg.video_token_id),
+                         torch.tensor([cfg.vision_end_token_id]), post])[None]
+        mask = torch.ones_like(ids)
+        hf_pos, hf_delta = m.model.get_rope_index(ids, mm_token_type_ids=torch.where(ids == cfg.video_token_id, 2, 0), video_grid_thw=thw,
+                                                  attention_mask=mask)
+        lay = text_layout(cfg, ids, mask, [g])
+        assert torch.equal(lay["position_ids"], hf_pos), g
+        assert torch.equal(mrope_position_ids(ids, mask, cfg.image_token_id, cfg.video_token_id, [], [g], v.spatial_merge,
+                                              v.tokens_per_second), hf_pos), g
+        assert int(hf_delta) == int(hf_pos.max()) + 1 - ids.shape[1]
