@@ -119,6 +119,46 @@ def csrc_hash():
     return h.hexdigest()[:16]
 
 
+def device_code_hash(path=None):
+    """sha256 over the `.hip_fatbin` section of the shipped library = the device code the process actually runs.  The stronger of the
+    two stamps: it survives edits that do not change the shipped kernels (comments, host code, `-DVQS_LAB`-only blocks; the build is
+    deterministic -- a comment-only edit of gemm_quad.inc rebuilds to the same section) and changes with anything that does, the
+    compiler included.  None if the library or the section is missing."""
+    import hashlib
+    import struct
+    path = path or os.path.join(ROOT, "t2v_metrics_amd", "libvqs_hip.so")
+    try:
+        with open(path, "rb") as f:
+            b = f.read()
+        if b[:4] != b"\x7fELF" or b[4] != 2:
+            return None
+        shoff = struct.unpack_from("<Q", b, 0x28)[0]
+        shentsize, shnum, shstrndx = struct.unpack_from("<HHH", b, 0x3A)
+
+        def sh(i):
+            name, _typ, _flags, _addr, off, size = struct.unpack_from("<IIQQQQ", b, shoff + i * shentsize)
+            return name, off, size
+        _, stroff, strsize = sh(shstrndx)
+        names = b[stroff: stroff + strsize]
+        for i in range(shnum):
+            n, off, size = sh(i)
+            if names[n: names.index(b"\0", n)] == b".hip_fatbin":
+                return hashlib.sha256(b[off: off + size]).hexdigest()[:16]
+    except Exception:
+        return None
+    return None
+
+
+def traffic_stamp_matches(tj):
+    """Is the PMC record `tj` (profiles/gemm_traffic_*.json) about the code this process runs?  Device-code stamp if the record has
+    one, else the source stamp of older records.  -> (bool, description)."""
+    if tj.get("device_code_sha256_16"):
+        now = device_code_hash()
+        return tj["device_code_sha256_16"] == now, "device code sha256 %s (now %s)" % (tj["device_code_sha256_16"], now)
+    now = csrc_hash()
+    return tj.get("csrc_sha256_16") == now, "csrc sha256 %s (now %s)" % (tj.get("csrc_sha256_16"), now)
+
+
 ALSO_LEGS = {
     # name: (argv after the interpreter, what BASELINE.json config it is)
     "xl": (["bench.py", "--model", "clip-flant5-xl", "--steps", "5", "--warmup", "2", "--cpu-pairs", "0", "--also", "none"],
@@ -460,14 +500,14 @@ def main():
         if os.path.exists(tpath) and args.workload == "synthetic" and args.pairs == 0 and not args.ragged:
             with open(tpath) as f:
                 tj = json.load(f)
-            # PMC counters cannot be read in-process: the number is valid only for the kernel sources it was measured on
-            if tj.get("csrc_sha256_16") == csrc_hash():
+            # PMC counters cannot be read in-process: the number is valid only for the device code it was measured on
+            same, how = traffic_stamp_matches(tj)
+            if same:
                 out["roofline"]["traffic"] = tj["traffic_bytes_per_launch"]
                 out["roofline"]["traffic_unit"] = ("bytes per launch (HBM-side: 2 x FETCH_SIZE + WRITE_SIZE), rocprofv3 --pmc passes over this command "
-                                                   "on the same kernel sources (csrc sha256 %s): profiles/%s" % (tj["csrc_sha256_16"], os.path.basename(tpath)))
+                                                   "on the same code, %s: profiles/%s" % (how, os.path.basename(tpath)))
             else:
-                out["roofline"]["traffic_unit"] = ("null: profiles/%s was measured on other kernel sources (csrc sha256 %s, now %s)"
-                                                   % (os.path.basename(tpath), tj.get("csrc_sha256_16"), csrc_hash()))
+                out["roofline"]["traffic_unit"] = "null: profiles/%s was measured on other code, %s" % (os.path.basename(tpath), how)
 
     default_run = (world == 1 and not double and args.model == "clip-flant5-xxl" and args.workload == "synthetic" and args.pairs == 0
                    and not args.ragged and not args.opt and B == 256)

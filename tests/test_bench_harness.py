@@ -62,3 +62,23 @@ def test_length_buckets_are_a_permutation_with_minimal_padding():
     waste = sum(int((lens[b].max() - lens[b]).sum()) for b in buckets)
     unsorted_waste = sum(int((lens[s:s + 256].max() - lens[s:s + 256]).sum()) for s in range(0, 9600, 256))
     assert waste <= 9600 and waste * 10 < unsorted_waste       # < 1 padded token per pair vs ~16 unsorted
+
+
+def test_traffic_provenance_stamps():
+    """roofline.traffic is reported only while the PMC record is about the code that runs: the device-code stamp (sha256 of the
+    library's .hip_fatbin section) when the record carries one, the source stamp otherwise."""
+    import json
+    import bench
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "t2v_metrics_amd", "libvqs_hip.so")
+    if not os.path.exists(so):
+        pytest.skip("library not built")
+    h = bench.device_code_hash()
+    assert h and len(h) == 16 and h == bench.device_code_hash(so)
+    assert bench.device_code_hash(__file__) is None                                  # not an ELF file
+    ok, how = bench.traffic_stamp_matches({"device_code_sha256_16": h, "csrc_sha256_16": "stale"})
+    assert ok and h in how                                                            # the device-code stamp wins
+    assert not bench.traffic_stamp_matches({"device_code_sha256_16": "0" * 16, "csrc_sha256_16": bench.csrc_hash()})[0]
+    assert bench.traffic_stamp_matches({"csrc_sha256_16": bench.csrc_hash()})[0]    # older records: source stamp
+    assert not bench.traffic_stamp_matches({"csrc_sha256_16": "0" * 16})[0]
+    rec = json.load(open(os.path.join(os.path.dirname(so), "..", "profiles", "gemm_traffic_xxl_b256.json")))
+    assert "device_code_sha256_16" in rec and "traffic_bytes_per_launch" in rec
