@@ -243,9 +243,9 @@ class Qwen25VLModel(VQAScoreModel):
         p = torch.softmax(scores.float() / temperature, dim=-1)                 # engine doubles in the CPU tests
         return p[torch.arange(p.shape[0]), token_ids.to(p.device)].cpu()
 
-    @torch.no_grad()
-    def forward(self, images: List[str], texts: List[str], fps=None, question_template: str = default_question_template,
-                answer_template: str = default_answer_template, max_new_tokens: int = 1, temperature: float = 1.0) -> torch.Tensor:
+    def _generate_scores(self, images, texts, fps, question_template, answer_template, max_new_tokens):
+        """Shared front half of forward / forward_with_trace: load, preprocess, batch by grid, greedy generation.
+        -> per sample (processed score rows, generated ids, answer ids)."""
         assert len(images) == len(texts), "Number of images/videos and texts must match"
         if max_new_tokens < 1:
             raise ValueError("max_new_tokens must be >= 1")
@@ -259,8 +259,8 @@ class Qwen25VLModel(VQAScoreModel):
                 prepared = list(pool.map(self.preprocess, items))
         else:
             prepared = [self.preprocess(it) for it in items]
-        scores = torch.zeros(len(images), dtype=torch.float32)
-        specials, stops = self._special_ids(), self._stop_ids()
+        stops = self._stop_ids()
+        out = [None] * len(images)
         # batch samples that share a grid (one vision call per group), at most max_batch at a time
         groups: Dict[Tuple[int, int, int], List[int]] = {}
         for i, (_, g) in enumerate(prepared):
@@ -279,20 +279,84 @@ class Qwen25VLModel(VQAScoreModel):
                 # position per further token; a sample stops at its first stop id, exactly as batch-1 generate does in the
                 # reference (:222-230) -- its later rows are computed and ignored (rows are independent)
                 step_scores, gen = self._greedy(merged, rows, [g] * len(chunk), max_new_tokens, stops)
-                # ---- score the answer tokens from the LAST positions of the generated scores (:239-289)
                 for k, i in enumerate(chunk):
-                    n_ans, offset = len(a_ids[k]), 0
-                    if gen[k][-1] in specials:
-                        n_ans = min(n_ans, len(step_scores[k]) - 1)
-                        offset = 1
-                        if n_ans <= 0:
-                            raise ValueError("No content tokens to score after removing special tokens")
-                    if len(step_scores[k]) < n_ans:
-                        n_ans = len(step_scores[k])
-                    pos = [len(step_scores[k]) - (n_ans - t + offset) for t in range(n_ans)]
-                    p = self._token_probs(torch.stack([step_scores[k][q] for q in pos]), torch.tensor(a_ids[k][:n_ans]), temperature)
-                    scores[i] = float(torch.prod(p.double()) ** (1.0 / n_ans))
+                    out[i] = (step_scores[k], gen[k], a_ids[k])
+        return out
+
+    @torch.no_grad()
+    def forward(self, images: List[str], texts: List[str], fps=None, question_template: str = default_question_template,
+                answer_template: str = default_answer_template, max_new_tokens: int = 1, temperature: float = 1.0) -> torch.Tensor:
+        scores = torch.zeros(len(images), dtype=torch.float32)
+        specials = self._special_ids()
+        # ---- score the answer tokens from the LAST positions of the generated scores (:239-289)
+        for i, (step_scores, gen, a_ids) in enumerate(self._generate_scores(images, texts, fps, question_template, answer_template,
+                                                                               max_new_tokens)):
+            n_ans, offset = len(a_ids), 0
+            if gen[-1] in specials:
+                n_ans = min(n_ans, len(step_scores) - 1)
+                offset = 1
+                if n_ans <= 0:
+                    raise ValueError("No content tokens to score after removing special tokens")
+            if len(step_scores) < n_ans:
+                n_ans = len(step_scores)
+            pos = [len(step_scores) - (n_ans - t + offset) for t in range(n_ans)]
+            p = self._token_probs(torch.stack([step_scores[q] for q in pos]), torch.tensor(a_ids[:n_ans]), temperature)
+            scores[i] = float(torch.prod(p.double()) ** (1.0 / n_ans))
         return scores
+
+    @torch.no_grad()
+    def forward_with_trace(self, images: List[str], texts: List[str], fps=None, question_template: str = default_question_template,
+                           answer_template: str = default_answer_template, max_new_tokens: int = 1, temperature: float = 1.0,
+                           score_position: str = "end", debug: bool = False) -> Tuple[torch.Tensor, List[Dict]]:
+        """forward() plus the per-sample trace of the reference's forward_with_trace (qwen2vl_model.py:303-493): `score_position`
+        "end" scores the last n answer tokens (one earlier when the generation ends in a special token), "start" the first n; the
+        trace holds the generated text, the scored positions and, per answer token, its probability and the five most likely
+        alternatives of softmax(scores / temperature)."""
+        assert score_position in ("start", "end"), f"score_position must be 'start' or 'end', got '{score_position}'"
+        specials = self._special_ids()
+        tok = self.tokenizer
+        probs, traces = [], []
+        for idx, (step_scores, gen, a_ids) in enumerate(self._generate_scores(images, texts, fps, question_template, answer_template,
+                                                                                 max_new_tokens)):
+            n_ans = len(a_ids)
+            if score_position == "start":
+                start, offset = 0, 0
+            else:
+                offset = 0
+                if gen[-1] in specials:
+                    n_ans = min(n_ans, len(step_scores) - 1)
+                    offset = 1
+                start = len(gen) - n_ans - offset
+            start = max(start, 0)
+            available = len(step_scores) - start
+            if available < n_ans:
+                print(f"  Warning: Only {available} tokens available at position, need {n_ans}, adjusting")
+                n_ans = available
+                a_ids = a_ids[:n_ans]
+            if n_ans <= 0:
+                raise ValueError("No tokens available to score at the specified position")
+            scored_indices = list(range(start, start + n_ans))
+            rows = torch.stack([step_scores[q] for q in scored_indices])
+            p = self._token_probs(rows, torch.tensor(a_ids[:n_ans]), temperature)
+            dist = torch.softmax(rows.float() / temperature, dim=-1)
+            top_p, top_i = torch.topk(dist, 5, dim=-1)
+            details = []
+            for t in range(n_ans):
+                details.append({'position': start + t, 'expected_token_id': a_ids[t], 'expected_token_text': tok.decode([a_ids[t]]),
+                                'probability': float(p[t]),
+                                'top_alternatives': [{'token_id': int(ti), 'token_text': tok.decode([int(ti)]), 'probability': float(tp)}
+                                                     for tp, ti in zip(top_p[t].tolist(), top_i[t].tolist())]})
+            prob = float(torch.prod(p.double()) ** (1.0 / n_ans))
+            trace = {'generated_text': tok.decode(gen, skip_special_tokens=True), 'generated_length': len(gen),
+                     'score_position': score_position, 'score_start_idx': start, 'scored_indices': scored_indices,
+                     'scored_tokens_text': tok.decode(gen[start: start + n_ans], skip_special_tokens=True), 'probability': prob,
+                     'token_details': details}
+            if debug:
+                print(f"Sample {idx + 1}/{len(images)}: {images[idx]} | {texts[idx]}\n  generated: {trace['generated_text']!r}; scoring positions "
+                      f"{scored_indices}; probability {prob:.6f}")
+            probs.append(prob)
+            traces.append(trace)
+        return torch.tensor(probs), traces
 
     @staticmethod
     def _warp(scores: torch.Tensor, temperature: float, top_p: float) -> torch.Tensor:

@@ -27,7 +27,7 @@ class FakeQwenTokenizer:
             text = text.replace(s, f" {s} ")
         return [SPECIALS[w] if w in SPECIALS else 10 + zlib.crc32(w.encode()) % (self.vocab - 10) for w in text.split()]
 
-    def decode(self, ids, skip_special_tokens=True):
+    def decode(self, ids, skip_special_tokens=False):
         special = set(SPECIALS.values())
         return " ".join(f"t{int(i)}" for i in ids if not (skip_special_tokens and int(i) in special))
 
@@ -361,3 +361,61 @@ def test_logits_processing_equals_hf_processors():
         got = Qwen25VLModel._warp(scores, temperature, top_p)
         assert torch.equal(torch.isinf(got), torch.isinf(ref)) and torch.allclose(got[~torch.isinf(got)], ref[~torch.isinf(ref)])
     assert int((~torch.isinf(Qwen25VLModel._warp(scores, 2.0, 1e-6))).sum()) == scores.shape[0]      # only the top token survives
+
+
+def test_forward_with_trace_follows_the_reference_rules(tmp_path):
+    """forward_with_trace (qwen2vl_model.py:303-493): scores equal forward() for score_position='end'; 'start' scores the first
+    generated positions; the trace fields and the special-token / short-generation adjustments follow the reference's arithmetic,
+    restated literally here on the double's own generation."""
+    cfg = get_qwen_config("qwen-tiny")
+    w = make_seeded_qwen_weights(cfg, seed=3, dtype=torch.bfloat16, lm_head_gain=4.0)
+    tok = FakeQwenTokenizer(cfg.text.vocab)
+    p = tmp_path / "img.npy"
+    np.save(p, np.random.RandomState(2).randint(0, 256, (112, 112, 3), dtype=np.uint8))
+    m = t2v.VQAScore(model="qwen2.5-vl-7b", device="cpu", config=cfg, engine=OracleQwenEngine(cfg, w), tokenizer=tok).model
+    m._gen_eos_ids = []
+    ans = "Yes indeed"
+    a = tok.encode(ans)
+    for pos_mode in ("end", "start"):
+        s, tr = m.forward_with_trace([str(p)], ["a red cube"], answer_template=ans, max_new_tokens=4, temperature=0.8, score_position=pos_mode)
+        t = tr[0]
+        assert t["generated_length"] == 4 and t["score_position"] == pos_mode and len(t["token_details"]) == 2
+        assert t["scored_indices"] == ([2, 3] if pos_mode == "end" else [0, 1]) and t["score_start_idx"] == t["scored_indices"][0]
+        probs = [d["probability"] for d in t["token_details"]]
+        assert abs(t["probability"] - (probs[0] * probs[1]) ** 0.5) <= 1e-7 and abs(float(s[0]) - t["probability"]) <= 1e-7
+        for d, want_id in zip(t["token_details"], a):
+            assert d["expected_token_id"] == want_id and d["expected_token_text"] == tok.decode([want_id])
+            alts = d["top_alternatives"]
+            assert len(alts) == 5 and all(alts[i]["probability"] >= alts[i + 1]["probability"] for i in range(4))
+            assert all(x["token_text"] == tok.decode([x["token_id"]]) for x in alts)
+            hit = [x for x in alts if x["token_id"] == want_id]
+            assert not hit or abs(hit[0]["probability"] - d["probability"]) <= 1e-6
+        assert t["generated_text"].split() == [f"t{i}" for i in _generated_ids(m, p, 4)]
+    # 'end' equals forward()
+    s_end, _ = m.forward_with_trace([str(p)], ["a red cube"], answer_template=ans, max_new_tokens=4, temperature=0.8)
+    assert abs(float(s_end[0]) - float(m.forward([str(p)], ["a red cube"], answer_template=ans, max_new_tokens=4, temperature=0.8)[0])) <= 1e-7
+    # generation ends in a special token: one position earlier; fewer generated tokens than answer tokens: n is cut
+    gen = _generated_ids(m, p, 4)
+    tok.eos_token_id = gen[1]
+    m._gen_eos_ids = [gen[1]]
+    s_sp, tr = m.forward_with_trace([str(p)], ["a red cube"], answer_template=ans, max_new_tokens=4)
+    assert tr[0]["generated_length"] == 2 and tr[0]["scored_indices"] == [0] and len(tr[0]["token_details"]) == 1     # n = min(2, 2 - 1), offset 1
+    s_st, tr = m.forward_with_trace([str(p)], ["a red cube"], answer_template=ans, max_new_tokens=4, score_position="start")
+    assert tr[0]["scored_indices"] == [0, 1]                                                                          # 'start' ignores the special rule
+    tok.eos_token_id = gen[0]
+    m._gen_eos_ids = [gen[0]]
+    with pytest.raises(ValueError, match="No tokens available"):
+        m.forward_with_trace([str(p)], ["a red cube"], answer_template=ans, max_new_tokens=4)
+    with pytest.raises(AssertionError):
+        m.forward_with_trace([str(p)], ["a red cube"], score_position="middle")
+
+
+def _generated_ids(m, path, n):
+    """The model's greedy ids for the default question on `path`, stop ids disabled."""
+    keep = m._gen_eos_ids
+    m._gen_eos_ids = []
+    try:
+        from t2v_metrics_amd.models.vqascore_models.qwen25vl_model import default_question_template
+        return m._generate_scores([str(path)], ["a red cube"], None, default_question_template, "Yes", n)[0][1]
+    finally:
+        m._gen_eos_ids = keep
