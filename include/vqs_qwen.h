@@ -86,6 +86,9 @@ int vqs_qwen_score(vqs_qwen_handle* h, const void* d_merged, const int32_t* d_in
  *   far; the caller advances it), d_cos / d_sin fp32 [B, head_dim/2] rotary table of that position (each M-RoPE axis at the prompt's
  *   last position + 1 + step, as HF generate advances position_ids); d_logits fp32 [B, t_vocab] of the new position.
  * Samples that have stopped may be fed any token: rows are independent. */
+/* Largest Lmax the cached decode step accepts (its one-row attention keeps Lmax fp32 scores in LDS); prefill and decode refuse a larger
+ * cache with VQS_ERR_INVALID before any launch.  The decode kernels also ignore / clamp a device-side length outside [0, Lmax). */
+#define VQS_QWEN_MAX_CACHE_POSITIONS 36864
 size_t vqs_qwen_kv_bytes(const vqs_qwen_handle* h, int32_t B, int32_t Lmax);
 int vqs_qwen_prefill(vqs_qwen_handle* h, const void* d_merged, const int32_t* d_input_ids, const int32_t* d_vis_slot,
                      const int32_t* d_seq_len, const int32_t* d_last_row, const float* d_cos, const float* d_sin, int32_t B,

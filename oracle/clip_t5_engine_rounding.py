@@ -74,15 +74,18 @@ def gelu_new_sigmoid(x: torch.Tensor) -> torch.Tensor:
     return x * torch.sigmoid(u2)
 
 
-def tiled_attention(q, k, v, scale: float, bias_table=None, key_len=None, round_fn=bf16_round, acc=torch.float64, causal=False):
+def tiled_attention(q, k, v, scale: float, bias_table=None, key_len=None, round_fn=bf16_round, acc=torch.float64, causal=False,
+                    round_out=None):
     """attn_fwd_dma_kernel<HAS_BIAS> (attn.hip:366-595) and attn_fwd_hd_kernel<128, CAUSAL> (attn.hip:468-672; same tiles,
     same softmax, key > query masked when ``causal``) restated on the CPU.  A tile the causal kernel skips for a 128-query
     block is a tile whose scores are all masked there: it moves neither the running max nor the sums, so masking is enough.
 
     q, k, v: [B, H, S, d] fp32 tensors holding bf16 values.  bias_table: [H, 2S-1] fp32, entry (key - query + S - 1),
     natural-log units (the kernel multiplies by log2e when it fills its LDS copies).  key_len: [B] or None.
-    Returns [B, S, H*64] fp32 holding bf16 values (``round_fn`` applied)."""
+    Returns [B, S, H*64] fp32 holding bf16 values (``round_fn`` applied to P, ``round_out`` -- default ``round_fn`` -- to
+    the output: the two are separate rounding classes of the error attribution, tools/error_attribution.py)."""
     B, H, S, d = q.shape
+    round_out = round_fn if round_out is None else round_out
     sl2 = float(np.float32(scale) * np.float32(LOG2E))
     s_raw = (q.to(acc) @ k.to(acc).transpose(-1, -2)).float()              # [B,H,S,S] fp32 accumulators of K.Q^T
     if bias_table is not None:
@@ -135,7 +138,7 @@ def tiled_attention(q, k, v, scale: float, bias_table=None, key_len=None, round_
         osum = osum + p.to(acc).sum(-1).float()
         o = o + (p.to(acc) @ v[..., kb:ke, :].to(acc)).float()
     inv = torch.where(osum > 0, 1.0 / osum, torch.zeros_like(osum))
-    out = round_fn(o * inv[..., None])
+    out = round_out(o * inv[..., None])
     return out.transpose(1, 2).reshape(B, S, H * d)
 
 
@@ -164,10 +167,22 @@ class EngineRoundedOracle(Oracle):
     """See the module docstring.  ``round_fn`` = identity turns every rounding off (used to pin this class against
     ``Oracle``); ``acc`` is the dtype matrix products are accumulated in."""
 
-    def __init__(self, cfg, weights, emulate="engine", round_fn=bf16_round, acc=torch.float64):
+    # every rounding site carries a class name "<stack>.<what>"; `classes` = the set of classes that round (None = all,
+    # the engine's arithmetic).  One class at a time = the error attribution of tools/error_attribution.py.
+    CLASSES = ("vit.norm", "vit.qkv", "vit.p", "vit.attn", "vit.act", "vit.delta", "vit.feat", "proj.mid", "proj.out",
+               "enc.norm", "enc.qkv", "enc.p", "enc.attn", "enc.act", "enc.delta", "enc.out",
+               "dec.norm", "dec.qkv", "dec.sattn", "dec.delta", "dec.cq", "dec.cqk", "dec.cprobs", "dec.cctx", "dec.cattn",
+               "dec.act", "dec.out")
+
+    def __init__(self, cfg, weights, emulate="engine", round_fn=bf16_round, acc=torch.float64, classes=None):
         super().__init__(cfg, weights)
         self.r = round_fn
         self.acc = acc
+        if classes is not None:
+            unknown = set(classes) - set(self.CLASSES)
+            if unknown:
+                raise ValueError(f"unknown rounding classes {sorted(unknown)}")
+        self.classes = None if classes is None else frozenset(classes)
         self.locked = None       # dict tap name -> engine tensor: stage-locked mode
         self.record = None       # dict: free-running mode stores every named intermediate here
         self.report = {}         # stage-locked mode: tap name -> {"frac_diff", "max_abs", "ref_absmax", "n"}
@@ -188,6 +203,14 @@ class EngineRoundedOracle(Oracle):
         return e
 
     # ---------------------------------------------------------------------------------------------- helpers
+    def rc(self, cls: str, x: torch.Tensor) -> torch.Tensor:
+        """The rounding of class `cls`: ``round_fn`` when the class is switched on, identity otherwise."""
+        assert cls in self.CLASSES, cls
+        return self.r(x) if self.classes is None or cls in self.classes else x
+
+    def rcf(self, cls: str):
+        return self.r if self.classes is None or cls in self.classes else (lambda x: x)
+
     def _mm(self, x: torch.Tensor, wname: str, bname: str | None = None) -> torch.Tensor:
         """fp32 accumulator of an nn.Linear over bf16 operands (+ bias added in fp32, as the GEMM epilogues do)."""
         w = self.w[wname].detach().to("cpu")
@@ -199,10 +222,10 @@ class EngineRoundedOracle(Oracle):
 
     # ---------------------------------------------------------------------------------------------- vision tower
     def vision_features(self, pixel_values: torch.Tensor) -> torch.Tensor:
-        v, r = self.cfg.vision, self.r
+        v, rc = self.cfg.vision, self.rc
         B = pixel_values.shape[0]
         g, p = v.grid, v.patch
-        x = r(pixel_values.to(torch.float32))                       # the engine receives bf16 pixels
+        x = self.r(pixel_values.to(torch.float32))                  # the engine receives bf16 pixels (an input, not a class)
         patches = x.reshape(B, 3, g, p, g, p).permute(0, 2, 4, 1, 3, 5).reshape(B, g * g, 3 * p * p)
         pe = self._emit("vit.patch_out", self._mm(patches, "vision.embeddings.patch_embedding.weight"))   # EPI_F32
         cls = self._w("vision.embeddings.class_embedding").reshape(1, 1, -1).expand(B, 1, -1)
@@ -212,32 +235,33 @@ class EngineRoundedOracle(Oracle):
         for i in range(v.layers_run):
             pfx = f"vision.encoder.layers.{i}."
             t = f"vit.{i}."
-            xn = self._emit(t + "xn0", r(layer_norm(h, self._w(pfx + "layer_norm1.weight"), self._w(pfx + "layer_norm1.bias"), v.ln_eps)))
+            xn = self._emit(t + "xn0", rc("vit.norm", layer_norm(h, self._w(pfx + "layer_norm1.weight"), self._w(pfx + "layer_norm1.bias"), v.ln_eps)))
 
             def heads(nm):
-                y = r(self._mm(xn, pfx + f"self_attn.{nm}_proj.weight", pfx + f"self_attn.{nm}_proj.bias"))
+                y = rc("vit.qkv", self._mm(xn, pfx + f"self_attn.{nm}_proj.weight", pfx + f"self_attn.{nm}_proj.bias"))
                 return self._emit(t + nm, y.reshape(B, S, v.heads, v.head_dim).transpose(1, 2))
 
-            att = tiled_attention(heads("q"), heads("k"), heads("v"), v.head_dim ** -0.5, None, None, r, self.acc)
+            att = tiled_attention(heads("q"), heads("k"), heads("v"), v.head_dim ** -0.5, None, None, self.rcf("vit.p"), self.acc,
+                                  round_out=self.rcf("vit.attn"))
             att = self._emit(t + "attn", att)
-            d_attn = self._emit(t + "d_attn", r(self._mm(att, pfx + "self_attn.out_proj.weight", pfx + "self_attn.out_proj.bias")))
+            d_attn = self._emit(t + "d_attn", rc("vit.delta", self._mm(att, pfx + "self_attn.out_proj.weight", pfx + "self_attn.out_proj.bias")))
             h1 = h + d_attn
-            xn = self._emit(t + "xn1", r(layer_norm(h1, self._w(pfx + "layer_norm2.weight"), self._w(pfx + "layer_norm2.bias"), v.ln_eps)))
-            mid = self._emit(t + "mid", r(quick_gelu(self._mm(xn, pfx + "mlp.fc1.weight", pfx + "mlp.fc1.bias"))))
-            d_mlp = self._emit(t + "d_mlp", r(self._mm(mid, pfx + "mlp.fc2.weight", pfx + "mlp.fc2.bias")))
+            xn = self._emit(t + "xn1", rc("vit.norm", layer_norm(h1, self._w(pfx + "layer_norm2.weight"), self._w(pfx + "layer_norm2.bias"), v.ln_eps)))
+            mid = self._emit(t + "mid", rc("vit.act", quick_gelu(self._mm(xn, pfx + "mlp.fc1.weight", pfx + "mlp.fc1.bias"))))
+            d_mlp = self._emit(t + "d_mlp", rc("vit.delta", self._mm(mid, pfx + "mlp.fc2.weight", pfx + "mlp.fc2.bias")))
             h = h1 + d_mlp
-        return self._emit("vit.feat_in", r(h[:, 1:]))               # drop_cls_cast: bf16 operand of the projector
+        return self._emit("vit.feat_in", rc("vit.feat", h[:, 1:]))               # drop_cls_cast: bf16 operand of the projector
 
     def projector(self, feats: torch.Tensor) -> torch.Tensor:
-        r = self.r
-        x = self._emit("vit.pmid", r(gelu_erf(self._mm(feats, "mm_projector.0.weight", "mm_projector.0.bias"))))
-        return self._emit("proj", r(self._mm(x, "mm_projector.2.weight", "mm_projector.2.bias")))
+        rc = self.rc
+        x = self._emit("vit.pmid", rc("proj.mid", gelu_erf(self._mm(feats, "mm_projector.0.weight", "mm_projector.0.bias"))))
+        return self._emit("proj", rc("proj.out", self._mm(x, "mm_projector.2.weight", "mm_projector.2.bias")))
 
     # ---------------------------------------------------------------------------------------------- T5
-    def _gated_ff(self, prefix: str, xn: torch.Tensor) -> torch.Tensor:
+    def _gated_ff(self, prefix: str, xn: torch.Tensor, cls: str = "enc.act") -> torch.Tensor:
         g = self._mm(xn, prefix + "wi_0.weight")
         l = self._mm(xn, prefix + "wi_1.weight")
-        return self.r(gelu_new_sigmoid(g) * l)                      # EPI_GATED: fp32 accumulators -> one bf16 product
+        return self.rc(cls, gelu_new_sigmoid(g) * l)                     # EPI_GATED: fp32 accumulators -> one bf16 product
 
     def enc_bias_table(self, S: int) -> torch.Tensor:
         """[H, 2S-1] fp32, entry (key - query + S - 1): relpos_table_kernel (elementwise.hip:590-609)."""
@@ -249,7 +273,7 @@ class EngineRoundedOracle(Oracle):
         return table[torch.from_numpy(bucket)].t().contiguous()
 
     def t5_encoder(self, emb: torch.Tensor, key_mask: torch.Tensor) -> torch.Tensor:
-        t, r = self.cfg.t5, self.r
+        t, rc = self.cfg.t5, self.rc
         B, S, _ = emb.shape
         klen = key_mask.sum(1)
         table = self.enc_bias_table(S)
@@ -258,19 +282,20 @@ class EngineRoundedOracle(Oracle):
             p = f"encoder.block.{i}."
             a = p + "layer.0.SelfAttention."
             n = f"enc.{i}."
-            xn = self._emit(n + "xn0", r(t5_rms_norm(h, self._w(p + "layer.0.layer_norm.weight"), t.ln_eps)))
+            xn = self._emit(n + "xn0", rc("enc.norm", t5_rms_norm(h, self._w(p + "layer.0.layer_norm.weight"), t.ln_eps)))
 
             def heads(nm):
-                return self._emit(n + nm, r(self._mm(xn, a + nm + ".weight")).reshape(B, S, t.heads, t.d_kv).transpose(1, 2))
+                return self._emit(n + nm, rc("enc.qkv", self._mm(xn, a + nm + ".weight")).reshape(B, S, t.heads, t.d_kv).transpose(1, 2))
 
-            att = self._emit(n + "attn", tiled_attention(heads("q"), heads("k"), heads("v"), 1.0, table, klen, r, self.acc))
-            d_attn = self._emit(n + "d_attn", r(self._mm(att, a + "o.weight")))
+            att = self._emit(n + "attn", tiled_attention(heads("q"), heads("k"), heads("v"), 1.0, table, klen, self.rcf("enc.p"), self.acc,
+                                                         round_out=self.rcf("enc.attn")))
+            d_attn = self._emit(n + "d_attn", rc("enc.delta", self._mm(att, a + "o.weight")))
             h1 = h + d_attn
-            xn = self._emit(n + "xn1", r(t5_rms_norm(h1, self._w(p + "layer.1.layer_norm.weight"), t.ln_eps)))
-            ff = self._emit(n + "ff", self._gated_ff(p + "layer.1.DenseReluDense.", xn))
-            d_ff = self._emit(n + "d_ff", r(self._mm(ff, p + "layer.1.DenseReluDense.wo.weight")))
+            xn = self._emit(n + "xn1", rc("enc.norm", t5_rms_norm(h1, self._w(p + "layer.1.layer_norm.weight"), t.ln_eps)))
+            ff = self._emit(n + "ff", self._gated_ff(p + "layer.1.DenseReluDense.", xn, "enc.act"))
+            d_ff = self._emit(n + "d_ff", rc("enc.delta", self._mm(ff, p + "layer.1.DenseReluDense.wo.weight")))
             h = h1 + d_ff
-        return self._emit("enc_out", r(t5_rms_norm(h, self._w("encoder.final_layer_norm.weight"), t.ln_eps)))
+        return self._emit("enc_out", rc("enc.out", t5_rms_norm(h, self._w("encoder.final_layer_norm.weight"), t.ln_eps)))
 
     def _dec_self_attention(self, qkv: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
         """dec_attn_kernel, self form: fp32 scores + bias, causal, fp32 softmax and P.V, bf16 output."""
@@ -282,21 +307,21 @@ class EngineRoundedOracle(Oracle):
         s = s.masked_fill(~causal, NEG_BIG)
         e = torch.exp(s - s.max(-1, keepdim=True).values)
         o = (e.to(self.acc) @ v.to(self.acc)).float() / e.sum(-1, keepdim=True)
-        return self.r(o).transpose(1, 2).reshape(B, T, t.inner)
+        return self.rc("dec.sattn", o).transpose(1, 2).reshape(B, T, t.inner)
 
     def _s_pad(self, S: int) -> int:
         return (S + 63) // 64 * 64
 
     def _dec_cross_attention(self, p: str, xn: torch.Tensor, enc_out: torch.Tensor, klen: torch.Tensor, n: str = "") -> torch.Tensor:
         """Reassociated cross-attention (vqs_api.cpp:781-812): (q_h Wk_h) E^T, masked softmax, (P E) Wv_h^T."""
-        t, r = self.cfg.t5, self.r
+        t, rc = self.cfg.t5, self.rc
         B, T, D = xn.shape
         S = enc_out.shape[1]
         H, dk = t.heads, t.d_kv
-        q = self._emit(n + "cq", r(self._mm(xn, p + "q.weight"))).reshape(B, T, H, dk)
+        q = self._emit(n + "cq", rc("dec.cq", self._mm(xn, p + "q.weight"))).reshape(B, T, H, dk)
         wk = self.w[p + "k.weight"].detach().to("cpu").to(self.acc).reshape(H, dk, D)
         wv = self.w[p + "v.weight"].detach().to("cpu").to(self.acc).reshape(H, dk, D)
-        qk = self._emit(n + "cqk", r(torch.einsum("bthd,hdD->bthD", q.to(self.acc), wk).float()))      # "cross q.Wk" -> bf16
+        qk = self._emit(n + "cqk", rc("dec.cqk", torch.einsum("bthd,hdD->bthD", q.to(self.acc), wk).float()))      # "cross q.Wk" -> bf16
         # the engine's score / probability rows are S_pad wide (keys >= S: zero-padded E^T columns; keys >= enc_len: masked)
         Sp = self._s_pad(S)
         sc = torch.einsum("bthD,bsD->bths", qk.to(self.acc), enc_out.to(self.acc)).float()  # "cross scores" fp32
@@ -305,15 +330,15 @@ class EngineRoundedOracle(Oracle):
         sc = self._emit(n + "cscores", sc, valid=live)
         sc = sc.masked_fill(~live, float("-inf"))
         e = torch.exp(sc - sc.max(-1, keepdim=True).values)
-        pr = self._emit(n + "cprobs", r(e * (1.0 / e.sum(-1, keepdim=True))))                # masked_softmax_kernel
-        ctx = r(torch.einsum("bths,bsD->bthD", pr[..., :S].to(self.acc), enc_out.to(self.acc)).float())   # "cross P.E" -> bf16
+        pr = self._emit(n + "cprobs", rc("dec.cprobs", e * (1.0 / e.sum(-1, keepdim=True))))                # masked_softmax_kernel
+        ctx = rc("dec.cctx", torch.einsum("bths,bsD->bthD", pr[..., :S].to(self.acc), enc_out.to(self.acc)).float())   # "cross P.E" -> bf16
         ctx = self._emit(n + "cctx", ctx)
-        out = r(torch.einsum("bthD,hdD->bthd", ctx.to(self.acc), wv).float())               # "cross ctx.Wv" -> bf16
+        out = rc("dec.cattn", torch.einsum("bthD,hdD->bthd", ctx.to(self.acc), wv).float())               # "cross ctx.Wv" -> bf16
         return self._emit(n + "cattn", out.reshape(B, T, H * dk))
 
     def t5_decoder(self, dec_ids: torch.Tensor, enc_out: torch.Tensor, key_mask: torch.Tensor) -> torch.Tensor:
         from .clip_t5_oracle import relative_position_bucket
-        t, r = self.cfg.t5, self.r
+        t, rc = self.cfg.t5, self.rc
         B, T = dec_ids.shape
         klen = key_mask.sum(1)
         h = self._emit("dec.emb", self._w("shared.weight")[dec_ids])
@@ -327,18 +352,18 @@ class EngineRoundedOracle(Oracle):
             p = f"decoder.block.{i}."
             sa = p + "layer.0.SelfAttention."
             n = f"dec.{i}."
-            xn = self._emit(n + "xn0", r(t5_rms_norm(h, self._w(p + "layer.0.layer_norm.weight"), t.ln_eps)))
-            qkv = self._emit(n + "qkv", torch.cat([r(self._mm(xn, sa + nm + ".weight")) for nm in ("q", "k", "v")], dim=-1))
+            xn = self._emit(n + "xn0", rc("dec.norm", t5_rms_norm(h, self._w(p + "layer.0.layer_norm.weight"), t.ln_eps)))
+            qkv = self._emit(n + "qkv", torch.cat([rc("dec.qkv", self._mm(xn, sa + nm + ".weight")) for nm in ("q", "k", "v")], dim=-1))
             sattn = self._emit(n + "sattn", self._dec_self_attention(qkv, self_bias))
-            h = h + self._emit(n + "d_self", r(self._mm(sattn, sa + "o.weight")))
-            xn = self._emit(n + "xn1", r(t5_rms_norm(h, self._w(p + "layer.1.layer_norm.weight"), t.ln_eps)))
+            h = h + self._emit(n + "d_self", rc("dec.delta", self._mm(sattn, sa + "o.weight")))
+            xn = self._emit(n + "xn1", rc("dec.norm", t5_rms_norm(h, self._w(p + "layer.1.layer_norm.weight"), t.ln_eps)))
             ca = p + "layer.1.EncDecAttention."
-            h = h + self._emit(n + "d_cross", r(self._mm(self._dec_cross_attention(ca, xn, enc_out, klen, n), ca + "o.weight")))
-            xn = self._emit(n + "xn2", r(t5_rms_norm(h, self._w(p + "layer.2.layer_norm.weight"), t.ln_eps)))
+            h = h + self._emit(n + "d_cross", rc("dec.delta", self._mm(self._dec_cross_attention(ca, xn, enc_out, klen, n), ca + "o.weight")))
+            xn = self._emit(n + "xn2", rc("dec.norm", t5_rms_norm(h, self._w(p + "layer.2.layer_norm.weight"), t.ln_eps)))
             ffp = p + "layer.2.DenseReluDense."
-            ff = self._emit(n + "ff", self._gated_ff(ffp, xn))
-            h = h + self._emit(n + "d_ff", r(self._mm(ff, ffp + "wo.weight")))
-        return self._emit("dec_out", r(t5_rms_norm(h, self._w("decoder.final_layer_norm.weight"), t.ln_eps)))
+            ff = self._emit(n + "ff", self._gated_ff(ffp, xn, "dec.act"))
+            h = h + self._emit(n + "d_ff", rc("dec.delta", self._mm(ff, ffp + "wo.weight")))
+        return self._emit("dec_out", rc("dec.out", t5_rms_norm(h, self._w("decoder.final_layer_norm.weight"), t.ln_eps)))
 
     def lm_logits(self, dec_out: torch.Tensor) -> torch.Tensor:
         return self._emit("logits", self._mm(dec_out, "lm_head.weight"))                    # EPI_F32

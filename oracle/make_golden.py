@@ -312,9 +312,11 @@ def golden_qwen(name: str, seed: int, grids, text_lens, gain: float, tag: str = 
 def golden_qwen_generate(name: str, seed: int, grids, text_lens, gain: float, steps: int, tag: str):
     """HF generate WITH its KV cache, greedy, `steps` tokens per sample (batch 1 each, as the reference runs it,
     qwen2vl_model.py:222-230): stores the prompt, the pixels, the generated ids and the scores of every step.  Pins what
-    vqs_qwen_prefill / vqs_qwen_decode must reproduce: the cached forward and the position of a generated token (cache position +
-    rope_delta, get_rope_index) -- including a video whose temporal positions run past its spatial ones, where that rule and
-    "continue behind the last text token" differ."""
+    vqs_qwen_prefill / vqs_qwen_decode must reproduce: the cached forward and the position of a generated token.  The rule the
+    fixture pins (t2v_metrics_amd/qwen/layout.py, test_cached_generation_matches_hf_generate_fixture) is "last prompt position
+    + 1 + step on every M-RoPE axis" -- NOT get_rope_index's "cache position + rope_delta" (= max prompt position + 1): the
+    fixture includes a video whose temporal positions run past its spatial ones, where the two differ and the rope_delta rule
+    misses HF generate's scores by 1.4."""
     from t2v_metrics_amd.qwen import get_qwen_config
     from t2v_metrics_amd.qwen.weights import make_seeded_qwen_weights
     cfg = get_qwen_config(name)

@@ -99,9 +99,6 @@ __device__ __forceinline__ void fill_bias_copies(float* bias_s, const float* bt,
     }
 }
 
-#ifdef VQS_LAB
-#include "lab/attn_regstaged.inc"
-#endif
 
 // =====================================================================================================
 // attn_fwd_dma_kernel -- same math, same MFMA operand maps and the same softmax code as attn_fwd_kernel; what changes
@@ -672,28 +669,8 @@ __global__ void __launch_bounds__(256) attn_fwd_hd_kernel(const AttnParams p) {
     }
 }
 
-#ifdef VQS_LAB
-static int attn_variant() {       // VQS_ATTN_VARIANT=0 selects the register-staged kernel (lab A/B); default = LDS-DMA kernel
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("VQS_ATTN_VARIANT");
-        v = e ? atoi(e) : 1;
-    }
-    return v;
-}
-
-static size_t attn_lds_pad() {    // lab: VQS_ATTN_LDS_PAD=<bytes> inflates the dynamic LDS request to lower the occupancy
-    static long v = -1;
-    if (v < 0) {
-        const char* e = getenv("VQS_ATTN_LDS_PAD");
-        v = e ? atol(e) : 0;
-    }
-    return (size_t)v;
-}
-#else
 static constexpr int attn_variant() { return 1; }        // the shipped library holds the LDS-DMA kernel only
 static constexpr size_t attn_lds_pad() { return 0; }
-#endif
 
 template <typename KernelT>
 static hipError_t launch_attn_t(KernelT kern, const AttnParams& p, size_t lds, hipStream_t stream) {
@@ -722,12 +699,6 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
     if ((p.hd != 0 && p.hd != 64) || p.out_hd != 0) return hipErrorInvalidValue;
     if (p.causal || (p.Hkv > 0 && p.Hkv != p.H)) return hipErrorInvalidValue;
     const size_t bias_bytes = p.bias_table ? (size_t)bias_copy_chunks(p.S) * 64 : 0;
-#ifdef VQS_LAB
-    if (attn_variant() == 0) {
-        const size_t lds = K_LDS + VT_LDS + bias_bytes;
-        return p.bias_table ? launch_attn_t(attn_fwd_kernel<true>, p, lds, stream) : launch_attn_t(attn_fwd_kernel<false>, p, lds, stream);
-    }
-#endif
     const size_t lds = 2 * ST_BYTES + bias_bytes;
     return p.bias_table ? launch_attn_t(attn_fwd_dma_kernel<true>, p, lds, stream)
                         : launch_attn_t(attn_fwd_dma_kernel<false>, p, lds, stream);

@@ -22,10 +22,9 @@
 #include <cstdlib>
 #include <type_traits>
 
-// Build flavours: the shipped library holds the kernels the engine launches (variant 0 one tile per workgroup, 2 / 5
-// ping-pong, 3 persistent with its schedule chosen by shape).  -DVQS_LAB (tools/lab builds only) adds the A/B forms kept
-// for the record -- the register-staged kernel (variant 1), the loader/consumer wave-specialised kernel (4), the forced
-// lock-step launch (7) and the VQS_L2_TOUCH environment switch.  Ablation builds of round 1 are in the git history.
+// Kernels of this file: variant 0 one tile per workgroup, 2 / 5 the ping-pong schedule, 3 / 11 persistent with the schedule
+// chosen by shape (3 hands the big bf16-result launches to the quad form of gemm_quad.inc).  The A/B forms of rounds 1-3
+// (register-staged, wave-specialised, wide, ring) and the ablation builds are in the git history only.
 
 namespace vqs {
 
@@ -947,421 +946,9 @@ __global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) 
 #undef PGLDS_A
 #undef PGLDS_W
 
-#ifdef VQS_LAB   // the wide form lost to the 8-wave forms by 8-10 % (round 2) and to the quad form by 25-35 %: lab builds only
-// =====================================================================================================
-// WIDE variant (VAR 6): the same 256x256x64 tile, LDS image, LDS-DMA staging, tile order and staged epilogue -- computed by
-// FOUR waves of 128x128 (one per SIMD, 256 fp32 accumulators per lane) instead of eight of 128x64.
-//
-// Why: the 8-wave forms move, per k-step of 16 and workgroup, 8 x (128 + 64) x 16 x 2 B = 48 KiB of fragments out of LDS plus
-// 16 KiB of LDS-DMA in -- 64 KiB = 512 cycles of the CU's 128 B/clk LDS port, exactly the 512 cycles the matrix pipes need for
-// that k-step: the main loop sits on the LDS roofline at the same time as on the MFMA one (PMC: matrix pipe busy 70 % of SIMD
-// cycles), and the vendor library runs the path's shapes ~19 % faster on identical data (profiles/r2_call30_*: 1.50 vs 1.25
-// PFLOP/s).  A 128x128 wave tile reads 4 x (128 + 128) x 16 x 2 B = 32 KiB per k-step: LDS port 75 % busy at full MFMA rate.
-// Same MFMA instruction, same operand maps, same K order per output element => bitwise the results of every other form
-// (test_gemm_wide_...).  One wave per SIMD: latency is hidden inside the wave's own stream (fragments of k-step s+1 are read
-// while the 16 MFMAs of k-step s run), not by a partner wave.
-// =====================================================================================================
-// The 256 fp32 accumulators of a lane are exactly the 256 AGPRs a one-wave-per-SIMD kernel owns.  Left to the register
-// allocator (builtin MFMAs, or "+a" operands) some accumulator tuples end up in scratch: there is no slack to colour 16
-// aligned 16-register tuples next to anything else.  So the wide kernel names its accumulators itself: accumulator IDX lives
-// in a[16 IDX : 16 IDX + 15], the MFMA / zeroing / read-back statements below are the only code that touches AGPRs, and
-// every one of them lists its registers as clobbered so the compiler keeps nothing of its own there.
-typedef uint32_t g_frag_t __attribute__((ext_vector_type(4)));
-#define VQS_ACC_CASES(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
-template <int IDX>
-__device__ __forceinline__ void mfma_fixed(const uint4& a, const uint4& b) {
-    const g_frag_t av = {a.x, a.y, a.z, a.w}, bv = {b.x, b.y, b.z, b.w};
-    if constexpr (IDX == 0) asm volatile("v_mfma_f32_32x32x16_bf16 a[0:15], %0, %1, a[0:15]" ::"v"(av), "v"(bv) : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15");
-    else if constexpr (IDX == 1) asm volatile("v_mfma_f32_32x32x16_bf16 a[16:31], %0, %1, a[16:31]" ::"v"(av), "v"(bv) : "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31");
-    else if constexpr (IDX == 2) asm volatile("v_mfma_f32_32x32x16_bf16 a[32:47], %0, %1, a[32:47]" ::"v"(av), "v"(bv) : "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47");
-    else if constexpr (IDX == 3) asm volatile("v_mfma_f32_32x32x16_bf16 a[48:63], %0, %1, a[48:63]" ::"v"(av), "v"(bv) : "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63");
-    else if constexpr (IDX == 4) asm volatile("v_mfma_f32_32x32x16_bf16 a[64:79], %0, %1, a[64:79]" ::"v"(av), "v"(bv) : "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79");
-    else if constexpr (IDX == 5) asm volatile("v_mfma_f32_32x32x16_bf16 a[80:95], %0, %1, a[80:95]" ::"v"(av), "v"(bv) : "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95");
-    else if constexpr (IDX == 6) asm volatile("v_mfma_f32_32x32x16_bf16 a[96:111], %0, %1, a[96:111]" ::"v"(av), "v"(bv) : "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111");
-    else if constexpr (IDX == 7) asm volatile("v_mfma_f32_32x32x16_bf16 a[112:127], %0, %1, a[112:127]" ::"v"(av), "v"(bv) : "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127");
-    else if constexpr (IDX == 8) asm volatile("v_mfma_f32_32x32x16_bf16 a[128:143], %0, %1, a[128:143]" ::"v"(av), "v"(bv) : "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143");
-    else if constexpr (IDX == 9) asm volatile("v_mfma_f32_32x32x16_bf16 a[144:159], %0, %1, a[144:159]" ::"v"(av), "v"(bv) : "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159");
-    else if constexpr (IDX == 10) asm volatile("v_mfma_f32_32x32x16_bf16 a[160:175], %0, %1, a[160:175]" ::"v"(av), "v"(bv) : "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175");
-    else if constexpr (IDX == 11) asm volatile("v_mfma_f32_32x32x16_bf16 a[176:191], %0, %1, a[176:191]" ::"v"(av), "v"(bv) : "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191");
-    else if constexpr (IDX == 12) asm volatile("v_mfma_f32_32x32x16_bf16 a[192:207], %0, %1, a[192:207]" ::"v"(av), "v"(bv) : "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207");
-    else if constexpr (IDX == 13) asm volatile("v_mfma_f32_32x32x16_bf16 a[208:223], %0, %1, a[208:223]" ::"v"(av), "v"(bv) : "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223");
-    else if constexpr (IDX == 14) asm volatile("v_mfma_f32_32x32x16_bf16 a[224:239], %0, %1, a[224:239]" ::"v"(av), "v"(bv) : "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239");
-    else if constexpr (IDX == 15) asm volatile("v_mfma_f32_32x32x16_bf16 a[240:255], %0, %1, a[240:255]" ::"v"(av), "v"(bv) : "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255");
-}
-// first k-step of an output tile: C = 0 as an inline constant (no 256 v_accvgpr_write per tile)
-template <int IDX>
-__device__ __forceinline__ void mfma_fixed_zero(const uint4& a, const uint4& b) {
-    const g_frag_t av = {a.x, a.y, a.z, a.w}, bv = {b.x, b.y, b.z, b.w};
-    if constexpr (IDX == 0) asm volatile("v_mfma_f32_32x32x16_bf16 a[0:15], %0, %1, 0" ::"v"(av), "v"(bv) : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15");
-    else if constexpr (IDX == 1) asm volatile("v_mfma_f32_32x32x16_bf16 a[16:31], %0, %1, 0" ::"v"(av), "v"(bv) : "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31");
-    else if constexpr (IDX == 2) asm volatile("v_mfma_f32_32x32x16_bf16 a[32:47], %0, %1, 0" ::"v"(av), "v"(bv) : "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47");
-    else if constexpr (IDX == 3) asm volatile("v_mfma_f32_32x32x16_bf16 a[48:63], %0, %1, 0" ::"v"(av), "v"(bv) : "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63");
-    else if constexpr (IDX == 4) asm volatile("v_mfma_f32_32x32x16_bf16 a[64:79], %0, %1, 0" ::"v"(av), "v"(bv) : "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79");
-    else if constexpr (IDX == 5) asm volatile("v_mfma_f32_32x32x16_bf16 a[80:95], %0, %1, 0" ::"v"(av), "v"(bv) : "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95");
-    else if constexpr (IDX == 6) asm volatile("v_mfma_f32_32x32x16_bf16 a[96:111], %0, %1, 0" ::"v"(av), "v"(bv) : "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111");
-    else if constexpr (IDX == 7) asm volatile("v_mfma_f32_32x32x16_bf16 a[112:127], %0, %1, 0" ::"v"(av), "v"(bv) : "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127");
-    else if constexpr (IDX == 8) asm volatile("v_mfma_f32_32x32x16_bf16 a[128:143], %0, %1, 0" ::"v"(av), "v"(bv) : "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143");
-    else if constexpr (IDX == 9) asm volatile("v_mfma_f32_32x32x16_bf16 a[144:159], %0, %1, 0" ::"v"(av), "v"(bv) : "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159");
-    else if constexpr (IDX == 10) asm volatile("v_mfma_f32_32x32x16_bf16 a[160:175], %0, %1, 0" ::"v"(av), "v"(bv) : "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175");
-    else if constexpr (IDX == 11) asm volatile("v_mfma_f32_32x32x16_bf16 a[176:191], %0, %1, 0" ::"v"(av), "v"(bv) : "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191");
-    else if constexpr (IDX == 12) asm volatile("v_mfma_f32_32x32x16_bf16 a[192:207], %0, %1, 0" ::"v"(av), "v"(bv) : "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207");
-    else if constexpr (IDX == 13) asm volatile("v_mfma_f32_32x32x16_bf16 a[208:223], %0, %1, 0" ::"v"(av), "v"(bv) : "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223");
-    else if constexpr (IDX == 14) asm volatile("v_mfma_f32_32x32x16_bf16 a[224:239], %0, %1, 0" ::"v"(av), "v"(bv) : "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239");
-    else if constexpr (IDX == 15) asm volatile("v_mfma_f32_32x32x16_bf16 a[240:255], %0, %1, 0" ::"v"(av), "v"(bv) : "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255");
-}
-__device__ __forceinline__ void acc_zero_all() {
-    asm volatile("v_accvgpr_write_b32 a0, 0\n\tv_accvgpr_write_b32 a1, 0\n\tv_accvgpr_write_b32 a2, 0\n\tv_accvgpr_write_b32 a3, 0\n\tv_accvgpr_write_b32 a4, 0\n\tv_accvgpr_write_b32 a5, 0\n\tv_accvgpr_write_b32 a6, 0\n\tv_accvgpr_write_b32 a7, 0" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7");
-    asm volatile("v_accvgpr_write_b32 a8, 0\n\tv_accvgpr_write_b32 a9, 0\n\tv_accvgpr_write_b32 a10, 0\n\tv_accvgpr_write_b32 a11, 0\n\tv_accvgpr_write_b32 a12, 0\n\tv_accvgpr_write_b32 a13, 0\n\tv_accvgpr_write_b32 a14, 0\n\tv_accvgpr_write_b32 a15, 0" ::: "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15");
-    asm volatile("v_accvgpr_write_b32 a16, 0\n\tv_accvgpr_write_b32 a17, 0\n\tv_accvgpr_write_b32 a18, 0\n\tv_accvgpr_write_b32 a19, 0\n\tv_accvgpr_write_b32 a20, 0\n\tv_accvgpr_write_b32 a21, 0\n\tv_accvgpr_write_b32 a22, 0\n\tv_accvgpr_write_b32 a23, 0" ::: "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23");
-    asm volatile("v_accvgpr_write_b32 a24, 0\n\tv_accvgpr_write_b32 a25, 0\n\tv_accvgpr_write_b32 a26, 0\n\tv_accvgpr_write_b32 a27, 0\n\tv_accvgpr_write_b32 a28, 0\n\tv_accvgpr_write_b32 a29, 0\n\tv_accvgpr_write_b32 a30, 0\n\tv_accvgpr_write_b32 a31, 0" ::: "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31");
-    asm volatile("v_accvgpr_write_b32 a32, 0\n\tv_accvgpr_write_b32 a33, 0\n\tv_accvgpr_write_b32 a34, 0\n\tv_accvgpr_write_b32 a35, 0\n\tv_accvgpr_write_b32 a36, 0\n\tv_accvgpr_write_b32 a37, 0\n\tv_accvgpr_write_b32 a38, 0\n\tv_accvgpr_write_b32 a39, 0" ::: "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39");
-    asm volatile("v_accvgpr_write_b32 a40, 0\n\tv_accvgpr_write_b32 a41, 0\n\tv_accvgpr_write_b32 a42, 0\n\tv_accvgpr_write_b32 a43, 0\n\tv_accvgpr_write_b32 a44, 0\n\tv_accvgpr_write_b32 a45, 0\n\tv_accvgpr_write_b32 a46, 0\n\tv_accvgpr_write_b32 a47, 0" ::: "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47");
-    asm volatile("v_accvgpr_write_b32 a48, 0\n\tv_accvgpr_write_b32 a49, 0\n\tv_accvgpr_write_b32 a50, 0\n\tv_accvgpr_write_b32 a51, 0\n\tv_accvgpr_write_b32 a52, 0\n\tv_accvgpr_write_b32 a53, 0\n\tv_accvgpr_write_b32 a54, 0\n\tv_accvgpr_write_b32 a55, 0" ::: "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55");
-    asm volatile("v_accvgpr_write_b32 a56, 0\n\tv_accvgpr_write_b32 a57, 0\n\tv_accvgpr_write_b32 a58, 0\n\tv_accvgpr_write_b32 a59, 0\n\tv_accvgpr_write_b32 a60, 0\n\tv_accvgpr_write_b32 a61, 0\n\tv_accvgpr_write_b32 a62, 0\n\tv_accvgpr_write_b32 a63, 0" ::: "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63");
-    asm volatile("v_accvgpr_write_b32 a64, 0\n\tv_accvgpr_write_b32 a65, 0\n\tv_accvgpr_write_b32 a66, 0\n\tv_accvgpr_write_b32 a67, 0\n\tv_accvgpr_write_b32 a68, 0\n\tv_accvgpr_write_b32 a69, 0\n\tv_accvgpr_write_b32 a70, 0\n\tv_accvgpr_write_b32 a71, 0" ::: "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71");
-    asm volatile("v_accvgpr_write_b32 a72, 0\n\tv_accvgpr_write_b32 a73, 0\n\tv_accvgpr_write_b32 a74, 0\n\tv_accvgpr_write_b32 a75, 0\n\tv_accvgpr_write_b32 a76, 0\n\tv_accvgpr_write_b32 a77, 0\n\tv_accvgpr_write_b32 a78, 0\n\tv_accvgpr_write_b32 a79, 0" ::: "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79");
-    asm volatile("v_accvgpr_write_b32 a80, 0\n\tv_accvgpr_write_b32 a81, 0\n\tv_accvgpr_write_b32 a82, 0\n\tv_accvgpr_write_b32 a83, 0\n\tv_accvgpr_write_b32 a84, 0\n\tv_accvgpr_write_b32 a85, 0\n\tv_accvgpr_write_b32 a86, 0\n\tv_accvgpr_write_b32 a87, 0" ::: "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87");
-    asm volatile("v_accvgpr_write_b32 a88, 0\n\tv_accvgpr_write_b32 a89, 0\n\tv_accvgpr_write_b32 a90, 0\n\tv_accvgpr_write_b32 a91, 0\n\tv_accvgpr_write_b32 a92, 0\n\tv_accvgpr_write_b32 a93, 0\n\tv_accvgpr_write_b32 a94, 0\n\tv_accvgpr_write_b32 a95, 0" ::: "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95");
-    asm volatile("v_accvgpr_write_b32 a96, 0\n\tv_accvgpr_write_b32 a97, 0\n\tv_accvgpr_write_b32 a98, 0\n\tv_accvgpr_write_b32 a99, 0\n\tv_accvgpr_write_b32 a100, 0\n\tv_accvgpr_write_b32 a101, 0\n\tv_accvgpr_write_b32 a102, 0\n\tv_accvgpr_write_b32 a103, 0" ::: "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103");
-    asm volatile("v_accvgpr_write_b32 a104, 0\n\tv_accvgpr_write_b32 a105, 0\n\tv_accvgpr_write_b32 a106, 0\n\tv_accvgpr_write_b32 a107, 0\n\tv_accvgpr_write_b32 a108, 0\n\tv_accvgpr_write_b32 a109, 0\n\tv_accvgpr_write_b32 a110, 0\n\tv_accvgpr_write_b32 a111, 0" ::: "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111");
-    asm volatile("v_accvgpr_write_b32 a112, 0\n\tv_accvgpr_write_b32 a113, 0\n\tv_accvgpr_write_b32 a114, 0\n\tv_accvgpr_write_b32 a115, 0\n\tv_accvgpr_write_b32 a116, 0\n\tv_accvgpr_write_b32 a117, 0\n\tv_accvgpr_write_b32 a118, 0\n\tv_accvgpr_write_b32 a119, 0" ::: "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119");
-    asm volatile("v_accvgpr_write_b32 a120, 0\n\tv_accvgpr_write_b32 a121, 0\n\tv_accvgpr_write_b32 a122, 0\n\tv_accvgpr_write_b32 a123, 0\n\tv_accvgpr_write_b32 a124, 0\n\tv_accvgpr_write_b32 a125, 0\n\tv_accvgpr_write_b32 a126, 0\n\tv_accvgpr_write_b32 a127, 0" ::: "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127");
-    asm volatile("v_accvgpr_write_b32 a128, 0\n\tv_accvgpr_write_b32 a129, 0\n\tv_accvgpr_write_b32 a130, 0\n\tv_accvgpr_write_b32 a131, 0\n\tv_accvgpr_write_b32 a132, 0\n\tv_accvgpr_write_b32 a133, 0\n\tv_accvgpr_write_b32 a134, 0\n\tv_accvgpr_write_b32 a135, 0" ::: "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135");
-    asm volatile("v_accvgpr_write_b32 a136, 0\n\tv_accvgpr_write_b32 a137, 0\n\tv_accvgpr_write_b32 a138, 0\n\tv_accvgpr_write_b32 a139, 0\n\tv_accvgpr_write_b32 a140, 0\n\tv_accvgpr_write_b32 a141, 0\n\tv_accvgpr_write_b32 a142, 0\n\tv_accvgpr_write_b32 a143, 0" ::: "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143");
-    asm volatile("v_accvgpr_write_b32 a144, 0\n\tv_accvgpr_write_b32 a145, 0\n\tv_accvgpr_write_b32 a146, 0\n\tv_accvgpr_write_b32 a147, 0\n\tv_accvgpr_write_b32 a148, 0\n\tv_accvgpr_write_b32 a149, 0\n\tv_accvgpr_write_b32 a150, 0\n\tv_accvgpr_write_b32 a151, 0" ::: "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151");
-    asm volatile("v_accvgpr_write_b32 a152, 0\n\tv_accvgpr_write_b32 a153, 0\n\tv_accvgpr_write_b32 a154, 0\n\tv_accvgpr_write_b32 a155, 0\n\tv_accvgpr_write_b32 a156, 0\n\tv_accvgpr_write_b32 a157, 0\n\tv_accvgpr_write_b32 a158, 0\n\tv_accvgpr_write_b32 a159, 0" ::: "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159");
-    asm volatile("v_accvgpr_write_b32 a160, 0\n\tv_accvgpr_write_b32 a161, 0\n\tv_accvgpr_write_b32 a162, 0\n\tv_accvgpr_write_b32 a163, 0\n\tv_accvgpr_write_b32 a164, 0\n\tv_accvgpr_write_b32 a165, 0\n\tv_accvgpr_write_b32 a166, 0\n\tv_accvgpr_write_b32 a167, 0" ::: "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167");
-    asm volatile("v_accvgpr_write_b32 a168, 0\n\tv_accvgpr_write_b32 a169, 0\n\tv_accvgpr_write_b32 a170, 0\n\tv_accvgpr_write_b32 a171, 0\n\tv_accvgpr_write_b32 a172, 0\n\tv_accvgpr_write_b32 a173, 0\n\tv_accvgpr_write_b32 a174, 0\n\tv_accvgpr_write_b32 a175, 0" ::: "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175");
-    asm volatile("v_accvgpr_write_b32 a176, 0\n\tv_accvgpr_write_b32 a177, 0\n\tv_accvgpr_write_b32 a178, 0\n\tv_accvgpr_write_b32 a179, 0\n\tv_accvgpr_write_b32 a180, 0\n\tv_accvgpr_write_b32 a181, 0\n\tv_accvgpr_write_b32 a182, 0\n\tv_accvgpr_write_b32 a183, 0" ::: "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183");
-    asm volatile("v_accvgpr_write_b32 a184, 0\n\tv_accvgpr_write_b32 a185, 0\n\tv_accvgpr_write_b32 a186, 0\n\tv_accvgpr_write_b32 a187, 0\n\tv_accvgpr_write_b32 a188, 0\n\tv_accvgpr_write_b32 a189, 0\n\tv_accvgpr_write_b32 a190, 0\n\tv_accvgpr_write_b32 a191, 0" ::: "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191");
-    asm volatile("v_accvgpr_write_b32 a192, 0\n\tv_accvgpr_write_b32 a193, 0\n\tv_accvgpr_write_b32 a194, 0\n\tv_accvgpr_write_b32 a195, 0\n\tv_accvgpr_write_b32 a196, 0\n\tv_accvgpr_write_b32 a197, 0\n\tv_accvgpr_write_b32 a198, 0\n\tv_accvgpr_write_b32 a199, 0" ::: "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199");
-    asm volatile("v_accvgpr_write_b32 a200, 0\n\tv_accvgpr_write_b32 a201, 0\n\tv_accvgpr_write_b32 a202, 0\n\tv_accvgpr_write_b32 a203, 0\n\tv_accvgpr_write_b32 a204, 0\n\tv_accvgpr_write_b32 a205, 0\n\tv_accvgpr_write_b32 a206, 0\n\tv_accvgpr_write_b32 a207, 0" ::: "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207");
-    asm volatile("v_accvgpr_write_b32 a208, 0\n\tv_accvgpr_write_b32 a209, 0\n\tv_accvgpr_write_b32 a210, 0\n\tv_accvgpr_write_b32 a211, 0\n\tv_accvgpr_write_b32 a212, 0\n\tv_accvgpr_write_b32 a213, 0\n\tv_accvgpr_write_b32 a214, 0\n\tv_accvgpr_write_b32 a215, 0" ::: "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215");
-    asm volatile("v_accvgpr_write_b32 a216, 0\n\tv_accvgpr_write_b32 a217, 0\n\tv_accvgpr_write_b32 a218, 0\n\tv_accvgpr_write_b32 a219, 0\n\tv_accvgpr_write_b32 a220, 0\n\tv_accvgpr_write_b32 a221, 0\n\tv_accvgpr_write_b32 a222, 0\n\tv_accvgpr_write_b32 a223, 0" ::: "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223");
-    asm volatile("v_accvgpr_write_b32 a224, 0\n\tv_accvgpr_write_b32 a225, 0\n\tv_accvgpr_write_b32 a226, 0\n\tv_accvgpr_write_b32 a227, 0\n\tv_accvgpr_write_b32 a228, 0\n\tv_accvgpr_write_b32 a229, 0\n\tv_accvgpr_write_b32 a230, 0\n\tv_accvgpr_write_b32 a231, 0" ::: "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231");
-    asm volatile("v_accvgpr_write_b32 a232, 0\n\tv_accvgpr_write_b32 a233, 0\n\tv_accvgpr_write_b32 a234, 0\n\tv_accvgpr_write_b32 a235, 0\n\tv_accvgpr_write_b32 a236, 0\n\tv_accvgpr_write_b32 a237, 0\n\tv_accvgpr_write_b32 a238, 0\n\tv_accvgpr_write_b32 a239, 0" ::: "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239");
-    asm volatile("v_accvgpr_write_b32 a240, 0\n\tv_accvgpr_write_b32 a241, 0\n\tv_accvgpr_write_b32 a242, 0\n\tv_accvgpr_write_b32 a243, 0\n\tv_accvgpr_write_b32 a244, 0\n\tv_accvgpr_write_b32 a245, 0\n\tv_accvgpr_write_b32 a246, 0\n\tv_accvgpr_write_b32 a247, 0" ::: "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247");
-    asm volatile("v_accvgpr_write_b32 a248, 0\n\tv_accvgpr_write_b32 a249, 0\n\tv_accvgpr_write_b32 a250, 0\n\tv_accvgpr_write_b32 a251, 0\n\tv_accvgpr_write_b32 a252, 0\n\tv_accvgpr_write_b32 a253, 0\n\tv_accvgpr_write_b32 a254, 0\n\tv_accvgpr_write_b32 a255, 0" ::: "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255");
-}
-template <int IDX>
-__device__ __forceinline__ void acc_read(f32x16& out) {
-    float t[16];
-    if constexpr (IDX == 0) asm volatile("v_accvgpr_read_b32 %0, a0\n\tv_accvgpr_read_b32 %1, a1\n\tv_accvgpr_read_b32 %2, a2\n\tv_accvgpr_read_b32 %3, a3\n\tv_accvgpr_read_b32 %4, a4\n\tv_accvgpr_read_b32 %5, a5\n\tv_accvgpr_read_b32 %6, a6\n\tv_accvgpr_read_b32 %7, a7\n\tv_accvgpr_read_b32 %8, a8\n\tv_accvgpr_read_b32 %9, a9\n\tv_accvgpr_read_b32 %10, a10\n\tv_accvgpr_read_b32 %11, a11\n\tv_accvgpr_read_b32 %12, a12\n\tv_accvgpr_read_b32 %13, a13\n\tv_accvgpr_read_b32 %14, a14\n\tv_accvgpr_read_b32 %15, a15" : "=v"(t[0]), "=v"(t[1]), "=v"(t[2]), "=v"(t[3]), "=v"(t[4]), "=v"(t[5]), "=v"(t[6]), "=v"(t[7]), "=v"(t[8]), "=v"(t[9]), "=v"(t[10]), "=v"(t[11]), "=v"(t[12]), "=v"(t[13]), "=v"(t[14]), "=v"(t[15]));
-    else if constexpr (IDX == 1) asm volatile("v_accvgpr_read_b32 %0, a16\n\tv_accvgpr_read_b32 %1, a17\n\tv_accvgpr_read_b32 %2, a18\n\tv_accvgpr_read_b32 %3, a19\n\tv_accvgpr_read_b32 %4, a20\n\tv_accvgpr_read_b32 %5, a21\n\tv_accvgpr_read_b32 %6, a22\n\tv_accvgpr_read_b32 %7, a23\n\tv_accvgpr_read_b32 %8, a24\n\tv_accvgpr_read_b32 %9, a25\n\tv_accvgpr_read_b32 %10, a26\n\tv_accvgpr_read_b32 %11, a27\n\tv_accvgpr_read_b32 %12, a28\n\tv_accvgpr_read_b32 %13, a29\n\tv_accvgpr_read_b32 %14, a30\n\tv_accvgpr_read_b32 %15, a31" : "=v"(t[0]), "=v"(t[1]), "=v"(t[2]), "=v"(t[3]), "=v"(t[4]), "=v"(t[5]), "=v"(t[6]), "=v"(t[7]), "=v"(t[8]), "=v"(t[9]), "=v"(t[10]), "=v"(t[11]), "=v"(t[12]), "=v"(t[13]), "=v"(t[14]), "=v"(t[15]));
-    else if constexpr (IDX == 2) asm volatile("v_accvgpr_read_b32 %0, a32\n\tv_accvgpr_read_b32 %1, a33\n\tv_accvgpr_read_b32 %2, a34\n\tv_accvgpr_read_b32 %3, a35\n\tv_accvgpr_read_b32 %4, a36\n\tv_accvgpr_read_b32 %5, a37\n\tv_accvgpr_read_b32 %6, a38\n\tv_accvgpr_read_b32 %7, a39\n\tv_accvgpr_read_b32 %8, a40\n\tv_accvgpr_read_b32 %9, a41\n\tv_accvgpr_read_b32 %10, a42\n\tv_accvgpr_read_b32 %11, a43\n\tv_accvgpr_read_b32 %12, a44\n\tv_accvgpr_read_b32 %13, a45\n\tv_accvgpr_read_b32 %14, a46\n\tv_accvgpr_read_b32 %15, a47" : "=v"(t[0]), "=v"(t[1]), "=v"(t[2]), "=v"(t[3]), "=v"(t[4]), "=v"(t[5]), "=v"(t[6]), "=v"(t[7]), "=v"(t[8]), "=v"(t[9]), "=v"(t[10]), "=v"(t[11]), "=v"(t[12]), "=v"(t[13]), "=v"(t[14]), "=v"(t[15]));
-    else if constexpr (IDX == 3) asm volatile("v_accvgpr_read_b32 %0, a48\n\tv_accvgpr_read_b32 %1, a49\n\tv_accvgpr_read_b32 %2, a50\n\tv_accvgpr_read_b32 %3, a51\n\tv_accvgpr_read_b32 %4, a52\n\tv_accvgpr_read_b32 %5, a53\n\tv_accvgpr_read_b32 %6, a54\n\tv_accvgpr_read_b32 %7, a55\n\tv_accvgpr_read_b32 %8, a56\n\tv_accvgpr_read_b32 %9, a57\n\tv_accvgpr_read_b32 %10, a58\n\tv_accvgpr_read_b32 %11, a59\n\tv_accvgpr_read_b32 %12, a60\n\tv_accvgpr_read_b32 %13, a61\n\tv_accvgpr_read_b32 %14, a62\n\tv_accvgpr_read_b32 %15, a63" : "=v"(t[0]), "=v"(t[1]), "=v"(t[2]), "=v"(t[3]), "=v"(t[4]), "=v"(t[5]), "=v"(t[6]), "=v"(t[7]), "=v"(t[8]), "=v"(t[9]), "=v"(t[10]), "=v"(t[11]), "=v"(t[12]), "=v"(t[13]), "=v"(t[14]), "=v"(t[15]));
-    else if constexpr (IDX == 4) asm volatile("v_accvgpr_read_b32 %0, a64\n\tv_accvgpr_read_b32 %1, a65\n\tv_accvgpr_read_b32 %2, a66\n\tv_accvgpr_read_b32 %3, a67\n\tv_accvgpr_read_b32 %4, a68\n\tv_accvgpr_read_b32 %5, a69\n\tv_accvgpr_read_b32 %6, a70\n\tv_accvgpr_read_b32 %7, a71\n\tv_accvgpr_read_b32 %8, a72\n\tv_accvgpr_read_b32 %9, a73\n\tv_accvgpr_read_b32 %10, a74\n\tv_accvgpr_read_b32 %11, a75\n\tv_accvgpr_read_b32 %12, a76\n\tv_accvgpr_read_b32 %13, a77\n\tv_accvgpr_read_b32 %14, a78\n\tv_accvgpr_read_b32 %15, a79" : "=v"(t[0]), "=v"(t[1]), "=v"(t[2]), "=v"(t[3]), "=v"(t[4]), "=v"(t[5]), "=v"(t[6]), "=v"(t[7]), "=v"(t[8]), "=v"(t[9]), "=v"(t[10]), "=v"(t[11]), "=v"(t[12]), "=v"(t[13]), "=v"(t[14]), "=v"(t[15]));
-    else if constexpr (IDX == 5) asm volatile("v_accvgpr_read_b32 %0, a80\n\tv_accvgpr_read_b32 %1, a81\n\tv_accvgpr_read_b32 %2, a82\n\tv_accvgpr_read_b32 %3, a83\n\tv_accvgpr_read_b32 %4, a84\n\tv_accvgpr_read_b32 %5, a85\n\tv_accvgpr_read_b32 %6, a86\n\tv_accvgpr_read_b32 %7, a87\n\tv_accvgpr_read_b32 %8, a88\n\tv_accvgpr_read_b32 %9, a89\n\tv_accvgpr_read_b32 %10, a90\n\tv_accvgpr_read_b32 %11, a91\n\tv_accvgpr_read_b32 %12, a92\n\tv_accvgpr_read_b32 %13, a93\n\tv_accvgpr_read_b32 %14, a94\n\tv_accvgpr_read_b32 %15, a95" : "=v"(t[0]), "=v"(t[1]), "=v"(t[2]), "=v"(t[3]), "=v"(t[4]), "=v"(t[5]), "=v"(t[6]), "=v"(t[7]), "=v"(t[8]), "=v"(t[9]), "=v"(t[10]), "=v"(t[11]), "=v"(t[12]), "=v"(t[13]), "=v"(t[14]), "=v"(t[15]));
-    else if constexpr (IDX == 6) asm volatile("v_accvgpr_read_b32 %0, a96\n\tv_accvgpr_read_b32 %1, a97\n\tv_accvgpr_read_b32 %2, a98\n\tv_accvgpr_read_b32 %3, a99\n\tv_accvgpr_read_b32 %4, a100\n\tv_accvgpr_read_b32 %5, a101\n\tv_accvgpr_read_b32 %6, a102\n\tv_accvgpr_read_b32 %7, a103\n\tv_accvgpr_read_b32 %8, a104\n\tv_accvgpr_read_b32 %9, a105\n\tv_accvgpr_read_b32 %10, a106\n\tv_accvgpr_read_b32 %11, a107\n\tv_accvgpr_read_b32 %12, a108\n\tv_accvgpr_read_b32 %13, a109\n\tv_accvgpr_read_b32 %14, a110\n\tv_accvgpr_read_b32 %15, a111" : "=v"(t[0]), "=v"(t[1]), "=v"(t[2]), "=v"(t[3]), "=v"(t[4]), "=v"(t[5]), "=v"(t[6]), "=v"(t[7]), "=v"(t[8]), "=v"(t[9]), "=v"(t[10]), "=v"(t[11]), "=v"(t[12]), "=v"(t[13]), "=v"(t[14]), "=v"(t[15]));
-    else if constexpr (IDX == 7) asm volatile("v_accvgpr_read_b32 %0, a112\n\tv_accvgpr_read_b32 %1, a113\n\tv_accvgpr_read_b32 %2, a114\n\tv_accvgpr_read_b32 %3, a115\n\tv_accvgpr_read_b32 %4, a116\n\tv_accvgpr_read_b32 %5, a117\n\tv_accvgpr_read_b32 %6, a118\n\tv_accvgpr_read_b32 %7, a119\n\tv_accvgpr_read_b32 %8, a120\n\tv_accvgpr_read_b32 %9, a121\n\tv_accvgpr_read_b32 %10, a122\n\tv_accvgpr_read_b32 %11, a123\n\tv_accvgpr_read_b32 %12, a124\n\tv_accvgpr_read_b32 %13, a125\n\tv_accvgpr_read_b32 %14, a126\n\tv_accvgpr_read_b32 %15, a127" : "=v"(t[0]), "=v"(t[1]), "=v"(t[2]), "=v"(t[3]), "=v"(t[4]), "=v"(t[5]), "=v"(t[6]), "=v"(t[7]), "=v"(t[8]), "=v"(t[9]), "=v"(t[10]), "=v"(t[11]), "=v"(t[12]), "=v"(t[13]), "=v"(t[14]), "=v"(t[15]));
-    else if constexpr (IDX == 8) asm volatile("v_accvgpr_read_b32 %0, a128\n\tv_accvgpr_read_b32 %1, a129\n\tv_accvgpr_read_b32 %2, a130\n\tv_accvgpr_read_b32 %3, a131\n\tv_accvgpr_read_b32 %4, a132\n\tv_accvgpr_read_b32 %5, a133\n\tv_accvgpr_read_b32 %6, a134\n\tv_accvgpr_read_b32 %7, a135\n\tv_accvgpr_read_b32 %8, a136\n\tv_accvgpr_read_b32 %9, a137\n\tv_accvgpr_read_b32 %10, a138\n\tv_accvgpr_read_b32 %11, a139\n\tv_accvgpr_read_b32 %12, a140\n\tv_accvgpr_read_b32 %13, a141\n\tv_accvgpr_read_b32 %14, a142\n\tv_accvgpr_read_b32 %15, a143" : "=v"(t[0]), "=v"(t[1]), "=v"(t[2]), "=v"(t[3]), "=v"(t[4]), "=v"(t[5]), "=v"(t[6]), "=v"(t[7]), "=v"(t[8]), "=v"(t[9]), "=v"(t[10]), "=v"(t[11]), "=v"(t[12]), "=v"(t[13]), "=v"(t[14]), "=v"(t[15]));
-    else if constexpr (IDX == 9) asm volatile("v_accvgpr_read_b32 %0, a144\n\tv_accvgpr_read_b32 %1, a145\n\tv_accvgpr_read_b32 %2, a146\n\tv_accvgpr_read_b32 %3, a147\n\tv_accvgpr_read_b32 %4, a148\n\tv_accvgpr_read_b32 %5, a149\n\tv_accvgpr_read_b32 %6, a150\n\tv_accvgpr_read_b32 %7, a151\n\tv_accvgpr_read_b32 %8, a152\n\tv_accvgpr_read_b32 %9, a153\n\tv_accvgpr_read_b32 %10, a154\n\tv_accvgpr_read_b32 %11, a155\n\tv_accvgpr_read_b32 %12, a156\n\tv_accvgpr_read_b32 %13, a157\n\tv_accvgpr_read_b32 %14, a158\n\tv_accvgpr_read_b32 %15, a159" : "=v"(t[0]), "=v"(t[1]), "=v"(t[2]), "=v"(t[3]), "=v"(t[4]), "=v"(t[5]), "=v"(t[6]), "=v"(t[7]), "=v"(t[8]), "=v"(t[9]), "=v"(t[10]), "=v"(t[11]), "=v"(t[12]), "=v"(t[13]), "=v"(t[14]), "=v"(t[15]));
-    else if constexpr (IDX == 10) asm volatile("v_accvgpr_read_b32 %0, a160\n\tv_accvgpr_read_b32 %1, a161\n\tv_accvgpr_read_b32 %2, a162\n\tv_accvgpr_read_b32 %3, a163\n\tv_accvgpr_read_b32 %4, a164\n\tv_accvgpr_read_b32 %5, a165\n\tv_accvgpr_read_b32 %6, a166\n\tv_accvgpr_read_b32 %7, a167\n\tv_accvgpr_read_b32 %8, a168\n\tv_accvgpr_read_b32 %9, a169\n\tv_accvgpr_read_b32 %10, a170\n\tv_accvgpr_read_b32 %11, a171\n\tv_accvgpr_read_b32 %12, a172\n\tv_accvgpr_read_b32 %13, a173\n\tv_accvgpr_read_b32 %14, a174\n\tv_accvgpr_read_b32 %15, a175" : "=v"(t[0]), "=v"(t[1]), "=v"(t[2]), "=v"(t[3]), "=v"(t[4]), "=v"(t[5]), "=v"(t[6]), "=v"(t[7]), "=v"(t[8]), "=v"(t[9]), "=v"(t[10]), "=v"(t[11]), "=v"(t[12]), "=v"(t[13]), "=v"(t[14]), "=v"(t[15]));
-    else if constexpr (IDX == 11) asm volatile("v_accvgpr_read_b32 %0, a176\n\tv_accvgpr_read_b32 %1, a177\n\tv_accvgpr_read_b32 %2, a178\n\tv_accvgpr_read_b32 %3, a179\n\tv_accvgpr_read_b32 %4, a180\n\tv_accvgpr_read_b32 %5, a181\n\tv_accvgpr_read_b32 %6, a182\n\tv_accvgpr_read_b32 %7, a183\n\tv_accvgpr_read_b32 %8, a184\n\tv_accvgpr_read_b32 %9, a185\n\tv_accvgpr_read_b32 %10, a186\n\tv_accvgpr_read_b32 %11, a187\n\tv_accvgpr_read_b32 %12, a188\n\tv_accvgpr_read_b32 %13, a189\n\tv_accvgpr_read_b32 %14, a190\n\tv_accvgpr_read_b32 %15, a191" : "=v"(t[0]), "=v"(t[1]), "=v"(t[2]), "=v"(t[3]), "=v"(t[4]), "=v"(t[5]), "=v"(t[6]), "=v"(t[7]), "=v"(t[8]), "=v"(t[9]), "=v"(t[10]), "=v"(t[11]), "=v"(t[12]), "=v"(t[13]), "=v"(t[14]), "=v"(t[15]));
-    else if constexpr (IDX == 12) asm volatile("v_accvgpr_read_b32 %0, a192\n\tv_accvgpr_read_b32 %1, a193\n\tv_accvgpr_read_b32 %2, a194\n\tv_accvgpr_read_b32 %3, a195\n\tv_accvgpr_read_b32 %4, a196\n\tv_accvgpr_read_b32 %5, a197\n\tv_accvgpr_read_b32 %6, a198\n\tv_accvgpr_read_b32 %7, a199\n\tv_accvgpr_read_b32 %8, a200\n\tv_accvgpr_read_b32 %9, a201\n\tv_accvgpr_read_b32 %10, a202\n\tv_accvgpr_read_b32 %11, a203\n\tv_accvgpr_read_b32 %12, a204\n\tv_accvgpr_read_b32 %13, a205\n\tv_accvgpr_read_b32 %14, a206\n\tv_accvgpr_read_b32 %15, a207" : "=v"(t[0]), "=v"(t[1]), "=v"(t[2]), "=v"(t[3]), "=v"(t[4]), "=v"(t[5]), "=v"(t[6]), "=v"(t[7]), "=v"(t[8]), "=v"(t[9]), "=v"(t[10]), "=v"(t[11]), "=v"(t[12]), "=v"(t[13]), "=v"(t[14]), "=v"(t[15]));
-    else if constexpr (IDX == 13) asm volatile("v_accvgpr_read_b32 %0, a208\n\tv_accvgpr_read_b32 %1, a209\n\tv_accvgpr_read_b32 %2, a210\n\tv_accvgpr_read_b32 %3, a211\n\tv_accvgpr_read_b32 %4, a212\n\tv_accvgpr_read_b32 %5, a213\n\tv_accvgpr_read_b32 %6, a214\n\tv_accvgpr_read_b32 %7, a215\n\tv_accvgpr_read_b32 %8, a216\n\tv_accvgpr_read_b32 %9, a217\n\tv_accvgpr_read_b32 %10, a218\n\tv_accvgpr_read_b32 %11, a219\n\tv_accvgpr_read_b32 %12, a220\n\tv_accvgpr_read_b32 %13, a221\n\tv_accvgpr_read_b32 %14, a222\n\tv_accvgpr_read_b32 %15, a223" : "=v"(t[0]), "=v"(t[1]), "=v"(t[2]), "=v"(t[3]), "=v"(t[4]), "=v"(t[5]), "=v"(t[6]), "=v"(t[7]), "=v"(t[8]), "=v"(t[9]), "=v"(t[10]), "=v"(t[11]), "=v"(t[12]), "=v"(t[13]), "=v"(t[14]), "=v"(t[15]));
-    else if constexpr (IDX == 14) asm volatile("v_accvgpr_read_b32 %0, a224\n\tv_accvgpr_read_b32 %1, a225\n\tv_accvgpr_read_b32 %2, a226\n\tv_accvgpr_read_b32 %3, a227\n\tv_accvgpr_read_b32 %4, a228\n\tv_accvgpr_read_b32 %5, a229\n\tv_accvgpr_read_b32 %6, a230\n\tv_accvgpr_read_b32 %7, a231\n\tv_accvgpr_read_b32 %8, a232\n\tv_accvgpr_read_b32 %9, a233\n\tv_accvgpr_read_b32 %10, a234\n\tv_accvgpr_read_b32 %11, a235\n\tv_accvgpr_read_b32 %12, a236\n\tv_accvgpr_read_b32 %13, a237\n\tv_accvgpr_read_b32 %14, a238\n\tv_accvgpr_read_b32 %15, a239" : "=v"(t[0]), "=v"(t[1]), "=v"(t[2]), "=v"(t[3]), "=v"(t[4]), "=v"(t[5]), "=v"(t[6]), "=v"(t[7]), "=v"(t[8]), "=v"(t[9]), "=v"(t[10]), "=v"(t[11]), "=v"(t[12]), "=v"(t[13]), "=v"(t[14]), "=v"(t[15]));
-    else if constexpr (IDX == 15) asm volatile("v_accvgpr_read_b32 %0, a240\n\tv_accvgpr_read_b32 %1, a241\n\tv_accvgpr_read_b32 %2, a242\n\tv_accvgpr_read_b32 %3, a243\n\tv_accvgpr_read_b32 %4, a244\n\tv_accvgpr_read_b32 %5, a245\n\tv_accvgpr_read_b32 %6, a246\n\tv_accvgpr_read_b32 %7, a247\n\tv_accvgpr_read_b32 %8, a248\n\tv_accvgpr_read_b32 %9, a249\n\tv_accvgpr_read_b32 %10, a250\n\tv_accvgpr_read_b32 %11, a251\n\tv_accvgpr_read_b32 %12, a252\n\tv_accvgpr_read_b32 %13, a253\n\tv_accvgpr_read_b32 %14, a254\n\tv_accvgpr_read_b32 %15, a255" : "=v"(t[0]), "=v"(t[1]), "=v"(t[2]), "=v"(t[3]), "=v"(t[4]), "=v"(t[5]), "=v"(t[6]), "=v"(t[7]), "=v"(t[8]), "=v"(t[9]), "=v"(t[10]), "=v"(t[11]), "=v"(t[12]), "=v"(t[13]), "=v"(t[14]), "=v"(t[15]));
-#pragma unroll
-    for (int r = 0; r < 16; ++r) out[r] = t[r];
-}
-
-__host__ __device__ constexpr int wide_acc_idx(int j) { return ((((j) & 3) >> 1) * 4 + ((j) >> 2)) * 2 + ((j) & 1); }   // MFMA j of a k-step -> AGPR tuple
-// VQS_WIDE_ABL (timing ablations, lab builds only; results are then garbage): 1 = no LDS-DMA in the K loop, 2 = no fragment reads
-#ifndef VQS_WIDE_ABL
-#define VQS_WIDE_ABL 0
-#endif
-// TOUCH = 1 (lab build, variant 9; not yet run on a GPU): waves 0 / 1 pull the cache lines of the A / W rows this workgroup is
-// responsible for -- its 1 / sharers part of the panels the XCD's window of concurrent tiles shares -- TWO K-tiles ahead into L2
-// with one dword LDS-DMA each per K-tile (into a sink nobody reads), so that the real staging DMA, issued one K-tile ahead, hits
-// L2 instead of waiting out the ~1 850-cycle far latency (the same hint the lock-step kernel uses for HBM-streamed panels; here
-// it addresses the form's whole problem).  The touch is the youngest VMEM op at the K-tile boundary: vmcnt(1) lets it fly.
-template <int EPI, int TOUCH = 0>
-__global__ void __launch_bounds__(256) gemm_bf16_wide(const GemmParams p) {
-    __shared__ __attribute__((aligned(16))) char wide_touch_sink[TOUCH != 0 ? 1024 : 16];
-    static_assert(EPI != EPI_RESID_RMS && EPI != EPI_F32_RESID && EPI != EPI_F32, "not carried by the wide form (fp32 results: lm_head and split-K partials, small launches)");
-    __shared__ __attribute__((aligned(16))) char lds[2 * STAGE_BYTES];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // 0..3, one wave per SIMD
-    const int wr = w >> 1, wc = w & 1;
-    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
-    const int nbatch = p.batch > 0 ? p.batch : 1;
-    const int nwg = tiles_m * tiles_n * nbatch;
-    const int nt = p.K / BK;
-    const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)LDS_PTR(lds));
-
-    auto tile_coords = [&](int pid, int& m0, int& n0, int& bz) {
-        tile_of_slot(pid, nwg, tiles_m, tiles_n, p.tile_gm, p.tile_ns, m0, n0, bz);
-    };
-
-    // staging: piece q (8 rows x 128 B = 1 KiB) of the A / W image, q = 4 i + w, i = 0..7; (row >> 1) & 7 of the row a lane stages
-    // = ((q & 1) << 2) + (lane >> 4) = ((w & 1) << 2) + (lane >> 4), as in the 8-wave forms.  Byte offsets in 32 bits (every
-    // operand of a batch entry is < 4 GiB): sixteen VGPRs of loop-carried state, not sixteen 64-bit pairs.
-    const int sw = ((w & 1) << 2) + (lane >> 4);
-    const uint32_t gchunk_b = (uint32_t)(((lane & 7) ^ sw) << 4);
-    const uint32_t lda_b = (uint32_t)p.lda * 2u, ldw_b = (uint32_t)p.ldw * 2u;
-    uint32_t pa[8], pb[8];
-    const v4i_t rsA = make_rsrc(p.A), rsW = make_rsrc(p.W);      // one batch entry (launcher): loop-invariant SGPR descriptors
-    auto set_ptrs = [&](int m0, int n0, int) {
-        const int r0 = w * 8 + (lane >> 3);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            pa[i] = (uint32_t)min(m0 + r0 + i * 32, p.M - 1) * lda_b + gchunk_b;
-            pb[i] = (uint32_t)min(n0 + r0 + i * 32, p.N - 1) * ldw_b + gchunk_b;
-        }
-    };
-    auto stage_all = [&](int s, int t) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const uint32_t da = lds_base + s * STAGE_BYTES + (i * 4 + w) * 1024;
-            bglds16(rsA, pa[i], (uint32_t)(t * BK * 2), da);
-            bglds16(rsW, pb[i], (uint32_t)(t * BK * 2), da + W_OFF);
-        }
-    };
-
-    const int swr = (lane >> 1) & 7;
-    int koff[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) koff[ks] = (((ks * 2 + (lane >> 5)) ^ swr) << 4);
-    const int a_row = (wr * 128 + (lane & 31)) * 128;
-    const int b_row = W_OFF + (wc * 128 + (lane & 31)) * 128;
-
-    int pid = blockIdx.x;
-    if (pid >= nwg) return;
-    int m0, n0, bz;
-    tile_coords(pid, m0, n0, bz);
-    set_ptrs(m0, n0, bz);
-    stage_all(0, 0);
-    int buf = 0;
-    bool counted = false;     // true: the only VMEM ops younger than the prefetched K-tile are a full epilogue's stores
-
-    // TOUCH state: wave 0 touches A rows, wave 1 W rows.  A window of 32 concurrent tiles per XCD is gm M-tiles x 32 / gm N-tiles:
-    // an A panel has 32 / gm sharers (this workgroup takes 8 gm of its 256 rows, picked by its N-tile index), a W panel gm sharers
-    const bool touch_wave = TOUCH != 0 && w < 2 && nt >= 2;
-    const v4i_t rsT = make_rsrc(w == 0 ? (const void*)p.A : (const void*)p.W);
-    const uint32_t touch_dst = (uint32_t)(uintptr_t)LDS_PTR(wide_touch_sink) + w * 256;
-    auto touch_off = [&](int tm0, int tn0) -> uint32_t {
-        const int gmr = p.tile_gm > 0 ? (p.tile_gm > 32 ? 32 : p.tile_gm) : 8;
-        if (w == 0) {
-            const int sharers = 32 / gmr > 0 ? 32 / gmr : 1, rows = 256 / sharers;
-            const int row = min(tm0 + rows * ((tn0 / BN) % sharers) + (lane % rows), p.M - 1);
-            return (uint32_t)row * lda_b;
-        }
-        const int rows = 256 / gmr;
-        const int row = min(tn0 + rows * ((tm0 / BM) % gmr) + (lane % rows), p.N - 1);
-        return (uint32_t)row * ldw_b;
-    };
-    uint32_t t_cur = 0, t_nxt = 0;
-
-    while (true) {
-        // accumulator (half, m, n) = columns n0 + wc*128 + half*64 + n*32 ..., rows m0 + wr*128 + m*32 ... lives in AGPR tuple
-        // (half*4 + m)*2 + n (see mfma_fixed); zeroed by the C = 0 form of the first k-step's MFMAs
-
-        const int next_pid = pid + gridDim.x;
-        const bool has_next = next_pid < nwg;
-        int nm0 = 0, nn0 = 0, nbz = 0;
-        if constexpr (TOUCH != 0) {
-            if (touch_wave) {
-                t_cur = touch_off(m0, n0);
-                if (has_next) {
-                    int xm0, xn0, xbz;
-                    tile_coords(next_pid, xm0, xn0, xbz);
-                    t_nxt = touch_off(xm0, xn0);
-                }
-            }
-        }
-
-        // One K-tile = 4 k-steps of 16 MFMAs, the instruction stream written out by hand (the MFMA statements are opaque to the
-        // scheduler, sched_barrier pins every LDS read where it stands): ONE wave per SIMD means one instruction per issue
-        // slot, and an MFMA leaves seven free slots in its 32-cycle shadow -- so never more than one LDS read or one LDS-DMA piece
-        // between two MFMAs.
-        //   k-steps 0..2: MFMA j of the current fragment set is followed (j < 8) by read j of the NEXT k-step's set;
-        //   k-steps 0, 1: MFMA j >= 8 is followed by one of the sixteen LDS-DMA pieces of the next K-tile (STAGE);
-        //   k-step 3: after its first 8 MFMAs the K-tile boundary (own DMA pieces landed, barrier), then MFMAs 8..15 each
-        //             followed by a read of the next K-tile's first set from the other stage (not LAST: the epilogue follows).
-        //   FIRST: first K-tile of an output tile, its k-step 0 writes the accumulators with C = 0.
-        // Read order A0 W0 W1 W2 W3 A1 A2 A3 = the order the next k-step's first MFMAs need them.
-        uint4 fa[2][4], fw[2][4];
-        // read R of k-step KS of the K-tile at SBASE into fragment set ST (order A0 W0 W1 W2 W3 A1 A2 A3); sched_barrier pins it
-#define WD_RDA(ST, M, SBASE, KS) if constexpr (!(VQS_WIDE_ABL & 2)) { fa[ST][M] = *reinterpret_cast<const uint4*>((SBASE) + a_row + (M) * 4096 + koff[KS]); } __builtin_amdgcn_sched_barrier(0)
-#define WD_RDW(ST, N, SBASE, KS) if constexpr (!(VQS_WIDE_ABL & 2)) { fw[ST][N] = *reinterpret_cast<const uint4*>((SBASE) + b_row + (N) * 4096 + koff[KS]); } __builtin_amdgcn_sched_barrier(0)
-#define WD_RD_0(ST, SBASE, KS) WD_RDA(ST, 0, SBASE, KS)
-#define WD_RD_1(ST, SBASE, KS) WD_RDW(ST, 0, SBASE, KS)
-#define WD_RD_2(ST, SBASE, KS) WD_RDW(ST, 1, SBASE, KS)
-#define WD_RD_3(ST, SBASE, KS) WD_RDW(ST, 2, SBASE, KS)
-#define WD_RD_4(ST, SBASE, KS) WD_RDW(ST, 3, SBASE, KS)
-#define WD_RD_5(ST, SBASE, KS) WD_RDA(ST, 1, SBASE, KS)
-#define WD_RD_6(ST, SBASE, KS) WD_RDA(ST, 2, SBASE, KS)
-#define WD_RD_7(ST, SBASE, KS) WD_RDA(ST, 3, SBASE, KS)
-#define WD_RD(ST, R, SBASE, KS) WD_RD_##R(ST, SBASE, KS)
-        // MFMA J of a k-step on set ST: row block J >> 2, column block J & 3 -> accumulator wide_acc_idx(J); ZERO: the C = 0 form
-#define WD_MFMA(ST, J, ZERO)                                                                                  \
-    do {                                                                                                      \
-        if constexpr (ZERO) mfma_fixed_zero<wide_acc_idx(J)>(fw[ST][(J) & 3], fa[ST][(J) >> 2]);              \
-        else mfma_fixed<wide_acc_idx(J)>(fw[ST][(J) & 3], fa[ST][(J) >> 2]);                                  \
-    } while (0)
-        // LDS-DMA instruction D = 0..15 of the next K-tile: even -> A piece D / 2, odd -> W piece D / 2
-#define WD_DMA(D)                                                                                             \
-    do {                                                                                                      \
-        if constexpr (STAGE && !(VQS_WIDE_ABL & 1)) {                                                         \
-            if (((D) & 1) == 0) bglds16(rsA, pa[(D) >> 1], koffs2, dst0 + ((D) >> 1) * 4096);                 \
-            else bglds16(rsW, pb[(D) >> 1], koffs2, dst0 + ((D) >> 1) * 4096 + W_OFF);                        \
-        }                                                                                                     \
-    } while (0)
-        auto ktile = [&](auto stage_tag, auto last_tag, auto first_tag, uint32_t koffs2, bool do_touch, uint32_t touch_voff, uint32_t touch_koff) {
-            constexpr bool STAGE = decltype(stage_tag)::value;
-            constexpr bool LAST = decltype(last_tag)::value;
-            constexpr bool FIRST = decltype(first_tag)::value;
-            const uint32_t dst0 = lds_base + (buf ^ 1) * STAGE_BYTES + w * 1024;
-            const char* sb = lds + buf * STAGE_BYTES;
-            const char* sn = lds + (buf ^ 1) * STAGE_BYTES;
-            // ---- k-step 0 (set 0): reads of k-step 1 -> set 1, then DMA instructions 0..7
-#define WD_A(J) WD_MFMA(0, J, FIRST); WD_RD(1, J, sb, 1);
-#define WD_B(J, D) WD_MFMA(0, J, FIRST); WD_DMA(D);
-            WD_A(0) WD_A(1) WD_A(2) WD_A(3) WD_A(4) WD_A(5) WD_A(6) WD_A(7)
-            WD_B(8, 0) WD_B(9, 1) WD_B(10, 2) WD_B(11, 3) WD_B(12, 4) WD_B(13, 5) WD_B(14, 6) WD_B(15, 7)
-#undef WD_A
-#undef WD_B
-            // ---- k-step 1 (set 1): reads of k-step 2 -> set 0, then DMA instructions 8..15
-#define WD_A(J) WD_MFMA(1, J, false); WD_RD(0, J, sb, 2);
-#define WD_B(J, D) WD_MFMA(1, J, false); WD_DMA(D);
-            WD_A(0) WD_A(1) WD_A(2) WD_A(3) WD_A(4) WD_A(5) WD_A(6) WD_A(7)
-            WD_B(8, 8) WD_B(9, 9) WD_B(10, 10) WD_B(11, 11) WD_B(12, 12) WD_B(13, 13) WD_B(14, 14) WD_B(15, 15)
-#undef WD_A
-#undef WD_B
-            // ---- k-step 2 (set 0): reads of k-step 3 -> set 1
-#define WD_A(J) WD_MFMA(0, J, false); WD_RD(1, J, sb, 3);
-#define WD_B(J) WD_MFMA(0, J, false);
-            WD_A(0) WD_A(1) WD_A(2) WD_A(3) WD_A(4) WD_A(5) WD_A(6) WD_A(7)
-            WD_B(8)
-            if constexpr (TOUCH != 0) {                            // after every real piece of this K-tile: the youngest VMEM op at the boundary
-                if (do_touch) bglds4s(rsT, touch_voff, touch_koff, touch_dst);
-            }
-            WD_B(9) WD_B(10) WD_B(11) WD_B(12) WD_B(13) WD_B(14) WD_B(15)
-#undef WD_A
-#undef WD_B
-            // ---- k-step 3 (set 1): 8 MFMAs, the K-tile boundary, 8 MFMAs each followed by a read of the next K-tile's set 0
-#define WD_A(J) WD_MFMA(1, J, false);
-#define WD_B(J, R) WD_MFMA(1, J, false); if constexpr (!LAST) { WD_RD(0, R, sn, 0); }
-            WD_A(0) WD_A(1) WD_A(2) WD_A(3) WD_A(4) WD_A(5) WD_A(6) WD_A(7)
-            if constexpr (!LAST) {
-                // WAR on stage `buf`: its last fragment reads (issued a k-step ago) are retired before the barrier after which
-                // another wave restages it (cdna_hip_programming.md: "1 phase after when an lgkmcnt ... retired those reads")
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (TOUCH != 0 && do_touch) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");   // ... all but this K-tile's touch
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own pieces of the next K-tile (issued >= 1.5 k-steps ago)
-                __builtin_amdgcn_s_barrier();                      // everybody's; and nobody reads stage `buf` any more
-            }
-            WD_B(8, 0) WD_B(9, 1) WD_B(10, 2) WD_B(11, 3) WD_B(12, 4) WD_B(13, 5) WD_B(14, 6) WD_B(15, 7)
-#undef WD_A
-#undef WD_B
-            buf ^= 1;
-        };
-
-        // top of an output tile: the prefetched first K-tile has landed (behind a counted epilogue: all but its stores)
-        if (counted) {
-            constexpr int NST = 2 * EpiStores<EPI>::value;       // two 64-column halves per wave
-            if constexpr (NST == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            else if constexpr (NST == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(63)" ::: "memory");   // the counter has 6 bits: 63 = "at most all but one store"
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        {
-            const char* s0 = lds + buf * STAGE_BYTES;
-            WD_RD(0, 0, s0, 0); WD_RD(0, 1, s0, 0); WD_RD(0, 2, s0, 0); WD_RD(0, 3, s0, 0);
-            WD_RD(0, 4, s0, 0); WD_RD(0, 5, s0, 0); WD_RD(0, 6, s0, 0); WD_RD(0, 7, s0, 0);
-        }
-
-        constexpr std::true_type YES{};
-        constexpr std::false_type NO{};
-        for (int t = 0; t < nt; ++t) {
-            const bool first = (t == 0);
-            // touch target: K-tile t + 2 of this tile, or K-tile t + 2 - nt of the next one
-            bool do_touch = false;
-            uint32_t tv = 0, tk = 0;
-            if constexpr (TOUCH != 0) {
-                if (touch_wave) {
-                    int kt2 = t + 2;
-                    tv = t_cur;
-                    do_touch = true;
-                    if (kt2 >= nt) {
-                        kt2 -= nt;
-                        tv = t_nxt;
-                        do_touch = has_next;
-                    }
-                    tk = (uint32_t)(kt2 * BK * 2);
-                }
-            }
-            if (t + 1 < nt) {
-                if (first) ktile(YES, NO, YES, (uint32_t)((t + 1) * BK * 2), do_touch, tv, tk);
-                else ktile(YES, NO, NO, (uint32_t)((t + 1) * BK * 2), do_touch, tv, tk);
-            } else if (has_next) {
-                tile_coords(next_pid, nm0, nn0, nbz);
-                set_ptrs(nm0, nn0, nbz);
-                if (first) ktile(YES, YES, YES, 0u, do_touch, tv, tk);
-                else ktile(YES, YES, NO, 0u, do_touch, tv, tk);
-            } else {
-                if (first) ktile(NO, YES, YES, 0u, do_touch, tv, tk);
-                else ktile(NO, YES, NO, 0u, do_touch, tv, tk);
-            }
-        }
-
-#undef WD_RD
-#undef WD_RD_0
-#undef WD_RD_1
-#undef WD_RD_2
-#undef WD_RD_3
-#undef WD_RD_4
-#undef WD_RD_5
-#undef WD_RD_6
-#undef WD_RD_7
-#undef WD_RDA
-#undef WD_RDW
-#undef WD_MFMA
-#undef WD_DMA
-
-        const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
-        // the MFMAs are opaque to the compiler's hazard recogniser: 18 wait states between the last one and the first
-        // v_accvgpr_read of its result (16-pass XDL write -> VALU read)
-        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
-        __builtin_amdgcn_s_barrier();                       // every wave is done reading stage buf^1
-        char* reg = lds + (buf ^ 1) * STAGE_BYTES + w * 16384;
-        {
-            f32x16 c[4][2];
-            acc_read<0>(c[0][0]); acc_read<1>(c[0][1]); acc_read<2>(c[1][0]); acc_read<3>(c[1][1]);
-            acc_read<4>(c[2][0]); acc_read<5>(c[2][1]); acc_read<6>(c[3][0]); acc_read<7>(c[3][1]);
-            staged_epilogue<EPI>(p, c, reg, m0, n0, bz, wr, 2 * wc, lane, full, nullptr);
-        }
-        {
-            f32x16 c[4][2];
-            acc_read<8>(c[0][0]); acc_read<9>(c[0][1]); acc_read<10>(c[1][0]); acc_read<11>(c[1][1]);
-            acc_read<12>(c[2][0]); acc_read<13>(c[2][1]); acc_read<14>(c[3][0]); acc_read<15>(c[3][1]);
-            staged_epilogue<EPI>(p, c, reg + 8192, m0, n0, bz, wr, 2 * wc + 1, lane, full, nullptr);
-        }
-        counted = full;
-        if (!has_next) break;
-        pid = next_pid;
-        m0 = nm0;
-        n0 = nn0;
-        bz = nbz;
-    }
-}
 
 
-#endif   // VQS_LAB (wide form)
 
-#ifdef VQS_LAB
-#include "lab/gemm_ws.inc"
-#endif
-
-
-#ifdef VQS_LAB
-#include "lab/gemm_ring.inc"
-#endif
 
 #include "gemm_quad.inc"
 
@@ -1599,12 +1186,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_pingpong(const GemmParams p) {
 // VQS_L2_TOUCH: 4 (default) = A-panel touch for N <= 2048; 3 = A and W panels for N <= 2048; 1 = A and W for every
 // lock-step launch; 0 = off
 static int l2_touch_mode() {
-#ifdef VQS_LAB
-    static const int mode = [] { const char* e = std::getenv("VQS_L2_TOUCH"); return e ? std::atoi(e) : 4; }();
-    return mode;
-#else
     return 4;
-#endif
 }
 
 // Which launches the quad form carries: a function of the epilogue and the WEIGHT's shape only (never of M).
@@ -1660,10 +1242,6 @@ static hipError_t launch_epi(const GemmParams& p, int variant, hipStream_t strea
     } else
     if (variant == 0 || (EPI == EPI_HEADS && p.S < 8 && variant != 1 && variant != 2))   // the staged epilogue steps rows by 8 within a sample
         hipLaunchKernelGGL((gemm_bf16_kernel<EPI, 0>), grid, block, 0, stream, p);
-#ifdef VQS_LAB
-    else if (variant == 1)
-        hipLaunchKernelGGL((gemm_bf16_kernel<EPI, 1>), grid, block, 0, stream, p);
-#endif
     else if (variant == 2)
         hipLaunchKernelGGL((gemm_bf16_kernel<EPI, 2>), grid, block, 0, stream, p);
     else if (form == 10) {
@@ -1673,32 +1251,12 @@ static hipError_t launch_epi(const GemmParams& p, int variant, hipStream_t strea
             const int nwg = tiles_m * tiles_n;
             hipLaunchKernelGGL((gemm_bf16_quad<EPI>), dim3(nwg < PERSISTENT_WGS ? nwg : PERSISTENT_WGS), dim3(256), 0, stream, p);
         }
-#ifdef VQS_LAB
-    } else if (variant == 6 && EPI != EPI_F32_RESID && EPI != EPI_F32 && p.batch <= 1 && tiles_m * tiles_n >= PERSISTENT_WGS) {
-        // wide form: bf16-result epilogues of the big launches; everything else of a variant-6 pass runs the default forms below
-        if constexpr (EPI != EPI_F32_RESID && EPI != EPI_F32)
-            hipLaunchKernelGGL((gemm_bf16_wide<EPI>), dim3(PERSISTENT_WGS), dim3(256), 0, stream, p);
-    } else if (variant == 9 && EPI != EPI_F32_RESID && EPI != EPI_F32 && p.batch <= 1 && tiles_m * tiles_n >= PERSISTENT_WGS) {
-        if constexpr (EPI != EPI_F32_RESID && EPI != EPI_F32)
-            hipLaunchKernelGGL((gemm_bf16_wide<EPI, 1>), dim3(PERSISTENT_WGS), dim3(256), 0, stream, p);
-    } else if (variant == 8 && EPI != EPI_F32_RESID && EPI != EPI_F32 && p.batch <= 1 && tiles_m * tiles_n >= PERSISTENT_WGS) {
-        if constexpr (EPI != EPI_F32_RESID && EPI != EPI_F32)
-            hipLaunchKernelGGL((gemm_bf16_ring<EPI>), dim3(PERSISTENT_WGS), dim3(256), 0, stream, p);
-#endif
     } else if (variant == 5 && EPI != EPI_F32_RESID) {
         if constexpr (EPI != EPI_F32_RESID) {
             const int nwg = tiles_m * tiles_n * (p.batch > 0 ? p.batch : 1);
             dim3 pgrid(nwg < PERSISTENT_WGS ? nwg : PERSISTENT_WGS);
             hipLaunchKernelGGL((gemm_bf16_pingpong<EPI>), pgrid, block, 0, stream, p);
         }
-#ifdef VQS_LAB
-    } else if (variant == 4 && EPI != EPI_F32_RESID) {
-        if constexpr (EPI != EPI_F32_RESID) {
-            const int nwg = tiles_m * tiles_n * (p.batch > 0 ? p.batch : 1);
-            dim3 pgrid(nwg < PERSISTENT_WGS ? nwg : PERSISTENT_WGS);
-            hipLaunchKernelGGL((gemm_bf16_ws<EPI>), pgrid, dim3(768), 0, stream, p);
-        }
-#endif
     } else {
         if constexpr (EPI == EPI_F32_RESID) {
             // the in-epilogue fp32 read-modify-write does not fit the persistent kernel's register budget (it
@@ -1734,9 +1292,7 @@ static hipError_t launch_epi(const GemmParams& p, int variant, hipStream_t strea
 hipError_t launch_gemm(const GemmParams& p_in, int epilogue, int variant, hipStream_t stream) {
     GemmParams p = p_in;
     resolve_tile_order(p, PERSISTENT_WGS);
-#ifndef VQS_LAB
     if (variant == 1 || variant == 4 || variant == 6 || variant == 7 || variant == 8 || variant == 9) return hipErrorInvalidValue;     // lab-only forms (see the file header)
-#endif
     // N: a lane stores 4 consecutive columns; fp32 output may have a ragged N if ldc leaves room for the overhang
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K % BK) != 0) return hipErrorInvalidValue;
     if ((p.N % 8) != 0 && !(epilogue == EPI_F32 && p.ldc >= ((p.N + 3) & ~3) && p.bias == nullptr)) return hipErrorInvalidValue;

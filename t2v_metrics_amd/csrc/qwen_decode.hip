@@ -32,6 +32,9 @@ __global__ void __launch_bounds__(64) qwen_decode_rope_append_kernel(const bf16_
     const int QN = (Hq + 2 * Hkv) * hd;
     const bf16_t* src = qkv + (size_t)b * QN + (size_t)slot * hd;
     const int pos = len[b];
+    // a stale or over-advanced d_len must not corrupt a neighbouring cache slab: positions outside [0, Lmax) write nothing
+    // (block-uniform early-out; the C-API caller owns d_len, only the Python wrapper checks it on the host)
+    if ((unsigned)pos >= (unsigned)Lmax) return;
     bf16_t* dst;
     bool rot = true;
     if (slot < Hq) {
@@ -78,7 +81,8 @@ __global__ void __launch_bounds__(256) qwen_decode_attn_kernel(const bf16_t* __r
     __shared__ float part[4][HD];
     const int h = blockIdx.x, b = blockIdx.y, t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int hk = h / (Hq / Hkv);
-    const int n = len[b] + 1;
+    // keys [0, len[b]]; a length outside the cache is clamped to it (the LDS score row holds Lmax floats)
+    const int n = min(max(len[b], 0), Lmax - 1) + 1;
     const bf16_t* K = kc + ((size_t)b * Hkv + hk) * Lmax * HD;
     const bf16_t* V = vc + ((size_t)b * Hkv + hk) * Lmax * HD;
     if (t < HD) qs[t] = d_bf2f(q[((size_t)b * Hq + h) * HD + t]);
@@ -136,7 +140,7 @@ __global__ void __launch_bounds__(256) qwen_decode_attn_kernel(const bf16_t* __r
 
 hipError_t launch_qwen_decode_attn(const bf16_t* q, const bf16_t* kc, const bf16_t* vc, const int* len, bf16_t* out, int B, int Hq,
                                    int Hkv, int Lmax, float scale, hipStream_t s) {
-    if (B <= 0 || Hq <= 0 || Hkv <= 0 || (Hq % Hkv) != 0 || Lmax <= 0 || Lmax > 36864 || B > 65535) return hipErrorInvalidValue;
+    if (B <= 0 || Hq <= 0 || Hkv <= 0 || (Hq % Hkv) != 0 || Lmax <= 0 || Lmax > 36864 /* VQS_QWEN_MAX_CACHE_POSITIONS */ || B > 65535) return hipErrorInvalidValue;
     const size_t lds = (size_t)Lmax * sizeof(float);
     if (lds > 48 * 1024) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(qwen_decode_attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -31,9 +31,6 @@ struct WEntry {
 #if defined(VQS_ATTN_TIMING) && VQS_ATTN_TIMING
 namespace vqs { hipError_t lab_set_attn_timing(unsigned long long* d_buf); }   // attn.hip, timing build only
 #endif
-#if defined(VQS_LAB) && defined(VQS_RING_TIMING) && VQS_RING_TIMING
-namespace vqs { hipError_t lab_set_ring_timing(unsigned long long* d_buf); }   // lab/gemm_ring.inc, timing build only
-#endif
 
 struct vqs_handle {
     vqs_config c;
@@ -421,10 +418,6 @@ int vqs_debug_tile_order(int32_t M, int32_t N, int32_t K, int32_t batch, int32_t
 int vqs_lab_set_attn_timing(void* d_buf) { return vqs::lab_set_attn_timing((unsigned long long*)d_buf) == hipSuccess ? VQS_OK : VQS_ERR_HIP; }
 #endif
 
-#if defined(VQS_LAB) && defined(VQS_RING_TIMING) && VQS_RING_TIMING
-// lab timing build only (make lab LABFLAGS=-DVQS_RING_TIMING=1): d_buf = 8 x uint64 on the device, zeroed by the caller
-int vqs_lab_set_ring_timing(void* d_buf) { return vqs::lab_set_ring_timing((unsigned long long*)d_buf) == hipSuccess ? VQS_OK : VQS_ERR_HIP; }
-#endif
 
 int64_t vqs_attention_lds_bytes(int32_t S, int32_t has_bias, int32_t hd) {
     if (S <= 0 || (hd != 0 && hd != 64 && hd != 128)) return -1;
@@ -476,14 +469,6 @@ int vqs_create(const vqs_config* cfg, vqs_handle** out) {
         h->h_lut_causal.push_back(vqs_relpos_bucket(-n, 0, c.rel_buckets, c.rel_max_distance));
     }
     h->gemm_variant = 3;   // persistent kernel, schedule chosen by shape (gemm.hip)
-#ifdef VQS_LAB
-    // lab builds only (tools/lab): in-situ A/B of the alternative forms through the environment
-    if (const char* cm = std::getenv("VQS_CROSS_MODE")) h->cross_mode = std::atoi(cm);
-    if (const char* sk = std::getenv("VQS_SPLITK")) h->splitk = std::atoi(sk);
-    if (const char* fn = std::getenv("VQS_FUSED_NORM")) h->fused_norm = std::atoi(fn);
-    if (const char* nd = std::getenv("VQS_NORM_DEFER")) h->norm_defer = std::atoi(nd);
-    if (const char* v = std::getenv("VQS_GEMM_VARIANT")) h->gemm_variant = std::atoi(v);
-#endif
     return VQS_OK;
 }
 
@@ -495,9 +480,6 @@ int vqs_set_option(vqs_handle* h, const char* name, int32_t value) {
     else if (n == "fused_norm" && (value == 0 || value == 1)) h->fused_norm = value;
     else if (n == "norm_defer" && (value == 0 || value == 1)) h->norm_defer = value;
     else if (n == "gemm_variant" && (value == 0 || value == 2 || value == 3 || value == 5 || value == 11)) h->gemm_variant = value;
-#ifdef VQS_LAB
-    else if (n == "gemm_variant" && (value == 6 || value == 7 || value == 8 || value == 9)) h->gemm_variant = value;     // lab forms: wide, forced lock-step, ring, wide + touch
-#endif
     else if (n.rfind("l2_touch:", 0) == 0 || n.rfind("nt_store:", 0) == 0 || n.rfind("tile_order:", 0) == 0) {
         // per weight shape [N, K], for the big launches of a pass; 0 removes the entry = the library's choice.  All three are
         // bitwise-neutral cache-policy knobs:

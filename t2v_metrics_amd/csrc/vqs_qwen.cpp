@@ -774,6 +774,8 @@ int vqs_qwen_prefill(vqs_qwen_handle* h, const void* d_merged, const int32_t* d_
                      int32_t L, float* d_logits, void* d_ws, size_t ws_bytes, void* d_kv, size_t kv_bytes, int32_t Lmax, void* stream) {
     if (!h) return VQS_ERR_INVALID;
     if (!d_kv || Lmax < L || kv_bytes < vqs_qwen_kv_bytes(h, B, Lmax)) return qfail(h, VQS_ERR_WORKSPACE, "prefill: KV cache missing or too small");
+    if (Lmax > VQS_QWEN_MAX_CACHE_POSITIONS)      // the decode step's one-row attention keeps Lmax fp32 scores in LDS: refuse BEFORE the prefill is spent
+        return qfail(h, VQS_ERR_INVALID, "prefill: Lmax exceeds the decode kernel's limit (" + std::to_string(VQS_QWEN_MAX_CACHE_POSITIONS) + " cache positions)");
     return score_impl(h, d_merged, d_input_ids, d_vis_slot, d_seq_len, d_last_row, d_cos, d_sin, B, L, d_logits, d_ws, ws_bytes, stream, d_kv,
                       Lmax);
 }
@@ -789,6 +791,7 @@ int vqs_qwen_decode(vqs_qwen_handle* h, const int32_t* d_ids, const int32_t* d_l
     if (!h->bound) return qfail(h, VQS_ERR_STATE, "decode: weights not bound");
     if (!d_ids || !d_len || !d_cos || !d_sin || !d_kv || !d_logits || !d_ws) return qfail(h, VQS_ERR_INVALID, "decode: null argument");
     if (B <= 0 || Lmax <= 0) return qfail(h, VQS_ERR_INVALID, "decode: need B > 0, Lmax > 0");
+    if (Lmax > VQS_QWEN_MAX_CACHE_POSITIONS) return qfail(h, VQS_ERR_INVALID, "decode: Lmax exceeds " + std::to_string(VQS_QWEN_MAX_CACHE_POSITIONS) + " cache positions");
     if (kv_bytes < vqs_qwen_kv_bytes(h, B, Lmax)) return qfail(h, VQS_ERR_WORKSPACE, "decode: KV cache too small");
     const vqs_qwen_config& c = h->c;
     const DecWs w = carve_decode(h, (char*)d_ws, B);

@@ -75,19 +75,34 @@ def patchify(frames: torch.Tensor, patch: int = 14, merge: int = 2, temporal: in
     return x.reshape(t * h * w, C * temporal * patch * patch).contiguous(), (t, h, w)
 
 
+HF_DEFAULT_TOP_K = 50      # transformers GenerationConfig default; a checkpoint's generation_config.json may override it
+
+
+def _read_generation_json(checkpoint_dir: str) -> dict:
+    import json
+    path = os.path.join(checkpoint_dir, "generation_config.json")
+    if not os.path.isfile(path):
+        return {}
+    with open(path) as f:
+        return json.load(f)
+
+
 def read_generation_config(checkpoint_dir: str):
     """(repetition_penalty, eos ids) from generation_config.json of the checkpoint directory: HF generate() applies the
     penalty in greedy mode too and stops at ANY of generation_config.eos_token_id (an int or a list -- [<|im_end|>,
     <|endoftext|>] for the Instruct checkpoints), not only at the tokenizer's eos.  (1.0, []) if the file is absent."""
-    import json
-    path = os.path.join(checkpoint_dir, "generation_config.json")
-    if not os.path.isfile(path):
-        return 1.0, []
-    with open(path) as f:
-        g = json.load(f)
+    g = _read_generation_json(checkpoint_dir)
     eos = g.get("eos_token_id", [])
     eos = [int(eos)] if isinstance(eos, int) else [int(e) for e in (eos or [])]
     return float(g.get("repetition_penalty", 1.0)), eos
+
+
+def read_top_k(checkpoint_dir: str) -> int:
+    """generation_config.top_k of the checkpoint; HF's default 50 when the file or the key is absent.  The reference's sampling
+    call (qwen2vl_model.py:541-546) passes do_sample / temperature / top_p only, so HF also applies THIS top-k filter
+    (TopKLogitsWarper sits between the temperature and the top-p warpers, generation/utils.py _get_logits_processor)."""
+    k = _read_generation_json(checkpoint_dir).get("top_k", HF_DEFAULT_TOP_K)
+    return HF_DEFAULT_TOP_K if k is None else int(k)
 
 
 def read_repetition_penalty(checkpoint_dir: str) -> float:
@@ -128,6 +143,7 @@ class Qwen25VLModel(VQAScoreModel):
         self.cfg = self._cfg
         self.repetition_penalty = 1.0
         self._gen_eos_ids = []
+        self.top_k = HF_DEFAULT_TOP_K
         if self._tokenizer_arg is not None:
             self.tokenizer = self._tokenizer_arg
         else:
@@ -153,6 +169,7 @@ class Qwen25VLModel(VQAScoreModel):
             from ...qwen.weights import load_qwen_checkpoint
             weights = load_qwen_checkpoint(path)           # accepts the published (legacy) and the in-memory key layout
             self.repetition_penalty, self._gen_eos_ids = read_generation_config(path)
+            self.top_k = read_top_k(path)
         self.engine = QwenEngine(self.cfg, weights, device=dev)
 
     # ------------------------------------------------------------------ host-side preparation
@@ -192,6 +209,47 @@ class Qwen25VLModel(VQAScoreModel):
         mean = torch.tensor(OPENAI_CLIP_MEAN).view(1, 3, 1, 1)
         std = torch.tensor(OPENAI_CLIP_STD).view(1, 3, 1, 1)
         return patchify((x - mean) / std, v.patch, v.spatial_merge, v.temporal_patch)
+
+    def _prepare_media(self, images, fps=None):
+        """Load and preprocess every DISTINCT medium once (same path string = same medium; the reference re-reads and re-encodes
+        the file for every prompt, score.py:104-106 + qwen2vl_model.py:190).  -> (prepared [(patches, grid)] per distinct medium,
+        kinds ['image'|'video'] per distinct medium, media_of [index into those] per sample)."""
+        first: Dict[str, int] = {}
+        media_of, uniq = [], []
+        for p in images:
+            key = p if isinstance(p, str) else None
+            if key is not None and key in first:
+                media_of.append(first[key])
+                continue
+            if key is not None:
+                first[key] = len(uniq)
+            media_of.append(len(uniq))
+            uniq.append(p)
+        items = self.load_images(uniq, fps)
+        # decode/resize/patch-flatten on a thread pool (PIL and torch release the GIL in their inner loops)
+        if len(items) > 1 and self.num_workers > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=min(self.num_workers, len(items))) as pool:
+                prepared = list(pool.map(self.preprocess, items))
+        else:
+            prepared = [self.preprocess(it) for it in items]
+        return prepared, [it['type'] for it in items], media_of
+
+    def _media_windows(self, prepared, media_of):
+        """Walk the samples grid by grid, medium by medium: yields (grid, sample indices, {medium: merged vision tokens
+        [n_tok, out_hidden]}) for windows of at most max_batch DISTINCT media.  Every medium is in exactly one window, so it is
+        encoded exactly once (one tower call per window) and its tokens live only while its own samples are scored -- the
+        device holds max_batch media at a time however long the pair list is."""
+        by_grid: Dict[Tuple[int, int, int], Dict[int, List[int]]] = {}
+        for i, u in enumerate(media_of):
+            by_grid.setdefault(prepared[u][1], {}).setdefault(u, []).append(i)
+        for g, by_medium in by_grid.items():
+            n_tok = g[0] * g[1] * g[2] // self.cfg.vision.merge_unit
+            us = list(by_medium)
+            for s in range(0, len(us), self.max_batch):
+                chunk = us[s: s + self.max_batch]
+                merged = self.engine.encode_vision(torch.cat([prepared[u][0] for u in chunk]), [g] * len(chunk))
+                yield g, [i for u in chunk for i in by_medium[u]], {u: merged[k * n_tok: (k + 1) * n_tok] for k, u in enumerate(chunk)}
 
     def build_ids(self, question: str, kind: str, n_tokens: int) -> List[int]:
         ph = VIDEO_PLACEHOLDER if kind == 'video' else IMAGE_PLACEHOLDER
@@ -251,27 +309,17 @@ class Qwen25VLModel(VQAScoreModel):
             raise ValueError("max_new_tokens must be >= 1")
         questions = [question_template.format(t) for t in texts]
         answers = [answer_template.format(t) for t in texts]
-        items = self.load_images(images, fps)
-        # decode/resize/patch-flatten on a thread pool (PIL and torch release the GIL in their inner loops)
-        if len(items) > 1 and self.num_workers > 1:
-            from concurrent.futures import ThreadPoolExecutor
-            with ThreadPoolExecutor(max_workers=min(self.num_workers, len(items))) as pool:
-                prepared = list(pool.map(self.preprocess, items))
-        else:
-            prepared = [self.preprocess(it) for it in items]
+        prepared, kinds, media_of = self._prepare_media(images, fps)
         stops = self._stop_ids()
         out = [None] * len(images)
-        # batch samples that share a grid (one vision call per group), at most max_batch at a time
-        groups: Dict[Tuple[int, int, int], List[int]] = {}
-        for i, (_, g) in enumerate(prepared):
-            groups.setdefault(g, []).append(i)
-        for g, idxs in groups.items():
+        # a sample's vision rows are its MEDIUM's (encoded once per call, however many prompts share it); samples are batched
+        # by grid, at most max_batch at a time
+        for g, idxs, merged_of in self._media_windows(prepared, media_of):
             for s in range(0, len(idxs), self.max_batch):
                 chunk = idxs[s: s + self.max_batch]
-                patches = torch.cat([prepared[i][0] for i in chunk])
-                merged = self.engine.encode_vision(patches, [g] * len(chunk))
+                merged = torch.cat([merged_of[media_of[i]] for i in chunk])
                 n_tok = g[0] * g[1] * g[2] // self.cfg.vision.merge_unit
-                rows = [self.build_ids(questions[i], items[i]['type'], n_tok) for i in chunk]
+                rows = [self.build_ids(questions[i], kinds[media_of[i]], n_tok) for i in chunk]
                 a_ids = [list(self.tokenizer.encode(answers[i], add_special_tokens=False)) for i in chunk]
                 if any(len(a) < 1 for a in a_ids):
                     raise ValueError("empty answer")
@@ -303,6 +351,14 @@ class Qwen25VLModel(VQAScoreModel):
             p = self._token_probs(torch.stack([step_scores[q] for q in pos]), torch.tensor(a_ids[:n_ans]), temperature)
             scores[i] = float(torch.prod(p.double()) ** (1.0 / n_ans))
         return scores
+
+    @torch.no_grad()
+    def forward_grid(self, images: List[str], texts: List[str], **kwargs) -> torch.Tensor:
+        """M media x N texts -> [M, N] (Score.forward's grid, /root/reference/t2v_metrics/score.py:103-106) as ONE pair list:
+        M tower passes, not M*N -- the reference calls forward([image] * N, texts) per image and re-encodes it N times."""
+        flat_i = [im for im in images for _ in texts]
+        flat_t = [t for _ in images for t in texts]
+        return self.forward(flat_i, flat_t, **kwargs).reshape(len(images), len(texts))
 
     @torch.no_grad()
     def forward_with_trace(self, images: List[str], texts: List[str], fps=None, question_template: str = default_question_template,
@@ -359,14 +415,22 @@ class Qwen25VLModel(VQAScoreModel):
         return torch.tensor(probs), traces
 
     @staticmethod
-    def _warp(scores: torch.Tensor, temperature: float, top_p: float) -> torch.Tensor:
-        """HF TemperatureLogitsWarper then TopPLogitsWarper (generation/logits_process.py): scores / temperature; sorted ascending,
-        the low tail whose cumulative probability is <= 1 - top_p is set to -inf, the most likely token always stays."""
+    def _warp(scores: torch.Tensor, temperature: float, top_p: float, top_k: int = 0) -> torch.Tensor:
+        """The warper chain HF builds for generate(do_sample=True, temperature=, top_p=) (generation/utils.py
+        _get_logits_processor, generation/logits_process.py): TemperatureLogitsWarper (scores / temperature), TopKLogitsWarper
+        (generation_config.top_k, default 50: everything below the k-th largest score -> -inf; 0 / None = no filter), then
+        TopPLogitsWarper (sorted ascending, the low tail whose cumulative probability is <= 1 - top_p -> -inf, the most likely
+        token always stays)."""
         x = scores.float() / temperature
-        srt, idx = x.sort(-1, descending=False)
-        drop = torch.softmax(srt, -1).cumsum(-1) <= (1.0 - top_p)
-        drop[..., -1:] = False
-        return x.masked_fill(torch.zeros_like(drop).scatter(-1, idx, drop), float("-inf"))
+        if top_k and top_k > 0:
+            k = min(int(top_k), x.shape[-1])
+            x = x.masked_fill(x < torch.topk(x, k)[0][..., -1, None], float("-inf"))
+        if top_p is not None and top_p < 1.0:
+            srt, idx = x.sort(-1, descending=False)
+            drop = torch.softmax(srt, -1).cumsum(-1) <= (1.0 - top_p)
+            drop[..., -1:] = False
+            x = x.masked_fill(torch.zeros_like(drop).scatter(-1, idx, drop), float("-inf"))
+        return x
 
     def _greedy(self, merged, rows: List[List[int]], grids, max_new_tokens: int, stops: List[int], pick=None):
         """Shared generation loop: prompt rows (token id lists, one video run each) -> (per-sample list of processed score rows,
@@ -405,28 +469,24 @@ class Qwen25VLModel(VQAScoreModel):
     def generate(self, images: List[str], texts: List[str], fps=None, max_new_tokens: int = 2048, temperature: float = 0.0,
                  do_sample: bool = None, top_p: float = 0.9) -> List[str]:
         """Free-form answers (qwen2vl_model.py:495-563): the text is the whole user turn; greedy unless temperature > 0, then
-        HF's temperature + nucleus sampling (TemperatureLogitsWarper, TopPLogitsWarper: the smallest set of tokens whose
-        probability reaches top_p is kept).  Decoded with skip_special_tokens=True and stripped."""
+        HF's sampling chain for those kwargs: temperature, the generation config's top-k (default 50), nucleus top_p (`_warp`).
+        Decoded with skip_special_tokens=True and stripped."""
         assert len(images) == len(texts), "Number of paths and texts must match"
         if do_sample is None:
             do_sample = temperature > 0
-        items = self.load_images(images, fps)
-        prepared = [self.preprocess(it) for it in items]
+        prepared, kinds, media_of = self._prepare_media(images, fps)
         pick = None
         if do_sample and temperature > 0:
             def pick(proc):
-                return torch.multinomial(torch.softmax(self._warp(proc, temperature, top_p), -1), 1)[:, 0]
+                return torch.multinomial(torch.softmax(self._warp(proc, temperature, top_p, getattr(self, "top_k", HF_DEFAULT_TOP_K)), -1), 1)[:, 0]
         stops = self._stop_ids()
         out = [""] * len(images)
-        groups: Dict[Tuple[int, int, int], List[int]] = {}
-        for i, (_, g) in enumerate(prepared):
-            groups.setdefault(g, []).append(i)
-        for g, idxs in groups.items():
+        for g, idxs, merged_of in self._media_windows(prepared, media_of):
             for s in range(0, len(idxs), self.max_batch):
                 chunk = idxs[s: s + self.max_batch]
-                merged = self.engine.encode_vision(torch.cat([prepared[i][0] for i in chunk]), [g] * len(chunk))
+                merged = torch.cat([merged_of[media_of[i]] for i in chunk])
                 n_tok = g[0] * g[1] * g[2] // self.cfg.vision.merge_unit
-                rows = [self.build_ids(texts[i], items[i]['type'], n_tok) for i in chunk]
+                rows = [self.build_ids(texts[i], kinds[media_of[i]], n_tok) for i in chunk]
                 _, gen = self._greedy(merged, rows, [g] * len(chunk), max_new_tokens, stops, pick)
                 for k, i in enumerate(chunk):
                     out[i] = self.tokenizer.decode(gen[k], skip_special_tokens=True).strip()

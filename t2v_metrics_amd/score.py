@@ -12,9 +12,10 @@ with the two hot loops rebuilt as real batches:
   * with ``torch.distributed`` initialised, ``batch_forward`` shards the samples over ranks (contiguous blocks) and
     all-gathers the scores (t2v_metrics_amd/sharding.py) -- the reference has no multi-GPU path.
 
-Video inputs: the reference falls back to extracting frames with ffmpeg/cv2 and concatenating them into one image
-for image-only models (score.py:72-101).  That pre-processing is outside the hot path (SURVEY.md §2 "frame helpers
-OUT OF SCOPE"); video paths raise NotImplementedError here instead of being silently mis-scored.
+Video inputs: as in the reference the decision is the model's ``video_mode`` (score.py:69-101): "direct" models get the
+container paths untouched (Qwen2.5-VL reads frame arrays; container decode needs decord/ffmpeg, which this image does
+not have, and says so itself), "concat" is the reference's ffmpeg/cv2 frame-concat pre-processing for image-only models
+-- outside the hot path (SURVEY.md §2 "frame helpers OUT OF SCOPE"): NotImplementedError instead of a silent mis-score.
 """
 from typing import List, Optional, TypedDict, Union
 
@@ -58,9 +59,19 @@ class Score(nn.Module):
             images = [images]
         if isinstance(texts, str):
             texts = [texts]
+        # video container paths: the gate is the MODEL's, as in the reference (score.py:69-101) -- a video-native model
+        # (video_mode "direct", e.g. qwen2.5-vl-7b) receives the paths untouched and decides itself what it can read
+        # (qwen2vl_model.py:135-158); "concat" = the ffmpeg/cv2 frame-concat pre-processing for image-only models, which is
+        # outside the MI355X hot path; anything else prints the reference's message and returns None like it does.
         if any(isinstance(img, str) and img[-4:].lower() in _VIDEO_EXT for img in images):
-            raise NotImplementedError("video inputs need the reference's ffmpeg/cv2 frame-concat pre-processing "
-                                      "(score.py:72-101), which is outside the MI355X hot path")
+            mode = getattr(self.model, "video_mode", None)
+            if mode == "concat":
+                raise NotImplementedError("video inputs for image-only models need the reference's ffmpeg/cv2 frame-concat "
+                                          "pre-processing (score.py:72-98), which is outside the MI355X hot path; pass "
+                                          "extracted frames or use a video-native model")
+            elif mode != "direct":
+                print("Invalid `video_mode` for the given model. Please check model's class attributes")
+                return
         if hasattr(self.model, 'forward_grid'):
             scores = self.model.forward_grid(images, texts, **kwargs)
         else:   # plain plugin interface: one call per image, as the reference does

@@ -361,6 +361,64 @@ def test_logits_processing_equals_hf_processors():
         got = Qwen25VLModel._warp(scores, temperature, top_p)
         assert torch.equal(torch.isinf(got), torch.isinf(ref)) and torch.allclose(got[~torch.isinf(got)], ref[~torch.isinf(ref)])
     assert int((~torch.isinf(Qwen25VLModel._warp(scores, 2.0, 1e-6))).sum()) == scores.shape[0]      # only the top token survives
+    # the chain HF itself builds for the reference's call generate(do_sample=True, temperature=, top_p=) with the library's
+    # default generation config: temperature -> top-k 50 -> top-p (the top-k warper was missing here)
+    from transformers import GenerationConfig
+    from transformers.generation.utils import GenerationMixin
+    for temperature, top_p in ((0.7, 0.9), (3.0, 0.95), (5.0, 0.999)):
+        gc = GenerationConfig(do_sample=True, temperature=temperature, top_p=top_p)
+        if gc.top_k is None:          # transformers 5.x applies the library defaults at generate() time (_prepare_generation_config)
+            gc.update(**GenerationConfig._get_default_generation_params(), defaults_only=True)
+        assert gc.top_k == 50
+        chain = GenerationMixin._get_logits_processor(GenerationMixin.__new__(GenerationMixin), gc, input_ids_seq_length=1,
+                                                      encoder_input_ids=None, prefix_allowed_tokens_fn=None, logits_processor=[])
+        assert [type(c).__name__ for c in chain] == ["TemperatureLogitsWarper", "TopKLogitsWarper", "TopPLogitsWarper"]
+        ref = chain(torch.zeros(scores.shape[0], 1, dtype=torch.long), scores.clone())
+        got = Qwen25VLModel._warp(scores, temperature, top_p, 50)
+        assert torch.equal(torch.isinf(got), torch.isinf(ref)) and torch.allclose(got[~torch.isinf(got)], ref[~torch.isinf(ref)])
+        assert int((~torch.isinf(got)).sum(-1).max()) <= 50
+    assert m.top_k == 50                                                    # no generation_config.json: HF's default
+
+
+def test_generation_config_top_k_is_read(tmp_path):
+    import json
+    from t2v_metrics_amd.models.vqascore_models.qwen25vl_model import read_top_k
+    assert read_top_k(str(tmp_path)) == 50
+    (tmp_path / "generation_config.json").write_text(json.dumps({"top_k": 1, "top_p": 0.001, "repetition_penalty": 1.05}))
+    assert read_top_k(str(tmp_path)) == 1
+
+
+def test_grid_costs_one_tower_pass_per_medium_and_video_paths_reach_the_model(tmp_path):
+    """An M x N grid runs the vision tower M times (the reference: M * N, score.py:104-106): Score.forward goes through
+    forward_grid, identical paths are one medium, and a medium's pairs never straddle two tower calls even when M * N exceeds
+    max_batch.  Container paths are passed to a video_mode == 'direct' model as the reference does (score.py:69-101); the model
+    itself refuses what it cannot decode (qwen2vl_model.py:135-158 needs decord)."""
+    cfg = get_qwen_config("qwen-tiny")
+    w = make_seeded_qwen_weights(cfg, seed=3, dtype=torch.bfloat16, lm_head_gain=4.0)
+    eng = OracleQwenEngine(cfg, w)
+    tok = FakeQwenTokenizer(cfg.text.vocab)
+    rng = np.random.RandomState(5)
+    paths = []
+    for i, shape in enumerate([(4, 112, 112, 3), (4, 112, 112, 3), (112, 168, 3)]):
+        p = tmp_path / f"m{i}.npy"
+        np.save(p, rng.randint(0, 256, shape, dtype=np.uint8))
+        paths.append(str(p))
+    texts = ["a cat jumps", "a dog runs fast", "two birds", "a red car", "rain"]
+    scorer = t2v.VQAScore(model="qwen2.5-vl-7b", device="cpu", config=cfg, engine=eng, tokenizer=tok, max_batch=4)
+    grid = scorer(images=paths, texts=texts)                       # 3 x 5 = 15 pairs, max_batch 4
+    assert grid.shape == (3, 5)
+    media_encoded = sum(len(c) for c in eng.vision_calls)
+    assert media_encoded == 3, eng.vision_calls                    # one tower pass per medium, not 15
+    # the grid equals pair-by-pair scoring (the reference's row loop)
+    eng.vision_calls.clear()
+    for i in (0, 2):
+        row = scorer.model.forward([paths[i]] * len(texts), texts)
+        assert torch.allclose(grid[i].cpu(), row, rtol=1e-5, atol=1e-7)
+    assert sum(len(c) for c in eng.vision_calls) == 2              # [path] * N is ONE medium as well
+    # video container paths: passed through to the direct-mode model, which refuses them itself
+    assert scorer.model.video_mode == "direct"
+    with pytest.raises(NotImplementedError, match="decord"):
+        scorer(images=["clip.mp4"], texts=["x"])
 
 
 def test_forward_with_trace_follows_the_reference_rules(tmp_path):

@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""Where the end-to-end |delta log P| of the HIP path comes from, by ROUNDING CLASS (CPU only).
+
+The rounding-matched oracle (oracle/clip_t5_engine_rounding.py) has a round-to-bf16 at every point where the engine holds a
+bf16 tensor; each such site carries a class name (`EngineRoundedOracle.CLASSES`, "<stack>.<what>").  This tool evaluates the
+bench pairs with ONE class rounding and everything else in fp32, and tabulates the distance of the label log-probs from the
+all-fp32 run -- the contribution of that class alone -- next to the stack-level groups, the engine's full set, and the
+candidate set "everything the engine could hold in fp32 / split-bf16 at < 2 % of a step" (decoder side, lm_head input,
+projector) switched off.  The lm_head is the last op and linear, so each run is read out under several head gains
+(lm_head x gain: gain 4 = peaked head) at no extra cost.
+
+Stage results are shared between runs: a decoder-side class reuses the unrounded vision + projector + encoder pass, an
+encoder-side class the unrounded vision + projector pass.
+
+  python tools/error_attribution.py --model clip-flant5-xl --pairs 16 --out profiles/r4_error_attribution
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import bench  # noqa: E402  (synth_batch: the bench's own pair generator)
+from oracle.clip_t5_engine_rounding import EngineRoundedOracle  # noqa: E402
+from oracle.clip_t5_oracle import Oracle, shift_right  # noqa: E402
+from t2v_metrics_amd.config import get_config  # noqa: E402
+from t2v_metrics_amd.weights import make_seeded_weights  # noqa: E402
+
+ALL = EngineRoundedOracle.CLASSES
+CHEAP = tuple(c for c in ALL if c.startswith(("dec.", "proj.")) or c == "enc.out")   # < 2.5 % of an XXL step in total
+
+
+def stack_of(c):
+    return c.split(".")[0]
+
+
+class Runner:
+    """Evaluates a class set, reusing upstream stage results that the set cannot have changed."""
+
+    def __init__(self, cfg, w, batch, acc, gains):
+        self.cfg, self.w, self.acc, self.gains = cfg, w, acc, gains
+        self.pix, self.idx, self.ids, self.labels = batch
+        self.cache = {}
+
+    def _oracle(self, classes):
+        return EngineRoundedOracle(self.cfg, self.w, acc=self.acc, classes=classes)
+
+    def run(self, classes):
+        classes = frozenset(classes)
+        o = self._oracle(classes)
+        with torch.no_grad():
+            k_vit = frozenset(c for c in classes if stack_of(c) == "vit")
+            k_proj = (k_vit, frozenset(c for c in classes if stack_of(c) == "proj"))
+            k_enc = (k_proj, frozenset(c for c in classes if stack_of(c) == "enc"))
+            if ("vit", k_vit) not in self.cache:
+                self.cache[("vit", k_vit)] = o.vision_features(self.pix)
+            if ("proj", k_proj) not in self.cache:
+                self.cache[("proj", k_proj)] = o.projector(self.cache[("vit", k_vit)])
+            if ("enc", k_enc) not in self.cache:
+                emb, mask, _ = o.splice(self.cache[("proj", k_proj)], self.idx, self.ids)
+                self.cache[("enc", k_enc)] = (o.t5_encoder(emb, mask), mask)
+            enc, mask = self.cache[("enc", k_enc)]
+            dec = o.t5_decoder(shift_right(self.labels, self.cfg.t5.decoder_start_id, self.cfg.t5.pad_id), enc, mask)
+            logits = o.lm_logits(dec)
+            return {g: Oracle.label_logprobs(logits * g, self.labels) for g in self.gains}
+
+    def drop(self, stack):
+        for k in [k for k in self.cache if k[0] == stack and k[1] != self._empty_key(stack)]:
+            del self.cache[k]
+
+    @staticmethod
+    def _empty_key(stack):
+        e = frozenset()
+        return {"vit": e, "proj": (e, e), "enc": ((e, e), e)}[stack]
+
+
+def stats(lp, ref):
+    d = (lp - ref).abs()
+    return {"max": float(d.max()), "mean": float(d.mean()), "yes_max": float(d[:, 0].max()), "yes_mean": float(d[:, 0].mean()),
+            "signed_mean": float((lp - ref).mean())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="clip-flant5-xl")
+    ap.add_argument("--pairs", type=int, default=16)
+    ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--gains", default="1,4")
+    ap.add_argument("--acc", default="float32", choices=["float32", "float64"])
+    ap.add_argument("--only", default="", help="comma list of run names (default: all runs)")
+    ap.add_argument("--out", default="")
+    a = ap.parse_args()
+    import warnings
+    warnings.filterwarnings("ignore")
+    cfg = get_config(a.model)
+    gains = [float(g) for g in a.gains.split(",")]
+    t00 = time.time()
+    w = make_seeded_weights(cfg, seed=0, device="cpu")
+    pix, idx, ids, labels = bench.synth_batch(cfg, a.pairs, a.seed, "cpu")
+    batch = (pix.float(), idx.long(), ids.long(), labels.long())
+    R = Runner(cfg, w, batch, getattr(torch, a.acc), gains)
+
+    runs = [("none (all fp32)", ())]
+    runs += [(c, (c,)) for c in ALL]
+    runs += [("stack vit.*", tuple(c for c in ALL if stack_of(c) == "vit")),
+             ("stack proj.*", tuple(c for c in ALL if stack_of(c) == "proj")),
+             ("stack enc.*", tuple(c for c in ALL if stack_of(c) == "enc")),
+             ("stack dec.*", tuple(c for c in ALL if stack_of(c) == "dec")),
+             ("cheap set (dec.* + proj.* + enc.out)", CHEAP),
+             ("engine minus cheap set", tuple(c for c in ALL if c not in CHEAP)),
+             ("engine (all classes)", ALL)]
+    if a.only:
+        keep = set(a.only.split(","))
+        runs = [r for r in runs if r[0] in keep or r[0].startswith("none")]
+    # order: decoder-only sets first (cheapest), vit-touching sets last; drop stage caches a later run cannot reuse
+    rank = lambda cl: 2 if any(stack_of(c) in ("vit", "proj") for c in cl) else 1 if any(stack_of(c) == "enc" for c in cl) else 0
+    runs.sort(key=lambda r: rank(r[1]))
+    results, ref = {}, None
+    print(f"# {cfg.name}, {a.pairs} pairs (bench.synth_batch seed {a.seed}), labels {labels[0].tolist()}, products in {a.acc}, "
+          f"gains {gains}, {torch.get_num_threads()} threads", flush=True)
+    for name, classes in runs:
+        t0 = time.time()
+        lp = R.run(classes)
+        if ref is None:
+            assert not classes
+            ref = lp
+            truth = Oracle(cfg, w).forward(*batch)["label_logprobs"]
+            results["_none_vs_fp32_oracle"] = float((lp[1.0] - truth).abs().max()) if 1.0 in lp else None
+            print(f"# unrounded run vs oracle/clip_t5_oracle.py (tiled attention, reassociated cross-attention, fp32): "
+                  f"{results['_none_vs_fp32_oracle']:.2e};  log P(yes) range [{float(truth[:, 0].min()):.2f}, {float(truth[:, 0].max()):.2f}]", flush=True)
+        results[name] = {f"gain{g:g}": stats(lp[g], ref[g]) for g in gains}
+        results[name]["seconds"] = round(time.time() - t0, 1)
+        print(f"{name:42s} " + "  ".join(f"g{g:g}: max {results[name][f'gain{g:g}']['max']:.2e} mean {results[name][f'gain{g:g}']['mean']:.2e}" for g in gains)
+              + f"   ({results[name]['seconds']} s)", flush=True)
+        if rank(classes) < 2:
+            pass
+        else:
+            R.drop("vit"); R.drop("proj"); R.drop("enc")
+        if rank(classes) == 1:
+            R.drop("enc")
+    results["_meta"] = {"model": cfg.name, "pairs": a.pairs, "seed": a.seed, "gains": gains, "acc": a.acc,
+                        "threads": torch.get_num_threads(), "seconds": round(time.time() - t00, 1),
+                        "logp_yes_fp32": [round(float(x), 4) for x in ref[gains[0]][:, 0]]}
+    if a.out:
+        with open(a.out + ".json", "w") as f:
+            json.dump(results, f, indent=1)
+        print("wrote", a.out + ".json")
+
+
+if __name__ == "__main__":
+    main()

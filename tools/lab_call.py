@@ -234,95 +234,6 @@ def main():
             return {"l2_touch:%dx%d" % s: v for s, v in pairs}
         in_situ("clip-flant5-xxl", [("rule (wo on)", "product", {}), ("wo off", "product", opt([(wo, 2)])), ("wo on + o on", "product", opt([(o, 1)])),
                                     ("wo on + qkv on", "product", opt([(qkv, 1)])), ("wo on + wi on", "product", opt([(wi, 1)]))], steps=3, rounds=3, tag="L")
-    if "W" in parts:                                             # the four-wave 128x128 GEMM form (variant 6) vs the 8-wave default and hipBLASLt
-        g = torch.Generator(device="cuda").manual_seed(0)
-        for tag, M, N, K, epi, S, H, has_bias in XXL + XL + VIT:
-            A = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
-            W = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(torch.bfloat16)
-            bias = torch.randn(N, device="cuda", generator=g).to(torch.bfloat16) if has_bias else None
-            out3 = engine.gemm(A, W, epi, bias=bias, S=S, H=H, variant=3)
-            out6 = engine.gemm(A, W, epi, bias=bias, S=S, H=H, variant=6)
-            same = bool(torch.equal(out3, out6))
-            ref = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
-            res = {}
-            for rnd in range(2):
-                for v, o in ((3, out3), (6, out6)):
-                    ms = time_ms(lambda: engine.gemm(A, W, epi, bias=bias, out=o, S=S, H=H, variant=v), 5)
-                    res.setdefault("variant%d" % v, []).append(round(2.0 * M * N * K / ms / 1e9, 1))
-                res.setdefault("torch_matmul_no_epilogue", []).append(round(2.0 * M * N * K / time_ms(lambda: torch.matmul(A, W.t(), out=ref), 5) / 1e9, 1))
-            emit({"part": "W", "shape": tag, "N": N, "K": K, "epilogue": epi, "tflops": res, "bitwise_equal_3_vs_6": same})
-            del A, W, out3, out6, ref
-            torch.cuda.empty_cache()
-    if "WI" in parts:                                            # ... in situ
-        in_situ("clip-flant5-xxl", [("8-wave forms (variant 3)", "product", {"gemm_variant": 3}), ("wide form (variant 6)", "product", {"gemm_variant": 6})],
-                steps=3, rounds=2, tag="WI")
-    if "RI" in parts:                                            # lab library (VQS_LIB_PATH): ring (8) and wide + touch (9) forms in situ against the default
-        in_situ("clip-flant5-xxl", [("8-wave forms (variant 3)", "product", {"gemm_variant": 3}), ("ring form (variant 8)", "product", {"gemm_variant": 8}),
-                                    ("wide + L2 touch (variant 9)", "product", {"gemm_variant": 9}), ("wide form (variant 6)", "product", {"gemm_variant": 6})],
-                steps=3, rounds=2, tag="RI")
-    if "WIX" in parts:
-        in_situ("clip-flant5-xl", [("8-wave forms (variant 3)", "product", {"gemm_variant": 3}), ("wide form (variant 6)", "product", {"gemm_variant": 6})],
-                steps=4, rounds=2, tag="WIX")
-    if "R" in parts:                                             # ring form (variant 8, lab library: VQS_LIB_PATH=build/lab/libvqs_hip_lab.so): bitwise check, then rate
-        from tests.gpu_util import randn_bf16
-        bad = []
-        for M, N, K, epi, S, H in [(33000, 2048, 64, 0, 0, 0), (33000 - 7, 2048 - 8, 128, 0, 0, 0), (20000, 4096, 1024, 1, 0, 0), (147456 // 4, 2048, 1024, 2, 0, 0),
-                                   (16384, 8192, 256, 5, 0, 0), (608 * 40, 3 * 1024, 192, 6, 608, 16), (577 * 64, 3 * 1024, 128, 6, 577, 16), (131072, 512, 2048, 0, 0, 0),
-                                   (70000, 512, 64, 0, 0, 0), (256 * 300 + 1, 256, 320, 0, 0, 0)]:
-            A = randn_bf16(M, K, seed=81)
-            W = randn_bf16(N, K, seed=82, scale=K ** -0.5)
-            bias = randn_bf16(N, seed=83) if epi in (0, 1, 2, 6) else None
-            ref = engine.gemm(A, W, epi, bias=bias, S=S, H=H, variant=0)
-            for rep in range(3):
-                for order in (None, (4, 2), (2, 1)):
-                    for v in (8, 9):                             # 8 = ring form, 9 = wide form + L2 touch two K-tiles ahead
-                        out = engine.gemm(A, W, epi, bias=bias, S=S, H=H, variant=v, tile_order=order)
-                        if not torch.equal(out, ref):
-                            d = (out.float() - ref.float()).abs()
-                            bad.append({"variant": v, "shape": [M, N, K, epi], "rep": rep, "order": order, "max_abs_diff": d.max().item(),
-                                        "frac": (d > 0).float().mean().item()})
-            del A, W, ref
-        emit({"part": "R", "bitwise_check": "ok" if not bad else "MISMATCH", "mismatching_variants": sorted({b["variant"] for b in bad}), "mismatches": bad[:8]})
-        g = torch.Generator(device="cuda").manual_seed(0)
-        for tag, M, N, K, epi, S, H, has_bias in XXL + XL + VIT:
-            A = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
-            W = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(torch.bfloat16)
-            bias = torch.randn(N, device="cuda", generator=g).to(torch.bfloat16) if has_bias else None
-            outs = {v: engine.gemm(A, W, epi, bias=bias, S=S, H=H, variant=v) for v in (3, 6, 8, 9)}
-            ref = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
-            res = {}
-            for rnd in range(2):
-                for v, o in outs.items():
-                    ms = time_ms(lambda: engine.gemm(A, W, epi, bias=bias, out=o, S=S, H=H, variant=v), 5)
-                    res.setdefault("variant%d" % v, []).append(round(2.0 * M * N * K / ms / 1e9, 1))
-                res.setdefault("torch_matmul_no_epilogue", []).append(round(2.0 * M * N * K / time_ms(lambda: torch.matmul(A, W.t(), out=ref), 5) / 1e9, 1))
-            emit({"part": "R", "shape": tag, "N": N, "K": K, "epilogue": epi, "tflops": res, "bitwise_equal_to_variant3": {v: bool(torch.equal(outs[3], o)) for v, o in outs.items() if v != 3}})
-            del A, W, outs, ref
-            torch.cuda.empty_cache()
-    if "RT" in parts:                                            # where the ring form's cycles go (lab timing build: make lab LABDIR=../../build/lab_timing LABFLAGS=-DVQS_RING_TIMING=1)
-        import ctypes
-        lib = engine.load_library(os.path.join(ROOT, "build", "lab_timing", "libvqs_hip_lab.so"))
-        lib.vqs_lab_set_ring_timing.argtypes = [ctypes.c_void_p]
-        g = torch.Generator(device="cuda").manual_seed(0)
-        for tag, M, N, K, epi, S, H, has_bias in [XXL[0], XXL[1], XXL[3], VIT[0], VIT[1]]:
-            A = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
-            W = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(torch.bfloat16)
-            out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
-            buf = torch.zeros(8, dtype=torch.int64, device="cuda")
-            assert lib.vqs_lab_set_ring_timing(buf.data_ptr()) == 0
-
-            def call():
-                assert lib.vqs_gemm(A.data_ptr(), W.data_ptr(), out.data_ptr(), None, None, M, N, K, K, K, N, 0, 0, 0, 8, torch.cuda.current_stream().cuda_stream) == 0
-            call()
-            torch.cuda.synchronize()
-            buf.zero_()
-            ms = time_ms(call, 3)
-            t = buf.cpu().tolist()
-            waves, bnd, tiles = max(t[6], 1), max(t[4], 1), max(t[5], 1)
-            emit({"part": "RT", "shape": tag, "tflops_with_probes": round(2.0 * M * N * K / ms / 1e9, 1), "cycles_per_boundary": {"vmcnt wait": round(t[0] / bnd, 1), "barrier": round(t[1] / bnd, 1)},
-                  "cycles_per_tile": {"epilogue incl. its stores": round(t[2] / tiles, 1), "whole tile": round(t[3] / tiles, 1), "mfma floor": K // 32 * 1024}, "waves": waves})
-            assert lib.vqs_lab_set_ring_timing(None) == 0
-            del A, W, out
     if "AT" in parts:                                            # per-phase cycle split of the self-attention kernel (timing build)
         import ctypes
         path = os.path.join(ROOT, "build", "lab", "libvqs_attn_timing.so")
@@ -349,22 +260,6 @@ def main():
             emit({"part": "AT", "shape": tag, "ms_per_call_with_probes": ms, "cycles_per_wave_tile": {n: round(t[i] / tiles, 1) for i, n in enumerate(names[:4])},
                   "cycles_per_wave": {n: round(t[4 + i] / waves, 1) for i, n in enumerate(names[4:])}, "wave_tiles": tiles, "waves": waves})
             assert lib.vqs_lab_set_attn_timing(None) == 0
-    if "WA" in parts:                                            # timing ablations of the wide form (lab builds; results are garbage by design)
-        g = torch.Generator(device="cuda").manual_seed(0)
-        libs = [("product", engine.load_library())] + [(n, engine.load_library(os.path.join(ROOT, "build", "lab", "libvqs_%s.so" % n)))
-                                                       for n in ("wide_abl1", "wide_abl2", "wide_abl3") if os.path.exists(os.path.join(ROOT, "build", "lab", "libvqs_%s.so" % n))]
-        for tag, M, N, K, epi, S, H, has_bias in [XXL[0], XXL[3], VIT[1]]:
-            A = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
-            W = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(torch.bfloat16)
-            out = engine.gemm(A, W, 0, variant=3)
-            res = {}
-            for name, lib in libs:
-                for v in ((3, 6) if name == "product" else (6,)):
-                    def call(lib=lib, v=v):
-                        lib.vqs_gemm(A.data_ptr(), W.data_ptr(), out.data_ptr(), None, None, M, N, K, K, K, N, 0, 0, 0, v, torch.cuda.current_stream().cuda_stream)
-                    res["%s v%d" % (name, v)] = [round(2.0 * M * N * K / time_ms(call, 5) / 1e9, 1) for _ in range(2)]
-            emit({"part": "WA", "shape": tag, "tflops_plain_epilogue": res})
-            del A, W, out
     if "V" in parts:                                             # lock-step (launcher's rule) vs forced ping-pong schedule, ViT shapes
         g = torch.Generator(device="cuda").manual_seed(0)
         for tag, M, N, K, epi, S, H, has_bias in VIT + [("projector.0", 147456, 4096, 1024, 2, 0, 0, True)]:
