@@ -62,6 +62,15 @@ def bf16_round(x: torch.Tensor) -> torch.Tensor:
     return x.to(torch.float32).to(torch.bfloat16).to(torch.float32)
 
 
+def split_bf16_round(x: torch.Tensor) -> torch.Tensor:
+    """The value a SPLIT-bf16 tensor holds: hi = bf16(x), lo = bf16(x - hi), stored as two bf16 planes and consumed as
+    hi + lo (two MFMA passes over the same weights, or one fp32 add in an elementwise kernel) -- 16 significant bits instead
+    of 8 (the engine's precise decoder, elementwise.hip split_store)."""
+    x = x.to(torch.float32)
+    hi = bf16_round(x)
+    return hi + bf16_round(x - hi)
+
+
 def _fma32(a: torch.Tensor, b, c) -> torch.Tensor:
     """fp32 fused multiply-add: the product of two fp32 is exact in fp64, so one fp64 add + one rounding to fp32
     reproduces v_fma_f32 except for rare double-rounding ties."""
@@ -174,10 +183,20 @@ class EngineRoundedOracle(Oracle):
                "dec.norm", "dec.qkv", "dec.sattn", "dec.delta", "dec.cq", "dec.cqk", "dec.cprobs", "dec.cctx", "dec.cattn",
                "dec.act", "dec.out")
 
-    def __init__(self, cfg, weights, emulate="engine", round_fn=bf16_round, acc=torch.float64, classes=None):
+    # the engine's precise decoder (vqs_set_option "dec_precise", default 1; round 4): every decoder activation that the error
+    # attribution (profiles/r4_error_attribution.md) shows to matter is a split-bf16 tensor or stays fp32 --
+    #   split (hi + lo planes): norm outputs, self-attention output, P.E context, ctx.Wv output, gated FFN product, final norm output
+    #   fp32, never rounded:    q|k|v of the self attention, the three deltas into the fp32 stream
+    #   bf16 as before:         the cross-attention score path (cq, q.Wk, probabilities), which reads the hi plane of the norm output
+    DEC_SPLIT = ("dec.norm", "dec.sattn", "dec.cctx", "dec.cattn", "dec.act", "dec.out")
+    DEC_FP32 = ("dec.qkv", "dec.delta")
+
+    def __init__(self, cfg, weights, emulate="engine", round_fn=bf16_round, acc=torch.float64, classes=None, dec_precise=True):
         super().__init__(cfg, weights)
         self.r = round_fn
         self.acc = acc
+        self.dec_precise = bool(dec_precise)
+        self.r2 = split_bf16_round if round_fn is bf16_round else round_fn
         if classes is not None:
             unknown = set(classes) - set(self.CLASSES)
             if unknown:
@@ -206,7 +225,13 @@ class EngineRoundedOracle(Oracle):
     def rc(self, cls: str, x: torch.Tensor) -> torch.Tensor:
         """The rounding of class `cls`: ``round_fn`` when the class is switched on, identity otherwise."""
         assert cls in self.CLASSES, cls
-        return self.r(x) if self.classes is None or cls in self.classes else x
+        if self.classes is not None and cls not in self.classes:
+            return x
+        if self.dec_precise and cls in self.DEC_FP32:
+            return x
+        if self.dec_precise and cls in self.DEC_SPLIT:
+            return self.r2(x)
+        return self.r(x)
 
     def rcf(self, cls: str):
         return self.r if self.classes is None or cls in self.classes else (lambda x: x)
@@ -318,7 +343,9 @@ class EngineRoundedOracle(Oracle):
         B, T, D = xn.shape
         S = enc_out.shape[1]
         H, dk = t.heads, t.d_kv
-        q = self._emit(n + "cq", rc("dec.cq", self._mm(xn, p + "q.weight"))).reshape(B, T, H, dk)
+        # precise decoder: the score path reads the HI plane of the split norm output (= bf16(xn): what it read before round 4)
+        xq = self.r(xn) if (self.dec_precise and (self.classes is None or "dec.cq" in self.classes)) else xn
+        q = self._emit(n + "cq", rc("dec.cq", self._mm(xq, p + "q.weight"))).reshape(B, T, H, dk)
         wk = self.w[p + "k.weight"].detach().to("cpu").to(self.acc).reshape(H, dk, D)
         wv = self.w[p + "v.weight"].detach().to("cpu").to(self.acc).reshape(H, dk, D)
         qk = self._emit(n + "cqk", rc("dec.cqk", torch.einsum("bthd,hdD->bthD", q.to(self.acc), wk).float()))      # "cross q.Wk" -> bf16
@@ -391,10 +418,25 @@ class EngineRoundedOracle(Oracle):
         width = {"xn0": t.d_model, "xn1": t.d_model, "xn2": t.d_model, "d_self": t.d_model, "d_cross": t.d_model, "d_ff": t.d_model,
                  "qkv": 3 * t.inner, "sattn": t.inner, "cq": t.inner, "cattn": t.inner, "ff": t.d_ff,
                  "cqk": t.heads * t.d_model, "cctx": t.heads * t.d_model, "cscores": t.heads * Sp, "cprobs": t.heads * Sp}
+        # precise decoder: "split" = the engine taps the two bf16 planes [2][rows][width] (value = plane 0 + plane 1, see
+        # taps_to_values); q|k|v and the three sub-layer outputs are fp32
+        split = {"xn0", "xn1", "xn2", "sattn", "cctx", "cattn", "ff"} if self.dec_precise else set()
+        f32_names = {"cscores"} | ({"qkv", "d_self", "d_cross", "d_ff"} if self.dec_precise else set())
         for i in range(t.dec_layers):
             for nm in self.TAP_NAMES_DEC:
-                out[f"dec.{i}.{nm}"] = ((MT, width[nm]), f32 if nm == "cscores" else bf)
+                out[f"dec.{i}.{nm}"] = ((MT, width[nm]), "split" if nm in split else (f32 if nm in f32_names else bf))
         return out
+
+    @staticmethod
+    def tap_alloc(shapes, device="cpu"):
+        """Tap buffers for tap_shapes(): a "split" entry is two bf16 planes [2, rows, width]."""
+        return {n: (torch.empty((2,) + tuple(shape), dtype=torch.bfloat16, device=device) if dt == "split"
+                    else torch.empty(shape, dtype=dt, device=device)) for n, (shape, dt) in shapes.items()}
+
+    @staticmethod
+    def taps_to_values(shapes, bufs):
+        """Tap buffers -> the tensors' values (CPU): split entries become fp32 hi + lo."""
+        return {n: ((b[0].float() + b[1].float()).cpu() if shapes[n][1] == "split" else b.cpu()) for n, b in bufs.items()}
 
     def forward_locked(self, taps, pixel_values, img_index, input_ids, labels):
         """Stage-locked pass: `taps` = the engine's intermediates of ITS pass over the same inputs (every name of

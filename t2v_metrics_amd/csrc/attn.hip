@@ -826,8 +826,67 @@ __global__ void __launch_bounds__(256) dec_attn_kernel(const DecAttnParams p) {
     }
 }
 
+// Precise self form (teacher-forced rows, no cache): q | k | v are FP32 columns of one [B*T, ldq] tensor (the summed partials of the
+// stacked hi / lo qkv GEMM -- never rounded), scores / softmax / P.V in fp32 as above, the output leaves as a split-bf16 tensor
+// (hi plane at out, lo plane at out + out_plane).  One workgroup per (head, sample), one wave: T <= 16 rows of 64 lanes.
+__global__ void __launch_bounds__(64) dec_self_attn_precise_kernel(const DecAttnParams p) {
+    __shared__ float q_s[DEC_TMAX][64], k_s[DEC_TMAX][64], v_s[DEC_TMAX][64], pr[DEC_TMAX][DEC_TMAX], rsum[DEC_TMAX];
+    const int T = p.T, lane = threadIdx.x, h = blockIdx.x, b = blockIdx.y;
+    const float* q = reinterpret_cast<const float*>(p.q);
+    const float* k = reinterpret_cast<const float*>(p.k);
+    const float* v = reinterpret_cast<const float*>(p.v);
+    for (int t = 0; t < T; ++t) {
+        const size_t row = ((size_t)b * T + t) * p.ldq + h * 64 + lane;
+        q_s[t][lane] = q[row];
+        k_s[t][lane] = k[row];
+        v_s[t][lane] = v[row];
+    }
+    __syncthreads();
+    // scores: lane -> (query t = lane / 16, key j = lane % 16) in passes of 4 queries; the dot product in d-ascending fmaf order
+    for (int t0 = 0; t0 < T; t0 += 4) {
+        const int t = t0 + (lane >> 4), j = lane & 15;
+        if (t < T && j < T) {
+            float a = 0.0f;
+#pragma unroll
+            for (int d = 0; d < 64; ++d) a = fmaf(q_s[t][d], k_s[j][d], a);
+            const bool masked = j > t;
+            if (!masked && p.bias_table) a += p.bias_table[h * T + (t - j)];
+            pr[t][j] = masked ? NEG_BIG : a;
+        }
+    }
+    __syncthreads();
+    if (lane < T) {                                   // one lane per query row: T <= 16 keys
+        const int t = lane;
+        float mx = NEG_BIG;
+        for (int j = 0; j < T; ++j) mx = fmaxf(mx, pr[t][j]);
+        float sm = 0.0f;
+        for (int j = 0; j < T; ++j) {
+            const float e = __expf(pr[t][j] - mx);
+            pr[t][j] = e;
+            sm += e;
+        }
+        rsum[t] = sm;
+    }
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        float o = 0.0f;
+        for (int j = 0; j <= t; ++j) o = fmaf(pr[t][j], v_s[j][lane], o);     // masked keys hold exp(NEG_BIG - mx) = 0
+        o = o / rsum[t];                                                       // one division at the end, as dec_attn_kernel
+        const bf16_t hi = a_f2bf(o);
+        const size_t dst = ((size_t)b * T + t) * ((size_t)p.H * 64) + h * 64 + lane;
+        p.out[dst] = hi;
+        p.out[dst + p.out_plane] = a_f2bf(o - a_bf2f(hi));
+    }
+}
+
 hipError_t launch_decoder_attention(const DecAttnParams& p, hipStream_t stream) {
     if (p.T <= 0 || p.T > DEC_TMAX || p.S <= 0) return hipErrorInvalidValue;
+    if (p.precise) {
+        if (p.cross || p.S != p.T || p.kv_stride_b != 0 || p.qpos0 != 0 || p.ldq != p.ldk || (p.bias_ld != 0 && p.bias_ld != p.T) || p.out_plane <= 0)
+            return hipErrorInvalidValue;              // teacher-forced self form only
+        hipLaunchKernelGGL(dec_self_attn_precise_kernel, dim3(p.H, p.B), dim3(64), 0, stream, p);
+        return hipGetLastError();
+    }
     size_t lds = ((size_t)p.T * 64 + (size_t)p.T * p.S + 4 * (size_t)p.T * 64 + 4 + p.T) * sizeof(float);
     lds = (lds + 15) & ~(size_t)15;
     if (lds > 65536) return hipErrorInvalidValue;

@@ -599,6 +599,120 @@ hipError_t launch_reduce_slices(const float* part, int nslices, size_t n, bf16_t
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Precise decoder glue (round 4).  The error attribution (profiles/r4_error_attribution.md) puts most of the path's
+// end-to-end |delta log P| into the bf16 roundings of the T-row DECODER (its rows feed the head directly; the encoder's
+// errors average out over ~600 keys), so those tensors are split-bf16 (two planes hi + lo = 16 significant bits, consumed by
+// the bf16 MFMA as two stacked row blocks) or stay fp32.  M = B*T rows: none of this is bandwidth that matters.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void e_split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+    hi = e_pack2_hw(a, b);
+    lo = e_pack2_hw(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+}
+__device__ __forceinline__ void e_split4_store(bf16_t* hi_p, bf16_t* lo_p, float4 v) {     // 4 consecutive elements, 8-byte aligned
+    uint2 h, l;
+    e_split2(v.x, v.y, h.x, l.x);
+    e_split2(v.z, v.w, h.y, l.y);
+    *reinterpret_cast<uint2*>(hi_p) = h;
+    *reinterpret_cast<uint2*>(lo_p) = l;
+}
+
+// One wave per row, any D % 4 == 0.  x += delta (fp32, stored) when delta != nullptr; statistics and scaling in the order of
+// norm_rows_reg_kernel (per-lane partial sums of squares, wave reduction, (x * rs) * w).
+__global__ void __launch_bounds__(256) rmsnorm_split_kernel(float* __restrict__ x, const float* __restrict__ delta,
+                                                            const bf16_t* __restrict__ w, bf16_t* __restrict__ out, long long out_plane,
+                                                            int M, int D, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= M) return;
+    float4* xr = reinterpret_cast<float4*>(x + (size_t)row * D);
+    const float4* dr = delta ? reinterpret_cast<const float4*>(delta + (size_t)row * D) : nullptr;
+    const int n4 = D >> 2;
+    float s2 = 0.0f;
+    for (int i = lane; i < n4; i += 64) {
+        float4 v = xr[i];
+        if (dr) {
+            const float4 d = dr[i];
+            v.x += d.x; v.y += d.y; v.z += d.z; v.w += d.w;
+            xr[i] = v;
+        }
+        s2 += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    const float rs = rsqrtf(wave_sum(s2) * (1.0f / (float)D) + eps);
+    const uint2* wr = reinterpret_cast<const uint2*>(w);
+    bf16_t* oh = out + (size_t)row * D;
+    for (int i = lane; i < n4; i += 64) {
+        const float4 v = xr[i];                      // this lane's own store above (same thread: ordered)
+        const float4 wv = bf4_to_f4(wr[i]);
+        e_split4_store(oh + 4 * i, oh + out_plane + 4 * i, make_float4(v.x * rs * wv.x, v.y * rs * wv.y, v.z * rs * wv.z, v.w * rs * wv.w));
+    }
+}
+
+hipError_t launch_rmsnorm_split(float* x, const float* delta, const bf16_t* w, bf16_t* out, long long out_plane, int M, int D,
+                                float eps, hipStream_t s) {
+    if (M <= 0 || D <= 0 || (D % 4) != 0 || (out_plane % 4) != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(rmsnorm_split_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, x, delta, w, out, out_plane, M, D, eps);
+    return hipGetLastError();
+}
+
+__device__ __forceinline__ float e_gelu_new(float x) {      // gemm.hip act_gelu_new: x * sigmoid(2u), hardware reciprocal
+    const float u2 = 1.5957691216057308f * (x + 0.044715f * x * x * x);   // 2u
+    return x * __builtin_amdgcn_rcpf(1.0f + __expf(-u2));
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256) sum_planes_kernel(const float* __restrict__ part, int nslices, long long slice_stride, int rows,
+                                                         int cols4, int ldp, void* __restrict__ out, int ld_out, long long out_plane) {
+    // thread -> (row, group of 4 output columns); cols4 = output columns / 4
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)rows * cols4) return;
+    const int r = (int)(i / cols4), c4 = (int)(i - (long long)r * cols4);
+    auto gather = [&](int col) {                      // (sum over slices of the hi rows) + (sum over slices of the lo rows)
+        const float* ph = part + (size_t)r * ldp + col;
+        const float* pl = part + (size_t)(rows + r) * ldp + col;
+        float4 a = *reinterpret_cast<const float4*>(ph);
+        float4 b = *reinterpret_cast<const float4*>(pl);
+        for (int k = 1; k < nslices; ++k) {
+            const float4 u = *reinterpret_cast<const float4*>(ph + (size_t)k * slice_stride);
+            const float4 v = *reinterpret_cast<const float4*>(pl + (size_t)k * slice_stride);
+            a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+            b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+        }
+        return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    };
+    if (MODE == SUM_GATED_SPLIT) {
+        const int oc = c4 * 4;                        // output column; packed order: block of 64 = 32 gate | 32 linear columns
+        const int gc = (oc >> 5) * 64 + (oc & 31);
+        const float4 g = gather(gc), l = gather(gc + 32);
+        bf16_t* oh = reinterpret_cast<bf16_t*>(out) + (size_t)r * ld_out + oc;
+        e_split4_store(oh, oh + out_plane, make_float4(e_gelu_new(g.x) * l.x, e_gelu_new(g.y) * l.y, e_gelu_new(g.z) * l.z, e_gelu_new(g.w) * l.w));
+    } else {
+        const float4 y = gather(c4 * 4);
+        if (MODE == SUM_F32) {
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)r * ld_out + c4 * 4) = y;
+        } else {
+            bf16_t* oh = reinterpret_cast<bf16_t*>(out) + (size_t)r * ld_out + c4 * 4;
+            e_split4_store(oh, oh + out_plane, y);
+        }
+    }
+}
+
+hipError_t launch_sum_planes(const float* part, int nslices, long long slice_stride, int rows, int cols, int ldp, int mode, void* out,
+                             int ld_out, long long out_plane, hipStream_t s) {
+    if (rows <= 0 || cols <= 0 || nslices <= 0 || (ldp % 4) != 0 || (ld_out % 4) != 0 || (out_plane % 4) != 0 || (slice_stride % 4) != 0)
+        return hipErrorInvalidValue;
+    const int out_cols = mode == SUM_GATED_SPLIT ? cols / 2 : cols;
+    if ((out_cols % 4) != 0 || (mode == SUM_GATED_SPLIT && (cols % 64) != 0)) return hipErrorInvalidValue;
+    const int cols4 = out_cols / 4;
+    const long long n = (long long)rows * cols4;
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (mode == SUM_F32) hipLaunchKernelGGL((sum_planes_kernel<SUM_F32>), grid, block, 0, s, part, nslices, slice_stride, rows, cols4, ldp, out, ld_out, out_plane);
+    else if (mode == SUM_SPLIT) hipLaunchKernelGGL((sum_planes_kernel<SUM_SPLIT>), grid, block, 0, s, part, nslices, slice_stride, rows, cols4, ldp, out, ld_out, out_plane);
+    else if (mode == SUM_GATED_SPLIT) hipLaunchKernelGGL((sum_planes_kernel<SUM_GATED_SPLIT>), grid, block, 0, s, part, nslices, slice_stride, rows, cols4, ldp, out, ld_out, out_plane);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
 // Greedy step of vqs_generate: tokens[b, T-1] = argmax_v logits[(b*T + T-1), v] (lowest index on ties, as torch.argmax)
 __global__ void __launch_bounds__(256) argmax_append_kernel(const float* __restrict__ logits, int ldl, int V,
                                                             int* __restrict__ tokens, int ld_tokens, int T, int dst_col) {

@@ -674,6 +674,42 @@ __device__ __forceinline__ void staged_epilogue(const GemmParams& p, f32x16 (&ac
                     if constexpr (EPI == EPI_HEADS) heads_off_step8(p.S, hdim, off_wrap, hs_run, off_run);   // next row of this lane: + 8 (also across the hm passes)
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if constexpr (EPI == EPI_BF16) {
+                    // split-bf16 result (GemmParams::split_off, wave-uniform): the same 64 rows once more, lo = bf16(acc - hi), to
+                    // the lo plane.  Twice the stores of the counted waits' constant (EpiStores): a vmcnt(n) with MORE stores
+                    // behind the staging DMA than n only waits longer (VMEM retires in order) -- never shorter.
+                    if (p.split_off != 0) {
+#pragma unroll
+                        for (int m2 = 0; m2 < 2; ++m2) {
+                            const int m = 2 * hm + m2;
+                            const int r = m2 * 32 + lr;
+#pragma unroll
+                            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                                for (int g = 0; g < 4; ++g) {
+                                    float o[4];
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) o[e] = acc[m][n][4 * g + e];
+                                    const uint32_t h0 = pack2(o[0], o[1]), h1 = pack2(o[2], o[3]);
+                                    uint2 v;
+                                    v.x = pack2(o[0] - __uint_as_float(h0 << 16), o[1] - __uint_as_float(h0 & 0xffff0000u));
+                                    v.y = pack2(o[2] - __uint_as_float(h1 << 16), o[3] - __uint_as_float(h1 & 0xffff0000u));
+                                    const int ch = n * 4 + g;
+                                    *reinterpret_cast<uint2*>(reg + r * 128 + ((ch ^ (r & 7)) << 4) + hh * 8) = v;
+                                }
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const int r = q * 8 + (lane >> 3), c = lane & 7;
+                            const uint4 v = *reinterpret_cast<const uint4*>(reg + r * 128 + ((c ^ (r & 7)) << 4));
+                            const int row = row_w + hm * 64 + r, col = col_w + c * 8;
+                            if (full || (row < p.M && col < p.N))
+                                st_row16(reinterpret_cast<bf16_t*>(p.C) + p.split_off + (size_t)bz * p.sC + (size_t)row * p.ldc + col, v, nt);
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    }
+                }
             }
         }
     }
@@ -1192,7 +1228,7 @@ static int l2_touch_mode() {
 // Which launches the quad form carries: a function of the epilogue and the WEIGHT's shape only (never of M).
 static bool quad_eligible_rt(const GemmParams& p, int epi) {
     if (!(epi == EPI_BF16 || epi == EPI_BF16_QGELU || epi == EPI_BF16_GELU || epi == EPI_GATED || epi == EPI_HEADS)) return false;
-    if (p.batch > 1 || p.K < 2 * BK || p.rowss_in != nullptr) return false;
+    if (p.batch > 1 || p.K < 2 * BK || p.rowss_in != nullptr || p.split_off != 0) return false;
     if (epi == EPI_GATED && (p.N % 64) != 0) return false;
     if (epi == EPI_HEADS) {
         // a wave's 128 columns must lie inside ONE of the q / k / v tensors (one head count per block); rows step by 4 within a sample
@@ -1210,7 +1246,8 @@ static bool quad_eligible(const GemmParams& p) { return quad_eligible_rt(p, EPI)
 // then falls back to the one-tile-per-workgroup kernel (same bits), anything else is an error -- never a wrapped offset.
 int gemm_form(const GemmParams& p, int epilogue, int variant) {
     if (epilogue == EPI_RESID_RMS) variant = variant == 5 ? 5 : 3;
-    const bool plain_v0 = !(p.hd > 64 || p.hd_src > 0 || p.inner_kv > 0 || p.Hkv > 0 || p.gate_act != 0 || (epilogue == EPI_GATED && p.bias != nullptr) || p.rowss_in != nullptr) &&
+    const bool plain_v0 = !(p.hd > 64 || p.hd_src > 0 || p.inner_kv > 0 || p.Hkv > 0 || p.gate_act != 0 || (epilogue == EPI_GATED && p.bias != nullptr) || p.rowss_in != nullptr ||
+                            p.split_off != 0) &&
                           p.batch <= 1 && epilogue != EPI_RESID_RMS;
     if (variant == 0 || variant == 2 || variant == 1) return plain_v0 ? 0 : -1;
     if (epilogue == EPI_HEADS && p.S < 8) return plain_v0 ? 0 : -1;
@@ -1298,6 +1335,7 @@ hipError_t launch_gemm(const GemmParams& p_in, int epilogue, int variant, hipStr
     if ((p.N % 8) != 0 && !(epilogue == EPI_F32 && p.ldc >= ((p.N + 3) & ~3) && p.bias == nullptr)) return hipErrorInvalidValue;
     if (p.batch > 1 && ((variant != 3 && variant != 4 && variant != 5 && variant != 6 && variant != 7 && variant != 8 && variant != 9 && variant != 10 && variant != 11) || epilogue == EPI_HEADS || epilogue == EPI_F32_RESID)) return hipErrorInvalidValue;
     if ((p.lda % 8) != 0 || (p.ldw % 8) != 0) return hipErrorInvalidValue;
+    if (p.split_off != 0 && (epilogue != EPI_BF16 || (p.split_off % 8) != 0)) return hipErrorInvalidValue;   // split-bf16 results: plain bf16 epilogue, staged form
     if ((p.hd > 64 || p.inner_kv > 0 || p.Hkv > 0 || p.gate_act != 0 || (epilogue == EPI_GATED && p.bias != nullptr)) &&
         variant != 3 && variant != 5 && variant != 6 && variant != 7 && variant != 8 && variant != 9 && variant != 10 && variant != 11)
         return hipErrorInvalidValue;   // generalised HEADS / GATED epilogues live in the persistent kernels only

@@ -44,6 +44,7 @@ struct vqs_handle {
     const bf16_t* patch_w = nullptr;
     std::vector<const bf16_t*> vit_qkv_w, vit_qkv_b, enc_qkv, enc_wi, dec_qkv, dec_ckv, dec_wi, dec_ckT;
     int cross_mode = 1;   // 1 = reassociated cross-attention (default), 0 = per-layer K|V projection of the encoder output
+    int dec_precise = 1;  // 1 = the scoring decoder holds its activations as split-bf16 / fp32 (decoder_pass_precise), 0 = bf16 (rounds 1-3)
     const int* lut_bidir = nullptr;
     const int* lut_causal = nullptr;
     int lut_len = 0;
@@ -138,7 +139,9 @@ struct ScoreWs {
     float* rs;                // [B*S] 1/rms per row, derived from rowss
     bf16_t *xn, *q, *k, *v, *attn, *ff, *enc_out, *ck, *cv;
     float* dhid;
-    bf16_t *dxn, *dqkv, *dattn, *dq, *dff;
+    bf16_t *dxn, *dqkv, *dattn, *dq, *dff;     // dxn, dattn, dff, cctx hold TWO planes [2][rows][width] (split-bf16; plane 0 = the bf16 tensor of rounds 1-3)
+    float *dqkv32, *ddelta32, *dscratch;       // precise decoder: fp32 q|k|v, fp32 sub-layer output, GEMM partials
+    size_t dscratch_bytes;
     bf16_t *enc_outT, *cqk, *cprobs, *cctx;
     float* cscores;
     int S_pad;
@@ -180,17 +183,26 @@ ScoreWs carve_score(const vqs_handle* h, char* base, int B, int L, int T,
     w.cv = cv.take<bf16_t>(M * I);
     w.dhid = cv.take<float>(MT * D);
     w.ddelta = cv.take<bf16_t>(MT * D);
-    w.dxn = cv.take<bf16_t>(MT * D, "dec_out");   // after a pass: the final-norm output (lm_head operand)
+    w.dxn = cv.take<bf16_t>(2 * MT * D, "dec_out");   // after a pass: the final-norm output (lm_head operand); hi plane, then lo plane
     w.dqkv = cv.take<bf16_t>(MT * 3 * I);
-    w.dattn = cv.take<bf16_t>(MT * I);
+    w.dattn = cv.take<bf16_t>(2 * MT * I);
     w.dq = cv.take<bf16_t>(MT * I);
-    w.dff = cv.take<bf16_t>(MT * F);
+    w.dff = cv.take<bf16_t>(2 * MT * F);
+    w.dqkv32 = cv.take<float>(MT * 3 * I);
+    w.ddelta32 = cv.take<float>(MT * D);
+    {   // fp32 partials of one decoder GEMM: [slices][2 * MT stacked rows][N] with slices * N <= 16 384 when split (dec_slices) or
+        // one slice of the widest N -- a function of the architecture, so no launch ever has to fall back for lack of scratch
+        size_t widest = 16384;
+        for (size_t n : {(size_t)3 * I, (size_t)2 * F, (size_t)c.vocab, (size_t)D}) widest = n > widest ? n : widest;
+        w.dscratch_bytes = 2 * MT * widest * sizeof(float);
+        w.dscratch = cv.take<float>(2 * MT * widest);
+    }
     w.S_pad = (S + 63) / 64 * 64;
     w.enc_outT = cv.take<bf16_t>((size_t)B * D * w.S_pad);
     w.cqk = cv.take<bf16_t>(MT * H * D);
     w.cscores = cv.take<float>(MT * H * w.S_pad);
     w.cprobs = cv.take<bf16_t>(MT * H * w.S_pad);
-    w.cctx = cv.take<bf16_t>(MT * H * D);
+    w.cctx = cv.take<bf16_t>(2 * MT * H * D);
     w.ldl = c.vocab;
     w.logits = cv.take<float>(MT * w.ldl, "logits");
     w.Tc = Tc;
@@ -284,6 +296,7 @@ struct GemmCall {
     int rowss_parts = 0;
     float rs_invd = 0.0f, rs_eps = 0.0f;
     int nt_store = 0;          // result rows leave with the non-temporal hint (call sites whose multi-GB output is streamed once)
+    long long split_off = 0;   // EPI_BF16: also store the lo plane of a split-bf16 result at C + split_off (vqs_kernels.h)
 };
 
 int run_gemm(vqs_handle* h, const GemmCall& g, hipStream_t st, const char* what) {
@@ -298,6 +311,7 @@ int run_gemm(vqs_handle* h, const GemmCall& g, hipStream_t st, const char* what)
     for (const vqs_handle::TileOrder& t : h->tile_orders)
         if (t.N == g.N && t.K == g.K) { p.tile_gm = t.gm; p.tile_ns = t.ns; }
     p.nt_store = g.nt_store;
+    p.split_off = g.split_off;
     for (const vqs_handle::NtStore& t : h->l2_touches)
         if (t.N == g.N && t.K == g.K && g.M >= 4096) p.l2_touch = t.on;
     for (const vqs_handle::NtStore& t : h->nt_stores)
@@ -352,6 +366,29 @@ int tap(vqs_handle* h, const char* stack, int layer, const char* what, const voi
     return VQS_OK;
 }
 #define TAP(stack, layer, what, ptr, elems) RUN(tap(h, stack, layer, what, ptr, (size_t)(elems) * sizeof(*(ptr)), st))
+
+// A split-bf16 tensor (planes [2][rows][width], `plane` elements apart) goes to its tap buffer as two planes of the tapped rows:
+// [2][window rows][width] bf16; the reader adds them (tests/gpu_util.py).
+int tap_split(vqs_handle* h, const char* stack, int layer, const char* what, const bf16_t* src, size_t plane, hipStream_t st) {
+    if (h->taps.empty()) return VQS_OK;
+    const std::string name = layer >= 0 ? std::string(stack) + "." + std::to_string(layer) + "." + what : std::string(stack) + "." + what;
+    auto it = h->taps.find(name);
+    if (it == h->taps.end()) return VQS_OK;
+    size_t bytes = plane * sizeof(bf16_t), first = 0;
+    if (h->tap_count > 0) {
+        if (h->tap_outer <= 0 || h->tap_first + h->tap_count > h->tap_outer || bytes % (size_t)h->tap_outer != 0)
+            return fail(h, VQS_ERR_INVALID, "tap " + name + ": window does not fit");
+        const size_t per = bytes / (size_t)h->tap_outer;
+        first = per * (size_t)h->tap_first;
+        bytes = per * (size_t)h->tap_count;
+    }
+    if (it->second.cap < 2 * bytes) return fail(h, VQS_ERR_WORKSPACE, "tap " + name + ": buffer too small (" + std::to_string(2 * bytes) + " bytes needed)");
+    for (int pl = 0; pl < 2; ++pl)
+        HIPCHK(h, hipMemcpyAsync(static_cast<char*>(it->second.dst) + pl * bytes, reinterpret_cast<const char*>(src + pl * plane) + first, bytes,
+                                 hipMemcpyDeviceToDevice, st), "tap copy");
+    return VQS_OK;
+}
+#define TAP2(stack, layer, what, ptr, plane_elems) RUN(tap_split(h, stack, layer, what, ptr, (size_t)(plane_elems), st))
 
 }  // namespace
 
@@ -479,6 +516,7 @@ int vqs_set_option(vqs_handle* h, const char* name, int32_t value) {
     else if (n == "splitk" && (value == 0 || value == 1)) h->splitk = value;
     else if (n == "fused_norm" && (value == 0 || value == 1)) h->fused_norm = value;
     else if (n == "norm_defer" && (value == 0 || value == 1)) h->norm_defer = value;
+    else if (n == "dec_precise" && (value == 0 || value == 1)) h->dec_precise = value;
     else if (n == "gemm_variant" && (value == 0 || value == 2 || value == 3 || value == 5 || value == 11)) h->gemm_variant = value;
     else if (n.rfind("l2_touch:", 0) == 0 || n.rfind("nt_store:", 0) == 0 || n.rfind("tile_order:", 0) == 0) {
         // per weight shape [N, K], for the big launches of a pass; 0 removes the entry = the library's choice.  All three are
@@ -862,25 +900,31 @@ static int encoder_pass(vqs_handle* h, const ScoreWs& w, const void* d_feats, co
     return VQS_OK;
 }
 
-// A decoder nn.Linear: out[MT, N] (bf16) = A[MT, K] . W[N, K]^T with MT = B*T (<= a few hundred rows).  One 256x256 tile per
-// workgroup leaves 16-80 of 256 CUs busy, each walking the whole K (56-133 us per launch at XL for 8-21 MB of weights).
-// Split-K: the same persistent kernel run as a batched GEMM whose batch entries are K-slices (operand pointers advance
-// by K/s columns, fp32 partial tiles go to `scratch`), then one pass sums the s slices in a fixed order into bf16 --
-// deterministic (no atomics).  s = the largest divisor of K/64 with 2 * N-tiles * s <= 256 CUs and >= 4 K-tiles per slice:
-// a function of the WEIGHT's shape only.  The slicing fixes the order in which a row's fp32 partial sums are added, so it must
-// not depend on how many rows the launch has -- a pair's score in a 256-pair batch (MT = 512, two M-tiles) has to be bit-equal
-// to its score in a 4-pair batch (reference contract: independent cells, score.py:104-106; round 2 derived s from the tile
-// count of the launch, which made the decoder's bits depend on ceil(MT / 256)).  Two M-tiles are assumed because that is the
-// bench batch; a single M-tile then runs on half the CUs it could use (small-batch latency, not the metric).
-static int dec_linear(vqs_handle* h, const bf16_t* A, const bf16_t* W, bf16_t* out, int MT, int N, int K, float* scratch,
-                      size_t scratch_bytes, hipStream_t st, const char* what) {
-    const int tiles = 2 * ((N + 255) / 256);
+// Split-K factor of a decoder nn.Linear: K-slices run as batch entries of the persistent kernel (operand pointers advance by
+// K/s columns, fp32 partial tiles go to scratch), one pass then sums the slices in a fixed order -- deterministic, no atomics.
+// s = the largest divisor of K/64 in 2..16 with tiles * s <= 256 CUs and >= 4 K-tiles per slice, where `tiles` counts `m_tiles`
+// M-tiles per N-tile: a function of the WEIGHT's shape only.  The slicing fixes the order in which a row's fp32 partial sums
+// are added, so it must not depend on how many rows the launch has -- a pair's score in a 256-pair batch has to be bit-equal to
+// its score in a 4-pair batch (reference contract: independent cells, score.py:104-106).  Round 2 derived s from the launch's tile
+// count (bits depended on ceil(MT / 256)); round 3 kept an MT <= 1024 cap and a scratch-size fallback that were M-dependent
+// switches of the same kind: both are gone -- the partials have their own workspace region sized by the architecture.
+static int dec_slices(const vqs_handle* h, int N, int K, int m_tiles) {
+    const int tiles = m_tiles * ((N + 255) / 256);
     const int nt = K / 64;
     int sk = 1;
-    if (h->splitk && MT <= 1024 && (K % 64) == 0 && (N % 8) == 0)
+    if (h->splitk && (K % 64) == 0 && (N % 8) == 0)
         for (int s2 = 2; s2 <= 16; ++s2)
             if (nt % s2 == 0 && tiles * s2 <= 256 && nt / s2 >= 4) sk = s2;
-    if (sk > 1 && (size_t)sk * MT * N * sizeof(float) <= scratch_bytes) {
+    return sk;
+}
+
+// A decoder nn.Linear of the bf16 decoder (rounds 1-3; vqs_generate and option dec_precise=0): out[MT, N] (bf16) = A[MT, K] . W[N, K]^T.
+// Two M-tiles are assumed for the slice count because that is the bench batch (MT = 512).
+static int dec_linear(vqs_handle* h, const bf16_t* A, const bf16_t* W, bf16_t* out, int MT, int N, int K, float* scratch,
+                      size_t scratch_bytes, hipStream_t st, const char* what) {
+    const int sk = dec_slices(h, N, K, 2);
+    if (sk > 1) {
+        if ((size_t)sk * MT * N * sizeof(float) > scratch_bytes) return fail(h, VQS_ERR_WORKSPACE, std::string(what) + ": decoder scratch too small");
         GemmCall g{A, W, scratch};
         g.M = MT; g.N = N; g.K = K / sk; g.lda = K; g.ldw = K; g.ldc = N; g.epi = vqs::EPI_F32;
         g.batch = sk; g.sA = K / sk; g.sW = K / sk; g.sC = (long long)MT * N;
@@ -891,6 +935,22 @@ static int dec_linear(vqs_handle* h, const bf16_t* A, const bf16_t* W, bf16_t* o
     GemmCall g{A, W, out};
     g.M = MT; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldc = N; g.epi = vqs::EPI_BF16;
     return run_gemm(h, g, st, what);
+}
+
+// A decoder nn.Linear of the PRECISE decoder: A2 is a split-bf16 tensor, planes [2][MT][K]; the two planes run as 2*MT stacked
+// rows of ONE GEMM over the same weights (and split-K slices as batch entries) into fp32 partials [slices][2*MT][N], which
+// launch_sum_planes adds -- hi rows first, slices in index order -- into `out` in the form `mode` names (fp32 / split / gated split).
+// The activation thus enters the bf16 MFMA with 16 significant bits and the result is never rounded to bf16.
+static int dec_linear_split(vqs_handle* h, const bf16_t* A2, const bf16_t* W, int MT, int N, int K, float* scratch, size_t scratch_bytes,
+                            int mode, void* out, int ld_out, long long out_plane, hipStream_t st, const char* what) {
+    const int sk = dec_slices(h, N, K, 4);
+    if ((size_t)sk * 2 * MT * N * sizeof(float) > scratch_bytes) return fail(h, VQS_ERR_WORKSPACE, std::string(what) + ": decoder scratch too small");
+    GemmCall g{A2, W, scratch};
+    g.M = 2 * MT; g.N = N; g.K = K / sk; g.lda = K; g.ldw = K; g.ldc = N; g.epi = vqs::EPI_F32;
+    g.batch = sk; g.sA = K / sk; g.sW = K / sk; g.sC = (long long)2 * MT * N;
+    RUN(run_gemm(h, g, st, what));
+    HIPCHK(h, vqs::launch_sum_planes(scratch, sk, (long long)2 * MT * N, MT, N, N, mode, out, ld_out, out_plane, st), "sum of stacked partials");
+    return VQS_OK;
 }
 
 // Decoder half: T teacher-forced rows per pair over the encoder output already in the workspace -> fp32 logits
@@ -907,8 +967,8 @@ static int decoder_pass(vqs_handle* h, const ScoreWs& w, const int32_t* d_labels
     h->tap_outer = B;
     // ---------------- decoder (teacher forced, T rows per pair)
     GETW(shared, "shared.weight", (int64_t)V * D);
-    float* scratch = reinterpret_cast<float*>(w.ff);          // the encoder's FFN buffer [B*S, F] bf16 is idle from here on
-    const size_t scratch_bytes = (size_t)M * F * sizeof(bf16_t);
+    float* scratch = w.dscratch;
+    const size_t scratch_bytes = w.dscratch_bytes;
     GETW(dec_rel, "decoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight", (int64_t)c.rel_buckets * H);
     const int TB = cached ? w.Tc : T;                          // row length of the decoder bias table
     if (!cached || pos0 == 0)
@@ -1030,6 +1090,118 @@ static int decoder_pass(vqs_handle* h, const ScoreWs& w, const int32_t* d_labels
     return VQS_OK;
 }
 
+// The scoring decoder of round 4 (option dec_precise, default 1): the same T teacher-forced rows per pair, but every activation the
+// error attribution (profiles/r4_error_attribution.md) shows to matter is held with 16 significant bits or in fp32:
+//   split-bf16 (planes hi | lo, consumed as 2*MT stacked rows of one GEMM): norm outputs, self-attention output, P.E context,
+//     ctx.Wv output, gated FFN product, final norm output (the lm_head operand);
+//   fp32, never rounded: q|k|v of the self-attention and the three sub-layer outputs added into the fp32 stream;
+//   bf16 as before: the cross-attention SCORE path (q, q.Wk, probabilities: <= 2e-4 of |delta log P| together), which reads the hi
+//     plane of the norm output -- bit for bit what rounds 1-3 computed there.
+// Same function as decoder_pass (HF modeling_t5.py:404-509), same launch sequence; the reference rounds every one of these
+// tensors to bf16 (mm_utils.py:228), so this is a deviation TOWARDS fp32 arithmetic, like the fp32 residual stream.
+static int decoder_pass_precise(vqs_handle* h, const ScoreWs& w, const int32_t* d_labels, int ld_labels, int B, int L, int T, hipStream_t st) {
+    const vqs_config& c = h->c;
+    const int P = h->P, S = L - 1 + P;
+    const int D = c.d_model, I = h->I, F = c.d_ff, H = c.n_heads, V = c.vocab;
+    const int MT = B * T;
+    h->tap_outer = B;
+    GETW(shared, "shared.weight", (int64_t)V * D);
+    GETW(dec_rel, "decoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight", (int64_t)c.rel_buckets * H);
+    float* scratch = w.dscratch;
+    const size_t sb = w.dscratch_bytes;
+    const long long pD = (long long)MT * D, pI = (long long)MT * I, pF = (long long)MT * F, pC = (long long)MT * H * D;   // plane sizes
+    HIPCHK(h, vqs::launch_relpos_table(dec_rel, h->lut_bidir, h->lut_causal, h->lut_len, c.rel_buckets, nullptr, H, S, w.dec_table, T, st),
+           "decoder bias table");
+    HIPCHK(h, vqs::launch_decoder_embed(d_labels, ld_labels, shared, w.dhid, B, T, D, V, st, 0), "decoder embed");
+    TAP("dec", -1, "emb", w.dhid, (size_t)MT * D);
+    const float* dpend = nullptr;
+    for (int i = 0; i < c.dec_layers; ++i) {
+        const std::string p = "decoder.block." + std::to_string(i) + ".";
+        GETW(ln0, p + "layer.0.layer_norm.weight", D);
+        GETW(so, p + "layer.0.SelfAttention.o.weight", (int64_t)D * I);
+        GETW(ln1, p + "layer.1.layer_norm.weight", D);
+        GETW(cq, p + "layer.1.EncDecAttention.q.weight", (int64_t)I * D);
+        GETW(cv_w, p + "layer.1.EncDecAttention.v.weight", (int64_t)I * D);
+        GETW(co, p + "layer.1.EncDecAttention.o.weight", (int64_t)D * I);
+        GETW(ln2, p + "layer.2.layer_norm.weight", D);
+        GETW(wo, p + "layer.2.DenseReluDense.wo.weight", (int64_t)D * F);
+
+        // ---- causal self-attention
+        HIPCHK(h, vqs::launch_rmsnorm_split(w.dhid, dpend, ln0, w.dxn, pD, MT, D, c.t5_ln_eps, st), "dec rmsnorm0");
+        dpend = nullptr;
+        TAP2("dec", i, "xn0", w.dxn, pD);
+        RUN(dec_linear_split(h, w.dxn, h->dec_qkv[i], MT, 3 * I, D, scratch, sb, vqs::SUM_F32, w.dqkv32, 3 * I, 0, st, "dec self qkv"));
+        TAP("dec", i, "qkv", w.dqkv32, (size_t)MT * 3 * I);
+        {
+            vqs::DecAttnParams a{reinterpret_cast<const bf16_t*>(w.dqkv32), reinterpret_cast<const bf16_t*>(w.dqkv32 + I),
+                                 reinterpret_cast<const bf16_t*>(w.dqkv32 + 2 * I), w.dattn, w.dec_table, nullptr, B, H, T, T, 3 * I, 3 * I, 0};
+            a.precise = 1;
+            a.out_plane = pI;
+            HIPCHK(h, vqs::launch_decoder_attention(a, st), "dec self attention");
+        }
+        TAP2("dec", i, "sattn", w.dattn, pI);
+        RUN(dec_linear_split(h, w.dattn, so, MT, D, I, scratch, sb, vqs::SUM_F32, w.ddelta32, D, 0, st, "dec self o"));
+        TAP("dec", i, "d_self", w.ddelta32, (size_t)MT * D);
+        // ---- cross-attention (reassociated, vqs_api.cpp decoder_pass): score path in bf16 off the hi plane, value path precise
+        HIPCHK(h, vqs::launch_rmsnorm_split(w.dhid, w.ddelta32, ln1, w.dxn, pD, MT, D, c.t5_ln_eps, st), "dec rmsnorm1");
+        TAP2("dec", i, "xn1", w.dxn, pD);
+        RUN(dec_linear(h, w.dxn, cq, w.dq, MT, I, D, scratch, sb, st, "dec cross q"));
+        TAP("dec", i, "cq", w.dq, (size_t)MT * I);
+        const int R = T * H;        // rows per pair, ordered (t, h)
+        {   // q'[(b,t), h, :] = q[(b,t), h*64:(h+1)*64] . Wk_h            batched over heads
+            GemmCall g{w.dq, h->dec_ckT[i], w.cqk};
+            g.M = MT; g.N = D; g.K = 64; g.lda = I; g.ldw = I; g.ldc = H * D; g.epi = vqs::EPI_BF16;
+            g.batch = H; g.sA = 64; g.sW = 64; g.sC = D;
+            RUN(run_gemm(h, g, st, "cross q.Wk"));
+            TAP("dec", i, "cqk", w.cqk, (size_t)MT * H * D);
+        }
+        {   // scores[b] [R, S] = q'[b] [R, D] . E[b]^T                      batched over pairs
+            GemmCall g{w.cqk, w.enc_out, w.cscores};
+            g.M = R; g.N = S; g.K = D; g.lda = D; g.ldw = D; g.ldc = w.S_pad; g.epi = vqs::EPI_F32;
+            g.batch = B; g.sA = (long long)R * D; g.sW = (long long)S * D; g.sC = (long long)R * w.S_pad;
+            RUN(run_gemm(h, g, st, "cross scores"));
+            TAP("dec", i, "cscores", w.cscores, (size_t)MT * H * w.S_pad);
+        }
+        HIPCHK(h, vqs::launch_masked_softmax(w.cscores, w.cprobs, w.enc_len, B, R, w.S_pad, st), "cross softmax");
+        TAP("dec", i, "cprobs", w.cprobs, (size_t)MT * H * w.S_pad);
+        {   // ctx[b] [R, D] = P[b] [R, S_pad] . E[b]   -> split-bf16: hi plane = the tensor of rounds 1-3, lo plane behind it
+            GemmCall g{w.cprobs, w.enc_outT, w.cctx};
+            g.M = R; g.N = D; g.K = w.S_pad; g.lda = w.S_pad; g.ldw = w.S_pad; g.ldc = D; g.epi = vqs::EPI_BF16;
+            g.batch = B; g.sA = (long long)R * w.S_pad; g.sW = (long long)D * w.S_pad; g.sC = (long long)R * D;
+            g.split_off = pC;
+            RUN(run_gemm(h, g, st, "cross P.E"));
+            TAP2("dec", i, "cctx", w.cctx, pC);
+        }
+        {   // out[(b,t), h*64:(h+1)*64] = ctx[(b,t), h, :] . Wv_h^T          batched over heads; both planes as 2*MT stacked rows
+            GemmCall g{w.cctx, cv_w, scratch};
+            g.M = 2 * MT; g.N = 64; g.K = D; g.lda = H * D; g.ldw = D; g.ldc = I; g.epi = vqs::EPI_F32;
+            g.batch = H; g.sA = D; g.sW = (long long)64 * D; g.sC = 64;
+            if ((size_t)2 * MT * I * sizeof(float) > sb) return fail(h, VQS_ERR_WORKSPACE, "cross ctx.Wv: decoder scratch too small");
+            RUN(run_gemm(h, g, st, "cross ctx.Wv"));
+            HIPCHK(h, vqs::launch_sum_planes(scratch, 1, 0, MT, I, I, vqs::SUM_SPLIT, w.dattn, I, pI, st), "cross ctx.Wv planes");
+        }
+        TAP2("dec", i, "cattn", w.dattn, pI);
+        RUN(dec_linear_split(h, w.dattn, co, MT, D, I, scratch, sb, vqs::SUM_F32, w.ddelta32, D, 0, st, "dec cross o"));
+        TAP("dec", i, "d_cross", w.ddelta32, (size_t)MT * D);
+        // ---- gated FFN
+        HIPCHK(h, vqs::launch_rmsnorm_split(w.dhid, w.ddelta32, ln2, w.dxn, pD, MT, D, c.t5_ln_eps, st), "dec rmsnorm2");
+        TAP2("dec", i, "xn2", w.dxn, pD);
+        RUN(dec_linear_split(h, w.dxn, h->dec_wi[i], MT, 2 * F, D, scratch, sb, vqs::SUM_GATED_SPLIT, w.dff, F, pF, st, "dec wi"));
+        TAP2("dec", i, "ff", w.dff, pF);
+        RUN(dec_linear_split(h, w.dff, wo, MT, D, F, scratch, sb, vqs::SUM_F32, w.ddelta32, D, 0, st, "dec wo"));
+        TAP("dec", i, "d_ff", w.ddelta32, (size_t)MT * D);
+        dpend = w.ddelta32;
+    }
+    {
+        GETW(fin, "decoder.final_layer_norm.weight", D);
+        GETW(head, "lm_head.weight", (int64_t)V * D);
+        HIPCHK(h, vqs::launch_rmsnorm_split(w.dhid, dpend, fin, w.dxn, pD, MT, D, c.t5_ln_eps, st), "dec final norm");
+        if ((w.ldl % 4) != 0 || (V % 4) != 0) return fail(h, VQS_ERR_INVALID, "precise decoder: vocabulary must be a multiple of 4");
+        RUN(dec_linear_split(h, w.dxn, head, MT, V, D, scratch, sb, vqs::SUM_F32, w.logits, w.ldl, 0, st, "lm_head"));
+    }
+    return VQS_OK;
+}
+
 int vqs_score(vqs_handle* h, const void* d_feats, const int32_t* d_img_index, const int32_t* d_input_ids,
               const int32_t* d_labels, int32_t B, int32_t L, int32_t T, float* d_lp, float* d_scores, void* d_ws,
               size_t ws_bytes, void* stream) {
@@ -1048,7 +1220,10 @@ int vqs_score(vqs_handle* h, const void* d_feats, const int32_t* d_img_index, co
     const int V = c.vocab;
 
     RUN(encoder_pass(h, w, d_feats, d_img_index, d_input_ids, B, L, st));
-    RUN(decoder_pass(h, w, d_labels, T, B, L, T, st));
+    if (h->dec_precise && h->cross_mode != 0)
+        RUN(decoder_pass_precise(h, w, d_labels, T, B, L, T, st));
+    else                                             // bf16 decoder of rounds 1-3 (option dec_precise=0, or the direct cross-attention form)
+        RUN(decoder_pass(h, w, d_labels, T, B, L, T, st));
     HIPCHK(h, vqs::launch_score_head(w.logits, w.ldl, V, d_labels, d_lp, d_scores, B, T, st), "score head");
     return VQS_OK;
 }

@@ -48,6 +48,10 @@ struct GemmParams {
     // workgroup -> tile order (gemm.hip tile_of_slot): M-tiles per group and number of N column ranges; 0 = default (8, 1).
     // A permutation of the tile list only -- results do not depend on it.
     int tile_gm = 0, tile_ns = 0;
+    // EPI_BF16, 8-wave staged epilogue only: the result leaves as a SPLIT-bf16 tensor -- hi = bf16(acc) at C (as always) and
+    // lo = bf16(acc - hi) at C + split_off (elements; 0 = off).  hi + lo carries 16 significant bits of the fp32 accumulator;
+    // the consumer stacks the two planes as rows of one GEMM and adds the two fp32 results (the precise decoder, vqs_api.cpp).
+    long long split_off = 0;
     int l2_touch = 0;        // lock-step persistent kernel: L2 prefetch of the A panel two K-tiles ahead; 0 = by shape (gemm.hip), 1 on, 2 off (a hint)
     int nt_store = 0;        // persistent kernels: result rows leave with the non-temporal hint (same bytes; a cache-policy hint)
     // EPI_RESID_RMS (producer side of the fused residual + RMSNorm)
@@ -197,6 +201,10 @@ struct DecAttnParams {
     long long kv_stride_b = 0;   // elements between the K/V rows of consecutive samples (default T * ldk)
     int qpos0 = 0;               // decoder position of query row 0 (causal mask and bias use qpos0 + t - key)
     int bias_ld = 0;             // row length of bias_table (default T)
+    // precise self form (teacher-forced only): q / k / v are FP32 [B*T, ldq] (the pointers above reinterpreted), the output is a
+    // split-bf16 tensor: hi plane at out, lo plane at out + out_plane (elements)
+    int precise = 0;
+    long long out_plane = 0;
 };
 hipError_t launch_decoder_attention(const DecAttnParams& p, hipStream_t stream);
 
@@ -238,6 +246,18 @@ hipError_t launch_rope_qk(bf16_t* q, bf16_t* k, const float* cs, const float* sn
                           hipStream_t s);
 hipError_t launch_rowss_to_rs(const float* rowss, int parts, int M, float invd, float eps, float* rs, hipStream_t s);
 hipError_t launch_reduce_slices(const float* part, int nslices, size_t n, bf16_t* out, hipStream_t s);
+// ---- the precise decoder's glue (elementwise.hip).  A split-bf16 tensor is two bf16 planes [2][rows][cols]: hi = bf16(x),
+// lo = bf16(x - hi); a GEMM consumes it as 2*rows stacked rows and the two fp32 results are added.
+// RMSNorm of the decoder rows: x (fp32 stream) += delta (fp32, optional; written back), out = split(w * x * rsqrt(mean x^2 + eps))
+hipError_t launch_rmsnorm_split(float* x, const float* delta, const bf16_t* w, bf16_t* out, long long out_plane, int M, int D,
+                                float eps, hipStream_t s);
+// Sum of GEMM partials: part is [nslices][2*rows][ldp] fp32 (split-K slices of a stacked hi / lo launch);
+//   y[r][c] = (sum_k part[k][r][c]) + (sum_k part[k][rows + r][c])   -- hi rows first, slices in index order (deterministic)
+// mode 0: out fp32 [rows, ld_out] = y;  mode 1: out = split(y), planes [rows, cols] at out and out + out_plane (ld_out = cols);
+// mode 2: cols = 2F in the packed wi order (blocks of 32 gate | 32 linear columns): out = split(gelu_new(gate) * linear), [rows, F] planes
+enum SumPlanesMode : int { SUM_F32 = 0, SUM_SPLIT = 1, SUM_GATED_SPLIT = 2 };
+hipError_t launch_sum_planes(const float* part, int nslices, long long slice_stride, int rows, int cols, int ldp, int mode, void* out,
+                             int ld_out, long long out_plane, hipStream_t s);
 // argmax of logits row (b*T + T-1) -> tokens[b, dst_col] (dst_col < 0: T-1)
 hipError_t launch_argmax_append(const float* logits, int ldl, int V, int* tokens, int ld_tokens, int B, int T,
                                 hipStream_t s, int dst_col = -1);

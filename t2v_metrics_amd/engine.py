@@ -139,6 +139,7 @@ class VqsEngine:
         self._ws: Optional[torch.Tensor] = None
         self._ws_shape = None
         self._ews: Optional[torch.Tensor] = None
+        self._options: Dict[str, int] = {}
         for k, v in (options or {}).items():
             self.set_option(k, v)
         self.bind(weights)
@@ -274,7 +275,12 @@ class VqsEngine:
         if name == "enc_out":
             return self._ws[off: off + 2 * B * S * t5.d_model].view(torch.bfloat16).view(B, S, t5.d_model)
         if name == "dec_out":
-            return self._ws[off: off + 2 * B * T * t5.d_model].view(torch.bfloat16).view(B, T, t5.d_model)
+            # the final norm's output is a split-bf16 tensor (planes hi | lo) under the precise decoder: its value is hi + lo;
+            # the bf16 decoder (option dec_precise=0, vqs_generate) writes plane 0 only
+            planes = self._ws[off: off + 2 * 2 * B * T * t5.d_model].view(torch.bfloat16).view(2, B, T, t5.d_model)
+            if self._options.get("dec_precise", 1) and self._options.get("cross_mode", 1):
+                return planes[0].float() + planes[1].float()
+            return planes[0]
         if name == "logits":
             return self._ws[off: off + 4 * B * T * ld.value].view(torch.float32).view(B, T, ld.value)[..., : t5.vocab]
         if name == "enc_len":
@@ -285,6 +291,7 @@ class VqsEngine:
 
     def set_option(self, name: str, value: int):
         self._check(self.lib.vqs_set_option(self._h, name.encode(), int(value)), "vqs_set_option")
+        self._options[name] = int(value)
 
     def tap(self, name: Optional[str], dst: Optional[torch.Tensor] = None):
         """Register `dst` (device tensor, kept alive by the caller) to receive the named intermediate of the next passes

@@ -45,8 +45,13 @@ def test_with_roundings_it_sits_at_the_bf16_floor_and_dispatches_from_oracle(nam
     out = emu.forward(pix.float(), idx, ids, labels, return_stages=True)
     d = (out["label_logprobs"] - ref).abs().max().item()
     assert 1e-5 < d < 8e-2, d                    # roundings are really applied, and only roundings
-    for k in ("vit_feats", "proj", "enc_out", "dec_out"):       # bf16-held tensors are exactly representable
+    for k in ("vit_feats", "proj", "enc_out"):                   # bf16-held tensors are exactly representable
         assert torch.equal(out[k], bf16_round(out[k])), k
+    # the decoder's final norm output is a SPLIT-bf16 tensor since round 4 (hi + lo planes): representable as such, not in one plane
+    from oracle.clip_t5_engine_rounding import split_bf16_round
+    assert torch.equal(out["dec_out"], split_bf16_round(out["dec_out"])) and not torch.equal(out["dec_out"], bf16_round(out["dec_out"]))
+    legacy = EngineRoundedOracle(cfg, w, dec_precise=False).forward(pix.float(), idx, ids, labels, return_stages=True)
+    assert torch.equal(legacy["dec_out"], bf16_round(legacy["dec_out"]))     # rounds 1-3's decoder: one bf16 plane
     with pytest.raises(ValueError):
         Oracle(cfg, w, emulate="nonsense")
 
@@ -89,7 +94,12 @@ def test_stage_locked_run_on_its_own_record_reports_zero(name):
     for n, (shape, dt) in shapes.items():
         assert rec[n].numel() == int(np.prod(shape)), n
     # hand the taps over the way the engine does: flat 2-D buffers in the engine's dtypes
-    taps = {n: (rec[n].reshape(shapes[n][0]).to(shapes[n][1]) if n in shapes else rec[n]) for n in rec}
+    def as_engine(n):                     # split tensors: the engine hands over two bf16 planes; here their exact sum
+        if n not in shapes:
+            return rec[n]
+        shape, dt = shapes[n]
+        return rec[n].reshape(shape) if dt == "split" else rec[n].reshape(shape).to(dt)
+    taps = {n: as_engine(n) for n in rec}
     report, lp = emu.forward_locked(taps, pix.float(), idx, ids, labels)
     assert set(report) == set(rec)
     assert all(r["max_abs"] == 0.0 for r in report.values()), {n: r for n, r in report.items() if r["max_abs"] > 0}

@@ -49,12 +49,12 @@ class Runner:
         self.pix, self.idx, self.ids, self.labels = batch
         self.cache = {}
 
-    def _oracle(self, classes):
-        return EngineRoundedOracle(self.cfg, self.w, acc=self.acc, classes=classes)
+    def _oracle(self, classes, dec_precise):
+        return EngineRoundedOracle(self.cfg, self.w, acc=self.acc, classes=classes, dec_precise=dec_precise)
 
-    def run(self, classes):
+    def run(self, classes, dec_precise=False):
         classes = frozenset(classes)
-        o = self._oracle(classes)
+        o = self._oracle(classes, dec_precise)
         with torch.no_grad():
             k_vit = frozenset(c for c in classes if stack_of(c) == "vit")
             k_proj = (k_vit, frozenset(c for c in classes if stack_of(c) == "proj"))
@@ -107,6 +107,7 @@ def main():
     batch = (pix.float(), idx.long(), ids.long(), labels.long())
     R = Runner(cfg, w, batch, getattr(torch, a.acc), gains)
 
+    # per-class and group runs model the engine of rounds 1-3 (every class a plain bf16 rounding)
     runs = [("none (all fp32)", ())]
     runs += [(c, (c,)) for c in ALL]
     runs += [("stack vit.*", tuple(c for c in ALL if stack_of(c) == "vit")),
@@ -115,7 +116,11 @@ def main():
              ("stack dec.*", tuple(c for c in ALL if stack_of(c) == "dec")),
              ("cheap set (dec.* + proj.* + enc.out)", CHEAP),
              ("engine minus cheap set", tuple(c for c in ALL if c not in CHEAP)),
-             ("engine (all classes)", ALL)]
+             ("engine (all classes)", ALL),
+             # round 4's engine: the same classes with the decoder's sensitive tensors split-bf16 / fp32 (EngineRoundedOracle.DEC_SPLIT)
+             ("engine, precise decoder (round 4)", ALL, True),
+             ("stack dec.*, precise decoder (round 4)", tuple(c for c in ALL if stack_of(c) == "dec"), True)]
+    runs = [r if len(r) == 3 else (r[0], r[1], False) for r in runs]
     if a.only:
         keep = set(a.only.split(","))
         runs = [r for r in runs if r[0] in keep or r[0].startswith("none")]
@@ -125,9 +130,9 @@ def main():
     results, ref = {}, None
     print(f"# {cfg.name}, {a.pairs} pairs (bench.synth_batch seed {a.seed}), labels {labels[0].tolist()}, products in {a.acc}, "
           f"gains {gains}, {torch.get_num_threads()} threads", flush=True)
-    for name, classes in runs:
+    for name, classes, precise in runs:
         t0 = time.time()
-        lp = R.run(classes)
+        lp = R.run(classes, precise)
         if ref is None:
             assert not classes
             ref = lp
