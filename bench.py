@@ -178,7 +178,7 @@ def run_also_leg(name):
     argv, what = ALSO_LEGS[name]
     t0 = time.perf_counter()
     try:
-        r = subprocess.run([sys.executable] + [os.path.join(ROOT, argv[0])] + argv[1:], capture_output=True, text=True, timeout=600,
+        r = subprocess.run([sys.executable] + [os.path.join(ROOT, argv[0])] + argv[1:], capture_output=True, text=True, timeout=420,
                            env={k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")})
         line = [l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1]
         j = json.loads(line)
@@ -277,7 +277,8 @@ def parse_args(argv=None):
                     "xl,genai1600,qwen,pipeline,config0; auto = all of them for the default single-GPU XXL run, none otherwise; none = off")
     ap.add_argument("--buckets", type=int, default=0, help="genai1600: time only this many length buckets, evenly spaced over the sorted workload (0 = all 38)")
     ap.add_argument("--cpu-emulation", action="store_true", help="also run the rounding-matched CPU oracle on pair 0 (~40 s at XXL)")
-    ap.add_argument("--cpu-reps", type=int, default=1, help="timed repetitions of the CPU reference (after 1 warm-up; a 4-pair XXL pass is ~45 s)")
+    ap.add_argument("--cpu-reps", type=int, default=3, help="timed repetitions of the CPU reference after 1 warm-up (BASELINE.md section 3: >= 3; a 4-pair XXL pass is ~50 s)")
+    ap.add_argument("--parity-pairs", type=int, default=16, help="pairs of the |delta log P| table (HIP vs fp32 truth, head gains 1 and 4)")
     ap.add_argument("--ragged", action="store_true", help="one batch of variable-length prompts, padded + masked (no bucketing)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="execution-form option of include/vqs.h vqs_set_option (e.g. gemm_variant=6, tile_order:20480x4096=520); "
@@ -522,23 +523,39 @@ def main():
         # reference of the cpu_baseline leg runs last, alone.
         import threading
         phase_a = [k for k in legs if k in ("xl", "genai1600")]
+        t_also = time.perf_counter()
+        ALSO_WALL_S = 480.0            # the extra legs may not take the default run past "a few minutes" on a slow box: later legs are skipped, and say so
+
+        def budget_left(k):
+            if time.perf_counter() - t_also <= ALSO_WALL_S:
+                return True
+            also[k] = {"what": ALSO_LEGS[k][1], "skipped": "wall budget of the extra legs (%.0f s) spent" % ALSO_WALL_S}
+            return False
 
         def run_phase_a():
             for k in phase_a:
-                also[k] = run_also_leg(k)
+                if budget_left(k):
+                    also[k] = run_also_leg(k)
         th = threading.Thread(target=run_phase_a)
         th.start()
         if "config0" in legs and args.cpu_pairs > 0:
             config0 = run_config0()
         th.join()
         for k in ("qwen", "pipeline"):
-            if k in legs:
+            if k in legs and budget_left(k):
                 also[k] = run_also_leg(k)
 
     failed = None
     if rank == 0 and world == 1 and args.cpu_pairs > 0 and not double and jobs:
+        parity, truth_dev = None, None
+        try:
+            parity, truth_dev = parity_sample(cfg, weights, eng, jobs[-1], args.parity_pairs)
+        except Exception as e:                           # noqa: BLE001 -- the table then falls back to the host-evaluated pairs
+            parity_err = repr(e)[:300]
         out["cpu_baseline"] = cpu_baseline(cfg, weights, jobs[-1], min(args.cpu_pairs, jobs[-1][2].shape[0]), lp, args.cpu_reps,
-                                           args.cpu_emulation)
+                                           args.cpu_emulation, parity, truth_dev)
+        if parity is None:
+            out["cpu_baseline"]["dlogp"]["parity_sample_error"] = parity_err
         if config0 is not None:
             out["cpu_baseline"]["config0"] = config0
         failed = out["cpu_baseline"]["dlogp"].get("violation")
@@ -571,7 +588,45 @@ def run_config0():
         return {"error": repr(e)[:300]}
 
 
-def cpu_baseline(cfg, weights, job, n_pairs, lp_gpu, reps, with_emulation=False):
+PARITY_GAINS = (1.0, 4.0)          # lm_head x gain: 1 = the seeded head (log P ~ -10), 4 = the peaked-head regime (the head is linear: re-read)
+DLOGP_BOUND = 1.0e-2               # end-to-end |delta log P| bound on the bench sample at gain 1 (3 x the measured 3e-3, profiles/r4_*)
+
+
+def parity_sample(cfg, weights, eng, job, n_pairs):
+    """|delta log P| of the HIP path against fp32 truth on the first n_pairs pairs of the batch the GPU scored last, at head gains 1
+    and 4 (a peaked head: the lm_head is the last op and linear, so the engine's fp32 logits and the truth's are re-read at gain g
+    -- exactly a model whose lm_head weights are g x, g a power of two).  Truth = oracle/clip_t5_oracle.py's arithmetic evaluated
+    in torch fp32 ON THE DEVICE (16 XXL pairs take the host cores ~10 minutes, the device seconds); cpu_baseline() cross-checks it
+    against the same oracle on the host cores on the pairs both evaluate.  Test infrastructure: runs after the timed region."""
+    from oracle.clip_t5_oracle import Oracle
+    pixels, img_index, ids, labels, _ = job
+    n = min(n_pairs, ids.shape[0])
+    dev = pixels.device
+    ids_c, lab_c = ids[:n].long(), labels[:n].long()
+    keep = int((ids_c != 0).sum(1).max())
+    t0 = time.perf_counter()
+    with torch.device(dev):
+        o = Oracle(cfg, weights, device=dev)
+        truth = o.forward(pixels[:n].float(), torch.arange(n, device=dev), ids_c[:, :keep], lab_c, return_stages=True)
+    torch.cuda.synchronize()
+    t_truth = time.perf_counter() - t0
+    logits_hip = eng.stage("logits")[:n].float()
+    logits_ref = truth["logits"].float()
+    out = {"pairs": n, "truth": "oracle/clip_t5_oracle.py evaluated in torch fp32 on the device (%.1f s); cross-checked on the host cores below" % t_truth,
+           "gains": {}}
+    for g in PARITY_GAINS:
+        lh = Oracle.label_logprobs(logits_hip * g, lab_c)
+        lr = Oracle.label_logprobs(logits_ref * g, lab_c)
+        d = (lh - lr)
+        per_pair = d.abs().max(1).values
+        out["gains"]["%g" % g] = {"max": float(per_pair.max()), "mean": float(per_pair.mean()), "mean_signed": float(d.mean()),
+                                  "yes_token_max": float(d[:, 0].abs().max()), "yes_token_mean": float(d[:, 0].abs().mean()),
+                                  "per_pair": [round(float(x), 6) for x in per_pair],
+                                  "logp_yes_range": [round(float(lr[:, 0].min()), 3), round(float(lr[:, 0].max()), 3)]}
+    return out, truth["label_logprobs"].float().cpu()
+
+
+def cpu_baseline(cfg, weights, job, n_pairs, lp_gpu, reps, with_emulation=False, parity=None, truth_dev=None, port_pairs=2):
     """The reference's arithmetic on the host cores: HF modules cast to bf16 as mm_utils.py:228 does,
     inference mode, all cores, 1 warm-up + `reps` timed repetitions on the first n_pairs pairs (one batch) of the batch the
     GPU scored last; beside it the fp32 port (oracle/clip_t5_oracle.py) on the same pairs = fp32 truth, and the per-pair
@@ -600,10 +655,18 @@ def cpu_baseline(cfg, weights, job, n_pairs, lp_gpu, reps, with_emulation=False)
     lp_ref = out_ref["label_logprobs"]
     stage_s = dict(ref.stage_s)
     del ref
-    # fp32 truth on the same pairs (the fp32 port up-casts every weight per use: slow by design)
+    # fp32 port on the host cores (up-casts every weight per use: slow by design, ~37 s per XXL pair): with a device-evaluated truth
+    # (parity_sample) it runs on `port_pairs` pairs only -- the port's own timing and the cross-check of that truth
+    n_port = n_pairs if truth_dev is None else max(1, min(port_pairs, n_pairs))
     t0 = time.perf_counter()
-    truth = Oracle(cfg, w_cpu).forward(px.float(), idx, ids_c, lab_c)["label_logprobs"]
+    truth_cpu = Oracle(cfg, w_cpu).forward(px[:n_port].float(), idx[:n_port], ids_c[:n_port], lab_c[:n_port])["label_logprobs"]
     t_port = time.perf_counter() - t0
+    truth_check = None
+    if truth_dev is None:
+        truth = truth_cpu
+    else:
+        truth = truth_dev[:n_pairs]
+        truth_check = float((truth_dev[:n_port] - truth_cpu).abs().max())
     emu = None
     if with_emulation:
         emu = Oracle(cfg, w_cpu, emulate="engine", acc=torch.float32).forward(px[:1].float(), idx[:1], ids_c[:1], lab_c[:1])["label_logprobs"]
@@ -616,11 +679,16 @@ def cpu_baseline(cfg, weights, job, n_pairs, lp_gpu, reps, with_emulation=False)
     e_ref = (lp_ref - truth)
     hip_pair = e_hip.abs().max(1).values
     ref_pair = e_ref.abs().max(1).values
-    violation = None
-    if float(hip_pair.max()) > 2.5e-2:
-        violation = "max |dlogP| HIP vs fp32 truth %.3e > 2.5e-2" % float(hip_pair.max())
-    elif float(hip_pair.mean()) > float(ref_pair.mean()):
-        violation = "mean |dlogP| vs fp32 truth: HIP %.3e > reference-as-shipped (HF bf16) %.3e" % (float(hip_pair.mean()), float(ref_pair.mean()))
+    # The exit-status gate is the ABSOLUTE bound only (a strict HIP-vs-reference comparison on a few cold pairs is a noisy
+    # gate); "HIP no closer to truth than the reference's own bf16 path" needs a margin and is reported as a warning field.
+    violation, warning = None, None
+    worst = max(float(hip_pair.max()), parity["gains"]["1"]["max"] if parity else 0.0)
+    if worst > DLOGP_BOUND:
+        violation = "max |dlogP| HIP vs fp32 truth %.3e > %.1e" % (worst, DLOGP_BOUND)
+    if truth_check is not None and truth_check > 2e-4:
+        violation = "device-evaluated fp32 truth differs from the host-evaluated oracle by %.3e" % truth_check
+    if float(hip_pair.mean()) > 1.5 * float(ref_pair.mean()):
+        warning = "mean |dlogP| vs fp32 truth: HIP %.3e > 1.5 x reference-as-shipped (HF bf16) %.3e" % (float(hip_pair.mean()), float(ref_pair.mean()))
     import transformers
     out = {"value": n_pairs / med, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "reference",
            "kind_detail": "reference as shipped: the HF modules its CLIP-FlanT5 wrapper calls, bf16, on the host cores (oracle/hf_reference.py)",
@@ -628,9 +696,12 @@ def cpu_baseline(cfg, weights, job, n_pairs, lp_gpu, reps, with_emulation=False)
                      f"1 warm-up + {len(timed)} timed repetitions, median {med:.2f} s (all: {', '.join('%.2f' % t for t in times)})",
            "stage_seconds_last_rep": stage_s,
            "host_cpus": os.cpu_count(), "cpu_model": cpu_model, "torch": torch.__version__, "transformers": transformers.__version__,
-           "port_fp32": {"value": n_pairs / t_port, "unit": "pairs/s", "kind": "port",
-                         "sample": f"oracle/clip_t5_oracle.py, fp32, the same {n_pairs} pairs, one cold pass ({t_port:.1f} s)"},
-           "dlogp": {"pairs": n_pairs,
+           "port_fp32": {"value": n_port / t_port, "unit": "pairs/s", "kind": "port",
+                         "sample": f"oracle/clip_t5_oracle.py, fp32, the first {n_port} of those pairs, one cold pass ({t_port:.1f} s)"},
+           "dlogp": {"pairs": parity["pairs"] if parity else n_pairs,
+                     "hip_vs_fp32_truth": parity,          # >= 16 pairs, head gains 1 and 4 (peaked): BASELINE.md section 3, row (iii) vs (i)
+                     "device_truth_vs_host_oracle_max": truth_check,
+                     "reference_pairs": n_pairs,
                      "per_pair_abs_hip_vs_fp32_truth": [round(float(x), 6) for x in hip_pair],
                      "per_pair_abs_hf_bf16_vs_fp32_truth": [round(float(x), 6) for x in ref_pair],
                      "per_pair_abs_hip_vs_hf_bf16": [round(float(x), 6) for x in (lp_hip - lp_ref).abs().max(1).values],
@@ -640,8 +711,8 @@ def cpu_baseline(cfg, weights, job, n_pairs, lp_gpu, reps, with_emulation=False)
                      "hip_closer_to_truth_than_hf_bf16_on_pairs": int((hip_pair <= ref_pair).sum()),
                      "rounding_matched_cpu_vs_fp32_truth_pair0": (emu - truth[:1]).abs().max().item() if emu is not None else None,
                      "logp_hip_pair0": lp_hip[0].tolist(), "logp_fp32_truth_pair0": truth[0].tolist(),
-                     "violation": violation},
-           "max_abs_dlogp_hip_vs_oracle": float(hip_pair.max())}
+                     "violation": violation, "warning": warning, "bound": DLOGP_BOUND},
+           "max_abs_dlogp_hip_vs_oracle": worst}
     del w_cpu
     return out
 

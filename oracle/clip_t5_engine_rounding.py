@@ -337,14 +337,27 @@ class EngineRoundedOracle(Oracle):
     def _s_pad(self, S: int) -> int:
         return (S + 63) // 64 * 64
 
-    def _dec_cross_attention(self, p: str, xn: torch.Tensor, enc_out: torch.Tensor, klen: torch.Tensor, n: str = "") -> torch.Tensor:
+    def _hi_plane(self, name: str, y: torch.Tensor):
+        """HI plane of the split tensor `name` whose unrounded fp32 value is y: stage-locked = the engine's own plane 0 (handed over
+        as "<name>#hi" by taps_to_values), free-running = bf16(y).  None when the tensor is not split (bf16 decoder / class off)."""
+        if not self.dec_precise or (self.classes is not None and "dec.norm" not in self.classes):
+            return None
+        if self.locked is not None:
+            return self.locked[name + "#hi"].detach().to("cpu", torch.float32).reshape(y.shape)
+        hi = self.r(y)
+        if self.record is not None:
+            self.record[name + "#hi"] = hi
+        return hi
+
+    def _dec_cross_attention(self, p: str, xn: torch.Tensor, enc_out: torch.Tensor, klen: torch.Tensor, n: str = "", xn_hi=None) -> torch.Tensor:
         """Reassociated cross-attention (vqs_api.cpp:781-812): (q_h Wk_h) E^T, masked softmax, (P E) Wv_h^T."""
         t, rc = self.cfg.t5, self.rc
         B, T, D = xn.shape
         S = enc_out.shape[1]
         H, dk = t.heads, t.d_kv
-        # precise decoder: the score path reads the HI plane of the split norm output (= bf16(xn): what it read before round 4)
-        xq = self.r(xn) if (self.dec_precise and (self.classes is None or "dec.cq" in self.classes)) else xn
+        # precise decoder: the score path reads the HI plane of the split norm output (xn_hi = bf16 of the norm's fp32 result: what
+        # it read before round 4).  Not bf16(hi + lo): lo is itself rounded and can land hi + lo exactly on a tie.
+        xq = xn if xn_hi is None else xn_hi
         q = self._emit(n + "cq", rc("dec.cq", self._mm(xq, p + "q.weight"))).reshape(B, T, H, dk)
         wk = self.w[p + "k.weight"].detach().to("cpu").to(self.acc).reshape(H, dk, D)
         wv = self.w[p + "v.weight"].detach().to("cpu").to(self.acc).reshape(H, dk, D)
@@ -383,9 +396,11 @@ class EngineRoundedOracle(Oracle):
             qkv = self._emit(n + "qkv", torch.cat([rc("dec.qkv", self._mm(xn, sa + nm + ".weight")) for nm in ("q", "k", "v")], dim=-1))
             sattn = self._emit(n + "sattn", self._dec_self_attention(qkv, self_bias))
             h = h + self._emit(n + "d_self", rc("dec.delta", self._mm(sattn, sa + "o.weight")))
-            xn = self._emit(n + "xn1", rc("dec.norm", t5_rms_norm(h, self._w(p + "layer.1.layer_norm.weight"), t.ln_eps)))
+            y1 = t5_rms_norm(h, self._w(p + "layer.1.layer_norm.weight"), t.ln_eps)
+            xn = self._emit(n + "xn1", rc("dec.norm", y1))
             ca = p + "layer.1.EncDecAttention."
-            h = h + self._emit(n + "d_cross", rc("dec.delta", self._mm(self._dec_cross_attention(ca, xn, enc_out, klen, n), ca + "o.weight")))
+            h = h + self._emit(n + "d_cross", rc("dec.delta", self._mm(self._dec_cross_attention(ca, xn, enc_out, klen, n, self._hi_plane(n + "xn1", y1)),
+                                                                        ca + "o.weight")))
             xn = self._emit(n + "xn2", rc("dec.norm", t5_rms_norm(h, self._w(p + "layer.2.layer_norm.weight"), t.ln_eps)))
             ffp = p + "layer.2.DenseReluDense."
             ff = self._emit(n + "ff", self._gated_ff(ffp, xn, "dec.act"))
@@ -436,7 +451,14 @@ class EngineRoundedOracle(Oracle):
     @staticmethod
     def taps_to_values(shapes, bufs):
         """Tap buffers -> the tensors' values (CPU): split entries become fp32 hi + lo."""
-        return {n: ((b[0].float() + b[1].float()).cpu() if shapes[n][1] == "split" else b.cpu()) for n, b in bufs.items()}
+        out = {}
+        for n, b in bufs.items():
+            if shapes[n][1] == "split":
+                out[n] = (b[0].float() + b[1].float()).cpu()
+                out[n + "#hi"] = b[0].float().cpu()
+            else:
+                out[n] = b.cpu()
+        return out
 
     def forward_locked(self, taps, pixel_values, img_index, input_ids, labels):
         """Stage-locked pass: `taps` = the engine's intermediates of ITS pass over the same inputs (every name of

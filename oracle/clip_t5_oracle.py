@@ -122,12 +122,16 @@ class Oracle:
             return object.__new__(EngineRoundedOracle)
         return object.__new__(cls)
 
-    def __init__(self, cfg, weights: Dict[str, torch.Tensor], emulate: Optional[str] = None):
+    def __init__(self, cfg, weights: Dict[str, torch.Tensor], emulate: Optional[str] = None, device="cpu"):
+        """device: where the fp32 arithmetic is evaluated.  "cpu" = the oracle proper.  bench.py's parity sample also evaluates
+        this same code in torch fp32 on the GPU (under ``with torch.device(dev)``) to get fp32 truth for more pairs than the
+        host cores can do in the bench's time budget; that evaluation is cross-checked against the CPU one on the pairs both do."""
         self.cfg = cfg
         self.w = weights
+        self.device = torch.device(device)
 
     def _w(self, name: str) -> torch.Tensor:
-        return self.w[name].detach().to("cpu", torch.float32)
+        return self.w[name].detach().to(self.device, torch.float32)
 
     # ------------------------------------------------------------------------------------------
     # vision tower: HF:models/clip/modeling_clip.py

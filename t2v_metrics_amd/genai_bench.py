@@ -49,35 +49,67 @@ def kendall_tau_b(gold_scores, metric_scores) -> float:
 def pairwise_acc_with_tie_optimization(gold_scores, metric_scores, sample_rate: float = 1.0,
                                        rng: Optional[np.random.RandomState] = None) -> Tuple[float, float]:
     """acc23 = (concordant + tied-in-both) / pairs, maximised over the tie threshold epsilon on the metric differences
-    (calc_metric variant "pairwise_acc_with_tie_optimization", dataset.py:163-166; tau_optimization.py:203-298 with a single
-    row).  Candidate thresholds: 0 and every distinct |metric difference|; a pair with |dm| <= epsilon counts as correct iff
-    the gold scores tie.  Returns (best accuracy, best threshold), the smallest threshold on ties of the maximum.
+    (calc_metric variant "pairwise_acc_with_tie_optimization", dataset.py:151-166; tau_optimization.py:203-298).
+    1-D inputs: one group.  2-D inputs [N items, M systems] (dataset.py:159-161 "group by item"): pairs are formed INSIDE each
+    row, ONE global threshold is searched, and the statistic is the mean over rows of the row's accuracy -- each pair weighs
+    1 / (rows x pairs of its row), which is what tau_optimization's per-row running sums add up to.
+    Candidate thresholds: 0 and every distinct |metric difference|; a pair with |dm| <= epsilon counts as correct iff the gold
+    scores tie.  Returns (best accuracy, best threshold), the smallest threshold on ties of the maximum (np.nanargmax).
     sample_rate < 1 subsamples pairs (approximate; the reference draws its sample pair by pair from np.random)."""
     if sample_rate <= 0 or sample_rate > 1:
         raise ValueError(f"`sample_rate` must be in the range (0, 1]. Found {sample_rate}")
     g, m = np.asarray(gold_scores, dtype=np.float64), np.asarray(metric_scores, dtype=np.float64)
-    assert g.shape == m.shape and g.ndim == 1
-    dg, dm = _pair_arrays(g, m)
+    if g.shape != m.shape:
+        raise ValueError('Human and metric scores must have the same shape.')
+    if g.ndim == 1:
+        g, m = g[None], m[None]
+    assert g.ndim == 2
+    i, j = np.triu_indices(g.shape[1], k=1)
+    dg, dm = (g[:, i] - g[:, j]), (m[:, i] - m[:, j])                       # [rows, pairs per row]
+    keep = np.ones(dg.shape, dtype=bool)
     if sample_rate < 1.0:
-        keep = (rng or np.random).random_sample(dg.size) <= sample_rate
-        dg, dm = dg[keep], dm[keep]
+        keep = (rng or np.random).random_sample(dg.shape) <= sample_rate
+    per_row = keep.sum(1)
+    rows = int((per_row > 0).sum())
+    if rows == 0:
+        return float("nan"), 0.0
+    if sample_rate == 1.0:
+        # every row has the same number of pairs: integer counts, exact ties between thresholds (smallest threshold wins, as the
+        # reference's nanargmax does on its list), one division at the end
+        wgt, scale = np.ones(dg.shape, dtype=np.int64), 1.0 / (rows * int(per_row[0]))
+    else:
+        wgt, scale = np.where(per_row > 0, 1.0 / np.maximum(per_row, 1), 0.0)[:, None] / rows * keep, 1.0   # a pair's share of the row-averaged accuracy
+    dg, dm, wgt = dg[keep], dm[keep], wgt[keep]
     adm = np.abs(dm)
     order = np.argsort(adm, kind="stable")
-    adm, dg, dm = adm[order], dg[order], dm[order]
-    gold_tie = dg == 0
-    conc = ((dg > 0) & (dm > 0)) | ((dg < 0) & (dm < 0))
-    P = adm.size
+    adm, dg, dm, wgt = adm[order], dg[order], dm[order], wgt[order]
+    gold_tie = (dg == 0) * wgt
+    conc = (((dg > 0) & (dm > 0)) | ((dg < 0) & (dm < 0))) * wgt
     # accuracy when the first k pairs (smallest differences) are metric ties: gold ties among them + concordant among the rest
     tie_prefix = np.concatenate([[0], np.cumsum(gold_tie)])
     conc_suffix = np.concatenate([np.cumsum(conc[::-1])[::-1], [0]])
-    acc = (tie_prefix + conc_suffix) / P
+    acc = tie_prefix + conc_suffix
     # threshold d <-> k = number of pairs with |dm| <= d
     thresholds = np.concatenate([[0.0], adm])
     ks = np.searchsorted(adm, thresholds, side="right")
     vals = acc[ks]
     uniq, first = np.unique(thresholds, return_index=True)
     best = int(np.argmax(vals[first]))
-    return float(vals[first][best]), float(uniq[best])
+    return float(vals[first][best] * scale), float(uniq[best])
+
+
+def calc_metric(gold_scores, metric_scores, variant: str = "pairwise_acc_with_tie_optimization", sample_rate: float = 1.0):
+    """dataset.py:151-188 for the variants the GenAI-Bench tables use: "pairwise_acc_with_tie_optimization" -> (accuracy,
+    threshold); "tau_b" -> mean over rows of Kendall tau-b, NaN rows skipped.  1-D = one group, 2-D = grouped by item."""
+    g, m = np.asarray(gold_scores), np.asarray(metric_scores)
+    assert g.shape == m.shape
+    if variant == "pairwise_acc_with_tie_optimization":
+        return pairwise_acc_with_tie_optimization(g, m, sample_rate)
+    if variant == "tau_b":
+        if g.ndim == 1:
+            g, m = g[None], m[None]
+        return float(np.nanmean(np.array([kendall_tau_b(a, b) for a, b in zip(g, m)])))
+    raise ValueError(f"unsupported variant {variant!r}")
 
 
 # ------------------------------------------------------------------------------------------------ dataset

@@ -167,5 +167,5 @@ def test_shipped_library_has_no_lab_code_and_reads_no_environment():
     for src in ("gemm.hip", "attn.hip", "elementwise.hip", "vqs_api.cpp", "vqs_qwen.cpp"):
         text = open(os.path.join(CSRC, src)).read()
         assert "getenv" not in text and "VQS_LAB" not in text, src + ": environment switch / lab flavour is back"
-    assert not os.path.exists(os.path.join(CSRC, "lab")), "csrc/lab is back"
         assert "VQS_ABLATE" not in text and "VQS_ATTN_ABLATE" not in text, src + ": ablation scaffolding is back"
+    assert not os.path.exists(os.path.join(CSRC, "lab")), "csrc/lab is back"

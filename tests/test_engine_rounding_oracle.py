@@ -89,6 +89,8 @@ def test_stage_locked_run_on_its_own_record_reports_zero(name):
     emu.record = {}
     free = emu.forward(pix.float(), idx, ids, labels)
     rec, emu.record = emu.record, None
+    hi = {n: rec.pop(n) for n in list(rec) if n.endswith("#hi")}
+    assert sorted(hi) == sorted(f"dec.{i}.xn1#hi" for i in range(cfg.t5.dec_layers))
     shapes = emu.tap_shapes(pix.shape[0], ids.shape[0], ids.shape[1], labels.shape[1])
     assert set(shapes) | {"proj", "enc_out", "dec_out", "logits"} == set(rec)
     for n, (shape, dt) in shapes.items():
@@ -100,6 +102,7 @@ def test_stage_locked_run_on_its_own_record_reports_zero(name):
         shape, dt = shapes[n]
         return rec[n].reshape(shape) if dt == "split" else rec[n].reshape(shape).to(dt)
     taps = {n: as_engine(n) for n in rec}
+    taps.update(hi)                                      # the hi planes the score path reads ("<name>#hi", as taps_to_values hands them over)
     report, lp = emu.forward_locked(taps, pix.float(), idx, ids, labels)
     assert set(report) == set(rec)
     assert all(r["max_abs"] == 0.0 for r in report.values()), {n: r for n, r in report.items() if r["max_abs"] > 0}

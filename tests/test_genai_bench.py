@@ -47,6 +47,46 @@ def test_metrics_match_scipy_and_the_reference_pair_loop():
         pairwise_acc_with_tie_optimization([1, 2], [1, 2], sample_rate=0.0)
 
 
+def _reference_tau_optimization():
+    """The reference's own module where it is on disk (this container; not the GPU box): /root/reference/tau_optimization.py."""
+    import importlib.util
+    path = "/root/reference/tau_optimization.py"
+    if not os.path.exists(path):
+        pytest.skip("reference tree not present")
+    spec = importlib.util.spec_from_file_location("ref_tau_optimization", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_pairwise_accuracy_equals_the_references_tau_optimization():
+    """The checker is the reference itself (tau_optimization.tau_optimization with TauSufficientStats.acc_23, as dataset.py:163-166
+    calls it): ungrouped vectors and the grouped N x M case (dataset.py:159-161), with heavy ties in both score sets."""
+    from t2v_metrics_amd.genai_bench import calc_metric
+    ref = _reference_tau_optimization()
+    rng = np.random.RandomState(7)
+    for trial in range(25):
+        if trial % 2 == 0:
+            shape = (int(rng.randint(2, 30)),)
+        else:
+            shape = (int(rng.randint(1, 9)), int(rng.randint(2, 8)))
+        gold = rng.randint(1, 6, size=shape).astype(float)
+        metric = np.round(rng.rand(*shape) + 0.2 * gold, 1 if trial % 3 == 0 else 3)
+        r = ref.tau_optimization(metric, gold, ref.TauSufficientStats.acc_23)
+        acc, thr = calc_metric(gold, metric, "pairwise_acc_with_tie_optimization")
+        assert abs(acc - r.best_tau) < 1e-12, (trial, shape, acc, r.best_tau)
+        # the threshold: the reference's running float sums can order two mathematically tied thresholds either way (here the
+        # counts are integers and the smallest wins), so it has to match only where the reference's maximum is unique
+        taus, ths = np.array(r.taus), np.array(r.thresholds)
+        if (taus > r.best_tau - 1e-9).sum() == 1:
+            assert abs(thr - r.best_threshold) < 1e-12, (trial, shape, thr, r.best_threshold)
+        else:
+            assert abs(taus[np.argmin(np.abs(ths - thr))] - r.best_tau) < 1e-9 and np.abs(ths - thr).min() < 1e-12
+    # rows without a pair (one system) do not count as rows
+    acc, _ = calc_metric(np.array([[1.0], [2.0]]), np.array([[0.1], [0.2]]))
+    assert np.isnan(acc)
+
+
 def _make_dataset(root, n_prompts=5):
     d = os.path.join(root, "GenAI-Image-527")
     os.makedirs(d)
