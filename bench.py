@@ -340,14 +340,11 @@ def main():
             os.environ.setdefault("WORLD_SIZE", "1")
         # one rank per GPU: keep the rank's host threads on the cores next to its device (first touch of pinned buffers, the image
         # thread pool): cores are split evenly by local rank unless the launcher already restricted the affinity
-        try:
-            cores = sorted(os.sched_getaffinity(0))
-            nloc = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-            if nloc > 1 and len(cores) >= 2 * nloc and os.environ.get("VQS_BENCH_NO_AFFINITY") != "1":
-                per = len(cores) // nloc
-                os.sched_setaffinity(0, cores[local_rank * per:(local_rank + 1) * per])
-        except (AttributeError, OSError):
-            pass
+        # (t2v_metrics_amd/sharding.py: the cores of the NUMA node the rank's GPU hangs off, shared evenly by the ranks of that node;
+        # an equal split of the allowed cores when the topology is unknown)
+        from t2v_metrics_amd.sharding import set_rank_affinity
+        if os.environ.get("VQS_BENCH_NO_AFFINITY") != "1" and not double:
+            set_rank_affinity(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
         if backend == "nccl":
             dist_mod.init_process_group(backend="nccl", device_id=device)
         else:

@@ -1,0 +1,150 @@
+"""Process pool for the integer half of the image input pipeline (decode + pad + PIL resize + crop -> uint8 [S, S, 3]).
+
+PIL decodes PNG / JPEG under the GIL, so threads do not scale the decode; worker PROCESSES do.  The workers are plain
+subprocesses running ``_imgprep.py`` (numpy + PIL only: ~0.1 s to start, no torch import, no HIP context, independent of how
+the user's main script is written -- unlike multiprocessing's spawn / forkserver start methods, which re-import ``__main__``).
+Results travel through ONE memory-mapped file under /dev/shm per pool (a uint8 [slots, S, S, 3] array the workers write rows
+of); requests and acknowledgements are JSON lines on the workers' pipes.  The parent side is a thread per in-flight request
+blocked on a pipe read (which releases the GIL).
+
+Reference counterpart: none -- the reference decodes one image per model call on the main thread
+(/root/reference/t2v_metrics/models/model.py:10-14, score.py:104-106); SURVEY.md §8f rank 1 widens the hot path to here.
+"""
+from __future__ import annotations
+
+import atexit
+import json
+import os
+import queue
+import subprocess
+import sys
+import tempfile
+import threading
+from concurrent.futures import ThreadPoolExecutor
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+_WORKER = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_imgprep.py")
+
+
+class ImagePoolError(RuntimeError):
+    pass
+
+
+class _Worker:
+    def __init__(self):
+        env = dict(os.environ)
+        env.update(OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")   # one core per worker
+        self.proc = subprocess.Popen([sys.executable, "-u", _WORKER], stdin=subprocess.PIPE, stdout=subprocess.PIPE, env=env,
+                                     text=True, bufsize=1)
+
+    def request(self, req: dict) -> dict:
+        try:
+            self.proc.stdin.write(json.dumps(req) + "\n")
+            self.proc.stdin.flush()
+            line = self.proc.stdout.readline()
+        except (BrokenPipeError, OSError) as e:
+            raise ImagePoolError(f"image worker died: {e}") from e
+        if not line:
+            raise ImagePoolError(f"image worker exited (code {self.proc.poll()})")
+        return json.loads(line)
+
+    def close(self):
+        try:
+            self.proc.stdin.close()
+        except OSError:
+            pass
+        try:
+            self.proc.wait(timeout=2)
+        except subprocess.TimeoutExpired:
+            self.proc.kill()
+
+
+class ImageProcessPool:
+    """load_u8(paths, size, pad) -> uint8 ndarray [N, size, size, 3] (a view of the pool's shared mapping, valid until the next
+    call), rows computed by `num_workers` worker processes; bytes identical to ``_imgprep.clip_preprocess_u8(image_loader(p))``."""
+
+    def __init__(self, num_workers: int):
+        self.num_workers = max(1, int(num_workers))
+        self._workers: List[_Worker] = []
+        self._idle: "queue.Queue[_Worker]" = queue.Queue()
+        self._threads: Optional[ThreadPoolExecutor] = None
+        self._shm_path: Optional[str] = None
+        self._shm: Optional[np.memmap] = None
+        self._lock = threading.Lock()
+        self._closed = False
+        atexit.register(self.close)
+
+    def _start(self):
+        if self._workers:
+            return
+        for _ in range(self.num_workers):
+            w = _Worker()
+            self._workers.append(w)
+            self._idle.put(w)
+        self._threads = ThreadPoolExecutor(max_workers=self.num_workers, thread_name_prefix="vqs-imgpool")
+
+    def _mapping(self, n: int, size: int) -> np.memmap:
+        need = (n, size, size, 3)
+        if self._shm is None or self._shm.shape[0] < n or self._shm.shape[1] != size:
+            self._drop_mapping()
+            d = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+            fd, self._shm_path = tempfile.mkstemp(prefix=f"vqs_img_{os.getpid()}_", suffix=".u8", dir=d)
+            os.close(fd)
+            slots = max(n, 64)
+            self._shm = np.memmap(self._shm_path, dtype=np.uint8, mode="w+", shape=(slots,) + need[1:])
+        return self._shm
+
+    def _drop_mapping(self):
+        if self._shm is not None:
+            del self._shm
+            self._shm = None
+        if self._shm_path is not None:
+            try:
+                os.unlink(self._shm_path)
+            except OSError:
+                pass
+            self._shm_path = None
+
+    def load_u8(self, paths: Sequence, size: int, pad: bool) -> np.ndarray:
+        if self._closed:
+            raise ImagePoolError("image pool is closed")
+        with self._lock:                       # one batch at a time per pool (the mapping is shared)
+            self._start()
+            n = len(paths)
+            if n == 0:
+                return np.zeros((0, size, size, 3), dtype=np.uint8)
+            shm = self._mapping(n, size)
+            slots = shm.shape[0]
+
+            def one(i_path):
+                i, p = i_path
+                w = self._idle.get()
+                try:
+                    return w.request({"slot": i, "path": str(p), "size": int(size), "pad": bool(pad), "shm": self._shm_path, "n": slots})
+                finally:
+                    self._idle.put(w)
+
+            replies = list(self._threads.map(one, enumerate(paths)))
+            bad = [r for r in replies if not r.get("ok")]
+            if bad:
+                raise ImagePoolError(f"{len(bad)} of {n} images failed; first: {paths[bad[0]['slot']] if bad[0]['slot'] >= 0 else '?'}: {bad[0].get('err')}")
+            return shm[:n]
+
+    def close(self):
+        if self._closed:
+            return
+        self._closed = True
+        if self._threads is not None:
+            self._threads.shutdown(wait=True)
+        for w in self._workers:
+            w.close()
+        self._workers = []
+        self._drop_mapping()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                      # noqa: BLE001 -- interpreter shutdown
+            pass

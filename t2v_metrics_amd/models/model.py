@@ -15,14 +15,7 @@ from PIL import Image
 from ..constants import HF_CACHE_DIR
 
 
-def image_loader(image_path) -> Image.Image:
-    """Decode one image path to an RGB PIL image.  ``.npy`` files hold OpenCV-style BGR arrays [H, W, 3] and are
-    channel-flipped (reference model.py:10-14); every other suffix is handed to PIL."""
-    if Path(str(image_path)).suffix.lower() == '.npy':
-        bgr = np.load(image_path)
-        return Image.fromarray(np.ascontiguousarray(bgr[..., ::-1]), 'RGB')
-    with Image.open(image_path) as im:
-        return im.convert("RGB")
+from .._imgprep import image_loader  # noqa: E402,F401  (reference model.py:10-14; defined in the torch-free module the image workers run)
 
 
 class ScoreModel(ABC):

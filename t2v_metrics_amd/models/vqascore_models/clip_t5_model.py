@@ -59,7 +59,7 @@ class CLIPT5Model(VQAScoreModel):
     def __init__(self, model_name='clip-flant5-xxl', device='cuda', cache_dir=HF_CACHE_DIR, *, weights=None,
                  tokenizer=None, checkpoint: Optional[str] = None, config=None, max_pairs: int = 256,
                  max_images: int = 256, seed: int = 0, engine=None, num_workers: Optional[int] = None,
-                 vision_tower: Optional[str] = None):
+                 vision_tower: Optional[str] = None, image_workers: str = "process"):
         """
         weights:    None -> load ``checkpoint`` (a local HF directory of safetensors); 'seeded' -> seeded random
                     weights at the exact architecture (benchmarks, tests); or a dict name -> tensor.
@@ -67,17 +67,31 @@ class CLIPT5Model(VQAScoreModel):
                     the checkpoint directory (the reference uses ``AutoTokenizer(use_fast=False)``, mm_utils.py:198).
         config:     a ClipT5Config overriding the registry entry (tests use the tiny configurations).
         engine:     an already constructed engine-like object (tests inject a recording fake).
-        num_workers: threads that decode + preprocess images (PIL releases the GIL); None -> min(32, cpu count).
-                    The reference does this serially inside forward(); at ~450 pairs/s the
+        num_workers: workers that decode + preprocess images; None -> min(32, cores this process may run on).
+                    The reference does this serially inside forward(); at ~200-550 pairs/s the
                     GPU would otherwise wait on PNG/JPEG decode.
+        image_workers: "process" (default) = worker processes (t2v_metrics_amd/imgpool.py: PIL decodes under the GIL, so
+                    only processes scale the decode -- what a rank needs when it has 1/8 of the host's cores), "thread" = the
+                    thread pool of rounds 1-3.  A custom ``self.image_loader`` always runs on threads (workers cannot see it).
         """
         assert config is not None or model_name in CLIP_T5_MODELS
         self._weights_arg, self._tokenizer_arg, self._checkpoint = weights, tokenizer, checkpoint
         self._cfg = config if config is not None else get_config(CLIP_T5_MODELS[model_name]['config'])
         self._seed, self._engine_arg = seed, engine
         self._vision_tower_dir = vision_tower
-        self.num_workers = min(32, os.cpu_count() or 1) if num_workers is None else max(1, int(num_workers))
+        try:
+            cores = len(os.sched_getaffinity(0))          # what this process may use (a rank's slice under taskset / the launcher)
+        except (AttributeError, OSError):
+            cores = os.cpu_count() or 1
+        self.num_workers = min(32, cores) if num_workers is None else max(1, int(num_workers))
+        if image_workers not in ("process", "thread"):
+            raise ValueError("image_workers must be 'process' or 'thread'")
+        self.image_workers = image_workers
         self._pool = None
+        self._proc_pool = None
+        self._staging = [None, None]              # two pinned uint8 staging buffers + the event of their last H2D copy
+        self._staging_ev = [None, None]
+        self._staging_next = 0
         self.max_pairs, self.max_images = int(max_pairs), int(max_images)
         self.context_len = CONTEXT_LEN
         self.image_aspect_ratio = 'pad'          # mm_utils.py:188,235
@@ -160,13 +174,38 @@ class CLIPT5Model(VQAScoreModel):
             out[i] = t
         return out
 
-    def _load_images_host_u8(self, image: List[str]) -> torch.Tensor:
-        """Decode + pad + PIL resize + crop on the host (thread pool; PIL releases the GIL) -> uint8 [N,S,S,3], pinned."""
+    def _staging_buffer(self, n: int):
+        """One of two pinned uint8 staging buffers [>= n, S, S, 3], allocated once and reused (pinning 87 MB per call costs as much
+        as the copy): a buffer is handed out again only after the H2D copy that last read it has completed (its event)."""
         S = self.cfg.vision.image
-        out = torch.empty(len(image), S, S, 3, dtype=torch.uint8)
-        if torch.cuda.is_available():
-            out = out.pin_memory()
+        k = self._staging_next
+        self._staging_next ^= 1
+        if self._staging_ev[k] is not None:
+            self._staging_ev[k].synchronize()
+        buf = self._staging[k]
+        if buf is None or buf.shape[0] < n:
+            buf = torch.empty(max(n, self.max_images), S, S, 3, dtype=torch.uint8)
+            if torch.cuda.is_available():
+                buf = buf.pin_memory()
+            self._staging[k] = buf
+        return k, buf[:n]
+
+    def _use_process_pool(self) -> bool:
+        from ..._imgprep import image_loader as default_loader
+        return self.image_workers == "process" and self.num_workers > 1 and self.image_loader is default_loader
+
+    def _load_images_host_u8(self, image: List[str]):
+        """Decode + pad + PIL resize + crop on the host -> (staging slot, uint8 [N,S,S,3] pinned).  Worker processes by default
+        (imgpool.py); threads for a custom image_loader or image_workers='thread'."""
+        S = self.cfg.vision.image
+        k, out = self._staging_buffer(len(image))
         arr = out.numpy()
+        if self._use_process_pool():
+            if self._proc_pool is None:
+                from ...imgpool import ImageProcessPool
+                self._proc_pool = ImageProcessPool(self.num_workers)
+            np.copyto(arr, self._proc_pool.load_u8(list(image), S, self.image_aspect_ratio == 'pad'))
+            return k, out
         pool = self._executor()
 
         def work(i_path):
@@ -177,7 +216,7 @@ class CLIPT5Model(VQAScoreModel):
         else:
             for ip in enumerate(image):
                 work(ip)
-        return out
+        return k, out
 
     def load_images(self, image: List[str]) -> torch.Tensor:
         """Decode + pad to square + CLIP-preprocess; returns bf16 [N,3,S,S] on the device.  With the HIP engine the
@@ -185,7 +224,11 @@ class CLIPT5Model(VQAScoreModel):
         bytes, no GIL-bound numpy arithmetic); test doubles without ``normalize_u8`` get the host float path."""
         if hasattr(self.engine, "normalize_u8") and str(self.device).startswith('cuda') and torch.cuda.is_available():
             from ...preprocess import OPENAI_CLIP_MEAN, OPENAI_CLIP_STD
-            u8 = self._load_images_host_u8(image).to(self.device, non_blocking=True)
+            k, host = self._load_images_host_u8(image)
+            u8 = host.to(self.device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._staging_ev[k] = ev
             return self.engine.normalize_u8(u8, OPENAI_CLIP_MEAN, OPENAI_CLIP_STD)
         px = self._load_images_host(image)
         if str(self.device).startswith('cuda') and torch.cuda.is_available():

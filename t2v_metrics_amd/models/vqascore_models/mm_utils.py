@@ -9,15 +9,7 @@ from PIL import Image
 from ...constants import IMAGE_TOKEN_INDEX, DEFAULT_IMAGE_TOKEN
 
 
-def expand2square(pil_img: Image.Image, background_color) -> Image.Image:
-    """Pad the shorter side symmetrically (floor on the leading side) so the image becomes square."""
-    w, h = pil_img.size
-    if w == h:
-        return pil_img
-    side = max(w, h)
-    canvas = Image.new(pil_img.mode, (side, side), background_color)
-    canvas.paste(pil_img, ((side - w) // 2, (side - h) // 2))
-    return canvas
+from ..._imgprep import expand2square  # noqa: E402,F401  (mm_utils.py:128-139; defined in the torch-free module the image workers run)
 
 
 def t5_tokenizer_image_token(prompt: str, tokenizer, image_token_index: int = IMAGE_TOKEN_INDEX,

@@ -45,3 +45,93 @@ def gather_rows(local: torch.Tensor, n_total: int) -> torch.Tensor:
         lo, hi = shard_range(n_total, r, ws)
         rows.append(out[r][: hi - lo])
     return torch.cat(rows, 0).cpu()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Host-core affinity of a rank: the cores of the NUMA node its GPU hangs off (first touch of the pinned staging buffers, the
+# image workers), shared evenly between the ranks of that node.  The reference has no multi-GPU path.
+# ----------------------------------------------------------------------------------------------------------------------
+def _parse_cpulist(text: str):
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def plan_rank_affinity(gpu_numa, node_cpus, allowed, local_rank: int):
+    """Pure planning step.  gpu_numa[i] = NUMA node of local GPU i (-1 = unknown); node_cpus = {node: [cpu, ...]}; allowed = cores
+    this process may use now.  Rank r (GPU r) gets an equal slice of its GPU's node, cut among the ranks on that node in rank
+    order; unknown topology (or a node with fewer allowed cores than ranks) falls back to an equal split of `allowed` by rank."""
+    allowed = sorted(allowed)
+    n = len(gpu_numa)
+    if n <= 1 or not 0 <= local_rank < n:
+        return allowed
+    node = gpu_numa[local_rank]
+    cpus = [c for c in node_cpus.get(node, []) if c in set(allowed)] if node is not None and node >= 0 else []
+    peers = [r for r in range(n) if gpu_numa[r] == node]
+    if cpus and len(cpus) >= len(peers):
+        per = len(cpus) // len(peers)
+        k = peers.index(local_rank)
+        return cpus[k * per:(k + 1) * per]
+    per = len(allowed) // n
+    return allowed[local_rank * per:(local_rank + 1) * per] if per > 0 else allowed
+
+
+def gpu_numa_nodes(n_gpus: int):
+    """NUMA node of each visible GPU from sysfs (the device's PCI address -> /sys/bus/pci/devices/<bdf>/numa_node), -1 if unknown.
+    (`rocm-smi --showtoponuma` prints the same numbers.)"""
+    out = []
+    for i in range(n_gpus):
+        node = -1
+        try:
+            bdf = torch.cuda.get_device_properties(i).pci_bus_id if hasattr(torch.cuda.get_device_properties(i), "pci_bus_id") else None
+            if bdf is None:
+                p = torch.cuda.get_device_properties(i)
+                bdf = "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, p.pci_device_id)
+            with open(f"/sys/bus/pci/devices/{str(bdf).lower()}/numa_node") as f:
+                node = int(f.read().strip())
+        except Exception:                      # noqa: BLE001 -- no sysfs entry / no such attribute: unknown
+            node = -1
+        out.append(node)
+    return out
+
+
+def set_rank_affinity(local_rank: int, local_world: int):
+    """Bind this process to its rank's cores (see plan_rank_affinity); returns the core list, or None when nothing was changed."""
+    import os
+    try:
+        allowed = os.sched_getaffinity(0)
+    except (AttributeError, OSError):
+        return None
+    if local_world <= 1 or len(allowed) < 2 * local_world:
+        return None
+    node_cpus = {}
+    base = "/sys/devices/system/node"
+    try:
+        for d in os.listdir(base):
+            if d.startswith("node") and d[4:].isdigit():
+                with open(os.path.join(base, d, "cpulist")) as f:
+                    cpus = _parse_cpulist(f.read())
+
+                def core_key(c):               # SMT siblings next to each other: a rank gets whole cores, not other ranks' second threads
+                    try:
+                        with open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list") as g:
+                            return (min(_parse_cpulist(g.read())), c)
+                    except OSError:
+                        return (c, c)
+                node_cpus[int(d[4:])] = sorted(cpus, key=core_key)
+    except OSError:
+        node_cpus = {}
+    n_gpus = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    numa = gpu_numa_nodes(n_gpus) if n_gpus >= local_world else [-1] * local_world
+    cores = plan_rank_affinity(numa[:local_world] if len(numa) >= local_world else [-1] * local_world, node_cpus, allowed, local_rank)
+    if not cores:
+        return None
+    try:
+        os.sched_setaffinity(0, cores)
+    except OSError:
+        return None
+    return cores

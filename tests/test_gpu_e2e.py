@@ -24,7 +24,8 @@ from t2v_metrics_amd.weights import make_seeded_weights
 pytestmark = pytest.mark.gpu
 
 LOGPROB_TOL = 1e-3          # north_star
-LOGPROB_TOL_BF16 = 2.5e-2   # bf16-operand bound per unit of logit scale (measured 0.004-0.010 at gain 1)
+LOGPROB_TOL_BF16 = 1.5e-2   # bf16-operand bound per unit of logit scale on the 128/256-wide test configurations: 3 x the measured
+                            # 3.5e-3 .. 5e-3 at gain 1 with the precise decoder (round 3: 2.5e-2 against 4e-3 .. 1e-2)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 

@@ -140,16 +140,19 @@ def _one_pair_three_way(cfg, w, eng, tag, seed, check_random=True):
     _record("fullsize/" + tag, out)
     for regime in ("planted-self", "planted-oracle", "planted-tilted"):
         assert out[regime]["logp_fp32"][0][0] > -3.0, out                        # the planted regimes really are peaked
-    # north_star's literal tolerance, where it is well defined: peaked head, direction = the decoder state (engine's or oracle's)
-    assert out["planted-self"]["dlogp_vs_fp32"] <= 1e-3, out
-    assert out["planted-oracle"]["dlogp_vs_fp32"] <= 1e-3, out
-    # first-order sensitive regimes: bf16 operand noise, calibrated by what the same arithmetic shows on
-    # the CPU, under an absolute ceiling (the emulator must not be able to widen the gate without limit -- ADVICE r2)
-    for regime in ("random-head", "planted-tilted"):
-        if regime in out:
-            o = out[regime]
-            assert o["dlogp_vs_fp32"] <= min(max(2.5e-2, 3.0 * o["rounding_matched_vs_fp32"]), 5e-2), (regime, out)
-    assert rel <= 0.05, rel
+    # north_star's literal tolerance |delta log P| <= 1e-3 in EVERY peaked regime (P(label) 0.2-0.8, where a real checkpoint's
+    # "Yes" sits): direction = the decoder state (engine's or oracle's; measured 1e-5 .. 3e-5 with the precise decoder of round 4)
+    # and the first-order sensitive tilted direction (measured 1.9e-4 / 2.1e-4; 3.9e-4 / 2.1e-3 with the bf16 decoder of round 3)
+    assert out["planted-self"]["dlogp_vs_fp32"] <= 1e-4, out
+    assert out["planted-oracle"]["dlogp_vs_fp32"] <= 1e-4, out
+    assert out["planted-tilted"]["dlogp_vs_fp32"] <= 1e-3, out
+    # the near-uniform seeded head (log P ~ -10.4: every one of 32 128 logits enters the normaliser): what is left is the bf16
+    # operand noise of the vision tower and the encoder (profiles/r4_error_attribution.md: 1.1e-3 + 0.6e-3 at XL).  Measured
+    # 1.0e-3 (XL) / 1.4e-3 (XXL); gate = 3 x that, and never more than 3 x what the same arithmetic shows on the CPU + 1e-3
+    if "random-head" in out:
+        o = out["random-head"]
+        assert o["dlogp_vs_fp32"] <= min(4.5e-3, 3.0 * o["rounding_matched_vs_fp32"] + 1e-3), out
+    assert rel <= 0.02, rel
 
 
 def test_xl_one_pair_three_way_random_and_peaked_head(xl):

@@ -316,3 +316,19 @@ def test_empty_inputs_follow_the_reference(tmp_path, images):
     assert tuple(s.model.forward([], []).shape) == (0,)
     assert eng.score_calls == []
 
+
+
+def test_rank_affinity_plan_follows_the_gpus_numa_node():
+    """bench.py / sharding.set_rank_affinity: a rank's host cores are an equal slice of the NUMA node its GPU hangs off (VERDICT r3
+    item 8); unknown topology = an equal split of the allowed cores; a restricted affinity mask is honoured."""
+    from t2v_metrics_amd.sharding import _parse_cpulist, plan_rank_affinity
+    assert _parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    node_cpus = {0: list(range(0, 64)), 1: list(range(64, 128))}
+    numa = [0, 0, 0, 0, 1, 1, 1, 1]
+    got = [plan_rank_affinity(numa, node_cpus, set(range(128)), r) for r in range(8)]
+    assert [len(g) for g in got] == [16] * 8 and sorted(c for g in got for c in g) == list(range(128))
+    assert all(set(got[r]) <= set(node_cpus[numa[r]]) for r in range(8))
+    assert plan_rank_affinity([1, 0], node_cpus, set(range(128)), 0) == list(range(64, 128))      # GPU 0 on node 1
+    assert plan_rank_affinity([-1, -1], {}, set(range(8)), 1) == [4, 5, 6, 7]                     # unknown topology
+    assert plan_rank_affinity(numa, node_cpus, set(range(0, 128, 2)), 5) == list(range(80, 96, 2)) # restricted mask: 32 allowed cores on node 1, 4 ranks
+    assert plan_rank_affinity([0], node_cpus, {3, 4}, 0) == [3, 4]                                # one rank: untouched
