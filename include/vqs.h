@@ -198,6 +198,12 @@ int vqs_score_head(const float* d_logits, int32_t ldl, int32_t V, const int32_t*
  * (tests/test_gpu_e2e.py).  The library reads NO environment variables.
  *   "cross_mode"   1 (default) reassociated decoder cross-attention, 0 per-layer K|V projection (what HF executes)
  *   "splitk"       1 (default) split-K for the decoder's skinny nn.Linear GEMMs, 0 single GEMMs
+ *   "dec_precise"  1 (default) the scoring decoder holds the activations that matter as split-bf16 / fp32 (16 significant bits
+ *                  into the bf16 MFMA as two stacked row planes, fp32 partial sums: round 4), 0 the bf16 decoder
+ *                  of rounds 1-3 (vqs_generate always runs that one)
+ *   "stream_gemm"  1 (default) skinny batched GEMMs (<= 128 rows per entry: the reassociated cross-attention's two products over
+ *                  the encoder output) run the HBM-streaming form (csrc/gemm_stream.inc), 0 the persistent 256-row kernel;
+ *                  bitwise equal
  *   "norm_defer"   1 (default) deferred store of the fp32 stream in the norm kernels (bitwise equal), 0 store in every norm
  *   "fused_norm"   0 (default) separate add+norm kernels, 1 residual update + RMSNorm operand in the o / wo GEMM epilogues
  *   "gemm_variant" 3 (default) the quad form (four waves of 128x128, 16x16x32 MFMAs; csrc/gemm_quad.inc) for every bf16-result

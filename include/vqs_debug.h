@@ -29,12 +29,20 @@ int vqs_debug_heads_rows(int32_t row0, int32_t S, int32_t hx, int32_t hdim, int3
 int vqs_debug_tile_order(int32_t M, int32_t N, int32_t K, int32_t batch, int32_t gm, int32_t ns, int32_t grid, int32_t* out);
 /* Host-side test hook, no device access: the kernel family a vqs_gemm launch of this shape resolves to, by the launcher's own
  * function (gemm.hip gemm_form): 10 = the quad form (four waves, 16x16x32 MFMAs; operand offsets relative to the output tile, no
- * size limit), 3 = an 8-wave persistent kernel (32-bit byte offsets into a batch entry's operands), 0 = one tile per workgroup
+ * size limit), 3 = an 8-wave persistent kernel (32-bit byte offsets into a batch entry's operands), 12 = the stream form (<= 128 rows
+ * per batch entry, W streamed from HBM; bitwise the results of 3: one family), 0 = one tile per workgroup
  * (64-bit pointers), -1 = not launchable.  Two properties the tests pin: the form of a bf16-result launch is a function of the
  * epilogue and the WEIGHT's shape only, never of M (a pair's bits must not depend on its batch), and an operand of 4 GiB or more
  * per batch entry never reaches a 32-bit kernel (it falls back to family 0 where that computes the same function, else -1). */
 int vqs_debug_gemm_form(int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t epilogue, int32_t batch, int32_t variant,
                         int32_t S, int32_t inner, int32_t inner_kv);
+/* Device-side test hook: the batched form of vqs_gemm that the engine's decoder launches (entry z reads A + z*sA, W + z*sW and
+ * writes C + z*sC, strides in elements; EPI_F32 or EPI_BF16 only), with the split-bf16 result store (split_off != 0: the lo plane
+ * bf16(acc - hi) goes to C + split_off) and no_stream = 1 keeping the launch off the stream form (csrc/gemm_stream.inc).  The
+ * per-kernel tests hold the stream form against the persistent kernel and against per-entry one-tile launches, bitwise. */
+int vqs_debug_gemm_batched(const void* A, const void* W, void* C, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t ldc,
+                           int32_t epilogue, int32_t batch, int64_t sA, int64_t sW, int64_t sC, int64_t split_off, int32_t no_stream,
+                           int32_t variant, void* stream);
 /* Tap window: taps copy only the rows of `count` consecutive outer entries starting at `first` -- pairs for the T5 stacks
  * (rows [first*S, (first+count)*S) of an [B*S, W] tensor, the same fraction of a head-major [B, H, S, 64] or a [B*T, W] one),
  * images for the vision tower (so the window's pairs must reference images first .. first+count-1 in order, as the bench

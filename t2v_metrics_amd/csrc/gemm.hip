@@ -987,6 +987,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) 
 
 
 #include "gemm_quad.inc"
+#include "gemm_stream.inc"
 
 // =====================================================================================================
 // Persistent PING-PONG variant (VAR 5).  Same tile, LDS image, tile map and staged epilogue as the persistent kernel
@@ -1251,7 +1252,8 @@ int gemm_form(const GemmParams& p, int epilogue, int variant) {
                           p.batch <= 1 && epilogue != EPI_RESID_RMS;
     if (variant == 0 || variant == 2 || variant == 1) return plain_v0 ? 0 : -1;
     if (epilogue == EPI_HEADS && p.S < 8) return plain_v0 ? 0 : -1;
-    if ((variant == 3 || variant == 10) && quad_eligible_rt(p, epilogue)) return 10;
+    if ((variant == 3 || variant == 10) && quad_eligible_rt(p, epilogue)) return 10;       // first: a quad call site stays quad for every M
+    if ((variant == 3 || variant == 11) && stream_eligible(p, epilogue)) return 12;         // stream form: bitwise the 8-wave forms (gemm_stream.inc)
     if (epilogue == EPI_HEADS && p.hd_src > 0 && p.hd_src != (p.hd > 0 ? p.hd : 64)) return -1;   // narrow heads in wide slots: quad form only
     if (epilogue == EPI_F32_RESID) return p.batch <= 1 ? 0 : -1;
     const bool fit = (uint64_t)p.M * (uint64_t)p.lda * 2ull < (1ull << 32) && (uint64_t)p.N * (uint64_t)p.ldw * 2ull < (1ull << 32);
@@ -1281,7 +1283,12 @@ static hipError_t launch_epi(const GemmParams& p, int variant, hipStream_t strea
         hipLaunchKernelGGL((gemm_bf16_kernel<EPI, 0>), grid, block, 0, stream, p);
     else if (variant == 2)
         hipLaunchKernelGGL((gemm_bf16_kernel<EPI, 2>), grid, block, 0, stream, p);
-    else if (form == 10) {
+    else if (form == 12) {
+        if constexpr (EPI == EPI_F32 || EPI == EPI_BF16) {
+            const int items = ((p.N + 127) / 128) * (p.batch > 0 ? p.batch : 1);
+            hipLaunchKernelGGL((gemm_bf16_stream<EPI>), dim3(items), dim3(256), 0, stream, p);
+        }
+    } else if (form == 10) {
         // quad form (gemm_quad.inc): every bf16-result launch of a call site, WHATEVER its M -- the form's k-order differs from the
         // 8-wave forms' in the last ulp, so a weight must not change form with the batch size (a pair's bits are batch-invariant)
         if constexpr (EPI == EPI_BF16 || EPI == EPI_BF16_QGELU || EPI == EPI_BF16_GELU || EPI == EPI_GATED || EPI == EPI_HEADS) {

@@ -44,6 +44,7 @@ struct vqs_handle {
     const bf16_t* patch_w = nullptr;
     std::vector<const bf16_t*> vit_qkv_w, vit_qkv_b, enc_qkv, enc_wi, dec_qkv, dec_ckv, dec_wi, dec_ckT;
     int cross_mode = 1;   // 1 = reassociated cross-attention (default), 0 = per-layer K|V projection of the encoder output
+    int stream_gemm = 1;  // 1 = skinny batched launches (M <= 128 rows per entry) take the HBM-streaming GEMM form (gemm_stream.inc; bitwise the 8-wave forms), 0 = never
     int dec_precise = 1;  // 1 = the scoring decoder holds its activations as split-bf16 / fp32 (decoder_pass_precise), 0 = bf16 (rounds 1-3)
     const int* lut_bidir = nullptr;
     const int* lut_causal = nullptr;
@@ -312,6 +313,7 @@ int run_gemm(vqs_handle* h, const GemmCall& g, hipStream_t st, const char* what)
         if (t.N == g.N && t.K == g.K) { p.tile_gm = t.gm; p.tile_ns = t.ns; }
     p.nt_store = g.nt_store;
     p.split_off = g.split_off;
+    p.no_stream = h->stream_gemm ? 0 : 1;
     for (const vqs_handle::NtStore& t : h->l2_touches)
         if (t.N == g.N && t.K == g.K && g.M >= 4096) p.l2_touch = t.on;
     for (const vqs_handle::NtStore& t : h->nt_stores)
@@ -418,6 +420,19 @@ int vqs_debug_gemm_form(int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ld
     return vqs::gemm_form(p, epilogue, variant & 0xff);
 }
 
+int vqs_debug_gemm_batched(const void* A, const void* W, void* C, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t ldc,
+                           int32_t epilogue, int32_t batch, int64_t sA, int64_t sW, int64_t sC, int64_t split_off, int32_t no_stream,
+                           int32_t variant, void* stream) {
+    if (!A || !W || !C || (epilogue != vqs::EPI_F32 && epilogue != vqs::EPI_BF16) || batch < 1) return VQS_ERR_INVALID;
+    vqs::GemmParams p{};
+    p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.C = C; p.bias = nullptr; p.resid = nullptr;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc;
+    p.S = 1; p.H = 0; p.inner = 1;
+    p.batch = batch; p.sA = sA; p.sW = sW; p.sC = sC;
+    p.split_off = split_off; p.no_stream = no_stream;
+    return vqs::launch_gemm(p, epilogue, variant & 0xff, (hipStream_t)stream) == hipSuccess ? VQS_OK : VQS_ERR_HIP;
+}
+
 int vqs_debug_heads_rows(int32_t row0, int32_t S, int32_t hx, int32_t hdim, int32_t n, int64_t* off_out) {
     if (row0 < 0 || S < 8 || hx <= 0 || hdim <= 0 || n <= 0 || !off_out) return VQS_ERR_INVALID;
     int hs;
@@ -517,6 +532,7 @@ int vqs_set_option(vqs_handle* h, const char* name, int32_t value) {
     else if (n == "fused_norm" && (value == 0 || value == 1)) h->fused_norm = value;
     else if (n == "norm_defer" && (value == 0 || value == 1)) h->norm_defer = value;
     else if (n == "dec_precise" && (value == 0 || value == 1)) h->dec_precise = value;
+    else if (n == "stream_gemm" && (value == 0 || value == 1)) h->stream_gemm = value;
     else if (n == "gemm_variant" && (value == 0 || value == 2 || value == 3 || value == 5 || value == 11)) h->gemm_variant = value;
     else if (n.rfind("l2_touch:", 0) == 0 || n.rfind("nt_store:", 0) == 0 || n.rfind("tile_order:", 0) == 0) {
         // per weight shape [N, K], for the big launches of a pass; 0 removes the entry = the library's choice.  All three are

@@ -52,6 +52,7 @@ struct GemmParams {
     // lo = bf16(acc - hi) at C + split_off (elements; 0 = off).  hi + lo carries 16 significant bits of the fp32 accumulator;
     // the consumer stacks the two planes as rows of one GEMM and adds the two fp32 results (the precise decoder, vqs_api.cpp).
     long long split_off = 0;
+    int no_stream = 0;       // 1: never the stream form (gemm_stream.inc) -- A/B switch; results are bitwise the same either way
     int l2_touch = 0;        // lock-step persistent kernel: L2 prefetch of the A panel two K-tiles ahead; 0 = by shape (gemm.hip), 1 on, 2 off (a hint)
     int nt_store = 0;        // persistent kernels: result rows leave with the non-temporal hint (same bytes; a cache-policy hint)
     // EPI_RESID_RMS (producer side of the fused residual + RMSNorm)

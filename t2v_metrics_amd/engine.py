@@ -73,6 +73,7 @@ _SIGNATURES = {
     "vqs_debug_tap": (_c_i32, [_c_vp, ctypes.c_char_p, _c_vp, ctypes.c_size_t]),
     "vqs_debug_tap_window": (_c_i32, [_c_vp, _c_i32, _c_i32]),
     "vqs_debug_gemm_form": (_c_i32, [_c_i32] * 11),
+    "vqs_debug_gemm_batched": (_c_i32, [_c_vp, _c_vp, _c_vp] + [_c_i32] * 8 + [_c_i64] * 4 + [_c_i32, _c_i32, _c_vp]),
     "vqs_debug_heads_rows": (_c_i32, [_c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_vp]),
     "vqs_debug_tile_order": (_c_i32, [_c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_vp]),
     "vqs_relpos_bucket": (_c_i32, [_c_i32, _c_i32, _c_i32, _c_i32]),
@@ -361,6 +362,23 @@ def gemm(A, W, epilogue: int, bias=None, resid=None, out=None, S: int = 0, H: in
     if rc != 0:
         raise VqsError(f"vqs_gemm failed ({rc})")
     return out
+
+
+def gemm_batched(A, W, epilogue: int, split: bool = False, no_stream: bool = False, variant: int = 3, ldc: int = None):
+    """Test hook (vqs_debug_gemm_batched): C[z] = A[z] @ W[z].T for A [Z, M, K] bf16 (any row stride), W [Z, N, K] bf16, epilogue 3
+    (fp32) or 0 (bf16; split=True also returns the lo plane of the split-bf16 result).  -> C [Z, M, ldc] (and lo)."""
+    lib = load_library()
+    Z, M, K = A.shape
+    N = W.shape[1]
+    ldc = N if ldc is None else ldc
+    dt = torch.float32 if epilogue == 3 else torch.bfloat16
+    out = torch.zeros((2 if split else 1), Z, M, ldc, dtype=dt, device=A.device)
+    rc = lib.vqs_debug_gemm_batched(A.data_ptr(), W.data_ptr(), out.data_ptr(), M, N, K, A.stride(1), W.stride(1), ldc, epilogue, Z,
+                                    A.stride(0), W.stride(0), M * ldc, (Z * M * ldc) if split else 0, 1 if no_stream else 0, variant,
+                                    _stream_ptr())
+    if rc != 0:
+        raise VqsError(f"vqs_debug_gemm_batched failed ({rc})")
+    return (out[0], out[1]) if split else out[0]
 
 
 def gemm_resid_rms(A, W, hres, lnw, variant: int = 3):

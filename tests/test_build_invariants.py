@@ -102,7 +102,7 @@ def test_gemm_kernels_own_the_cu():
     variants that have one, + 32 KiB of epilogue scratch in the quad form = all 160 KiB) leave no room for a second, and the
     persistent grid is sized for that.  The 8-wave forms are 512 threads (two waves per SIMD, <= 256 registers per lane); the
     quad form is 256 threads -- ONE wave per SIMD, whose 256 fp32 accumulators per lane are the whole AGPR file."""
-    quad = 0
+    quad = stream = 0
     ks = _kernels("gemm.hip")
     for name, k in ks.items():
         if name == "__asm__" or "gemm_bf16" not in name:
@@ -111,10 +111,15 @@ def test_gemm_kernels_own_the_cu():
         if "gemm_bf16_quad" in name:
             quad += 1
             assert k["lds"] == 2 * 65536 + 32768 and k["wg"] == 256 and k["vgpr"] <= 512, (name, k)
+        elif "gemm_bf16_stream" in name:
+            # stream form (round 4): five 32-KiB slab stages = all 160 KiB, four waves, no scratch
+            stream += 1
+            assert k["lds"] == 5 * 32768 and k["wg"] == 256 and k["scratch"] == 0, (name, k)
         else:
             assert 2 * 65536 <= k["lds"] <= 2 * 65536 + 8192, (name, k)
             assert k["wg"] == 512, (name, k)
     assert quad == 5, "quad form: epilogues bf16, quick_gelu, erf-GELU, gated, head-major"
+    assert stream == 2, "stream form: fp32 and bf16 (+ split) results"
 
 
 def test_quad_form_keeps_the_compiler_out_of_its_accumulators():

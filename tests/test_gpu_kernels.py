@@ -121,6 +121,37 @@ def test_gemm_quad_form_is_bitwise_the_other_forms(eng, M, N, K, epi, S, H):
         assert_close(out, full, 2e-2, 1e-2, "quad form vs fp32")
 
 
+@pytest.mark.parametrize("Z,M,N,K,epi", [(256, 128, 608, 256, 3), (256, 128, 512, 640, 0), (300, 64, 96, 64, 3), (200, 100, 260, 192, 0),
+                                         (1, 128, 24576 + 132, 128, 3), (1500, 33, 40, 320, 0), (40, 128, 4096, 128, 0)])
+def test_gemm_stream_form_is_bitwise_the_persistent_kernel(eng, Z, M, N, K, epi):
+    """gemm_stream.inc (<= 128 rows per batch entry, W streamed through a five-stage LDS ring) against the 256-row persistent kernel
+    on the same batched launch (option no_stream) and against one-tile-per-workgroup launches entry by entry: torch.equal -- same
+    MFMA, operand roles, k order.  Ragged M / N, a single K slab, fewer slabs than ring stages, the split-bf16 store (hi + lo of the
+    fp32 accumulator), a result pitch wider than N; every launch's form is checked through the launcher's own host function."""
+    from t2v_metrics_amd.engine import load_library
+    g = torch.Generator(device="cuda").manual_seed(97)
+    A = torch.randn(Z, M, K, device="cuda", generator=g).to(torch.bfloat16)
+    W = (torch.randn(Z, N, K, device="cuda", generator=g) * K ** -0.5).to(torch.bfloat16)
+    lib = load_library()
+    assert lib.vqs_debug_gemm_form(M, N, K, K, K, epi, Z, 3, 0, 0, 0) == 12, "this shape must take the stream form"
+    ldc = ((N + 63) // 64) * 64
+    split = epi == 0
+    got = eng.gemm_batched(A, W, epi, split=split, ldc=ldc)
+    ref = eng.gemm_batched(A, W, epi, split=split, ldc=ldc, no_stream=True)
+    for a, b in zip(got if split else (got,), ref if split else (ref,)):
+        assert torch.equal(a[..., :N], b[..., :N]), f"stream vs persistent {Z}x{M}x{N}x{K} epi {epi}: {(a[..., :N].float() - b[..., :N].float()).abs().max().item()}"
+        assert float(a[..., N:].abs().max()) == 0.0 if ldc > N else True          # nothing written beyond N
+    hi = got[0] if split else got
+    for z in (0, Z // 2, Z - 1):
+        one = eng.gemm(A[z], W[z], epi, variant=0)
+        assert torch.equal(hi[z, :, :N], one), f"entry {z} vs the one-tile kernel"
+    if split:                                                                    # hi + lo carries 16 bits of the fp32 accumulator
+        acc = eng.gemm_batched(A, W, 3, ldc=ldc)
+        two = got[0].float() + got[1].float()
+        rel = ((two - acc)[..., :N].abs() / acc[..., :N].abs().clamp(min=1e-3)).max().item()
+        assert rel <= 2.0 ** -15, rel
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 512, 128), (1000, 768, 256), (70000, 512, 64)])
 @pytest.mark.parametrize("variant", [3, 5])
 def test_gemm_fused_residual_rmsnorm(eng, M, N, K, variant):

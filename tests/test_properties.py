@@ -265,9 +265,25 @@ def test_gemm_form_depends_on_the_weight_never_on_the_row_count(M, shape):
     the kernel family of a call site is a function of the epilogue and the weight's shape -- for every M the same."""
     N, K, epi = shape
     S, inner = (608, N // 3) if epi == 6 else (0, 0)
-    f = _form(M, N, K, epi, S=S, inner=inner)
-    assert f == _form(7, N, K, epi, S=S, inner=inner) == _form(155648, N, K, epi, S=S, inner=inner)
+    # 3 (persistent 8-wave) and 12 (stream form, round 4: few rows, many columns) produce the same bits -- one family; what must
+    # not move with M is membership in the quad form (10), whose summation order differs
+    fam = lambda f: 3 if f == 12 else f
+    f = fam(_form(M, N, K, epi, S=S, inner=inner))
+    assert f == fam(_form(7, N, K, epi, S=S, inner=inner)) == fam(_form(155648, N, K, epi, S=S, inner=inner))
     assert f == (10 if epi in (0, 1, 2, 5, 6) and K >= 128 else 3)
+
+
+def test_stream_form_takes_skinny_launches_with_many_columns_only():
+    """gemm_stream.inc: <= 128 rows per batch entry, >= 192 (entry, 128-column) items, plain fp32 / bf16 results that are not quad call
+    sites; everything else keeps its kernel."""
+    assert _form(128, 608, 4096, 3, batch=256) == 12          # cross scores at the bench batch: 5 x 256 items
+    assert _form(128, 4096, 640, 0, batch=256) == 12          # cross P.E (bf16 result, batched: never a quad launch)
+    assert _form(128, 608, 4096, 3, batch=16) == 3            # 80 items: the persistent kernel
+    assert _form(129, 608, 4096, 3, batch=256) == 3           # more rows than the form holds
+    assert _form(64, 152064, 3584, 3) == 12                   # a decode step's lm_head
+    assert _form(64, 32768, 4096, 0) == 10                    # a bf16-result nn.Linear is a quad call site for EVERY M
+    assert _form(64, 32768, 4096, 0, variant=11) == 12        # under the 8-wave rule the same launch may stream (same bits as 3)
+    assert _form(128, 32768, 4096, 5) == 10 and _form(128, 32768, 4096, 3, variant=0) == 0
 
 
 def test_gemm_operands_of_4_gib_never_reach_a_32_bit_kernel():
