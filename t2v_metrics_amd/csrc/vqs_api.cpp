@@ -298,6 +298,7 @@ struct GemmCall {
     float rs_invd = 0.0f, rs_eps = 0.0f;
     int nt_store = 0;          // result rows leave with the non-temporal hint (call sites whose multi-GB output is streamed once)
     long long split_off = 0;   // EPI_BF16: also store the lo plane of a split-bf16 result at C + split_off (vqs_kernels.h)
+    int no_stream = 0;         // 1: keep this launch off the stream form (same bits either way)
 };
 
 int run_gemm(vqs_handle* h, const GemmCall& g, hipStream_t st, const char* what) {
@@ -313,7 +314,7 @@ int run_gemm(vqs_handle* h, const GemmCall& g, hipStream_t st, const char* what)
         if (t.N == g.N && t.K == g.K) { p.tile_gm = t.gm; p.tile_ns = t.ns; }
     p.nt_store = g.nt_store;
     p.split_off = g.split_off;
-    p.no_stream = h->stream_gemm ? 0 : 1;
+    p.no_stream = (h->stream_gemm && !g.no_stream) ? 0 : 1;
     for (const vqs_handle::NtStore& t : h->l2_touches)
         if (t.N == g.N && t.K == g.K && g.M >= 4096) p.l2_touch = t.on;
     for (const vqs_handle::NtStore& t : h->nt_stores)
@@ -1070,7 +1071,9 @@ static int decoder_pass(vqs_handle* h, const ScoreWs& w, const int32_t* d_labels
                 GemmCall g{w.cprobs, w.enc_outT, w.cctx};
                 g.M = R; g.N = D; g.K = w.S_pad; g.lda = w.S_pad; g.ldw = w.S_pad; g.ldc = D; g.epi = vqs::EPI_BF16;
                 g.batch = B; g.sA = (long long)R * w.S_pad; g.sW = (long long)D * w.S_pad; g.sC = (long long)R * D;
-                RUN(run_gemm(h, g, st, "cross P.E"));
+                g.no_stream = 1;      // K = S_pad = 640: ten slabs per item -- the stream form's pipeline fill per item costs more than its
+                                  // deeper ring gains (0.50 vs 0.41 ms per launch, profiles/r4_call4_*); the scores launch (K = D) streams
+            RUN(run_gemm(h, g, st, "cross P.E"));
                 TAP("dec", i, "cctx", w.cctx, (size_t)MT * H * D);
             }
             {   // out[(b,t), h*64:(h+1)*64] = ctx[(b,t), h, :] . Wv_h^T          batched over heads
@@ -1185,6 +1188,8 @@ static int decoder_pass_precise(vqs_handle* h, const ScoreWs& w, const int32_t* 
             g.M = R; g.N = D; g.K = w.S_pad; g.lda = w.S_pad; g.ldw = w.S_pad; g.ldc = D; g.epi = vqs::EPI_BF16;
             g.batch = B; g.sA = (long long)R * w.S_pad; g.sW = (long long)D * w.S_pad; g.sC = (long long)R * D;
             g.split_off = pC;
+            g.no_stream = 1;      // K = S_pad = 640: ten slabs per item -- the stream form's pipeline fill per item costs more than its
+                                  // deeper ring gains (0.50 vs 0.41 ms per launch, profiles/r4_call4_*); the scores launch (K = D) streams
             RUN(run_gemm(h, g, st, "cross P.E"));
             TAP2("dec", i, "cctx", w.cctx, pC);
         }
