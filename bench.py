@@ -167,8 +167,9 @@ ALSO_LEGS = {
                   "configs[2]: clip-flant5-xxl, GenAI-Bench-1600 stand-in, 6 of its 38 length buckets"),
     "qwen": (["bench.py", "--model", "qwen2.5-vl-7b", "--steps", "3", "--warmup", "1", "--cpu-pairs", "0", "--also", "none"],
              "configs[4]: qwen2.5-vl-7b, 8-frame video samples"),
-    "pipeline": (["tools/bench_pipeline.py", "--model", "clip-flant5-xxl", "--pairs", "512", "--reps", "1"],
-                 "SURVEY 8f-1: VQAScoreModel.forward from 512x512 PNG files (decode, preprocessing, H2D, tokenisation, engine)"),
+    "pipeline": (["tools/bench_pipeline.py", "--model", "clip-flant5-xxl", "--pairs", "1280", "--reps", "1", "--host-slice", "8"],
+                 "SURVEY 8f-1: VQAScoreModel.forward from 512x512 PNG files (decode, preprocessing, H2D, tokenisation, engine) on 1/8 of the "
+                 "host's cores -- a rank's share at 8 GPUs per node"),
 }
 
 
@@ -193,7 +194,7 @@ def run_also_leg(name):
     if isinstance(j.get("roofline"), dict):
         out["roofline_frac"] = j["roofline"].get("frac")
         out["roofline_achieved_tflops"] = j["roofline"].get("achieved")
-    for k in ("model_frac_of_mfma_peak", "host_preprocess_256_images_s", "workers", "pairs", "png_edge"):
+    for k in ("model_frac_of_mfma_peak", "host_preprocess_256_images_s", "workers", "pairs", "png_edge", "image_workers", "host_threads_allowed"):
         if k in j:
             out[k] = j[k]
     return out
@@ -586,7 +587,8 @@ def run_config0():
 
 
 PARITY_GAINS = (1.0, 4.0)          # lm_head x gain: 1 = the seeded head (log P ~ -10), 4 = the peaked-head regime (the head is linear: re-read)
-DLOGP_BOUND = 1.0e-2               # end-to-end |delta log P| bound on the bench sample at gain 1 (3 x the measured 3e-3, profiles/r4_*)
+DLOGP_BOUND = 4.5e-3               # end-to-end |delta log P| bound on the bench sample at gain 1: 3 x the measured 1.45e-3 max over 16 XXL pairs
+                                   # (profiles/r4_call5_*; mean 7.0e-4; round 3's bf16 decoder: 2.6e-3 .. 9.0e-3, gate 2.5e-2)
 
 
 def parity_sample(cfg, weights, eng, job, n_pairs):

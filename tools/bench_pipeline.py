@@ -31,16 +31,35 @@ def main():
     ap.add_argument("--workers", type=int, default=None)
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--image-workers", default="process", choices=["process", "thread"], help="decode workers: processes (default) or the GIL-sharing thread pool of rounds 1-3")
+    ap.add_argument("--host-slice", type=int, default=0, help="N > 1: run on 1/N of the host (what a rank gets at N GPUs per node): the first "
+                    "cores/N physical cores of NUMA node 0 with their SMT siblings (sched_setaffinity before anything starts)")
     args = ap.parse_args()
+    if args.host_slice > 1:
+        from t2v_metrics_amd.sharding import _parse_cpulist
+        node0 = _parse_cpulist(open("/sys/devices/system/node/node0/cpulist").read()) if os.path.exists("/sys/devices/system/node/node0/cpulist") else sorted(os.sched_getaffinity(0))
+        cores = {}
+        for c in node0:
+            try:
+                sib = tuple(_parse_cpulist(open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read()))
+            except OSError:
+                sib = (c,)
+            cores.setdefault(min(sib), sib)
+        total_cores = (os.cpu_count() or len(node0)) // max(1, len(next(iter(cores.values()))))
+        take = max(1, total_cores // args.host_slice)
+        mine = sorted(c for k in sorted(cores)[:take] for c in cores[k])
+        os.sched_setaffinity(0, mine)
+        torch.set_num_threads(max(1, len(mine) // 2))
     tmp = tempfile.mkdtemp(prefix="vqs_imgs_")
     rng = np.random.RandomState(0)
     base = rng.randint(0, 256, (args.size // 8, args.size // 8, 3), dtype=np.uint8)
-    paths = []
-    for i in range(args.pairs):          # smooth-ish images (upsampled noise + per-image offset): realistic PNG sizes
+    def make(i):                         # smooth-ish images (upsampled noise + per-image offset): realistic PNG sizes
         im = Image.fromarray(np.roll(base, i, axis=0)).resize((args.size, args.size + (i % 3) * 16), Image.BILINEAR)
         p = os.path.join(tmp, f"im{i:05d}.png")
-        im.save(p)
-        paths.append(p)
+        im.save(p, compress_level=1)
+        return p
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(32, len(os.sched_getaffinity(0)))) as ex:
+        paths = list(ex.map(make, range(args.pairs)))
     texts = [f"a photo number {i} of someone doing something in place {i % 17}" for i in range(args.pairs)]
     from t2v_metrics_amd.config import get_config
     cfg = get_config(args.model)
