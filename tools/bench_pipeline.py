@@ -55,7 +55,7 @@ def main():
     def make(i):                         # smooth-ish images (upsampled noise + per-image offset): realistic PNG sizes
         im = Image.fromarray(np.roll(base, i, axis=0)).resize((args.size, args.size + (i % 3) * 16), Image.BILINEAR)
         p = os.path.join(tmp, f"im{i:05d}.png")
-        im.save(p, compress_level=1)
+        im.save(p)
         return p
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=min(32, len(os.sched_getaffinity(0)))) as ex:
