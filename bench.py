@@ -194,7 +194,8 @@ def run_also_leg(name):
     if isinstance(j.get("roofline"), dict):
         out["roofline_frac"] = j["roofline"].get("frac")
         out["roofline_achieved_tflops"] = j["roofline"].get("achieved")
-    for k in ("model_frac_of_mfma_peak", "host_preprocess_256_images_s", "workers", "pairs", "png_edge", "image_workers", "host_threads_allowed"):
+    for k in ("model_frac_of_mfma_peak", "host_preprocess_256_images_s", "workers", "pairs", "png_edge", "image_workers", "host_threads_allowed",
+              "engine_only_same_inputs_pairs_per_s", "ratio_to_engine_only_same_inputs", "encoder_len_first_batch"):
         if k in j:
             out[k] = j[k]
     return out

@@ -80,7 +80,35 @@ def main():
         sc = m.forward(paths, texts)
         torch.cuda.synchronize()
         best = min(best, time.perf_counter() - t0)
-    print(json.dumps({"metric": "pairs/s through VQAScoreModel.forward incl. PNG decode, preprocessing, H2D, tokenisation",
+    # where a step's time goes: the same call once more with the library's per-launch HIP events on (GEMM launches only) and the
+    # prompt lengths the tokenizer produced (the engine computes over 575 + L positions per pair)
+    diag = {}
+    if hasattr(m.engine, "profile"):
+        from t2v_metrics_amd.models.vqascore_models.clip_t5_model import default_question_template
+        ids, _ = m.tokenize([default_question_template.format(t) for t in texts[:256]], ["Yes"] * 256)
+        m.engine.profile(True)
+        m.engine.profile_read(reset=True)
+        t0 = time.perf_counter()
+        m.forward(paths, texts)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        m.engine.profile(False)
+        n_gemm, gemm_ms, gemm_flops = m.engine.profile_read(reset=True)
+        # the engine alone on the SAME inputs (pixels resident, same prompt lengths): the rate the pipeline can at best deliver
+        px = m.load_images(paths[:256])
+        ids_d, lab_d = m.tokenize([default_question_template.format(t) for t in texts[:256]], ["Yes"] * 256)
+        idx_d = torch.arange(256, dtype=torch.int32)
+        for _ in range(1):
+            m.engine.score(m.engine.encode_images(px), idx_d, ids_d, lab_d)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            m.engine.score(m.engine.encode_images(px), idx_d, ids_d, lab_d)
+        torch.cuda.synchronize()
+        eng_only = 3 * 256 / (time.perf_counter() - t0)
+        diag = {"profiled_call_wall_s": wall, "engine_only_same_inputs_pairs_per_s": eng_only, "ratio_to_engine_only_same_inputs": (args.pairs / best) / eng_only, "gemm_ms_per_256_pairs": gemm_ms * 256 / args.pairs, "gemm_tflops": gemm_flops / max(gemm_ms, 1e-9) / 1e9,
+                "prompt_ids_per_pair_first_batch": int(ids.shape[1]), "encoder_len_first_batch": int(ids.shape[1]) - 1 + cfg.vision.n_patches}
+    print(json.dumps({"metric": "pairs/s through VQAScoreModel.forward incl. PNG decode, preprocessing, H2D, tokenisation", **diag,
                       "value": args.pairs / best, "pairs": args.pairs, "png_edge": args.size, "model": args.model,
                       "workers": m.num_workers, "image_workers": args.image_workers, "host_cpus": os.cpu_count(),
                       "host_threads_allowed": len(os.sched_getaffinity(0)),

@@ -94,7 +94,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--gains", default="1,4")
     ap.add_argument("--acc", default="float32", choices=["float32", "float64"])
-    ap.add_argument("--only", default="", help="comma list of run names (default: all runs)")
+    ap.add_argument("--only", default="", help="semicolon-separated run names (default: all runs)")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     import warnings
@@ -118,11 +118,11 @@ def main():
              ("engine minus cheap set", tuple(c for c in ALL if c not in CHEAP)),
              ("engine (all classes)", ALL),
              # round 4's engine: the same classes with the decoder's sensitive tensors split-bf16 / fp32 (EngineRoundedOracle.DEC_SPLIT)
-             ("engine, precise decoder (round 4)", ALL, True),
-             ("stack dec.*, precise decoder (round 4)", tuple(c for c in ALL if stack_of(c) == "dec"), True)]
+             ("engine with the precise decoder (round 4)", ALL, True),
+             ("stack dec.* with the precise decoder (round 4)", tuple(c for c in ALL if stack_of(c) == "dec"), True)]
     runs = [r if len(r) == 3 else (r[0], r[1], False) for r in runs]
     if a.only:
-        keep = set(a.only.split(","))
+        keep = set(a.only.split(";"))
         runs = [r for r in runs if r[0] in keep or r[0].startswith("none")]
     # order: decoder-only sets first (cheapest), vit-touching sets last; drop stage caches a later run cannot reuse
     rank = lambda cl: 2 if any(stack_of(c) in ("vit", "proj") for c in cl) else 1 if any(stack_of(c) == "enc" for c in cl) else 0
