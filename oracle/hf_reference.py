@@ -109,6 +109,7 @@ class HFReference:
         labels = labels.long()
         out = self.tm(inputs_embeds=emb[:, :keep], attention_mask=mask[:, :keep], labels=labels)
         logits = out.logits.float()
+        self.last_logits = logits                            # tools/pin_oracle_fullsize.py compares them with the fp32 oracle's
         safe = labels.clamp(min=0)
         lp = torch.log_softmax(logits, -1).gather(-1, safe[..., None])[..., 0]
         lp = torch.where(labels == -100, torch.zeros_like(lp), lp)
