@@ -27,6 +27,15 @@ int main() {
     assert(vqs_debug_tap_window(h, 3, 2) == 0 && vqs_debug_tap_window(h, 0, 0) == 0 && vqs_debug_tap_window(h, -1, 2) != 0);
     // GEMM form resolution (host arithmetic): the quad form for bf16 results whatever M, the 32-bit kernels refuse >= 4 GiB operands
     assert(vqs_debug_gemm_form(155648, 20480, 4096, 4096, 4096, 5, 1, 3, 0, 0, 0) == 10 && vqs_debug_gemm_form(2, 20480, 4096, 4096, 4096, 5, 1, 3, 0, 0, 0) == 10);
+    // round 4: the stream form's rule (<= 128 rows per entry, >= 192 items, not a quad call site) and the batched debug launch's argument checks
+    assert(vqs_debug_gemm_form(128, 608, 4096, 4096, 4096, 3, 256, 3, 0, 0, 0) == 12 && vqs_debug_gemm_form(128, 608, 4096, 4096, 4096, 3, 16, 3, 0, 0, 0) == 3);
+    assert(vqs_debug_gemm_form(64, 32768, 4096, 4096, 4096, 0, 1, 3, 0, 0, 0) == 10);
+    assert(vqs_debug_gemm_batched(nullptr, nullptr, nullptr, 128, 608, 4096, 4096, 4096, 640, 3, 256, 0, 0, 0, 0, 0, 3, nullptr) == VQS_ERR_INVALID);
+    {
+        int dummy2 = 0;
+        assert(vqs_debug_gemm_batched(&dummy2, &dummy2, &dummy2, 128, 608, 4096, 4096, 4096, 640, 5, 256, 0, 0, 0, 0, 0, 3, nullptr) == VQS_ERR_INVALID);   // gated: not a batched debug epilogue
+        assert(vqs_debug_gemm_batched(&dummy2, &dummy2, &dummy2, 128, 608, 4096, 4096, 4096, 640, 3, 0, 0, 0, 0, 0, 0, 3, nullptr) == VQS_ERR_INVALID);     // batch < 1
+    }
     assert(vqs_debug_gemm_form(400000, 4096, 10240, 10240, 10240, 3, 1, 3, 0, 0, 0) == 0 && vqs_debug_gemm_form(400000, 4096, 10240, 10240, 10240, 3, 2, 3, 0, 0, 0) == -1);
     int64_t ld = 0;
     assert(vqs_workspace_offset(h, "logits", 4, 33, 2, &ld) >= 0 && ld == 32128);
@@ -88,6 +97,10 @@ int main() {
         assert(vqs_qwen_decode(qh, &dummy, &dummy, nullptr, nullptr, 1, 16, &dummy, 1 << 20, nullptr, &dummy, 1 << 20, nullptr) != 0);   // not bound
         assert(vqs_qwen_prefill(qh, &dummy, &dummy, &dummy, &dummy, &dummy, nullptr, nullptr, 1, 16, nullptr, &dummy, 16, nullptr, 0, 16, nullptr) != 0);
         assert(vqs_qwen_prefill(qh, &dummy, &dummy, &dummy, &dummy, &dummy, nullptr, nullptr, 1, 16, nullptr, &dummy, 16, &dummy, 16, 8, nullptr) != 0);   // Lmax < L
+        // a cache longer than the decode kernel can address is refused by the prefill itself, before anything is launched
+        assert(vqs_qwen_prefill(qh, &dummy, &dummy, &dummy, &dummy, &dummy, nullptr, nullptr, 1, 16, nullptr, &dummy, 16, &dummy, (size_t)-1,
+                                VQS_QWEN_MAX_CACHE_POSITIONS + 1, nullptr) == VQS_ERR_INVALID);
+        assert(strstr(vqs_qwen_last_error(qh), "cache positions") != nullptr);
         assert(vqs_qwen_score(qh, &dummy, &dummy, &dummy, &dummy, &dummy, nullptr, nullptr, 1, 16, nullptr, &dummy, 16, nullptr) != 0);
         vqs_qwen_destroy(qh);
         q.t_heads = 27;        // hidden not divisible by heads
