@@ -713,6 +713,59 @@ hipError_t launch_sum_planes(const float* part, int nslices, long long slice_str
     return hipGetLastError();
 }
 
+// Split-K epilogue with the GEMM epilogues' arithmetic, for launches that run as fp32 partials (the Qwen2.5-VL decode step's skinny
+// nn.Linears on the stream form): out bf16 [rows, ld_out] = f(sum_k part[k][r][c] (+ bias[c])), slices summed in index order.
+// gated = 0: f = identity.  gated = 1: the N = 2 F' columns are in the packed gate|up order (blocks of 64 = 32 gate | 32 up columns)
+// and out[r][32 j + w] = SiLU(gate) * up (gemm.hip EPI_GATED, gate_act = 1: x * rcp(1 + exp(-x)), hardware reciprocal).
+template <int GATED>
+__global__ void __launch_bounds__(256) reduce_slices_act_kernel(const float* __restrict__ part, int nslices, long long slice_stride, int rows,
+                                                                int cols4, int ldp, const bf16_t* __restrict__ bias, bf16_t* __restrict__ out,
+                                                                int ld_out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)rows * cols4) return;
+    const int r = (int)(i / cols4), c4 = (int)(i - (long long)r * cols4);
+    auto gather = [&](int col) {
+        const float* ph = part + (size_t)r * ldp + col;
+        float4 a = *reinterpret_cast<const float4*>(ph);
+        for (int k = 1; k < nslices; ++k) {
+            const float4 u = *reinterpret_cast<const float4*>(ph + (size_t)k * slice_stride);
+            a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+        }
+        if (bias != nullptr) {
+            const float4 b = bf4_to_f4(*reinterpret_cast<const uint2*>(bias + col));
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        return a;
+    };
+    const int oc = c4 * 4;
+    float4 y;
+    if (GATED) {
+        const int gc = (oc >> 5) * 64 + (oc & 31);
+        const float4 g = gather(gc), u = gather(gc + 32);
+        auto silu = [](float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); };
+        y = make_float4(silu(g.x) * u.x, silu(g.y) * u.y, silu(g.z) * u.z, silu(g.w) * u.w);
+    } else {
+        y = gather(oc);
+    }
+    uint2 o;
+    o.x = e_pack2_hw(y.x, y.y);
+    o.y = e_pack2_hw(y.z, y.w);
+    *reinterpret_cast<uint2*>(out + (size_t)r * ld_out + oc) = o;
+}
+
+hipError_t launch_reduce_slices_act(const float* part, int nslices, long long slice_stride, int rows, int cols, int ldp, const bf16_t* bias,
+                                    int gated, bf16_t* out, int ld_out, hipStream_t s) {
+    if (rows <= 0 || cols <= 0 || nslices <= 0 || (ldp % 4) != 0 || (ld_out % 4) != 0 || (slice_stride % 4) != 0) return hipErrorInvalidValue;
+    const int out_cols = gated ? cols / 2 : cols;
+    if ((out_cols % 4) != 0 || (gated && (cols % 64) != 0)) return hipErrorInvalidValue;
+    const int cols4 = out_cols / 4;
+    const long long n = (long long)rows * cols4;
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (gated) hipLaunchKernelGGL((reduce_slices_act_kernel<1>), grid, block, 0, s, part, nslices, slice_stride, rows, cols4, ldp, bias, out, ld_out);
+    else hipLaunchKernelGGL((reduce_slices_act_kernel<0>), grid, block, 0, s, part, nslices, slice_stride, rows, cols4, ldp, bias, out, ld_out);
+    return hipGetLastError();
+}
+
 // Greedy step of vqs_generate: tokens[b, T-1] = argmax_v logits[(b*T + T-1), v] (lowest index on ties, as torch.argmax)
 __global__ void __launch_bounds__(256) argmax_append_kernel(const float* __restrict__ logits, int ldl, int V,
                                                             int* __restrict__ tokens, int ld_tokens, int T, int dst_col) {

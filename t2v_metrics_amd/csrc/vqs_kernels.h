@@ -257,6 +257,9 @@ hipError_t launch_rmsnorm_split(float* x, const float* delta, const bf16_t* w, b
 // mode 0: out fp32 [rows, ld_out] = y;  mode 1: out = split(y), planes [rows, cols] at out and out + out_plane (ld_out = cols);
 // mode 2: cols = 2F in the packed wi order (blocks of 32 gate | 32 linear columns): out = split(gelu_new(gate) * linear), [rows, F] planes
 enum SumPlanesMode : int { SUM_F32 = 0, SUM_SPLIT = 1, SUM_GATED_SPLIT = 2 };
+// out bf16 [rows, ld_out] = f(sum of fp32 partial slices (+ bias)); gated: packed gate|up columns -> SiLU(gate) * up  (elementwise.hip)
+hipError_t launch_reduce_slices_act(const float* part, int nslices, long long slice_stride, int rows, int cols, int ldp, const bf16_t* bias,
+                                    int gated, bf16_t* out, int ld_out, hipStream_t s);
 hipError_t launch_sum_planes(const float* part, int nslices, long long slice_stride, int rows, int cols, int ldp, int mode, void* out,
                              int ld_out, long long out_plane, hipStream_t s);
 // argmax of logits row (b*T + T-1) -> tokens[b, dst_col] (dst_col < 0: T-1)

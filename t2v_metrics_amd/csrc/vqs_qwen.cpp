@@ -734,6 +734,8 @@ struct DecWs {
     float* hidden;
     bf16_t *xn, *delta, *delta2, *qkv, *q, *attn, *ff;
     int* neg1;
+    float* part;              // fp32 partials of one decode nn.Linear: [K slices][B][N]
+    size_t part_bytes;
     size_t total;
 };
 DecWs carve_decode(const vqs_qwen_handle* h, char* base, int B) {
@@ -750,8 +752,59 @@ DecWs carve_decode(const vqs_qwen_handle* h, char* base, int B) {
     w.attn = cv.take<bf16_t>(b * h->t_iq);
     w.ff = cv.take<bf16_t>(b * h->t_ffld);
     w.neg1 = cv.take<int>(b);
+    {   // widest partial set: 16 K-slices of the narrow launches (qkv / o / down) or one slice of gate|up
+        size_t widest = 16 * (size_t)(h->t_iq + 2 * h->t_ikv);
+        widest = std::max(widest, 16 * (size_t)c.t_hidden);
+        widest = std::max(widest, (size_t)2 * h->t_mlp_p);
+        w.part_bytes = b * widest * sizeof(float);
+        w.part = cv.take<float>(b * widest);
+    }
     w.total = align_up(cv.off);
     return w;
+}
+
+// A decode step's nn.Linear (M = B rows, one per sample): the 256-row quad tiles of the prefill put one M-tile x N/256 N-tiles = 14-18
+// workgroups on the chip for qkv / o / down and computed on 192 padding rows; the step ran at 7 % of the HBM roofline (round 3).
+// Here the launch is the stream form (gemm_stream.inc: <= 128 rows, W streamed through a five-stage LDS ring) over K slices as batch
+// entries -- the fewest slices (a divisor of K / 64, <= 16) that put >= 192 (slice, 128-column) items on the chip: a function of the
+// weight's shape only -- into fp32 partials, and one reducer pass applies the epilogue (bias, or SiLU(gate) * up on the packed
+// gate|up columns) and rounds to bf16.  Falls back to the persistent kernel (same bits) when the form does not apply (B > 128).
+int decode_linear(vqs_qwen_handle* h, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias, bf16_t* out, int ldo, int B,
+                  int N, int K, int gated, const DecWs& w, hipStream_t st, const char* what) {
+    const int nblk = (N + 127) / 128, nsl = K / 64;
+    int sk = 1;
+    if (nblk < 192 && (K % 64) == 0) {
+        int best = 1;
+        for (int s2 = 2; s2 <= 16; ++s2)
+            if (nsl % s2 == 0) {
+                best = s2;
+                if (nblk * s2 >= 192) break;
+            }
+        sk = best;
+    }
+    if ((size_t)sk * B * N * sizeof(float) > w.part_bytes) return qfail(h, VQS_ERR_WORKSPACE, std::string(what) + ": decode scratch too small");
+    vqs::GemmParams p{};
+    p.A = A; p.W = W; p.C = w.part; p.bias = nullptr; p.resid = nullptr;
+    p.M = B; p.N = N; p.K = K / sk; p.lda = lda; p.ldw = ldw; p.ldc = N;
+    p.S = 1; p.H = 0; p.inner = 1;
+    p.batch = sk; p.sA = K / sk; p.sW = K / sk; p.sC = (long long)B * N;
+    if (h->prof) {
+        while (h->ev.size() < h->ev_used + 2) {
+            hipEvent_t e;
+            QHIP(h, hipEventCreate(&e), "hipEventCreate");
+            h->ev.push_back(e);
+        }
+        QHIP(h, hipEventRecord(h->ev[h->ev_used], st), "hipEventRecord");
+    }
+    QHIP(h, vqs::launch_gemm(p, vqs::EPI_F32, 3, st), std::string("gemm ") + what);
+    if (h->prof) {
+        QHIP(h, hipEventRecord(h->ev[h->ev_used + 1], st), "hipEventRecord");
+        h->ev_used += 2;
+        h->prof_flops += 2.0 * (double)B * (double)N * (double)K;
+        h->prof_bytes += 2.0 * ((double)B + (double)N) * (double)K + 4.0 * (double)sk * (double)B * (double)N;
+    }
+    QHIP(h, vqs::launch_reduce_slices_act(w.part, sk, (long long)B * N, B, N, N, bias, gated, out, ldo, st), std::string("reduce ") + what);
+    return VQS_OK;
 }
 }  // namespace
 
@@ -815,39 +868,23 @@ int vqs_qwen_decode(vqs_qwen_handle* h, const int32_t* d_ids, const int32_t* d_l
         QHIP(h, vqs::launch_rmsnorm(w.hidden, pend_attn ? pend_attn : pend, ln1, w.xn, B, TH, c.t_eps, st, pend_attn ? pend : nullptr, true, XLD), "input_layernorm");
         QTAP("dec", i, "h", w.hidden, (size_t)B * TH);
         QRUN(qtap2d(h, "dec", i, "xn0", w.xn, TH, B, XLD, st));
-        {   // one position per sample: head-major [B, heads, 1, 128] IS token-major [B, heads * 128]
-            GCall g{w.xn, h->t_qkv_w[i], w.qkv};
-            g.bias = h->t_qkv_b[i];
-            g.M = B; g.N = QN; g.K = TH; g.lda = XLD; g.ldw = TH; g.ldc = QN; g.epi = vqs::EPI_BF16;
-            QRUN(qgemm(h, g, st, "decode qkv"));
-        }
+        // one position per sample: head-major [B, heads, 1, 128] IS token-major [B, heads * 128]
+        QRUN(decode_linear(h, w.xn, XLD, h->t_qkv_w[i], TH, h->t_qkv_b[i], w.qkv, QN, B, QN, TH, 0, w, st, "decode qkv"));
         QTAP("dec", i, "qkv", w.qkv, (size_t)B * QN);
         QHIP(h, vqs::launch_qwen_decode_rope_append(w.qkv, d_cos, d_sin, d_len, w.q, kc, vc, B, c.t_heads, c.t_kv_heads, HDP, h->t_hd / 2, Lmax, st),
              "decode rope + append");
         QTAP("dec", i, "q", w.q, (size_t)B * IQ);
         QHIP(h, vqs::launch_qwen_decode_attn(w.q, kc, vc, d_len, w.attn, B, c.t_heads, c.t_kv_heads, Lmax, scale, st), "decode attention");
         QTAP("dec", i, "attn", w.attn, (size_t)B * IQ);
-        {
-            GCall g{w.attn, h->t_o_w[i], w.delta};
-            g.M = B; g.N = TH; g.K = IQ; g.lda = IQ; g.ldw = IQ; g.ldc = TH; g.epi = vqs::EPI_BF16;
-            QRUN(qgemm(h, g, st, "decode o_proj"));
-        }
+        QRUN(decode_linear(h, w.attn, IQ, h->t_o_w[i], IQ, nullptr, w.delta, TH, B, TH, IQ, 0, w, st, "decode o_proj"));
         QTAP("dec", i, "d_attn", w.delta, (size_t)B * TH);
         QHIP(h, vqs::launch_rmsnorm(w.hidden, w.delta, ln2, w.xn, B, TH, c.t_eps, st, nullptr, false, XLD), "post_attention_layernorm");
         QRUN(qtap2d(h, "dec", i, "xn1", w.xn, TH, B, XLD, st));
         pend_attn = w.delta;
-        {
-            GCall g{w.xn, h->t_gu_w[i], w.ff};
-            g.M = B; g.N = 2 * h->t_mlp_p; g.K = TH; g.lda = XLD; g.ldw = XLD; g.ldc = h->t_ffld; g.epi = vqs::EPI_GATED; g.gate_act = 1;
-            QRUN(qgemm(h, g, st, "decode gate|up"));
-        }
+        QRUN(decode_linear(h, w.xn, XLD, h->t_gu_w[i], XLD, nullptr, w.ff, h->t_ffld, B, 2 * h->t_mlp_p, TH, 1, w, st, "decode gate|up"));
         QTAP("dec", i, "ff", w.ff, (size_t)B * h->t_ffld);
-        {
-            GCall g{w.ff, h->t_down_w[i], w.delta2};
-            g.M = B; g.N = TH; g.K = h->t_ffld; g.lda = h->t_ffld; g.ldw = h->t_ffld; g.ldc = TH; g.epi = vqs::EPI_BF16;
-            QRUN(qgemm(h, g, st, "decode down_proj"));
-            pend = w.delta2;
-        }
+        QRUN(decode_linear(h, w.ff, h->t_ffld, h->t_down_w[i], h->t_ffld, nullptr, w.delta2, TH, B, TH, h->t_ffld, 0, w, st, "decode down_proj"));
+        pend = w.delta2;
         QTAP("dec", i, "d_mlp", w.delta2, (size_t)B * TH);
     }
     QW(fin, "model.language_model.norm.weight", TH);
