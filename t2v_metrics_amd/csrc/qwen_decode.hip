@@ -138,9 +138,179 @@ __global__ void __launch_bounds__(256) qwen_decode_attn_kernel(const bf16_t* __r
     }
 }
 
+// Grouped-query form of the same step: ONE block per (key/value head, sample) serves all G = Hq / Hkv query heads that share the head,
+// so a cached K / V row is read once (the per-query-head kernel above re-reads it G = 7 times and walks it one thread per row: 64 lanes
+// 256 B apart per load instruction -- 385 GB/s at B = 64, L = 808: 7.7 of the step's 13 ms of kernel time, profiles/r4_call12_*).
+// Lane map for both passes: a wave instruction covers 4 consecutive keys x 16 chunks of 16 B (8 dims) = four whole 256-byte rows;
+// wave w takes the key groups w, w + 4, ...; eight loads are in flight per wave before the first use.  Scores: per head an 8-term dot
+// per lane, summed over the row's 16 lanes by xor-shuffles (1, 2, 4, 8), scaled, kept in LDS [G][Lmax]; softmax statistics per head in
+// fp32, probabilities NOT rounded (as above); output: per lane 8 dims x G heads of fp32 accumulators, the 4 key sub-rows folded by
+// xor-shuffles (16, 32), the four waves' partial rows added in wave order, one division, bf16.  Dynamic LDS: G * Lmax floats.
+static constexpr int QD_GMAX = 8;
+__global__ void __launch_bounds__(256) qwen_decode_attn_gqa_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc,
+                                                                   const bf16_t* __restrict__ vc, const int* __restrict__ len,
+                                                                   bf16_t* __restrict__ out, int Hq, int Hkv, int Lmax, float scale) {
+    constexpr int HD = 128, U = 8;
+    extern __shared__ __attribute__((aligned(16))) float d_smem[];      // sc[G][Lp]
+    __shared__ float red[4][QD_GMAX];
+    __shared__ float stat[2][QD_GMAX];                                  // max, sum per head
+    __shared__ float part[4][QD_GMAX][HD];
+    const int hk = blockIdx.x, b = blockIdx.y, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int G = Hq / Hkv;
+    const int n = min(max(len[b], 0), Lmax - 1) + 1;
+    const int Lp = (Lmax + 3) & ~3;
+    float* sc = d_smem;
+    const bf16_t* K = kc + ((size_t)b * Hkv + hk) * Lmax * HD;
+    const bf16_t* V = vc + ((size_t)b * Hkv + hk) * Lmax * HD;
+    const int sub = lane >> 4, c = lane & 15;
+    auto cvt8 = [](const uint4& u, float (&f)[8]) {
+        const uint32_t w4[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            f[2 * e] = __uint_as_float(w4[e] << 16);
+            f[2 * e + 1] = __uint_as_float(w4[e] & 0xffff0000u);
+        }
+    };
+    // ---- scores
+    {
+        float qf[QD_GMAX][8];
+#pragma unroll
+        for (int g = 0; g < QD_GMAX; ++g)
+            if (g < G) cvt8(*reinterpret_cast<const uint4*>(q + ((size_t)b * Hq + (size_t)hk * G + g) * HD + 8 * c), qf[g]);
+        float mx[QD_GMAX];
+#pragma unroll
+        for (int g = 0; g < QD_GMAX; ++g) mx[g] = -3.0e38f;
+        for (int j0 = wv * 4; j0 < n; j0 += 16 * U) {
+            uint4 kv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = j0 + 16 * u + sub;
+                kv[u] = j < n ? *reinterpret_cast<const uint4*>(K + (size_t)j * HD + 8 * c) : make_uint4(0u, 0u, 0u, 0u);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = j0 + 16 * u + sub;
+                float kf[8];
+                cvt8(kv[u], kf);
+#pragma unroll
+                for (int g = 0; g < QD_GMAX; ++g)
+                    if (g < G) {
+                        float d = 0.0f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) d = fmaf(qf[g][e], kf[e], d);
+                        d += __shfl_xor(d, 1);
+                        d += __shfl_xor(d, 2);
+                        d += __shfl_xor(d, 4);
+                        d += __shfl_xor(d, 8);
+                        const float tj = d * scale;
+                        if (j < n) {
+                            if (c == 0) sc[g * Lp + j] = tj;
+                            mx[g] = fmaxf(mx[g], tj);
+                        }
+                    }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < QD_GMAX; ++g)
+            if (g < G) {
+                float m = mx[g];
+                m = fmaxf(m, __shfl_xor(m, 16));
+                m = fmaxf(m, __shfl_xor(m, 32));
+                if (lane == 0) red[wv][g] = m;
+            }
+    }
+    __syncthreads();
+    if (t < G) stat[0][t] = fmaxf(fmaxf(red[0][t], red[1][t]), fmaxf(red[2][t], red[3][t]));
+    __syncthreads();
+    // ---- probabilities (fp32, not rounded) and their sums
+    {
+        float ls[QD_GMAX];
+#pragma unroll
+        for (int g = 0; g < QD_GMAX; ++g) ls[g] = 0.0f;
+        for (int j = t; j < n; j += 256)
+#pragma unroll
+            for (int g = 0; g < QD_GMAX; ++g)
+                if (g < G) {
+                    const float p = __expf(sc[g * Lp + j] - stat[0][g]);
+                    sc[g * Lp + j] = p;
+                    ls[g] += p;
+                }
+#pragma unroll
+        for (int g = 0; g < QD_GMAX; ++g)
+            if (g < G) {
+                float v = ls[g];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+                if (lane == 0) red[wv][g] = v;
+            }
+    }
+    __syncthreads();
+    if (t < G) stat[1][t] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+    // ---- output
+    {
+        float acc[QD_GMAX][8];
+#pragma unroll
+        for (int g = 0; g < QD_GMAX; ++g)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[g][e] = 0.0f;
+        for (int j0 = wv * 4; j0 < n; j0 += 16 * U) {
+            uint4 vv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = j0 + 16 * u + sub;
+                vv[u] = j < n ? *reinterpret_cast<const uint4*>(V + (size_t)j * HD + 8 * c) : make_uint4(0u, 0u, 0u, 0u);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = j0 + 16 * u + sub;
+                if (j < n) {
+                    float vf[8];
+                    cvt8(vv[u], vf);
+#pragma unroll
+                    for (int g = 0; g < QD_GMAX; ++g)
+                        if (g < G) {
+                            const float p = sc[g * Lp + j];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) acc[g][e] = fmaf(p, vf[e], acc[g][e]);
+                        }
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < QD_GMAX; ++g)
+            if (g < G) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float v = acc[g][e];
+                    v += __shfl_xor(v, 16);
+                    v += __shfl_xor(v, 32);
+                    if (sub == 0) part[wv][g][8 * c + e] = v;
+                }
+            }
+    }
+    __syncthreads();
+    for (int i = t; i < G * HD; i += 256) {
+        const int g = i / HD, d = i - g * HD;
+        const float o = ((part[0][g][d] + part[1][g][d]) + (part[2][g][d] + part[3][g][d])) / stat[1][g];
+        out[((size_t)b * Hq + (size_t)hk * G + g) * HD + d] = d_f2bf(o);
+    }
+}
+
 hipError_t launch_qwen_decode_attn(const bf16_t* q, const bf16_t* kc, const bf16_t* vc, const int* len, bf16_t* out, int B, int Hq,
                                    int Hkv, int Lmax, float scale, hipStream_t s) {
     if (B <= 0 || Hq <= 0 || Hkv <= 0 || (Hq % Hkv) != 0 || Lmax <= 0 || Lmax > 36864 /* VQS_QWEN_MAX_CACHE_POSITIONS */ || B > 65535) return hipErrorInvalidValue;
+    {   // grouped-query form wherever its G score rows fit LDS (Lmax <= ~4 300 positions at G = 7); the per-query-head kernel beyond
+        const int G = Hq / Hkv;
+        const size_t glds = (size_t)G * ((Lmax + 3) & ~3) * sizeof(float);
+        if (G <= QD_GMAX && glds <= 120 * 1024) {
+            if (glds > 48 * 1024) {
+                const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(qwen_decode_attn_gqa_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds);
+                if (e != hipSuccess) return e;
+            }
+            hipLaunchKernelGGL(qwen_decode_attn_gqa_kernel, dim3((unsigned)Hkv, (unsigned)B), dim3(256), glds, s, q, kc, vc, len, out, Hq, Hkv, Lmax, scale);
+            return hipGetLastError();
+        }
+    }
     const size_t lds = (size_t)Lmax * sizeof(float);
     if (lds > 48 * 1024) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(qwen_decode_attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -139,7 +139,11 @@ class QwenEngine:
                                                   t["seq_len"].data_ptr(), t["last_row"].data_ptr(), t["cos"].data_ptr(),
                                                   t["sin"].data_ptr(), B, L, logits.data_ptr(), ws.data_ptr(), ws.numel(), kv.data_ptr(),
                                                   kv.numel(), Lmax, _stream_ptr()), "vqs_qwen_prefill")
-            state = {"kv": kv, "len": t["seq_len"].clone(), "Lmax": Lmax, "B": B, "pos": lay["next_pos"].clone(), "steps": 0}
+            # len_host_max: the longest sample's length, tracked on the HOST -- decode() checks the cache bound without reading the device
+            # tensor (round 3 did `int(state["len"].max())` per step: a device sync that serialised the host's ~400 launches per step
+            # with the GPU's work; the decode kernels themselves ignore / clamp a length outside the cache, qwen_decode.hip)
+            state = {"kv": kv, "len": t["seq_len"].clone(), "Lmax": Lmax, "B": B, "pos": lay["next_pos"].clone(), "steps": 0,
+                     "len_host_max": int(lay["seq_len"].max())}
             return logits, state
 
     def decode(self, state, token_ids: torch.Tensor) -> torch.Tensor:
@@ -147,7 +151,7 @@ class QwenEngine:
         -> fp32 [B, vocab] logits of that position.  Advances `state`."""
         from .layout import decode_tables
         B = state["B"]
-        if int(state["len"].max()) >= state["Lmax"]:
+        if state["len_host_max"] >= state["Lmax"]:
             raise VqsError("KV cache is full: prefill(..., max_new_tokens) sized it")
         cos, sin = decode_tables(self.cfg, state["pos"])
         with torch.cuda.device(self.device):
@@ -162,6 +166,7 @@ class QwenEngine:
                                                  state["Lmax"], state["kv"].data_ptr(), state["kv"].numel(), logits.data_ptr(),
                                                  state["ws"].data_ptr(), state["ws"].numel(), _stream_ptr()), "vqs_qwen_decode")
             state["len"] += 1
+            state["len_host_max"] += 1
             state["pos"] = state["pos"] + 1
             state["steps"] += 1
             return logits
