@@ -147,14 +147,15 @@ __global__ void __launch_bounds__(256) qwen_decode_attn_kernel(const bf16_t* __r
 // fp32, probabilities NOT rounded (as above); output: per lane 8 dims x G heads of fp32 accumulators, the 4 key sub-rows folded by
 // xor-shuffles (16, 32), the four waves' partial rows added in wave order, one division, bf16.  Dynamic LDS: G * Lmax floats.
 static constexpr int QD_GMAX = 8;
-__global__ void __launch_bounds__(256) qwen_decode_attn_gqa_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc,
+static constexpr int QD_NW = 8;            // waves per block: eight split the key range, two per SIMD cover each other's load latency
+__global__ void __launch_bounds__(64 * QD_NW) qwen_decode_attn_gqa_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc,
                                                                    const bf16_t* __restrict__ vc, const int* __restrict__ len,
                                                                    bf16_t* __restrict__ out, int Hq, int Hkv, int Lmax, float scale) {
     constexpr int HD = 128, U = 8;
     extern __shared__ __attribute__((aligned(16))) float d_smem[];      // sc[G][Lp]
-    __shared__ float red[4][QD_GMAX];
+    __shared__ float red[QD_NW][QD_GMAX];
     __shared__ float stat[2][QD_GMAX];                                  // max, sum per head
-    __shared__ float part[4][QD_GMAX][HD];
+    __shared__ float part[QD_NW][QD_GMAX][HD];
     const int hk = blockIdx.x, b = blockIdx.y, t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int G = Hq / Hkv;
     const int n = min(max(len[b], 0), Lmax - 1) + 1;
@@ -180,16 +181,16 @@ __global__ void __launch_bounds__(256) qwen_decode_attn_gqa_kernel(const bf16_t*
         float mx[QD_GMAX];
 #pragma unroll
         for (int g = 0; g < QD_GMAX; ++g) mx[g] = -3.0e38f;
-        for (int j0 = wv * 4; j0 < n; j0 += 16 * U) {
+        for (int j0 = wv * 4; j0 < n; j0 += 4 * QD_NW * U) {
             uint4 kv[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int j = j0 + 16 * u + sub;
+                const int j = j0 + 4 * QD_NW * u + sub;
                 kv[u] = j < n ? *reinterpret_cast<const uint4*>(K + (size_t)j * HD + 8 * c) : make_uint4(0u, 0u, 0u, 0u);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int j = j0 + 16 * u + sub;
+                const int j = j0 + 4 * QD_NW * u + sub;
                 float kf[8];
                 cvt8(kv[u], kf);
 #pragma unroll
@@ -220,14 +221,19 @@ __global__ void __launch_bounds__(256) qwen_decode_attn_gqa_kernel(const bf16_t*
             }
     }
     __syncthreads();
-    if (t < G) stat[0][t] = fmaxf(fmaxf(red[0][t], red[1][t]), fmaxf(red[2][t], red[3][t]));
+    if (t < G) {
+        float m = red[0][t];
+#pragma unroll
+        for (int i = 1; i < QD_NW; ++i) m = fmaxf(m, red[i][t]);
+        stat[0][t] = m;
+    }
     __syncthreads();
     // ---- probabilities (fp32, not rounded) and their sums
     {
         float ls[QD_GMAX];
 #pragma unroll
         for (int g = 0; g < QD_GMAX; ++g) ls[g] = 0.0f;
-        for (int j = t; j < n; j += 256)
+        for (int j = t; j < n; j += 64 * QD_NW)
 #pragma unroll
             for (int g = 0; g < QD_GMAX; ++g)
                 if (g < G) {
@@ -245,7 +251,12 @@ __global__ void __launch_bounds__(256) qwen_decode_attn_gqa_kernel(const bf16_t*
             }
     }
     __syncthreads();
-    if (t < G) stat[1][t] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+    if (t < G) {
+        float v = red[0][t];
+#pragma unroll
+        for (int i = 1; i < QD_NW; ++i) v += red[i][t];
+        stat[1][t] = v;
+    }
     // ---- output
     {
         float acc[QD_GMAX][8];
@@ -253,16 +264,16 @@ __global__ void __launch_bounds__(256) qwen_decode_attn_gqa_kernel(const bf16_t*
         for (int g = 0; g < QD_GMAX; ++g)
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[g][e] = 0.0f;
-        for (int j0 = wv * 4; j0 < n; j0 += 16 * U) {
+        for (int j0 = wv * 4; j0 < n; j0 += 4 * QD_NW * U) {
             uint4 vv[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int j = j0 + 16 * u + sub;
+                const int j = j0 + 4 * QD_NW * u + sub;
                 vv[u] = j < n ? *reinterpret_cast<const uint4*>(V + (size_t)j * HD + 8 * c) : make_uint4(0u, 0u, 0u, 0u);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int j = j0 + 16 * u + sub;
+                const int j = j0 + 4 * QD_NW * u + sub;
                 if (j < n) {
                     float vf[8];
                     cvt8(vv[u], vf);
@@ -289,9 +300,12 @@ __global__ void __launch_bounds__(256) qwen_decode_attn_gqa_kernel(const bf16_t*
             }
     }
     __syncthreads();
-    for (int i = t; i < G * HD; i += 256) {
+    for (int i = t; i < G * HD; i += 64 * QD_NW) {
         const int g = i / HD, d = i - g * HD;
-        const float o = ((part[0][g][d] + part[1][g][d]) + (part[2][g][d] + part[3][g][d])) / stat[1][g];
+        float o = part[0][g][d];
+#pragma unroll
+        for (int i2 = 1; i2 < QD_NW; ++i2) o += part[i2][g][d];
+        o = o / stat[1][g];
         out[((size_t)b * Hq + (size_t)hk * G + g) * HD + d] = d_f2bf(o);
     }
 }
@@ -307,7 +321,7 @@ hipError_t launch_qwen_decode_attn(const bf16_t* q, const bf16_t* kc, const bf16
                 const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(qwen_decode_attn_gqa_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds);
                 if (e != hipSuccess) return e;
             }
-            hipLaunchKernelGGL(qwen_decode_attn_gqa_kernel, dim3((unsigned)Hkv, (unsigned)B), dim3(256), glds, s, q, kc, vc, len, out, Hq, Hkv, Lmax, scale);
+            hipLaunchKernelGGL(qwen_decode_attn_gqa_kernel, dim3((unsigned)Hkv, (unsigned)B), dim3(64 * QD_NW), glds, s, q, kc, vc, len, out, Hq, Hkv, Lmax, scale);
             return hipGetLastError();
         }
     }

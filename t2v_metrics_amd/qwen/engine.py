@@ -142,7 +142,11 @@ class QwenEngine:
             # len_host_max: the longest sample's length, tracked on the HOST -- decode() checks the cache bound without reading the device
             # tensor (round 3 did `int(state["len"].max())` per step: a device sync that serialised the host's ~400 launches per step
             # with the GPU's work; the decode kernels themselves ignore / clamp a length outside the cache, qwen_decode.hip)
-            state = {"kv": kv, "len": t["seq_len"].clone(), "Lmax": Lmax, "B": B, "pos": lay["next_pos"].clone(), "steps": 0,
+            # pos: the next token's M-RoPE position per axis, kept ON THE DEVICE -- decode() derives its cos / sin tables there (a few
+            # tiny launches) instead of on the host: the host tables cost two blocking H2D copies per step, each a stream synchronise
+            # (PyTorch syncs after a pageable copy), i.e. the host's launches never overlapped the GPU's work, and torch's CPU thread
+            # pool stalled a step by 70 ms now and then (profiles/r4_call15_*)
+            state = {"kv": kv, "len": t["seq_len"].clone(), "Lmax": Lmax, "B": B, "pos": lay["next_pos"].clone().to(dev), "steps": 0,
                      "len_host_max": int(lay["seq_len"].max())}
             return logits, state
 
@@ -157,7 +161,7 @@ class QwenEngine:
         with torch.cuda.device(self.device):
             dev = self.device
             ids = token_ids.to(dev, torch.int32).contiguous()
-            cos, sin = cos.to(dev), sin.to(dev)
+            cos, sin = cos.to(dev), sin.to(dev)          # no-ops: the tables were computed on the device
             logits = torch.empty(B, self.cfg.text.vocab, dtype=torch.float32, device=dev)
             need = self.lib.vqs_qwen_decode_workspace_bytes(self._h, B)
             if state.get("ws") is None or state["ws"].numel() < need:

@@ -119,7 +119,7 @@ def decode_tables(cfg: Qwen25VLConfig, positions: torch.Tensor) -> Tuple[torch.T
     """positions long [3, B] (t, h, w axes of the new token; equal when the prompt ends in text) -> cos, sin fp32 [B, head_dim/2],
     M-RoPE sections applied as in text_layout."""
     hd = cfg.text.head_dim
-    inv_freq = 1.0 / (cfg.text.rope_theta ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
-    freqs = positions[..., None].float() * inv_freq                                  # [3, B, hd/2]
+    inv_freq = 1.0 / (cfg.text.rope_theta ** (torch.arange(0, hd, 2, dtype=torch.float32, device=positions.device) / hd))
+    freqs = positions[..., None].float() * inv_freq                                  # [3, B, hd/2]; on the positions' device
     ang = torch.cat([m[i % 3] for i, m in enumerate(freqs.split(list(cfg.text.mrope_section), dim=-1))], dim=-1)
     return ang.cos().contiguous(), ang.sin().contiguous()

@@ -343,7 +343,7 @@ def test_qwen_kv_cache_decode_matches_a_prefill_over_the_longer_sequence(name):
         bufs = {n: torch.zeros(sh, dtype=dt, device="cuda") for n, (sh, dt) in shapes.items()}
         for n, buf in bufs.items():
             eng.tap(n, buf)
-        length, pos = state["len"].long().cpu().clone(), state["pos"].clone()
+        length, pos = state["len"].long().cpu().clone(), state["pos"].cpu().clone()     # the oracle evaluates the tables on the host
         lg_dev = eng.decode(state, forced[t])
         torch.cuda.synchronize()
         eng.tap(None)

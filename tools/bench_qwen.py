@@ -100,15 +100,19 @@ def main():
         eng.decode(state, tok)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        host = 0.0
         for _ in range(n):
-            tok = eng.decode(state, tok).argmax(-1)
+            h0 = time.perf_counter()
+            lg = eng.decode(state, tok)                     # returns when the step's launches are ENQUEUED
+            host += time.perf_counter() - h0
+            tok = lg.argmax(-1)
         torch.cuda.synchronize()
         dtd = (time.perf_counter() - t0) / n
         t_ = cfg.text
         wbytes = 2.0 * (t_.layers * (t_.hidden * (t_.heads + 2 * t_.kv_heads) * t_.head_dim + t_.hidden * t_.heads * t_.head_dim + 3 * t_.hidden * t_.mlp)
                         + t_.vocab * t_.hidden)
         kvbytes = 2.0 * 2 * t_.layers * B * t_.kv_heads * (L + n / 2) * 128
-        out["decode"] = {"ms_per_step": 1e3 * dtd, "tokens_per_s": B / dtd, "batch": B, "steps": n,
+        out["decode"] = {"ms_per_step": 1e3 * dtd, "host_enqueue_ms_per_step": 1e3 * host / n, "tokens_per_s": B / dtd, "batch": B, "steps": n,
                          "hbm_bound": {"weight_bytes": wbytes, "kv_bytes": kvbytes, "achieved_GBps": (wbytes + kvbytes) / dtd / 1e9, "peak_GBps": 8000.0,
                                        "frac": (wbytes + kvbytes) / dtd / 8e12}}
     if args.cpu_samples > 0:
