@@ -194,6 +194,9 @@ def run_also_leg(name):
     if isinstance(j.get("roofline"), dict):
         out["roofline_frac"] = j["roofline"].get("frac")
         out["roofline_achieved_tflops"] = j["roofline"].get("achieved")
+    if isinstance(j.get("decode"), dict):
+        out["decode_ms_per_step"] = j["decode"].get("ms_per_step")
+        out["decode_tokens_per_s"] = j["decode"].get("tokens_per_s")
     for k in ("model_frac_of_mfma_peak", "host_preprocess_256_images_s", "workers", "pairs", "png_edge", "image_workers", "host_threads_allowed",
               "engine_only_same_inputs_pairs_per_s", "ratio_to_engine_only_same_inputs", "encoder_len_first_batch"):
         if k in j:
@@ -296,7 +299,8 @@ def main():
         if args.gpus != 1:
             raise SystemExit("the Qwen2.5-VL bench line is single-GPU (replicas need no collective: run one process per GPU)")
         sys.argv = [os.path.join(ROOT, "tools", "bench_qwen.py"), "--model", args.model, "--steps", str(args.steps), "--warmup",
-                    str(args.warmup), "--batch", str(min(args.batch, 64)), "--cpu-samples", str(min(args.cpu_pairs, 1))]
+                    str(args.warmup), "--batch", str(min(args.batch, 64)), "--cpu-samples", str(min(args.cpu_pairs, 1)),
+                    "--decode-steps", "16"]          # + the cached decode step (generation beyond the first token), reported under "decode"
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import bench_qwen
         return bench_qwen.main()
