@@ -209,10 +209,11 @@ int vqs_score_head(const float* d_logits, int32_t ldl, int32_t V, const int32_t*
  *   "gemm_variant" 3 (default) the quad form (four waves of 128x128, 16x16x32 MFMAs; csrc/gemm_quad.inc) for every bf16-result
  *                  launch with one batch entry and K >= 128, the persistent 8-wave kernels for the rest (fp32 results, batched,
  *                  tiny K); 11 the persistent 8-wave kernels everywhere (rounds 1-2's product path); 0 one tile per workgroup;
- *                  2 / 5 the ping-pong schedule.  0 / 2 / 5 / 11 are mutually bitwise equal; the quad form sums the same products
- *                  in another order (16x16x32 instead of 32x32x16 MFMAs) and differs from them in the last bf16 ulp of ~1e-3 of the
- *                  elements, which is why a call site runs ONE form for every M (csrc/gemm_quad.inc, "Numerics").  Other values
- *                  are rejected (the A/B forms of rounds 1-3 left the tree in round 4)
+ *                  2 / 5 the ping-pong schedule.  All of them -- and the stream form (csrc/gemm_stream.inc) -- are bitwise equal:
+ *                  a 16x16x32 MFMA adds a k-step's 32 products in the order two 32x32x16 MFMAs do, and every form walks k
+ *                  ascending in one accumulator chain (tests/test_gpu_kernels.py holds each against variant 0 with torch.equal;
+ *                  a call site nevertheless keeps ONE form for every M, csrc/gemm_quad.inc).  Other values are rejected (the A/B
+ *                  forms of rounds 1-3 left the tree in round 4)
  *   per-shape cache-policy names ("tile_order:", "l2_touch:", "nt_store:"): lab switches, see include/vqs_debug.h
  * Returns VQS_ERR_INVALID for an unknown name or value. */
 int vqs_set_option(vqs_handle* h, const char* name, int32_t value);
