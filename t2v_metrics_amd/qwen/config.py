@@ -85,7 +85,13 @@ QWEN_SMALL_C80 = Qwen25VLConfig(
     text=QwenTextConfig(vocab=1024, hidden=256, layers=2, heads=2, kv_heads=1, mlp=384, mrope_section=(16, 24, 24)),
     image_token_id=4, video_token_id=5, vision_start_token_id=6, vision_end_token_id=7,
 )
-_CONFIGS = {c.name: c for c in (QWEN25_VL_7B, QWEN_TINY, QWEN_SMALL, QWEN_SMALL_C80)}
+QWEN_TINY_G7 = Qwen25VLConfig(
+    name="qwen-tiny-g7",            # the 7B language model's grouped-query ratio in small: 7 query heads per key/value head (7 x 64-wide heads)
+    vision=QwenVisionConfig(depth=4, hidden=64, heads=2, mlp=96, window=56, fullatt_blocks=(1, 3), out_hidden=448),
+    text=QwenTextConfig(vocab=512, hidden=448, layers=2, heads=7, kv_heads=1, mlp=256, mrope_section=(8, 12, 12)),
+    image_token_id=4, video_token_id=5, vision_start_token_id=6, vision_end_token_id=7,
+)
+_CONFIGS = {c.name: c for c in (QWEN25_VL_7B, QWEN_TINY, QWEN_SMALL, QWEN_SMALL_C80, QWEN_TINY_G7)}
 
 
 def get_qwen_config(name: str) -> Qwen25VLConfig:

@@ -289,7 +289,7 @@ def test_qwen_7b_full_size_one_sample_against_the_cpu_oracle():
     eng.close()
 
 
-@pytest.mark.parametrize("name", ["qwen-tiny", "qwen-small"])
+@pytest.mark.parametrize("name", ["qwen-tiny", "qwen-small", "qwen-tiny-g7"])      # -g7: the 7B model's 7 query heads per kv head (grouped-query decode kernel)
 def test_qwen_kv_cache_decode_matches_a_prefill_over_the_longer_sequence(name):
     """vqs_qwen_prefill + vqs_qwen_decode (one cached position per call) against vqs_qwen_score over prompt + the same tokens, three
     steps on a ragged right-padded batch (32-lane padded heads with 4/2 grouped-query heads; 128-lane heads with 2/1): the two run
