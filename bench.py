@@ -612,7 +612,8 @@ def parity_sample(cfg, weights, eng, job, n_pairs):
     with torch.device(dev):
         o = Oracle(cfg, weights, device=dev)
         truth = o.forward(pixels[:n].float(), torch.arange(n, device=dev), ids_c[:, :keep], lab_c, return_stages=True)
-    torch.cuda.synchronize()
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
     t_truth = time.perf_counter() - t0
     logits_hip = eng.stage("logits")[:n].float()
     logits_ref = truth["logits"].float()

@@ -1,0 +1,75 @@
+"""CPU tests of the round-4 parity tooling: the per-class switches of the rounding-matched oracle (what tools/error_attribution.py
+varies), the split-bf16 rounding, and the arithmetic of bench.py's 16-pair |delta log P| table (parity_sample) on an engine double."""
+import numpy as np
+import pytest
+import torch
+
+from oracle.clip_t5_engine_rounding import EngineRoundedOracle, bf16_round, split_bf16_round
+from oracle.clip_t5_oracle import Oracle
+from t2v_metrics_amd.config import get_config
+from t2v_metrics_amd.weights import make_seeded_weights
+
+
+def _case(name="tiny", seed=3):
+    cfg = get_config(name)
+    w = make_seeded_weights(cfg, seed=seed, device="cpu", lm_head_gain=2.0)
+    g = torch.Generator().manual_seed(seed)
+    pix = torch.randn(2, 3, cfg.vision.image, cfg.vision.image, generator=g).to(torch.bfloat16).float()
+    ids = torch.tensor([[11, 12, -200, 13, 14, 1, 7, 1], [21, -200, 22, 1, 0, 0, 0, 0], [5, 6, 7, -200, 9, 1, 0, 0]])
+    labels = torch.tensor([[40, 1], [41, 1], [42, 1]])
+    return cfg, w, pix, torch.tensor([0, 1, 1]), ids, labels
+
+
+def test_split_bf16_round_carries_sixteen_bits():
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(4096, generator=g) * torch.logspace(-6, 6, 4096)
+    y = split_bf16_round(x)
+    hi = bf16_round(x)
+    assert torch.equal(bf16_round(y - hi), y - hi)                          # y = hi + a bf16 value
+    rel = ((y - x).abs() / x.abs()).max().item()
+    assert rel <= 2.0 ** -16 and ((bf16_round(x) - x).abs() / x.abs()).max().item() > 2.0 ** -10
+    assert torch.equal(split_bf16_round(hi), hi)                            # bf16 values pass through unchanged
+    # bf16(hi + lo) is NOT always hi: lo is rounded itself and can put the sum exactly on a tie (why the oracle carries the hi plane)
+    assert (bf16_round(y) != hi).any()
+
+
+def test_rounding_classes_switch_individually_and_the_precise_decoder_is_closer():
+    cfg, w, pix, idx, ids, labels = _case()
+    ref = Oracle(cfg, w).forward(pix, idx, ids, labels)["label_logprobs"]
+    run = lambda **kw: EngineRoundedOracle(cfg, w, acc=torch.float32, **kw).forward(pix, idx, ids, labels)["label_logprobs"]
+    none = run(classes=())
+    assert (none - ref).abs().max().item() <= 2e-5                          # every class off = the fp32 oracle
+    errs = {}
+    for c in EngineRoundedOracle.CLASSES:
+        errs[c] = (run(classes=(c,), dec_precise=False) - none).abs().max().item()
+        assert errs[c] > 0.0, c                                             # every class is a live rounding site
+    assert abs((run(dec_precise=False) - run(classes=EngineRoundedOracle.CLASSES, dec_precise=False)).abs().max().item()) == 0.0
+    dec = [c for c in EngineRoundedOracle.CLASSES if c.startswith("dec.")]
+    legacy = (run(classes=dec, dec_precise=False) - none).abs().max().item()
+    precise = (run(classes=dec, dec_precise=True) - none).abs().max().item()
+    assert precise < 0.25 * legacy, (precise, legacy)                       # the decoder's own contribution shrinks by >= 4x
+    with pytest.raises(ValueError):
+        EngineRoundedOracle(cfg, w, classes=("dec.nope",))
+
+
+def test_bench_parity_sample_table_on_an_engine_double():
+    """parity_sample: truth = the oracle on the job's device, HIP logits = the engine's `logits` stage; head gains re-read both."""
+    import bench
+    cfg, w, pix, idx, ids, labels = _case()
+    pix3 = pix[[0, 1, 1]]                                                    # one image per pair, as the bench batch has
+    truth = Oracle(cfg, w).forward(pix3, torch.arange(3), ids, labels, return_stages=True)
+
+    class Eng:
+        def stage(self, name):
+            assert name == "logits"
+            return truth["logits"] + 1e-3 * torch.sign(truth["logits"])      # a known perturbation
+
+    job = (pix3.to(torch.bfloat16), torch.arange(3), ids.int(), labels.int(), None)
+    out, lp_truth = bench.parity_sample(cfg, w, Eng(), job, 16)
+    assert out["pairs"] == 3 and set(out["gains"]) == {"1", "4"}
+    assert torch.allclose(lp_truth, truth["label_logprobs"], atol=1e-6)
+    g1, g4 = out["gains"]["1"], out["gains"]["4"]
+    assert 0 < g1["max"] <= 2.5e-3 and g1["mean"] <= g1["max"] and len(g1["per_pair"]) == 3
+    assert g4["max"] > g1["max"]                                             # the same logit error weighs more under a peaked head
+    lr = Oracle.label_logprobs(truth["logits"] * 4.0, labels)
+    assert abs(g4["logp_yes_range"][0] - float(lr[:, 0].min())) < 1e-3
