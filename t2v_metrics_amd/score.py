@@ -80,11 +80,16 @@ class Score(nn.Module):
 
     def batch_forward(self, dataset: List[ImageTextDict], batch_size: int = 16, num_frames: int = 4,
                       **kwargs) -> torch.Tensor:
-        """dataset[k] = {'images': [..n_vis..], 'texts': [..n_txt..]} -> fp32 [len(dataset), n_vis, n_txt]."""
+        """dataset[k] = {'images' | 'videos': [..n_vis..], 'texts': [..n_txt..]} -> fp32 [len(dataset), n_vis, n_txt]."""
         num_samples = len(dataset)
-        if "videos" in dataset[0]:
-            raise NotImplementedError("video datasets are outside the MI355X hot path")
-        num_visuals = len(dataset[0]['images'])
+        # the reference keys a dataset's media under "videos" or "images" (score.py:124-128); a video-native model (video_mode
+        # "direct") takes either -- the paths go to the model untouched, as in forward(); for image-only models a video dataset would
+        # need the ffmpeg/cv2 frame-concat pre-processing, which is outside the MI355X hot path
+        media_type = "videos" if "videos" in dataset[0] else "images"
+        if media_type == "videos" and getattr(self.model, "video_mode", None) != "direct":
+            raise NotImplementedError("video datasets need a video-native model (video_mode 'direct'); the frame-concat path for image-only "
+                                      "models is outside the MI355X hot path")
+        num_visuals = len(dataset[0][media_type])
         num_texts = len(dataset[0]['texts'])
         lo, hi = sharding.shard_range(num_samples)
         local = torch.zeros(hi - lo, num_visuals, num_texts)
@@ -94,11 +99,11 @@ class Score(nn.Module):
             texts: List[str] = []
             for k in range(start, stop):
                 sample = dataset[k]
-                assert len(sample['images']) == num_visuals, \
-                    f"Number of image options in sample {k} is {len(sample['images'])}. Expected {num_visuals}."
+                assert len(sample[media_type]) == num_visuals, \
+                    f"Number of visual (image/video) options in sample {k} is {len(sample[media_type])}. Expected {num_visuals} visuals."
                 assert len(sample['texts']) == num_texts, \
                     f"Number of text options in sample {k} is {len(sample['texts'])}. Expected {num_texts} texts."
-                for v in sample['images']:
+                for v in sample[media_type]:
                     for t in sample['texts']:
                         images.append(v)
                         texts.append(t)

@@ -477,3 +477,28 @@ def _generated_ids(m, path, n):
         return m._generate_scores([str(path)], ["a red cube"], None, default_question_template, "Yes", n)[0][1]
     finally:
         m._gen_eos_ids = keep
+
+
+def test_batch_forward_takes_a_videos_dataset_for_a_direct_mode_model(tmp_path):
+    """The reference keys a dataset's media under "videos" or "images" (score.py:124-128); Qwen2.5-VL (video_mode "direct") scores either
+    through batch_forward, an image-only model refuses a video dataset."""
+    cfg = get_qwen_config("qwen-tiny")
+    w = make_seeded_qwen_weights(cfg, seed=3, dtype=torch.bfloat16, lm_head_gain=4.0)
+    eng = OracleQwenEngine(cfg, w)
+    rng = np.random.RandomState(2)
+    paths = []
+    for i in range(3):
+        p = tmp_path / f"v{i}.npy"
+        np.save(p, rng.randint(0, 256, (4, 112, 112, 3), dtype=np.uint8))
+        paths.append(str(p))
+    scorer = t2v.VQAScore(model="qwen2.5-vl-7b", device="cpu", config=cfg, engine=eng, tokenizer=FakeQwenTokenizer(cfg.text.vocab))
+    ds_v = [{"videos": [paths[k]], "texts": ["a cat jumps", "a dog runs"]} for k in range(3)]
+    ds_i = [{"images": [paths[k]], "texts": ["a cat jumps", "a dog runs"]} for k in range(3)]
+    sv, si = scorer.batch_forward(ds_v, batch_size=2), scorer.batch_forward(ds_i, batch_size=2)
+    assert sv.shape == (3, 1, 2) and torch.equal(sv, si)
+    from tests.test_host_api import FakeTokenizer, RecordingEngine
+    from t2v_metrics_amd.config import get_config
+    ccfg = get_config("tiny")
+    img_only = t2v.VQAScore(model="clip-flant5-xl", device="cpu", config=ccfg, engine=RecordingEngine(ccfg), tokenizer=FakeTokenizer(ccfg.t5.vocab))
+    with pytest.raises(NotImplementedError, match="video-native"):
+        img_only.batch_forward(ds_v)
