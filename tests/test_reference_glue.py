@@ -8,9 +8,6 @@ this package's restatements on the same inputs: same ids, same pixels, same [M, 
 
 /root/reference does not exist on the GPU box: every test here skips there, and nothing under ``-m gpu`` depends on it.
 """
-import importlib
-import os
-import sys
 import types
 import zlib
 
@@ -23,31 +20,13 @@ import t2v_metrics_amd.constants as our_constants
 from t2v_metrics_amd.models.vqascore_models.mm_utils import expand2square, t5_tokenizer_image_token
 from t2v_metrics_amd.score import Score as OurScore
 
-REF_ROOT = "/root/reference/t2v_metrics"
-_PKG = "_t2v_reference_as_it_lies"
+from tests.reference_loader import reference_module
 
 
 def _reference():
     """``(constants, mm_utils, score)`` modules of the reference, loaded from where they lie."""
-    if not os.path.isfile(os.path.join(REF_ROOT, "score.py")):
-        pytest.skip("the reference tree is not on this machine")
-    if _PKG not in sys.modules:
-        for name, sub in ((_PKG, ""), (_PKG + ".models", "models"), (_PKG + ".models.vqascore_models", "models/vqascore_models")):
-            m = types.ModuleType(name)
-            m.__path__ = [os.path.join(REF_ROOT, sub)]      # a package whose __init__ is never executed
-            m.__package__ = name
-            sys.modules[name] = m
-        if "cv2" not in sys.modules:
-            try:
-                importlib.import_module("cv2")
-            except ImportError:                             # mm_utils imports it for the frame helpers, which are not called here
-                sys.modules["cv2"] = types.ModuleType("cv2")
-    try:
-        return (importlib.import_module(_PKG + ".constants"),
-                importlib.import_module(_PKG + ".models.vqascore_models.mm_utils"),
-                importlib.import_module(_PKG + ".score"))
-    except ImportError as e:                                # pragma: no cover - a dependency of the reference missing here
-        pytest.skip(f"the reference does not import here: {e}")
+    return (reference_module("constants"), reference_module("models.vqascore_models.mm_utils", optional=("cv2",)),
+            reference_module("score", optional=("cv2",)))
 
 
 class WordTokenizer:
