@@ -46,15 +46,29 @@ def kendall_tau_b(gold_scores, metric_scores) -> float:
     return float((con - dis) / np.sqrt(tot - xtie) / np.sqrt(tot - ytie))
 
 
+def tau_with_tie_optimization(gold_scores, metric_scores, sample_rate: float = 1.0,
+                              rng: Optional[np.random.RandomState] = None) -> Tuple[float, float]:
+    """tau23 = (concordant + tied-in-both - discordant - tied-in-one) / pairs under the same threshold search (calc_metric variant
+    "tau_with_tie_optimization", dataset.py:171-174; TauSufficientStats.tau_23, tau_optimization.py:60-67)."""
+    return _tie_search(gold_scores, metric_scores, sample_rate, rng, True)
+
+
 def pairwise_acc_with_tie_optimization(gold_scores, metric_scores, sample_rate: float = 1.0,
                                        rng: Optional[np.random.RandomState] = None) -> Tuple[float, float]:
-    """acc23 = (concordant + tied-in-both) / pairs, maximised over the tie threshold epsilon on the metric differences
-    (calc_metric variant "pairwise_acc_with_tie_optimization", dataset.py:151-166; tau_optimization.py:203-298).
+    """acc23 = (concordant + tied-in-both) / pairs, maximised over the tie threshold (calc_metric's default variant,
+    dataset.py:163-166; TauSufficientStats.acc_23, tau_optimization.py:69-70)."""
+    return _tie_search(gold_scores, metric_scores, sample_rate, rng, False)
+
+
+def _tie_search(gold_scores, metric_scores, sample_rate: float = 1.0, rng: Optional[np.random.RandomState] = None,
+                signed: bool = False) -> Tuple[float, float]:
+    """The threshold search of tau_optimization.py:203-298 for a statistic that is a sum over pairs: acc23 (a pair scores 1 or 0) or,
+    with `signed`, tau23 (+1 or -1).  The tie threshold epsilon on the metric differences is chosen to maximise the statistic.
     1-D inputs: one group.  2-D inputs [N items, M systems] (dataset.py:159-161 "group by item"): pairs are formed INSIDE each
     row, ONE global threshold is searched, and the statistic is the mean over rows of the row's accuracy -- each pair weighs
     1 / (rows x pairs of its row), which is what tau_optimization's per-row running sums add up to.
     Candidate thresholds: 0 and every distinct |metric difference|; a pair with |dm| <= epsilon counts as correct iff the gold
-    scores tie.  Returns (best accuracy, best threshold), the smallest threshold on ties of the maximum (np.nanargmax).
+    scores tie.  Returns (best value, best threshold), the smallest threshold on ties of the maximum (np.nanargmax).
     sample_rate < 1 subsamples pairs (approximate; the reference draws its sample pair by pair from np.random)."""
     if sample_rate <= 0 or sample_rate > 1:
         raise ValueError(f"`sample_rate` must be in the range (0, 1]. Found {sample_rate}")
@@ -85,6 +99,8 @@ def pairwise_acc_with_tie_optimization(gold_scores, metric_scores, sample_rate: 
     adm, dg, dm, wgt = adm[order], dg[order], dm[order], wgt[order]
     gold_tie = (dg == 0) * wgt
     conc = (((dg > 0) & (dm > 0)) | ((dg < 0) & (dm < 0))) * wgt
+    if signed:      # tau23: a pair that is not counted +1 counts -1 (discordant, or tied in exactly one of the two score lists)
+        gold_tie, conc = 2 * gold_tie - wgt, 2 * conc - wgt
     # accuracy when the first k pairs (smallest differences) are metric ties: gold ties among them + concordant among the rest
     tie_prefix = np.concatenate([[0], np.cumsum(gold_tie)])
     conc_suffix = np.concatenate([np.cumsum(conc[::-1])[::-1], [0]])
@@ -98,17 +114,54 @@ def pairwise_acc_with_tie_optimization(gold_scores, metric_scores, sample_rate: 
     return float(vals[first][best] * scale), float(uniq[best])
 
 
+def pairwise_acc_ignore_tie(gold_scores, metric_scores) -> Tuple[float, float]:
+    """concordant / (pairs - pairs tied only in the gold scores) with no threshold introduced (calc_metric variant
+    "pairwise_acc_ignore_tie", dataset.py:167-170 = ``result.taus[0], result.thresholds[0]``; TauSufficientStats.acc_ignore_tie,
+    tau_optimization.py:72-76), mean over rows.  A row whose every pair is tied only in the gold scores has no defined value (the
+    reference stops in a debugger there): ValueError."""
+    g, m = np.asarray(gold_scores, dtype=np.float64), np.asarray(metric_scores, dtype=np.float64)
+    if g.ndim == 1:
+        g, m = g[None], m[None]
+    i, j = np.triu_indices(g.shape[1], k=1)
+    dg, dm = g[:, i] - g[:, j], m[:, i] - m[:, j]
+    con = (((dg > 0) & (dm > 0)) | ((dg < 0) & (dm < 0))).sum(1)
+    den = dg.shape[1] - ((dg == 0) & (dm != 0)).sum(1)
+    if (den == 0).any():
+        raise ValueError("a row in which every pair is tied in the gold scores only has no accuracy")
+    return float(np.mean(con / den)), 0.0
+
+
+def kendall_tau_c(gold_scores, metric_scores) -> float:
+    """Kendall tau-c (KendallVariants variant 'c', dataset.py:136-138): 2 (C - D) / (n^2 (m - 1) / m), m = the smaller number of
+    distinct values of the two lists."""
+    g, m = np.asarray(gold_scores, dtype=np.float64), np.asarray(metric_scores, dtype=np.float64)
+    dg, dm = _pair_arrays(g, m)
+    con = int(((dg > 0) & (dm > 0) | (dg < 0) & (dm < 0)).sum())
+    dis = int(((dg > 0) & (dm < 0) | (dg < 0) & (dm > 0)).sum())
+    tot = dg.size
+    if int((dm == 0).sum()) == tot or int((dg == 0).sum()) == tot:
+        return float("nan")
+    classes = min(len(set(m.tolist())), len(set(g.tolist())))
+    return float(2 * (con - dis) / (g.size ** 2 * (classes - 1) / classes))
+
+
 def calc_metric(gold_scores, metric_scores, variant: str = "pairwise_acc_with_tie_optimization", sample_rate: float = 1.0):
-    """dataset.py:151-188 for the variants the GenAI-Bench tables use: "pairwise_acc_with_tie_optimization" -> (accuracy,
-    threshold); "tau_b" -> mean over rows of Kendall tau-b, NaN rows skipped.  1-D = one group, 2-D = grouped by item."""
+    """dataset.py:151-188, all five variants: "pairwise_acc_with_tie_optimization" / "tau_with_tie_optimization" -> (best value, best
+    threshold); "pairwise_acc_ignore_tie" -> (value, 0.0); "tau_b" / "tau_c" -> mean over rows, NaN rows skipped.  1-D = one group,
+    2-D = grouped by item (last dimension = systems)."""
     g, m = np.asarray(gold_scores), np.asarray(metric_scores)
     assert g.shape == m.shape
     if variant == "pairwise_acc_with_tie_optimization":
         return pairwise_acc_with_tie_optimization(g, m, sample_rate)
-    if variant == "tau_b":
+    if variant == "tau_with_tie_optimization":
+        return tau_with_tie_optimization(g, m, sample_rate)
+    if variant == "pairwise_acc_ignore_tie":
+        return pairwise_acc_ignore_tie(g, m)
+    if variant in ("tau_b", "tau_c"):
         if g.ndim == 1:
             g, m = g[None], m[None]
-        return float(np.nanmean(np.array([kendall_tau_b(a, b) for a, b in zip(g, m)])))
+        fn = kendall_tau_b if variant == "tau_b" else kendall_tau_c
+        return float(np.nanmean(np.array([fn(a, b) for a, b in zip(g, m)])))
     raise ValueError(f"unsupported variant {variant!r}")
 
 

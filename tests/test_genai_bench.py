@@ -124,3 +124,98 @@ def test_dataset_wrapper_and_cached_driver(tmp_path):
         GenAIBenchImage(root_dir=str(tmp_path / "nowhere"), num_prompts=1600)
     with pytest.raises(RuntimeError, match="no network"):
         GenAIBenchImage(root_dir=str(tmp_path / "nowhere"), num_prompts=1600, download=True)
+
+
+def _reference_dataset_module():
+    """/root/reference/dataset.py as it lies (its ``calc_metric`` imports ``tau_optimization`` by its top-level name; ``cv2`` is
+    imported at the top for the video datasets and never called here)."""
+    import importlib.util
+    import sys
+    import types
+    path = "/root/reference/dataset.py"
+    if not os.path.exists(path):
+        pytest.skip("reference tree not present")
+    sys.modules.setdefault("tau_optimization", _reference_tau_optimization())
+    if "cv2" not in sys.modules:
+        try:
+            import cv2  # noqa: F401
+        except ImportError:
+            sys.modules["cv2"] = types.ModuleType("cv2")
+    spec = importlib.util.spec_from_file_location("ref_dataset", path)
+    mod = importlib.util.module_from_spec(spec)
+    try:
+        spec.loader.exec_module(mod)
+    except ImportError as e:
+        pytest.skip(f"the reference's dataset.py does not import here: {e}")
+    return mod
+
+
+@pytest.mark.parametrize("variant", ["pairwise_acc_with_tie_optimization", "tau_with_tie_optimization", "pairwise_acc_ignore_tie",
+                                     "tau_b", "tau_c"])
+def test_calc_metric_equals_the_references_for_every_variant(variant):
+    """dataset.py:151-188 run next to ours: 1-D (one group) and 2-D (grouped by item) inputs, ratings that tie a lot, metric scores
+    with and without exact ties."""
+    from t2v_metrics_amd.genai_bench import calc_metric
+    ref = _reference_dataset_module()
+    rng = np.random.RandomState(11)
+    cases = []
+    for n in (5, 17, 60):
+        gold = rng.randint(1, 6, size=n).astype(float)
+        cases.append((gold, np.round(rng.rand(n) + 0.2 * gold, 2)))           # metric ties present
+        cases.append((gold, rng.rand(n) + 0.1 * gold))                       # none
+    for rows, cols in ((4, 6), (25, 6), (3, 12)):
+        gold = rng.randint(1, 6, size=(rows, cols)).astype(float)
+        gold[:, 0] += 0.5                                                    # no row is constant in gold
+        cases.append((gold, np.round(rng.rand(rows, cols) + 0.2 * gold, 1)))
+        cases.append((gold, rng.rand(rows, cols)))
+    for gold, metric in cases:
+        want = ref.calc_metric(gold, metric, variant=variant)
+        got = calc_metric(gold, metric, variant=variant)
+        if isinstance(want, tuple):
+            assert isinstance(got, tuple) and len(got) == 2
+            assert got[0] == pytest.approx(float(want[0]), rel=1e-12, abs=1e-12), (variant, gold.shape)
+            if variant == "pairwise_acc_ignore_tie":
+                assert got[1] == want[1] == 0.0
+            else:
+                # thresholds: only where the reference's maximum is unique under its running float sums (see the acc23 test above)
+                taus = np.asarray(sys_modules_tau().tau_optimization(
+                    metric if metric.ndim == 2 else metric[None], gold if gold.ndim == 2 else gold[None],
+                    getattr(sys_modules_tau().TauSufficientStats, "acc_23" if variant.startswith("pairwise") else "tau_23")).taus)
+                if (np.abs(taus - taus.max()) < 1e-12).sum() == 1:
+                    assert got[1] == pytest.approx(float(want[1]), rel=1e-12, abs=1e-15)
+        else:
+            assert got == pytest.approx(float(want), rel=1e-12, abs=1e-12), (variant, gold.shape)
+    with pytest.raises(ValueError):
+        calc_metric([1.0, 2.0], [1.0, 2.0], variant="tau_a")
+
+
+def sys_modules_tau():
+    import sys
+    return sys.modules["tau_optimization"]
+
+
+def test_dataset_wrapper_equals_the_references_class_on_the_same_directory(tmp_path, capsys):
+    """GenAIBench_Image (dataset.py:1225-1391) instantiated on the synthetic directory next to ours: same length, items, order,
+    correlation tables (whole set and per skill)."""
+    ref = _reference_dataset_module()
+    _make_dataset(str(tmp_path))
+    ours = GenAIBenchImage(root_dir=str(tmp_path), num_prompts=527)
+    theirs = ref.GenAIBench_Image(root_dir=str(tmp_path), num_prompts=527, download=False)
+    assert len(ours) == len(theirs)
+    for k in range(len(ours)):
+        assert ours[k] == theirs[k]
+    scores = torch.rand(len(ours), 1, 1, generator=torch.Generator().manual_seed(9))
+    a, b = ours.evaluate_scores(scores), theirs.evaluate_scores(scores)
+    assert set(a) == set(b) == {"alignment"}
+
+    def same(x, y):
+        assert set(x) == set(y) == {"pearson", "kendall_b", "pairwise_acc"}
+        assert x["pearson"] == pytest.approx(float(y["pearson"]), rel=1e-12)
+        assert x["kendall_b"] == pytest.approx(float(y["kendall_b"]), rel=1e-12)
+        assert x["pairwise_acc"][0] == pytest.approx(float(y["pairwise_acc"][0]), rel=1e-12)
+    same(a["alignment"], b["alignment"])
+    pa, pb = ours.evaluate_scores_per_skill(scores), theirs.evaluate_scores_per_skill(scores)
+    assert list(pa) == list(pb)
+    for tag in pa:
+        same(pa[tag]["alignment"], pb[tag]["alignment"])
+    capsys.readouterr()
