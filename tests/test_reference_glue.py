@@ -176,3 +176,21 @@ def test_batch_forward_rejects_ragged_samples_like_the_reference():
         ours.batch_forward(dataset, batch_size=1)
     with pytest.raises(Exception):                           # the reference trips in DataLoader collation or on its own assert
         theirs.batch_forward(dataset, batch_size=2)
+
+
+def test_image_loader_is_the_references(tmp_path):
+    """models/model.py:10-14: a .npy file holds BGR pixels (cv2 layout) and is flipped to RGB, everything else goes through PIL."""
+    from t2v_metrics_amd.models.model import image_loader
+    ref = reference_module("models.model")
+    rs = np.random.RandomState(8)
+    px = rs.randint(0, 256, (9, 13, 3), dtype=np.uint8)
+    np.save(tmp_path / "a.npy", px)
+    Image.fromarray(px).save(tmp_path / "a.png")
+    Image.fromarray(px[..., 0]).save(tmp_path / "grey.png")                      # mode L -> RGB
+    Image.fromarray(np.dstack([px, px[..., :1]]), "RGBA").save(tmp_path / "alpha.png")
+    Image.fromarray(px).save(tmp_path / "a.jpg", quality=90)
+    for name in ("a.npy", "a.png", "grey.png", "alpha.png", "a.jpg"):
+        ours, theirs = image_loader(str(tmp_path / name)), ref.image_loader(str(tmp_path / name))
+        assert ours.mode == theirs.mode == "RGB" and ours.size == theirs.size
+        assert np.array_equal(np.asarray(ours), np.asarray(theirs)), name
+    assert np.array_equal(np.asarray(image_loader(str(tmp_path / "a.npy"))), px[..., ::-1])
