@@ -85,6 +85,9 @@ class StubProcessor:
         medium, text = messages[0]["content"]
         return chat_prompt(text["text"], "<|video_pad|>" if medium["type"] == "video" else "<|image_pad|>")
 
+    def batch_decode(self, rows, skip_special_tokens=True, clean_up_tokenization_spaces=False):
+        return [self.tokenizer.decode(r, skip_special_tokens=skip_special_tokens) for r in rows]
+
     def __call__(self, text, images=None, videos=None, padding=True, return_tensors="pt", do_resize=False, **kw):
         assert len(text) == 1 and (images is None) != (videos is None) and do_resize is False
         return Inputs(input_ids=torch.tensor([self.tokenizer.encode(text[0], add_special_tokens=False)]))
@@ -98,8 +101,8 @@ class StubGenerator:
         self.stop_ids = list(stop_ids)
         self.calls = 0
 
-    def generate(self, input_ids, max_new_tokens, temperature, do_sample, output_scores, return_dict_in_generate):
-        assert temperature == 1.0 and do_sample is False and output_scores and return_dict_in_generate
+    def generate(self, input_ids, max_new_tokens, do_sample, temperature=1.0, output_scores=False, return_dict_in_generate=False):
+        assert temperature == 1.0 and do_sample is False and output_scores == return_dict_in_generate
         self.calls += 1
         prompt, gen, scores = input_ids[0].tolist(), [], []
         for _ in range(max_new_tokens):
@@ -108,6 +111,8 @@ class StubGenerator:
             gen.append(int(row.argmax()))
             if gen[-1] in self.stop_ids:
                 break
+        if not return_dict_in_generate:                       # the free-form generate() call: just the sequences
+            return torch.tensor([prompt + gen])
         return types.SimpleNamespace(sequences=torch.tensor([prompt + gen]), scores=tuple(scores))
 
 
@@ -247,3 +252,22 @@ def test_one_generation_per_pair_in_the_reference_one_tower_pass_per_medium_here
     a, b = ours.forward(images, texts), theirs.forward(images, texts)
     assert torch.allclose(a, b, rtol=2e-6, atol=1e-12)
     assert theirs.model.calls == 4 and sum(len(g) for g in seen) == 2          # 4 generate() calls there; 2 media encoded here
+
+
+def test_greedy_generate_returns_the_references_strings(tmp_path, media):
+    """generate() (:495-563) with temperature 0: the text is the whole user turn, greedy until a stop id or the budget, decoded without
+    special tokens and stripped."""
+    g = _first_tokens(TEXTS, 3)
+    for stops, special in (((), {}), ((g[0][2], g[1][1]), {"eos_token_id": g[1][1]})):
+        ours, theirs = _pair(tmp_path, stop_ids=stops, **special)
+        questions = [f'Does this figure show "{t}"? Please answer Yes or No.' for t in TEXTS]     # so that _first_tokens' script applies
+        for budget in (1, 3, 7):
+            a = ours.generate(media, questions, max_new_tokens=budget)
+            b = theirs.generate(media, questions, max_new_tokens=budget)
+            assert a == b and len(a) == 3 and all(isinstance(x, str) for x in a)
+        if stops:                                                                                  # stopped early where the script says so
+            full = ours.generate(media, questions, max_new_tokens=7)
+            assert len(full[0].split()) <= 3 and len(full[1].split()) <= 2 and len(full[2].split()) == 7
+    for m in _pair(tmp_path):
+        with pytest.raises(AssertionError, match="must match"):
+            m.generate(media, TEXTS[:1])

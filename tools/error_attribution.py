@@ -120,6 +120,15 @@ def main():
              # round 4's engine: the same classes with the decoder's sensitive tensors split-bf16 / fp32 (EngineRoundedOracle.DEC_SPLIT)
              ("engine with the precise decoder (round 4)", ALL, True),
              ("stack dec.* with the precise decoder (round 4)", tuple(c for c in ALL if stack_of(c) == "dec"), True)]
+    # what a further precise stage could buy at best: the round-4 engine with that stage's classes not rounded at all
+    without = lambda *drop: tuple(c for c in ALL if not any(c == d or (d.endswith(".*") and c.startswith(d[:-1])) for d in drop))
+    runs += [("what-if: precise decoder, proj.* exact", without("proj.*"), True),
+             ("what-if: precise decoder, vit.* exact", without("vit.*"), True),
+             ("what-if: precise decoder, vit.* proj.* exact", without("vit.*", "proj.*"), True),
+             ("what-if: precise decoder, vit.norm vit.delta exact", without("vit.norm", "vit.delta"), True),
+             ("what-if: precise decoder, vit.norm vit.delta vit.qkv exact", without("vit.norm", "vit.delta", "vit.qkv"), True),
+             ("what-if: precise decoder, enc.* exact", without("enc.*"), True),
+             ("what-if: precise decoder, vit.* proj.* enc.* exact", without("vit.*", "proj.*", "enc.*"), True)]
     runs = [r if len(r) == 3 else (r[0], r[1], False) for r in runs]
     if a.only:
         keep = set(a.only.split(";"))
