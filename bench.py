@@ -149,9 +149,100 @@ def device_code_hash(path=None):
     return None
 
 
+def _fatbin_section(path):
+    import struct
+    with open(path, "rb") as f:
+        b = f.read()
+    if b[:4] != b"\x7fELF" or b[4] != 2:
+        return None
+    shoff = struct.unpack_from("<Q", b, 0x28)[0]
+    shentsize, shnum, shstrndx = struct.unpack_from("<HHH", b, 0x3A)
+
+    def sh(i):
+        name, _typ, _flags, _addr, off, size = struct.unpack_from("<IIQQQQ", b, shoff + i * shentsize)
+        return name, off, size
+    _, stroff, strsize = sh(shstrndx)
+    names = b[stroff: stroff + strsize]
+    for i in range(shnum):
+        n, off, size = sh(i)
+        if names[n: names.index(b"\0", n)] == b".hip_fatbin":
+            return b[off: off + size]
+    return None
+
+
+def device_kernels(path=None):
+    """{kernel symbol: (machine code bytes, kernel descriptor bytes)} of every kernel in the gfx950 code objects of the shipped library:
+    the `.hip_fatbin` section is a sequence of clang offload bundles (one per translation unit), each holding one amdgcn ELF whose
+    symbol table names a FUNC symbol `<kernel>` in .text and an OBJECT symbol `<kernel>.kd` (64-byte descriptor: register counts, LDS
+    size, ...) in .rodata."""
+    import struct
+    path = path or os.path.join(ROOT, "t2v_metrics_amd", "libvqs_hip.so")
+    fb = _fatbin_section(path)
+    if fb is None:
+        return {}
+    out = {}
+    magic, at = b"__CLANG_OFFLOAD_BUNDLE__", 0
+    while True:
+        at = fb.find(magic, at)
+        if at < 0:
+            break
+        n_entries = struct.unpack_from("<Q", fb, at + 24)[0]
+        q = at + 32
+        for _ in range(n_entries):
+            off, size, tl = struct.unpack_from("<QQQ", fb, q)
+            triple = fb[q + 24: q + 24 + tl]
+            q += 24 + tl
+            if b"amdgcn" not in triple or size == 0:
+                continue
+            e = fb[at + off: at + off + size]
+            if e[:4] != b"\x7fELF":
+                continue
+            shoff = struct.unpack_from("<Q", e, 0x28)[0]
+            shentsize, shnum, _ = struct.unpack_from("<HHH", e, 0x3A)
+            secs = [struct.unpack_from("<IIQQQQII", e, shoff + i * shentsize) for i in range(shnum)]   # name type flags addr off size link info
+            for (_n, typ, _f, _a, soff, ssize, link, _i) in secs:
+                if typ != 2:                                   # SHT_SYMTAB
+                    continue
+                stab = secs[link]
+                strs = e[stab[4]: stab[4] + stab[5]]
+                syms = {}
+                for k in range(ssize // 24):
+                    st_name, st_info, _o, st_shndx, st_value, st_size = struct.unpack_from("<IBBHQQ", e, soff + 24 * k)
+                    if st_shndx == 0 or st_shndx >= shnum or st_size == 0:
+                        continue
+                    name = strs[st_name: strs.index(b"\0", st_name)].decode()
+                    sec = secs[st_shndx]
+                    lo = sec[4] + (st_value - sec[3])
+                    syms[name] = e[lo: lo + st_size]
+                for name, code in syms.items():
+                    if name + ".kd" in syms:
+                        out[name] = (code, syms[name + ".kd"])
+        at += len(magic)
+    return out
+
+
+def gemm_kernels_hash(path=None):
+    """sha256 over the machine code and the kernel descriptors of every GEMM kernel of the shipped library (`vqs::gemm_bf16_*`, the launches
+    `roofline.traffic` was measured on), by sorted symbol name.  Finer than device_code_hash(): it does not change when OTHER kernels are
+    added to or edited in the library, and changes with any instruction or register count of a GEMM kernel.  None without the library."""
+    import hashlib
+    ks = {n: v for n, v in device_kernels(path).items() if "gemm_bf16_" in n}
+    if not ks:
+        return None
+    h = hashlib.sha256()
+    for n in sorted(ks):
+        code, kd = ks[n]
+        kd = kd[:16] + b"\0" * 8 + kd[24:]          # kernel_code_entry_byte_offset: where the linker put the code, not what it is
+        h.update(n.encode() + b"\0" + code + b"\0" + kd)
+    return h.hexdigest()[:16]
+
+
 def traffic_stamp_matches(tj):
-    """Is the PMC record `tj` (profiles/gemm_traffic_*.json) about the code this process runs?  Device-code stamp if the record has
-    one, else the source stamp of older records.  -> (bool, description)."""
+    """Is the PMC record `tj` (profiles/gemm_traffic_*.json) about the code this process runs?  The stamp of the GEMM kernels' machine
+    code if the record has one, else the whole-library device-code stamp, else the source stamp of older records.  -> (bool, description)."""
+    if tj.get("gemm_kernels_sha256_16"):       # the measured kernels themselves (survives additions of other kernels to the library)
+        now = gemm_kernels_hash()
+        return tj["gemm_kernels_sha256_16"] == now, "GEMM kernels' code sha256 %s (now %s)" % (tj["gemm_kernels_sha256_16"], now)
     if tj.get("device_code_sha256_16"):
         now = device_code_hash()
         return tj["device_code_sha256_16"] == now, "device code sha256 %s (now %s)" % (tj["device_code_sha256_16"], now)

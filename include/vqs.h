@@ -201,6 +201,13 @@ int vqs_score_head(const float* d_logits, int32_t ldl, int32_t V, const int32_t*
  *   "dec_precise"  1 (default) the scoring decoder holds the activations that matter as split-bf16 / fp32 (16 significant bits
  *                  into the bf16 MFMA as two stacked row planes, fp32 partial sums: round 4), 0 the bf16 decoder
  *                  of rounds 1-3 (vqs_generate always runs that one)
+ *   "vit_fp16"     0 (default) the vision tower and the projector hold their 16-bit tensors in bf16, as the reference does
+ *                  (mm_utils.py:228); 1 IEEE fp16 instead: fp16 copies of their linear weights (made by vqs_bind_weights; bf16 -> fp16 is
+ *                  exact for 2^-14 <= |w| < 65 520), fp16 activations through the same kernels on fp16 MFMAs (same rate, same bytes),
+ *                  fp32 accumulation / residual stream / statistics unchanged, the feature tensor still bf16 (one cast at the end).  11
+ *                  significant bits instead of 8 where the error attribution (profiles/r4_error_attribution.md) puts most of what is
+ *                  left of the end-to-end |delta log P|.  CLIP was trained in fp16; the T5 stack is not fp16-safe and is not touched.
+ *                  Needs gemm_variant 3.  Set it before asking for the encode workspace size (one more buffer).
  *   "stream_gemm"  1 (default) skinny batched GEMMs (<= 128 rows per entry: the reassociated cross-attention's two products over
  *                  the encoder output) run the HBM-streaming form (csrc/gemm_stream.inc), 0 the persistent 256-row kernel;
  *                  bitwise equal

@@ -151,10 +151,10 @@ def tiled_attention(q, k, v, scale: float, bias_table=None, key_len=None, round_
     return out.transpose(1, 2).reshape(B, S, H * d)
 
 
-def compare_tap(y: torch.Tensor, e: torch.Tensor, valid: torch.Tensor | None = None) -> dict:
+def compare_tap(y: torch.Tensor, e: torch.Tensor, valid: torch.Tensor | None = None, mant_bits: int = 7) -> dict:
     """Distance of an oracle result `y` from the engine's tensor `e` of the same launch (both fp32, same shape), over the
-    `valid` elements if given.  Per-element measure: the difference in units of the element's OWN bf16 ulp (2^(exponent - 7)
-    of the larger of the two values) plus an absolute floor of 2^-18 of the tensor's top value -- the fp32 summation noise a
+    `valid` elements if given.  Per-element measure: the difference in units of the element's OWN ulp in the tensor's 16-bit type
+    (bf16: 2^(exponent - 7) of the larger of the two values; `mant_bits` = 10 for an fp16 tensor) plus an absolute floor of 2^-18 of the tensor's top value -- the fp32 summation noise a
     result that cancels to nearly nothing still carries.  An absmax-relative bound alone lets a defect confined to small
     elements through."""
     d = (y - e).abs()
@@ -166,9 +166,12 @@ def compare_tap(y: torch.Tensor, e: torch.Tensor, valid: torch.Tensor | None = N
         n = d.numel()
         ref_abs = float(e.abs().max())
     big = torch.maximum(y.abs(), e.abs())
-    own_ulp = torch.ldexp(torch.ones_like(big), torch.frexp(big).exponent - 8)
+    # bf16: 7 stored mantissa bits; an fp16 tensor (mant_bits = 10, the fp16 vision tower): 10, and nothing finer than its subnormal grid 2^-24
+    own_ulp = torch.ldexp(torch.ones_like(big), torch.frexp(big).exponent - 1 - mant_bits)
+    if mant_bits == 10:
+        own_ulp = own_ulp.clamp_min(2.0 ** -24)
     own = d / (own_ulp + ref_abs * 2.0 ** -18 + 1e-37)
-    return {"frac_diff": float((d > 0).sum()) / max(n, 1), "max_abs": float(d.max()), "ref_absmax": ref_abs, "n": n,
+    return {"frac_diff": float((d > 0).sum()) / max(n, 1), "max_abs": float(d.max()), "ref_absmax": ref_abs, "n": n, "mant_bits": mant_bits,
             "max_own_ulps": float(own.max()), "frac_over_1_own_ulp": float((own > 1.0).sum()) / max(n, 1)}
 
 
@@ -191,12 +194,33 @@ class EngineRoundedOracle(Oracle):
     DEC_SPLIT = ("dec.norm", "dec.sattn", "dec.cctx", "dec.cattn", "dec.act", "dec.out")
     DEC_FP32 = ("dec.qkv", "dec.delta")
 
-    def __init__(self, cfg, weights, emulate="engine", round_fn=bf16_round, acc=torch.float64, classes=None, dec_precise=True):
+    def __init__(self, cfg, weights, emulate="engine", round_fn=bf16_round, acc=torch.float64, classes=None, dec_precise=True,
+                 split_classes=(), half_classes=(), vit_fp16=False):
+        """`split_classes`: classes (of the tower / projector / encoder) to model as split-bf16 tensors instead of bf16 ones -- a
+        what-if for tools/error_attribution.py, nothing the engine does today; the extra name "vit.v" splits the value heads only
+        (q and k stay bf16: the score path).  `half_classes`: classes to model as IEEE fp16 tensors (11 significant bits instead of
+        8, same MFMA rate); the weights of a stack with a half class are then fp16 too (bf16 -> fp16 is exact above 2^-14).
+        `vit_fp16` = the engine's option of that name (vqs_set_option "vit_fp16"): every class of the tower and the projector's hidden
+        tensor are fp16, the linear weights of both are the fp16 copies (the patch embedding keeps bf16 operands), and the projector's
+        output is rounded to fp16 by its GEMM and then to bf16 by the cast into the C ABI's feature tensor."""
         super().__init__(cfg, weights)
         self.r = round_fn
         self.acc = acc
         self.dec_precise = bool(dec_precise)
         self.r2 = split_bf16_round if round_fn is bf16_round else round_fn
+        unknown = set(split_classes) - set(self.CLASSES) - {"vit.v"}
+        if unknown:
+            raise ValueError(f"unknown split classes {sorted(unknown)}")
+        self.split_extra = frozenset(split_classes)
+        unknown = set(half_classes) - set(self.CLASSES)
+        if unknown:
+            raise ValueError(f"unknown half classes {sorted(unknown)}")
+        self.vit_fp16 = bool(vit_fp16)
+        if self.vit_fp16:
+            half_classes = tuple(half_classes) + tuple(c for c in self.CLASSES if c.startswith("vit.")) + ("proj.mid",)
+        self.half_extra = frozenset(half_classes)
+        self.half_stacks = frozenset(c.split(".")[0] for c in self.half_extra)
+        self.rh = (lambda x: x.to(torch.float16).to(torch.float32)) if round_fn is bf16_round else round_fn
         if classes is not None:
             unknown = set(classes) - set(self.CLASSES)
             if unknown:
@@ -216,9 +240,10 @@ class EngineRoundedOracle(Oracle):
             return y
         if name not in self.locked:
             raise KeyError(f"stage-locked run needs the engine tap {name!r}")
+        mant = 10 if self.locked[name].dtype == torch.float16 else 7
         e = self.locked[name].detach().to("cpu", torch.float32)
         e = e.reshape(-1)[: y.numel()].reshape(y.shape) if e.numel() >= y.numel() and e.shape != y.shape else e
-        self.report[name] = compare_tap(y, e, valid)
+        self.report[name] = compare_tap(y, e, valid, mant)
         return e
 
     # ---------------------------------------------------------------------------------------------- helpers
@@ -229,16 +254,23 @@ class EngineRoundedOracle(Oracle):
             return x
         if self.dec_precise and cls in self.DEC_FP32:
             return x
-        if self.dec_precise and cls in self.DEC_SPLIT:
+        if (self.dec_precise and cls in self.DEC_SPLIT) or cls in self.split_extra:
             return self.r2(x)
+        if cls in self.half_extra:
+            return self.rh(x)
         return self.r(x)
 
     def rcf(self, cls: str):
-        return self.r if self.classes is None or cls in self.classes else (lambda x: x)
+        if self.classes is not None and cls not in self.classes:
+            return lambda x: x
+        return self.r2 if cls in self.split_extra else self.rh if cls in self.half_extra else self.r
 
     def _mm(self, x: torch.Tensor, wname: str, bname: str | None = None) -> torch.Tensor:
         """fp32 accumulator of an nn.Linear over bf16 operands (+ bias added in fp32, as the GEMM epilogues do)."""
         w = self.w[wname].detach().to("cpu")
+        stack = {"vision": "vit", "mm_projector": "proj"}.get(wname.split(".")[0])
+        if stack in self.half_stacks and "patch_embedding" not in wname:
+            w = w.to(torch.float16)                 # what a bf16 checkpoint becomes in an fp16 tower
         w = w.reshape(w.shape[0], -1).to(self.acc)
         y = (x.to(self.acc) @ w.t()).float()
         if bname is not None:
@@ -263,7 +295,9 @@ class EngineRoundedOracle(Oracle):
             xn = self._emit(t + "xn0", rc("vit.norm", layer_norm(h, self._w(pfx + "layer_norm1.weight"), self._w(pfx + "layer_norm1.bias"), v.ln_eps)))
 
             def heads(nm):
-                y = rc("vit.qkv", self._mm(xn, pfx + f"self_attn.{nm}_proj.weight", pfx + f"self_attn.{nm}_proj.bias"))
+                y = self._mm(xn, pfx + f"self_attn.{nm}_proj.weight", pfx + f"self_attn.{nm}_proj.bias")
+                value_split = nm == "v" and "vit.v" in self.split_extra and (self.classes is None or "vit.qkv" in self.classes)
+                y = self.r2(y) if value_split else rc("vit.qkv", y)
                 return self._emit(t + nm, y.reshape(B, S, v.heads, v.head_dim).transpose(1, 2))
 
             att = tiled_attention(heads("q"), heads("k"), heads("v"), v.head_dim ** -0.5, None, None, self.rcf("vit.p"), self.acc,
@@ -280,7 +314,10 @@ class EngineRoundedOracle(Oracle):
     def projector(self, feats: torch.Tensor) -> torch.Tensor:
         rc = self.rc
         x = self._emit("vit.pmid", rc("proj.mid", gelu_erf(self._mm(feats, "mm_projector.0.weight", "mm_projector.0.bias"))))
-        return self._emit("proj", rc("proj.out", self._mm(x, "mm_projector.2.weight", "mm_projector.2.bias")))
+        y = self._mm(x, "mm_projector.2.weight", "mm_projector.2.bias")
+        if self.vit_fp16 and (self.classes is None or "proj.out" in self.classes):
+            y = self.rh(y)                          # the fp16 GEMM result, before the cast to the bf16 feature tensor
+        return self._emit("proj", rc("proj.out", y))
 
     # ---------------------------------------------------------------------------------------------- T5
     def _gated_ff(self, prefix: str, xn: torch.Tensor, cls: str = "enc.act") -> torch.Tensor:
@@ -421,12 +458,13 @@ class EngineRoundedOracle(Oracle):
         NS, NP, S = n_img * v.seq, n_img * v.n_patches, L - 1 + v.n_patches
         M, MT, Sp = B * S, B * T, self._s_pad(S)
         bf, f32 = torch.bfloat16, torch.float32
+        vt = torch.float16 if self.vit_fp16 else bf             # the tower's 16-bit tensors
         out = {"vit.patch_out": ((NP, v.hidden), f32), "vit.h0": ((NS, v.hidden), f32),
-               "vit.feat_in": ((NP, v.hidden), bf), "vit.pmid": ((NP, t.d_model), bf),
+               "vit.feat_in": ((NP, v.hidden), vt), "vit.pmid": ((NP, t.d_model), vt),
                "enc.emb": ((M, t.d_model), f32), "dec.emb": ((MT, t.d_model), f32)}
         for i in range(v.layers_run):
             for nm in self.TAP_NAMES_VIT:
-                out[f"vit.{i}.{nm}"] = ((NS, v.mlp if nm == "mid" else v.hidden), bf)
+                out[f"vit.{i}.{nm}"] = ((NS, v.mlp if nm == "mid" else v.hidden), vt)
         for i in range(t.layers):
             for nm in self.TAP_NAMES_ENC:
                 out[f"enc.{i}.{nm}"] = ((M, {"ff": t.d_ff, "xn0": t.d_model, "xn1": t.d_model, "d_attn": t.d_model, "d_ff": t.d_model}.get(nm, t.inner)), bf)

@@ -46,6 +46,17 @@ __device__ __forceinline__ uint32_t a_pack2(float a, float b) {   // v_cvt_pk_bf
     return __builtin_bit_cast(uint32_t, v);
 }
 
+// fp16 operand forms (AttnParams::f16: the fp16 vision tower): the 32x32x16 MFMA takes bf16 or fp16 fragments in the same layout at the
+// same rate; P and the output are packed to the operand type
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 a_f16x2;
+__device__ __forceinline__ uint32_t a_pack2h(float a, float b) {   // two v_cvt_f16_f32 (RNE) + v_pack_b32_f16
+    a_f16x2 v;
+    v[0] = (_Float16)a;
+    v[1] = (_Float16)b;
+    return __builtin_bit_cast(uint32_t, v);
+}
+
 // v_max3_f32 without the IEEE-mode operand canonicalisation (v_max_f32 x, x) that fmaxf() costs per input:
 // the scores are finite by construction (masking uses NEG_BIG, not -inf)
 // max over the two half-waves (lane <-> lane ^ 32) without the LDS round trip of __shfl_xor (ds_bpermute_b32 + a
@@ -167,285 +178,25 @@ __device__ __forceinline__ unsigned long long a_now() {
 #ifndef VQS_ATTN_BIAS_ACC
 #define VQS_ATTN_BIAS_ACC 0
 #endif
-template <bool HAS_BIAS>
-__global__ void __launch_bounds__(256) attn_fwd_dma_kernel(const AttnParams p) {
-    constexpr bool BIAS_ACC = VQS_ATTN_BIAS_ACC != 0;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* bias_s = reinterpret_cast<float*>(smem + 2 * ST_BYTES);
-    const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)A_LDS_PTR(smem));
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int hh = lane >> 5;
-#if VQS_ATTN_TIMING
-    unsigned long long t_acc[6] = {0, 0, 0, 0, 0, 0};
-    unsigned long long t_tiles = 0;
-#endif
-    A_T(t_start);
-    // XCD-aware work map (workgroup L runs on XCD L % 8): the q-blocks of one (sample, head) get consecutive slots of
-    // ONE XCD, so its K/V tiles are fetched from HBM once and re-read from that XCD's L2 -- with the natural 3-D
-    // grid the 5 q-blocks landed on 5 different XCDs and the PMC showed K/V crossing the fabric 5 times
-    // (6.9 GB per T5-XL call, 4.6 TB/s: the kernel was fabric-bound).
-    const int S = p.S;
-    const int nqb = (S + 127) >> 7;
-    const int slot = blockIdx.x >> 3;
-    const int qb = slot % nqb;
-    const int g = (slot / nqb) * 8 + (blockIdx.x & 7);
-    if (g >= p.B * p.H) return;
-    const int b = g / p.H, h = g - b * p.H;
-    const size_t bh = (size_t)b * p.H + h;
-    const bf16_t* Q = p.q + bh * S * 64;
-    const bf16_t* K = p.k + bh * S * 64;
-    const bf16_t* V = p.v + bh * S * 64;
-    const int klen = p.key_len ? min(p.key_len[b], S) : S;
-    const int ntiles = (klen + KT - 1) / KT;
-
-    constexpr float LOG2E = 1.4426950408889634f;
-    const int bias_cs = bias_copy_chunks(S);
-    // BIAS_ACC: the table holds bias / scale and is the INITIAL VALUE of the score accumulators (the matrix pipe adds it);
-    // otherwise it holds bias * log2 e and is added by an FMA per score after the product
-    if (HAS_BIAS) fill_bias_copies(bias_s, p.bias_table + (size_t)h * (2 * S - 1), 2 * S - 1, bias_cs * 4, tid, BIAS_ACC ? 1.0f / p.scale : LOG2E);
-    const float sl2 = p.scale * LOG2E;
-
-    const int qrow = qb * 128 + wv * 32 + (lane & 31);
-    const int qrow_c = min(qrow, S - 1);
-    uint4 qf[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-        qf[ks] = *reinterpret_cast<const uint4*>(Q + (size_t)qrow_c * 64 + 16 * ks + 8 * hh);
-
-    // ---- staging: wave wv issues K pieces wv, wv+4 (8 keys each) and V sub-tiles (kh = 0 / 1, db = wv)
-    const a_v4i rsK = a_make_rsrc(K), rsV = a_make_rsrc(V);
-    int k_row[2], v_row[2];
-    uint32_t k_col[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int r = 8 * (wv + 4 * j) + (lane >> 3);
-        k_row[j] = r;
-        k_col[j] = (uint32_t)(((lane & 7) ^ ((r >> 1) & 7)) << 4);
-        v_row[j] = 32 * j + 4 * (((lane >> 3) - (wv & 1)) & 7) + ((lane >> 1) & 3);
-    }
-    const uint32_t v_col = (uint32_t)((16 * wv + 8 * (lane & 1)) * 2);
-    auto stage = [&](int kt, int st) {
-        const int kb = kt * KT;
-        const uint32_t sb = lds_base + st * ST_BYTES;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            a_bglds16(rsK, (uint32_t)min(kb + k_row[j], S - 1) * 128u + k_col[j], sb + (wv + 4 * j) * 1024);
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            a_bglds16(rsV, (uint32_t)min(kb + v_row[j], S - 1) * 128u + v_col, sb + 8192 + (4 * j + wv) * 1024);
-    };
-
-    f32x16 o[2];
-#pragma unroll
-    for (int df = 0; df < 2; ++df)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[df][r] = 0.0f;
-    f32x16 osum;                                  // every row = sum over keys of P[key][query] (ones . P^T)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) osum[r] = 0.0f;
-    float m_run = NEG_BIG;
-    uint4 ones;
-    ones.x = ones.y = ones.z = ones.w = 0x3f803f80u;      // bf16 1.0 x 8
-
-    const int swr = (lane >> 1) & 7;
-    const int jb = 4 * hh - qrow_c + (S - 1);
-    const char* bias_rd = reinterpret_cast<const char*>(bias_s) + (jb & 3) * bias_cs * 16 + (jb & ~3) * 4;
-    const int k_rd = (lane & 31) * 128;
-    // transpose-read addressing: 16-lane group g = lane>>4 -> (half = g>>1 = hh, d half dbl = g&1); lane tq = lane&15
-    // supplies row tq>>2, 8-B column slot tq&3 of its group's [4 keys][16 d] block
-    const int dbl = (lane >> 4) & 1, tq = lane & 15;
-    int v_rd[4];                                  // [2*t + rd]: block (4t + hh + 2rd), rotated by dbl
-#pragma unroll
-    for (int xi = 0; xi < 4; ++xi)
-        v_rd[xi] = 8192 + dbl * 1024 + (((2 * xi + hh + dbl) & 7) << 7) + (tq >> 2) * 32 + (tq & 3) * 8;
-
-    // The Q fragments must be "arrived" for the compiler BEFORE the loop: otherwise it parks its s_waitcnt vmcnt(n) for
-    // them inside the loop body, where every iteration they would also drain the next tile's in-flight DMA.
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[ks].x), "+v"(qf[ks].y), "+v"(qf[ks].z), "+v"(qf[ks].w));
-    if (ntiles > 0) stage(0, 0);
-    A_T(t_pro);
-    A_ACC(4, t_pro, t_start);
-    for (int kt = 0; kt < ntiles; ++kt) {
-        const int st = kt & 1;
-        A_T(t0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of tile kt have landed
-        __syncthreads();                                       // ... everybody's; stage st^1 is no longer read
-        if (kt + 1 < ntiles) stage(kt + 1, st ^ 1);
-        const char* k_lds = smem + st * ST_BYTES;
-        A_T(t1);
-        A_ACC(0, t1, t0);
-
-        // ---- S^T = K . Q^T   (i <-> key, j <-> query)
-        const int kb = kt * KT;
-        f32x16 s[2];
-        if (HAS_BIAS && BIAS_ACC) {
-            // accumulators start at bias[key - query] / scale: eight ds_read_b128 straight into the C operand of the first
-            // MFMAs, no per-score add afterwards (the softmax below is then the bias-free form: ONE FMA + v_exp_f32 per score)
-            const char* bp = bias_rd + kb * 4;
-#pragma unroll
-            for (int kf = 0; kf < 2; ++kf)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float4 bv = *reinterpret_cast<const float4*>(bp + kf * 128 + g * 32);
-                    s[kf][4 * g + 0] = bv.x;
-                    s[kf][4 * g + 1] = bv.y;
-                    s[kf][4 * g + 2] = bv.z;
-                    s[kf][4 * g + 3] = bv.w;
-                }
-        } else {
-#pragma unroll
-            for (int kf = 0; kf < 2; ++kf)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s[kf][r] = 0.0f;
-        }
-        {
-            uint4 kfr[4][2];
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int kf = 0; kf < 2; ++kf)
-                    kfr[ks][kf] = *reinterpret_cast<const uint4*>(k_lds + kf * 4096 + k_rd + (((2 * ks + hh) ^ swr) << 4));
-            // all sixteen LDS reads of the tile (bias + K fragments) in flight before the first MFMA: left alone the scheduler
-            // reuses two fragment registers and waits lgkmcnt(0) in front of every MFMA pair
-            if (HAS_BIAS && BIAS_ACC) __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int kf = 0; kf < 2; ++kf)
-                    s[kf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kfr[ks][kf]),
-                                                                    __builtin_bit_cast(bf16x8, qf[ks]), s[kf], 0, 0, 0);
-        }
-
-        // ---- softmax numerators.  With a bias the scores move to the log2 domain first (t = s*c + bias, c = scale*log2 e,
-        // one FMA) and p = 2^(t - m) is a subtract + v_exp_f32; without one the row max is taken on the raw scores
-        // (c > 0) and p = 2^(s*c - m) is ONE FMA + v_exp_f32.  The row SUM is not accumulated here: the PV step
-        // below gets it from the matrix pipe (an all-ones A operand), which has slack while the VALU does not.
-        constexpr bool LOG2_DOMAIN = HAS_BIAS && !BIAS_ACC;      // scores already hold s*c + bias*log2 e before the max
-        if (LOG2_DOMAIN) {
-            const char* bp = bias_rd + kb * 4;
-#pragma unroll
-            for (int kf = 0; kf < 2; ++kf)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float4 bv = *reinterpret_cast<const float4*>(bp + kf * 128 + g * 32);
-                    s[kf][4 * g + 0] = fmaf(s[kf][4 * g + 0], sl2, bv.x);
-                    s[kf][4 * g + 1] = fmaf(s[kf][4 * g + 1], sl2, bv.y);
-                    s[kf][4 * g + 2] = fmaf(s[kf][4 * g + 2], sl2, bv.z);
-                    s[kf][4 * g + 3] = fmaf(s[kf][4 * g + 3], sl2, bv.w);
-                }
-        }
-#if VQS_ATTN_TIMING
-        asm volatile("" : "+v"(s[0][0]), "+v"(s[1][15]));      // the scores exist before the clock is read
-#endif
-        A_T(t2);
-        A_ACC(1, t2, t1);
-        if (kb + KT > klen) {                       // wave-uniform: only the last tile of a sample is ragged
-#pragma unroll
-            for (int kf = 0; kf < 2; ++kf)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = kb + kf * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    if (key >= klen) s[kf][r] = NEG_BIG;
-                }
-        }
-#define VQS_SV(i) s[(i) >> 4][(i) & 15]
-        float mx = a_max3(VQS_SV(0), VQS_SV(1), VQS_SV(2));
-#pragma unroll
-        for (int i = 3; i < 31; i += 2) mx = a_max3(mx, VQS_SV(i), VQS_SV(i + 1));
-        mx = fmaxf(mx, VQS_SV(31));
-#undef VQS_SV
-        mx = a_max_xhalf(mx);
-        if (!LOG2_DOMAIN) mx *= sl2;                // to the log2 domain (scale > 0)
-        // keep the old running max while the new one is at most 2^RESCALE_THR above it; rescale only on a real jump
-        if (__any(mx > m_run + RESCALE_THR)) {
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            m_run = m_new;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                o[0][r] *= alpha;
-                o[1][r] *= alpha;
-                osum[r] *= alpha;
-            }
-        }
-        const float neg_m = -m_run;
-#if VQS_ATTN_TIMING
-        asm volatile("" : "+v"(o[0][0]), "+v"(osum[0]));
-#endif
-        A_T(t3);
-        A_ACC(2, t3, t2);
-#pragma unroll
-        for (int kf = 0; kf < 2; ++kf)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                s[kf][r] = __builtin_amdgcn_exp2f(LOG2_DOMAIN ? s[kf][r] + neg_m : fmaf(s[kf][r], sl2, neg_m));
-        // ---- O^T += V^T . P^T   (i <-> d, j <-> query, k-slot (half,j) <-> key 16t + 4*half + 8*(j>>2) + (j&3))
-#pragma unroll
-        for (int kf = 0; kf < 2; ++kf)
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                uint4 pb;
-                pb.x = a_pack2(s[kf][8 * t + 0], s[kf][8 * t + 1]);
-                pb.y = a_pack2(s[kf][8 * t + 2], s[kf][8 * t + 3]);
-                pb.z = a_pack2(s[kf][8 * t + 4], s[kf][8 * t + 5]);
-                pb.w = a_pack2(s[kf][8 * t + 6], s[kf][8 * t + 7]);
-                osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, pb),
-                                                                osum, 0, 0, 0);
-#pragma unroll
-                for (int df = 0; df < 2; ++df) {
-                    const char* vp = k_lds + kf * 4096 + df * 2048;
-                    const a_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) a_v4s*)A_LDS_PTR(vp + v_rd[2 * t + 0]));
-                    const a_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) a_v4s*)A_LDS_PTR(vp + v_rd[2 * t + 1]));
-                    const uint2 lo2 = __builtin_bit_cast(uint2, lo), hi2 = __builtin_bit_cast(uint2, hi);
-                    uint4 va;
-                    va.x = lo2.x; va.y = lo2.y; va.z = hi2.x; va.w = hi2.y;
-                    o[df] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, va),
-                                                                   __builtin_bit_cast(bf16x8, pb), o[df], 0, 0, 0);
-                }
-            }
-#if VQS_ATTN_TIMING
-        asm volatile("" : "+v"(o[0][0]), "+v"(o[1][15]), "+v"(osum[0]));
-        {
-            A_T(t4);
-            A_ACC(3, t4, t3);
-            ++t_tiles;
-        }
-#endif
-    }
-    A_T(t_loop_end);
-
-    const float l_tot = osum[0];                  // all 32 rows of the ones-product are the same row sum
-    const float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
-    if (qrow < S) {
-        bf16_t* orow = p.out + ((size_t)b * S + qrow) * ((size_t)p.H * 64) + h * 64;
-#pragma unroll
-        for (int df = 0; df < 2; ++df)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                uint2 v;
-                v.x = a_pack2(o[df][4 * g + 0] * inv, o[df][4 * g + 1] * inv);
-                v.y = a_pack2(o[df][4 * g + 2] * inv, o[df][4 * g + 3] * inv);
-                *reinterpret_cast<uint2*>(orow + df * 32 + 8 * g + 4 * hh) = v;
-            }
-    }
-#if VQS_ATTN_TIMING
-    {
-        A_T(t_end);
-        A_ACC(5, t_end, t_loop_end);
-        if (g_attn_timing != nullptr && lane == 0) {
-            for (int i = 0; i < 6; ++i) atomicAdd(g_attn_timing + i, t_acc[i]);
-            atomicAdd(g_attn_timing + 6, t_tiles);
-            atomicAdd(g_attn_timing + 7, 1ull);
-        }
-    }
-#endif
-}
+#define ATTN_DMA_KERNEL attn_fwd_dma_kernel
+#define ATTN_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0)
+#define ATTN_PACK2(x, y) a_pack2(x, y)
+#define ATTN_ONES 0x3f803f80u
+#include "attn_dma_kernel.inc"
+#undef ATTN_DMA_KERNEL
+#undef ATTN_MFMA
+#undef ATTN_PACK2
+#undef ATTN_ONES
+// the same kernel on IEEE fp16 q / k / v with an fp16 output (AttnParams::f16: the fp16 vision tower)
+#define ATTN_DMA_KERNEL attn_fwd_dma_f16_kernel
+#define ATTN_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0)
+#define ATTN_PACK2(x, y) a_pack2h(x, y)
+#define ATTN_ONES 0x3c003c00u
+#include "attn_dma_kernel.inc"
+#undef ATTN_DMA_KERNEL
+#undef ATTN_MFMA
+#undef ATTN_PACK2
+#undef ATTN_ONES
 
 #if VQS_ATTN_TIMING
 hipError_t lab_set_attn_timing(unsigned long long* d_buf) { return hipMemcpyToSymbol(HIP_SYMBOL(g_attn_timing), &d_buf, sizeof(d_buf)); }
@@ -690,6 +441,7 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
     if (p.B <= 0 || p.H <= 0 || p.S <= 0) return hipErrorInvalidValue;
     if (p.hd == 128) {
         const int Hkv = p.Hkv > 0 ? p.Hkv : p.H;
+        if (p.f16) return hipErrorInvalidValue;
         if (p.bias_table != nullptr || Hkv <= 0 || (p.H % Hkv) != 0) return hipErrorInvalidValue;
         if (p.out_hd < 0 || p.out_hd > 128 || (p.out_hd & 3)) return hipErrorInvalidValue;
         const size_t lds = 2 * 2 * (size_t)KT * 128 * 2;            // two stages of K + V tiles
@@ -700,6 +452,8 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
     if (p.causal || (p.Hkv > 0 && p.Hkv != p.H)) return hipErrorInvalidValue;
     const size_t bias_bytes = p.bias_table ? (size_t)bias_copy_chunks(p.S) * 64 : 0;
     const size_t lds = 2 * ST_BYTES + bias_bytes;
+    if (p.f16)      // fp16 q / k / v / out: the vision tower (no position bias there)
+        return p.bias_table ? hipErrorInvalidValue : launch_attn_t(attn_fwd_dma_f16_kernel<false>, p, lds, stream);
     return p.bias_table ? launch_attn_t(attn_fwd_dma_kernel<true>, p, lds, stream)
                         : launch_attn_t(attn_fwd_dma_kernel<false>, p, lds, stream);
 }

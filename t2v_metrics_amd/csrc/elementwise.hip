@@ -53,6 +53,30 @@ __device__ __forceinline__ uint32_t e_pack2_hw(float a, float b) {   // v_cvt_pk
     return __builtin_bit_cast(uint32_t, v);
 }
 
+// IEEE fp16 forms of the two conversions (the fp16 vision tower: deltas in, operand out)
+typedef __attribute__((ext_vector_type(4))) _Float16 e_f16x4;
+typedef __attribute__((ext_vector_type(2))) _Float16 e_f16x2;
+__device__ __forceinline__ float4 h4_to_f4(uint2 u) {
+    const e_f16x4 h = __builtin_bit_cast(e_f16x4, u);
+    return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+}
+__device__ __forceinline__ uint32_t e_pack2_h(float a, float b) {    // two v_cvt_f16_f32 (RNE; overflow -> inf) + v_pack_b32_f16
+    e_f16x2 v;
+    v[0] = (_Float16)a;
+    v[1] = (_Float16)b;
+    return __builtin_bit_cast(uint32_t, v);
+}
+template <bool F16>
+__device__ __forceinline__ float4 d4_to_f4(uint2 u) {
+    if constexpr (F16) return h4_to_f4(u);
+    else return bf4_to_f4(u);
+}
+template <bool F16>
+__device__ __forceinline__ uint32_t e_pack2_t(float a, float b) {
+    if constexpr (F16) return e_pack2_h(a, b);
+    else return e_pack2_hw(a, b);
+}
+
 // The fp32 stream is touched once per norm and not again before gigabytes of other traffic have passed: its loads and
 // stores are non-temporal (in situ +0.4 % for the loads alone, 0 for the stores alone, +0.76 % for both against cached
 // accesses, profiles/r1_call88_ab_norm_nt.txt), which leaves L2 / Infinity Cache to the bf16 operands the GEMMs read
@@ -72,8 +96,8 @@ __device__ __forceinline__ void st_stream(float4* p, float4 v) {
     __builtin_nontemporal_store(u, reinterpret_cast<e_f4v*>(p));
 }
 
-// KIND 0: RMSNorm (bsh unused); KIND 1: LayerNorm.
-template <int NV, int KIND, int ADD, bool OUT_F32>
+// KIND 0: RMSNorm (bsh unused); KIND 1: LayerNorm.  F16: the deltas and the 16-bit output are IEEE fp16 (w, bsh stay bf16).
+template <int NV, int KIND, int ADD, bool OUT_F32, bool F16 = false>
 __global__ void __launch_bounds__(256) norm_rows_reg_kernel(float* __restrict__ x, const bf16_t* __restrict__ delta,
                                                             const bf16_t* __restrict__ delta2,
                                                             const bf16_t* __restrict__ w, const bf16_t* __restrict__ bsh,
@@ -98,7 +122,7 @@ __global__ void __launch_bounds__(256) norm_rows_reg_kernel(float* __restrict__ 
             for (int j = 0; j < NV; ++j) e[j] = ld_delta_last(er + lane + 64 * j);
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
-                const float4 f = bf4_to_f4(d[j]), g = bf4_to_f4(e[j]);
+                const float4 f = d4_to_f4<F16>(d[j]), g = d4_to_f4<F16>(e[j]);
                 v[j].x = (v[j].x + f.x) + g.x; v[j].y = (v[j].y + f.y) + g.y;
                 v[j].z = (v[j].z + f.z) + g.z; v[j].w = (v[j].w + f.w) + g.w;
                 st_stream(xr + lane + 64 * j, v[j]);
@@ -106,7 +130,7 @@ __global__ void __launch_bounds__(256) norm_rows_reg_kernel(float* __restrict__ 
         } else {
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
-                const float4 f = bf4_to_f4(d[j]);
+                const float4 f = d4_to_f4<F16>(d[j]);
                 v[j].x += f.x; v[j].y += f.y; v[j].z += f.z; v[j].w += f.w;
                 if (ADD == 1) st_stream(xr + lane + 64 * j, v[j]);
             }
@@ -140,15 +164,15 @@ __global__ void __launch_bounds__(256) norm_rows_reg_kernel(float* __restrict__ 
             reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)row * out_ld)[i] = make_float4(o0, o1, o2, o3);
         } else {
             uint2 o;
-            o.x = e_pack2_hw(o0, o1);
-            o.y = e_pack2_hw(o2, o3);
+            o.x = e_pack2_t<F16>(o0, o1);
+            o.y = e_pack2_t<F16>(o2, o3);
             reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(out) + (size_t)row * out_ld)[i] = o;
         }
     }
 }
 
 // any D % 4 == 0
-template <int KIND, int ADD, bool OUT_F32>
+template <int KIND, int ADD, bool OUT_F32, bool F16 = false>
 __global__ void __launch_bounds__(256) norm_rows_loop_kernel(float* __restrict__ x, const bf16_t* __restrict__ delta,
                                                              const bf16_t* __restrict__ delta2,
                                                              const bf16_t* __restrict__ w, const bf16_t* __restrict__ bsh,
@@ -165,7 +189,7 @@ __global__ void __launch_bounds__(256) norm_rows_loop_kernel(float* __restrict__
     auto value = [&](int i) {
         float4 v = xr[i];
         if (ADD == 2) {
-            const float4 d = bf4_to_f4(dr[i]);
+            const float4 d = d4_to_f4<F16>(dr[i]);
             v.x += d.x; v.y += d.y; v.z += d.z; v.w += d.w;
         }
         return v;
@@ -174,10 +198,10 @@ __global__ void __launch_bounds__(256) norm_rows_loop_kernel(float* __restrict__
     if (ADD == 1 || ADD == 3) {
         for (int i = lane; i < nv; i += 64) {
             float4 v = xr[i];
-            const float4 d = bf4_to_f4(dr[i]);
+            const float4 d = d4_to_f4<F16>(dr[i]);
             v.x += d.x; v.y += d.y; v.z += d.z; v.w += d.w;
             if (ADD == 3) {
-                const float4 e = bf4_to_f4(er[i]);
+                const float4 e = d4_to_f4<F16>(er[i]);
                 v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w;
             }
             xr[i] = v;
@@ -210,32 +234,32 @@ __global__ void __launch_bounds__(256) norm_rows_loop_kernel(float* __restrict__
             reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)row * out_ld)[i] = make_float4(o0, o1, o2, o3);
         } else {
             uint2 o;
-            o.x = e_pack2_hw(o0, o1);
-            o.y = e_pack2_hw(o2, o3);
+            o.x = e_pack2_t<F16>(o0, o1);
+            o.y = e_pack2_t<F16>(o2, o3);
             reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(out) + (size_t)row * out_ld)[i] = o;
         }
     }
 }
 
 // out_ld: row pitch of `out` in elements (0 = D; a multiple of 4).  The stream x and the deltas are always dense.
-template <int KIND, int ADD, bool OUT_F32>
+template <int KIND, int ADD, bool OUT_F32, bool F16 = false>
 static hipError_t launch_norm_t(float* x, const bf16_t* delta, const bf16_t* delta2, const bf16_t* w, const bf16_t* b, void* out,
                                 int M, int D, float eps, hipStream_t s, int out_ld = 0) {
     const dim3 grid((M + 3) / 4), block(256);
     if (out_ld <= 0) out_ld = D;
     if (out_ld < D || (out_ld & 3)) return hipErrorInvalidValue;
     if (D == 1024)
-        hipLaunchKernelGGL((norm_rows_reg_kernel<4, KIND, ADD, OUT_F32>), grid, block, 0, s, x, delta, delta2, w, b, out, M, eps, out_ld);
+        hipLaunchKernelGGL((norm_rows_reg_kernel<4, KIND, ADD, OUT_F32, F16>), grid, block, 0, s, x, delta, delta2, w, b, out, M, eps, out_ld);
     else if (D == 2048)
-        hipLaunchKernelGGL((norm_rows_reg_kernel<8, KIND, ADD, OUT_F32>), grid, block, 0, s, x, delta, delta2, w, b, out, M, eps, out_ld);
+        hipLaunchKernelGGL((norm_rows_reg_kernel<8, KIND, ADD, OUT_F32, F16>), grid, block, 0, s, x, delta, delta2, w, b, out, M, eps, out_ld);
     else if (D == 4096)
-        hipLaunchKernelGGL((norm_rows_reg_kernel<16, KIND, ADD, OUT_F32>), grid, block, 0, s, x, delta, delta2, w, b, out, M, eps, out_ld);
+        hipLaunchKernelGGL((norm_rows_reg_kernel<16, KIND, ADD, OUT_F32, F16>), grid, block, 0, s, x, delta, delta2, w, b, out, M, eps, out_ld);
     else if (D == 1280)     // Qwen2.5-VL vision tower
-        hipLaunchKernelGGL((norm_rows_reg_kernel<5, KIND, ADD, OUT_F32>), grid, block, 0, s, x, delta, delta2, w, b, out, M, eps, out_ld);
+        hipLaunchKernelGGL((norm_rows_reg_kernel<5, KIND, ADD, OUT_F32, F16>), grid, block, 0, s, x, delta, delta2, w, b, out, M, eps, out_ld);
     else if (D == 3584)     // Qwen2.5-VL-7B language model
-        hipLaunchKernelGGL((norm_rows_reg_kernel<14, KIND, ADD, OUT_F32>), grid, block, 0, s, x, delta, delta2, w, b, out, M, eps, out_ld);
+        hipLaunchKernelGGL((norm_rows_reg_kernel<14, KIND, ADD, OUT_F32, F16>), grid, block, 0, s, x, delta, delta2, w, b, out, M, eps, out_ld);
     else
-        hipLaunchKernelGGL((norm_rows_loop_kernel<KIND, ADD, OUT_F32>), grid, block, 0, s, x, delta, delta2, w, b, out, M, D, eps, out_ld);
+        hipLaunchKernelGGL((norm_rows_loop_kernel<KIND, ADD, OUT_F32, F16>), grid, block, 0, s, x, delta, delta2, w, b, out, M, D, eps, out_ld);
     return hipGetLastError();
 }
 
@@ -259,9 +283,19 @@ hipError_t launch_rmsnorm(float* x, const bf16_t* delta, const bf16_t* w, bf16_t
 }
 
 hipError_t launch_layernorm(float* x, const bf16_t* delta, const bf16_t* w, const bf16_t* b, void* out, int out_f32, int M,
-                            int D, float eps, hipStream_t s, const bf16_t* delta2, bool store_x) {
+                            int D, float eps, hipStream_t s, const bf16_t* delta2, bool store_x, bool f16) {
     if (D % 4) return hipErrorInvalidValue;
     const int mode = norm_add_mode(delta, delta2, store_x);
+    if (f16 && !out_f32) {  // fp16 deltas in, fp16 operand out (the fp16 vision tower)
+        switch (mode) {
+            case 0: return launch_norm_t<1, 0, false, true>(x, delta, delta2, w, b, out, M, D, eps, s);
+            case 1: return launch_norm_t<1, 1, false, true>(x, delta, delta2, w, b, out, M, D, eps, s);
+            case 2: return launch_norm_t<1, 2, false, true>(x, delta, delta2, w, b, out, M, D, eps, s);
+            case 3: return launch_norm_t<1, 3, false, true>(x, delta, delta2, w, b, out, M, D, eps, s);
+            default: return hipErrorInvalidValue;
+        }
+    }
+    if (f16 && delta) return hipErrorInvalidValue;       // an fp32-output norm with an fp16 delta: not a form the tower has
     if (out_f32) {          // fp32 output is only needed for the plain and the stored single-delta form
         if (mode == 0) return launch_norm_t<1, 0, true>(x, delta, delta2, w, b, out, M, D, eps, s);
         if (mode == 1) return launch_norm_t<1, 1, true>(x, delta, delta2, w, b, out, M, D, eps, s);
@@ -329,6 +363,7 @@ hipError_t launch_vit_assemble(const float* patch_out, const bf16_t* cls, const 
 }
 
 // feature select: hidden_states[-2][:, 1:] -> bf16 rows for the projector GEMM
+template <bool F16>
 __global__ void __launch_bounds__(256) drop_cls_cast_kernel(float* __restrict__ hidden,
                                                             const bf16_t* __restrict__ delta, bf16_t* __restrict__ out,
                                                             int P, int D) {
@@ -340,20 +375,58 @@ __global__ void __launch_bounds__(256) drop_cls_cast_kernel(float* __restrict__ 
     for (int i = threadIdx.x; i < (D >> 2); i += 256) {
         float4 v = src[i];
         if (dsrc) {
-            const float4 d = bf4_to_f4(dsrc[i]);
+            const float4 d = d4_to_f4<F16>(dsrc[i]);
             v.x += d.x; v.y += d.y; v.z += d.z; v.w += d.w;
             src[i] = v;      // materialise hidden_states[-2] for the patch rows (the CLS row is never needed)
         }
         uint2 o;
-        o.x = e_pack2(v.x, v.y);
-        o.y = e_pack2(v.z, v.w);
+        if constexpr (F16) {
+            o.x = e_pack2_h(v.x, v.y);
+            o.y = e_pack2_h(v.z, v.w);
+        } else {
+            o.x = e_pack2(v.x, v.y);
+            o.y = e_pack2(v.z, v.w);
+        }
         dst[i] = o;
     }
 }
 
-hipError_t launch_drop_cls_cast(float* hidden, const bf16_t* delta, bf16_t* out, int N, int P, int D, hipStream_t s) {
+hipError_t launch_drop_cls_cast(float* hidden, const bf16_t* delta, bf16_t* out, int N, int P, int D, hipStream_t s, bool f16) {
     if (D % 4) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(drop_cls_cast_kernel, dim3(P, N), dim3(256), 0, s, hidden, delta, out, P, D);
+    if (f16) hipLaunchKernelGGL(drop_cls_cast_kernel<true>, dim3(P, N), dim3(256), 0, s, hidden, delta, out, P, D);
+    else hipLaunchKernelGGL(drop_cls_cast_kernel<false>, dim3(P, N), dim3(256), 0, s, hidden, delta, out, P, D);
+    return hipGetLastError();
+}
+
+// 16-bit type changes, 8 elements per lane: bf16 -> fp16 (the fp16 tower's copies of a bf16 checkpoint's weights; exact for
+// 2^-14 <= |w| < 65 520, below that the fp16 subnormal grid / zero, RNE) and fp16 -> bf16 (its projector output back into the bf16
+// image-feature tensor of the C ABI; RNE from 11 to 8 significant bits).
+template <bool TO_F16>
+__global__ void __launch_bounds__(256) cast16_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n8) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const uint4 v = in[i];
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if constexpr (TO_F16) {
+            o[k] = e_pack2_h(__uint_as_float(w[k] << 16), __uint_as_float(w[k] & 0xffff0000u));
+        } else {
+            const e_f16x2 h = __builtin_bit_cast(e_f16x2, w[k]);
+            o[k] = e_pack2_hw((float)h[0], (float)h[1]);
+        }
+    }
+    out[i] = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+hipError_t launch_cast16(const bf16_t* in, bf16_t* out, size_t n, bool to_f16, hipStream_t s) {
+    if (n % 8) return hipErrorInvalidValue;
+    const size_t n8 = n / 8;
+    if (n8 == 0) return hipSuccess;
+    const dim3 grid((unsigned)((n8 + 255) / 256));
+    if (to_f16) hipLaunchKernelGGL(cast16_kernel<true>, grid, dim3(256), 0, s, (const uint4*)in, (uint4*)out, n8);
+    else hipLaunchKernelGGL(cast16_kernel<false>, grid, dim3(256), 0, s, (const uint4*)in, (uint4*)out, n8);
     return hipGetLastError();
 }
 

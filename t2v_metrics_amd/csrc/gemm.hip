@@ -51,6 +51,14 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {
     return __builtin_bit_cast(uint32_t, v);
 }
 
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+__device__ __forceinline__ uint32_t pack2h(float a, float b) {   // two v_cvt_f16_f32 (RNE, overflow -> inf) + v_pack_b32_f16
+    f16x2_t v;
+    v[0] = (_Float16)a;
+    v[1] = (_Float16)b;
+    return __builtin_bit_cast(uint32_t, v);
+}
+
 // x * sigmoid(1.702 x)                                               HF activations.py:117-123
 // sigmoid's reciprocal is the hardware v_rcp_f32 (1 ulp): __frcp_rn is a correctly rounded division -- two v_div_scale, v_rcp,
 // five FMAs, v_div_fmas, v_div_fixup per element (ISA), 9 extra VALU instructions per output element in an epilogue that no
@@ -1246,6 +1254,8 @@ static bool quad_eligible(const GemmParams& p) { return quad_eligible_rt(p, EPI)
 // operands), -1 not launchable.  The 32-bit forms refuse operands of 4 GiB or more per batch entry; a plain single-entry launch
 // then falls back to the one-tile-per-workgroup kernel (same bits), anything else is an error -- never a wrapped offset.
 int gemm_form(const GemmParams& p, int epilogue, int variant) {
+    if (p.f16)      // fp16 operands: the quad form only (every 16-bit-result linear of the vision tower and the projector resolves to it)
+        return (variant == 3 || variant == 10) && epilogue != EPI_GATED && quad_eligible_rt(p, epilogue) ? 10 : -1;
     if (epilogue == EPI_RESID_RMS) variant = variant == 5 ? 5 : 3;
     const bool plain_v0 = !(p.hd > 64 || p.hd_src > 0 || p.inner_kv > 0 || p.Hkv > 0 || p.gate_act != 0 || (epilogue == EPI_GATED && p.bias != nullptr) || p.rowss_in != nullptr ||
                             p.split_off != 0) &&
@@ -1293,7 +1303,13 @@ static hipError_t launch_epi(const GemmParams& p, int variant, hipStream_t strea
         // 8-wave forms' in the last ulp, so a weight must not change form with the batch size (a pair's bits are batch-invariant)
         if constexpr (EPI == EPI_BF16 || EPI == EPI_BF16_QGELU || EPI == EPI_BF16_GELU || EPI == EPI_GATED || EPI == EPI_HEADS) {
             const int nwg = tiles_m * tiles_n;
-            hipLaunchKernelGGL((gemm_bf16_quad<EPI>), dim3(nwg < PERSISTENT_WGS ? nwg : PERSISTENT_WGS), dim3(256), 0, stream, p);
+            const dim3 qgrid(nwg < PERSISTENT_WGS ? nwg : PERSISTENT_WGS);
+            if (p.f16) {
+                if constexpr (EPI != EPI_GATED) hipLaunchKernelGGL((gemm_f16_quad<EPI>), qgrid, dim3(256), 0, stream, p);
+                else return hipErrorInvalidValue;
+            } else {
+                hipLaunchKernelGGL((gemm_bf16_quad<EPI>), qgrid, dim3(256), 0, stream, p);
+            }
         }
     } else if (variant == 5 && EPI != EPI_F32_RESID) {
         if constexpr (EPI != EPI_F32_RESID) {

@@ -45,6 +45,13 @@ struct vqs_handle {
     std::vector<const bf16_t*> vit_qkv_w, vit_qkv_b, enc_qkv, enc_wi, dec_qkv, dec_ckv, dec_wi, dec_ckT;
     int cross_mode = 1;   // 1 = reassociated cross-attention (default), 0 = per-layer K|V projection of the encoder output
     int stream_gemm = 1;  // 1 = skinny batched launches (M <= 128 rows per entry) take the HBM-streaming GEMM form (gemm_stream.inc; bitwise the 8-wave forms), 0 = never
+    int vit_fp16 = 0;     // 1 = the vision tower and the projector run on IEEE fp16 operands (11 significant bits instead of bf16's 8, same MFMA rate and
+                          // bytes): fp16 copies of their weights (made at bind time), fp16 activations, fp32 accumulation / residual stream / statistics
+                          // as before; the image features leave as bf16 (the C ABI's type).  CLIP was trained in fp16; the T5 stack is NOT fp16-safe
+                          // and stays bf16.  0 = bf16 tower (rounds 1-4 default)
+    std::vector<const bf16_t*> vit_qkv_w16, vit_out_w16, vit_fc1_w16, vit_fc2_w16;   // the fp16 copies (packed buffer)
+    const bf16_t* proj0_w16 = nullptr;
+    const bf16_t* proj2_w16 = nullptr;
     int dec_precise = 1;  // 1 = the scoring decoder holds its activations as split-bf16 / fp32 (decoder_pass_precise), 0 = bf16 (rounds 1-3)
     const int* lut_bidir = nullptr;
     const int* lut_causal = nullptr;
@@ -106,6 +113,7 @@ struct EncodeWs {
     float* hidden;
     bf16_t *delta, *delta2;
     bf16_t *xn, *q, *k, *v, *attn, *mid, *feat_in, *pmid;
+    bf16_t* pout16;          // option vit_fp16: the projector's fp16 output before it is cast into the caller's bf16 feature tensor
     size_t total;
 };
 
@@ -128,6 +136,7 @@ EncodeWs carve_encode(const vqs_handle* h, char* base, int N, std::unordered_map
     w.mid = cv.take<bf16_t>(NS * c.vis_mlp);
     w.feat_in = cv.take<bf16_t>(NP * c.vis_hidden);
     w.pmid = cv.take<bf16_t>(NP * c.d_model);
+    w.pout16 = h->vit_fp16 ? cv.take<bf16_t>(NP * c.d_model) : nullptr;
     w.total = align_up(cv.off);
     return w;
 }
@@ -215,6 +224,8 @@ ScoreWs carve_score(const vqs_handle* h, char* base, int B, int L, int T,
 struct PackedLayout {
     size_t patch_w;
     std::vector<size_t> vit_qkv_w, vit_qkv_b, enc_qkv, enc_wi, dec_qkv, dec_ckv, dec_wi, dec_ckT;
+    std::vector<size_t> vit_qkv_w16, vit_out_w16, vit_fc1_w16, vit_fc2_w16;    // fp16 copies for option vit_fp16 (always laid out: 0.45 GB for ViT-L)
+    size_t proj0_w16, proj2_w16;
     size_t lut_bidir, lut_causal;
     size_t total;
 };
@@ -245,6 +256,14 @@ PackedLayout packed_layout(const vqs_handle* h) {
         pl.dec_ckT.push_back(take(I * D));
         pl.dec_wi.push_back(take(2 * F * D));
     }
+    for (int i = 0; i < c.vis_layers_run; ++i) {
+        pl.vit_qkv_w16.push_back(take(3 * hid * hid));
+        pl.vit_out_w16.push_back(take(hid * hid));
+        pl.vit_fc1_w16.push_back(take((size_t)c.vis_mlp * hid));
+        pl.vit_fc2_w16.push_back(take((size_t)c.vis_mlp * hid));
+    }
+    pl.proj0_w16 = take(D * hid);
+    pl.proj2_w16 = take(D * D);
     pl.lut_bidir = take(2 * (size_t)(c.rel_max_distance + 1));   // int32 = 2 bf16 slots each
     pl.lut_causal = take(2 * (size_t)(c.rel_max_distance + 1));
     pl.total = align_up(cv.off);
@@ -299,6 +318,7 @@ struct GemmCall {
     int nt_store = 0;          // result rows leave with the non-temporal hint (call sites whose multi-GB output is streamed once)
     long long split_off = 0;   // EPI_BF16: also store the lo plane of a split-bf16 result at C + split_off (vqs_kernels.h)
     int no_stream = 0;         // 1: keep this launch off the stream form (same bits either way)
+    int f16 = 0;               // A, W and the 16-bit result are IEEE fp16 (the fp16 vision tower; quad form only)
 };
 
 int run_gemm(vqs_handle* h, const GemmCall& g, hipStream_t st, const char* what) {
@@ -314,6 +334,7 @@ int run_gemm(vqs_handle* h, const GemmCall& g, hipStream_t st, const char* what)
         if (t.N == g.N && t.K == g.K) { p.tile_gm = t.gm; p.tile_ns = t.ns; }
     p.nt_store = g.nt_store;
     p.split_off = g.split_off;
+    p.f16 = g.f16;
     p.no_stream = (h->stream_gemm && !g.no_stream) ? 0 : 1;
     for (const vqs_handle::NtStore& t : h->l2_touches)
         if (t.N == g.N && t.K == g.K && g.M >= 4096) p.l2_touch = t.on;
@@ -533,6 +554,7 @@ int vqs_set_option(vqs_handle* h, const char* name, int32_t value) {
     else if (n == "fused_norm" && (value == 0 || value == 1)) h->fused_norm = value;
     else if (n == "norm_defer" && (value == 0 || value == 1)) h->norm_defer = value;
     else if (n == "dec_precise" && (value == 0 || value == 1)) h->dec_precise = value;
+    else if (n == "vit_fp16" && (value == 0 || value == 1)) h->vit_fp16 = value;
     else if (n == "stream_gemm" && (value == 0 || value == 1)) h->stream_gemm = value;
     else if (n == "gemm_variant" && (value == 0 || value == 2 || value == 3 || value == 5 || value == 11)) h->gemm_variant = value;
     else if (n.rfind("l2_touch:", 0) == 0 || n.rfind("nt_store:", 0) == 0 || n.rfind("tile_order:", 0) == 0) {
@@ -610,6 +632,31 @@ int vqs_bind_weights(vqs_handle* h, const vqs_weight_desc* weights, int32_t n, v
         h->vit_qkv_w.push_back(at(pl.vit_qkv_w[i]));
         h->vit_qkv_b.push_back(at(pl.vit_qkv_b[i]));
     }
+    // fp16 copies of the tower's and the projector's linear weights (option vit_fp16): bf16 -> fp16 is exact for 2^-14 <= |w| < 65 520
+    h->vit_qkv_w16.clear(); h->vit_out_w16.clear(); h->vit_fc1_w16.clear(); h->vit_fc2_w16.clear();
+    for (int i = 0; i < c.vis_layers_run; ++i) {
+        const std::string p = "vision.encoder.layers." + std::to_string(i) + ".";
+        const size_t mlp = (size_t)c.vis_mlp;
+        GETW(ow, p + "self_attn.out_proj.weight", (int64_t)hid * hid);
+        GETW(f1w, p + "mlp.fc1.weight", (int64_t)mlp * hid);
+        GETW(f2w, p + "mlp.fc2.weight", (int64_t)hid * mlp);
+        HIPCHK(h, vqs::launch_cast16(at(pl.vit_qkv_w[i]), at(pl.vit_qkv_w16[i]), (size_t)3 * hid * hid, true, st), "fp16 vit qkv");
+        HIPCHK(h, vqs::launch_cast16(ow, at(pl.vit_out_w16[i]), (size_t)hid * hid, true, st), "fp16 vit out_proj");
+        HIPCHK(h, vqs::launch_cast16(f1w, at(pl.vit_fc1_w16[i]), mlp * hid, true, st), "fp16 vit fc1");
+        HIPCHK(h, vqs::launch_cast16(f2w, at(pl.vit_fc2_w16[i]), mlp * hid, true, st), "fp16 vit fc2");
+        h->vit_qkv_w16.push_back(at(pl.vit_qkv_w16[i]));
+        h->vit_out_w16.push_back(at(pl.vit_out_w16[i]));
+        h->vit_fc1_w16.push_back(at(pl.vit_fc1_w16[i]));
+        h->vit_fc2_w16.push_back(at(pl.vit_fc2_w16[i]));
+    }
+    {
+        GETW(p0w, "mm_projector.0.weight", (int64_t)D * hid);
+        GETW(p2w, "mm_projector.2.weight", (int64_t)D * D);
+        HIPCHK(h, vqs::launch_cast16(p0w, at(pl.proj0_w16), (size_t)D * hid, true, st), "fp16 mm_projector.0");
+        HIPCHK(h, vqs::launch_cast16(p2w, at(pl.proj2_w16), (size_t)D * D, true, st), "fp16 mm_projector.2");
+        h->proj0_w16 = at(pl.proj0_w16);
+        h->proj2_w16 = at(pl.proj2_w16);
+    }
     auto pack_qkv = [&](const std::string& prefix, bf16_t* dst, int first, int count) -> int {
         const char* nm[3] = {"q", "k", "v"};
         for (int j = 0; j < count; ++j) {
@@ -673,6 +720,11 @@ int vqs_encode_images(vqs_handle* h, const void* d_pixels, int32_t N, void* d_fe
     const int hid = c.vis_hidden, P = h->P, Sv = h->Sv, mlp = c.vis_mlp, D = c.d_model;
     const int NP = N * P, NS = N * Sv;
     h->tap_outer = N;
+    // option vit_fp16: every 16-bit tensor of the tower and the projector (norm outputs, q / k / v, attention output, deltas, FFN
+    // product, selected features, projector hidden) is IEEE fp16 and every linear reads the fp16 copy of its weight; the fp32 residual
+    // stream, the norm statistics, the softmax and all accumulation are what they were.  The patch embedding (fp32 result) keeps its
+    // bf16 operands.
+    const bool f16 = h->vit_fp16 != 0;
 
     GETW(cls, "vision.embeddings.class_embedding", hid);
     GETW(pos, "vision.embeddings.position_embedding.weight", (int64_t)Sv * hid);
@@ -712,15 +764,16 @@ int vqs_encode_images(vqs_handle* h, const void* d_pixels, int32_t N, void* d_fe
         GETW(f2b, p + "mlp.fc2.bias", hid);
 
         if (pend_attn)
-            HIPCHK(h, vqs::launch_layernorm(w.hidden, pend_attn, ln1w, ln1b, w.xn, 0, NS, hid, c.vis_ln_eps, st, pend), "layer_norm1");
+            HIPCHK(h, vqs::launch_layernorm(w.hidden, pend_attn, ln1w, ln1b, w.xn, 0, NS, hid, c.vis_ln_eps, st, pend, true, f16), "layer_norm1");
         else
-            HIPCHK(h, vqs::launch_layernorm(w.hidden, pend, ln1w, ln1b, w.xn, 0, NS, hid, c.vis_ln_eps, st), "layer_norm1");
+            HIPCHK(h, vqs::launch_layernorm(w.hidden, pend, ln1w, ln1b, w.xn, 0, NS, hid, c.vis_ln_eps, st, nullptr, true, f16), "layer_norm1");
         pend = nullptr;
         pend_attn = nullptr;
         TAP("vit", i, "xn0", w.xn, (size_t)NS * hid);
         {
-            GemmCall g{w.xn, h->vit_qkv_w[i], nullptr};
+            GemmCall g{w.xn, f16 ? h->vit_qkv_w16[i] : h->vit_qkv_w[i], nullptr};
             g.bias = h->vit_qkv_b[i];
+            g.f16 = f16;
             g.M = NS; g.N = 3 * hid; g.K = hid; g.lda = hid; g.ldw = hid; g.ldc = 0; g.epi = vqs::EPI_HEADS;
             g.S = Sv; g.H = c.vis_heads; g.inner = hid;
             g.heads[0] = w.q; g.heads[1] = w.k; g.heads[2] = w.v;
@@ -728,6 +781,7 @@ int vqs_encode_images(vqs_handle* h, const void* d_pixels, int32_t N, void* d_fe
         }
         {
             vqs::AttnParams a{w.q, w.k, w.v, w.attn, nullptr, nullptr, N, c.vis_heads, Sv, 0.125f};
+            a.f16 = f16;
             TAP("vit", i, "q", w.q, (size_t)NS * hid);
             TAP("vit", i, "k", w.k, (size_t)NS * hid);
             TAP("vit", i, "v", w.v, (size_t)NS * hid);
@@ -735,26 +789,29 @@ int vqs_encode_images(vqs_handle* h, const void* d_pixels, int32_t N, void* d_fe
             TAP("vit", i, "attn", w.attn, (size_t)NS * hid);
         }
         {
-            GemmCall g{w.attn, ow, w.delta};
+            GemmCall g{w.attn, f16 ? h->vit_out_w16[i] : ow, w.delta};
             g.bias = ob;
+            g.f16 = f16;
             g.M = NS; g.N = hid; g.K = hid; g.lda = hid; g.ldw = hid; g.ldc = hid; g.epi = vqs::EPI_BF16;
             RUN(run_gemm(h, g, st, "vit out_proj"));
             TAP("vit", i, "d_attn", w.delta, (size_t)NS * hid);
         }
-        HIPCHK(h, vqs::launch_layernorm(w.hidden, w.delta, ln2w, ln2b, w.xn, 0, NS, hid, c.vis_ln_eps, st, nullptr, !defer), "layer_norm2");
+        HIPCHK(h, vqs::launch_layernorm(w.hidden, w.delta, ln2w, ln2b, w.xn, 0, NS, hid, c.vis_ln_eps, st, nullptr, !defer, f16), "layer_norm2");
         if (defer) pend_attn = w.delta;
         TAP("vit", i, "xn1", w.xn, (size_t)NS * hid);
         {
-            GemmCall g{w.xn, f1w, w.mid};
+            GemmCall g{w.xn, f16 ? h->vit_fc1_w16[i] : f1w, w.mid};
             g.bias = f1b;
+            g.f16 = f16;
             g.M = NS; g.N = mlp; g.K = hid; g.lda = hid; g.ldw = hid; g.ldc = mlp; g.epi = vqs::EPI_BF16_QGELU;
             RUN(run_gemm(h, g, st, "vit fc1"));
             TAP("vit", i, "mid", w.mid, (size_t)NS * mlp);
         }
         {
             bf16_t* dst = defer ? w.delta2 : w.delta;
-            GemmCall g{w.mid, f2w, dst};
+            GemmCall g{w.mid, f16 ? h->vit_fc2_w16[i] : f2w, dst};
             g.bias = f2b;
+            g.f16 = f16;
             g.M = NS; g.N = hid; g.K = mlp; g.lda = mlp; g.ldw = mlp; g.ldc = hid; g.epi = vqs::EPI_BF16;
             RUN(run_gemm(h, g, st, "vit fc2"));
             TAP("vit", i, "d_mlp", dst, (size_t)NS * hid);
@@ -762,25 +819,29 @@ int vqs_encode_images(vqs_handle* h, const void* d_pixels, int32_t N, void* d_fe
         }
     }
     // hidden_states[-2][:, 1:] = hidden + pending fc2 output, CLS dropped, cast to the projector's operand type
-    HIPCHK(h, vqs::launch_drop_cls_cast(w.hidden, pend, w.feat_in, N, P, hid, st), "feature select");
+    HIPCHK(h, vqs::launch_drop_cls_cast(w.hidden, pend, w.feat_in, N, P, hid, st, f16), "feature select");
     TAP("vit", -1, "feat_in", w.feat_in, (size_t)NP * hid);
     GETW(p0w, "mm_projector.0.weight", (int64_t)D * hid);
     GETW(p0b, "mm_projector.0.bias", D);
     GETW(p2w, "mm_projector.2.weight", (int64_t)D * D);
     GETW(p2b, "mm_projector.2.bias", D);
     {
-        GemmCall g{w.feat_in, p0w, w.pmid};
+        GemmCall g{w.feat_in, f16 ? h->proj0_w16 : p0w, w.pmid};
         g.bias = p0b;
+        g.f16 = f16;
         g.M = NP; g.N = D; g.K = hid; g.lda = hid; g.ldw = hid; g.ldc = D; g.epi = vqs::EPI_BF16_GELU;
         RUN(run_gemm(h, g, st, "mm_projector.0"));
         TAP("vit", -1, "pmid", w.pmid, (size_t)NP * D);
     }
     {
-        GemmCall g{w.pmid, p2w, d_feats};
+        GemmCall g{w.pmid, f16 ? h->proj2_w16 : p2w, f16 ? (void*)w.pout16 : d_feats};
         g.bias = p2b;
+        g.f16 = f16;
         g.M = NP; g.N = D; g.K = D; g.lda = D; g.ldw = D; g.ldc = D; g.epi = vqs::EPI_BF16;
         RUN(run_gemm(h, g, st, "mm_projector.2"));
     }
+    if (f16)    // the image features are a bf16 tensor of the C ABI (vqs_score reads them as such): one rounding from 11 to 8 significant bits
+        HIPCHK(h, vqs::launch_cast16(w.pout16, (bf16_t*)d_feats, (size_t)NP * D, false, st), "features fp16 -> bf16");
     return VQS_OK;
 }
 

@@ -33,6 +33,9 @@ struct GemmParams {
     int lda, ldw, ldc;       // in elements
     // EPI_HEADS
     int S, H, inner;
+    int f16 = 0;             // any epilogue; host-side only (selects the kernel): 1 = A, W and the 16-bit result are IEEE fp16 instead of bf16
+                             // (quad form only; bias stays bf16) -- the fp16 vision tower.  Sits in what was alignment padding: no other
+                             // field moved, the kernels' argument block is byte for byte what it was.
     bf16_t* heads_out[3];
     int hd = 0;              // head width (0 = 64); 128 for Qwen2.5-VL
     int hd_src = 0;          // columns per head in the GEMM's N when narrower than hd (0 = hd): the product's heads are written into
@@ -183,6 +186,7 @@ struct AttnParams {
     int causal = 0;           // key <= query
     int out_hd = 0;           // hd = 128 only: lanes of a head written to `out`, which is then [B*S, H*out_hd] (0 = hd); the Qwen2.5-VL
                               // tower's 80-lane heads leave compact so that the proj GEMM contracts over 1280, not 2048
+    int f16 = 0;              // hd = 64, no bias only: q / k / v / out are IEEE fp16 tensors instead of bf16 (the fp16 vision tower)
 };
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream);
 size_t attention_lds_bytes(int S, bool has_bias, int hd);   // dynamic LDS request of that launch (host-side arithmetic)
@@ -216,7 +220,8 @@ hipError_t launch_decoder_attention(const DecAttnParams& p, hipStream_t stream);
 hipError_t launch_rmsnorm(float* x, const bf16_t* delta, const bf16_t* w, bf16_t* out, int M, int D, float eps,
                           hipStream_t s, const bf16_t* delta2 = nullptr, bool store_x = true, int out_ld = 0);   // out_ld: row pitch of out (0 = D)
 hipError_t launch_layernorm(float* x, const bf16_t* delta, const bf16_t* w, const bf16_t* b, void* out, int out_f32, int M,
-                            int D, float eps, hipStream_t s, const bf16_t* delta2 = nullptr, bool store_x = true);
+                            int D, float eps, hipStream_t s, const bf16_t* delta2 = nullptr, bool store_x = true, bool f16 = false);
+// f16: the deltas and the 16-bit output are IEEE fp16 tensors (the fp16 vision tower); w / b stay bf16
 // pixels bf16 [N,3,IMG,IMG] -> rows [N*G*G, Kpad] in (c,ky,kx) order, zero padded
 hipError_t launch_im2col(const bf16_t* pixels, bf16_t* out, int N, int img, int patch, int kpad, hipStream_t s);
 // hidden[n, 0] = cls + pos[0]; hidden[n, 1+p] = patch_out[n*P+p] + pos[1+p]   (fp32 out)
@@ -224,7 +229,9 @@ hipError_t launch_vit_assemble(const float* patch_out, const bf16_t* cls, const 
                                int P, int D, hipStream_t s);
 // stream fp32 [N, 1+P, D] -> bf16 [N*P, D] dropping the CLS row
 hipError_t launch_drop_cls_cast(float* hidden, const bf16_t* delta, bf16_t* out, int N, int P, int D,
-                                hipStream_t s);
+                                hipStream_t s, bool f16 = false);   // f16: `delta` and `out` are IEEE fp16 tensors
+// n 16-bit elements (n % 8 == 0, 16-byte aligned): bf16 -> fp16 (to_f16) or fp16 -> bf16, round-to-nearest-even
+hipError_t launch_cast16(const bf16_t* in, bf16_t* out, size_t n, bool to_f16, hipStream_t s);
 // per sample: sentinel position and spliced length from int32 ids [B,L] (pad = 0 trailing, sentinel = -200)
 hipError_t launch_prompt_scan(const int* ids, int B, int L, int P, int* sent_pos, int* enc_len, int* err_flag,
                               hipStream_t s);

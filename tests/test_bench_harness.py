@@ -82,3 +82,14 @@ def test_traffic_provenance_stamps():
     assert not bench.traffic_stamp_matches({"csrc_sha256_16": "0" * 16})[0]
     rec = json.load(open(os.path.join(os.path.dirname(so), "..", "profiles", "gemm_traffic_xxl_b256.json")))
     assert "device_code_sha256_16" in rec and "traffic_bytes_per_launch" in rec
+    # the finest stamp: machine code + descriptors of the GEMM kernels alone -- what the counters were collected on.  The committed
+    # record must be about the kernels this tree builds (an edit of a GEMM kernel without a new PMC run fails HERE, not silently on the box)
+    g = bench.gemm_kernels_hash()
+    assert g and len(g) == 16 and g == bench.gemm_kernels_hash(so) and bench.gemm_kernels_hash(__file__) is None
+    ks = bench.device_kernels(so)
+    assert len(ks) > 100 and all(len(kd) == 64 and len(code) > 0 for code, kd in ks.values())
+    assert sum("gemm_bf16_quad" in n for n in ks) == 5 and sum("gemm_f16_quad" in n for n in ks) == 4
+    ok, how = bench.traffic_stamp_matches({"gemm_kernels_sha256_16": g, "device_code_sha256_16": "stale"})
+    assert ok and g in how                                                            # ... and it wins over the whole-library stamp
+    assert not bench.traffic_stamp_matches({"gemm_kernels_sha256_16": "0" * 16, "device_code_sha256_16": h})[0]
+    assert rec["gemm_kernels_sha256_16"] == g, "profiles/gemm_traffic_xxl_b256.json was measured on other GEMM kernels: re-run tools/gpu_pmc_bench.sh"

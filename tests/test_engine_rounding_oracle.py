@@ -113,3 +113,48 @@ def test_stage_locked_run_on_its_own_record_reports_zero(name):
     report, _ = emu.forward_locked(taps, pix.float(), idx, ids, labels)
     off = [n for n, r in report.items() if r["max_abs"] > 0]
     assert off == ["enc.1.attn", "enc.1.d_attn"], off
+
+
+@pytest.mark.parametrize("name", ["tiny", "small"])
+def test_fp16_tower_mode_is_the_same_function_with_finer_roundings(name):
+    """`vit_fp16=True` models the engine's option of that name: the tower's and the projector's tensors are IEEE fp16 (11 significant
+    bits), their linear weights fp16 copies, the feature tensor still bf16.  Roundings off = the fp32 oracle; roundings on = closer to it
+    than the bf16 tower; the tower's taps are fp16 tensors; a stage-locked run on its own record reports zero, with fp16 ulps."""
+    cfg, w, pix, idx, ids, labels = _case(name)
+    o = Oracle(cfg, w)
+    ref = o.forward(pix.float(), idx, ids, labels, return_stages=True)
+    off = EngineRoundedOracle(cfg, w, round_fn=lambda x: x.float(), vit_fp16=True).forward(pix.float(), idx, ids, labels, return_stages=True)
+    for k in ("vit_feats", "proj", "label_logprobs"):
+        assert (ref[k] - off[k]).abs().max().item() <= 5e-5 * max(1.0, ref[k].abs().max().item()), k   # fp16 weight copies: exact above 2^-14
+    bf = EngineRoundedOracle(cfg, w).forward(pix.float(), idx, ids, labels, return_stages=True)
+    emu = Oracle(cfg, w, emulate="engine", vit_fp16=True)
+    emu.record = {}
+    hf = emu.forward(pix.float(), idx, ids, labels, return_stages=True)
+    rec, emu.record = emu.record, None
+    e_bf, e_hf = (bf["vit_feats"] - ref["vit_feats"]).abs().mean().item(), (hf["vit_feats"] - ref["vit_feats"]).abs().mean().item()
+    assert e_hf < 0.3 * e_bf, (e_hf, e_bf)                               # the tower's own output: three more bits
+    assert torch.equal(hf["vit_feats"], hf["vit_feats"].half().float()) and not torch.equal(hf["vit_feats"], bf16_round(hf["vit_feats"]))
+    assert torch.equal(hf["proj"], bf16_round(hf["proj"]))                # the feature tensor of the C ABI stays bf16
+    assert (hf["proj"] - ref["proj"]).abs().mean().item() < (bf["proj"] - ref["proj"]).abs().mean().item()
+    # taps: the tower's 16-bit tensors are fp16, everything else what it was
+    shapes = emu.tap_shapes(pix.shape[0], ids.shape[0], ids.shape[1], labels.shape[1])
+    base = EngineRoundedOracle(cfg, w).tap_shapes(pix.shape[0], ids.shape[0], ids.shape[1], labels.shape[1])
+    assert set(shapes) == set(base)
+    for n in shapes:
+        tower16 = n.startswith("vit.") and n not in ("vit.patch_out", "vit.h0")
+        assert shapes[n][0] == base[n][0] and shapes[n][1] == (torch.float16 if tower16 else base[n][1]), n
+    hi = {n: rec.pop(n) for n in list(rec) if n.endswith("#hi")}
+    taps = {n: (rec[n].reshape(shapes[n][0]) if n in shapes and shapes[n][1] == "split" else rec[n].reshape(shapes[n][0]).to(shapes[n][1]) if n in shapes else rec[n])
+            for n in rec}
+    taps.update(hi)
+    report, lp = emu.forward_locked(taps, pix.float(), idx, ids, labels)
+    assert all(r["max_abs"] == 0.0 for r in report.values()), {n: r for n, r in report.items() if r["max_abs"] > 0}
+    assert torch.equal(lp, hf["label_logprobs"])
+    assert sum(r["mant_bits"] == 10 for r in report.values()) == 9 * cfg.vision.layers_run + 2
+    # one fp16 ulp planted in a tower tensor is seen as one ulp (with bf16 ulps it would read as 1/8 and pass any bound)
+    t = taps["vit.0.mid"].clone()
+    k = int(t.abs().float().argmax())
+    t.view(-1)[k] = (t.view(-1)[k].view(torch.int16) + 1).view(torch.float16)            # the next fp16 value away from zero
+    taps["vit.0.mid"] = t
+    report, _ = emu.forward_locked(taps, pix.float(), idx, ids, labels)
+    assert 0.99 <= report["vit.0.mid"]["max_own_ulps"] <= 1.01, report["vit.0.mid"]

@@ -299,6 +299,42 @@ def test_precise_decoder_is_closer_to_fp32_than_the_bf16_decoder():
     assert float((out["precise"] - out["precise-unsplit"]).abs().max()) <= 2e-3                  # only the bf16 score path can flip a rounding
 
 
+def test_fp16_vision_tower_is_closer_to_fp32_than_the_bf16_tower():
+    """Option vit_fp16 (default 0): the vision tower and the projector on IEEE fp16 operands -- three more significant bits than bf16 at the
+    same MFMA rate and bytes (CLIP was trained in fp16; the T5 stack is not fp16-safe and stays bf16).  Same function: both agree with the
+    fp32 oracle; the image features (what the tower hands to the T5 pass) are several times closer to the oracle's with fp16 operands, the
+    label log-probs closer in the mean; bitwise repeatable; switching the option back restores the bf16 tower's bits on the same handle."""
+    from oracle.clip_t5_oracle import Oracle
+    from t2v_metrics_amd.engine import VqsEngine
+    cfg = get_config("small")
+    w = make_seeded_weights(cfg, seed=31, device="cpu", lm_head_gain=4.0)
+    pix, img_index, ids, labels = _inputs(cfg, 16, 5, 24, 2, seed=14)
+    o = Oracle(cfg, w)
+    ref = o.forward(pix.float(), img_index, ids, labels)
+    feats_ref = o.projector(o.vision_features(pix.float()))
+    eng = VqsEngine(cfg, w, device="cuda:0")
+    out, feats = {}, {}
+    try:
+        for mode, val in (("bf16", 0), ("fp16", 1), ("fp16-b", 1), ("bf16-again", 0)):
+            eng.set_option("vit_fp16", val)
+            f = eng.encode_images(pix.cuda())
+            lp, _ = eng.score(f, img_index, ids, labels)
+            torch.cuda.synchronize()
+            out[mode], feats[mode] = lp.cpu(), f.float().cpu()
+    finally:
+        eng.close()
+    assert torch.equal(out["fp16"], out["fp16-b"]) and torch.equal(feats["fp16"], feats["fp16-b"])
+    assert torch.equal(out["bf16"], out["bf16-again"]) and torch.equal(feats["bf16"], feats["bf16-again"])
+    assert feats["fp16"].dtype == feats["bf16"].dtype and not torch.equal(feats["fp16"], feats["bf16"])
+    ferr = {k: float((feats[k] - feats_ref.reshape(feats[k].shape)).abs().mean()) for k in ("bf16", "fp16")}
+    err = {k: (out[k] - ref["label_logprobs"]).abs() for k in ("bf16", "fp16")}
+    _record("fp16-vision-tower", {"features_mean_abs_err": ferr, "logp": {k: {"max": float(e.max()), "mean": float(e.mean())} for k, e in err.items()}})
+    # both towers end in a bf16 feature tensor, so the fp16 tower's feature error is bounded below by that last rounding: well under the
+    # bf16 tower's accumulated error, not eight times under
+    assert ferr["fp16"] < 0.75 * ferr["bf16"], ferr
+    assert float(err["fp16"].max()) <= 2.5e-2 and float(err["fp16"].mean()) <= float(err["bf16"].mean()) * 1.25 + 1e-4, err   # CPU emulation of this case: 3.6e-3 vs 4.8e-3
+
+
 def test_fused_residual_rmsnorm_matches_separate_kernels():
     """Option fused_norm=1: the T5 encoder's o / wo GEMM epilogues update the residual stream and hand the next RMSNorm's
     operand + row sums of squares to the consuming GEMM (no norm kernel).  Default (0): separate add+norm kernels.

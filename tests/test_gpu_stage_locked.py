@@ -27,13 +27,15 @@ ATTENTION_TAPS = ("attn", "sattn", "cctx", "cattn")
 PRECISE_DEC_TAPS = ("xn0", "xn1", "xn2", "qkv", "sattn", "d_self", "cctx", "cattn", "d_cross", "ff", "d_ff")   # fp32 or split-bf16 in the decoder
 
 
-def run_stage_locked(cfg, w, eng, pix, idx, ids, labels, tag, window=None):
+def run_stage_locked(cfg, w, eng, pix, idx, ids, labels, tag, window=None, vit_fp16=False):
     """window = (first, count): the pass runs on the WHOLE batch, the taps and the oracle cover pairs first .. first+count-1
     (vqs_debug_tap_window; their images must be rows first .. of `pix` in order) -- the stage-locked check of a few sampled
     pairs inside a batch too large to tap whole (the benchmarked 256-pair XXL batch)."""
     from oracle.clip_t5_oracle import Oracle
     w_cpu = {k: v.cpu() for k, v in w.items()}
-    emu = Oracle(cfg, w_cpu, emulate="engine")
+    # vit_fp16: the engine must already run its tower on fp16 operands (option "vit_fp16"); the oracle then rounds the tower's tensors to
+    # fp16, reads the fp16 copies of its weights and decodes the tower's taps as fp16
+    emu = Oracle(cfg, w_cpu, emulate="engine", vit_fp16=vit_fp16)
     B, L = ids.shape
     T = labels.shape[1]
     if window is None:
@@ -98,7 +100,10 @@ def run_stage_locked(cfg, w, eng, pix, idx, ids, labels, tag, window=None):
             ok = rel <= 4e-5
         else:
             ulps = 2.0 if kind in ATTENTION_TAPS else 1.0
-            ok = r["frac_diff"] <= 5e-3 and rel <= ulps * 2.0 ** -7 * 1.001
+            # one ulp of the tensor's 16-bit type at its top binade: 2^-7 for bf16, 2^-10 for the fp16 tower's tensors (there a flipped
+            # rounding is eight times smaller, and eight times as many elements sit within fp32 summation noise of a rounding boundary)
+            fp16 = r.get("mant_bits", 7) == 10
+            ok = r["frac_diff"] <= (4e-2 if fp16 else 5e-3) and rel <= ulps * 2.0 ** -r.get("mant_bits", 7) * 1.001
             # per element: a launch whose inputs are not re-rounded inside it (GEMM + epilogue, norm) differs from the oracle by
             # at most ONE ulp of the element's own binade (+ the fp32-summation floor, see _emit) -- a defect confined to
             # small-magnitude elements fails here although it passes the absmax-relative bound.  The attention kernels round P
@@ -123,6 +128,22 @@ def test_every_launch_of_a_pass_matches_the_oracle_on_the_engines_own_inputs(nam
     eng = VqsEngine(cfg, w, device="cuda:0")
     try:
         run_stage_locked(cfg, w, eng, pix, img_index, ids, labels, f"{name}-B{B}-L{L}-T{T}-gain{gain}")
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("name,B,n_img,L,T,gain", [("tiny", 3, 2, 9, 3, 1.0), ("small", 4, 2, 20, 2, 4.0)])
+def test_every_launch_matches_the_oracle_with_the_fp16_vision_tower(name, B, n_img, L, T, gain):
+    """Option vit_fp16: the tower and the projector on IEEE fp16 operands (fp16 MFMA, fp16 copies of the weights).  Every launch output of
+    the tower within ONE fp16 ulp of the oracle that rounds to fp16 at the same points; the T5 stacks exactly as before."""
+    from t2v_metrics_amd.engine import VqsEngine
+    cfg = get_config(name)
+    w = make_seeded_weights(cfg, seed=11, device="cpu", lm_head_gain=gain)
+    pix, img_index, ids, labels = _inputs(cfg, B, n_img, L, T, seed=100 + B)
+    eng = VqsEngine(cfg, w, device="cuda:0", options={"vit_fp16": 1})
+    try:
+        report, _ = run_stage_locked(cfg, w, eng, pix, img_index, ids, labels, f"{name}-B{B}-L{L}-T{T}-gain{gain}-vit_fp16", vit_fp16=True)
+        assert sum(r["mant_bits"] == 10 for r in report.values()) == 9 * cfg.vision.layers_run + 2
     finally:
         eng.close()
 

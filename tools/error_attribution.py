@@ -49,24 +49,28 @@ class Runner:
         self.pix, self.idx, self.ids, self.labels = batch
         self.cache = {}
 
-    def _oracle(self, classes, dec_precise):
-        return EngineRoundedOracle(self.cfg, self.w, acc=self.acc, classes=classes, dec_precise=dec_precise)
+    def _oracle(self, classes, dec_precise, split=()):
+        half = tuple(c[5:] for c in split if c.startswith("half:"))          # "half:<class>" entries of a what-if's set: fp16 tensors
+        split = tuple(c for c in split if not c.startswith("half:"))
+        return EngineRoundedOracle(self.cfg, self.w, acc=self.acc, classes=classes, dec_precise=dec_precise, split_classes=split,
+                                   half_classes=half)
 
-    def run(self, classes, dec_precise=False):
+    def run(self, classes, dec_precise=False, split=()):
         classes = frozenset(classes)
-        o = self._oracle(classes, dec_precise)
+        o = self._oracle(classes, dec_precise, split)
         with torch.no_grad():
             k_vit = frozenset(c for c in classes if stack_of(c) == "vit")
             k_proj = (k_vit, frozenset(c for c in classes if stack_of(c) == "proj"))
             k_enc = (k_proj, frozenset(c for c in classes if stack_of(c) == "enc"))
-            if ("vit", k_vit) not in self.cache:
-                self.cache[("vit", k_vit)] = o.vision_features(self.pix)
-            if ("proj", k_proj) not in self.cache:
-                self.cache[("proj", k_proj)] = o.projector(self.cache[("vit", k_vit)])
-            if ("enc", k_enc) not in self.cache:
-                emb, mask, _ = o.splice(self.cache[("proj", k_proj)], self.idx, self.ids)
-                self.cache[("enc", k_enc)] = (o.t5_encoder(emb, mask), mask)
-            enc, mask = self.cache[("enc", k_enc)]
+            sp = frozenset(split)                      # a what-if's split set changes what a class's rounding is
+            if ("vit", k_vit, sp) not in self.cache:
+                self.cache[("vit", k_vit, sp)] = o.vision_features(self.pix)
+            if ("proj", k_proj, sp) not in self.cache:
+                self.cache[("proj", k_proj, sp)] = o.projector(self.cache[("vit", k_vit, sp)])
+            if ("enc", k_enc, sp) not in self.cache:
+                emb, mask, _ = o.splice(self.cache[("proj", k_proj, sp)], self.idx, self.ids)
+                self.cache[("enc", k_enc, sp)] = (o.t5_encoder(emb, mask), mask)
+            enc, mask = self.cache[("enc", k_enc, sp)]
             dec = o.t5_decoder(shift_right(self.labels, self.cfg.t5.decoder_start_id, self.cfg.t5.pad_id), enc, mask)
             logits = o.lm_logits(dec)
             return {g: Oracle.label_logprobs(logits * g, self.labels) for g in self.gains}
@@ -129,7 +133,18 @@ def main():
              ("what-if: precise decoder, vit.norm vit.delta vit.qkv exact", without("vit.norm", "vit.delta", "vit.qkv"), True),
              ("what-if: precise decoder, enc.* exact", without("enc.*"), True),
              ("what-if: precise decoder, vit.* proj.* enc.* exact", without("vit.*", "proj.*", "enc.*"), True)]
-    runs = [r if len(r) == 3 else (r[0], r[1], False) for r in runs]
+    # ... and what it would buy as an implementable design: those tensors split-bf16 (16 bits) instead of exact
+    VIT_SPLIT = ("vit.norm", "vit.v", "vit.attn", "vit.act", "vit.delta", "vit.feat")          # q, k and the probabilities stay bf16
+    runs += [("what-if: precise decoder, split vit (norm v attn act delta feat)", ALL, True, VIT_SPLIT),
+             ("what-if: precise decoder, split vit + split proj", ALL, True, VIT_SPLIT + ("proj.mid", "proj.out")),
+             ("what-if: precise decoder, split vit without v", ALL, True, tuple(c for c in VIT_SPLIT if c != "vit.v")),
+             ("what-if: precise decoder, split vit + split proj + split enc.out", ALL, True, VIT_SPLIT + ("proj.mid", "proj.out", "enc.out"))]
+    # ... or as an fp16 tower: the same MFMA rate and bytes as bf16, three more significant bits (CLIP was trained in fp16; T5 is not fp16-safe)
+    half = lambda *stacks: tuple("half:" + c for c in ALL if stack_of(c) in stacks)
+    runs += [("what-if: precise decoder, vit.* in fp16", ALL, True, half("vit")),
+             ("what-if: precise decoder, vit.* proj.* in fp16", ALL, True, half("vit", "proj")),
+             ("what-if: bf16 decoder, vit.* proj.* in fp16", ALL, False, half("vit", "proj"))]
+    runs = [(r + (False, ()))[:4] if len(r) < 4 else r for r in runs]          # (name, classes, precise decoder, split set)
     if a.only:
         keep = set(a.only.split(";"))
         runs = [r for r in runs if r[0] in keep or r[0].startswith("none")]
@@ -139,9 +154,9 @@ def main():
     results, ref = {}, None
     print(f"# {cfg.name}, {a.pairs} pairs (bench.synth_batch seed {a.seed}), labels {labels[0].tolist()}, products in {a.acc}, "
           f"gains {gains}, {torch.get_num_threads()} threads", flush=True)
-    for name, classes, precise in runs:
+    for name, classes, precise, split in runs:
         t0 = time.time()
-        lp = R.run(classes, precise)
+        lp = R.run(classes, precise, split)
         if ref is None:
             assert not classes
             ref = lp

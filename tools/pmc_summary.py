@@ -45,6 +45,7 @@ if cnt["FETCH_SIZE"] and cnt["WRITE_SIZE"]:
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         import bench
         out["csrc_sha256_16"] = bench.csrc_hash()
+        out["gemm_kernels_sha256_16"] = bench.gemm_kernels_hash()     # machine code + descriptors of the vqs::gemm_bf16_* kernels alone
         out["device_code_sha256_16"] = bench.device_code_hash()       # the .hip_fatbin section of the library the passes ran
     except Exception as e:
         out["csrc_sha256_16"] = None
