@@ -725,6 +725,8 @@ int vqs_encode_images(vqs_handle* h, const void* d_pixels, int32_t N, void* d_fe
     // stream, the norm statistics, the softmax and all accumulation are what they were.  The patch embedding (fp32 result) keeps its
     // bf16 operands.
     const bool f16 = h->vit_fp16 != 0;
+    if (f16 && h->gemm_variant != 3)
+        return fail(h, VQS_ERR_STATE, "encode_images: option vit_fp16 needs gemm_variant 3 (the fp16 linears exist in the quad form only)");
 
     GETW(cls, "vision.embeddings.class_embedding", hid);
     GETW(pos, "vision.embeddings.position_embedding.weight", (int64_t)Sv * hid);
