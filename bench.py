@@ -549,6 +549,7 @@ def main():
         n_len += len(lens)
     flops_pair = flops_sum / max(n_len, 1)
     s_e = (jobs[0][2].shape[1] - 1 + cfg.vision.n_patches) if jobs else 0
+    tower_fp16 = bool(eng.get_option("vit_fp16")) if hasattr(eng, "get_option") else False
     out = {
         "metric": METRIC + cfg.name,
         "value": value,
@@ -566,6 +567,9 @@ def main():
         "config": {"workload": f"{cfg.name} bf16, {info['name']}",
                    "pairs_per_gpu_per_step": B, "encoder_len": s_e, "decoder_len": T, "total_pairs": total_pairs,
                    "parallelism": f"replica x{world} (pairs sharded, RCCL all_gather of scores)",
+                   "arithmetic": ("T5 stacks: bf16 operands (the reference's dtype, mm_utils.py:228), decoder activations split-bf16 / fp32; vision tower + projector: "
+                                  + ("IEEE fp16 operands (option vit_fp16 = 1: 11 significant bits, same MFMA rate and bytes)" if tower_fp16 else "bf16 operands (option vit_fp16 = 0)")
+                                  + "; fp32 accumulation, residual streams, statistics, softmax"),
                    **({"options": args.opt} if args.opt else {})},
         "ranks_seen": ranks_seen,
         "collective": (backend + (" (RCCL over xGMI)" if backend == "nccl" else "")) if dist is not None else None,
@@ -582,7 +586,8 @@ def main():
     }
     if n_gemm > 0 and gemm_ms > 0:
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12
-        out["roofline"] = {"kernel": "vqs::gemm_bf16_quad (bf16-result launches) + gemm_bf16_persistent (fp32-result / batched): every GEMM launch of the step",
+        out["roofline"] = {"kernel": "vqs::gemm_bf16_quad / gemm_f16_quad (16-bit-result launches: the same kernel on bf16 / fp16 fragments) + gemm_bf16_persistent / "
+                                     "gemm_bf16_stream (fp32-result / batched): every GEMM launch of the step",
                            "bound": "mfma", "achieved": achieved,
                            "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
                            "traffic": None, "launches": n_gemm, "avg_launch_ms": gemm_ms / n_gemm,
@@ -599,8 +604,10 @@ def main():
             same, how = traffic_stamp_matches(tj)
             if same:
                 out["roofline"]["traffic"] = tj["traffic_bytes_per_launch"]
-                out["roofline"]["traffic_unit"] = ("bytes per launch (HBM-side: 2 x FETCH_SIZE + WRITE_SIZE), rocprofv3 --pmc passes over this command "
-                                                   "on the same code, %s: profiles/%s" % (how, os.path.basename(tpath)))
+                out["roofline"]["traffic_unit"] = ("bytes per launch (fabric side, Infinity-Cache hits included: 2 x FETCH_SIZE + WRITE_SIZE), rocprofv3 --pmc passes over "
+                                                   "this command on the same code, %s: profiles/%s" % (how, os.path.basename(tpath))
+                                                   + ("; collected with the bf16 tower (vit_fp16 = 0) -- the fp16 tower's launches (94 of a step's 432) run the same kernel "
+                                                      "on fp16 fragments: same tiles, same bytes" if tower_fp16 and not tj.get("vit_fp16") else ""))
             else:
                 out["roofline"]["traffic_unit"] = "null: profiles/%s was measured on other code, %s" % (os.path.basename(tpath), how)
 

@@ -201,13 +201,14 @@ int vqs_score_head(const float* d_logits, int32_t ldl, int32_t V, const int32_t*
  *   "dec_precise"  1 (default) the scoring decoder holds the activations that matter as split-bf16 / fp32 (16 significant bits
  *                  into the bf16 MFMA as two stacked row planes, fp32 partial sums: round 4), 0 the bf16 decoder
  *                  of rounds 1-3 (vqs_generate always runs that one)
- *   "vit_fp16"     0 (default) the vision tower and the projector hold their 16-bit tensors in bf16, as the reference does
- *                  (mm_utils.py:228); 1 IEEE fp16 instead: fp16 copies of their linear weights (made by vqs_bind_weights; bf16 -> fp16 is
+ *   "vit_fp16"     1 (default) the vision tower and the projector hold their 16-bit tensors in IEEE fp16: fp16 copies of their linear weights (made by vqs_bind_weights; bf16 -> fp16 is
  *                  exact for 2^-14 <= |w| < 65 520), fp16 activations through the same kernels on fp16 MFMAs (same rate, same bytes),
  *                  fp32 accumulation / residual stream / statistics unchanged, the feature tensor still bf16 (one cast at the end).  11
  *                  significant bits instead of 8 where the error attribution (profiles/r4_error_attribution.md) puts most of what is
- *                  left of the end-to-end |delta log P|.  CLIP was trained in fp16; the T5 stack is not fp16-safe and is not touched.
- *                  Needs gemm_variant 3.  Set it before asking for the encode workspace size (one more buffer).
+ *                  left of the end-to-end |delta log P| (measured on the benchmarked batch: max 1.45e-3 -> 7.0e-4, mean 7.0e-4 -> 3.3e-4,
+ *                  throughput 201.0 -> 200.5 pairs/s; profiles/r4_call18_*).  CLIP was trained in fp16; the T5 stack is not fp16-safe and
+ *                  is not touched.  0: bf16 there too, the reference's dtype (mm_utils.py:228) and rounds 1-3's tower.  1 needs
+ *                  gemm_variant 3.  Set it before asking for the encode workspace size (one more buffer).
  *   "stream_gemm"  1 (default) skinny batched GEMMs (<= 128 rows per entry: the reassociated cross-attention's two products over
  *                  the encoder output) run the HBM-streaming form (csrc/gemm_stream.inc), 0 the persistent 256-row kernel;
  *                  bitwise equal
@@ -224,6 +225,9 @@ int vqs_score_head(const float* d_logits, int32_t ldl, int32_t V, const int32_t*
  *   per-shape cache-policy names ("tile_order:", "l2_touch:", "nt_store:"): lab switches, see include/vqs_debug.h
  * Returns VQS_ERR_INVALID for an unknown name or value. */
 int vqs_set_option(vqs_handle* h, const char* name, int32_t value);
+/* the current value of one of the scalar options above (not the per-shape "tile_order:" / "nt_store:" / "l2_touch:" entries); what a
+ * checker asks to mirror the arithmetic the handle will run (the rounding-matched oracle, tests/test_gpu_stage_locked.py) */
+int vqs_get_option(const vqs_handle* h, const char* name, int32_t* value);
 
 /* Test hooks (stage taps, host-side restatements of the kernels' index arithmetic) and the cache-policy / execution-form lab
  * switches of vqs_set_option are declared and documented in include/vqs_debug.h -- not part of the drop-in boundary. */

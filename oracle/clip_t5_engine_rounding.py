@@ -195,7 +195,7 @@ class EngineRoundedOracle(Oracle):
     DEC_FP32 = ("dec.qkv", "dec.delta")
 
     def __init__(self, cfg, weights, emulate="engine", round_fn=bf16_round, acc=torch.float64, classes=None, dec_precise=True,
-                 split_classes=(), half_classes=(), vit_fp16=False):
+                 split_classes=(), half_classes=(), vit_fp16=True):
         """`split_classes`: classes (of the tower / projector / encoder) to model as split-bf16 tensors instead of bf16 ones -- a
         what-if for tools/error_attribution.py, nothing the engine does today; the extra name "vit.v" splits the value heads only
         (q and k stay bf16: the score path).  `half_classes`: classes to model as IEEE fp16 tensors (11 significant bits instead of
@@ -215,7 +215,7 @@ class EngineRoundedOracle(Oracle):
         unknown = set(half_classes) - set(self.CLASSES)
         if unknown:
             raise ValueError(f"unknown half classes {sorted(unknown)}")
-        self.vit_fp16 = bool(vit_fp16)
+        self.vit_fp16 = bool(vit_fp16)           # default = what ships (the engine's default); False = the bf16 tower of rounds 1-3
         if self.vit_fp16:
             half_classes = tuple(half_classes) + tuple(c for c in self.CLASSES if c.startswith("vit.")) + ("proj.mid",)
         self.half_extra = frozenset(half_classes)

@@ -45,10 +45,10 @@ struct vqs_handle {
     std::vector<const bf16_t*> vit_qkv_w, vit_qkv_b, enc_qkv, enc_wi, dec_qkv, dec_ckv, dec_wi, dec_ckT;
     int cross_mode = 1;   // 1 = reassociated cross-attention (default), 0 = per-layer K|V projection of the encoder output
     int stream_gemm = 1;  // 1 = skinny batched launches (M <= 128 rows per entry) take the HBM-streaming GEMM form (gemm_stream.inc; bitwise the 8-wave forms), 0 = never
-    int vit_fp16 = 0;     // 1 = the vision tower and the projector run on IEEE fp16 operands (11 significant bits instead of bf16's 8, same MFMA rate and
+    int vit_fp16 = 1;     // 1 (default) = the vision tower and the projector run on IEEE fp16 operands (11 significant bits instead of bf16's 8, same MFMA rate and
                           // bytes): fp16 copies of their weights (made at bind time), fp16 activations, fp32 accumulation / residual stream / statistics
                           // as before; the image features leave as bf16 (the C ABI's type).  CLIP was trained in fp16; the T5 stack is NOT fp16-safe
-                          // and stays bf16.  0 = bf16 tower (rounds 1-4 default)
+                          // and stays bf16.  0 = the bf16 tower of rounds 1-3 (what the reference's dtype would give)
     std::vector<const bf16_t*> vit_qkv_w16, vit_out_w16, vit_fc1_w16, vit_fc2_w16;   // the fp16 copies (packed buffer)
     const bf16_t* proj0_w16 = nullptr;
     const bf16_t* proj2_w16 = nullptr;
@@ -586,6 +586,21 @@ int vqs_set_option(vqs_handle* h, const char* name, int32_t value) {
     return VQS_OK;
 }
 
+int vqs_get_option(const vqs_handle* h, const char* name, int32_t* value) {
+    if (!h || !name || !value) return VQS_ERR_INVALID;
+    const std::string n(name);
+    if (n == "cross_mode") *value = h->cross_mode;
+    else if (n == "splitk") *value = h->splitk;
+    else if (n == "fused_norm") *value = h->fused_norm;
+    else if (n == "norm_defer") *value = h->norm_defer;
+    else if (n == "dec_precise") *value = h->dec_precise;
+    else if (n == "vit_fp16") *value = h->vit_fp16;
+    else if (n == "stream_gemm") *value = h->stream_gemm;
+    else if (n == "gemm_variant") *value = h->gemm_variant;
+    else return VQS_ERR_INVALID;
+    return VQS_OK;
+}
+
 void vqs_destroy(vqs_handle* h) {
     if (!h) return;
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
@@ -726,7 +741,7 @@ int vqs_encode_images(vqs_handle* h, const void* d_pixels, int32_t N, void* d_fe
     // bf16 operands.
     const bool f16 = h->vit_fp16 != 0;
     if (f16 && h->gemm_variant != 3)
-        return fail(h, VQS_ERR_STATE, "encode_images: option vit_fp16 needs gemm_variant 3 (the fp16 linears exist in the quad form only)");
+        return fail(h, VQS_ERR_STATE, "encode_images: the fp16 vision tower (option vit_fp16, default 1) needs gemm_variant 3 -- its linears exist in the quad form only; set vit_fp16=0 to A/B other GEMM forms");
 
     GETW(cls, "vision.embeddings.class_embedding", hid);
     GETW(pos, "vision.embeddings.position_embedding.weight", (int64_t)Sv * hid);

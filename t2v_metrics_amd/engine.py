@@ -70,6 +70,7 @@ _SIGNATURES = {
     "vqs_score_head": (_c_i32, [_c_vp, _c_i32, _c_i32, _c_vp, _c_vp, _c_vp, _c_i32, _c_i32, _c_vp]),
     "vqs_attention_lds_bytes": (ctypes.c_int64, [_c_i32, _c_i32, _c_i32]),
     "vqs_set_option": (_c_i32, [_c_vp, ctypes.c_char_p, _c_i32]),
+    "vqs_get_option": (_c_i32, [_c_vp, ctypes.c_char_p, ctypes.POINTER(_c_i32)]),
     "vqs_debug_tap": (_c_i32, [_c_vp, ctypes.c_char_p, _c_vp, ctypes.c_size_t]),
     "vqs_debug_tap_window": (_c_i32, [_c_vp, _c_i32, _c_i32]),
     "vqs_debug_gemm_form": (_c_i32, [_c_i32] * 11),
@@ -289,6 +290,12 @@ class VqsEngine:
         if name == "flags":
             return self._ws[off: off + 4].view(torch.int32)
         raise VqsError(f"unknown stage {name}")
+
+    def get_option(self, name: str) -> int:
+        """Current value of a scalar execution-form option (include/vqs.h), defaults included."""
+        v = _c_i32(0)
+        self._check(self.lib.vqs_get_option(self._h, name.encode(), ctypes.byref(v)), "vqs_get_option")
+        return int(v.value)
 
     def set_option(self, name: str, value: int):
         self._check(self.lib.vqs_set_option(self._h, name.encode(), int(value)), "vqs_set_option")

@@ -21,6 +21,14 @@ int main() {
     assert(vqs_generate_workspace_bytes(h, 4, 33, 64) > 0 && vqs_generate_workspace_bytes(h, 4, 33, 100000) == 0);
     assert(vqs_set_option(h, "cross_mode", 0) == 0 && vqs_set_option(h, "cross_mode", 1) == 0);
     assert(vqs_set_option(h, "cross_mode", 7) != 0 && vqs_set_option(h, "nonsense", 1) != 0 && vqs_set_option(h, nullptr, 1) != 0);
+    {
+        int32_t v = -1;                                   // defaults are readable, a set is read back, unknown names and null arguments are refused
+        assert(vqs_get_option(h, "vit_fp16", &v) == 0 && v == 1 && vqs_get_option(h, "dec_precise", &v) == 0 && v == 1);
+        assert(vqs_get_option(h, "gemm_variant", &v) == 0 && v == 3 && vqs_get_option(h, "cross_mode", &v) == 0 && v == 1);
+        assert(vqs_set_option(h, "vit_fp16", 0) == 0 && vqs_get_option(h, "vit_fp16", &v) == 0 && v == 0 && vqs_set_option(h, "vit_fp16", 1) == 0);
+        assert(vqs_set_option(h, "vit_fp16", 2) != 0 && vqs_get_option(h, "nonsense", &v) != 0 && vqs_get_option(h, "vit_fp16", nullptr) != 0);
+        assert(vqs_get_option(nullptr, "vit_fp16", &v) != 0 && vqs_get_option(h, nullptr, &v) != 0 && vqs_get_option(h, "tile_order:64x64", &v) != 0);
+    }
     assert(strlen(vqs_last_error(h)) > 0);
     int dummy = 0;
     assert(vqs_debug_tap(h, "enc.3.xn0", &dummy, 4) == 0 && vqs_debug_tap(h, "enc.3.xn0", nullptr, 0) == 0 && vqs_debug_tap(h, nullptr, nullptr, 0) == 0);

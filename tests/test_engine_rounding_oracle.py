@@ -45,8 +45,11 @@ def test_with_roundings_it_sits_at_the_bf16_floor_and_dispatches_from_oracle(nam
     out = emu.forward(pix.float(), idx, ids, labels, return_stages=True)
     d = (out["label_logprobs"] - ref).abs().max().item()
     assert 1e-5 < d < 8e-2, d                    # roundings are really applied, and only roundings
-    for k in ("vit_feats", "proj", "enc_out"):                   # bf16-held tensors are exactly representable
+    for k in ("proj", "enc_out"):                                # bf16-held tensors are exactly representable
         assert torch.equal(out[k], bf16_round(out[k])), k
+    assert emu.vit_fp16 and torch.equal(out["vit_feats"], out["vit_feats"].half().float())     # the tower ships in fp16 (option vit_fp16 = 1)
+    bf_tower = EngineRoundedOracle(cfg, w, vit_fp16=False).forward(pix.float(), idx, ids, labels, return_stages=True)
+    assert torch.equal(bf_tower["vit_feats"], bf16_round(bf_tower["vit_feats"]))               # rounds 1-3's tower: bf16
     # the decoder's final norm output is a SPLIT-bf16 tensor since round 4 (hi + lo planes): representable as such, not in one plane
     from oracle.clip_t5_engine_rounding import split_bf16_round
     assert torch.equal(out["dec_out"], split_bf16_round(out["dec_out"])) and not torch.equal(out["dec_out"], bf16_round(out["dec_out"]))
@@ -126,8 +129,9 @@ def test_fp16_tower_mode_is_the_same_function_with_finer_roundings(name):
     off = EngineRoundedOracle(cfg, w, round_fn=lambda x: x.float(), vit_fp16=True).forward(pix.float(), idx, ids, labels, return_stages=True)
     for k in ("vit_feats", "proj", "label_logprobs"):
         assert (ref[k] - off[k]).abs().max().item() <= 5e-5 * max(1.0, ref[k].abs().max().item()), k   # fp16 weight copies: exact above 2^-14
-    bf = EngineRoundedOracle(cfg, w).forward(pix.float(), idx, ids, labels, return_stages=True)
-    emu = Oracle(cfg, w, emulate="engine", vit_fp16=True)
+    bf = EngineRoundedOracle(cfg, w, vit_fp16=False).forward(pix.float(), idx, ids, labels, return_stages=True)
+    emu = Oracle(cfg, w, emulate="engine")                               # the default IS the fp16 tower
+    assert emu.vit_fp16
     emu.record = {}
     hf = emu.forward(pix.float(), idx, ids, labels, return_stages=True)
     rec, emu.record = emu.record, None
@@ -138,7 +142,7 @@ def test_fp16_tower_mode_is_the_same_function_with_finer_roundings(name):
     assert (hf["proj"] - ref["proj"]).abs().mean().item() < (bf["proj"] - ref["proj"]).abs().mean().item()
     # taps: the tower's 16-bit tensors are fp16, everything else what it was
     shapes = emu.tap_shapes(pix.shape[0], ids.shape[0], ids.shape[1], labels.shape[1])
-    base = EngineRoundedOracle(cfg, w).tap_shapes(pix.shape[0], ids.shape[0], ids.shape[1], labels.shape[1])
+    base = EngineRoundedOracle(cfg, w, vit_fp16=False).tap_shapes(pix.shape[0], ids.shape[0], ids.shape[1], labels.shape[1])
     assert set(shapes) == set(base)
     for n in shapes:
         tower16 = n.startswith("vit.") and n not in ("vit.patch_out", "vit.h0")

@@ -27,7 +27,7 @@ ATTENTION_TAPS = ("attn", "sattn", "cctx", "cattn")
 PRECISE_DEC_TAPS = ("xn0", "xn1", "xn2", "qkv", "sattn", "d_self", "cctx", "cattn", "d_cross", "ff", "d_ff")   # fp32 or split-bf16 in the decoder
 
 
-def run_stage_locked(cfg, w, eng, pix, idx, ids, labels, tag, window=None, vit_fp16=False):
+def run_stage_locked(cfg, w, eng, pix, idx, ids, labels, tag, window=None, vit_fp16=None):
     """window = (first, count): the pass runs on the WHOLE batch, the taps and the oracle cover pairs first .. first+count-1
     (vqs_debug_tap_window; their images must be rows first .. of `pix` in order) -- the stage-locked check of a few sampled
     pairs inside a batch too large to tap whole (the benchmarked 256-pair XXL batch)."""
@@ -35,6 +35,9 @@ def run_stage_locked(cfg, w, eng, pix, idx, ids, labels, tag, window=None, vit_f
     w_cpu = {k: v.cpu() for k, v in w.items()}
     # vit_fp16: the engine must already run its tower on fp16 operands (option "vit_fp16"); the oracle then rounds the tower's tensors to
     # fp16, reads the fp16 copies of its weights and decodes the tower's taps as fp16
+    if vit_fp16 is None:
+        vit_fp16 = bool(eng.get_option("vit_fp16"))          # the engine's own setting (default: fp16 tower)
+    assert vit_fp16 == bool(eng.get_option("vit_fp16"))
     emu = Oracle(cfg, w_cpu, emulate="engine", vit_fp16=vit_fp16)
     B, L = ids.shape
     T = labels.shape[1]
@@ -140,10 +143,14 @@ def test_every_launch_matches_the_oracle_with_the_fp16_vision_tower(name, B, n_i
     cfg = get_config(name)
     w = make_seeded_weights(cfg, seed=11, device="cpu", lm_head_gain=gain)
     pix, img_index, ids, labels = _inputs(cfg, B, n_img, L, T, seed=100 + B)
-    eng = VqsEngine(cfg, w, device="cuda:0", options={"vit_fp16": 1})
+    eng = VqsEngine(cfg, w, device="cuda:0")
     try:
-        report, _ = run_stage_locked(cfg, w, eng, pix, img_index, ids, labels, f"{name}-B{B}-L{L}-T{T}-gain{gain}-vit_fp16", vit_fp16=True)
+        assert eng.get_option("vit_fp16") == 1 and eng.get_option("dec_precise") == 1          # what ships
+        report, _ = run_stage_locked(cfg, w, eng, pix, img_index, ids, labels, f"{name}-B{B}-L{L}-T{T}-gain{gain}-vit_fp16")
         assert sum(r["mant_bits"] == 10 for r in report.values()) == 9 * cfg.vision.layers_run + 2
+        eng.set_option("vit_fp16", 0)                                                         # ... and the bf16 tower of rounds 1-3, same handle
+        report, _ = run_stage_locked(cfg, w, eng, pix, img_index, ids, labels, f"{name}-B{B}-L{L}-T{T}-gain{gain}-vit_bf16")
+        assert not any(r["mant_bits"] == 10 for r in report.values())
     finally:
         eng.close()
 
