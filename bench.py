@@ -690,8 +690,8 @@ def run_config0():
 
 
 PARITY_GAINS = (1.0, 4.0)          # lm_head x gain: 1 = the seeded head (log P ~ -10), 4 = the peaked-head regime (the head is linear: re-read)
-DLOGP_BOUND = 4.5e-3               # end-to-end |delta log P| bound on the bench sample at gain 1: 3 x the measured 1.45e-3 max over 16 XXL pairs
-                                   # (profiles/r4_call5_*; mean 7.0e-4; round 3's bf16 decoder: 2.6e-3 .. 9.0e-3, gate 2.5e-2)
+DLOGP_BOUND = 2.1e-3               # end-to-end |delta log P| bound on the bench sample at gain 1: 3 x the measured 6.98e-4 max over 16 XXL pairs
+                                   # (profiles/r4_call18_*; mean 3.30e-4; with the bf16 tower 1.45e-3 / 7.0e-4; round 3's bf16 decoder: 2.6e-3 .. 9.0e-3, gate 2.5e-2)
 
 
 def parity_sample(cfg, weights, eng, job, n_pairs):
