@@ -50,11 +50,12 @@ class Runner:
         self.cache = {}
 
     def _oracle(self, classes, dec_precise, split=()):
+        ship = "ship:vit_fp16" in split                                      # the engine's option itself (fp16 GEMM result of the projector, then bf16)
         half = tuple(c[5:] for c in split if c.startswith("half:"))          # "half:<class>" entries of a what-if's set: fp16 tensors
-        split = tuple(c for c in split if not c.startswith("half:"))
+        split = tuple(c for c in split if not c.startswith(("half:", "ship:")))
         # vit_fp16=False: the table models every class as a bf16 rounding (the engine of rounds 1-3) and adds fp16 / split stages explicitly
         return EngineRoundedOracle(self.cfg, self.w, acc=self.acc, classes=classes, dec_precise=dec_precise, split_classes=split,
-                                   half_classes=half, vit_fp16=False)
+                                   half_classes=half, vit_fp16=ship)
 
     def run(self, classes, dec_precise=False, split=()):
         classes = frozenset(classes)
@@ -145,7 +146,8 @@ def main():
     # (the last of these, with the projector's output rounded to fp16 and then to the bf16 feature tensor, is what ships: option vit_fp16)
     runs += [("what-if: precise decoder, vit.* in fp16", ALL, True, half("vit")),
              ("what-if: precise decoder, vit.* proj.* in fp16", ALL, True, half("vit", "proj")),
-             ("what-if: bf16 decoder, vit.* proj.* in fp16", ALL, False, half("vit", "proj"))]
+             ("what-if: bf16 decoder, vit.* proj.* in fp16", ALL, False, half("vit", "proj")),
+             ("engine as shipped at the end of round 4 (precise decoder + option vit_fp16)", ALL, True, ("ship:vit_fp16",))]
     runs = [(r + (False, ()))[:4] if len(r) < 4 else r for r in runs]          # (name, classes, precise decoder, split set)
     if a.only:
         keep = set(a.only.split(";"))
