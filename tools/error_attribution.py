@@ -148,6 +148,11 @@ def main():
              ("what-if: precise decoder, vit.* proj.* in fp16", ALL, True, half("vit", "proj")),
              ("what-if: bf16 decoder, vit.* proj.* in fp16", ALL, False, half("vit", "proj")),
              ("engine as shipped at the end of round 4 (precise decoder + option vit_fp16)", ALL, True, ("ship:vit_fp16",))]
+    # next candidate: the encoder's attention side in fp16 as well -- what HF's own fp16 T5 path holds in fp16 (it keeps only `wo` in fp32,
+    # modeling_t5.py `_keep_in_fp32_modules`); the residual stream is fp32 here anyway
+    enc_attn_side = ("half:enc.norm", "half:enc.qkv", "half:enc.p", "half:enc.attn", "half:enc.out")
+    runs += [("what-if: as shipped + encoder norm / q k v / P / attention output / final norm in fp16", ALL, True, ("ship:vit_fp16",) + enc_attn_side),
+             ("what-if: as shipped + every encoder class in fp16", ALL, True, ("ship:vit_fp16",) + half("enc"))]
     runs = [(r + (False, ()))[:4] if len(r) < 4 else r for r in runs]          # (name, classes, precise decoder, split set)
     if a.only:
         keep = set(a.only.split(";"))
