@@ -50,7 +50,7 @@ __device__ __forceinline__ uint32_t a_pack2(float a, float b) {   // v_cvt_pk_bf
 // same rate; P and the output are packed to the operand type
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(2))) _Float16 a_f16x2;
-__device__ __forceinline__ uint32_t a_pack2h(float a, float b) {   // two v_cvt_f16_f32 (RNE) + v_pack_b32_f16
+__device__ __forceinline__ uint32_t a_pack2h(float a, float b) {   // v_cvt_pk_f16_f32 on gfx950 (RNE, overflow -> inf)
     a_f16x2 v;
     v[0] = (_Float16)a;
     v[1] = (_Float16)b;

@@ -60,7 +60,7 @@ __device__ __forceinline__ float4 h4_to_f4(uint2 u) {
     const e_f16x4 h = __builtin_bit_cast(e_f16x4, u);
     return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
 }
-__device__ __forceinline__ uint32_t e_pack2_h(float a, float b) {    // two v_cvt_f16_f32 (RNE; overflow -> inf) + v_pack_b32_f16
+__device__ __forceinline__ uint32_t e_pack2_h(float a, float b) {    // v_cvt_pk_f16_f32 on gfx950 (RNE; overflow -> inf)
     e_f16x2 v;
     v[0] = (_Float16)a;
     v[1] = (_Float16)b;

@@ -52,7 +52,7 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {
 }
 
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
-__device__ __forceinline__ uint32_t pack2h(float a, float b) {   // two v_cvt_f16_f32 (RNE, overflow -> inf) + v_pack_b32_f16
+__device__ __forceinline__ uint32_t pack2h(float a, float b) {   // v_cvt_pk_f16_f32 on gfx950 (RNE, overflow -> inf)
     f16x2_t v;
     v[0] = (_Float16)a;
     v[1] = (_Float16)b;
