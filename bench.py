@@ -221,12 +221,16 @@ def device_kernels(path=None):
     return out
 
 
-def gemm_kernels_hash(path=None):
+GEMM_KERNEL_PATTERNS = ("gemm_bf16_",)      # the record of round 4 was collected before the fp16 instantiations existed; newer records name theirs
+
+
+def gemm_kernels_hash(path=None, patterns=GEMM_KERNEL_PATTERNS):
     """sha256 over the machine code and the kernel descriptors of every GEMM kernel of the shipped library (`vqs::gemm_bf16_*`, the launches
-    `roofline.traffic` was measured on), by sorted symbol name.  Finer than device_code_hash(): it does not change when OTHER kernels are
+    `roofline.traffic` was measured on; `patterns`: which symbols count -- a record made with the fp16 tower in the step names
+    ("gemm_bf16_", "gemm_f16_")), by sorted symbol name.  Finer than device_code_hash(): it does not change when OTHER kernels are
     added to or edited in the library, and changes with any instruction or register count of a GEMM kernel.  None without the library."""
     import hashlib
-    ks = {n: v for n, v in device_kernels(path).items() if "gemm_bf16_" in n}
+    ks = {n: v for n, v in device_kernels(path).items() if any(p in n for p in patterns)}
     if not ks:
         return None
     h = hashlib.sha256()
@@ -241,7 +245,7 @@ def traffic_stamp_matches(tj):
     """Is the PMC record `tj` (profiles/gemm_traffic_*.json) about the code this process runs?  The stamp of the GEMM kernels' machine
     code if the record has one, else the whole-library device-code stamp, else the source stamp of older records.  -> (bool, description)."""
     if tj.get("gemm_kernels_sha256_16"):       # the measured kernels themselves (survives additions of other kernels to the library)
-        now = gemm_kernels_hash()
+        now = gemm_kernels_hash(patterns=tuple(tj.get("gemm_kernels_patterns") or GEMM_KERNEL_PATTERNS))
         return tj["gemm_kernels_sha256_16"] == now, "GEMM kernels' code sha256 %s (now %s)" % (tj["gemm_kernels_sha256_16"], now)
     if tj.get("device_code_sha256_16"):
         now = device_code_hash()

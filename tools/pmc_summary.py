@@ -24,11 +24,13 @@ for key, c in res.items():
 #   FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-B read requests as 64 B => x2
 #   (MI355X_MICROARCH.md, "HBM"); WRITE_SIZE is taken as reported (uncalibrated there).
 import json, os
+seen_f16 = False
 tot = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}
 cnt = {"FETCH_SIZE": 0, "WRITE_SIZE": 0}
 for key, c in res.items():
-    if "gemm_bf16" not in key[0]:
+    if "gemm_bf16" not in key[0] and "gemm_f16" not in key[0]:     # the fp16 tower's launches are GEMM launches of the step too
         continue
+    seen_f16 = seen_f16 or "gemm_f16" in key[0]
     for cn in tot:
         if cn in c:
             v, n, dur = c[cn]
@@ -38,14 +40,16 @@ if cnt["FETCH_SIZE"] and cnt["WRITE_SIZE"]:
     fetch = 2.0 * 1024.0 * tot["FETCH_SIZE"] / cnt["FETCH_SIZE"]
     write = 1024.0 * tot["WRITE_SIZE"] / cnt["WRITE_SIZE"]
     out = {"source": "rocprofv3 --kernel-trace --pmc (separate FETCH_SIZE / WRITE_SIZE passes) over bench.py --steps 1 --warmup 1",
-           "kernels": "vqs::gemm_bf16_* (all GEMM launches of the run)", "launches_per_pass": cnt["FETCH_SIZE"],
+           "kernels": "vqs::gemm_bf16_* + vqs::gemm_f16_* (all GEMM launches of the run)", "launches_per_pass": cnt["FETCH_SIZE"],
+           "vit_fp16": seen_f16,           # were fp16 GEMM launches (the fp16 vision tower) part of the collection?
            "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write, "traffic_bytes_per_launch": fetch + write,
            "corrections": "FETCH_SIZE KiB x 1024 x 2 (gfx950 128-B requests tallied at 64 B); WRITE_SIZE KiB x 1024 as reported"}
     try:                                    # stamp with the kernel sources the counters were taken on (bench.py checks it)
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         import bench
         out["csrc_sha256_16"] = bench.csrc_hash()
-        out["gemm_kernels_sha256_16"] = bench.gemm_kernels_hash()     # machine code + descriptors of the vqs::gemm_bf16_* kernels alone
+        out["gemm_kernels_patterns"] = ["gemm_bf16_", "gemm_f16_"]
+        out["gemm_kernels_sha256_16"] = bench.gemm_kernels_hash(patterns=tuple(out["gemm_kernels_patterns"]))   # machine code + descriptors of the GEMM kernels alone
         out["device_code_sha256_16"] = bench.device_code_hash()       # the .hip_fatbin section of the library the passes ran
     except Exception as e:
         out["csrc_sha256_16"] = None
