@@ -93,3 +93,46 @@ def test_traffic_provenance_stamps():
     assert ok and g in how                                                            # ... and it wins over the whole-library stamp
     assert not bench.traffic_stamp_matches({"gemm_kernels_sha256_16": "0" * 16, "device_code_sha256_16": h})[0]
     assert rec["gemm_kernels_sha256_16"] == g, "profiles/gemm_traffic_xxl_b256.json was measured on other GEMM kernels: re-run tools/gpu_pmc_bench.sh"
+
+
+def test_pmc_summary_counts_both_gemm_kernel_families_and_stamps_the_record(tmp_path):
+    """tools/pmc_summary.py on a synthetic rocprofv3 database (two passes: FETCH_SIZE, WRITE_SIZE): the per-launch traffic averages over
+    the bf16 AND the fp16 GEMM launches, other kernels are left out, the record says whether fp16 launches were in the collection and carries
+    the stamps bench.traffic_stamp_matches checks -- so that the next collection on the GPU box does not fail on the summary step."""
+    import json
+    import sqlite3
+    import subprocess
+    import sys
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, "t2v_metrics_amd", "libvqs_hip.so")):
+        pytest.skip("library not built")
+    rows = {"FETCH_SIZE": [("void vqs::gemm_bf16_quad<5>(vqs::GemmParams)", 65536, 3, 4000.0), ("void vqs::gemm_f16_quad<0>(vqs::GemmParams)", 65536, 1, 2000.0),
+                           ("void vqs::attn_fwd_dma_kernel<true>(vqs::AttnParams)", 1024, 5, 9e9)],
+            "WRITE_SIZE": [("void vqs::gemm_bf16_quad<5>(vqs::GemmParams)", 65536, 3, 1000.0), ("void vqs::gemm_f16_quad<0>(vqs::GemmParams)", 65536, 1, 3000.0)]}
+    for with_f16 in (True, False):
+        d = tmp_path / ("f16" if with_f16 else "bf16")
+        d.mkdir()
+        for i, (ctr, rs) in enumerate(rows.items()):
+            con = sqlite3.connect(str(d / f"pass{i + 1}_results.db"))
+            con.execute("create table counters_collection (kernel_name text, counter_name text, grid_size int, value real, start int, end int)")
+            for kn, gs, n, v in rs:
+                if "gemm_f16" in kn and not with_f16:
+                    continue
+                for _ in range(n):
+                    con.execute("insert into counters_collection values (?,?,?,?,?,?)", (kn, ctr, gs, v, 0, 1000))
+            con.commit()
+            con.close()
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "pmc_summary.py"), str(d), "vqs::"], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr[-800:]
+        rec = json.load(open(d / "gemm_traffic.json"))
+        n = 4 if with_f16 else 3
+        fetch = 2 * 1024 * ((3 * 4000.0 + (2000.0 if with_f16 else 0.0)) / n)       # KiB -> bytes, x2: gfx950 tallies 128-B requests at 64 B
+        write = 1024 * ((3 * 1000.0 + (3000.0 if with_f16 else 0.0)) / n)
+        assert rec["launches_per_pass"] == n and rec["vit_fp16"] is with_f16
+        assert rec["fetch_bytes_per_launch"] == pytest.approx(fetch) and rec["write_bytes_per_launch"] == pytest.approx(write)
+        assert rec["traffic_bytes_per_launch"] == pytest.approx(fetch + write)
+        assert rec["gemm_kernels_patterns"] == ["gemm_bf16_", "gemm_f16_"]
+        assert rec["gemm_kernels_sha256_16"] == bench.gemm_kernels_hash(patterns=("gemm_bf16_", "gemm_f16_")) != bench.gemm_kernels_hash()
+        ok, how = bench.traffic_stamp_matches(rec)
+        assert ok and rec["gemm_kernels_sha256_16"] in how
