@@ -8,9 +8,7 @@ from abc import ABC, abstractmethod
 from pathlib import Path
 from typing import List
 
-import numpy as np
 import torch
-from PIL import Image
 
 from ..constants import HF_CACHE_DIR
 

@@ -26,7 +26,6 @@ import torch
 
 from ...config import get_config
 from ...constants import (CONTEXT_LEN, DEFAULT_IMAGE_TOKEN, HF_CACHE_DIR, IGNORE_INDEX, IMAGE_TOKEN_INDEX, SYSTEM_MSG)
-from ...preprocess import preprocess_batch
 from .mm_utils import t5_tokenizer_image_token
 from .vqa_model import VQAScoreModel
 

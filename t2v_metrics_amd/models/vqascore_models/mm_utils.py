@@ -4,7 +4,6 @@ t5_tokenizer_image_token)."""
 from typing import List, Sequence
 
 import torch
-from PIL import Image
 
 from ...constants import IMAGE_TOKEN_INDEX, DEFAULT_IMAGE_TOKEN
 

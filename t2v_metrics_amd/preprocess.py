@@ -11,7 +11,7 @@ the output is handed to the device as bf16.
 """
 from __future__ import annotations
 
-from typing import Iterable, List, Sequence
+from typing import Sequence
 
 import numpy as np
 import torch

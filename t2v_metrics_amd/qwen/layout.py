@@ -5,7 +5,7 @@ path supports: every video of one vision call has the same (t, h, w) grid (the w
 attention windows at the right / bottom edge of a frame are handled by a padded windowed layout."""
 from __future__ import annotations
 
-from typing import Dict, List, Sequence, Tuple
+from typing import Dict, Sequence, Tuple
 
 import torch
 

@@ -82,7 +82,6 @@ def test_missing_library_fails_loudly(tmp_path):
 
 
 def test_engine_refuses_cpu_device():
-    import torch
     from t2v_metrics_amd import engine
     from t2v_metrics_amd.config import get_config
     with pytest.raises(engine.VqsError, match="no CPU path"):

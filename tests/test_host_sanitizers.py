@@ -5,7 +5,6 @@ offsets, the argument checks of the pass entry points, the integer helpers -- li
 and the ordinary device objects.  The reference has no sanitizer or race tooling; the device side is
 covered by the bitwise-repeatability and stage-locked tests on the GPU."""
 import os
-import shutil
 import subprocess
 
 import pytest

@@ -1,6 +1,5 @@
 """CPU tests of the round-4 parity tooling: the per-class switches of the rounding-matched oracle (what tools/error_attribution.py
 varies), the split-bf16 rounding, and the arithmetic of bench.py's 16-pair |delta log P| table (parity_sample) on an engine double."""
-import numpy as np
 import pytest
 import torch
 
