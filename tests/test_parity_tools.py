@@ -51,6 +51,30 @@ def test_rounding_classes_switch_individually_and_the_precise_decoder_is_closer(
         EngineRoundedOracle(cfg, w, classes=("dec.nope",))
 
 
+def test_what_if_switches_of_the_attribution_tool():
+    """`split_classes` / `half_classes` / `vit_fp16` (what tools/error_attribution.py's what-if runs vary): a stage modelled as split-bf16 or
+    fp16 tensors sits between its bf16 model and exact; "vit.v" splits the value heads only; unknown names are refused; the engine's option
+    (vit_fp16 = True, the default) is the all-fp16 tower with the projector's result rounded to fp16 and then to the bf16 feature tensor."""
+    cfg, w, pix, idx, ids, labels = _case()
+    feats = lambda **kw: EngineRoundedOracle(cfg, w, acc=torch.float32, dec_precise=True, **kw).vision_features(pix)
+    exact = feats(classes=(), vit_fp16=False)
+    vit = tuple(c for c in EngineRoundedOracle.CLASSES if c.startswith("vit."))
+    err = lambda f: (f - exact).abs().mean().item()
+    e_bf = err(feats(classes=vit, vit_fp16=False))
+    e_half = err(feats(classes=vit, vit_fp16=False, half_classes=vit))
+    e_split = err(feats(classes=vit, vit_fp16=False, split_classes=("vit.norm", "vit.v", "vit.attn", "vit.act", "vit.delta", "vit.feat")))
+    e_split_no_v = err(feats(classes=vit, vit_fp16=False, split_classes=("vit.norm", "vit.attn", "vit.act", "vit.delta", "vit.feat")))
+    assert 0.0 < e_half < 0.25 * e_bf and 0.0 < e_split < 0.5 * e_bf and e_split < e_split_no_v < e_bf, (e_bf, e_half, e_split, e_split_no_v)   # q, k, P stay bf16 in the split model
+    assert torch.equal(feats(classes=vit, vit_fp16=False, half_classes=vit), feats(classes=vit, vit_fp16=True))      # the option = every tower class in fp16
+    o = EngineRoundedOracle(cfg, w, acc=torch.float32)
+    assert o.vit_fp16 and "proj.mid" in o.half_extra and "proj.out" not in o.half_extra
+    proj = o.projector(o.vision_features(pix))
+    assert torch.equal(proj, bf16_round(proj))                              # the feature tensor handed to the T5 pass stays bf16
+    for bad in ({"split_classes": ("vit.nope",)}, {"half_classes": ("vit.v",)}, {"half_classes": ("enc.nope",)}):
+        with pytest.raises(ValueError):
+            EngineRoundedOracle(cfg, w, **bad)
+
+
 def test_bench_parity_sample_table_on_an_engine_double():
     """parity_sample: truth = the oracle on the job's device, HIP logits = the engine's `logits` stage; head gains re-read both."""
     import bench
