@@ -174,3 +174,20 @@ def test_shipped_library_has_no_lab_code_and_reads_no_environment():
         assert "getenv" not in text and "VQS_LAB" not in text, src + ": environment switch / lab flavour is back"
         assert "VQS_ABLATE" not in text and "VQS_ATTN_ABLATE" not in text, src + ": ablation scaffolding is back"
     assert not os.path.exists(os.path.join(CSRC, "lab")), "csrc/lab is back"
+
+
+def test_the_tree_builds_to_the_device_code_the_gpu_records_were_made_with():
+    """profiles/validated_device_code.json names the device code (sha256 of the library's .hip_fatbin section; the build is deterministic)
+    that the last GPU runs of the suite / the bench were made with.  A device-code edit makes this fail on the CPU, before anything is
+    claimed about it: re-run the GPU suite, then update the record with the new hash and the new logs."""
+    import json
+    import bench
+    rec = json.load(open(os.path.join(ROOT, "profiles", "validated_device_code.json")))
+    so = os.path.join(ROOT, "t2v_metrics_amd", "libvqs_hip.so")
+    if not os.path.exists(so):
+        pytest.skip("library not built")
+    assert bench.device_code_hash(so) == rec["device_code_sha256_16"], \
+        "the shipped device code differs from the GPU-validated build: run the -m gpu suite and update profiles/validated_device_code.json"
+    assert bench.gemm_kernels_hash(so) == rec["gemm_kernels_sha256_16"]
+    for ref in rec["validated_by"]:
+        assert os.path.exists(os.path.join(ROOT, ref.split(" ")[0])), ref
