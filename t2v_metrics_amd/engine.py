@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from typing import Dict, Optional, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import torch
 
@@ -121,6 +121,21 @@ def make_vqs_config(cfg: ClipT5Config) -> VqsConfig:
                      t.d_ff, t.layers, t.dec_layers, t.vocab, t.rel_buckets, t.rel_max_distance, t.ln_eps)
 
 
+FP16_MAX_FINITE_ROUNDED = 65520.0      # values at or above this round to +-inf in IEEE fp16
+
+
+def fp16_unsafe_weights(weights: Dict[str, torch.Tensor]) -> List[str]:
+    """Names of the vision tower's / projector's linear weights that an fp16 copy cannot hold (|w| >= 65 520, or not finite): the
+    tensors vqs_bind_weights converts for option vit_fp16.  Any device; one reduction per tensor."""
+    bad = []
+    for k, w in weights.items():
+        if w.dim() == 2 and k.endswith(".weight") and (k.startswith("vision.encoder.layers.") or k.startswith("mm_projector.")):
+            m = float(w.detach().abs().max().float()) if w.numel() else 0.0
+            if not (m < FP16_MAX_FINITE_ROUNDED):          # also catches NaN / inf
+                bad.append(k)
+    return bad
+
+
 class VqsEngine:
     """One CLIP-FlanT5 replica on one GPU."""
 
@@ -179,6 +194,15 @@ class VqsEngine:
             rc = self.lib.vqs_bind_weights(self._h, descs, n, self._packed.data_ptr(), nbytes, _stream_ptr())
             self._check(rc, "vqs_bind_weights")
             torch.cuda.current_stream().synchronize()   # the bucket LUT upload reads handle-owned host memory
+            self._check_fp16_weights()
+
+    def _check_fp16_weights(self):
+        """The fp16 vision tower (option vit_fp16, default 1) reads fp16 copies of the tower's and the projector's linear weights: a
+        checkpoint whose weights do not fit the format must say so at bind time, not score with infinities."""
+        self._fp16_unsafe = fp16_unsafe_weights(self.weights)
+        if self._fp16_unsafe and self.get_option("vit_fp16"):
+            raise VqsError("these vision-tower / projector weights exceed the fp16 range (|w| >= 65520): %s -- pass options={'vit_fp16': 0} "
+                           "to run the tower on bf16 operands" % ", ".join(self._fp16_unsafe[:4]))
 
     # ------------------------------------------------------------------ the two stages
     def encode_images(self, pixels: torch.Tensor) -> torch.Tensor:
@@ -298,6 +322,8 @@ class VqsEngine:
         return int(v.value)
 
     def set_option(self, name: str, value: int):
+        if name == "vit_fp16" and int(value) == 1 and getattr(self, "_fp16_unsafe", None):
+            raise VqsError("vit_fp16 = 1 refused: weights outside the fp16 range: " + ", ".join(self._fp16_unsafe[:4]))
         self._check(self.lib.vqs_set_option(self._h, name.encode(), int(value)), "vqs_set_option")
         self._options[name] = int(value)
 

@@ -332,3 +332,38 @@ def test_rank_affinity_plan_follows_the_gpus_numa_node():
     assert plan_rank_affinity([-1, -1], {}, set(range(8)), 1) == [4, 5, 6, 7]                     # unknown topology
     assert plan_rank_affinity(numa, node_cpus, set(range(0, 128, 2)), 5) == list(range(80, 96, 2)) # restricted mask: 32 allowed cores on node 1, 4 ranks
     assert plan_rank_affinity([0], node_cpus, {3, 4}, 0) == [3, 4]                                # one rank: untouched
+
+
+def test_weights_that_do_not_fit_fp16_are_named_before_the_fp16_tower_reads_them():
+    """engine.fp16_unsafe_weights: the tensors vqs_bind_weights copies to fp16 for option vit_fp16 (the tower's and the projector's linear
+    weights) must be finite and below 65 520 in magnitude; VqsEngine.bind raises with their names otherwise."""
+    from t2v_metrics_amd.engine import FP16_MAX_FINITE_ROUNDED, fp16_unsafe_weights
+    from t2v_metrics_amd.weights import make_seeded_weights
+    cfg = get_config("tiny")
+    w = make_seeded_weights(cfg, seed=3, device="cpu")
+    assert fp16_unsafe_weights(w) == []
+    assert torch.tensor(FP16_MAX_FINITE_ROUNDED).half().isinf() and torch.isfinite(torch.tensor(65504.0).half())
+    k1, k2 = "vision.encoder.layers.1.mlp.fc1.weight", "mm_projector.2.weight"
+    w[k1] = w[k1].clone(); w[k1][0, 0] = 7.0e4
+    w[k2] = w[k2].clone(); w[k2][1, 1] = float("nan")
+    t5 = "encoder.block.0.layer.1.DenseReluDense.wo.weight"
+    w[t5] = w[t5].clone(); w[t5][0, 0] = 1.0e6                                   # the T5 stacks stay bf16: not this check's business
+    w["vision.encoder.layers.0.layer_norm1.weight"] = w["vision.encoder.layers.0.layer_norm1.weight"] * 1e5   # norm parameters stay bf16 too
+    assert sorted(fp16_unsafe_weights(w)) == sorted([k1, k2])
+    # the engine's bind-time check and the option guard, on an engine object without a device (the handle's option is stubbed)
+    from t2v_metrics_amd.engine import VqsEngine, VqsError
+    e = object.__new__(VqsEngine)
+    e.weights, e._h = w, None
+    for on in (1, 0):
+        e.get_option = lambda name, on=on: on
+        if on:
+            with pytest.raises(VqsError, match="exceed the fp16 range.*vit_fp16"):
+                e._check_fp16_weights()
+        else:
+            e._check_fp16_weights()                                              # bf16 tower: nothing to refuse
+    with pytest.raises(VqsError, match="vit_fp16 = 1 refused"):
+        e.set_option("vit_fp16", 1)
+    e.weights = make_seeded_weights(cfg, seed=3, device="cpu")
+    e.get_option = lambda name: 1
+    e._check_fp16_weights()
+    assert e._fp16_unsafe == []
