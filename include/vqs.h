@@ -208,7 +208,9 @@ int vqs_score_head(const float* d_logits, int32_t ldl, int32_t V, const int32_t*
  *                  left of the end-to-end |delta log P| (measured on the benchmarked batch: max 1.45e-3 -> 7.0e-4, mean 7.0e-4 -> 3.3e-4,
  *                  throughput 201.0 -> 200.5 pairs/s; profiles/r4_call18_*).  CLIP was trained in fp16; the T5 stack is not fp16-safe and
  *                  is not touched.  0: bf16 there too, the reference's dtype (mm_utils.py:228) and rounds 1-3's tower.  1 needs
- *                  gemm_variant 3.  Set it before asking for the encode workspace size (one more buffer).
+ *                  gemm_variant 3.  Set it before asking for the encode workspace size (one more buffer).  The tower's / projector's
+ *                  linear weights must be finite and below 65 520 in magnitude (any CLIP checkpoint is: the model was trained in fp16);
+ *                  the library does not look -- the Python binding checks at bind time and names the tensors (engine.fp16_unsafe_weights).
  *   "stream_gemm"  1 (default) skinny batched GEMMs (<= 128 rows per entry: the reassociated cross-attention's two products over
  *                  the encoder output) run the HBM-streaming form (csrc/gemm_stream.inc), 0 the persistent 256-row kernel;
  *                  bitwise equal
