@@ -262,6 +262,9 @@ ALSO_LEGS = {
                   "configs[2]: clip-flant5-xxl, GenAI-Bench-1600 stand-in, 6 of its 38 length buckets"),
     "qwen": (["bench.py", "--model", "qwen2.5-vl-7b", "--steps", "3", "--warmup", "1", "--cpu-pairs", "0", "--also", "none"],
              "configs[4]: qwen2.5-vl-7b, 8-frame video samples"),
+    "bf16_tower": (["bench.py", "--steps", "3", "--warmup", "1", "--cpu-pairs", "0", "--also", "none", "--opt", "vit_fp16=0", "--parity-only", "16"],
+                   "the headline configuration with the vision tower on bf16 operands (option vit_fp16 = 0: the reference's dtype, rounds 1-3's tower): "
+                   "throughput and the 16-pair |delta log P| table next to the main line's fp16 tower"),
     "pipeline": (["tools/bench_pipeline.py", "--model", "clip-flant5-xxl", "--pairs", "1280", "--reps", "1", "--host-slice", "8"],
                  "SURVEY 8f-1: VQAScoreModel.forward from 512x512 PNG files (decode, preprocessing, H2D, tokenisation, engine) on 1/8 of the "
                  "host's cores -- a rank's share at 8 GPUs per node"),
@@ -292,6 +295,9 @@ def run_also_leg(name):
     if isinstance(j.get("decode"), dict):
         out["decode_ms_per_step"] = j["decode"].get("ms_per_step")
         out["decode_tokens_per_s"] = j["decode"].get("tokens_per_s")
+    if isinstance(j.get("parity"), dict) and isinstance(j["parity"].get("gains"), dict):
+        out["dlogp_hip_vs_fp32_truth"] = {g: {k: v.get(k) for k in ("max", "mean")} for g, v in j["parity"]["gains"].items()}
+        out["dlogp_pairs"] = j["parity"].get("pairs")
     for k in ("model_frac_of_mfma_peak", "host_preprocess_256_images_s", "workers", "pairs", "png_edge", "image_workers", "host_threads_allowed",
               "engine_only_same_inputs_pairs_per_s", "ratio_to_engine_only_same_inputs", "encoder_len_first_batch"):
         if k in j:
@@ -379,6 +385,8 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-emulation", action="store_true", help="also run the rounding-matched CPU oracle on pair 0 (~40 s at XXL)")
     ap.add_argument("--cpu-reps", type=int, default=3, help="timed repetitions of the CPU reference after 1 warm-up (BASELINE.md section 3: >= 3; a 4-pair XXL pass is ~50 s)")
     ap.add_argument("--parity-pairs", type=int, default=16, help="pairs of the |delta log P| table (HIP vs fp32 truth, head gains 1 and 4)")
+    ap.add_argument("--parity-only", type=int, default=0, metavar="N", help="report the N-pair |delta log P| table (device-evaluated fp32 truth) without the CPU "
+                    "reference leg: used by the also-leg that runs the bf16 tower")
     ap.add_argument("--ragged", action="store_true", help="one batch of variable-length prompts, padded + masked (no bucketing)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="execution-form option of include/vqs.h vqs_set_option (e.g. gemm_variant=6, tile_order:20480x4096=520); "
@@ -617,7 +625,7 @@ def main():
 
     default_run = (world == 1 and not double and args.model == "clip-flant5-xxl" and args.workload == "synthetic" and args.pairs == 0
                    and not args.ragged and not args.opt and B == 256)
-    legs = [] if args.also == "none" else ([k for k in ("xl", "genai1600", "qwen", "pipeline", "config0")] if args.also == "auto" else args.also.split(","))
+    legs = [] if args.also == "none" else ([k for k in ("xl", "genai1600", "bf16_tower", "qwen", "pipeline", "config0")] if args.also == "auto" else args.also.split(","))
     if args.also == "auto" and not default_run:
         legs = []
     also, config0 = {}, None
@@ -627,7 +635,7 @@ def main():
         # next to a 128-thread CPU job, profiles/r3_call17_*) and the PNG pipeline (uses the host cores itself) run alone; the CPU
         # reference of the cpu_baseline leg runs last, alone.
         import threading
-        phase_a = [k for k in legs if k in ("xl", "genai1600")]
+        phase_a = [k for k in legs if k in ("xl", "genai1600", "bf16_tower")]
         t_also = time.perf_counter()
         ALSO_WALL_S = 480.0            # the extra legs may not take the default run past "a few minutes" on a slow box: later legs are skipped, and say so
 
@@ -664,6 +672,11 @@ def main():
         if config0 is not None:
             out["cpu_baseline"]["config0"] = config0
         failed = out["cpu_baseline"]["dlogp"].get("violation")
+    if rank == 0 and world == 1 and args.parity_only > 0 and args.cpu_pairs <= 0 and not double and jobs:
+        try:
+            out["parity"], _ = parity_sample(cfg, weights, eng, jobs[-1], args.parity_only)
+        except Exception as e:                           # noqa: BLE001 -- reported, not raised
+            out["parity"] = {"error": repr(e)[:300]}
     if also:
         out["also"] = also
 
