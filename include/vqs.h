@@ -137,7 +137,7 @@ const char* vqs_profile_report(vqs_handle* h);
 /* ---- single-kernel entry points (parity tests and micro-benchmarks call the kernels through these) ---- */
 /* epilogue: 0 bf16, 1 bf16+quick_gelu, 2 bf16+erf-gelu, 3 fp32, 4 fp32 + residual, 5 gated gelu_new (W rows
  * interleaved per 32: wi_0 block then wi_1 block; C is [M, N/2]), 6 head-major scatter (q/k/v = C, C+B*H*S*64, ...)
- * variant (bits 0-7): 0 one tile per workgroup, 2 / 5 ping-pong, 3 persistent (engine default), 6 four-wave wide form; bits 8-15 = gm, bits 16-23 = ns:
+ * variant (bits 0-7): 0 one tile per workgroup, 2 / 5 ping-pong, 3 the library's choice by epilogue and weight shape (engine default: quad form for a 16-bit result with K >= 128, stream form for few rows per batch entry, else the 8-wave persistent kernel), 10 quad form, 11 the 8-wave rule of rounds 1-2 for every launch; 1 / 4 / 6-9 (the lab forms of rounds 1-3, among them the four-wave wide form) are refused; bits 8-15 = gm, bits 16-23 = ns:
  * the workgroup -> tile ORDER (groups of gm M-tiles x all N-tiles, N cut into ns column ranges walked one after the other;
  * 0 = the library's choice by shape).  The order only permutes which workgroup computes a tile when: results are bitwise
  * identical.  Bit 24: result rows leave with the non-temporal hint; bits 25-26: A-panel L2 prefetch of the lock-step kernel

@@ -195,7 +195,7 @@ class EngineRoundedOracle(Oracle):
     DEC_FP32 = ("dec.qkv", "dec.delta")
 
     def __init__(self, cfg, weights, emulate="engine", round_fn=bf16_round, acc=torch.float64, classes=None, dec_precise=True,
-                 split_classes=(), half_classes=(), vit_fp16=True):
+                 split_classes=(), half_classes=(), vit_fp16=True, device="cpu"):
         """`split_classes`: classes (of the tower / projector / encoder) to model as split-bf16 tensors instead of bf16 ones -- a
         what-if for tools/error_attribution.py, nothing the engine does today; the extra name "vit.v" splits the value heads only
         (q and k stay bf16: the score path).  `half_classes`: classes to model as IEEE fp16 tensors (11 significant bits instead of
@@ -203,7 +203,7 @@ class EngineRoundedOracle(Oracle):
         `vit_fp16` = the engine's option of that name (vqs_set_option "vit_fp16"): every class of the tower and the projector's hidden
         tensor are fp16, the linear weights of both are the fp16 copies (the patch embedding keeps bf16 operands), and the projector's
         output is rounded to fp16 by its GEMM and then to bf16 by the cast into the C ABI's feature tensor."""
-        super().__init__(cfg, weights)
+        super().__init__(cfg, weights, device=device)     # device != "cpu": the what-if runs of tools/error_attribution.py evaluated on the GPU (under `with torch.device(dev)`)
         self.r = round_fn
         self.acc = acc
         self.dec_precise = bool(dec_precise)
@@ -241,7 +241,7 @@ class EngineRoundedOracle(Oracle):
         if name not in self.locked:
             raise KeyError(f"stage-locked run needs the engine tap {name!r}")
         mant = 10 if self.locked[name].dtype == torch.float16 else 7
-        e = self.locked[name].detach().to("cpu", torch.float32)
+        e = self.locked[name].detach().to(self.device, torch.float32)
         e = e.reshape(-1)[: y.numel()].reshape(y.shape) if e.numel() >= y.numel() and e.shape != y.shape else e
         self.report[name] = compare_tap(y, e, valid, mant)
         return e
@@ -267,7 +267,7 @@ class EngineRoundedOracle(Oracle):
 
     def _mm(self, x: torch.Tensor, wname: str, bname: str | None = None) -> torch.Tensor:
         """fp32 accumulator of an nn.Linear over bf16 operands (+ bias added in fp32, as the GEMM epilogues do)."""
-        w = self.w[wname].detach().to("cpu")
+        w = self.w[wname].detach().to(self.device)
         stack = {"vision": "vit", "mm_projector": "proj"}.get(wname.split(".")[0])
         if stack in self.half_stacks and "patch_embedding" not in wname:
             w = w.to(torch.float16)                 # what a bf16 checkpoint becomes in an fp16 tower
@@ -380,7 +380,7 @@ class EngineRoundedOracle(Oracle):
         if not self.dec_precise or (self.classes is not None and "dec.norm" not in self.classes):
             return None
         if self.locked is not None:
-            return self.locked[name + "#hi"].detach().to("cpu", torch.float32).reshape(y.shape)
+            return self.locked[name + "#hi"].detach().to(self.device, torch.float32).reshape(y.shape)
         hi = self.r(y)
         if self.record is not None:
             self.record[name + "#hi"] = hi
@@ -396,8 +396,8 @@ class EngineRoundedOracle(Oracle):
         # it read before round 4).  Not bf16(hi + lo): lo is itself rounded and can land hi + lo exactly on a tie.
         xq = xn if xn_hi is None else xn_hi
         q = self._emit(n + "cq", rc("dec.cq", self._mm(xq, p + "q.weight"))).reshape(B, T, H, dk)
-        wk = self.w[p + "k.weight"].detach().to("cpu").to(self.acc).reshape(H, dk, D)
-        wv = self.w[p + "v.weight"].detach().to("cpu").to(self.acc).reshape(H, dk, D)
+        wk = self.w[p + "k.weight"].detach().to(self.device).to(self.acc).reshape(H, dk, D)
+        wv = self.w[p + "v.weight"].detach().to(self.device).to(self.acc).reshape(H, dk, D)
         qk = self._emit(n + "cqk", rc("dec.cqk", torch.einsum("bthd,hdD->bthD", q.to(self.acc), wk).float()))      # "cross q.Wk" -> bf16
         # the engine's score / probability rows are S_pad wide (keys >= S: zero-padded E^T columns; keys >= enc_len: masked)
         Sp = self._s_pad(S)

@@ -117,12 +117,27 @@ def mrope_position_ids(input_ids: torch.Tensor, attention_mask: torch.Tensor, im
 
 
 class QwenOracle:
-    def __init__(self, cfg, weights: Dict[str, torch.Tensor]):
+    def __init__(self, cfg, weights: Dict[str, torch.Tensor], device="cpu", hook=None):
+        """device "cpu" = the oracle proper (fp32 copies of every weight held on the host).  Any other device: the SAME code evaluated in
+        torch fp32 there (call it under ``with torch.device(dev)``), weights converted on use -- how tools/bench_qwen.py and
+        tools/qwen_error_attribution.py get fp32 truth for several 7B-size samples in seconds.
+        hook(cls, x, pos_dim): identity in the oracle (None).  The error-attribution tool passes a function that rounds the tensors of
+        class `cls` the way the engine stores them (`pos_dim` = the dimension that indexes token positions, or None for vision rows);
+        the classes name the engine's 16-bit storage points, they do not change what is computed."""
         self.cfg = cfg
-        self.w = {k: v.detach().to(torch.float32).cpu() for k, v in weights.items()}
+        self.device = torch.device(device)
+        self.hook = hook
+        if self.device.type == "cpu":
+            self.w = {k: v.detach().to(torch.float32).cpu() for k, v in weights.items()}
+        else:
+            self.w = weights
 
     def _w(self, name: str) -> torch.Tensor:
-        return self.w[name]
+        w = self.w[name]
+        return w if self.device.type == "cpu" else w.detach().to(self.device, torch.float32)
+
+    def _r(self, cls: str, x: torch.Tensor, pos_dim=None) -> torch.Tensor:
+        return x if self.hook is None else self.hook(cls, x, pos_dim)
 
     # ------------------------------------------------------------------------------------------ vision tower
     def _segment_attention(self, q, k, v, cu: Sequence[int], scale: float) -> torch.Tensor:
@@ -131,7 +146,7 @@ class QwenOracle:
         out = torch.empty_like(q)
         for a, b in zip(cu[:-1], cu[1:]):
             s = torch.einsum("qhd,khd->hqk", q[a:b], k[a:b]) * scale
-            p = torch.softmax(s, dim=-1, dtype=torch.float32)
+            p = self._r("vis.p", torch.softmax(s, dim=-1, dtype=torch.float32))
             out[a:b] = torch.einsum("hqk,khd->qhd", p, v[a:b])
         return out.reshape(q.shape[0], -1)
 
@@ -140,7 +155,7 @@ class QwenOracle:
         (un-windowed) cell order."""
         v = self.cfg.vision
         # patch embed: Conv3d with stride = kernel == a matmul over the flattened receptive field (:116-122)
-        h = pixel_values.to(torch.float32) @ self._w("model.visual.patch_embed.proj.weight").reshape(v.hidden, -1).t()
+        h = self._r("vis.in", pixel_values.to(torch.float32)) @ self._w("model.visual.patch_embed.proj.weight").reshape(v.hidden, -1).t()
         N = h.shape[0]
         widx, cu_win = vision_window_index(grid_thw, v.spatial_merge, v.window, v.patch)
         cu_full = frame_seqlens(grid_thw)
@@ -157,24 +172,25 @@ class QwenOracle:
         stages = {}
         for i in range(v.depth):
             p = f"model.visual.blocks.{i}."
-            x = rms_norm(h, self._w(p + "norm1.weight"), v.rms_eps)
-            qkv = x @ self._w(p + "attn.qkv.weight").t() + self._w(p + "attn.qkv.bias")
+            r = self._r
+            x = r("vis.norm", rms_norm(h, self._w(p + "norm1.weight"), v.rms_eps))
+            qkv = r("vis.qkv", x @ self._w(p + "attn.qkv.weight").t() + self._w(p + "attn.qkv.bias"))
             q, k, val = qkv.reshape(N, 3, v.heads, v.head_dim).permute(1, 0, 2, 3).unbind(0)
-            q = q * cos + rotate_half(q) * sin                                           # :160-172
-            k = k * cos + rotate_half(k) * sin
-            a = self._segment_attention(q, k, val, cu_full if i in v.fullatt_blocks else cu_win, v.head_dim ** -0.5)
-            h = h + a @ self._w(p + "attn.proj.weight").t() + self._w(p + "attn.proj.bias")
-            x = rms_norm(h, self._w(p + "norm2.weight"), v.rms_eps)
+            q = r("vis.rope", q * cos + rotate_half(q) * sin)                            # :160-172
+            k = r("vis.rope", k * cos + rotate_half(k) * sin)
+            a = r("vis.attn", self._segment_attention(q, k, val, cu_full if i in v.fullatt_blocks else cu_win, v.head_dim ** -0.5))
+            h = h + r("vis.delta", a @ self._w(p + "attn.proj.weight").t() + self._w(p + "attn.proj.bias"))
+            x = r("vis.norm", rms_norm(h, self._w(p + "norm2.weight"), v.rms_eps))
             g = F.silu(x @ self._w(p + "mlp.gate_proj.weight").t() + self._w(p + "mlp.gate_proj.bias"))
             u = x @ self._w(p + "mlp.up_proj.weight").t() + self._w(p + "mlp.up_proj.bias")
-            h = h + (g * u) @ self._w(p + "mlp.down_proj.weight").t() + self._w(p + "mlp.down_proj.bias")
+            h = h + r("vis.delta", r("vis.act", g * u) @ self._w(p + "mlp.down_proj.weight").t() + self._w(p + "mlp.down_proj.bias"))
             if return_stages:
                 stages[f"vis_block{i}"] = h.clone()
         # merger (:137-150): RMSNorm, 4 neighbouring patches concatenated, Linear - GELU(erf) - Linear; then undo the
         # window permutation (:463-465)
-        x = rms_norm(h, self._w("model.visual.merger.ln_q.weight"), 1e-6).reshape(N // v.merge_unit, -1)
-        x = F.gelu(x @ self._w("model.visual.merger.mlp.0.weight").t() + self._w("model.visual.merger.mlp.0.bias"))
-        x = x @ self._w("model.visual.merger.mlp.2.weight").t() + self._w("model.visual.merger.mlp.2.bias")
+        x = self._r("vis.norm", rms_norm(h, self._w("model.visual.merger.ln_q.weight"), 1e-6)).reshape(N // v.merge_unit, -1)
+        x = self._r("vis.mid", F.gelu(x @ self._w("model.visual.merger.mlp.0.weight").t() + self._w("model.visual.merger.mlp.0.bias")))
+        x = self._r("vis.merged", x @ self._w("model.visual.merger.mlp.2.weight").t() + self._w("model.visual.merger.mlp.2.bias"))
         merged = x[torch.argsort(widx)]
         if return_stages:
             return merged, stages
@@ -201,21 +217,23 @@ class QwenOracle:
         h = embeds.to(torch.float32)
         for i in range(t.layers):
             p = f"model.language_model.layers.{i}."
-            x = rms_norm(h, self._w(p + "input_layernorm.weight"), t.rms_eps)
-            q = (x @ self._w(p + "self_attn.q_proj.weight").t() + self._w(p + "self_attn.q_proj.bias")).view(B, L, t.heads, hd).transpose(1, 2)
-            k = (x @ self._w(p + "self_attn.k_proj.weight").t() + self._w(p + "self_attn.k_proj.bias")).view(B, L, t.kv_heads, hd).transpose(1, 2)
-            v = (x @ self._w(p + "self_attn.v_proj.weight").t() + self._w(p + "self_attn.v_proj.bias")).view(B, L, t.kv_heads, hd).transpose(1, 2)
-            q = q * cos + rotate_half(q) * sin
-            k = k * cos + rotate_half(k) * sin
+            r = self._r
+            x = r("txt.norm", rms_norm(h, self._w(p + "input_layernorm.weight"), t.rms_eps), 1)
+            q = r("txt.qkv", x @ self._w(p + "self_attn.q_proj.weight").t() + self._w(p + "self_attn.q_proj.bias"), 1).view(B, L, t.heads, hd).transpose(1, 2)
+            k = r("txt.qkv", x @ self._w(p + "self_attn.k_proj.weight").t() + self._w(p + "self_attn.k_proj.bias"), 1).view(B, L, t.kv_heads, hd).transpose(1, 2)
+            v = r("txt.qkv", x @ self._w(p + "self_attn.v_proj.weight").t() + self._w(p + "self_attn.v_proj.bias"), 1).view(B, L, t.kv_heads, hd).transpose(1, 2)
+            q = r("txt.rope", q * cos + rotate_half(q) * sin, 2)
+            k = r("txt.rope", k * cos + rotate_half(k) * sin, 2)
             k = k.repeat_interleave(rep, dim=1)                                           # repeat_kv :175-184
             v = v.repeat_interleave(rep, dim=1)
             s = q @ k.transpose(2, 3) * hd ** -0.5 + add
-            a = torch.softmax(s, dim=-1, dtype=torch.float32) @ v
-            h = h + a.transpose(1, 2).reshape(B, L, -1) @ self._w(p + "self_attn.o_proj.weight").t()
-            x = rms_norm(h, self._w(p + "post_attention_layernorm.weight"), t.rms_eps)
+            a = r("txt.attn", r("txt.p", torch.softmax(s, dim=-1, dtype=torch.float32), 2) @ v, 2)
+            del s
+            h = h + r("txt.delta", a.transpose(1, 2).reshape(B, L, -1) @ self._w(p + "self_attn.o_proj.weight").t(), 1)
+            x = r("txt.norm", rms_norm(h, self._w(p + "post_attention_layernorm.weight"), t.rms_eps), 1)
             g = F.silu(x @ self._w(p + "mlp.gate_proj.weight").t())
-            h = h + (g * (x @ self._w(p + "mlp.up_proj.weight").t())) @ self._w(p + "mlp.down_proj.weight").t()
-        return rms_norm(h, self._w("model.language_model.norm.weight"), t.rms_eps)
+            h = h + r("txt.delta", r("txt.act", g * (x @ self._w(p + "mlp.up_proj.weight").t()), 1) @ self._w(p + "mlp.down_proj.weight").t(), 1)
+        return self._r("txt.out", rms_norm(h, self._w("model.language_model.norm.weight"), t.rms_eps), 1)
 
     # ------------------------------------------------------------------------------------------ whole pass
     def forward(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, pixel_values_videos: torch.Tensor,
@@ -229,7 +247,7 @@ class QwenOracle:
             emb = self._w("model.language_model.embed_tokens.weight")[input_ids.clamp(min=0)]
             mask = input_ids == c.video_token_id
             assert int(mask.sum()) == merged.shape[0], "video placeholder count != merged vision tokens (:1094-1133)"
-            emb = emb.masked_scatter(mask[..., None].expand_as(emb), merged)              # :1226-1232
+            emb = emb.masked_scatter(mask[..., None].expand_as(emb), merged.to(emb.dtype))  # :1226-1232
             pos = mrope_position_ids(input_ids, attention_mask, c.image_token_id, c.video_token_id, [], video_grid_thw,
                                      c.vision.spatial_merge, c.vision.tokens_per_second)
             hid = self.text_model(emb, pos, attention_mask)

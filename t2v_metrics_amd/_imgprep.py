@@ -86,7 +86,7 @@ def clip_preprocess_u8(img: Image.Image, image_size: int = 336, pad_to_square: b
 # Worker process.  Protocol (one JSON object per line on stdin / stdout; imgpool.ImageProcessPool is the other end):
 #   request  {"slot": i, "path": p, "size": S, "pad": bool, "shm": file under /dev/shm (or any tmpfs), "n": slots in it}
 #            the result goes to bytes [i * S*S*3, (i+1) * S*S*3) of that file (a uint8 [n, S, S, 3] array, memory-mapped)
-#   reply    {"slot": i, "ok": true}  or  {"slot": i, "ok": false, "err": "..."}
+#   reply    {"slot": i, "ok": true}  or  {"slot": i, "ok": false, "etype": "FileNotFoundError", "errno": 2, "err": "..."}
 # The worker keeps the last mapping open; it exits when stdin closes.
 # ----------------------------------------------------------------------------------------------------------------------
 def _worker_main():
@@ -109,7 +109,8 @@ def _worker_main():
             mapped[slot] = clip_preprocess_u8(image_loader(req["path"]), S, bool(req["pad"]))
             out.write(json.dumps({"slot": slot, "ok": True}) + "\n")
         except Exception as e:                                   # noqa: BLE001 -- reported to the parent, which raises
-            out.write(json.dumps({"slot": slot, "ok": False, "err": f"{type(e).__name__}: {e}"[:500]}) + "\n")
+            out.write(json.dumps({"slot": slot, "ok": False, "etype": type(e).__name__, "errno": getattr(e, "errno", None),
+                                  "err": f"{type(e).__name__}: {e}"[:500]}) + "\n")
         out.flush()
 
 

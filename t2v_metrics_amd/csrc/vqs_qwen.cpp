@@ -738,6 +738,20 @@ struct DecWs {
     size_t part_bytes;
     size_t total;
 };
+// K slices of a decode-step linear (decode_linear below): the fewest slices (a divisor of K / 64, <= 16) that put >= 192
+// (slice, 128-column) items on the chip -- a function of the weight's shape only.  carve_decode sizes the partial buffer with it.
+int decode_slices(int N, int K) {
+    const int nblk = (N + 127) / 128, nsl = K / 64;
+    if (nblk >= 192 || (K % 64) != 0) return 1;
+    int best = 1;
+    for (int s2 = 2; s2 <= 16; ++s2)
+        if (nsl % s2 == 0) {
+            best = s2;
+            if (nblk * s2 >= 192) break;
+        }
+    return best;
+}
+
 DecWs carve_decode(const vqs_qwen_handle* h, char* base, int B) {
     const vqs_qwen_config& c = h->c;
     Carver cv{base};
@@ -752,10 +766,13 @@ DecWs carve_decode(const vqs_qwen_handle* h, char* base, int B) {
     w.attn = cv.take<bf16_t>(b * h->t_iq);
     w.ff = cv.take<bf16_t>(b * h->t_ffld);
     w.neg1 = cv.take<int>(b);
-    {   // widest partial set: 16 K-slices of the narrow launches (qkv / o / down) or one slice of gate|up
-        size_t widest = 16 * (size_t)(h->t_iq + 2 * h->t_ikv);
-        widest = std::max(widest, 16 * (size_t)c.t_hidden);
-        widest = std::max(widest, (size_t)2 * h->t_mlp_p);
+    {   // widest partial set of the step's four linears: slices(N, K) x N fp32 per row, by the SAME rule decode_linear launches with
+        // (a hand-written bound missed gate|up with two slices -- Qwen2.5-VL-3B's 2048 / 11008 -- and every step failed)
+        const int QN = h->t_iq + 2 * h->t_ikv;
+        size_t widest = (size_t)decode_slices(QN, c.t_hidden) * QN;                                       // qkv
+        widest = std::max(widest, (size_t)decode_slices(c.t_hidden, h->t_iq) * c.t_hidden);               // o_proj
+        widest = std::max(widest, (size_t)decode_slices(2 * h->t_mlp_p, c.t_hidden) * 2 * h->t_mlp_p);    // gate|up
+        widest = std::max(widest, (size_t)decode_slices(c.t_hidden, h->t_ffld) * c.t_hidden);             // down_proj
         w.part_bytes = b * widest * sizeof(float);
         w.part = cv.take<float>(b * widest);
     }
@@ -771,17 +788,7 @@ DecWs carve_decode(const vqs_qwen_handle* h, char* base, int B) {
 // gate|up columns) and rounds to bf16.  Falls back to the persistent kernel (same bits) when the form does not apply (B > 128).
 int decode_linear(vqs_qwen_handle* h, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias, bf16_t* out, int ldo, int B,
                   int N, int K, int gated, const DecWs& w, hipStream_t st, const char* what) {
-    const int nblk = (N + 127) / 128, nsl = K / 64;
-    int sk = 1;
-    if (nblk < 192 && (K % 64) == 0) {
-        int best = 1;
-        for (int s2 = 2; s2 <= 16; ++s2)
-            if (nsl % s2 == 0) {
-                best = s2;
-                if (nblk * s2 >= 192) break;
-            }
-        sk = best;
-    }
+    const int sk = decode_slices(N, K);
     if ((size_t)sk * B * N * sizeof(float) > w.part_bytes) return qfail(h, VQS_ERR_WORKSPACE, std::string(what) + ": decode scratch too small");
     vqs::GemmParams p{};
     p.A = A; p.W = W; p.C = w.part; p.bias = nullptr; p.resid = nullptr;

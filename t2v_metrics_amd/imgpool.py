@@ -32,6 +32,20 @@ class ImagePoolError(RuntimeError):
     pass
 
 
+def _as_original_error(reply: dict, msg: str, path: str) -> Exception:
+    """The exception type the in-process loader would have raised, rebuilt from the worker's reply (OSError family and PIL's
+    UnidentifiedImageError, itself an OSError); anything else stays an ImagePoolError."""
+    etype, errno_ = reply.get("etype"), reply.get("errno")
+    if etype == "UnidentifiedImageError":
+        from PIL import UnidentifiedImageError
+        return UnidentifiedImageError(msg)
+    cls = {"FileNotFoundError": FileNotFoundError, "IsADirectoryError": IsADirectoryError, "PermissionError": PermissionError,
+           "NotADirectoryError": NotADirectoryError, "OSError": OSError}.get(etype)
+    if cls is not None:
+        return cls(errno_, msg, path) if isinstance(errno_, int) else cls(msg)
+    return ImagePoolError(msg)
+
+
 class _Worker:
     def __init__(self):
         env = dict(os.environ)
@@ -123,14 +137,30 @@ class ImageProcessPool:
                 w = self._idle.get()
                 try:
                     return w.request({"slot": i, "path": str(p), "size": int(size), "pad": bool(pad), "shm": self._shm_path, "n": slots})
+                except ImagePoolError:
+                    # the worker's pipe is gone: it must not go back on the idle queue (every later request handed to it would fail:
+                    # ADVICE r4) -- a fresh process takes its place, this request is reported as failed
+                    w.close()
+                    w = self._respawn(w)
+                    raise
                 finally:
                     self._idle.put(w)
 
             replies = list(self._threads.map(one, enumerate(paths)))
             bad = [r for r in replies if not r.get("ok")]
             if bad:
-                raise ImagePoolError(f"{len(bad)} of {n} images failed; first: {paths[bad[0]['slot']] if bad[0]['slot'] >= 0 else '?'}: {bad[0].get('err')}")
+                first = bad[0]
+                path = paths[first["slot"]] if first.get("slot", -1) >= 0 else "?"
+                msg = f"{len(bad)} of {n} images failed; first: {path}: {first.get('err')}"
+                # what the reference's image_loader raises for a bad path (PIL's Image.open: FileNotFoundError / UnidentifiedImageError /
+                # another OSError, models/model.py:10-14) is what a caller of the pooled loader sees too
+                raise _as_original_error(first, msg, str(path))
             return shm[:n]
+
+    def _respawn(self, dead: "_Worker") -> "_Worker":
+        w = _Worker()
+        self._workers = [w if x is dead else x for x in self._workers]
+        return w
 
     def close(self):
         if self._closed:

@@ -224,9 +224,15 @@ class CLIPT5Model(VQAScoreModel):
         if hasattr(self.engine, "normalize_u8") and str(self.device).startswith('cuda') and torch.cuda.is_available():
             from ...preprocess import OPENAI_CLIP_MEAN, OPENAI_CLIP_STD
             k, host = self._load_images_host_u8(image)
-            u8 = host.to(self.device, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
+            # This runs on the image thread ("vqs-img"), whose CURRENT device is 0 whatever the main thread set: the copy, the event that
+            # guards the staging buffer's reuse and the kernel behind them must all sit on THIS model's device and its current stream
+            # (an event recorded on device 0 while the DMA runs on cuda:k is complete at once -- the buffer would be overwritten under
+            # the copy: ADVICE r4)
+            with torch.cuda.device(self.device):
+                stream = torch.cuda.current_stream(self.device)
+                u8 = host.to(self.device, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(stream)
             self._staging_ev[k] = ev
             return self.engine.normalize_u8(u8, OPENAI_CLIP_MEAN, OPENAI_CLIP_STD)
         px = self._load_images_host(image)

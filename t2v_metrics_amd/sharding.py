@@ -80,18 +80,20 @@ def plan_rank_affinity(gpu_numa, node_cpus, allowed, local_rank: int):
     return allowed[local_rank * per:(local_rank + 1) * per] if per > 0 else allowed
 
 
-def gpu_numa_nodes(n_gpus: int):
-    """NUMA node of each visible GPU from sysfs (the device's PCI address -> /sys/bus/pci/devices/<bdf>/numa_node), -1 if unknown.
+def pci_bdf(props) -> str:
+    """PCI address "dddd:bb:dd.0" of a device from torch's device properties: `pci_domain_id` / `pci_bus_id` / `pci_device_id` are
+    INTEGERS (the bus id alone was taken for the address, so the sysfs lookup never hit)."""
+    return "%04x:%02x:%02x.0" % (int(getattr(props, "pci_domain_id", 0)), int(props.pci_bus_id), int(getattr(props, "pci_device_id", 0)))
+
+
+def gpu_numa_nodes(n_gpus: int, sysfs: str = "/sys/bus/pci/devices"):
+    """NUMA node of each visible GPU from sysfs (the device's PCI address -> <sysfs>/<bdf>/numa_node), -1 if unknown.
     (`rocm-smi --showtoponuma` prints the same numbers.)"""
     out = []
     for i in range(n_gpus):
         node = -1
         try:
-            bdf = torch.cuda.get_device_properties(i).pci_bus_id if hasattr(torch.cuda.get_device_properties(i), "pci_bus_id") else None
-            if bdf is None:
-                p = torch.cuda.get_device_properties(i)
-                bdf = "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, p.pci_device_id)
-            with open(f"/sys/bus/pci/devices/{str(bdf).lower()}/numa_node") as f:
+            with open(f"{sysfs}/{pci_bdf(torch.cuda.get_device_properties(i))}/numa_node") as f:
                 node = int(f.read().strip())
         except Exception:                      # noqa: BLE001 -- no sysfs entry / no such attribute: unknown
             node = -1

@@ -300,7 +300,7 @@ def test_precise_decoder_is_closer_to_fp32_than_the_bf16_decoder():
 
 
 def test_fp16_vision_tower_is_closer_to_fp32_than_the_bf16_tower():
-    """Option vit_fp16 (default 0): the vision tower and the projector on IEEE fp16 operands -- three more significant bits than bf16 at the
+    """Option vit_fp16 (default 1; 0 = the bf16 tower of rounds 1-3): the vision tower and the projector on IEEE fp16 operands -- three more significant bits than bf16 at the
     same MFMA rate and bytes (CLIP was trained in fp16; the T5 stack is not fp16-safe and stays bf16).  Same function: both agree with the
     fp32 oracle; the image features (what the tower hands to the T5 pass) are several times closer to the oracle's with fp16 operands, the
     label log-probs closer in the mean; bitwise repeatable; switching the option back restores the bf16 tower's bits on the same handle."""

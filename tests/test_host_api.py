@@ -367,3 +367,17 @@ def test_weights_that_do_not_fit_fp16_are_named_before_the_fp16_tower_reads_them
     e.get_option = lambda name: 1
     e._check_fp16_weights()
     assert e._fp16_unsafe == []
+
+
+def test_gpu_numa_lookup_formats_the_pci_address_from_torchs_integer_fields(tmp_path, monkeypatch):
+    """torch's `pci_bus_id` is an int, not a BDF string -- the sysfs path must be built from domain / bus / device."""
+    import types
+    from t2v_metrics_amd import sharding
+    props = [types.SimpleNamespace(pci_domain_id=0, pci_bus_id=0x05, pci_device_id=0), types.SimpleNamespace(pci_domain_id=1, pci_bus_id=0xc5, pci_device_id=0),
+             types.SimpleNamespace(pci_domain_id=0, pci_bus_id=0x99, pci_device_id=0)]
+    assert [sharding.pci_bdf(p) for p in props] == ["0000:05:00.0", "0001:c5:00.0", "0000:99:00.0"]
+    for bdf, node in (("0000:05:00.0", 0), ("0001:c5:00.0", 1)):
+        (tmp_path / bdf).mkdir()
+        (tmp_path / bdf / "numa_node").write_text("%d\n" % node)
+    monkeypatch.setattr(sharding.torch.cuda, "get_device_properties", lambda i: props[i])
+    assert sharding.gpu_numa_nodes(3, sysfs=str(tmp_path)) == [0, 1, -1]        # the third device has no sysfs entry: unknown

@@ -27,6 +27,14 @@ def _files(tmp_path, n=9):
     return paths
 
 
+def _raises_of(fn):
+    try:
+        fn()
+    except Exception as e:                       # noqa: BLE001
+        return e
+    raise AssertionError("did not raise")
+
+
 def test_pool_bytes_equal_the_in_process_path_and_errors_surface(tmp_path):
     paths = _files(tmp_path)
     pool = ImageProcessPool(3)
@@ -36,8 +44,29 @@ def test_pool_bytes_equal_the_in_process_path_and_errors_surface(tmp_path):
             want = np.stack([clip_preprocess_u8(image_loader(p), size, pad) for p in paths])
             assert got.shape == want.shape and np.array_equal(got, want)
         assert pool.load_u8([], 56, True).shape == (0, 56, 56, 3)
-        with pytest.raises(ImagePoolError, match="nope.png"):
+        # a bad path raises what the reference's in-process loader raises (PIL's Image.open, models/model.py:10-14), not a pool-specific type
+        with pytest.raises(FileNotFoundError, match="nope.png") as ei:
             pool.load_u8(paths[:2] + [str(tmp_path / "nope.png")], 56, True)
+        assert not isinstance(ei.value, ImagePoolError) and ei.value.errno == 2
+        junk = tmp_path / "junk.png"
+        junk.write_bytes(b"not an image")
+        from PIL import UnidentifiedImageError
+        with pytest.raises(UnidentifiedImageError):
+            pool.load_u8([str(junk)], 56, True)
+        with pytest.raises(type(_raises_of(lambda: image_loader(str(junk))))):
+            pool.load_u8([str(junk)], 56, True)
+        # a worker whose process died is replaced, not handed the next request
+        victim = pool._workers[0]
+        victim.proc.kill()
+        victim.proc.wait()
+        for _ in range(3):                       # the dead worker is somewhere on the idle queue: at most one batch reports it
+            try:
+                got = np.array(pool.load_u8(paths, 56, True))
+                break
+            except ImagePoolError:
+                continue
+        assert np.array_equal(got, np.stack([clip_preprocess_u8(image_loader(p), 56, True) for p in paths]))
+        assert victim not in pool._workers and len(pool._workers) == 3 and all(w.proc.poll() is None for w in pool._workers)
         assert np.array_equal(np.array(pool.load_u8(paths[:2], 56, True)), np.stack([clip_preprocess_u8(image_loader(p), 56, True) for p in paths[:2]]))
         shm = pool._shm_path
         assert os.path.exists(shm)

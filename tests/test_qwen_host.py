@@ -502,3 +502,42 @@ def test_batch_forward_takes_a_videos_dataset_for_a_direct_mode_model(tmp_path):
     img_only = t2v.VQAScore(model="clip-flant5-xl", device="cpu", config=ccfg, engine=RecordingEngine(ccfg), tokenizer=FakeTokenizer(ccfg.t5.vocab))
     with pytest.raises(NotImplementedError, match="video-native"):
         img_only.batch_forward(ds_v)
+
+
+def test_decode_workspace_covers_the_partials_of_every_linear_at_other_model_sizes():
+    """the decode step's split-K scratch was sized by a hand-written bound that missed gate|up with two K slices (Qwen2.5-VL-3B:
+    hidden 2048, mlp 11008 -- every decode step would have returned VQS_ERR_WORKSPACE).  carve_decode now sizes it with the slice rule
+    decode_linear launches with; here the rule is restated and the host-side workspace query (no GPU needed) checked against it."""
+    import ctypes
+    from t2v_metrics_amd.engine import load_library
+    from t2v_metrics_amd.qwen.engine import VqsQwenConfig, _SIGS
+    lib = load_library()
+    for name in ("vqs_qwen_create", "vqs_qwen_destroy", "vqs_qwen_decode_workspace_bytes"):
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = _SIGS[name]
+
+    def slices(N, K):
+        nblk, nsl = (N + 127) // 128, K // 64
+        if nblk >= 192 or K % 64:
+            return 1
+        best = 1
+        for s in range(2, 17):
+            if nsl % s == 0:
+                best = s
+                if nblk * s >= 192:
+                    break
+        return best
+
+    for hidden, heads, kv, mlp in ((2048, 16, 2, 11008), (1024, 8, 2, 4096), (3584, 28, 4, 18944)):     # 3B, a 1024-wide model, 7B
+        c = VqsQwenConfig(32, 1280, 16, 3420, 1176, 4, hidden, 0x80808080, 1e-6, 151936, hidden, 4, heads, kv, mlp, 1e-6)
+        h = ctypes.c_void_p()
+        assert lib.vqs_qwen_create(ctypes.byref(c), ctypes.byref(h)) == 0
+        try:
+            QN, IQ = (heads + 2 * kv) * 128, heads * 128
+            gu = 2 * (-(-mlp // 32) * 32)
+            ffld = -(-mlp // 64) * 64
+            widest = max(slices(QN, hidden) * QN, slices(hidden, IQ) * hidden, slices(gu, hidden) * gu, slices(hidden, ffld) * hidden)
+            for B in (1, 4, 64):
+                assert lib.vqs_qwen_decode_workspace_bytes(h, B) >= B * widest * 4, (hidden, mlp, B)
+        finally:
+            lib.vqs_qwen_destroy(h)

@@ -46,7 +46,7 @@ class Runner:
 
     def __init__(self, cfg, w, batch, acc, gains):
         self.cfg, self.w, self.acc, self.gains = cfg, w, acc, gains
-        self.pix, self.idx, self.ids, self.labels = batch
+        self.pix, self.idx, self.ids, self.labels = self.batch = batch
         self.cache = {}
 
     def _oracle(self, classes, dec_precise, split=()):
@@ -55,7 +55,7 @@ class Runner:
         split = tuple(c for c in split if not c.startswith(("half:", "ship:")))
         # vit_fp16=False: the table models every class as a bf16 rounding (the engine of rounds 1-3) and adds fp16 / split stages explicitly
         return EngineRoundedOracle(self.cfg, self.w, acc=self.acc, classes=classes, dec_precise=dec_precise, split_classes=split,
-                                   half_classes=half, vit_fp16=ship)
+                                   half_classes=half, vit_fp16=ship, device=self.pix.device)
 
     def run(self, classes, dec_precise=False, split=()):
         classes = frozenset(classes)
@@ -102,16 +102,34 @@ def main():
     ap.add_argument("--acc", default="float32", choices=["float32", "float64"])
     ap.add_argument("--only", default="", help="semicolon-separated run names (default: all runs)")
     ap.add_argument("--out", default="")
+    ap.add_argument("--device", default="cpu", help="cuda: evaluate the same oracle code in torch on the GPU (XXL, 64 pairs: a minute per run "
+                    "instead of hours; test infrastructure either way -- the engine is not involved)")
+    ap.add_argument("--chunk", type=int, default=0, help="evaluate the pairs in chunks of this many (bounds the [B,H,S,S] score tensors)")
     a = ap.parse_args()
     import warnings
     warnings.filterwarnings("ignore")
     cfg = get_config(a.model)
     gains = [float(g) for g in a.gains.split(",")]
     t00 = time.time()
-    w = make_seeded_weights(cfg, seed=0, device="cpu")
-    pix, idx, ids, labels = bench.synth_batch(cfg, a.pairs, a.seed, "cpu")
+    dev = torch.device(a.device)
+    w = make_seeded_weights(cfg, seed=0, device=dev)
+    pix, idx, ids, labels = bench.synth_batch(cfg, a.pairs, a.seed, dev)
     batch = (pix.float(), idx.long(), ids.long(), labels.long())
-    R = Runner(cfg, w, batch, getattr(torch, a.acc), gains)
+    chunk = a.chunk if a.chunk > 0 else a.pairs
+    Rs = [Runner(cfg, w, (batch[0][s: s + chunk], torch.arange(min(chunk, a.pairs - s), device=dev), batch[2][s: s + chunk], batch[3][s: s + chunk]),
+                 getattr(torch, a.acc), gains) for s in range(0, a.pairs, chunk)]        # synth_batch: pair i uses image i
+
+    class R:                                      # the chunks side by side: every pair is independent of the others in its batch
+        @staticmethod
+        def run(classes, precise=False, split=()):
+            with torch.device(dev):
+                outs = [r.run(classes, precise, split) for r in Rs]
+            return {g: torch.cat([o[g] for o in outs]).cpu() for g in gains}
+
+        @staticmethod
+        def drop(stack):
+            for r in Rs:
+                r.drop(stack)
 
     # per-class and group runs model the engine of rounds 1-3 (every class a plain bf16 rounding)
     runs = [("none (all fp32)", ())]
@@ -153,6 +171,15 @@ def main():
     enc_attn_side = ("half:enc.norm", "half:enc.qkv", "half:enc.p", "half:enc.attn", "half:enc.out")
     runs += [("what-if: as shipped + encoder norm / q k v / P / attention output / final norm in fp16", ALL, True, ("ship:vit_fp16",) + enc_attn_side),
              ("what-if: as shipped + every encoder class in fp16", ALL, True, ("ship:vit_fp16",) + half("enc"))]
+    # round 5: what is left once the encoder's attention side is fp16 -- the feature tensor (proj.out: fp16 GEMM result rounded to bf16 for the
+    # C ABI), the encoder's bf16 sub-layer outputs / FFN product, the decoder's floor
+    runs += [("r5: shipped + enc attention side fp16 + feature tensor fp16", ALL, True, ("ship:vit_fp16",) + enc_attn_side + ("half:proj.out",)),
+             ("r5: shipped + feature tensor fp16", ALL, True, ("ship:vit_fp16", "half:proj.out")),
+             ("r5: shipped + enc attention side fp16 + feature fp16, enc.delta enc.act exact", without("enc.delta", "enc.act"), True,
+              ("ship:vit_fp16",) + enc_attn_side + ("half:proj.out",)),
+             ("r5: shipped + enc attention side fp16 + feature fp16 + enc.out split", ALL, True,
+              ("ship:vit_fp16", "half:enc.norm", "half:enc.qkv", "half:enc.p", "half:enc.attn", "enc.out", "half:proj.out")),
+             ("r5: decoder floor (vit proj enc exact)", without("vit.*", "proj.*", "enc.*"), True, ())]
     runs = [(r + (False, ()))[:4] if len(r) < 4 else r for r in runs]          # (name, classes, precise decoder, split set)
     if a.only:
         keep = set(a.only.split(";"))
@@ -169,7 +196,8 @@ def main():
         if ref is None:
             assert not classes
             ref = lp
-            truth = Oracle(cfg, w).forward(*batch)["label_logprobs"]
+            with torch.device(dev):
+                truth = torch.cat([Oracle(cfg, w, device=dev).forward(*r_.batch)["label_logprobs"] for r_ in Rs]).cpu()
             results["_none_vs_fp32_oracle"] = float((lp[1.0] - truth).abs().max()) if 1.0 in lp else None
             print(f"# unrounded run vs oracle/clip_t5_oracle.py (tiled attention, reassociated cross-attention, fp32): "
                   f"{results['_none_vs_fp32_oracle']:.2e};  log P(yes) range [{float(truth[:, 0].min()):.2f}, {float(truth[:, 0].max()):.2f}]", flush=True)
@@ -183,7 +211,7 @@ def main():
             R.drop("vit"); R.drop("proj"); R.drop("enc")
         if rank(classes) == 1:
             R.drop("enc")
-    results["_meta"] = {"model": cfg.name, "pairs": a.pairs, "seed": a.seed, "gains": gains, "acc": a.acc,
+    results["_meta"] = {"model": cfg.name, "pairs": a.pairs, "device": a.device + (" (" + torch.cuda.get_device_name(0) + ")" if dev.type == "cuda" else ""), "seed": a.seed, "gains": gains, "acc": a.acc,
                         "threads": torch.get_num_threads(), "seconds": round(time.time() - t00, 1),
                         "logp_yes_fp32": [round(float(x), 4) for x in ref[gains[0]][:, 0]]}
     if a.out:
