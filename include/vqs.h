@@ -118,7 +118,7 @@ int vqs_generate(vqs_handle* h, const void* d_feats, const int32_t* d_img_index,
 
 /* Byte offset of a named intermediate inside the vqs_score / vqs_encode_images workspace (parity tests read
  * stages through this): "enc_in" fp32 [B,S_e,D], "enc_out" bf16 [B,S_e,D], "dec_out" bf16 [B*T,D] (final decoder norm = lm_head operand), "logits" fp32 [B*T, ld],
- * "vit_hidden" fp32 [n_img, 1+P, hidden] (patch rows = hidden_states[-2]; CLS row lags one sub-layer), "enc_len" int32 [B], "flags" int32[1] (bit0 = malformed prompt).
+ * "vit_hidden" fp32 [n_img, 1+P, hidden] (patch rows = hidden_states[-2]; CLS row lags one sub-layer), "enc_len" int32 [B], "flags" int32[1] (bit 0 = malformed prompt; bit 1 = a pair's label log-probs are not finite: with the fp16 options an activation left the fp16 range -- rerun with vit_fp16=0 / enc_fp16=0).
  * For encode-stage names pass B = n_img, L = T = 0.  Returns -1 for an unknown name.
  * *ld_out (optional) receives the row stride in elements. */
 int64_t vqs_workspace_offset(const vqs_handle* h, const char* name, int32_t B, int32_t L, int32_t T, int64_t* ld_out);
@@ -141,7 +141,9 @@ const char* vqs_profile_report(vqs_handle* h);
  * the workgroup -> tile ORDER (groups of gm M-tiles x all N-tiles, N cut into ns column ranges walked one after the other;
  * 0 = the library's choice by shape).  The order only permutes which workgroup computes a tile when: results are bitwise
  * identical.  Bit 24: result rows leave with the non-temporal hint; bits 25-26: A-panel L2 prefetch of the lock-step kernel
- * (0 by shape, 1 on, 2 off) -- cache-policy hints, bitwise-neutral as well. */
+ * (0 by shape, 1 on, 2 off) -- cache-policy hints, bitwise-neutral as well.  Bits 27-28: operand type of a 16-bit-result launch (quad
+ * form only): 0 A, W and C bf16; 1 IEEE fp16 A, W and C (bias stays bf16; not the gated epilogue); 2 fp16 A and W, bf16 C (epilogues 0
+ * and 5) -- the instantiations options vit_fp16 / enc_fp16 run. */
 int vqs_gemm(const void* d_A, const void* d_W, void* d_C, const void* d_bias, const float* d_resid, int32_t M, int32_t N,
              int32_t K, int32_t lda, int32_t ldw, int32_t ldc, int32_t epilogue, int32_t S, int32_t H, int32_t variant,
              void* stream);
@@ -211,6 +213,15 @@ int vqs_score_head(const float* d_logits, int32_t ldl, int32_t V, const int32_t*
  *                  gemm_variant 3.  Set it before asking for the encode workspace size (one more buffer).  The tower's / projector's
  *                  linear weights must be finite and below 65 520 in magnitude (any CLIP checkpoint is: the model was trained in fp16);
  *                  the library does not look -- the Python binding checks at bind time and names the tensors (engine.fp16_unsafe_weights).
+ *   "enc_fp16"     1 (default, round 5) the ATTENTION SIDE of the T5 encoder holds its 16-bit tensors in IEEE fp16: both RMSNorm outputs, q / k / v, the
+ *                  softmax probabilities and the attention output; q|k|v, o and the gated wi read fp16 copies of their weights (made by
+ *                  vqs_bind_weights: 7.2 GB more packed buffer at XXL) -- what HF's own fp16 T5 path holds in fp16.  The sub-layer outputs (the
+ *                  o / wo results added into the fp32 stream), the gated FFN product, the wo GEMM and the encoder's final output stay bf16:
+ *                  Flan-T5 leaves the fp16 range in its FFN (HF keeps `wo` in fp32 for that, modeling_t5.py _keep_in_fp32_modules).  Same
+ *                  MFMA rate and bytes; measured effect and the attribution behind it: profiles/r5_error_attribution_xxl.md.  0: bf16 there
+ *                  too (the reference's dtype, rounds 1-4's encoder).  1 needs gemm_variant 3 and fused_norm 0.  Weight range as for
+ *                  vit_fp16 (the Python binding checks at bind time); an activation that leaves the fp16 range turns into a non-finite
+ *                  score, which vqs_score reports through its status word (flags bit 1) -- the binding raises and names this option.
  *   "stream_gemm"  1 (default) skinny batched GEMMs (<= 128 rows per entry: the reassociated cross-attention's two products over
  *                  the encoder output) run the HBM-streaming form (csrc/gemm_stream.inc), 0 the persistent 256-row kernel;
  *                  bitwise equal

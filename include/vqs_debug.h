@@ -43,6 +43,18 @@ int vqs_debug_gemm_form(int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ld
 int vqs_debug_gemm_batched(const void* A, const void* W, void* C, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t ldc,
                            int32_t epilogue, int32_t batch, int64_t sA, int64_t sW, int64_t sC, int64_t split_off, int32_t no_stream,
                            int32_t variant, void* stream);
+/* Device-side test hooks for the fp16 instantiations (options vit_fp16 / enc_fp16): the single-kernel entry points of vqs.h name bf16
+ * tensors; these run the same launches on IEEE fp16 ones so that the per-kernel tests cover the fp16 kernels at shapes of their own
+ * (edge tiles, ragged key lengths), not only at the tower's / encoder's shapes through whole passes.
+ *   vqs_debug_attention_f16: vqs_attention with q / k / v / out in fp16 (d_bias_table NULL: the vision tower's kernel; non-NULL: the T5
+ *     encoder's, with the per-head position-bias table and the key-length mask).
+ *   vqs_debug_norm16: vqs_norm_deferred's forms with 16-bit types by `types`: 1 = RMSNorm, bf16 deltas in, fp16 operand out (T5 encoder),
+ *     3 = LayerNorm, fp16 deltas in, fp16 operand out (vision tower); d_delta may be NULL (plain norm).  Other combinations: VQS_ERR_INVALID.
+ * The fp16 GEMMs are reached through vqs_gemm's variant word (bits 27-28, vqs.h). */
+int vqs_debug_attention_f16(const void* d_q, const void* d_k, const void* d_v, void* d_out, const float* d_bias_table, const int32_t* d_key_len,
+                            int32_t B, int32_t H, int32_t S, float scale, void* stream);
+int vqs_debug_norm16(int32_t kind, float* d_x, const void* d_delta, const void* d_delta2, int32_t store_x, const void* d_w, const void* d_b,
+                     void* d_out, int32_t M, int32_t D, float eps, int32_t types, void* stream);
 /* Tap window: taps copy only the rows of `count` consecutive outer entries starting at `first` -- pairs for the T5 stacks
  * (rows [first*S, (first+count)*S) of an [B*S, W] tensor, the same fraction of a head-major [B, H, S, 64] or a [B*T, W] one),
  * images for the vision tower (so the window's pairs must reference images first .. first+count-1 in order, as the bench

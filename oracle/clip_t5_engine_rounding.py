@@ -191,18 +191,25 @@ class EngineRoundedOracle(Oracle):
     #   split (hi + lo planes): norm outputs, self-attention output, P.E context, ctx.Wv output, gated FFN product, final norm output
     #   fp32, never rounded:    q|k|v of the self attention, the three deltas into the fp32 stream
     #   bf16 as before:         the cross-attention score path (cq, q.Wk, probabilities), which reads the hi plane of the norm output
+    # option enc_fp16: the encoder's tensor classes held in IEEE fp16, and the linears that read fp16 weight copies
+    ENC_FP16_CLASSES = ("enc.norm", "enc.qkv", "enc.p", "enc.attn")
+    ENC_FP16_LINEARS = ("SelfAttention.q.weight", "SelfAttention.k.weight", "SelfAttention.v.weight", "SelfAttention.o.weight",
+                        "DenseReluDense.wi_0.weight", "DenseReluDense.wi_1.weight")
     DEC_SPLIT = ("dec.norm", "dec.sattn", "dec.cctx", "dec.cattn", "dec.act", "dec.out")
     DEC_FP32 = ("dec.qkv", "dec.delta")
 
     def __init__(self, cfg, weights, emulate="engine", round_fn=bf16_round, acc=torch.float64, classes=None, dec_precise=True,
-                 split_classes=(), half_classes=(), vit_fp16=True, device="cpu"):
+                 split_classes=(), half_classes=(), vit_fp16=True, device="cpu", enc_fp16=True):
         """`split_classes`: classes (of the tower / projector / encoder) to model as split-bf16 tensors instead of bf16 ones -- a
         what-if for tools/error_attribution.py, nothing the engine does today; the extra name "vit.v" splits the value heads only
         (q and k stay bf16: the score path).  `half_classes`: classes to model as IEEE fp16 tensors (11 significant bits instead of
         8, same MFMA rate); the weights of a stack with a half class are then fp16 too (bf16 -> fp16 is exact above 2^-14).
         `vit_fp16` = the engine's option of that name (vqs_set_option "vit_fp16"): every class of the tower and the projector's hidden
         tensor are fp16, the linear weights of both are the fp16 copies (the patch embedding keeps bf16 operands), and the projector's
-        output is rounded to fp16 by its GEMM and then to bf16 by the cast into the C ABI's feature tensor."""
+        output is rounded to fp16 by its GEMM and then to bf16 by the cast into the C ABI's feature tensor.
+        `enc_fp16` = the engine's option of that name (round 5, default 1): the ATTENTION SIDE of the T5 encoder -- both norm outputs, q / k / v,
+        the probabilities, the attention output -- is IEEE fp16 and q / k / v / o / wi_0 / wi_1 are read as fp16 copies; the sub-layer outputs,
+        the gated product, the wo GEMM and the encoder's final output stay bf16 (vqs_api.cpp encoder_pass)."""
         super().__init__(cfg, weights, device=device)     # device != "cpu": the what-if runs of tools/error_attribution.py evaluated on the GPU (under `with torch.device(dev)`)
         self.r = round_fn
         self.acc = acc
@@ -218,6 +225,9 @@ class EngineRoundedOracle(Oracle):
         self.vit_fp16 = bool(vit_fp16)           # default = what ships (the engine's default); False = the bf16 tower of rounds 1-3
         if self.vit_fp16:
             half_classes = tuple(half_classes) + tuple(c for c in self.CLASSES if c.startswith("vit.")) + ("proj.mid",)
+        self.enc_fp16 = bool(enc_fp16)
+        if self.enc_fp16:
+            half_classes = tuple(half_classes) + self.ENC_FP16_CLASSES
         self.half_extra = frozenset(half_classes)
         self.half_stacks = frozenset(c.split(".")[0] for c in self.half_extra)
         self.rh = (lambda x: x.to(torch.float16).to(torch.float32)) if round_fn is bf16_round else round_fn
@@ -271,6 +281,8 @@ class EngineRoundedOracle(Oracle):
         stack = {"vision": "vit", "mm_projector": "proj"}.get(wname.split(".")[0])
         if stack in self.half_stacks and "patch_embedding" not in wname:
             w = w.to(torch.float16)                 # what a bf16 checkpoint becomes in an fp16 tower
+        if self.enc_fp16 and wname.startswith("encoder.") and wname.endswith(self.ENC_FP16_LINEARS):
+            w = w.to(torch.float16)                 # ... and in the encoder's fp16 attention side (wo keeps bf16 operands)
         w = w.reshape(w.shape[0], -1).to(self.acc)
         y = (x.to(self.acc) @ w.t()).float()
         if bname is not None:
@@ -465,9 +477,11 @@ class EngineRoundedOracle(Oracle):
         for i in range(v.layers_run):
             for nm in self.TAP_NAMES_VIT:
                 out[f"vit.{i}.{nm}"] = ((NS, v.mlp if nm == "mid" else v.hidden), vt)
+        et = torch.float16 if self.enc_fp16 else bf            # the encoder's attention-side tensors (option enc_fp16)
         for i in range(t.layers):
             for nm in self.TAP_NAMES_ENC:
-                out[f"enc.{i}.{nm}"] = ((M, {"ff": t.d_ff, "xn0": t.d_model, "xn1": t.d_model, "d_attn": t.d_model, "d_ff": t.d_model}.get(nm, t.inner)), bf)
+                out[f"enc.{i}.{nm}"] = ((M, {"ff": t.d_ff, "xn0": t.d_model, "xn1": t.d_model, "d_attn": t.d_model, "d_ff": t.d_model}.get(nm, t.inner)),
+                                        et if nm in ("xn0", "q", "k", "v", "attn", "xn1") else bf)
         width = {"xn0": t.d_model, "xn1": t.d_model, "xn2": t.d_model, "d_self": t.d_model, "d_cross": t.d_model, "d_ff": t.d_model,
                  "qkv": 3 * t.inner, "sattn": t.inner, "cq": t.inner, "cattn": t.inner, "ff": t.d_ff,
                  "cqk": t.heads * t.d_model, "cctx": t.heads * t.d_model, "cscores": t.heads * Sp, "cprobs": t.heads * Sp}

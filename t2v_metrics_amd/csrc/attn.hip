@@ -452,8 +452,9 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
     if (p.causal || (p.Hkv > 0 && p.Hkv != p.H)) return hipErrorInvalidValue;
     const size_t bias_bytes = p.bias_table ? (size_t)bias_copy_chunks(p.S) * 64 : 0;
     const size_t lds = 2 * ST_BYTES + bias_bytes;
-    if (p.f16)      // fp16 q / k / v / out: the vision tower (no position bias there)
-        return p.bias_table ? hipErrorInvalidValue : launch_attn_t(attn_fwd_dma_f16_kernel<false>, p, lds, stream);
+    if (p.f16)      // fp16 q / k / v / out: the vision tower (no bias) and the T5 encoder of option enc_fp16 (position bias + key mask)
+        return p.bias_table ? launch_attn_t(attn_fwd_dma_f16_kernel<true>, p, lds, stream)
+                            : launch_attn_t(attn_fwd_dma_f16_kernel<false>, p, lds, stream);
     return p.bias_table ? launch_attn_t(attn_fwd_dma_kernel<true>, p, lds, stream)
                         : launch_attn_t(attn_fwd_dma_kernel<false>, p, lds, stream);
 }

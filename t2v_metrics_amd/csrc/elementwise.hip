@@ -96,8 +96,10 @@ __device__ __forceinline__ void st_stream(float4* p, float4 v) {
     __builtin_nontemporal_store(u, reinterpret_cast<e_f4v*>(p));
 }
 
-// KIND 0: RMSNorm (bsh unused); KIND 1: LayerNorm.  F16: the deltas and the 16-bit output are IEEE fp16 (w, bsh stay bf16).
-template <int NV, int KIND, int ADD, bool OUT_F32, bool F16 = false>
+// KIND 0: RMSNorm (bsh unused); KIND 1: LayerNorm.  F16: the 16-bit output is IEEE fp16; DF16: the deltas are (w, bsh stay bf16).  The
+// vision tower has both (its sub-layer outputs are fp16 tensors); the T5 encoder of option enc_fp16 has an fp16 operand out and bf16
+// deltas in (Flan-T5's sub-layer outputs do not fit fp16).
+template <int NV, int KIND, int ADD, bool OUT_F32, bool F16 = false, bool DF16 = F16>
 __global__ void __launch_bounds__(256) norm_rows_reg_kernel(float* __restrict__ x, const bf16_t* __restrict__ delta,
                                                             const bf16_t* __restrict__ delta2,
                                                             const bf16_t* __restrict__ w, const bf16_t* __restrict__ bsh,
@@ -122,7 +124,7 @@ __global__ void __launch_bounds__(256) norm_rows_reg_kernel(float* __restrict__ 
             for (int j = 0; j < NV; ++j) e[j] = ld_delta_last(er + lane + 64 * j);
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
-                const float4 f = d4_to_f4<F16>(d[j]), g = d4_to_f4<F16>(e[j]);
+                const float4 f = d4_to_f4<DF16>(d[j]), g = d4_to_f4<DF16>(e[j]);
                 v[j].x = (v[j].x + f.x) + g.x; v[j].y = (v[j].y + f.y) + g.y;
                 v[j].z = (v[j].z + f.z) + g.z; v[j].w = (v[j].w + f.w) + g.w;
                 st_stream(xr + lane + 64 * j, v[j]);
@@ -130,7 +132,7 @@ __global__ void __launch_bounds__(256) norm_rows_reg_kernel(float* __restrict__ 
         } else {
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
-                const float4 f = d4_to_f4<F16>(d[j]);
+                const float4 f = d4_to_f4<DF16>(d[j]);
                 v[j].x += f.x; v[j].y += f.y; v[j].z += f.z; v[j].w += f.w;
                 if (ADD == 1) st_stream(xr + lane + 64 * j, v[j]);
             }
@@ -172,7 +174,7 @@ __global__ void __launch_bounds__(256) norm_rows_reg_kernel(float* __restrict__ 
 }
 
 // any D % 4 == 0
-template <int KIND, int ADD, bool OUT_F32, bool F16 = false>
+template <int KIND, int ADD, bool OUT_F32, bool F16 = false, bool DF16 = F16>
 __global__ void __launch_bounds__(256) norm_rows_loop_kernel(float* __restrict__ x, const bf16_t* __restrict__ delta,
                                                              const bf16_t* __restrict__ delta2,
                                                              const bf16_t* __restrict__ w, const bf16_t* __restrict__ bsh,
@@ -189,7 +191,7 @@ __global__ void __launch_bounds__(256) norm_rows_loop_kernel(float* __restrict__
     auto value = [&](int i) {
         float4 v = xr[i];
         if (ADD == 2) {
-            const float4 d = d4_to_f4<F16>(dr[i]);
+            const float4 d = d4_to_f4<DF16>(dr[i]);
             v.x += d.x; v.y += d.y; v.z += d.z; v.w += d.w;
         }
         return v;
@@ -198,10 +200,10 @@ __global__ void __launch_bounds__(256) norm_rows_loop_kernel(float* __restrict__
     if (ADD == 1 || ADD == 3) {
         for (int i = lane; i < nv; i += 64) {
             float4 v = xr[i];
-            const float4 d = d4_to_f4<F16>(dr[i]);
+            const float4 d = d4_to_f4<DF16>(dr[i]);
             v.x += d.x; v.y += d.y; v.z += d.z; v.w += d.w;
             if (ADD == 3) {
-                const float4 e = d4_to_f4<F16>(er[i]);
+                const float4 e = d4_to_f4<DF16>(er[i]);
                 v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w;
             }
             xr[i] = v;
@@ -242,24 +244,24 @@ __global__ void __launch_bounds__(256) norm_rows_loop_kernel(float* __restrict__
 }
 
 // out_ld: row pitch of `out` in elements (0 = D; a multiple of 4).  The stream x and the deltas are always dense.
-template <int KIND, int ADD, bool OUT_F32, bool F16 = false>
+template <int KIND, int ADD, bool OUT_F32, bool F16 = false, bool DF16 = F16>
 static hipError_t launch_norm_t(float* x, const bf16_t* delta, const bf16_t* delta2, const bf16_t* w, const bf16_t* b, void* out,
                                 int M, int D, float eps, hipStream_t s, int out_ld = 0) {
     const dim3 grid((M + 3) / 4), block(256);
     if (out_ld <= 0) out_ld = D;
     if (out_ld < D || (out_ld & 3)) return hipErrorInvalidValue;
     if (D == 1024)
-        hipLaunchKernelGGL((norm_rows_reg_kernel<4, KIND, ADD, OUT_F32, F16>), grid, block, 0, s, x, delta, delta2, w, b, out, M, eps, out_ld);
+        hipLaunchKernelGGL((norm_rows_reg_kernel<4, KIND, ADD, OUT_F32, F16, DF16>), grid, block, 0, s, x, delta, delta2, w, b, out, M, eps, out_ld);
     else if (D == 2048)
-        hipLaunchKernelGGL((norm_rows_reg_kernel<8, KIND, ADD, OUT_F32, F16>), grid, block, 0, s, x, delta, delta2, w, b, out, M, eps, out_ld);
+        hipLaunchKernelGGL((norm_rows_reg_kernel<8, KIND, ADD, OUT_F32, F16, DF16>), grid, block, 0, s, x, delta, delta2, w, b, out, M, eps, out_ld);
     else if (D == 4096)
-        hipLaunchKernelGGL((norm_rows_reg_kernel<16, KIND, ADD, OUT_F32, F16>), grid, block, 0, s, x, delta, delta2, w, b, out, M, eps, out_ld);
+        hipLaunchKernelGGL((norm_rows_reg_kernel<16, KIND, ADD, OUT_F32, F16, DF16>), grid, block, 0, s, x, delta, delta2, w, b, out, M, eps, out_ld);
     else if (D == 1280)     // Qwen2.5-VL vision tower
-        hipLaunchKernelGGL((norm_rows_reg_kernel<5, KIND, ADD, OUT_F32, F16>), grid, block, 0, s, x, delta, delta2, w, b, out, M, eps, out_ld);
+        hipLaunchKernelGGL((norm_rows_reg_kernel<5, KIND, ADD, OUT_F32, F16, DF16>), grid, block, 0, s, x, delta, delta2, w, b, out, M, eps, out_ld);
     else if (D == 3584)     // Qwen2.5-VL-7B language model
-        hipLaunchKernelGGL((norm_rows_reg_kernel<14, KIND, ADD, OUT_F32, F16>), grid, block, 0, s, x, delta, delta2, w, b, out, M, eps, out_ld);
+        hipLaunchKernelGGL((norm_rows_reg_kernel<14, KIND, ADD, OUT_F32, F16, DF16>), grid, block, 0, s, x, delta, delta2, w, b, out, M, eps, out_ld);
     else
-        hipLaunchKernelGGL((norm_rows_loop_kernel<KIND, ADD, OUT_F32, F16>), grid, block, 0, s, x, delta, delta2, w, b, out, M, D, eps, out_ld);
+        hipLaunchKernelGGL((norm_rows_loop_kernel<KIND, ADD, OUT_F32, F16, DF16>), grid, block, 0, s, x, delta, delta2, w, b, out, M, D, eps, out_ld);
     return hipGetLastError();
 }
 
@@ -271,8 +273,17 @@ static int norm_add_mode(const bf16_t* delta, const bf16_t* delta2, bool store_x
 }
 
 hipError_t launch_rmsnorm(float* x, const bf16_t* delta, const bf16_t* w, bf16_t* out, int M, int D, float eps,
-                          hipStream_t s, const bf16_t* delta2, bool store_x, int out_ld) {
+                          hipStream_t s, const bf16_t* delta2, bool store_x, int out_ld, bool out_f16) {
     if (D % 4) return hipErrorInvalidValue;
+    if (out_f16) {          // bf16 deltas in, IEEE fp16 operand out (the T5 encoder of option enc_fp16)
+        switch (norm_add_mode(delta, delta2, store_x)) {
+            case 0: return launch_norm_t<0, 0, false, true, false>(x, delta, delta2, w, nullptr, out, M, D, eps, s, out_ld);
+            case 1: return launch_norm_t<0, 1, false, true, false>(x, delta, delta2, w, nullptr, out, M, D, eps, s, out_ld);
+            case 2: return launch_norm_t<0, 2, false, true, false>(x, delta, delta2, w, nullptr, out, M, D, eps, s, out_ld);
+            case 3: return launch_norm_t<0, 3, false, true, false>(x, delta, delta2, w, nullptr, out, M, D, eps, s, out_ld);
+            default: return hipErrorInvalidValue;
+        }
+    }
     switch (norm_add_mode(delta, delta2, store_x)) {
         case 0: return launch_norm_t<0, 0, false>(x, delta, delta2, w, nullptr, out, M, D, eps, s, out_ld);
         case 1: return launch_norm_t<0, 1, false>(x, delta, delta2, w, nullptr, out, M, D, eps, s, out_ld);
@@ -940,8 +951,12 @@ __global__ void __launch_bounds__(256) logprob_kernel(const float* __restrict__ 
     }
 }
 
+// flags (optional, the pass's status word): bit 1 is set when a pair's label log-probs are not finite.  With the fp16 options (vit_fp16 /
+// enc_fp16) an activation beyond the fp16 range is stored as +-inf by v_cvt_pk_f16_f32; it reaches this kernel as NaN logits whatever
+// stage it came from (an inf operand makes the next norm's rsqrt(mean x^2) zero: inf * 0), so ONE check here guards every fp16 store
+// of the pass without touching a hot kernel.
 __global__ void score_fold_kernel(const float* __restrict__ lp, const int* __restrict__ labels,
-                                  float* __restrict__ scores, int B, int T) {
+                                  float* __restrict__ scores, int B, int T, int* __restrict__ flags) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     float s = 0.0f;
@@ -949,12 +964,13 @@ __global__ void score_fold_kernel(const float* __restrict__ lp, const int* __res
     for (int t = 0; t < T; ++t)
         if (labels[(size_t)b * T + t] != -100) { s += lp[(size_t)b * T + t]; ++n; }
     scores[b] = expf(s / (float)max(n, 1));
+    if (flags != nullptr && !(fabsf(s) <= 3.0e38f)) atomicOr(flags, 2);
 }
 
 hipError_t launch_score_head(const float* logits, int ldl, int V, const int* labels, float* label_logprobs,
-                             float* scores, int B, int T, hipStream_t s) {
+                             float* scores, int B, int T, hipStream_t s, int* flags) {
     hipLaunchKernelGGL(logprob_kernel, dim3(B * T), dim3(256), 0, s, logits, ldl, V, labels, label_logprobs);
-    hipLaunchKernelGGL(score_fold_kernel, dim3((B + 63) / 64), dim3(64), 0, s, label_logprobs, labels, scores, B, T);
+    hipLaunchKernelGGL(score_fold_kernel, dim3((B + 63) / 64), dim3(64), 0, s, label_logprobs, labels, scores, B, T, flags);
     return hipGetLastError();
 }
 

@@ -1254,8 +1254,10 @@ static bool quad_eligible(const GemmParams& p) { return quad_eligible_rt(p, EPI)
 // operands), -1 not launchable.  The 32-bit forms refuse operands of 4 GiB or more per batch entry; a plain single-entry launch
 // then falls back to the one-tile-per-workgroup kernel (same bits), anything else is an error -- never a wrapped offset.
 int gemm_form(const GemmParams& p, int epilogue, int variant) {
-    if (p.f16)      // fp16 operands: the quad form only (every 16-bit-result linear of the vision tower and the projector resolves to it)
-        return (variant == 3 || variant == 10) && epilogue != EPI_GATED && quad_eligible_rt(p, epilogue) ? 10 : -1;
+    if (p.f16)      // fp16 operands: the quad form only (every 16-bit-result linear of the vision tower, the projector and -- option enc_fp16 --
+                    // the T5 encoder's attention side resolves to it); 1 = fp16 result (no gated epilogue), 2 = bf16 result (plain / gated only)
+        return (variant == 3 || variant == 10) && quad_eligible_rt(p, epilogue) &&
+                       (p.f16 == 1 ? epilogue != EPI_GATED : (p.f16 == 2 && (epilogue == EPI_BF16 || epilogue == EPI_GATED))) ? 10 : -1;
     if (epilogue == EPI_RESID_RMS) variant = variant == 5 ? 5 : 3;
     const bool plain_v0 = !(p.hd > 64 || p.hd_src > 0 || p.inner_kv > 0 || p.Hkv > 0 || p.gate_act != 0 || (epilogue == EPI_GATED && p.bias != nullptr) || p.rowss_in != nullptr ||
                             p.split_off != 0) &&
@@ -1304,7 +1306,10 @@ static hipError_t launch_epi(const GemmParams& p, int variant, hipStream_t strea
         if constexpr (EPI == EPI_BF16 || EPI == EPI_BF16_QGELU || EPI == EPI_BF16_GELU || EPI == EPI_GATED || EPI == EPI_HEADS) {
             const int nwg = tiles_m * tiles_n;
             const dim3 qgrid(nwg < PERSISTENT_WGS ? nwg : PERSISTENT_WGS);
-            if (p.f16) {
+            if (p.f16 == 2) {
+                if constexpr (EPI == EPI_BF16 || EPI == EPI_GATED) hipLaunchKernelGGL((gemm_f16b_quad<EPI>), qgrid, dim3(256), 0, stream, p);
+                else return hipErrorInvalidValue;
+            } else if (p.f16) {
                 if constexpr (EPI != EPI_GATED) hipLaunchKernelGGL((gemm_f16_quad<EPI>), qgrid, dim3(256), 0, stream, p);
                 else return hipErrorInvalidValue;
             } else {

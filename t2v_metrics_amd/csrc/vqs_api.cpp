@@ -53,6 +53,13 @@ struct vqs_handle {
     const bf16_t* proj0_w16 = nullptr;
     const bf16_t* proj2_w16 = nullptr;
     int dec_precise = 1;  // 1 = the scoring decoder holds its activations as split-bf16 / fp32 (decoder_pass_precise), 0 = bf16 (rounds 1-3)
+    int enc_fp16 = 1;     // 1 (default, round 5) = the ATTENTION SIDE of the T5 encoder runs on IEEE fp16 tensors: both norm outputs, q / k / v, the
+                          // softmax probabilities and the attention output are fp16, and q|k|v, o and the gated wi read fp16 copies of their weights
+                          // (made at bind time) -- what HF's own fp16 T5 path holds in fp16.  The sub-layer outputs (o / wo results), the gated FFN
+                          // product and the wo GEMM stay bf16: those are where Flan-T5 leaves the fp16 range (HF keeps `wo` in fp32 for it,
+                          // modeling_t5.py _keep_in_fp32_modules); the residual stream is fp32 here anyway.  Same MFMA rate, same bytes, three more
+                          // significant bits on five of the encoder's seven 16-bit tensor classes (profiles/r5_error_attribution_xxl.md).  0 = bf16
+    std::vector<const bf16_t*> enc_qkv16, enc_o16, enc_wi16;   // the fp16 copies (packed buffer)
     const int* lut_bidir = nullptr;
     const int* lut_causal = nullptr;
     int lut_len = 0;
@@ -226,6 +233,7 @@ struct PackedLayout {
     std::vector<size_t> vit_qkv_w, vit_qkv_b, enc_qkv, enc_wi, dec_qkv, dec_ckv, dec_wi, dec_ckT;
     std::vector<size_t> vit_qkv_w16, vit_out_w16, vit_fc1_w16, vit_fc2_w16;    // fp16 copies for option vit_fp16 (always laid out: 0.45 GB for ViT-L)
     size_t proj0_w16, proj2_w16;
+    std::vector<size_t> enc_qkv16, enc_o16, enc_wi16;                          // fp16 copies for option enc_fp16 (always laid out: 7.2 GB at XXL, 1.9 GB at XL)
     size_t lut_bidir, lut_causal;
     size_t total;
 };
@@ -264,6 +272,11 @@ PackedLayout packed_layout(const vqs_handle* h) {
     }
     pl.proj0_w16 = take(D * hid);
     pl.proj2_w16 = take(D * D);
+    for (int i = 0; i < c.enc_layers; ++i) {
+        pl.enc_qkv16.push_back(take(3 * I * D));
+        pl.enc_o16.push_back(take(D * I));
+        pl.enc_wi16.push_back(take(2 * F * D));
+    }
     pl.lut_bidir = take(2 * (size_t)(c.rel_max_distance + 1));   // int32 = 2 bf16 slots each
     pl.lut_causal = take(2 * (size_t)(c.rel_max_distance + 1));
     pl.total = align_up(cv.off);
@@ -555,6 +568,7 @@ int vqs_set_option(vqs_handle* h, const char* name, int32_t value) {
     else if (n == "norm_defer" && (value == 0 || value == 1)) h->norm_defer = value;
     else if (n == "dec_precise" && (value == 0 || value == 1)) h->dec_precise = value;
     else if (n == "vit_fp16" && (value == 0 || value == 1)) h->vit_fp16 = value;
+    else if (n == "enc_fp16" && (value == 0 || value == 1)) h->enc_fp16 = value;
     else if (n == "stream_gemm" && (value == 0 || value == 1)) h->stream_gemm = value;
     else if (n == "gemm_variant" && (value == 0 || value == 2 || value == 3 || value == 5 || value == 11)) h->gemm_variant = value;
     else if (n.rfind("l2_touch:", 0) == 0 || n.rfind("nt_store:", 0) == 0 || n.rfind("tile_order:", 0) == 0) {
@@ -595,6 +609,7 @@ int vqs_get_option(const vqs_handle* h, const char* name, int32_t* value) {
     else if (n == "norm_defer") *value = h->norm_defer;
     else if (n == "dec_precise") *value = h->dec_precise;
     else if (n == "vit_fp16") *value = h->vit_fp16;
+    else if (n == "enc_fp16") *value = h->enc_fp16;
     else if (n == "stream_gemm") *value = h->stream_gemm;
     else if (n == "gemm_variant") *value = h->gemm_variant;
     else return VQS_ERR_INVALID;
@@ -686,6 +701,7 @@ int vqs_bind_weights(vqs_handle* h, const vqs_weight_desc* weights, int32_t n, v
         HIPCHK(h, vqs::launch_interleave_gate(w0, w1, dst, F, D, st), "pack wi");
         return VQS_OK;
     };
+    h->enc_qkv16.clear(); h->enc_o16.clear(); h->enc_wi16.clear();
     h->enc_qkv.clear(); h->enc_wi.clear(); h->dec_qkv.clear(); h->dec_ckv.clear(); h->dec_wi.clear(); h->dec_ckT.clear();
     for (int i = 0; i < c.enc_layers; ++i) {
         const std::string p = "encoder.block." + std::to_string(i) + ".";
@@ -693,6 +709,14 @@ int vqs_bind_weights(vqs_handle* h, const vqs_weight_desc* weights, int32_t n, v
         RUN(pack_wi(p + "layer.1.DenseReluDense.", at(pl.enc_wi[i])));
         h->enc_qkv.push_back(at(pl.enc_qkv[i]));
         h->enc_wi.push_back(at(pl.enc_wi[i]));
+        // fp16 copies for option enc_fp16 (of the PACKED q|k|v and interleaved wi_0|wi_1, and of o): exact for 2^-14 <= |w| < 65 520
+        GETW(ow, p + "layer.0.SelfAttention.o.weight", (int64_t)D * I);
+        HIPCHK(h, vqs::launch_cast16(at(pl.enc_qkv[i]), at(pl.enc_qkv16[i]), (size_t)3 * I * D, true, st), "fp16 enc qkv");
+        HIPCHK(h, vqs::launch_cast16(ow, at(pl.enc_o16[i]), (size_t)D * I, true, st), "fp16 enc o");
+        HIPCHK(h, vqs::launch_cast16(at(pl.enc_wi[i]), at(pl.enc_wi16[i]), (size_t)2 * F * D, true, st), "fp16 enc wi");
+        h->enc_qkv16.push_back(at(pl.enc_qkv16[i]));
+        h->enc_o16.push_back(at(pl.enc_o16[i]));
+        h->enc_wi16.push_back(at(pl.enc_wi16[i]));
     }
     for (int i = 0; i < c.dec_layers; ++i) {
         const std::string p = "decoder.block." + std::to_string(i) + ".";
@@ -901,6 +925,13 @@ static int encoder_pass(vqs_handle* h, const ScoreWs& w, const void* d_feats, co
     const bf16_t* pend = nullptr;
     const bf16_t* pend_attn = nullptr;   // deferred store (see the vision tower): the attention delta the stream has not absorbed yet
     const bool defer = h->norm_defer != 0 && !fused;
+    // option enc_fp16: the attention side on IEEE fp16 tensors (see the option's comment in vqs_handle): xn (both norms), q / k / v, P, the
+    // attention output are fp16 and q|k|v, o, wi read their fp16 weight copies; o's and wo's results (the deltas) and the gated product stay
+    // bf16, wo runs as before.  The final norm's output (the tensor the decoder reads) stays bf16.
+    const bool e16 = h->enc_fp16 != 0;
+    if (e16 && (h->gemm_variant != 3 || fused))
+        return fail(h, VQS_ERR_STATE, "score: the fp16 encoder attention side (option enc_fp16, default 1) needs gemm_variant 3 and fused_norm 0 -- its linears "
+                                      "exist in the quad form only; set enc_fp16=0 to A/B other GEMM forms");
     auto consume = [&](GemmCall& g) {
         if (scaled) {
             g.rowss_in = w.rs; g.rowss_parts = 0;
@@ -917,23 +948,25 @@ static int encoder_pass(vqs_handle* h, const ScoreWs& w, const void* d_feats, co
         GETW(wo, p + "layer.1.DenseReluDense.wo.weight", (int64_t)D * F);
         if (!scaled) {
             if (pend_attn)
-                HIPCHK(h, vqs::launch_rmsnorm(w.hidden, pend_attn, ln0, w.xn, M, D, c.t5_ln_eps, st, pend), "enc rmsnorm0");
+                HIPCHK(h, vqs::launch_rmsnorm(w.hidden, pend_attn, ln0, w.xn, M, D, c.t5_ln_eps, st, pend, true, 0, e16), "enc rmsnorm0");
             else
-                HIPCHK(h, vqs::launch_rmsnorm(w.hidden, pend, ln0, w.xn, M, D, c.t5_ln_eps, st), "enc rmsnorm0");
+                HIPCHK(h, vqs::launch_rmsnorm(w.hidden, pend, ln0, w.xn, M, D, c.t5_ln_eps, st, nullptr, true, 0, e16), "enc rmsnorm0");
             pend = nullptr;
             pend_attn = nullptr;
         }
         TAP("enc", i, "xn0", w.xn, (size_t)M * D);
         {
-            GemmCall g{w.xn, h->enc_qkv[i], nullptr};
+            GemmCall g{w.xn, e16 ? h->enc_qkv16[i] : h->enc_qkv[i], nullptr};
             g.M = M; g.N = 3 * I; g.K = D; g.lda = D; g.ldw = D; g.ldc = 0; g.epi = vqs::EPI_HEADS;
             g.S = S; g.H = H; g.inner = I;
             g.heads[0] = w.q; g.heads[1] = w.k; g.heads[2] = w.v;
+            g.f16 = e16 ? 1 : 0;
             consume(g);
             RUN(run_gemm(h, g, st, "enc qkv"));
         }
         {
             vqs::AttnParams a{w.q, w.k, w.v, w.attn, w.enc_table, w.enc_len, B, H, S, 1.0f};
+            a.f16 = e16 ? 1 : 0;
             TAP("enc", i, "q", w.q, (size_t)M * I);
             TAP("enc", i, "k", w.k, (size_t)M * I);
             TAP("enc", i, "v", w.v, (size_t)M * I);
@@ -941,8 +974,9 @@ static int encoder_pass(vqs_handle* h, const ScoreWs& w, const void* d_feats, co
             TAP("enc", i, "attn", w.attn, (size_t)M * I);
         }
         {
-            GemmCall g{w.attn, ow, w.delta};
+            GemmCall g{w.attn, e16 ? h->enc_o16[i] : ow, w.delta};
             g.M = M; g.N = D; g.K = I; g.lda = I; g.ldw = I; g.ldc = D; g.epi = vqs::EPI_BF16;
+            g.f16 = e16 ? 2 : 0;                 // fp16 operands, bf16 delta
             if (fused) produce(g, ln1);
             RUN(run_gemm(h, g, st, "enc o"));
             if (!fused) TAP("enc", i, "d_attn", w.delta, (size_t)M * D);
@@ -951,14 +985,15 @@ static int encoder_pass(vqs_handle* h, const ScoreWs& w, const void* d_feats, co
         if (fused) {
             scaled = true;
         } else {
-            HIPCHK(h, vqs::launch_rmsnorm(w.hidden, w.delta, ln1, w.xn, M, D, c.t5_ln_eps, st, nullptr, !defer), "enc rmsnorm1");
+            HIPCHK(h, vqs::launch_rmsnorm(w.hidden, w.delta, ln1, w.xn, M, D, c.t5_ln_eps, st, nullptr, !defer, 0, e16), "enc rmsnorm1");
             if (defer) pend_attn = w.delta;
             scaled = false;
             TAP("enc", i, "xn1", w.xn, (size_t)M * D);
         }
         {
-            GemmCall g{w.xn, h->enc_wi[i], w.ff};
+            GemmCall g{w.xn, e16 ? h->enc_wi16[i] : h->enc_wi[i], w.ff};
             g.M = M; g.N = 2 * F; g.K = D; g.lda = D; g.ldw = D; g.ldc = F; g.epi = vqs::EPI_GATED;
+            g.f16 = e16 ? 2 : 0;                 // fp16 operands, bf16 gated product
             consume(g);
             RUN(run_gemm(h, g, st, "enc wi"));
             TAP("enc", i, "ff", w.ff, (size_t)M * F);
@@ -1323,7 +1358,7 @@ int vqs_score(vqs_handle* h, const void* d_feats, const int32_t* d_img_index, co
         RUN(decoder_pass_precise(h, w, d_labels, T, B, L, T, st));
     else                                             // bf16 decoder of rounds 1-3 (option dec_precise=0, or the direct cross-attention form)
         RUN(decoder_pass(h, w, d_labels, T, B, L, T, st));
-    HIPCHK(h, vqs::launch_score_head(w.logits, w.ldl, V, d_labels, d_lp, d_scores, B, T, st), "score head");
+    HIPCHK(h, vqs::launch_score_head(w.logits, w.ldl, V, d_labels, d_lp, d_scores, B, T, st, w.flags), "score head");
     return VQS_OK;
 }
 
@@ -1465,6 +1500,8 @@ int vqs_gemm(const void* A, const void* W, void* C, const void* bias, const floa
     p.tile_ns = (variant >> 16) & 0xff;
     p.nt_store = (variant >> 24) & 1;      // bit 24: non-temporal result stores; bits 25-26: A-panel L2 touch (0 by shape, 1 on, 2 off)
     p.l2_touch = (variant >> 25) & 3;
+    p.f16 = (variant >> 27) & 3;           // bits 27-28: 0 bf16 operands and result, 1 IEEE fp16 operands and result, 2 fp16 operands / bf16 result
+    if (p.f16 == 3) return VQS_ERR_INVALID;
     return vqs::launch_gemm(p, epilogue, variant & 0xff, (hipStream_t)stream) == hipSuccess ? VQS_OK : VQS_ERR_HIP;
 }
 
@@ -1472,6 +1509,28 @@ int vqs_attention(const void* q, const void* k, const void* v, void* out, const 
                   int32_t B, int32_t H, int32_t S, float scale, void* stream) {
     vqs::AttnParams a{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, bias_table, key_len, B, H, S, scale};
     return vqs::launch_attention(a, (hipStream_t)stream) == hipSuccess ? VQS_OK : VQS_ERR_HIP;
+}
+
+int vqs_debug_attention_f16(const void* q, const void* k, const void* v, void* out, const float* bias_table, const int32_t* key_len,
+                            int32_t B, int32_t H, int32_t S, float scale, void* stream) {
+    vqs::AttnParams a{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, bias_table, key_len, B, H, S, scale};
+    a.f16 = 1;
+    return vqs::launch_attention(a, (hipStream_t)stream) == hipSuccess ? VQS_OK : VQS_ERR_HIP;
+}
+
+int vqs_debug_norm16(int32_t kind, float* x, const void* delta, const void* delta2, int32_t store_x, const void* w, const void* b,
+                     void* out, int32_t M, int32_t D, float eps, int32_t types, void* stream) {
+    if (!x || !w || !out || (kind == 1 && !b) || (kind != 0 && kind != 1)) return VQS_ERR_INVALID;
+    hipError_t e;
+    if (kind == 0 && types == 1)          // RMSNorm, bf16 deltas in, fp16 operand out: the T5 encoder of option enc_fp16
+        e = vqs::launch_rmsnorm(x, (const bf16_t*)delta, (const bf16_t*)w, (bf16_t*)out, M, D, eps, (hipStream_t)stream, (const bf16_t*)delta2,
+                                store_x != 0, 0, true);
+    else if (kind == 1 && types == 3)     // LayerNorm, fp16 deltas in, fp16 operand out: the vision tower of option vit_fp16
+        e = vqs::launch_layernorm(x, (const bf16_t*)delta, (const bf16_t*)w, (const bf16_t*)b, out, 0, M, D, eps, (hipStream_t)stream,
+                                  (const bf16_t*)delta2, store_x != 0, true);
+    else
+        return VQS_ERR_INVALID;
+    return e == hipSuccess ? VQS_OK : (e == hipErrorInvalidValue ? VQS_ERR_INVALID : VQS_ERR_HIP);
 }
 
 int vqs_normalize_u8(const void* d_u8, void* d_out, int32_t N, int32_t H, int32_t W, const float* mean3, const float* std3,

@@ -34,7 +34,8 @@ struct GemmParams {
     // EPI_HEADS
     int S, H, inner;
     int f16 = 0;             // any epilogue; host-side only (selects the kernel): 1 = A, W and the 16-bit result are IEEE fp16 instead of bf16
-                             // (quad form only; bias stays bf16) -- the fp16 vision tower.  Sits in what was alignment padding: no other
+                             // (quad form only; bias stays bf16) -- the fp16 vision tower; 2 = A and W fp16, the 16-bit result bf16 (plain and
+                             // gated epilogue: the T5 encoder's o / wi of option enc_fp16).  Sits in what was alignment padding: no other
                              // field moved, the kernels' argument block is byte for byte what it was.
     bf16_t* heads_out[3];
     int hd = 0;              // head width (0 = 64); 128 for Qwen2.5-VL
@@ -186,7 +187,7 @@ struct AttnParams {
     int causal = 0;           // key <= query
     int out_hd = 0;           // hd = 128 only: lanes of a head written to `out`, which is then [B*S, H*out_hd] (0 = hd); the Qwen2.5-VL
                               // tower's 80-lane heads leave compact so that the proj GEMM contracts over 1280, not 2048
-    int f16 = 0;              // hd = 64, no bias only: q / k / v / out are IEEE fp16 tensors instead of bf16 (the fp16 vision tower)
+    int f16 = 0;              // hd = 64 only: q / k / v / out are IEEE fp16 tensors instead of bf16 (the fp16 vision tower; with a bias table: the T5 encoder of option enc_fp16)
 };
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream);
 size_t attention_lds_bytes(int S, bool has_bias, int hd);   // dynamic LDS request of that launch (host-side arithmetic)
@@ -218,7 +219,8 @@ hipError_t launch_decoder_attention(const DecAttnParams& p, hipStream_t stream);
 // delta2 / store_x select the deferred-store forms (elementwise.hip): (delta, store_x=false) normalises x + delta without
 // writing the stream; (delta, delta2) stores x = (x + delta) + delta2.
 hipError_t launch_rmsnorm(float* x, const bf16_t* delta, const bf16_t* w, bf16_t* out, int M, int D, float eps,
-                          hipStream_t s, const bf16_t* delta2 = nullptr, bool store_x = true, int out_ld = 0);   // out_ld: row pitch of out (0 = D)
+                          hipStream_t s, const bf16_t* delta2 = nullptr, bool store_x = true, int out_ld = 0, bool out_f16 = false);
+// out_ld: row pitch of out (0 = D); out_f16: the operand leaves as IEEE fp16 (deltas stay bf16): the T5 encoder of option enc_fp16
 hipError_t launch_layernorm(float* x, const bf16_t* delta, const bf16_t* w, const bf16_t* b, void* out, int out_f32, int M,
                             int D, float eps, hipStream_t s, const bf16_t* delta2 = nullptr, bool store_x = true, bool f16 = false);
 // f16: the deltas and the 16-bit output are IEEE fp16 tensors (the fp16 vision tower); w / b stay bf16
@@ -278,7 +280,7 @@ hipError_t launch_relpos_table(const bf16_t* rel_weight, const int* bucket_lut_b
                                hipStream_t s);
 // logits fp32 [B*T, ldl] -> label_logprobs [B,T] (0 where label == -100) and scores [B]
 hipError_t launch_score_head(const float* logits, int ldl, int V, const int* labels, float* label_logprobs,
-                             float* scores, int B, int T, hipStream_t s);
+                             float* scores, int B, int T, hipStream_t s, int* flags = nullptr);
 // reassociated decoder cross-attention helpers
 hipError_t launch_transpose_pad(const bf16_t* in, bf16_t* out, int B, int S, int D, int S_pad, hipStream_t s);
 hipError_t launch_masked_softmax(const float* scores, bf16_t* probs, const int* key_len, int B, int rows, int S_pad,

@@ -73,6 +73,8 @@ _SIGNATURES = {
     "vqs_get_option": (_c_i32, [_c_vp, ctypes.c_char_p, ctypes.POINTER(_c_i32)]),
     "vqs_debug_tap": (_c_i32, [_c_vp, ctypes.c_char_p, _c_vp, ctypes.c_size_t]),
     "vqs_debug_tap_window": (_c_i32, [_c_vp, _c_i32, _c_i32]),
+    "vqs_debug_attention_f16": (_c_i32, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i32, _c_i32, _c_i32, ctypes.c_float, _c_vp]),
+    "vqs_debug_norm16": (_c_i32, [_c_i32, _c_vp, _c_vp, _c_vp, _c_i32, _c_vp, _c_vp, _c_vp, _c_i32, _c_i32, ctypes.c_float, _c_i32, _c_vp]),
     "vqs_debug_gemm_form": (_c_i32, [_c_i32] * 11),
     "vqs_debug_gemm_batched": (_c_i32, [_c_vp, _c_vp, _c_vp] + [_c_i32] * 8 + [_c_i64] * 4 + [_c_i32, _c_i32, _c_vp]),
     "vqs_debug_heads_rows": (_c_i32, [_c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_vp]),
@@ -124,12 +126,23 @@ def make_vqs_config(cfg: ClipT5Config) -> VqsConfig:
 FP16_MAX_FINITE_ROUNDED = 65520.0      # values at or above this round to +-inf in IEEE fp16
 
 
-def fp16_unsafe_weights(weights: Dict[str, torch.Tensor]) -> List[str]:
-    """Names of the vision tower's / projector's linear weights that an fp16 copy cannot hold (|w| >= 65 520, or not finite): the
-    tensors vqs_bind_weights converts for option vit_fp16.  Any device; one reduction per tensor."""
+_ENC_FP16_LINEARS = ("layer.0.SelfAttention.q.weight", "layer.0.SelfAttention.k.weight", "layer.0.SelfAttention.v.weight",
+                     "layer.0.SelfAttention.o.weight", "layer.1.DenseReluDense.wi_0.weight", "layer.1.DenseReluDense.wi_1.weight")
+
+
+def fp16_unsafe_weights(weights: Dict[str, torch.Tensor], stack: str = "vit") -> List[str]:
+    """Names of the linear weights that an fp16 copy cannot hold (|w| >= 65 520, or not finite) among the tensors vqs_bind_weights
+    converts: stack "vit" = the vision tower's and the projector's (option vit_fp16), "enc" = the T5 encoder's q / k / v / o / wi_0 / wi_1
+    (option enc_fp16; wo keeps bf16 operands).  Any device; one reduction per tensor."""
     bad = []
     for k, w in weights.items():
-        if w.dim() == 2 and k.endswith(".weight") and (k.startswith("vision.encoder.layers.") or k.startswith("mm_projector.")):
+        if w.dim() != 2 or not k.endswith(".weight"):
+            continue
+        if stack == "vit":
+            mine = k.startswith("vision.encoder.layers.") or k.startswith("mm_projector.")
+        else:
+            mine = k.startswith("encoder.block.") and k.endswith(_ENC_FP16_LINEARS)
+        if mine:
             m = float(w.detach().abs().max().float()) if w.numel() else 0.0
             if not (m < FP16_MAX_FINITE_ROUNDED):          # also catches NaN / inf
                 bad.append(k)
@@ -203,6 +216,10 @@ class VqsEngine:
         if self._fp16_unsafe and self.get_option("vit_fp16"):
             raise VqsError("these vision-tower / projector weights exceed the fp16 range (|w| >= 65520): %s -- pass options={'vit_fp16': 0} "
                            "to run the tower on bf16 operands" % ", ".join(self._fp16_unsafe[:4]))
+        self._enc_fp16_unsafe = fp16_unsafe_weights(self.weights, "enc")
+        if self._enc_fp16_unsafe and self.get_option("enc_fp16"):
+            raise VqsError("these T5-encoder weights exceed the fp16 range (|w| >= 65520): %s -- pass options={'enc_fp16': 0} to run the "
+                           "encoder's attention side on bf16 operands" % ", ".join(self._enc_fp16_unsafe[:4]))
 
     # ------------------------------------------------------------------ the two stages
     def encode_images(self, pixels: torch.Tensor) -> torch.Tensor:
@@ -324,6 +341,8 @@ class VqsEngine:
     def set_option(self, name: str, value: int):
         if name == "vit_fp16" and int(value) == 1 and getattr(self, "_fp16_unsafe", None):
             raise VqsError("vit_fp16 = 1 refused: weights outside the fp16 range: " + ", ".join(self._fp16_unsafe[:4]))
+        if name == "enc_fp16" and int(value) == 1 and getattr(self, "_enc_fp16_unsafe", None):
+            raise VqsError("enc_fp16 = 1 refused: weights outside the fp16 range: " + ", ".join(self._enc_fp16_unsafe[:4]))
         self._check(self.lib.vqs_set_option(self._h, name.encode(), int(value)), "vqs_set_option")
         self._options[name] = int(value)
 
@@ -364,29 +383,33 @@ class VqsEngine:
 
 # ---------------------------------------------------------------------- single-kernel wrappers (tests, microbench)
 def gemm(A, W, epilogue: int, bias=None, resid=None, out=None, S: int = 0, H: int = 0, variant: int = 0, tile_order=None,
-         nt_store: bool = False, l2_touch: int = 0):
+         nt_store: bool = False, l2_touch: int = 0, ftype: int = 0):
     """C = epilogue(A @ W.T).  A [M,K] bf16, W [N,K] bf16.  See include/vqs.h for epilogue codes.
     tile_order = (gm, ns): workgroup -> tile order of the launch (a permutation of the tile list); nt_store: non-temporal result
-    stores; l2_touch: 1 / 2 = A-panel L2 prefetch on / off (0: by shape).  All three are bitwise-neutral."""
+    stores; l2_touch: 1 / 2 = A-panel L2 prefetch on / off (0: by shape).  All three are bitwise-neutral.
+    ftype (bits 27-28 of the variant word): 0 bf16 tensors; 1 A, W and the 16-bit result IEEE fp16; 2 A, W fp16, result bf16."""
     if tile_order is not None:
         variant = (variant & 0xff) | (int(tile_order[0]) << 8) | (int(tile_order[1]) << 16)
-    variant |= (1 << 24 if nt_store else 0) | ((int(l2_touch) & 3) << 25)
+    variant |= (1 << 24 if nt_store else 0) | ((int(l2_touch) & 3) << 25) | ((int(ftype) & 3) << 27)
+    t16 = torch.float16 if ftype == 1 else torch.bfloat16
+    if A.dtype != (torch.float16 if ftype else torch.bfloat16) or W.dtype != A.dtype:
+        raise VqsError("gemm: operand dtype does not match ftype")
     lib = load_library()
     M, K = A.shape
     N = W.shape[0]
     dev = A.device
     if epilogue in (0, 1, 2):
-        out = torch.empty(M, N, dtype=torch.bfloat16, device=dev) if out is None else out
+        out = torch.empty(M, N, dtype=t16, device=dev) if out is None else out
         ldc = N
     elif epilogue in (3, 4):
         out = torch.empty(M, N, dtype=torch.float32, device=dev) if out is None else out
         ldc = N
     elif epilogue == 5:
-        out = torch.empty(M, N // 2, dtype=torch.bfloat16, device=dev) if out is None else out
+        out = torch.empty(M, N // 2, dtype=t16, device=dev) if out is None else out
         ldc = N // 2
     elif epilogue == 6:
         nsel = N // (H * 64)
-        out = torch.empty(nsel, M // S, H, S, 64, dtype=torch.bfloat16, device=dev) if out is None else out
+        out = torch.empty(nsel, M // S, H, S, 64, dtype=t16, device=dev) if out is None else out
         ldc = 0
     else:
         raise ValueError(epilogue)
@@ -453,14 +476,28 @@ def gemm_rowscaled(A, W, epilogue: int, rowss, d_norm: int, eps: float, S: int =
 
 
 def attention(q, k, v, scale: float, bias_table=None, key_len=None):
+    """q, k, v [B,H,S,64] bf16 -> bf16 [B*S, H*64]; fp16 tensors run the fp16 instantiation (test hook vqs_debug_attention_f16)."""
     lib = load_library()
     B, H, S, d = q.shape
-    assert d == 64
-    out = torch.empty(B * S, H * 64, dtype=torch.bfloat16, device=q.device)
-    rc = lib.vqs_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), _ptr(bias_table), _ptr(key_len), B, H,
-                           S, scale, _stream_ptr())
+    assert d == 64 and k.dtype == q.dtype and v.dtype == q.dtype
+    out = torch.empty(B * S, H * 64, dtype=q.dtype, device=q.device)
+    fn = lib.vqs_debug_attention_f16 if q.dtype == torch.float16 else lib.vqs_attention
+    rc = fn(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), _ptr(bias_table), _ptr(key_len), B, H, S, scale, _stream_ptr())
     if rc != 0:
         raise VqsError(f"vqs_attention failed ({rc})")
+    return out
+
+
+def norm16(kind: int, x, delta, w, b=None, delta2=None, store_x: bool = True, types: int = 1, eps: float = 1e-6):
+    """Test hook (vqs_debug_norm16): the norm kernels' 16-bit forms.  x fp32 [M,D] (updated in place as the engine's stream is),
+    types 1 = RMSNorm with bf16 deltas and an fp16 operand out, 3 = LayerNorm with fp16 deltas and an fp16 operand out."""
+    lib = load_library()
+    M, D = x.shape
+    out = torch.empty(M, D, dtype=torch.float16, device=x.device)
+    rc = lib.vqs_debug_norm16(kind, x.data_ptr(), _ptr(delta), _ptr(delta2), 1 if store_x else 0, w.data_ptr(), _ptr(b), out.data_ptr(), M, D,
+                              eps, types, _stream_ptr())
+    if rc != 0:
+        raise VqsError(f"vqs_debug_norm16 failed ({rc})")
     return out
 
 

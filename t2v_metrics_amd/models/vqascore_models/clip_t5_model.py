@@ -58,8 +58,10 @@ class CLIPT5Model(VQAScoreModel):
     def __init__(self, model_name='clip-flant5-xxl', device='cuda', cache_dir=HF_CACHE_DIR, *, weights=None,
                  tokenizer=None, checkpoint: Optional[str] = None, config=None, max_pairs: int = 256,
                  max_images: int = 256, seed: int = 0, engine=None, num_workers: Optional[int] = None,
-                 vision_tower: Optional[str] = None, image_workers: str = "process"):
+                 vision_tower: Optional[str] = None, image_workers: str = "process", engine_options: Optional[Dict[str, int]] = None):
         """
+        engine_options: execution-form options of the HIP engine (include/vqs.h vqs_set_option), e.g. {'vit_fp16': 0, 'enc_fp16': 0} to run
+                    the vision tower and the T5 encoder's attention side on bf16 operands (the reference's dtype) instead of IEEE fp16.
         weights:    None -> load ``checkpoint`` (a local HF directory of safetensors); 'seeded' -> seeded random
                     weights at the exact architecture (benchmarks, tests); or a dict name -> tensor.
         tokenizer:  any object with ``tokenizer(text).input_ids`` (HF protocol); None -> the slow T5 tokenizer of
@@ -77,6 +79,7 @@ class CLIPT5Model(VQAScoreModel):
         self._weights_arg, self._tokenizer_arg, self._checkpoint = weights, tokenizer, checkpoint
         self._cfg = config if config is not None else get_config(CLIP_T5_MODELS[model_name]['config'])
         self._seed, self._engine_arg = seed, engine
+        self._engine_options = dict(engine_options or {})
         self._vision_tower_dir = vision_tower
         try:
             cores = len(os.sched_getaffinity(0))          # what this process may use (a rank's slice under taskset / the launcher)
@@ -112,7 +115,7 @@ class CLIPT5Model(VQAScoreModel):
             weights = make_seeded_weights(self.cfg, seed=self._seed, device=dev)
         else:
             weights = load_checkpoint_weights(self.cfg, self._read_checkpoint(), dev, vision_state_dict=self._read_vision_tower())
-        self.engine = VqsEngine(self.cfg, weights, device=dev)
+        self.engine = VqsEngine(self.cfg, weights, device=dev, options=self._engine_options)
 
     def _checkpoint_dir(self) -> str:
         if self._checkpoint:
@@ -317,6 +320,16 @@ class CLIPT5Model(VQAScoreModel):
         inv = torch.empty_like(order)
         inv[order] = torch.arange(n)
         sc = torch.cat(scores).float().cpu()[inv]
+        if not bool(torch.isfinite(sc).all()):
+            # Non-finite scores: with the fp16 execution options (the vision tower and the T5 encoder's attention side hold their 16-bit
+            # tensors in IEEE fp16) an activation beyond 65 504 is stored as inf and reaches the score as NaN (the library raises status
+            # bit 1 for the same condition, include/vqs.h "flags").  bf16 operands do not overflow -- say how to get them.
+            bad = int((~torch.isfinite(sc)).sum())
+            opts = {k: self.engine.get_option(k) for k in ("vit_fp16", "enc_fp16")} if hasattr(self.engine, "get_option") else {}
+            raise RuntimeError(f"{bad} of {sc.numel()} scores are not finite"
+                               + (f" with the fp16 execution options {opts}: an activation left the fp16 range -- construct the scorer with "
+                                  "engine_options={'vit_fp16': 0, 'enc_fp16': 0} to run those stages on bf16 operands" if any(opts.values()) else
+                                  ": the checkpoint's weights or the inputs are not finite"))
         if return_logprobs:
             return sc, torch.cat(lps).float().cpu()[inv]
         return sc

@@ -9,8 +9,8 @@ with the two hot loops rebuilt as real batches:
     encoded once and all M*N pairs go through the T5 passes in engine-sized batches (``model.forward_grid``).
   * reference ``batch_forward`` (score.py:143-153) iterates DataLoader batches but still scores ONE pair per model
     call.  Here every DataLoader batch is flattened into one pair list (images deduplicated) and scored in one call.
-  * with ``torch.distributed`` initialised, ``batch_forward`` shards the samples over ranks (contiguous blocks) and
-    all-gathers the scores (t2v_metrics_amd/sharding.py) -- the reference has no multi-GPU path.
+  * with ``torch.distributed`` initialised, ``forward`` shards the grid by IMAGE and ``batch_forward`` the samples over ranks
+    (contiguous blocks) and all-gathers the scores (t2v_metrics_amd/sharding.py) -- the reference has no multi-GPU path.
 
 Video inputs: as in the reference the decision is the model's ``video_mode`` (score.py:69-101): "direct" models get the
 container paths untouched (Qwen2.5-VL reads frame arrays; container decode needs decord/ffmpeg, which this image does
@@ -72,10 +72,23 @@ class Score(nn.Module):
             elif mode != "direct":
                 print("Invalid `video_mode` for the given model. Please check model's class attributes")
                 return
-        if hasattr(self.model, 'forward_grid'):
-            scores = self.model.forward_grid(images, texts, **kwargs)
+        # With torch.distributed initialised (one process per GPU, every rank making the SAME call) the grid is sharded BY IMAGE: rank r
+        # encodes and scores the rows of its contiguous block of images, so each image still goes through the vision tower once in the
+        # whole job, and one gather of fp32 rows hands every rank the [m, n] grid (the reference's row loop,
+        # score.py:104-106, is the unit that is sharded).  `shard=False` keeps the whole grid on the calling rank (ranks scoring
+        # DIFFERENT grids at the same time must say so: the gather is a collective).
+        shard = kwargs.pop("shard", True) and sharding.world()[1] > 1
+        m = len(images)
+        lo, hi = sharding.shard_range(m) if shard else (0, m)
+        mine = images[lo:hi]
+        if not mine:
+            scores = torch.zeros(0, len(texts))
+        elif hasattr(self.model, 'forward_grid'):
+            scores = self.model.forward_grid(mine, texts, **kwargs)
         else:   # plain plugin interface: one call per image, as the reference does
-            scores = torch.stack([self.model.forward([image] * len(texts), texts, **kwargs) for image in images])
+            scores = torch.stack([self.model.forward([image] * len(texts), texts, **kwargs) for image in mine])
+        if shard:                                 # every rank enters, also one that owns no image (m < world size)
+            scores = sharding.gather_rows(scores.float().cpu().reshape(hi - lo, len(texts)), m)
         return scores.to(self._out_device(), torch.float32)
 
     def batch_forward(self, dataset: List[ImageTextDict], batch_size: int = 16, num_frames: int = 4,

@@ -142,11 +142,12 @@ def test_fp16_tower_mode_is_the_same_function_with_finer_roundings(name):
     assert (hf["proj"] - ref["proj"]).abs().mean().item() < (bf["proj"] - ref["proj"]).abs().mean().item()
     # taps: the tower's 16-bit tensors are fp16, everything else what it was
     shapes = emu.tap_shapes(pix.shape[0], ids.shape[0], ids.shape[1], labels.shape[1])
-    base = EngineRoundedOracle(cfg, w, vit_fp16=False).tap_shapes(pix.shape[0], ids.shape[0], ids.shape[1], labels.shape[1])
+    base = EngineRoundedOracle(cfg, w, vit_fp16=False, enc_fp16=False).tap_shapes(pix.shape[0], ids.shape[0], ids.shape[1], labels.shape[1])
     assert set(shapes) == set(base)
     for n in shapes:
         tower16 = n.startswith("vit.") and n not in ("vit.patch_out", "vit.h0")
-        assert shapes[n][0] == base[n][0] and shapes[n][1] == (torch.float16 if tower16 else base[n][1]), n
+        enc16 = n.startswith("enc.") and n.split(".")[-1] in ("xn0", "q", "k", "v", "attn", "xn1")      # option enc_fp16 (default): the attention side
+        assert shapes[n][0] == base[n][0] and shapes[n][1] == (torch.float16 if (tower16 or enc16) else base[n][1]), n
     hi = {n: rec.pop(n) for n in list(rec) if n.endswith("#hi")}
     taps = {n: (rec[n].reshape(shapes[n][0]) if n in shapes and shapes[n][1] == "split" else rec[n].reshape(shapes[n][0]).to(shapes[n][1]) if n in shapes else rec[n])
             for n in rec}
@@ -154,7 +155,7 @@ def test_fp16_tower_mode_is_the_same_function_with_finer_roundings(name):
     report, lp = emu.forward_locked(taps, pix.float(), idx, ids, labels)
     assert all(r["max_abs"] == 0.0 for r in report.values()), {n: r for n, r in report.items() if r["max_abs"] > 0}
     assert torch.equal(lp, hf["label_logprobs"])
-    assert sum(r["mant_bits"] == 10 for r in report.values()) == 9 * cfg.vision.layers_run + 2
+    assert sum(r["mant_bits"] == 10 for r in report.values()) == 9 * cfg.vision.layers_run + 2 + 6 * cfg.t5.layers
     # one fp16 ulp planted in a tower tensor is seen as one ulp (with bf16 ulps it would read as 1/8 and pass any bound)
     t = taps["vit.0.mid"].clone()
     k = int(t.abs().float().argmax())
@@ -162,3 +163,28 @@ def test_fp16_tower_mode_is_the_same_function_with_finer_roundings(name):
     taps["vit.0.mid"] = t
     report, _ = emu.forward_locked(taps, pix.float(), idx, ids, labels)
     assert 0.99 <= report["vit.0.mid"]["max_own_ulps"] <= 1.01, report["vit.0.mid"]
+
+
+@pytest.mark.parametrize("name", ["tiny", "small"])
+def test_fp16_encoder_attention_side_mode(name):
+    """`enc_fp16=True` (the engine's option of that name, default since round 5): the encoder's norm outputs, q / k / v, probabilities and
+    attention output are IEEE fp16 and q / k / v / o / wi read fp16 weight copies; sub-layer outputs, the gated product and the encoder's
+    output stay bf16.  Roundings off = the fp32 oracle; the encoder's output is closer to fp32 than with the bf16 attention side."""
+    cfg, w, pix, idx, ids, labels = _case(name)
+    ref = Oracle(cfg, w).forward(pix.float(), idx, ids, labels, return_stages=True)
+    off = EngineRoundedOracle(cfg, w, round_fn=lambda x: x.float()).forward(pix.float(), idx, ids, labels, return_stages=True)
+    assert (ref["label_logprobs"] - off["label_logprobs"]).abs().max().item() <= 5e-5
+    e = {}
+    for flag in (False, True):
+        o = EngineRoundedOracle(cfg, w, enc_fp16=flag, classes=tuple(c for c in EngineRoundedOracle.CLASSES if c.startswith("enc.")))
+        assert o.enc_fp16 is flag and (set(o.ENC_FP16_CLASSES) <= o.half_extra) is flag
+        o.record = {}
+        out = o.forward(pix.float(), idx, ids, labels, return_stages=True)
+        e[flag] = (out["enc_out"] - ref["enc_out"]).abs().mean().item()
+        rec = o.record
+        x = rec["enc.0.xn0"]
+        assert torch.equal(x, x.half().float()) is flag or torch.equal(x, bf16_round(x))              # fp16 operand / bf16 operand
+        for nm in ("d_attn", "ff", "d_ff"):                                                           # stay bf16 either way
+            assert torch.equal(rec[f"enc.0.{nm}"], bf16_round(rec[f"enc.0.{nm}"])), nm
+        assert torch.equal(out["enc_out"], bf16_round(out["enc_out"]))
+    assert e[True] < 0.8 * e[False], e

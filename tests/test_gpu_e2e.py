@@ -335,6 +335,79 @@ def test_fp16_vision_tower_is_closer_to_fp32_than_the_bf16_tower():
     assert float(err["fp16"].max()) <= 2.5e-2 and float(err["fp16"].mean()) <= float(err["bf16"].mean()) * 1.25 + 1e-4, err   # CPU emulation of this case: 3.6e-3 vs 4.8e-3
 
 
+def test_fp16_encoder_attention_side_is_closer_to_fp32_than_the_bf16_encoder():
+    """Option enc_fp16 (round 5, default 1; 0 = the bf16 encoder of rounds 1-4): the T5 encoder's norm outputs, q / k / v, probabilities and
+    attention output in IEEE fp16, q|k|v / o / wi on fp16 weight copies; sub-layer outputs, the gated product, wo and the encoder's output
+    stay bf16.  Same function: both agree with the fp32 oracle; the encoder's OUTPUT (what the decoder reads) is closer to the oracle's
+    with the fp16 attention side; bitwise repeatable; switching back restores the bf16 encoder's bits on the same handle; a GEMM form
+    without fp16 instantiations refuses the option by name."""
+    from oracle.clip_t5_oracle import Oracle
+    from t2v_metrics_amd.engine import VqsEngine, VqsError
+    cfg = get_config("small")
+    w = make_seeded_weights(cfg, seed=37, device="cpu", lm_head_gain=4.0)
+    pix, img_index, ids, labels = _inputs(cfg, 16, 5, 24, 2, seed=15)
+    o = Oracle(cfg, w)
+    ref = o.forward(pix.float(), img_index, ids, labels, return_stages=True)
+    eng = VqsEngine(cfg, w, device="cuda:0")
+    out, enc = {}, {}
+    try:
+        assert eng.get_option("enc_fp16") == 1
+        feats = eng.encode_images(pix.cuda())
+        for mode, val in (("bf16", 0), ("fp16", 1), ("fp16-b", 1), ("bf16-again", 0)):
+            eng.set_option("enc_fp16", val)
+            lp, _ = eng.score(feats, img_index, ids, labels)
+            torch.cuda.synchronize()
+            out[mode], enc[mode] = lp.cpu(), eng.stage("enc_out").float().cpu().clone()
+        eng.set_option("enc_fp16", 1)
+        eng.set_option("gemm_variant", 11)
+        with pytest.raises(VqsError, match="enc_fp16"):
+            eng.score(feats, img_index, ids, labels)
+    finally:
+        eng.close()
+    assert torch.equal(out["fp16"], out["fp16-b"]) and torch.equal(enc["fp16"], enc["fp16-b"])
+    assert torch.equal(out["bf16"], out["bf16-again"]) and torch.equal(enc["bf16"], enc["bf16-again"])
+    assert not torch.equal(enc["fp16"], enc["bf16"])
+    # the oracle's encoder output on the ENGINE's own image features would isolate the encoder; the features differ from the oracle's by the
+    # tower's noise in both legs alike, so the comparison of the two legs against the oracle's encoder output is still like for like
+    mask = ref["enc_mask"].reshape(-1)
+    eerr = {k: float((enc[k].reshape(ref["enc_out"].shape[0] * ref["enc_out"].shape[1], -1) - ref["enc_out"].reshape(-1, ref["enc_out"].shape[-1]))[mask].abs().mean())
+            for k in ("bf16", "fp16")}
+    err = {k: (out[k] - ref["label_logprobs"]).abs() for k in ("bf16", "fp16")}
+    _record("fp16-encoder-attention-side", {"enc_out_mean_abs_err": eerr, "logp": {k: {"max": float(e.max()), "mean": float(e.mean())} for k, e in err.items()}})
+    assert eerr["fp16"] < 0.9 * eerr["bf16"], eerr                 # two of the encoder's bf16 classes remain (deltas, FFN product) + the bf16 output itself
+    assert float(err["fp16"].max()) <= 2.5e-2 and float(err["fp16"].mean()) <= float(err["bf16"].mean()) * 1.25 + 1e-4, err
+
+
+@pytest.mark.parametrize("stack,option", [("vit", "vit_fp16"), ("enc", "enc_fp16")])
+def test_an_activation_beyond_the_fp16_range_raises_the_status_bit_and_names_the_option(stack, option):
+    """v_cvt_pk_f16_f32 stores +-inf for |x| >= 65 520 without a trace.  A planted activation of ~1e5 (a norm gain of the
+    first layer scaled up) must (a) set bit 1 of the pass's status word, (b) make the scores non-finite rather than silently wrong,
+    (c) make the model wrapper raise and name the fp16 options -- and with that stage on bf16 operands the same weights score finitely."""
+    import t2v_metrics_amd as t2v
+    from t2v_metrics_amd.engine import VqsEngine
+    from tests.test_host_api import FakeTokenizer
+    cfg = get_config("small")
+    w = make_seeded_weights(cfg, seed=41, device="cpu")
+    key = "vision.encoder.layers.0.layer_norm1.weight" if stack == "vit" else "encoder.block.0.layer.0.layer_norm.weight"
+    w[key] = (w[key].float() * 0 + 1.0e5).to(torch.bfloat16)      # the norm's output (an fp16 tensor under the option) is ~1e5 x a unit-variance row
+    pix, img_index, ids, labels = _inputs(cfg, 4, 2, 12, 2, seed=16)
+    eng = VqsEngine(cfg, w, device="cuda:0")
+    try:
+        lp, sc = eng.score(eng.encode_images(pix.cuda()), img_index, ids, labels)
+        torch.cuda.synchronize()
+        assert int(eng.stage("flags")[0]) & 2 and not bool(torch.isfinite(sc).all())
+        eng.set_option(option, 0)
+        lp, sc = eng.score(eng.encode_images(pix.cuda()), img_index, ids, labels)
+        torch.cuda.synchronize()
+        assert int(eng.stage("flags")[0]) == 0 and bool(torch.isfinite(sc).all()) and bool(torch.isfinite(lp).all())
+    finally:
+        eng.close()
+    model = t2v.VQAScore(model="clip-flant5-xl", device="cuda:0", config=cfg, weights=w, tokenizer=FakeTokenizer(cfg.t5.vocab), image_workers="thread").model
+    model.load_images = lambda paths: pix[: len(paths)].cuda()
+    with pytest.raises(RuntimeError, match="fp16 range.*enc_fp16"):
+        model.score_pairs(["a", "b"], [0, 1], ["one caption", "another caption"], ["Yes", "Yes"])
+
+
 def test_fused_residual_rmsnorm_matches_separate_kernels():
     """Option fused_norm=1: the T5 encoder's o / wo GEMM epilogues update the residual stream and hand the next RMSNorm's
     operand + row sums of squares to the consuming GEMM (no norm kernel).  Default (0): separate add+norm kernels.
@@ -347,7 +420,8 @@ def test_fused_residual_rmsnorm_matches_separate_kernels():
     ref = Oracle(cfg, w).forward(pix.float(), img_index, ids, labels)["label_logprobs"]
     out = {}
     for mode in ("0", "1", "1b"):
-        eng = VqsEngine(cfg, w, device="cuda:0", options={"fused_norm": int(mode[0])})
+        # the fused epilogue runs the 8-wave bf16 kernels: the fp16 attention side (option enc_fp16, quad form only) is off for both legs
+        eng = VqsEngine(cfg, w, device="cuda:0", options={"fused_norm": int(mode[0]), "enc_fp16": 0})
         lp, _ = eng.score(eng.encode_images(pix.cuda()), img_index, ids, labels)
         torch.cuda.synchronize()
         out[mode] = lp.cpu()

@@ -421,3 +421,135 @@ def test_relpos_bucket_host_function_matches_golden(eng, golden_dir):
     for r, vb, vc in zip(g["relative_position"], g["bidirectional"], g["causal"]):
         assert eng.relpos_bucket(int(r), True) == int(vb)
         assert eng.relpos_bucket(int(r), False) == int(vc)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# fp16 instantiations (options vit_fp16 / enc_fp16): the same kernels on IEEE fp16 fragments.  In whole passes they only ever see the
+# tower's / the encoder's own shapes; here: shapes of their own, edge tiles, ragged key lengths, every epilogue they carry
+# (VERDICT r4 item 5).  Reference = fp32 torch on the SAME fp16 inputs; the result is held to fp16 (ftype 1) or bf16 (ftype 2) rounding.
+# ---------------------------------------------------------------------------------------------------------------------------
+def _randn_f16(*shape, seed, scale=1.0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return (torch.randn(*shape, device="cuda", generator=g) * scale).to(torch.float16)
+
+
+@pytest.mark.parametrize("M,N,K,epi,S,H", [
+    (300, 264, 192, 0, 0, 0),               # ragged M and N edges inside one tile
+    (2065, 1024, 1024, 0, 0, 0),
+    (33000 - 7, 2048 - 8, 128, 0, 0, 0),    # many tiles per workgroup, ragged edges in the middle of a run
+    (9000, 640, 192, 1, 0, 0),              # quick_gelu + bias
+    (5000, 768, 256, 2, 0, 0),              # erf-GELU + bias
+    (608 * 12, 3 * 1024, 192, 6, 608, 16),  # head-major scatter, sample boundaries inside tiles (T5 encoder: no bias)
+    (577 * 9, 3 * 1024, 128, 6, 577, 16),   # ... with the ViT's odd sequence length
+    (131072, 512, 2048, 0, 0, 0)])          # long K
+def test_gemm_fp16_operands_fp16_result(eng, M, N, K, epi, S, H):
+    A = _randn_f16(M, K, seed=81)
+    W = _randn_f16(N, K, seed=82, scale=K ** -0.5)
+    bias = randn_bf16(N, seed=83) if epi != 6 else None
+    out = eng.gemm(A, W, epi, bias=bias, S=S, H=H, variant=3, ftype=1)
+    assert out.dtype == torch.float16
+    assert torch.equal(out, eng.gemm(A, W, epi, bias=bias, S=S, H=H, variant=3, ftype=1))          # repeatable
+    ref = A.float() @ W.float().t() + (bias.float() if bias is not None else 0.0)
+    ref = quick_gelu(ref) if epi == 1 else (gelu_erf(ref) if epi == 2 else ref)
+    if epi == 6:
+        ref = ref.reshape(M // S, S, N // (H * 64), H, 64).permute(2, 0, 3, 1, 4)                   # [q|k|v, B, H, S, 64]
+    # an fp16 result: 2^-11 relative rounding + fp32 summation order; three bits tighter than the bf16 kernels' bound
+    assert_close(out, ref, 2.5e-3, 1.5e-3, f"gemm f16/f16 epi {epi} {M}x{N}x{K}")
+    # the bf16 kernel on the same VALUES rounded to bf16 cannot be this close: the test would pass on a silently-bf16 launch otherwise
+    if epi == 0 and K >= 1024:
+        coarse = eng.gemm(A.to(torch.bfloat16), W.to(torch.bfloat16), 0, bias=bias, variant=3)
+        assert (coarse.float() - ref).abs().mean() > 3 * (out.float() - ref).abs().mean()
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(300, 264, 192, 0), (33000 - 7, 2048 - 8, 128, 0), (20000, 2048, 1024, 0),
+                                       (16384, 8192, 256, 5), (9000 - 3, 1024, 2048, 5), (608 * 9, 5120 * 2, 2048, 5)])
+def test_gemm_fp16_operands_bf16_result(eng, M, N, K, epi):
+    """gemm_f16b_quad: fp16 operands, bf16 result -- the T5 encoder's o projection (plain) and gated wi of option enc_fp16."""
+    A = _randn_f16(M, K, seed=84)
+    if epi == 5:
+        F = N // 2
+        w0, w1 = _randn_f16(F, K, seed=85, scale=K ** -0.5), _randn_f16(F, K, seed=86, scale=K ** -0.5)
+        W = interleave_gate(w0, w1)
+        ref = gelu_new(A.float() @ w0.float().t()) * (A.float() @ w1.float().t())
+    else:
+        W = _randn_f16(N, K, seed=85, scale=K ** -0.5)
+        ref = A.float() @ W.float().t()
+    out = eng.gemm(A, W, epi, variant=3, ftype=2)
+    assert out.dtype == torch.bfloat16 and torch.equal(out, eng.gemm(A, W, epi, variant=3, ftype=2))
+    assert_close(out, ref, 2e-2, 1e-2, f"gemm f16/bf16 epi {epi} {M}x{N}x{K}")
+    # exactly the bf16 rounding of the fp16-operand product: against the fp16-result kernel on the same operands (same MFMAs, same k
+    # order, another pack) the plain epilogue must agree to the last bit after rounding that result's fp32 ... it cannot be read back,
+    # so instead: the result must be within ONE bf16 ulp of the fp32 reference wherever the reference is not at a rounding boundary
+    if epi == 0:
+        err = (out.float() - ref).abs()
+        ulp = torch.ldexp(torch.ones_like(ref), torch.frexp(ref).exponent - 8)
+        assert float((err > 0.51 * ulp + 1e-6 * ref.abs().max()).float().mean()) < 2e-3
+
+
+def test_fp16_gemm_refuses_what_it_has_no_kernel_for(eng):
+    A, W = _randn_f16(512, 256, seed=87), _randn_f16(512, 256, seed=88)
+    from t2v_metrics_amd.engine import VqsError
+    with pytest.raises(VqsError):
+        eng.gemm(A, W, 5, variant=3, ftype=1)          # no fp16 tensor leaves a gated FFN
+    with pytest.raises(VqsError):
+        eng.gemm(A, W, 1, variant=3, ftype=2)          # fp16 in / bf16 out: plain and gated only
+    with pytest.raises(VqsError):
+        eng.gemm(A, W, 0, variant=11, ftype=1)         # the 8-wave forms have no fp16 instantiation
+    with pytest.raises(VqsError):
+        eng.gemm(A[:, :64].contiguous(), W[:, :64].contiguous(), 0, variant=3, ftype=1)   # K < 128 is not a quad launch
+
+
+@pytest.mark.parametrize("B,H,S,use_bias,ragged", [(2, 3, 577, False, False), (3, 2, 608, True, True), (2, 4, 333, True, False),
+                                                   (3, 2, 200, False, True), (1, 2, 64, True, False), (4, 1, 648, True, True)])
+def test_attention_fp16(eng, B, H, S, use_bias, ragged):
+    """attn_fwd_dma_f16_kernel<false> (vision tower) and <true> (T5 encoder of option enc_fp16: position-bias table + key mask)."""
+    q = _randn_f16(B, H, S, 64, seed=91, scale=0.5 if use_bias else 1.0)
+    k = _randn_f16(B, H, S, 64, seed=92, scale=0.5 if use_bias else 1.0)
+    v = _randn_f16(B, H, S, 64, seed=93)
+    scale = 1.0 if use_bias else 0.125
+    table = bias = key_len = None
+    if use_bias:
+        table = torch.randn(H, 2 * S - 1, device="cuda", generator=torch.Generator(device="cuda").manual_seed(94))
+        idx = (torch.arange(S)[None, :] - torch.arange(S)[:, None] + S - 1).to("cuda")
+        bias = table[:, idx]
+    if ragged:
+        key_len = torch.tensor([S, max(1, S // 3), S - 1][:B] + [S] * max(0, B - 3), dtype=torch.int32, device="cuda")
+    ref = attention_ref(q, k, v, scale, bias, key_len)
+    out = eng.attention(q, k, v, scale, bias_table=table, key_len=key_len)
+    assert out.dtype == torch.float16 and torch.equal(out, eng.attention(q, k, v, scale, bias_table=table, key_len=key_len))
+    assert_close(out, ref, 4e-3, 3e-3, f"attention fp16 B{B} H{H} S{S} bias={use_bias} ragged={ragged}")   # P is an fp16 tensor: 8 x below the bf16 kernel's bound
+    coarse = eng.attention(q.to(torch.bfloat16), k.to(torch.bfloat16), v.to(torch.bfloat16), scale, bias_table=table, key_len=key_len)
+    assert (coarse.float() - ref).abs().mean() > 2.5 * (out.float() - ref).abs().mean()
+
+
+@pytest.mark.parametrize("M,D", [(9, 96), (257, 1024), (130, 2048), (33, 4096)])
+def test_norms_with_fp16_operand_out(eng, M, D):
+    """RMSNorm with bf16 deltas in and an fp16 operand out (T5 encoder, option enc_fp16): every add mode, against fp32 torch and -- the
+    stream -- bit for bit against the bf16-output kernel (same additions, only the output's pack differs); LayerNorm with fp16 deltas
+    (vision tower)."""
+    g = torch.Generator(device="cuda").manual_seed(95)
+    x = torch.randn(M, D, device="cuda", generator=g) * 3.0 + 0.5
+    w, b = randn_bf16(D, seed=96), randn_bf16(D, seed=97)
+    d1 = torch.randn(M, D, device="cuda", generator=g).to(torch.bfloat16)
+    d2 = torch.randn(M, D, device="cuda", generator=g).to(torch.bfloat16)
+    rms = lambda t: w.float() * (t * torch.rsqrt(t.pow(2).mean(-1, keepdim=True) + 1e-6))
+    assert_close(eng.norm16(0, x.clone(), None, w, types=1), rms(x), 1.5e-3, 1e-3, "rmsnorm -> fp16")
+    x1 = x.clone()
+    out = eng.norm16(0, x1, d1, w, types=1)
+    xb = x.clone()
+    eng.rmsnorm(xb, w, 1e-6, delta=d1)
+    assert torch.equal(x1, xb)                                                       # the stream: the bf16-output kernel's bits
+    assert_close(out, rms(x + d1.float()), 1.5e-3, 1e-3, "rmsnorm + add -> fp16")
+    x2 = x.clone()
+    out = eng.norm16(0, x2, d1, w, types=1, store_x=False)
+    assert torch.equal(x2, x) and torch.equal(out, eng.norm16(0, x.clone(), d1, w, types=1))   # not stored: same operand, stream untouched
+    x3 = x.clone()
+    out = eng.norm16(0, x3, d1, w, delta2=d2, types=1)
+    assert_close(x3, (x + d1.float()) + d2.float(), 1e-6, 1e-6, "two pending deltas")
+    assert_close(out, rms((x + d1.float()) + d2.float()), 1.5e-3, 1e-3, "rmsnorm + two deltas -> fp16")
+    h1 = d1.to(torch.float16)
+    x4 = x.clone()
+    out = eng.norm16(1, x4, h1, w, b=b, types=3, eps=1e-5)
+    xs = x + h1.float()
+    assert_close(x4, xs, 1e-6, 1e-6, "layernorm fp16 delta write-back")
+    assert_close(out, torch.nn.functional.layer_norm(xs, (D,), w.float(), b.float(), 1e-5), 1.5e-3, 1e-3, "layernorm fp16")

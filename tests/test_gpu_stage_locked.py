@@ -38,7 +38,8 @@ def run_stage_locked(cfg, w, eng, pix, idx, ids, labels, tag, window=None, vit_f
     if vit_fp16 is None:
         vit_fp16 = bool(eng.get_option("vit_fp16"))          # the engine's own setting (default: fp16 tower)
     assert vit_fp16 == bool(eng.get_option("vit_fp16"))
-    emu = Oracle(cfg, w_cpu, emulate="engine", vit_fp16=vit_fp16)
+    # enc_fp16 (round 5, default 1): likewise for the encoder's attention side -- the oracle follows the engine's setting
+    emu = Oracle(cfg, w_cpu, emulate="engine", vit_fp16=vit_fp16, enc_fp16=bool(eng.get_option("enc_fp16")))
     B, L = ids.shape
     T = labels.shape[1]
     if window is None:
@@ -145,11 +146,16 @@ def test_every_launch_matches_the_oracle_with_the_fp16_vision_tower(name, B, n_i
     pix, img_index, ids, labels = _inputs(cfg, B, n_img, L, T, seed=100 + B)
     eng = VqsEngine(cfg, w, device="cuda:0")
     try:
-        assert eng.get_option("vit_fp16") == 1 and eng.get_option("dec_precise") == 1          # what ships
+        assert eng.get_option("vit_fp16") == 1 and eng.get_option("dec_precise") == 1 and eng.get_option("enc_fp16") == 1          # what ships
         report, _ = run_stage_locked(cfg, w, eng, pix, img_index, ids, labels, f"{name}-B{B}-L{L}-T{T}-gain{gain}-vit_fp16")
-        assert sum(r["mant_bits"] == 10 for r in report.values()) == 9 * cfg.vision.layers_run + 2
-        eng.set_option("vit_fp16", 0)                                                         # ... and the bf16 tower of rounds 1-3, same handle
+        # fp16 tensors: 9 per tower layer + feature select + projector hidden; 6 per encoder layer (both norm outputs, q, k, v, attention output)
+        assert sum(r["mant_bits"] == 10 for r in report.values()) == 9 * cfg.vision.layers_run + 2 + 6 * cfg.t5.layers
+        eng.set_option("vit_fp16", 0)                                                         # ... the bf16 tower of rounds 1-3, same handle
         report, _ = run_stage_locked(cfg, w, eng, pix, img_index, ids, labels, f"{name}-B{B}-L{L}-T{T}-gain{gain}-vit_bf16")
+        assert sum(r["mant_bits"] == 10 for r in report.values()) == 6 * cfg.t5.layers
+        assert all(n.startswith("enc.") for n, r in report.items() if r["mant_bits"] == 10)
+        eng.set_option("enc_fp16", 0)                                                         # ... and the bf16 encoder of rounds 1-4
+        report, _ = run_stage_locked(cfg, w, eng, pix, img_index, ids, labels, f"{name}-B{B}-L{L}-T{T}-gain{gain}-all_bf16")
         assert not any(r["mant_bits"] == 10 for r in report.values())
     finally:
         eng.close()

@@ -83,8 +83,16 @@ def test_bench_parity_sample_table_on_an_engine_double():
     truth = Oracle(cfg, w).forward(pix3, torch.arange(3), ids, labels, return_stages=True)
 
     class Eng:
+        scored = 0
+
+        def encode_images(self, pixels):
+            return pixels
+
+        def score(self, feats, img_index, ids_, labels_):                   # parity_sample re-scores the job it tabulates
+            self.scored += 1
+
         def stage(self, name):
-            assert name == "logits"
+            assert name == "logits" and self.scored
             return truth["logits"] + 1e-3 * torch.sign(truth["logits"])      # a known perturbation
 
     job = (pix3.to(torch.bfloat16), torch.arange(3), ids.int(), labels.int(), None)
@@ -96,3 +104,13 @@ def test_bench_parity_sample_table_on_an_engine_double():
     assert g4["max"] > g1["max"]                                             # the same logit error weighs more under a peaked head
     lr = Oracle.label_logprobs(truth["logits"] * 4.0, labels)
     assert abs(g4["logp_yes_range"][0] - float(lr[:, 0].min())) < 1e-3
+    assert out["bound"] == bench.DLOGP_BOUND == 1e-3 and g1["pairs_over_bound"] == sum(x > 1e-3 for x in g1["per_pair"])
+    assert out["encoder_len_range"][0] <= out["encoder_len_range"][1] and g1["yes_token_max"] <= g1["max"]
+    # jobs of different lengths: the shortest and the longest are tabulated, half of the pairs each, and merged
+    eng = Eng()
+    short = (job[0], job[1], ids.int()[:, : ids.shape[1]], job[3], None)
+    longer = (job[0], job[1], torch.cat([ids.int(), torch.zeros(3, 2, dtype=torch.int32)], 1), job[3], None)
+    table, _ = bench.parity_jobs(cfg, w, eng, [short, longer, longer], 4)
+    assert table["pairs"] == 4 and len(table["gains"]["1"]["per_job"]) == 2 and len(table["gains"]["1"]["per_pair"]) == 4
+    one, _ = bench.parity_jobs(cfg, w, eng, [short, short], 2)
+    assert one["pairs"] == 2 and "per_job" not in one["gains"]["1"]

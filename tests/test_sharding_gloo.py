@@ -55,6 +55,18 @@ def _worker(rank, ws, port, tmp, out_path):
         assert n_scored == (hi - lo) * 2              # each rank scored only its own block
         if rank == 0:
             np.save(out_path, out.numpy())
+        # the M x N grid call under sharding (by IMAGE -- each rank encodes only its own images, one gather of rows)
+        for m_img, tag in ((3, "grid3"), (1, "grid1")):           # 1 image on 2 ranks: rank 1 owns nothing and still joins the gather
+            eng.encode_calls.clear(); eng.score_calls.clear()
+            texts = [f"text {j}" for j in range(4)]
+            grid = s(images=imgs[:m_img], texts=texts)
+            assert grid.shape == (m_img, 4)
+            lo, hi = sharding.shard_range(m_img)
+            assert sum(c[0] for c in eng.encode_calls) == hi - lo, (eng.encode_calls, lo, hi)      # this rank's engine saw only its images
+            assert sum(c[0][0] for c in eng.score_calls) == (hi - lo) * 4
+            np.save(out_path.replace(".npy", f"_{tag}_r{rank}.npy"), grid.numpy())
+        whole = s(images=imgs, texts=["a", "b"], shard=False)     # opt-out: the whole grid on the calling rank, no collective
+        assert whole.shape == (3, 2) and sum(c[0] for c in eng.encode_calls) >= 3
     finally:
         dist.destroy_process_group()
 
@@ -79,3 +91,7 @@ def test_batch_forward_sharded_over_two_gloo_ranks(tmp_path):
     dataset = [{"images": [imgs[k % len(imgs)]], "texts": [f"caption number {k}", f"other {k}"]} for k in range(7)]
     single = s.batch_forward(dataset, batch_size=3).numpy()
     assert np.array_equal(sharded, single)
+    for m_img, tag in ((3, "grid3"), (1, "grid1")):
+        want = s(images=imgs[:m_img], texts=[f"text {j}" for j in range(4)]).numpy()
+        for r in range(2):                                        # every rank holds the whole gathered grid, equal to the single-process one
+            assert np.array_equal(np.load(out_path.replace(".npy", f"_{tag}_r{r}.npy")), want), (tag, r)
