@@ -388,8 +388,17 @@ def test_an_activation_beyond_the_fp16_range_raises_the_status_bit_and_names_the
     from tests.test_host_api import FakeTokenizer
     cfg = get_config("small")
     w = make_seeded_weights(cfg, seed=41, device="cpu")
-    key = "vision.encoder.layers.0.layer_norm1.weight" if stack == "vit" else "encoder.block.0.layer.0.layer_norm.weight"
-    w[key] = (w[key].float() * 0 + 1.0e5).to(torch.bfloat16)      # the norm's output (an fp16 tensor under the option) is ~1e5 x a unit-variance row
+    if stack == "vit":
+        # eight units of layer 0's FFN get a bias of 1e5: the FFN product (an fp16 tensor under the option) holds 1e5 there -- inf in fp16, an
+        # ordinary number in bf16, and later LayerNorms bring the stream back to scale.  (Not a norm gain: q.k of 1e10 leaves the range in
+        # which the bias-free softmax's single FMA 2^(s c - m) is meaningful in ANY operand type.)
+        key = "vision.encoder.layers.0.mlp.fc1.bias"
+        b = w[key].float().clone()
+        b[:8] = 1.0e5
+        w[key] = b.to(torch.bfloat16)
+    else:
+        key = "encoder.block.0.layer.0.layer_norm.weight"
+        w[key] = (w[key].float() * 0 + 1.0e5).to(torch.bfloat16)  # the norm's output (an fp16 tensor under the option) is ~1e5 x a unit-variance row
     pix, img_index, ids, labels = _inputs(cfg, 4, 2, 12, 2, seed=16)
     eng = VqsEngine(cfg, w, device="cuda:0")
     try:

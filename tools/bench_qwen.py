@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--cpu-samples", type=int, default=0)
     ap.add_argument("--decode-steps", type=int, default=0, help="also time N cached decode steps behind one prefill (KV cache)")
+    ap.add_argument("--parity-samples", type=int, default=0, help="|delta log P(answer)| of the first N samples against the fp32 oracle evaluated "
+                    "in torch fp32 on the device (oracle/qwen25vl_oracle.py; 8 samples: ~3 s)")
     args = ap.parse_args()
     from t2v_metrics_amd.qwen.engine import QwenEngine
     cfg = get_qwen_config(args.model)
@@ -127,6 +129,34 @@ def main():
         out["cpu_baseline"] = {"value": n / dtc, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
                                "sample": f"first {n} sample(s) of the batch, fp32 oracle ({dtc:.1f} s)",
                                "max_abs_dlogp_hip_vs_oracle": float((lp - lr).abs().max())}
+    if args.parity_samples > 0:
+        # BASELINE.md section 3's criterion for this row: HIP vs fp32 truth on the SAME inputs.  Truth = the oracle's code in torch fp32 on
+        # the device (the host cores need minutes per 7B-size sample); test infrastructure, after the timed region.
+        from oracle.qwen25vl_oracle import QwenOracle
+        n = min(args.parity_samples, B)
+        t0 = time.perf_counter()
+        o = QwenOracle(cfg, eng._weights, device=dev)
+        refs = []
+        with torch.device(dev):
+            for s0 in range(0, n, 4):
+                e0 = min(s0 + 4, n)
+                refs.append(o.forward(ids[s0:e0].to(dev), mask[s0:e0].to(dev), px[s0 * n_patches: e0 * n_patches].float(), grids[s0:e0]).float())
+        torch.cuda.synchronize()
+        t_truth = time.perf_counter() - t0
+        lr = torch.log_softmax(torch.cat(refs), -1)
+        lh = torch.log_softmax(logits[:n].float(), -1)
+        d_ans = (lh[:, yes_id] - lr[:, yes_id]).abs()
+        top5 = lr.topk(5, -1).indices
+        d_top = (lh.gather(-1, top5) - lr.gather(-1, top5)).abs().max(-1).values
+        BOUND = 1e-3
+        out["parity"] = {"pairs": n, "bound": BOUND, "truth": "oracle/qwen25vl_oracle.py evaluated in torch fp32 on the device (%.1f s)" % t_truth,
+                         "gains": {"1": {"max": float(d_ans.max()), "mean": float(d_ans.mean()), "yes_token_max": float(d_ans.max()),
+                                         "pairs_over_bound": int((d_ans > BOUND).sum()), "per_pair": [round(float(x), 6) for x in d_ans],
+                                         "top5_max": float(d_top.max()), "top5_mean": float(d_top.mean()),
+                                         "logp_yes_range": [round(float(lr[:, yes_id].min()), 3), round(float(lr[:, yes_id].max()), 3)]}},
+                         "status": ("within the 1e-3 bound" if float(d_ans.max()) <= BOUND else
+                                    "ABOVE the 1e-3 bound: this row's language model and tower hold every 16-bit tensor in bf16 (what the checkpoint was "
+                                    "trained in); the attribution of what is left is profiles/r5_qwen_error_attribution.md")}
     print(json.dumps(out), flush=True)
 
 

@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""Real-checkpoint verifier: for a maintainer who has `zhiqiulin/clip-flant5-xxl` (or -xl) on disk.
+
+Everything in this repository is pinned against seeded weights, because neither the checkpoints nor `spiece.model` are reachable from
+the build container ("parity unpinned").  This tool closes that gap on a box that has them: it scores the reference's own
+example -- the four images of `images/0/` x the four captions of the v3.0 README (/root/reference/V_3.0_README.md:122,123,178,179;
+the M x N call of :110-124) -- through the REAL tokenizer and the REAL weights, three ways, and prints BASELINE.md section 3's table:
+
+  (i)   fp32 truth             the HF modules in fp32 on the host cores (oracle/hf_reference.py, dtype float32)
+  (ii)  reference as shipped   the same modules cast to bf16 (mm_utils.py:228) -- what `t2v_metrics.VQAScore(model='clip-flant5-xxl')` runs
+  (iii) this repository        the HIP engine on the MI355X (no CPU fallback: without a device this row is reported as NOT RUN)
+
+per pair: log P("Yes") and the score exp(mean label log-prob) (the v3.0 forward's return value); then |(iii) - (i)|,
+|(ii) - (i)|, |(iii) - (ii)| as max / mean, the verdict against north_star's 1e-3, the shape / range checks of the reference's smoke test
+(/root/reference/test.py:106-144), and the ids the tokenizer gives the answer template (the id of `_Yes` -- 2163 [RECALLED] -- is printed
+so that the bench's synthetic label can be checked against it).  All three legs go through the SAME host glue (this package's
+VQAScore wrapper: prompt formatting, `t5_tokenizer_image_token`, `expand2square` + CLIP preprocessing), which tests/test_reference_glue.py
+holds equal to the reference's own files.
+
+    python tools/verify_checkpoint.py --checkpoint /data/clip-flant5-xxl [--vision-tower /data/clip-vit-large-patch14-336]
+                                      [--model clip-flant5-xxl] [--images a.png b.jpg ...] [--texts "caption" ...] [--skip-fp32] [--json out.json]
+
+Loader semantics matched: /root/reference/t2v_metrics/models/vqascore_models/mm_utils.py:198-241 (slow T5 tokenizer, bf16 cast, the CLIP
+tower loaded separately).  TEST INFRASTRUCTURE: legs (i) and (ii) are the checker; nothing here is imported by the product path.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+import warnings
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+CAPTIONS = ["The brown dog chases the black dog around the tree.",           # V_3.0_README.md:178,179,122,123
+            "Two cats sit at the window, the blue one intently watching the rain, the red one curled up asleep.",
+            "someone talks on the phone angrily while another person sits happily",
+            "someone talks on the phone happily while another person sits angrily"]
+IMAGES = ["DALLE3.png", "DeepFloyd.jpg", "Midjourney.jpg", "SDXL.jpg"]        # images/0/ of the reference tree
+BOUND = 1e-3                                                                   # north_star: |delta log P("Yes")| vs the reference CPU path
+
+
+def default_images():
+    for base in (os.path.join(os.getcwd(), "images", "0"), "/root/reference/images/0"):
+        paths = [os.path.join(base, f) for f in IMAGES]
+        if all(os.path.exists(p) for p in paths):
+            return paths
+    raise SystemExit("no --images given and the reference's images/0/{%s} are not under ./images/0 or /root/reference/images/0" % ",".join(IMAGES))
+
+
+def run(checkpoint, vision_tower=None, model="clip-flant5-xxl", images=None, texts=None, device=None, skip_fp32=False, config=None,
+        tokenizer=None, out=sys.stdout):
+    """-> report dict.  `config` / `tokenizer`: test hooks (a tiny ClipT5Config and an in-test SentencePiece model)."""
+    warnings.filterwarnings("ignore")
+    import t2v_metrics_amd as t2v
+    from oracle.hf_reference import HFEngine
+    from t2v_metrics_amd.config import get_config
+    from t2v_metrics_amd.models.vqascore_models.clip_t5_model import CLIP_T5_MODELS, default_answer_template, default_question_template
+    from t2v_metrics_amd.weights import load_checkpoint_weights, read_checkpoint_dir
+
+    cfg = config if config is not None else get_config(CLIP_T5_MODELS[model]["config"])
+    images = list(images) if images else default_images()
+    texts = list(texts) if texts else list(CAPTIONS)
+    say = lambda *a: print(*a, file=out, flush=True)
+    say(f"# checkpoint {checkpoint}" + (f" + vision tower {vision_tower}" if vision_tower else "") + f"; {cfg.name}; {len(images)} images x {len(texts)} texts")
+    t0 = time.perf_counter()
+    vsd = read_checkpoint_dir(vision_tower) if vision_tower else None
+    w = load_checkpoint_weights(cfg, read_checkpoint_dir(checkpoint), "cpu", vision_state_dict=vsd)
+    say(f"# {len(w)} tensors read and cast to bf16 (mm_utils.py:228) in {time.perf_counter() - t0:.1f} s")
+    if tokenizer is None:
+        from transformers import AutoTokenizer
+        tokenizer = AutoTokenizer.from_pretrained(checkpoint, use_fast=False, model_max_length=2048)     # mm_utils.py:198
+    # the tower may live in its own directory, which the model wrapper resolves itself when it LOADS; here the weights are handed over
+    common = dict(model=model, cache_dir=os.path.dirname(checkpoint) or ".", tokenizer=tokenizer, weights=w, config=config)
+
+    def grid(scorer):
+        m = scorer.model
+        pair_image = [i for i in range(len(images)) for _ in texts]
+        q = [default_question_template.format(t) for _ in images for t in texts]
+        a = [default_answer_template.format(t) for _ in images for t in texts]
+        sc, lp = m.score_pairs(images, pair_image, q, a, return_logprobs=True)
+        return sc.reshape(len(images), len(texts)), lp.reshape(len(images), len(texts), -1)
+
+    rep = {"checkpoint": checkpoint, "model": cfg.name, "images": images, "texts": texts, "legs": {}, "bound": BOUND}
+    ans_ids = tokenizer(default_answer_template).input_ids
+    rep["answer_template_ids"] = [int(x) for x in ans_ids]
+    say(f"# answer template {default_answer_template!r} -> label ids {rep['answer_template_ids']}  (the bench's synthetic labels are [2163, 1]: "
+        f"`_Yes`, </s> [RECALLED]; {'MATCH' if rep['answer_template_ids'] == [2163, 1] else 'differ -- compare'})")
+    legs = []
+    if not skip_fp32:
+        legs.append(("(i) fp32 truth: HF modules, float32, host cores", lambda: t2v.VQAScore(device="cpu", engine=HFEngine(cfg, w, torch.float32), **common)))
+    legs.append(("(ii) reference as shipped: HF modules, bf16, host cores", lambda: t2v.VQAScore(device="cpu", engine=HFEngine(cfg, w, torch.bfloat16), **common)))
+    dev = device if device is not None else ("cuda:0" if torch.cuda.is_available() else None)
+    if dev is not None and str(dev).startswith("cuda"):
+        legs.append(("(iii) this repository: HIP engine on " + torch.cuda.get_device_name(0), lambda: t2v.VQAScore(device=dev, **common)))
+    else:
+        rep["legs"]["(iii)"] = {"not_run": "no HIP device on this box -- the product path has no CPU route (run this tool on the MI355X)"}
+        say("# (iii) NOT RUN: no HIP device on this box; the product path has no CPU route")
+    res = {}
+    for name, make in legs:
+        t0 = time.perf_counter()
+        scorer = make()
+        t_load = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        with torch.inference_mode():
+            sc, lp = grid(scorer)
+        dt = time.perf_counter() - t0
+        # the reference's smoke-test assertions (test.py:110-112, 138-139)
+        assert tuple(sc.shape) == (len(images), len(texts)), sc.shape
+        assert bool(((sc >= 0) & (sc <= 1)).all()), "scores outside [0, 1]"
+        key = name.split(" ")[0]
+        res[key] = (sc.double(), lp.double())
+        rep["legs"][key] = {"what": name, "load_s": round(t_load, 1), "score_s": round(dt, 2), "scores": sc.tolist(), "logp_yes": lp[..., 0].tolist()}
+        say(f"\n## {name}   (load {t_load:.1f} s, 16-pair grid {dt:.2f} s)")
+        say("   score[i][j] = image i x text j        log P(Yes)")
+        for i in range(len(images)):
+            say("   " + "  ".join(f"{float(x):.4f}" for x in sc[i]) + "      " + "  ".join(f"{float(x):+.4f}" for x in lp[i, :, 0]))
+        del scorer
+
+    def dist(a, b):
+        d = (res[a][1][..., 0] - res[b][1][..., 0]).abs()
+        return {"max": float(d.max()), "mean": float(d.mean())}
+
+    say("\n## |delta log P(Yes)| over the grid (max / mean)")
+    table = {}
+    for a, b, what in (("(iii)", "(i)", "HIP vs fp32 truth          <- north_star's criterion"), ("(ii)", "(i)", "reference as shipped vs fp32 truth"),
+                       ("(iii)", "(ii)", "HIP vs reference as shipped")):
+        if a in res and b in res:
+            table[f"{a} vs {b}"] = dist(a, b)
+            say(f"   {a:6s} vs {b:5s} {table[f'{a} vs {b}']['max']:.3e} / {table[f'{a} vs {b}']['mean']:.3e}   {what}")
+    rep["dlogp"] = table
+    if "(iii) vs (i)" in table:
+        ok = table["(iii) vs (i)"]["max"] <= BOUND
+        rep["verdict"] = "PASS" if ok else "FAIL"
+        say(f"\n## verdict: {'PASS' if ok else 'FAIL'} -- max |delta log P(Yes)| HIP vs fp32 truth {table['(iii) vs (i)']['max']:.3e} {'<=' if ok else '>'} {BOUND:.0e}")
+    else:
+        rep["verdict"] = "INCOMPLETE: needs legs (i) and (iii)"
+        say("\n## verdict: INCOMPLETE (needs the fp32 leg and an MI355X)")
+    return rep
+
+
+def main():
+    ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
+    ap.add_argument("--checkpoint", required=True, help="local HF directory of zhiqiulin/clip-flant5-xxl (or -xl): weight shards + tokenizer files")
+    ap.add_argument("--vision-tower", default=None, help="directory of openai/clip-vit-large-patch14-336 when the tower is not inside the checkpoint")
+    ap.add_argument("--model", default="clip-flant5-xxl", choices=["clip-flant5-xxl", "clip-flant5-xl"])
+    ap.add_argument("--images", nargs="*", default=None)
+    ap.add_argument("--texts", nargs="*", default=None)
+    ap.add_argument("--device", default=None, help="cuda:0 (default when a device is visible) | cpu (skips the HIP leg)")
+    ap.add_argument("--skip-fp32", action="store_true", help="skip leg (i) (46 GB of fp32 weights at XXL, minutes per pair on the host)")
+    ap.add_argument("--json", default="")
+    a = ap.parse_args()
+    rep = run(a.checkpoint, a.vision_tower, a.model, a.images, a.texts, a.device, a.skip_fp32)
+    if a.json:
+        with open(a.json, "w") as f:
+            json.dump(rep, f, indent=1)
+    sys.exit(0 if rep["verdict"] in ("PASS",) or rep["verdict"].startswith("INCOMPLETE") else 1)
+
+
+if __name__ == "__main__":
+    main()
