@@ -225,6 +225,9 @@ class EngineRoundedOracle(Oracle):
         self.vit_fp16 = bool(vit_fp16)           # default = what ships (the engine's default); False = the bf16 tower of rounds 1-3
         if self.vit_fp16:
             half_classes = tuple(half_classes) + tuple(c for c in self.CLASSES if c.startswith("vit.")) + ("proj.mid",)
+        # enc_fp16 == "attn" (a what-if of tools/error_attribution.py, nothing the engine does): only the attention sub-block -- the FFN's norm
+        # output and the wi weights stay bf16
+        self.enc_ffn_bf16 = enc_fp16 == "attn"
         self.enc_fp16 = bool(enc_fp16)
         if self.enc_fp16:
             half_classes = tuple(half_classes) + self.ENC_FP16_CLASSES
@@ -281,7 +284,7 @@ class EngineRoundedOracle(Oracle):
         stack = {"vision": "vit", "mm_projector": "proj"}.get(wname.split(".")[0])
         if stack in self.half_stacks and "patch_embedding" not in wname:
             w = w.to(torch.float16)                 # what a bf16 checkpoint becomes in an fp16 tower
-        if self.enc_fp16 and wname.startswith("encoder.") and wname.endswith(self.ENC_FP16_LINEARS):
+        if self.enc_fp16 and wname.startswith("encoder.") and wname.endswith(self.ENC_FP16_LINEARS) and not (self.enc_ffn_bf16 and "DenseReluDense" in wname):
             w = w.to(torch.float16)                 # ... and in the encoder's fp16 attention side (wo keeps bf16 operands)
         w = w.reshape(w.shape[0], -1).to(self.acc)
         y = (x.to(self.acc) @ w.t()).float()
@@ -365,7 +368,8 @@ class EngineRoundedOracle(Oracle):
                                                          round_out=self.rcf("enc.attn")))
             d_attn = self._emit(n + "d_attn", rc("enc.delta", self._mm(att, a + "o.weight")))
             h1 = h + d_attn
-            xn = self._emit(n + "xn1", rc("enc.norm", t5_rms_norm(h1, self._w(p + "layer.1.layer_norm.weight"), t.ln_eps)))
+            y1 = t5_rms_norm(h1, self._w(p + "layer.1.layer_norm.weight"), t.ln_eps)
+            xn = self._emit(n + "xn1", self.r(y1) if (self.enc_ffn_bf16 and (self.classes is None or "enc.norm" in self.classes)) else rc("enc.norm", y1))
             ff = self._emit(n + "ff", self._gated_ff(p + "layer.1.DenseReluDense.", xn, "enc.act"))
             d_ff = self._emit(n + "d_ff", rc("enc.delta", self._mm(ff, p + "layer.1.DenseReluDense.wo.weight")))
             h = h1 + d_ff
@@ -501,15 +505,15 @@ class EngineRoundedOracle(Oracle):
                     else torch.empty(shape, dtype=dt, device=device)) for n, (shape, dt) in shapes.items()}
 
     @staticmethod
-    def taps_to_values(shapes, bufs):
-        """Tap buffers -> the tensors' values (CPU): split entries become fp32 hi + lo."""
+    def taps_to_values(shapes, bufs, device="cpu"):
+        """Tap buffers -> the tensors' values on `device` (own copies): split entries become fp32 hi + lo."""
         out = {}
         for n, b in bufs.items():
             if shapes[n][1] == "split":
-                out[n] = (b[0].float() + b[1].float()).cpu()
-                out[n + "#hi"] = b[0].float().cpu()
+                out[n] = (b[0].float() + b[1].float()).to(device)
+                out[n + "#hi"] = b[0].float().to(device)
             else:
-                out[n] = b.cpu()
+                out[n] = b.to(device).clone() if torch.device(device).type != "cpu" else b.cpu()
         return out
 
     def forward_locked(self, taps, pixel_values, img_index, input_ids, labels):

@@ -76,5 +76,6 @@ def test_stage_locked_rows_of_two_sampled_pairs_inside_the_256_batch(xxl_bench):
     workgroups' tile lists), each against the oracle on the engine's own inputs."""
     from tests.test_gpu_stage_locked import run_stage_locked
     cfg, w, eng, (pix, idx, ids, labels), lp256, sc256 = xxl_bench
-    report, lp = run_stage_locked(cfg, w, eng, pix, idx.cpu(), ids, labels, "clip-flant5-xxl/bench-batch-256/pairs-130-131", window=(130, 2))
+    report, lp = run_stage_locked(cfg, w, eng, pix, idx.cpu(), ids, labels, "clip-flant5-xxl/bench-batch-256/pairs-130-131", window=(130, 2),
+                                  oracle_device="cuda")
     assert torch.equal(lp, lp256[130:132].cpu())                                    # the tapped pass is the same pass

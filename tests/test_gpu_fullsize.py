@@ -96,11 +96,16 @@ def _one_pair_three_way(cfg, w, eng, tag, seed, check_random=True):
     pix, idx, ids, labels = _batch(cfg, 1, 1, 33, seed=seed)
     head = w["lm_head.weight"]
     saved = head[[2163, 1]].clone()
-    w_cpu = {k: v.cpu() for k, v in w.items()}
-    ref = Oracle(cfg, w_cpu).forward(pix.float(), idx, ids, labels, return_stages=True)
-    emu = Oracle(cfg, w_cpu, emulate="engine").forward(pix.float(), idx, ids, labels, return_stages=True)   # ~40 s at XXL
-    head_cpu = w_cpu["lm_head.weight"].float().clone()
-    del w_cpu
+    # Both oracles are evaluated by torch ON THE DEVICE (the same code; the host cores need ~40 s per XXL pass and pair, the device a
+    # second): test infrastructure after the engine's pass.  tests/test_oracle_golden.py and bench.py's cross-check pin the device
+    # evaluation of this code to the host's (1.9e-6 on log-probs).
+    dev = torch.device("cuda:0")
+    with torch.device(dev):
+        ref = Oracle(cfg, w, device=dev).forward(pix.float().to(dev), idx.to(dev), ids.to(dev), labels.to(dev), return_stages=True)
+        emu = Oracle(cfg, w, emulate="engine", device=dev).forward(pix.float().to(dev), idx.to(dev), ids.to(dev), labels.to(dev), return_stages=True)
+    ref = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in ref.items()}
+    emu = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in emu.items()}
+    head_cpu = w["lm_head.weight"].float().cpu().clone()
     x_ref = ref["dec_out"].float()[0]                                            # [T, D]
     out = {}
     try:
@@ -151,7 +156,9 @@ def _one_pair_three_way(cfg, w, eng, tag, seed, check_random=True):
     # 1.0e-3 (XL) / 1.4e-3 (XXL); gate = 3 x that, and never more than 3 x what the same arithmetic shows on the CPU + 1e-3
     if "random-head" in out:
         o = out["random-head"]
-        assert o["dlogp_vs_fp32"] <= min(4.5e-3, 3.0 * o["rounding_matched_vs_fp32"] + 1e-3), out
+        # round 5 (fp16 tower + fp16 encoder attention side): one pair is one draw of a distribution whose maximum over 256 bench pairs
+        # measured 7.6e-4 (XXL) / 8.3e-4 (XL), mean 2.9e-4 / 3.1e-4 (profiles/r5_call2_*): gate 1.5e-3 (round 4: 4.5e-3, round 3: 2.5e-2)
+        assert o["dlogp_vs_fp32"] <= min(1.5e-3, 3.0 * o["rounding_matched_vs_fp32"] + 1e-3), out
     assert rel <= 0.02, rel
 
 

@@ -274,7 +274,10 @@ def test_qwen_7b_full_size_one_sample_against_the_cpu_oracle():
     # (fp32 accumulation on the host: same <= 1 ulp criterion, ~4x cheaper than fp64 at this size)
     _stage_locked("qwen/fullsize-7b", cfg, w, eng, px.cuda(), grid, ids, mask, [grid], vis_layers=[0, 7, 31], txt_layers=[0, 13, 27],
                   acc=torch.float32, merged=merged_dev)
-    ref = QwenOracle(cfg, {k: v.cpu() for k, v in w.items()}).forward(ids, mask, px.float(), [grid])
+    # the fp32 oracle's code evaluated by torch on the device (the host cores need ~1 min for this one sample; tests/test_qwen_oracle.py pins
+    # the code to HF on the host)
+    with torch.device("cuda:0"):
+        ref = QwenOracle(cfg, w, device="cuda:0").forward(ids.cuda(), mask.cuda(), px.float().cuda(), [grid]).float().cpu()
     lp, ref_lp = torch.log_softmax(logits, -1)[0], torch.log_softmax(ref, -1)[0]
     toks = ref_lp.topk(5).indices.tolist() + [9454]
     d = max(abs(lp[t].item() - ref_lp[t].item()) for t in toks)

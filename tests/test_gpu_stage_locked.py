@@ -27,19 +27,24 @@ ATTENTION_TAPS = ("attn", "sattn", "cctx", "cattn")
 PRECISE_DEC_TAPS = ("xn0", "xn1", "xn2", "qkv", "sattn", "d_self", "cctx", "cattn", "d_cross", "ff", "d_ff")   # fp32 or split-bf16 in the decoder
 
 
-def run_stage_locked(cfg, w, eng, pix, idx, ids, labels, tag, window=None, vit_fp16=None):
+def run_stage_locked(cfg, w, eng, pix, idx, ids, labels, tag, window=None, vit_fp16=None, oracle_device="cpu"):
     """window = (first, count): the pass runs on the WHOLE batch, the taps and the oracle cover pairs first .. first+count-1
     (vqs_debug_tap_window; their images must be rows first .. of `pix` in order) -- the stage-locked check of a few sampled
     pairs inside a batch too large to tap whole (the benchmarked 256-pair XXL batch)."""
+    # oracle_device: where the oracle's torch code is evaluated.  "cpu" = the oracle proper (every tiny / small case).  The full-size cases
+    # (XL / XXL, ~650-790 launch outputs over 11.5 B parameters) pass "cuda": the SAME oracle code run by torch on the GPU in fp64 -- minutes
+    # of host time become seconds (the six host-oracle-bound tests were 700 s of the suite's 764 s in round 4).  Test infrastructure either
+    # way; the comparison is per launch on the engine's own inputs, so the evaluation device only moves fp64 summation order.
     from oracle.clip_t5_oracle import Oracle
-    w_cpu = {k: v.cpu() for k, v in w.items()}
+    odev = torch.device(oracle_device)
+    w_cpu = {k: v.cpu() for k, v in w.items()} if odev.type == "cpu" else w
     # vit_fp16: the engine must already run its tower on fp16 operands (option "vit_fp16"); the oracle then rounds the tower's tensors to
     # fp16, reads the fp16 copies of its weights and decodes the tower's taps as fp16
     if vit_fp16 is None:
         vit_fp16 = bool(eng.get_option("vit_fp16"))          # the engine's own setting (default: fp16 tower)
     assert vit_fp16 == bool(eng.get_option("vit_fp16"))
     # enc_fp16 (round 5, default 1): likewise for the encoder's attention side -- the oracle follows the engine's setting
-    emu = Oracle(cfg, w_cpu, emulate="engine", vit_fp16=vit_fp16, enc_fp16=bool(eng.get_option("enc_fp16")))
+    emu = Oracle(cfg, w_cpu, emulate="engine", vit_fp16=vit_fp16, enc_fp16=bool(eng.get_option("enc_fp16")), device=odev)
     B, L = ids.shape
     T = labels.shape[1]
     if window is None:
@@ -61,20 +66,22 @@ def run_stage_locked(cfg, w, eng, pix, idx, ids, labels, tag, window=None, vit_f
     finally:
         eng.tap(None)
         eng.tap_window(0, 0)
-    taps = emu.taps_to_values(shapes, bufs)
+    taps = emu.taps_to_values(shapes, bufs, device=odev)
     S = L - 1 + cfg.vision.n_patches
     sl = slice(first, first + cnt)
     enc_out = eng.stage("enc_out").reshape(B, S, -1)[sl].reshape(cnt * S, -1)
     dec_out = eng.stage("dec_out").reshape(B, T, -1)[sl].reshape(cnt * T, -1)
     logits = eng.stage("logits").reshape(B, T, -1)[sl].reshape(cnt * T, -1)
-    taps.update(proj=feats[first:first + n_img_t].cpu() if window is not None else feats.cpu(), enc_out=enc_out.cpu(), dec_out=dec_out.cpu(),
-                logits=logits.cpu())
+    taps.update(proj=(feats[first:first + n_img_t] if window is not None else feats).to(odev).clone(), enc_out=enc_out.to(odev).clone(),
+                dec_out=dec_out.to(odev).clone(), logits=logits.to(odev).clone())
     del bufs
     if window is None:
         pix_o, idx_o = pix, idx
     else:
         pix_o, idx_o = pix[sl], torch.arange(cnt, dtype=idx.dtype)
-    report, lp_from_engine_logits = emu.forward_locked(taps, pix_o.float().cpu(), idx_o.cpu(), ids[sl].cpu(), labels[sl].cpu())
+    with torch.device(odev):
+        report, lp_from_engine_logits = emu.forward_locked(taps, pix_o.float().to(odev), idx_o.to(odev), ids[sl].to(odev), labels[sl].to(odev))
+    lp_from_engine_logits = lp_from_engine_logits.cpu()
     lp = lp[sl]
     # ---- summary for profiles/
     worst = {}
@@ -171,7 +178,7 @@ def test_full_size_pass_stage_locked(model):
     eng = VqsEngine(cfg, w, device="cuda:0")
     try:
         pix, idx, ids, labels = _batch(cfg, 2, 2, 33, seed=21)
-        run_stage_locked(cfg, w, eng, pix, idx, ids, labels, model)
+        run_stage_locked(cfg, w, eng, pix, idx, ids, labels, model, oracle_device="cuda")
     finally:
         eng.close()
         del w

@@ -381,3 +381,68 @@ def test_gpu_numa_lookup_formats_the_pci_address_from_torchs_integer_fields(tmp_
         (tmp_path / bdf / "numa_node").write_text("%d\n" % node)
     monkeypatch.setattr(sharding.torch.cuda, "get_device_properties", lambda i: props[i])
     assert sharding.gpu_numa_nodes(3, sysfs=str(tmp_path)) == [0, 1, -1]        # the third device has no sysfs entry: unknown
+
+
+def test_staging_event_is_recorded_on_the_models_device_and_stream(tmp_path, monkeypatch):
+    """load_images runs on the image thread, whose current device is 0 whatever the main thread set.  The H2D copy of a
+    reused pinned staging buffer and the event that guards the buffer's next use must sit on the MODEL's device and its current stream --
+    an event recorded on device 0 while the copy runs on cuda:1 is complete at once and the buffer is overwritten under the DMA.  No second
+    GPU here: torch.cuda's device / stream / event entry points are replaced by recorders and the call is made from a worker thread."""
+    import threading
+    from PIL import Image
+    import t2v_metrics_amd as t2v
+    from t2v_metrics_amd.config import get_config
+    cfg = get_config("tiny")
+    rng = np.random.RandomState(4)
+    paths = []
+    for i in range(3):
+        p = tmp_path / f"s{i}.png"
+        Image.fromarray(rng.randint(0, 256, (40, 40, 3), dtype=np.uint8)).save(p)
+        paths.append(str(p))
+
+    class Eng(RecordingEngine):
+        def normalize_u8(self, u8, mean, std):
+            log.append(("normalize", getattr(tls, "device", None)))
+            return u8.permute(0, 3, 1, 2).float()
+
+    log, tls = [], threading.local()
+    m = t2v.VQAScore(model="clip-flant5-xl", device="cpu", config=cfg, engine=Eng(cfg), tokenizer=FakeTokenizer(cfg.t5.vocab), image_workers="thread").model
+    m.device = "cuda:1"                                        # a rank whose GPU is not device 0
+
+    class FakeDeviceCtx:
+        def __init__(self, dev):
+            self.dev = str(dev)
+
+        def __enter__(self):
+            self.prev = getattr(tls, "device", "cuda:0")       # a fresh thread's current device is 0
+            tls.device = self.dev
+
+        def __exit__(self, *a):
+            tls.device = self.prev
+
+    class FakeEvent:
+        def record(self, stream=None):
+            log.append(("record", getattr(tls, "device", "cuda:0"), stream))
+
+        def synchronize(self):
+            log.append(("sync",))
+
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "device", FakeDeviceCtx)
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda dev=None: ("stream-of", str(dev) if dev is not None else getattr(tls, "device", "cuda:0")))
+    monkeypatch.setattr(torch.cuda, "Event", FakeEvent)
+    monkeypatch.setattr(torch.Tensor, "pin_memory", lambda self, *a, **k: self)
+    real_to = torch.Tensor.to
+
+    def fake_to(self, *a, **k):
+        if a and str(a[0]).startswith("cuda"):
+            log.append(("h2d", str(a[0]), getattr(tls, "device", "cuda:0")))
+            return self
+        return real_to(self, *a, **k)
+    monkeypatch.setattr(torch.Tensor, "to", fake_to)
+    th = threading.Thread(target=lambda: m.load_images(paths))
+    th.start(); th.join()
+    kinds = [e[0] for e in log]
+    assert kinds == ["h2d", "record", "normalize"], log
+    assert log[0][1:] == ("cuda:1", "cuda:1")                  # the copy is issued with cuda:1 current ...
+    assert log[1][1] == "cuda:1" and log[1][2] == ("stream-of", "cuda:1")      # ... and the event is recorded on cuda:1's current stream

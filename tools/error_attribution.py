@@ -51,11 +51,12 @@ class Runner:
 
     def _oracle(self, classes, dec_precise, split=()):
         ship = "ship:vit_fp16" in split                                      # the engine's option itself (fp16 GEMM result of the projector, then bf16)
+        enc16 = "attn" if "ship:enc_fp16_attn" in split else ("ship:enc_fp16" in split)   # the engine's option enc_fp16 (round 5) / its attention-sub-block-only what-if
         half = tuple(c[5:] for c in split if c.startswith("half:"))          # "half:<class>" entries of a what-if's set: fp16 tensors
         split = tuple(c for c in split if not c.startswith(("half:", "ship:")))
         # vit_fp16=False: the table models every class as a bf16 rounding (the engine of rounds 1-3) and adds fp16 / split stages explicitly
         return EngineRoundedOracle(self.cfg, self.w, acc=self.acc, classes=classes, dec_precise=dec_precise, split_classes=split,
-                                   half_classes=half, vit_fp16=ship, device=self.pix.device)
+                                   half_classes=half, vit_fp16=ship, device=self.pix.device, enc_fp16=enc16)
 
     def run(self, classes, dec_precise=False, split=()):
         classes = frozenset(classes)
@@ -179,7 +180,11 @@ def main():
               ("ship:vit_fp16",) + enc_attn_side + ("half:proj.out",)),
              ("r5: shipped + enc attention side fp16 + feature fp16 + enc.out split", ALL, True,
               ("ship:vit_fp16", "half:enc.norm", "half:enc.qkv", "half:enc.p", "half:enc.attn", "enc.out", "half:proj.out")),
-             ("r5: decoder floor (vit proj enc exact)", without("vit.*", "proj.*", "enc.*"), True, ())]
+             ("r5: decoder floor (vit proj enc exact)", without("vit.*", "proj.*", "enc.*"), True, ()),
+             ("r5: the engine as shipped in round 5 (precise decoder + vit_fp16 + enc_fp16)", ALL, True, ("ship:vit_fp16", "ship:enc_fp16")),
+             ("r5: as round 5 but only the attention sub-block in fp16 (FFN norm output and wi stay bf16)", ALL, True, ("ship:vit_fp16", "ship:enc_fp16_attn")),
+             ("r5: round 5 + decoder cross score path (q, q.Wk, probabilities) and the encoder output in fp16", ALL, True,
+              ("ship:vit_fp16", "ship:enc_fp16", "half:enc.out", "half:dec.cq", "half:dec.cqk", "half:dec.cprobs"))]
     runs = [(r + (False, ()))[:4] if len(r) < 4 else r for r in runs]          # (name, classes, precise decoder, split set)
     if a.only:
         keep = set(a.only.split(";"))
