@@ -107,7 +107,12 @@ int vqs_qwen_debug_tap(vqs_qwen_handle* h, const char* name, void* d_dst, size_t
 
 /* Test hook: "x_pitch" = row pitch (elements, a multiple of 64, >= hidden) of the language model's normalised activations and packed
  * gate|up weight rows; the library's choice is hidden for hidden <= 2048 and the next power of two >= 4096 above that.
- * Must be called before vqs_qwen_bind_weights.  Results do not depend on it. */
+ * Must be called before vqs_qwen_bind_weights.  Results do not depend on it.
+ * Execution-form switch: "tail_precise" 1 (default, round 5) = vqs_qwen_score / vqs_qwen_prefill take their logits from a PRECISE re-evaluation
+ * of every sample's last prompt position -- the one row the reference reads (qwen2vl_model.py:222-301: scores[0] of generate) -- carried
+ * layer by layer beside the bf16 prefill with 16 significant bits (split-bf16 operands as stacked rows of the same GEMMs, fp32 partial sums,
+ * fp32 q / softmax / sub-layer outputs; attention over the layer's bf16 K / V); 0 = the logits of the bf16 prefill's last row (rounds 2-4).
+ * Same function either way; the attribution behind it and the measured effect: profiles/r5_qwen_error_attribution.md.  Any time after create. */
 int vqs_qwen_debug_option(vqs_qwen_handle* h, const char* name, int64_t value);
 
 #ifdef __cplusplus

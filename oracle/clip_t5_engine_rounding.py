@@ -206,7 +206,7 @@ class EngineRoundedOracle(Oracle):
         8, same MFMA rate); the weights of a stack with a half class are then fp16 too (bf16 -> fp16 is exact above 2^-14).
         `vit_fp16` = the engine's option of that name (vqs_set_option "vit_fp16"): every class of the tower and the projector's hidden
         tensor are fp16, the linear weights of both are the fp16 copies (the patch embedding keeps bf16 operands), and the projector's
-        output is rounded to fp16 by its GEMM and then to bf16 by the cast into the C ABI's feature tensor.
+        output is rounded ONCE, from the fp32 accumulator to the C ABI's bf16 feature tensor (round 4 rounded to fp16 first).
         `enc_fp16` = the engine's option of that name (round 5, default 1): the ATTENTION SIDE of the T5 encoder -- both norm outputs, q / k / v,
         the probabilities, the attention output -- is IEEE fp16 and q / k / v / o / wi_0 / wi_1 are read as fp16 copies; the sub-layer outputs,
         the gated product, the wo GEMM and the encoder's final output stay bf16 (vqs_api.cpp encoder_pass)."""
@@ -330,8 +330,7 @@ class EngineRoundedOracle(Oracle):
         rc = self.rc
         x = self._emit("vit.pmid", rc("proj.mid", gelu_erf(self._mm(feats, "mm_projector.0.weight", "mm_projector.0.bias"))))
         y = self._mm(x, "mm_projector.2.weight", "mm_projector.2.bias")
-        if self.vit_fp16 and (self.classes is None or "proj.out" in self.classes):
-            y = self.rh(y)                          # the fp16 GEMM result, before the cast to the bf16 feature tensor
+        # round 5: the fp16-operand GEMM rounds its fp32 accumulator to the bf16 feature tensor directly (round 4: to fp16, then a cast)
         return self._emit("proj", rc("proj.out", y))
 
     # ---------------------------------------------------------------------------------------------- T5

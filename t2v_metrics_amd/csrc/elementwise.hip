@@ -744,9 +744,12 @@ __device__ __forceinline__ float e_gelu_new(float x) {      // gemm.hip act_gelu
     return x * __builtin_amdgcn_rcpf(1.0f + __expf(-u2));
 }
 
-template <int MODE>
+// SILU_BIAS (the Qwen2.5-VL precise tail, vqs_qwen.cpp): a bf16 bias [cols] is added to the gathered sums (nullptr = none) and the gated
+// form applies SiLU(gate) * up instead of gelu_new(gate) * linear -- the arithmetic of gemm.hip's EPI_GATED with gate_act = 1.
+template <int MODE, bool SILU_BIAS = false>
 __global__ void __launch_bounds__(256) sum_planes_kernel(const float* __restrict__ part, int nslices, long long slice_stride, int rows,
-                                                         int cols4, int ldp, void* __restrict__ out, int ld_out, long long out_plane) {
+                                                         int cols4, int ldp, void* __restrict__ out, int ld_out, long long out_plane,
+                                                         const bf16_t* __restrict__ bias = nullptr) {
     // thread -> (row, group of 4 output columns); cols4 = output columns / 4
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long long)rows * cols4) return;
@@ -762,14 +765,23 @@ __global__ void __launch_bounds__(256) sum_planes_kernel(const float* __restrict
             a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
             b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
         }
-        return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+        float4 y = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+        if (SILU_BIAS && bias != nullptr) {
+            const float4 bb = bf4_to_f4(*reinterpret_cast<const uint2*>(bias + col));
+            y.x += bb.x; y.y += bb.y; y.z += bb.z; y.w += bb.w;
+        }
+        return y;
     };
     if (MODE == SUM_GATED_SPLIT) {
         const int oc = c4 * 4;                        // output column; packed order: block of 64 = 32 gate | 32 linear columns
         const int gc = (oc >> 5) * 64 + (oc & 31);
         const float4 g = gather(gc), l = gather(gc + 32);
         bf16_t* oh = reinterpret_cast<bf16_t*>(out) + (size_t)r * ld_out + oc;
-        e_split4_store(oh, oh + out_plane, make_float4(e_gelu_new(g.x) * l.x, e_gelu_new(g.y) * l.y, e_gelu_new(g.z) * l.z, e_gelu_new(g.w) * l.w));
+        auto act = [](float x) {
+            if (SILU_BIAS) return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+            return e_gelu_new(x);
+        };
+        e_split4_store(oh, oh + out_plane, make_float4(act(g.x) * l.x, act(g.y) * l.y, act(g.z) * l.z, act(g.w) * l.w));
     } else {
         const float4 y = gather(c4 * 4);
         if (MODE == SUM_F32) {
@@ -782,7 +794,7 @@ __global__ void __launch_bounds__(256) sum_planes_kernel(const float* __restrict
 }
 
 hipError_t launch_sum_planes(const float* part, int nslices, long long slice_stride, int rows, int cols, int ldp, int mode, void* out,
-                             int ld_out, long long out_plane, hipStream_t s) {
+                             int ld_out, long long out_plane, hipStream_t s, const bf16_t* bias, int silu) {
     if (rows <= 0 || cols <= 0 || nslices <= 0 || (ldp % 4) != 0 || (ld_out % 4) != 0 || (out_plane % 4) != 0 || (slice_stride % 4) != 0)
         return hipErrorInvalidValue;
     const int out_cols = mode == SUM_GATED_SPLIT ? cols / 2 : cols;
@@ -790,6 +802,13 @@ hipError_t launch_sum_planes(const float* part, int nslices, long long slice_str
     const int cols4 = out_cols / 4;
     const long long n = (long long)rows * cols4;
     const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (bias != nullptr || silu) {        // the Qwen2.5-VL tail's forms: bias of the qkv projection, SiLU gating
+        if (mode == SUM_F32) hipLaunchKernelGGL((sum_planes_kernel<SUM_F32, true>), grid, block, 0, s, part, nslices, slice_stride, rows, cols4, ldp, out, ld_out, out_plane, bias);
+        else if (mode == SUM_SPLIT) hipLaunchKernelGGL((sum_planes_kernel<SUM_SPLIT, true>), grid, block, 0, s, part, nslices, slice_stride, rows, cols4, ldp, out, ld_out, out_plane, bias);
+        else if (mode == SUM_GATED_SPLIT) hipLaunchKernelGGL((sum_planes_kernel<SUM_GATED_SPLIT, true>), grid, block, 0, s, part, nslices, slice_stride, rows, cols4, ldp, out, ld_out, out_plane, bias);
+        else return hipErrorInvalidValue;
+        return hipGetLastError();
+    }
     if (mode == SUM_F32) hipLaunchKernelGGL((sum_planes_kernel<SUM_F32>), grid, block, 0, s, part, nslices, slice_stride, rows, cols4, ldp, out, ld_out, out_plane);
     else if (mode == SUM_SPLIT) hipLaunchKernelGGL((sum_planes_kernel<SUM_SPLIT>), grid, block, 0, s, part, nslices, slice_stride, rows, cols4, ldp, out, ld_out, out_plane);
     else if (mode == SUM_GATED_SPLIT) hipLaunchKernelGGL((sum_planes_kernel<SUM_GATED_SPLIT>), grid, block, 0, s, part, nslices, slice_stride, rows, cols4, ldp, out, ld_out, out_plane);

@@ -71,9 +71,14 @@ hipError_t launch_qwen_decode_rope_append(const bf16_t* qkv, const float* cs, co
 // fp32) -> t_j = s_j * scale in LDS.  m = max t; p_j = exp(t_j - m), fp32, NOT rounded (a one-row softmax has no matrix-pipe operand
 // to round for); l = sum p.  Output: wave w takes keys w, w + 4, ...; lane i the lanes 2i, 2i + 1 (one coalesced 256-byte V row per
 // wave and key), the four partial rows are added in wave order, divided by l, rounded to bf16.  Dynamic LDS: (len + 1) floats.
-__global__ void __launch_bounds__(256) qwen_decode_attn_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc,
+// PRECISE (the precise tail of vqs_qwen_score, vqs_qwen.cpp): q is an fp32 row (already rotated), `len` holds the COUNT of valid keys
+// (the prompt's own length: the row attends to itself through the K / V rows the prefill wrote), and the output leaves as a split-bf16
+// tensor: hi plane at out, lo = bf16(o - hi) at out + out_plane.
+template <bool PRECISE>
+__global__ void __launch_bounds__(256) qwen_decode_attn_kernel(const void* __restrict__ q_, const bf16_t* __restrict__ kc,
                                                                const bf16_t* __restrict__ vc, const int* __restrict__ len,
-                                                               bf16_t* __restrict__ out, int Hq, int Hkv, int Lmax, float scale) {
+                                                               bf16_t* __restrict__ out, int Hq, int Hkv, int Lmax, float scale,
+                                                               long long out_plane) {
     constexpr int HD = 128;
     extern __shared__ __attribute__((aligned(16))) float d_smem[];
     __shared__ float qs[HD];
@@ -82,10 +87,13 @@ __global__ void __launch_bounds__(256) qwen_decode_attn_kernel(const bf16_t* __r
     const int h = blockIdx.x, b = blockIdx.y, t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int hk = h / (Hq / Hkv);
     // keys [0, len[b]]; a length outside the cache is clamped to it (the LDS score row holds Lmax floats)
-    const int n = min(max(len[b], 0), Lmax - 1) + 1;
+    const int n = PRECISE ? min(max(len[b], 1), Lmax) : min(max(len[b], 0), Lmax - 1) + 1;
     const bf16_t* K = kc + ((size_t)b * Hkv + hk) * Lmax * HD;
     const bf16_t* V = vc + ((size_t)b * Hkv + hk) * Lmax * HD;
-    if (t < HD) qs[t] = d_bf2f(q[((size_t)b * Hq + h) * HD + t]);
+    if (t < HD) {
+        if (PRECISE) qs[t] = reinterpret_cast<const float*>(q_)[((size_t)b * Hq + h) * HD + t];
+        else qs[t] = d_bf2f(reinterpret_cast<const bf16_t*>(q_)[((size_t)b * Hq + h) * HD + t]);
+    }
     __syncthreads();
     float mx = -3.0e38f;
     for (int j = t; j < n; j += 256) {
@@ -134,7 +142,9 @@ __global__ void __launch_bounds__(256) qwen_decode_attn_kernel(const bf16_t* __r
     __syncthreads();
     if (t < HD) {
         const float o = ((part[0][t] + part[1][t]) + (part[2][t] + part[3][t])) / l;
-        out[((size_t)b * Hq + h) * HD + t] = d_f2bf(o);
+        const bf16_t hi = d_f2bf(o);
+        out[((size_t)b * Hq + h) * HD + t] = hi;
+        if (PRECISE) out[out_plane + ((size_t)b * Hq + h) * HD + t] = d_f2bf(o - d_bf2f(hi));
     }
 }
 
@@ -148,9 +158,11 @@ __global__ void __launch_bounds__(256) qwen_decode_attn_kernel(const bf16_t* __r
 // xor-shuffles (16, 32), the four waves' partial rows added in wave order, one division, bf16.  Dynamic LDS: G * Lmax floats.
 static constexpr int QD_GMAX = 8;
 static constexpr int QD_NW = 8;            // waves per block: eight split the key range, two per SIMD cover each other's load latency
-__global__ void __launch_bounds__(64 * QD_NW) qwen_decode_attn_gqa_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc,
+template <bool PRECISE>
+__global__ void __launch_bounds__(64 * QD_NW) qwen_decode_attn_gqa_kernel(const void* __restrict__ q_, const bf16_t* __restrict__ kc,
                                                                    const bf16_t* __restrict__ vc, const int* __restrict__ len,
-                                                                   bf16_t* __restrict__ out, int Hq, int Hkv, int Lmax, float scale) {
+                                                                   bf16_t* __restrict__ out, int Hq, int Hkv, int Lmax, float scale,
+                                                                   long long out_plane) {
     constexpr int HD = 128, U = 8;
     extern __shared__ __attribute__((aligned(16))) float d_smem[];      // sc[G][Lp]
     __shared__ float red[QD_NW][QD_GMAX];
@@ -158,7 +170,7 @@ __global__ void __launch_bounds__(64 * QD_NW) qwen_decode_attn_gqa_kernel(const 
     __shared__ float part[QD_NW][QD_GMAX][HD];
     const int hk = blockIdx.x, b = blockIdx.y, t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int G = Hq / Hkv;
-    const int n = min(max(len[b], 0), Lmax - 1) + 1;
+    const int n = PRECISE ? min(max(len[b], 1), Lmax) : min(max(len[b], 0), Lmax - 1) + 1;
     const int Lp = (Lmax + 3) & ~3;
     float* sc = d_smem;
     const bf16_t* K = kc + ((size_t)b * Hkv + hk) * Lmax * HD;
@@ -177,7 +189,17 @@ __global__ void __launch_bounds__(64 * QD_NW) qwen_decode_attn_gqa_kernel(const 
         float qf[QD_GMAX][8];
 #pragma unroll
         for (int g = 0; g < QD_GMAX; ++g)
-            if (g < G) cvt8(*reinterpret_cast<const uint4*>(q + ((size_t)b * Hq + (size_t)hk * G + g) * HD + 8 * c), qf[g]);
+            if (g < G) {
+                const size_t qo = ((size_t)b * Hq + (size_t)hk * G + g) * HD + 8 * c;
+                if (PRECISE) {
+                    const float4 a = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(q_) + qo)[0];
+                    const float4 bq = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(q_) + qo)[1];
+                    qf[g][0] = a.x; qf[g][1] = a.y; qf[g][2] = a.z; qf[g][3] = a.w;
+                    qf[g][4] = bq.x; qf[g][5] = bq.y; qf[g][6] = bq.z; qf[g][7] = bq.w;
+                } else {
+                    cvt8(*reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(q_) + qo), qf[g]);
+                }
+            }
         float mx[QD_GMAX];
 #pragma unroll
         for (int g = 0; g < QD_GMAX; ++g) mx[g] = -3.0e38f;
@@ -306,31 +328,86 @@ __global__ void __launch_bounds__(64 * QD_NW) qwen_decode_attn_gqa_kernel(const 
 #pragma unroll
         for (int i2 = 1; i2 < QD_NW; ++i2) o += part[i2][g][d];
         o = o / stat[1][g];
-        out[((size_t)b * Hq + (size_t)hk * G + g) * HD + d] = d_f2bf(o);
+        const bf16_t hi = d_f2bf(o);
+        out[((size_t)b * Hq + (size_t)hk * G + g) * HD + d] = hi;
+        if (PRECISE) out[out_plane + ((size_t)b * Hq + (size_t)hk * G + g) * HD + d] = d_f2bf(o - d_bf2f(hi));
     }
 }
 
-hipError_t launch_qwen_decode_attn(const bf16_t* q, const bf16_t* kc, const bf16_t* vc, const int* len, bf16_t* out, int B, int Hq,
-                                   int Hkv, int Lmax, float scale, hipStream_t s) {
+template <bool PRECISE>
+static hipError_t launch_decode_attn_t(const void* q, const bf16_t* kc, const bf16_t* vc, const int* len, bf16_t* out, int B, int Hq, int Hkv, int Lmax,
+                                       float scale, long long out_plane, hipStream_t s) {
     if (B <= 0 || Hq <= 0 || Hkv <= 0 || (Hq % Hkv) != 0 || Lmax <= 0 || Lmax > 36864 /* VQS_QWEN_MAX_CACHE_POSITIONS */ || B > 65535) return hipErrorInvalidValue;
     {   // grouped-query form wherever its G score rows fit LDS (Lmax <= ~4 300 positions at G = 7); the per-query-head kernel beyond
         const int G = Hq / Hkv;
         const size_t glds = (size_t)G * ((Lmax + 3) & ~3) * sizeof(float);
         if (G <= QD_GMAX && glds <= 120 * 1024) {
             if (glds > 48 * 1024) {
-                const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(qwen_decode_attn_gqa_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds);
+                const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(qwen_decode_attn_gqa_kernel<PRECISE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds);
                 if (e != hipSuccess) return e;
             }
-            hipLaunchKernelGGL(qwen_decode_attn_gqa_kernel, dim3((unsigned)Hkv, (unsigned)B), dim3(64 * QD_NW), glds, s, q, kc, vc, len, out, Hq, Hkv, Lmax, scale);
+            hipLaunchKernelGGL(qwen_decode_attn_gqa_kernel<PRECISE>, dim3((unsigned)Hkv, (unsigned)B), dim3(64 * QD_NW), glds, s, q, kc, vc, len, out, Hq, Hkv, Lmax, scale, out_plane);
             return hipGetLastError();
         }
     }
     const size_t lds = (size_t)Lmax * sizeof(float);
     if (lds > 48 * 1024) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(qwen_decode_attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(qwen_decode_attn_kernel<PRECISE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(qwen_decode_attn_kernel, dim3((unsigned)Hq, (unsigned)B), dim3(256), lds, s, q, kc, vc, len, out, Hq, Hkv, Lmax, scale);
+    hipLaunchKernelGGL(qwen_decode_attn_kernel<PRECISE>, dim3((unsigned)Hq, (unsigned)B), dim3(256), lds, s, q, kc, vc, len, out, Hq, Hkv, Lmax, scale, out_plane);
+    return hipGetLastError();
+}
+
+hipError_t launch_qwen_decode_attn(const bf16_t* q, const bf16_t* kc, const bf16_t* vc, const int* len, bf16_t* out, int B, int Hq,
+                                   int Hkv, int Lmax, float scale, hipStream_t s) {
+    return launch_decode_attn_t<false>(q, kc, vc, len, out, B, Hq, Hkv, Lmax, scale, 0, s);
+}
+
+// The precise tail's attention (vqs_qwen.cpp): q fp32 [B, Hq * 128] (rotated), keys / values = the prefill's head-major K / V of this layer
+// ([B, Hkv, Lmax, 128] bf16, Lmax = the batch's padded length), count[b] = the sample's valid length; out = split-bf16 [2][B][Hq * 128].
+hipError_t launch_qwen_tail_attn(const float* q, const bf16_t* k, const bf16_t* v, const int* count, bf16_t* out, long long out_plane, int B, int Hq,
+                                 int Hkv, int Lmax, float scale, hipStream_t s) {
+    return launch_decode_attn_t<true>(q, k, v, count, out, B, Hq, Hkv, Lmax, scale, out_plane, s);
+}
+
+// The precise tail's rotary embedding: q columns of the fp32 q|k|v row of each sample's LAST position, rotated by that position's table
+// (rope_qk_kernel's arithmetic -- x[i] c[i] - x[i + half] s[i], x[i + half] c[i] + x[i] s[i] -- without its bf16 rounding), -> fp32 [B, Hq * hd].
+// Block (query head, sample), 64 threads; table row = row[b] (the sample's last valid position in the [B * L, half] tables).
+__global__ void __launch_bounds__(64) qwen_tail_rope_q_kernel(const float* __restrict__ qkv, int ld, const float* __restrict__ cs,
+                                                              const float* __restrict__ sn, const int* __restrict__ row, float* __restrict__ q_out,
+                                                              int Hq, int hd, int half) {
+    const int h = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+    const float* src = qkv + (size_t)b * ld + (size_t)h * hd;
+    float* dst = q_out + ((size_t)b * Hq + h) * hd;
+    const size_t tr = (size_t)row[b] * half;
+    if (t < half) {
+        const float a = src[t], c2 = src[t + half];
+        const float c = cs[tr + t], s = sn[tr + t];
+        dst[t] = a * c - c2 * s;
+        dst[t + half] = c2 * c + a * s;
+    }
+    for (int d = 2 * half + t; d < hd; d += 64) dst[d] = src[d];
+}
+
+// dst[r, :] = src[map[r], :] (fp32 rows): the precise tail's starting state = the embedding rows of the last positions
+__global__ void __launch_bounds__(256) gather_rows_f32_kernel(const float* __restrict__ src, const int* __restrict__ map, float* __restrict__ dst,
+                                                              int cols4, int src_ld) {
+    const float4* s4 = reinterpret_cast<const float4*>(src + (size_t)map[blockIdx.x] * src_ld);
+    float4* d4 = reinterpret_cast<float4*>(dst + (size_t)blockIdx.x * cols4 * 4);
+    for (int i = threadIdx.x; i < cols4; i += 256) d4[i] = s4[i];
+}
+
+hipError_t launch_gather_rows_f32(const float* src, const int* map, float* dst, int rows, int cols, int src_ld, hipStream_t s) {
+    if (rows <= 0 || cols <= 0 || (cols & 3) || (src_ld & 3)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gather_rows_f32_kernel, dim3((unsigned)rows), dim3(256), 0, s, src, map, dst, cols / 4, src_ld);
+    return hipGetLastError();
+}
+
+hipError_t launch_qwen_tail_rope_q(const float* qkv, int ld, const float* cs, const float* sn, const int* row, float* q_out, int B, int Hq, int hd,
+                                   int half, hipStream_t s) {
+    if (B <= 0 || Hq <= 0 || half <= 0 || half > 64 || 2 * half > hd || B > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(qwen_tail_rope_q_kernel, dim3((unsigned)Hq, (unsigned)B), dim3(64), 0, s, qkv, ld, cs, sn, row, q_out, Hq, hd, half);
     return hipGetLastError();
 }
 

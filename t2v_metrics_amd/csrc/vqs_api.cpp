@@ -120,7 +120,6 @@ struct EncodeWs {
     float* hidden;
     bf16_t *delta, *delta2;
     bf16_t *xn, *q, *k, *v, *attn, *mid, *feat_in, *pmid;
-    bf16_t* pout16;          // option vit_fp16: the projector's fp16 output before it is cast into the caller's bf16 feature tensor
     size_t total;
 };
 
@@ -143,7 +142,6 @@ EncodeWs carve_encode(const vqs_handle* h, char* base, int N, std::unordered_map
     w.mid = cv.take<bf16_t>(NS * c.vis_mlp);
     w.feat_in = cv.take<bf16_t>(NP * c.vis_hidden);
     w.pmid = cv.take<bf16_t>(NP * c.d_model);
-    w.pout16 = h->vit_fp16 ? cv.take<bf16_t>(NP * c.d_model) : nullptr;
     w.total = align_up(cv.off);
     return w;
 }
@@ -875,14 +873,15 @@ int vqs_encode_images(vqs_handle* h, const void* d_pixels, int32_t N, void* d_fe
         TAP("vit", -1, "pmid", w.pmid, (size_t)NP * D);
     }
     {
-        GemmCall g{w.pmid, f16 ? h->proj2_w16 : p2w, f16 ? (void*)w.pout16 : d_feats};
+        // the image features are a bf16 tensor of the C ABI (vqs_score reads them as such).  Round 4 wrote the fp16 result and cast it
+        // (two roundings, one more pass over 2.4 GB); the fp16-operand / bf16-result instantiation of the quad kernel (round 5,
+        // gemm_f16b_quad) rounds the fp32 accumulator to bf16 ONCE and writes the feature tensor itself
+        GemmCall g{w.pmid, f16 ? h->proj2_w16 : p2w, d_feats};
         g.bias = p2b;
-        g.f16 = f16;
+        g.f16 = f16 ? 2 : 0;
         g.M = NP; g.N = D; g.K = D; g.lda = D; g.ldw = D; g.ldc = D; g.epi = vqs::EPI_BF16;
         RUN(run_gemm(h, g, st, "mm_projector.2"));
     }
-    if (f16)    // the image features are a bf16 tensor of the C ABI (vqs_score reads them as such): one rounding from 11 to 8 significant bits
-        HIPCHK(h, vqs::launch_cast16(w.pout16, (bf16_t*)d_feats, (size_t)NP * D, false, st), "features fp16 -> bf16");
     return VQS_OK;
 }
 

@@ -252,6 +252,11 @@ hipError_t launch_qwen_decode_rope_append(const bf16_t* qkv, const float* cs, co
                                           bf16_t* vc, int B, int Hq, int Hkv, int hd, int half, int Lmax, hipStream_t s);
 hipError_t launch_qwen_decode_attn(const bf16_t* q, const bf16_t* kc, const bf16_t* vc, const int* len, bf16_t* out, int B, int Hq,
                                    int Hkv, int Lmax, float scale, hipStream_t s);
+hipError_t launch_qwen_tail_attn(const float* q, const bf16_t* k, const bf16_t* v, const int* count, bf16_t* out, long long out_plane, int B, int Hq,
+                                 int Hkv, int Lmax, float scale, hipStream_t s);
+hipError_t launch_gather_rows_f32(const float* src, const int* map, float* dst, int rows, int cols, int src_ld, hipStream_t s);
+hipError_t launch_qwen_tail_rope_q(const float* qkv, int ld, const float* cs, const float* sn, const int* row, float* q_out, int B, int Hq, int hd,
+                                   int half, hipStream_t s);
 hipError_t launch_rope_qk(bf16_t* q, bf16_t* k, const float* cs, const float* sn, int B, int Hq, int Hk, int S, int hd, int half,
                           hipStream_t s);
 hipError_t launch_rowss_to_rs(const float* rowss, int parts, int M, float invd, float eps, float* rs, hipStream_t s);
@@ -270,7 +275,7 @@ enum SumPlanesMode : int { SUM_F32 = 0, SUM_SPLIT = 1, SUM_GATED_SPLIT = 2 };
 hipError_t launch_reduce_slices_act(const float* part, int nslices, long long slice_stride, int rows, int cols, int ldp, const bf16_t* bias,
                                     int gated, bf16_t* out, int ld_out, hipStream_t s);
 hipError_t launch_sum_planes(const float* part, int nslices, long long slice_stride, int rows, int cols, int ldp, int mode, void* out,
-                             int ld_out, long long out_plane, hipStream_t s);
+                             int ld_out, long long out_plane, hipStream_t s, const bf16_t* bias = nullptr, int silu = 0);
 // argmax of logits row (b*T + T-1) -> tokens[b, dst_col] (dst_col < 0: T-1)
 hipError_t launch_argmax_append(const float* logits, int ldl, int V, int* tokens, int ld_tokens, int B, int T,
                                 hipStream_t s, int dst_col = -1);

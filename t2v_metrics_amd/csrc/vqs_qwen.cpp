@@ -62,6 +62,12 @@ struct vqs_qwen_handle {
     // stage taps (vqs_qwen_debug_tap): point name -> (caller buffer, capacity); a pass copies the named intermediate there
     struct Tap { void* dst; size_t cap; };
     std::unordered_map<std::string, Tap> taps;
+    // 1 (default, round 5) = vqs_qwen_score / vqs_qwen_prefill re-evaluate every sample's LAST prompt position -- the one row that feeds the
+    // head -- layer by layer with 16 significant bits (split-bf16 operands as stacked rows of the same GEMMs, fp32 partial sums, fp32
+    // q and softmax over the layer's bf16 K / V) and take the logits from that row: the "precise tail" (tail_pass below; the analogue of the
+    // CLIP-FlanT5 row's precise decoder).  The error attribution (profiles/r5_qwen_error_attribution.md) puts two thirds of the row's
+    // |delta log P| into this one row's bf16 roundings.  0 = logits from the bf16 prefill's last row (rounds 2-4)
+    int tail_precise = 1;
 };
 
 namespace {
@@ -319,9 +325,30 @@ VisWs carve_vision(const vqs_qwen_handle* h, char* base, int N, int Np) {
     return w;
 }
 
+// K slices of a decode-step linear (decode_linear below): the fewest slices (a divisor of K / 64, <= 16) that put >= 192
+// (slice, 128-column) items on the chip -- a function of the weight's shape only.  carve_decode sizes the partial buffer with it.
+int decode_slices(int N, int K) {
+    const int nblk = (N + 127) / 128, nsl = K / 64;
+    if (nblk >= 192 || (K % 64) != 0) return 1;
+    int best = 1;
+    for (int s2 = 2; s2 <= 16; ++s2)
+        if (nsl % s2 == 0) {
+            best = s2;
+            if (nblk * s2 >= 192) break;
+        }
+    return best;
+}
+
+static constexpr int TAIL_ROWS = 64;      // samples per chunk of the precise tail: 2 x 64 stacked rows = the stream GEMM form's 128-row limit
 struct TxtWs {
     bf16_t *xn, *delta, *delta2, *q, *k, *v, *attn, *ff, *last;
     float* hidden;
+    // precise tail (vqs_qwen_handle::tail_precise): per-sample state for all B samples, chunk-sized operands
+    float *t_h, *t_delta;         // fp32 stream row and pending sub-layer output of every sample's last position [B, hidden]
+    float *t_qkv, *t_q;           // fp32 q|k|v row and rotated q of a chunk
+    bf16_t *t_xn, *t_attn, *t_ff; // split-bf16 operands of a chunk: planes [2][rows][width]
+    float* t_part;                // fp32 partials of a chunk's stacked launch
+    size_t t_part_bytes;
     size_t total;
 };
 TxtWs carve_text(const vqs_qwen_handle* h, char* base, int B, int L) {
@@ -339,6 +366,23 @@ TxtWs carve_text(const vqs_qwen_handle* h, char* base, int B, int L) {
     w.attn = cv.take<bf16_t>(M * h->t_iq);
     w.ff = cv.take<bf16_t>(M * h->t_ffld);
     w.last = cv.take<bf16_t>((size_t)B * c.t_hidden);
+    {   // precise tail: always laid out (a few hundred MB at 7B), so that the option can be toggled on a bound handle
+        const size_t Bc = (size_t)std::min(B, TAIL_ROWS), QN = (size_t)h->t_iq + 2 * h->t_ikv;
+        w.t_h = cv.take<float>((size_t)B * c.t_hidden);
+        w.t_delta = cv.take<float>((size_t)B * c.t_hidden);
+        w.t_qkv = cv.take<float>(Bc * QN);
+        w.t_q = cv.take<float>(Bc * h->t_iq);
+        w.t_xn = cv.take<bf16_t>(2 * Bc * c.t_hidden);
+        w.t_attn = cv.take<bf16_t>(2 * Bc * h->t_iq);
+        w.t_ff = cv.take<bf16_t>(2 * Bc * h->t_ffld);
+        size_t widest = (size_t)decode_slices((int)QN, c.t_hidden) * QN;
+        widest = std::max(widest, (size_t)decode_slices(c.t_hidden, h->t_iq) * c.t_hidden);
+        widest = std::max(widest, (size_t)decode_slices(2 * h->t_mlp_p, c.t_hidden) * 2 * h->t_mlp_p);
+        widest = std::max(widest, (size_t)decode_slices(c.t_hidden, h->t_ffld) * c.t_hidden);
+        widest = std::max(widest, (size_t)decode_slices(c.t_vocab, c.t_hidden) * c.t_vocab);
+        w.t_part_bytes = 2 * Bc * widest * sizeof(float);
+        w.t_part = cv.take<float>(2 * Bc * widest);
+    }
     w.total = align_up(cv.off);
     return w;
 }
@@ -422,6 +466,11 @@ int vqs_qwen_debug_option(vqs_qwen_handle* h, const char* name, int64_t value) {
         if (value < h->c.t_hidden || (value % 64) != 0 || value > 8 * (int64_t)h->c.t_hidden + 4096)
             return qfail(h, VQS_ERR_INVALID, "x_pitch: a multiple of 64 elements, >= hidden");
         h->t_xld = (int)value;
+        return VQS_OK;
+    }
+    if (std::string(name) == "tail_precise") {   // see vqs_qwen_handle::tail_precise
+        if (value != 0 && value != 1) return qfail(h, VQS_ERR_INVALID, "tail_precise: 0 or 1");
+        h->tail_precise = (int)value;
         return VQS_OK;
     }
     return qfail(h, VQS_ERR_INVALID, std::string("unknown option ") + name);
@@ -637,6 +686,87 @@ namespace {
 // KV cache: layer i holds K at slab 2i and V at slab 2i + 1, each [B, kv_heads, Lmax, 128] bf16 (K after the rotary embedding)
 inline size_t kv_slab(const vqs_qwen_handle* h, int B, int Lmax) { return (size_t)B * h->c.t_kv_heads * (size_t)Lmax * HDP; }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The precise tail (vqs_qwen_handle::tail_precise).  The reference reads ONE row of the prefill -- the logits of the last prompt position
+// (qwen2vl_model.py:222-301: scores[0] of generate) -- and in a decoder-only model that row's own 28-layer residual path feeds the head
+// directly, while every other row reaches it only through attention (averaged over ~800 keys).  So that one row per sample is evaluated
+// again, layer by layer next to the bf16 prefill, with 16 significant bits: RMSNorm outputs, the attention output and the gated product
+// are split-bf16 tensors (two bf16 planes, consumed as 2 x rows STACKED rows of the same GEMM over the same weights, fp32 partial sums
+// added afterwards), q|k|v, q after the rotary embedding, the softmax and the three sub-layer outputs stay fp32.  Its attention reads the
+// layer's K / V as the prefill left them (bf16, head-major, the row's own position included).  Same function as the prefill's last row
+// (HF Qwen2_5_VLDecoderLayer, modeling_qwen2_5_vl.py:720-787), evaluated closer to fp32 -- like the CLIP-FlanT5 row's precise decoder.
+// Cost: the language model's weights streamed once more per chunk of 64 samples (~1 % of the 7B pass at B = 64).
+// ---------------------------------------------------------------------------------------------------------------------------------
+// One nn.Linear of the tail: A2 = split-bf16 [2][rows][lda] (planes rows * lda apart) as 2 * rows stacked rows, K slices as batch
+// entries (decode_slices: the decode step's rule), fp32 partials, then launch_sum_planes adds planes and slices (+ bias / SiLU gate).
+int tail_linear(vqs_qwen_handle* h, const bf16_t* A2, int lda, const bf16_t* W, int ldw, const bf16_t* bias, int rows, int N, int K, int mode,
+                void* out, int ld_out, long long out_plane, const TxtWs& w, hipStream_t st, const char* what) {
+    const int sk = decode_slices(N, K);
+    if ((size_t)sk * 2 * rows * N * sizeof(float) > w.t_part_bytes) return qfail(h, VQS_ERR_WORKSPACE, std::string(what) + ": tail scratch too small");
+    vqs::GemmParams p{};
+    p.A = A2; p.W = W; p.C = w.t_part; p.bias = nullptr; p.resid = nullptr;
+    p.M = 2 * rows; p.N = N; p.K = K / sk; p.lda = lda; p.ldw = ldw; p.ldc = N;
+    p.S = 1; p.H = 0; p.inner = 1;
+    p.batch = sk; p.sA = K / sk; p.sW = K / sk; p.sC = (long long)2 * rows * N;
+    if (h->prof) {
+        while (h->ev.size() < h->ev_used + 2) {
+            hipEvent_t e;
+            QHIP(h, hipEventCreate(&e), "hipEventCreate");
+            h->ev.push_back(e);
+        }
+        QHIP(h, hipEventRecord(h->ev[h->ev_used], st), "hipEventRecord");
+    }
+    QHIP(h, vqs::launch_gemm(p, vqs::EPI_F32, 3, st), std::string("gemm ") + what);
+    if (h->prof) {
+        QHIP(h, hipEventRecord(h->ev[h->ev_used + 1], st), "hipEventRecord");
+        h->ev_used += 2;
+        h->prof_flops += 2.0 * 2.0 * (double)rows * (double)N * (double)K;
+        h->prof_bytes += 2.0 * (2.0 * (double)rows + (double)N) * (double)K + 4.0 * (double)sk * 2.0 * (double)rows * (double)N;
+    }
+    QHIP(h, vqs::launch_sum_planes(w.t_part, sk, (long long)2 * rows * N, rows, N, N, mode, out, ld_out, out_plane, st, bias,
+                                   mode == vqs::SUM_GATED_SPLIT ? 1 : 0), std::string("sum ") + what);
+    return VQS_OK;
+}
+
+// One decoder layer of the tail for every chunk of <= TAIL_ROWS samples; w.k / w.v hold THIS layer's K (rotated) and V of the prefill.
+int tail_layer(vqs_qwen_handle* h, const TxtWs& w, int i, const bf16_t* ln1, const bf16_t* ln2, const int32_t* d_seq_len, const int32_t* d_last_row,
+               const float* d_cos, const float* d_sin, int B, int L, bool first, hipStream_t st) {
+    const vqs_qwen_config& c = h->c;
+    const int TH = c.t_hidden, IQ = h->t_iq, IKV = h->t_ikv, QN = IQ + 2 * IKV;
+    const float scale = 1.0f / sqrtf((float)h->t_hd);
+    for (int c0 = 0; c0 < B; c0 += TAIL_ROWS) {
+        const int rows = std::min(TAIL_ROWS, B - c0);
+        float* th = w.t_h + (size_t)c0 * TH;
+        float* td = w.t_delta + (size_t)c0 * TH;
+        // ---- attention sub-layer
+        QHIP(h, vqs::launch_rmsnorm_split(th, first ? nullptr : td, ln1, w.t_xn, (long long)rows * TH, rows, TH, c.t_eps, st), "tail input_layernorm");
+        QRUN(tail_linear(h, w.t_xn, TH, h->t_qkv_w[i], TH, h->t_qkv_b[i], rows, QN, TH, vqs::SUM_F32, w.t_qkv, QN, 0, w, st, "tail qkv"));
+        QHIP(h, vqs::launch_qwen_tail_rope_q(w.t_qkv, QN, d_cos, d_sin, d_last_row + c0, w.t_q, rows, c.t_heads, HDP, h->t_hd / 2, st), "tail rope");
+        QHIP(h, vqs::launch_qwen_tail_attn(w.t_q, w.k + (size_t)c0 * L * IKV, w.v + (size_t)c0 * L * IKV, d_seq_len + c0, w.t_attn, (long long)rows * IQ, rows,
+                                           c.t_heads, c.t_kv_heads, L, scale, st), "tail attention");
+        QRUN(tail_linear(h, w.t_attn, IQ, h->t_o_w[i], IQ, nullptr, rows, TH, IQ, vqs::SUM_F32, td, TH, 0, w, st, "tail o_proj"));
+        // ---- gated FFN
+        QHIP(h, vqs::launch_rmsnorm_split(th, td, ln2, w.t_xn, (long long)rows * TH, rows, TH, c.t_eps, st), "tail post_attention_layernorm");
+        QHIP(h, hipMemsetAsync(w.t_ff, 0, (size_t)2 * rows * h->t_ffld * sizeof(bf16_t), st), "tail clear ff padding");
+        QRUN(tail_linear(h, w.t_xn, TH, h->t_gu_w[i], h->t_xld, nullptr, rows, 2 * h->t_mlp_p, TH, vqs::SUM_GATED_SPLIT, w.t_ff, h->t_ffld,
+                         (long long)rows * h->t_ffld, w, st, "tail gate|up"));
+        QRUN(tail_linear(h, w.t_ff, h->t_ffld, h->t_down_w[i], h->t_ffld, nullptr, rows, TH, h->t_ffld, vqs::SUM_F32, td, TH, 0, w, st, "tail down_proj"));
+    }
+    return VQS_OK;
+}
+
+// final norm + lm_head of the tail -> d_logits [B, vocab] fp32
+int tail_head(vqs_qwen_handle* h, const TxtWs& w, const bf16_t* fin, const bf16_t* head, float* d_logits, int B, hipStream_t st) {
+    const vqs_qwen_config& c = h->c;
+    const int TH = c.t_hidden;
+    for (int c0 = 0; c0 < B; c0 += TAIL_ROWS) {
+        const int rows = std::min(TAIL_ROWS, B - c0);
+        QHIP(h, vqs::launch_rmsnorm_split(w.t_h + (size_t)c0 * TH, w.t_delta + (size_t)c0 * TH, fin, w.t_xn, (long long)rows * TH, rows, TH, c.t_eps, st), "tail final norm");
+        QRUN(tail_linear(h, w.t_xn, TH, head, TH, nullptr, rows, c.t_vocab, TH, vqs::SUM_F32, d_logits + (size_t)c0 * c.t_vocab, c.t_vocab, 0, w, st, "tail lm_head"));
+    }
+    return VQS_OK;
+}
+
 // vqs_qwen_score / vqs_qwen_prefill: d_kv != nullptr also keeps every layer's K and V
 int score_impl(vqs_qwen_handle* h, const void* d_merged, const int32_t* d_input_ids, const int32_t* d_vis_slot,
                const int32_t* d_seq_len, const int32_t* d_last_row, const float* d_cos, const float* d_sin, int32_t B,
@@ -656,6 +786,9 @@ int score_impl(vqs_qwen_handle* h, const void* d_merged, const int32_t* d_input_
     QHIP(h, vqs::launch_qwen_embed(d_input_ids, d_vis_slot, embed, (const bf16_t*)d_merged, w.hidden, M, TH, c.t_vocab, st), "embed + splice");
     QHIP(h, hipMemsetAsync(w.ff, 0, (size_t)M * h->t_ffld * sizeof(bf16_t), st), "clear ff padding");
     QTAP("txt", -1, "emb", w.hidden, (size_t)M * TH);
+    const bool tail = h->tail_precise != 0 && (c.t_vocab % 4) == 0 && (c.t_hidden % 4) == 0;
+    if (tail)      // the tail's starting state: the embedding rows of the last positions (fp32 copies of bf16 values: exact)
+        QHIP(h, vqs::launch_gather_rows_f32(w.hidden, d_last_row, w.t_h, B, TH, TH, st), "tail embed rows");
 
     const bf16_t* pend = nullptr;
     const bf16_t* pend_attn = nullptr;   // attention delta the fp32 stream has not absorbed yet
@@ -693,6 +826,8 @@ int score_impl(vqs_qwen_handle* h, const void* d_merged, const int32_t* d_input_
             QHIP(h, vqs::launch_attention(a, st), "attention");
         }
         QTAP("txt", i, "attn", w.attn, (size_t)M * IQ);
+        if (tail)      // this layer's K / V are in w.k / w.v until the next layer's qkv launch
+            QRUN(tail_layer(h, w, i, ln1, ln2, d_seq_len, d_last_row, d_cos, d_sin, B, L, i == 0, st));
         {
             GCall g{w.attn, h->t_o_w[i], w.delta};
             g.M = M; g.N = TH; g.K = IQ; g.lda = IQ; g.ldw = IQ; g.ldc = TH; g.epi = vqs::EPI_BF16;
@@ -721,6 +856,10 @@ int score_impl(vqs_qwen_handle* h, const void* d_merged, const int32_t* d_input_
     QHIP(h, vqs::launch_rmsnorm(w.hidden, pend_attn ? pend_attn : pend, fin, w.xn, M, TH, c.t_eps, st, pend_attn ? pend : nullptr, true, XLD), "final norm");
     QTAP("txt", -1, "h_out", w.hidden, (size_t)M * TH);
     QRUN(qtap2d(h, "txt", -1, "xnf", w.xn, TH, M, XLD, st));
+    if (tail) {
+        QRUN(tail_head(h, w, fin, head, d_logits, B, st));
+        return VQS_OK;
+    }
     QHIP(h, vqs::launch_gather_rows_bf16(w.xn, nullptr, d_last_row, w.last, B, TH, XLD, TH, st), "last positions");
     {
         GCall g{w.last, head, d_logits};
@@ -738,20 +877,6 @@ struct DecWs {
     size_t part_bytes;
     size_t total;
 };
-// K slices of a decode-step linear (decode_linear below): the fewest slices (a divisor of K / 64, <= 16) that put >= 192
-// (slice, 128-column) items on the chip -- a function of the weight's shape only.  carve_decode sizes the partial buffer with it.
-int decode_slices(int N, int K) {
-    const int nblk = (N + 127) / 128, nsl = K / 64;
-    if (nblk >= 192 || (K % 64) != 0) return 1;
-    int best = 1;
-    for (int s2 = 2; s2 <= 16; ++s2)
-        if (nsl % s2 == 0) {
-            best = s2;
-            if (nblk * s2 >= 192) break;
-        }
-    return best;
-}
-
 DecWs carve_decode(const vqs_qwen_handle* h, char* base, int B) {
     const vqs_qwen_config& c = h->c;
     Carver cv{base};

@@ -73,6 +73,11 @@ class QwenEngine:
             torch.cuda.synchronize()
         self._ws = None
 
+    def set_option(self, name: str, value: int):
+        """Execution-form switches of include/vqs_qwen.h (vqs_qwen_debug_option): "tail_precise" 1 (default) = the logits come from the
+        precise re-evaluation of every sample's last prompt position, 0 = from the bf16 prefill's last row (rounds 2-4)."""
+        self._check(self.lib.vqs_qwen_debug_option(self._h, name.encode(), int(value)), "vqs_qwen_debug_option")
+
     def _check(self, rc, what):
         if rc != 0:
             raise VqsError(f"{what} failed ({rc}): {self.lib.vqs_qwen_last_error(self._h).decode()}")

@@ -126,6 +126,7 @@ def _stage_locked(tag, cfg, w, eng, px, grid, ids, mask, grids, vis_layers=None,
     from oracle.qwen25vl_engine_rounding import FP32_TAPS, QwenEngineRounded, text_tap_shapes, vision_tap_shapes
     from t2v_metrics_amd.qwen.layout import text_layout, vision_layout
     emu = QwenEngineRounded(cfg, {k: v.cpu() for k, v in w.items()}, acc=acc)
+    eng.set_option("tail_precise", 0)        # the launches checked here are the bf16 prefill's, its last row's logits included; the tail has its own tests
     reports = {}
     if px is not None:
         lay = vision_layout(cfg, [grid])
@@ -181,8 +182,112 @@ def _stage_locked(tag, cfg, w, eng, px, grid, ids, mask, grids, vis_layers=None,
     os.makedirs(out, exist_ok=True)
     with open(os.path.join(out, "stage_locked.jsonl"), "a") as f:
         f.write(json.dumps({"case": tag, "launch_outputs_checked": len(reports), "worst_by_kind": worst}) + "\n")
+    eng.set_option("tail_precise", 1)
     assert not bad, f"{len(bad)} of {len(reports)} launch outputs off: {bad[:6]}"
     return reports
+
+
+def _tail_reference(cfg, w, ids, mask, grids, emb_last, k_taps, v_taps):
+    """What the precise tail computes, in plain fp32 torch on the device: every sample's LAST prompt position through all layers -- its own
+    q, softmax and sub-layer outputs in fp32, attending over the ENGINE's K / V of each layer (bf16 tensors of the prefill, the row's own
+    position included) -- then the final norm and lm_head.  Formulas: oracle/qwen25vl_oracle.py (HF Qwen2_5_VLDecoderLayer :720-787)."""
+    from oracle.qwen25vl_oracle import rms_norm, rotate_half
+    from t2v_metrics_amd.qwen.layout import text_layout
+    import torch.nn.functional as F
+    t = cfg.text
+    B, L = ids.shape
+    lay = text_layout(cfg, ids, mask, grids)
+    last = lay["last_row"].long()                                                        # b * L + last index
+    hd, half = t.head_dim, t.head_dim // 2
+    cos, sin = lay["cos"].reshape(B * L, half)[last].cuda(), lay["sin"].reshape(B * L, half)[last].cuda()   # [B, half]
+    n = lay["seq_len"].long().cuda()
+    W = lambda name: w[name].float().cuda()
+    h = emb_last.float().cuda()
+    rep = t.heads // t.kv_heads
+    for i in range(t.layers):
+        p = f"model.language_model.layers.{i}."
+        x = rms_norm(h, W(p + "input_layernorm.weight"), t.rms_eps)
+        q = (x @ W(p + "self_attn.q_proj.weight").t() + W(p + "self_attn.q_proj.bias")).view(B, t.heads, hd)
+        a, b2 = q[..., :half], q[..., half:]
+        q = torch.cat([a * cos[:, None] - b2 * sin[:, None], b2 * cos[:, None] + a * sin[:, None]], -1)
+        K = k_taps[i].float().cuda()[..., :hd].repeat_interleave(rep, 1)                  # [B, H, L, hd]
+        V = v_taps[i].float().cuda()[..., :hd].repeat_interleave(rep, 1)
+        sc = torch.einsum("bhd,bhld->bhl", q, K) * hd ** -0.5
+        sc = sc.masked_fill(torch.arange(L, device="cuda")[None, None, :] >= n[:, None, None], float("-inf"))
+        o = torch.einsum("bhl,bhld->bhd", torch.softmax(sc, -1), V).reshape(B, -1)
+        h = h + o @ W(p + "self_attn.o_proj.weight").t()
+        x = rms_norm(h, W(p + "post_attention_layernorm.weight"), t.rms_eps)
+        h = h + (F.silu(x @ W(p + "mlp.gate_proj.weight").t()) * (x @ W(p + "mlp.up_proj.weight").t())) @ W(p + "mlp.down_proj.weight").t()
+    return rms_norm(h, W("model.language_model.norm.weight"), t.rms_eps) @ W("lm_head.weight").t()
+
+
+@pytest.mark.parametrize("name,fixture", [("qwen-tiny", "qwen_tiny"), ("qwen-small", "qwen_small"), ("qwen-tiny", "qwen_tiny_ragged")])
+def test_qwen_precise_tail_is_the_fp32_last_row_over_the_engines_kv(golden_dir, name, fixture):
+    """Option tail_precise (default 1): the logits are the last prompt position re-evaluated with 16 significant bits.  Check of its
+    arithmetic on the ENGINE's own inputs: an fp32 evaluation of that row over the K / V tensors the prefill produced (tapped, every layer)
+    must reproduce the engine's logits to split-bf16 accuracy (2^-16 per operand; bf16 operands would be 100 x off) -- on ragged batches
+    (different last positions, masked tails), padded heads and grouped-query heads; and against fp32 truth the tail is closer than the bf16
+    last row of rounds 2-4 on the same pass."""
+    from oracle.qwen25vl_oracle import QwenOracle
+    from t2v_metrics_amd.qwen.engine import QwenEngine
+    from t2v_metrics_amd.qwen.layout import text_layout
+    z = np.load(os.path.join(golden_dir, fixture + ".npz"))
+    cfg = get_qwen_config(name)
+    w = make_seeded_qwen_weights(cfg, seed=int(z["seed"]), dtype=torch.bfloat16, lm_head_gain=float(z["gain"]))
+    eng = QwenEngine(cfg, w)
+    grids = [tuple(int(x) for x in g) for g in z["grids"]]
+    ids, mask = torch.from_numpy(z["input_ids"]), torch.from_numpy(z["attention_mask"])
+    px = torch.from_numpy(z["pixel_values"])
+    merged, off = [], 0
+    for g in grids:
+        n = g[0] * g[1] * g[2]
+        merged.append(eng.encode_vision(px[off: off + n], [g]))
+        off += n
+    merged = torch.cat(merged)
+    B, L = ids.shape
+    t = cfg.text
+    kv_shape = (B, t.kv_heads, L, 128)
+    bufs = {}
+    for i in range(t.layers):
+        for nm in ("k", "v"):
+            bufs[f"txt.{i}.{nm}"] = torch.zeros(kv_shape, dtype=torch.bfloat16, device="cuda")
+    bufs["txt.emb"] = torch.zeros(B * L, t.hidden, dtype=torch.float32, device="cuda")
+    for nme, b in bufs.items():
+        eng.tap(nme, b)
+    assert True
+    logits_tail = eng.score_logits(merged, ids, mask, grids).float()
+    torch.cuda.synchronize()
+    eng.tap(None)
+    lay = text_layout(cfg, ids, mask, grids)
+    emb_last = bufs["txt.emb"][lay["last_row"].long().cuda()]
+    ref = _tail_reference(cfg, w, ids, mask, grids, emb_last, [bufs[f"txt.{i}.k"] for i in range(t.layers)], [bufs[f"txt.{i}.v"] for i in range(t.layers)])
+    top = float(ref.abs().max())
+    err_tail = float((logits_tail - ref).abs().max()) / top
+    eng.set_option("tail_precise", 0)
+    logits_bf16 = eng.score_logits(merged, ids, mask, grids).float()
+    torch.cuda.synchronize()
+    eng.set_option("tail_precise", 1)
+    again = eng.score_logits(merged, ids, mask, grids).float()
+    torch.cuda.synchronize()
+    assert torch.equal(again, logits_tail)                                               # bitwise repeatable, option restored
+    err_bf16 = float((logits_bf16 - ref).abs().max()) / top
+    # fp32 truth of the whole pass (host oracle): the tail is closer to it than the bf16 last row
+    truth = QwenOracle(cfg, w).forward(ids, mask, px.float(), grids)
+    lp_t, lp_b, lp_r = (torch.log_softmax(x.float().cpu(), -1) for x in (logits_tail, logits_bf16, truth))
+    top5 = lp_r.topk(5, -1).indices
+    e_t = (lp_t.gather(-1, top5) - lp_r.gather(-1, top5)).abs()
+    e_b = (lp_b.gather(-1, top5) - lp_r.gather(-1, top5)).abs()
+    import json
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_e2e.jsonl"), "a") as f:
+        f.write(json.dumps({"case": f"qwen-precise-tail/{fixture}", "tail_vs_fp32_last_row_over_engine_kv_rel": err_tail, "bf16_last_row_vs_same_rel": err_bf16,
+                            "dlogp_top5_vs_fp32_truth": {"tail": {"max": float(e_t.max()), "mean": float(e_t.mean())},
+                                                         "bf16_last_row": {"max": float(e_b.max()), "mean": float(e_b.mean())}}}) + "\n")
+    assert err_tail <= 6e-5, (err_tail, err_bf16)          # split-bf16 operands: 2^-16 relative per rounding, a few dozen roundings deep
+    assert err_bf16 > 5 * err_tail, (err_tail, err_bf16)   # the bf16 row is not this close: the check would notice a tail that silently ran in bf16
+    assert float(e_t.mean()) <= float(e_b.mean()) * 1.05 + 1e-4, (float(e_t.mean()), float(e_b.mean()))
+    eng.close()
 
 
 @pytest.mark.parametrize("name,fixture", [("qwen-tiny", "qwen_tiny"), ("qwen-small", "qwen_small"), ("qwen-tiny", "qwen_tiny_ragged")])

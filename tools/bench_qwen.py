@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--decode-steps", type=int, default=0, help="also time N cached decode steps behind one prefill (KV cache)")
     ap.add_argument("--parity-samples", type=int, default=0, help="|delta log P(answer)| of the first N samples against the fp32 oracle evaluated "
                     "in torch fp32 on the device (oracle/qwen25vl_oracle.py; 8 samples: ~3 s)")
+    ap.add_argument("--tail", type=int, default=1, help="option tail_precise (1 = the default: logits from the precise re-evaluation of the last position)")
     args = ap.parse_args()
     from t2v_metrics_amd.qwen.engine import QwenEngine
     cfg = get_qwen_config(args.model)
@@ -42,6 +43,7 @@ def main():
     t0 = time.perf_counter()
     w = make_seeded_qwen_weights(cfg, seed=0, device="cpu")
     eng = QwenEngine(cfg, w, device=dev)
+    eng.set_option("tail_precise", args.tail)
     t_init = time.perf_counter() - t0
     B = args.batch
     grid = (4, 24, 32)
@@ -84,7 +86,7 @@ def main():
            "config": {"workload": f"{cfg.name}, batch={B} x 8-frame 336x448 video (3072 patches -> 768 vision tokens) + 40 text tokens", "L": L},
            "algorithmic_tflop_per_sample": fl / 1e12, "model_tflops": B * args.steps / dt * fl / 1e12,
            "model_frac_of_mfma_peak": B * args.steps / dt * fl / 1e12 / 2500.0, "init_s": t_init,
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None}
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "tail_precise": args.tail}
     if n_gemm > 0 and gemm_ms > 0:
         ach = gemm_flops / (gemm_ms * 1e-3) / 1e12
         out["roofline"] = {"kernel": "vqs::gemm_bf16_quad + gemm_bf16_persistent (every GEMM launch of the step; "
