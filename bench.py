@@ -263,9 +263,9 @@ ALSO_LEGS = {
                   "shortest and longest batch (ragged prompts, padded and masked)"),
     "qwen": (["bench.py", "--model", "qwen2.5-vl-7b", "--steps", "3", "--warmup", "1", "--cpu-pairs", "0", "--also", "none", "--parity-only", "8"],
              "configs[4]: qwen2.5-vl-7b, 8-frame video samples; + |delta log P(answer)| of 8 samples against the fp32 oracle evaluated on the device"),
-    "bf16_operands": (["bench.py", "--steps", "3", "--warmup", "1", "--cpu-pairs", "0", "--also", "none", "--opt", "vit_fp16=0", "--opt", "enc_fp16=0", "--parity-only", "32"],
+    "bf16_operands": (["bench.py", "--steps", "3", "--warmup", "1", "--cpu-pairs", "0", "--also", "none", "--opt", "vit_fp16=0", "--opt", "enc_fp16=0", "--opt", "dec_fp16=0", "--parity-only", "32"],
                       "INFORMATIONAL, allowed to exceed the bound: the headline configuration with every 16-bit tensor of the vision tower and the T5 encoder "
-                      "in bf16 (options vit_fp16 = 0, enc_fp16 = 0: the reference's dtype, mm_utils.py:228; rounds 1-3's arithmetic there) -- throughput and "
+                      "in bf16 (options vit_fp16 = 0, enc_fp16 = 0, dec_fp16 = 0: the reference's dtype, mm_utils.py:228; rounds 1-3's arithmetic there) -- throughput and "
                       "the 32-pair |delta log P| table next to the main line's fp16 forms"),
     "pipeline": (["tools/bench_pipeline.py", "--model", "clip-flant5-xxl", "--pairs", "1280", "--reps", "1", "--host-slice", "8"],
                  "SURVEY 8f-1: VQAScoreModel.forward from 512x512 PNG files (decode, preprocessing, H2D, tokenisation, engine) on 1/8 of the "
@@ -573,6 +573,7 @@ def main():
     s_e = (jobs[0][2].shape[1] - 1 + cfg.vision.n_patches) if jobs else 0
     tower_fp16 = bool(eng.get_option("vit_fp16")) if hasattr(eng, "get_option") else False
     enc_fp16 = bool(eng.get_option("enc_fp16")) if hasattr(eng, "get_option") else False
+    dec_fp16 = bool(eng.get_option("dec_fp16") and eng.get_option("dec_precise") and eng.get_option("cross_mode")) if hasattr(eng, "get_option") else False
     out = {
         "metric": METRIC + cfg.name,
         "value": value,
@@ -585,8 +586,8 @@ def main():
         "scaling": info["scaling"],
         "vs_baseline": None,
         "dtype": ("bf16 (T5 GEMM operands; decoder activations split-bf16 / fp32)"
-                  + (" + fp16 (vision tower + projector" + (", T5 encoder attention side)" if enc_fp16 else ")") if tower_fp16
-                     else (" + fp16 (T5 encoder attention side)" if enc_fp16 else ""))
+                  + (" + fp16 (vision tower + projector" + (", T5 encoder attention side" if enc_fp16 else "") + (", decoder cross-attention score path" if dec_fp16 else "") + ")"
+                     if tower_fp16 else (" + fp16 (T5 encoder attention side)" if enc_fp16 else ""))
                   + ": 16-bit MFMA operands at one rate, fp32 accumulation"),
         "data": "synthetic (seeded 224x224 uint8 images resized to 336, seeded token ids, seeded random weights)"
                 if not double else "ENGINE DOUBLE -- harness self-test, not a measurement",
@@ -597,6 +598,8 @@ def main():
                                   + ("IEEE fp16 operands (option vit_fp16 = 1: 11 significant bits, same MFMA rate and bytes)" if tower_fp16 else "bf16 operands (option vit_fp16 = 0)")
                                   + "; T5 encoder attention side (norm outputs, q / k / v, probabilities, attention output; q|k|v, o, wi weights): "
                                   + ("IEEE fp16 (option enc_fp16 = 1), sub-layer outputs / FFN product / wo bf16" if enc_fp16 else "bf16 (option enc_fp16 = 0)")
+                                  + "; encoder output + decoder cross-attention score path (q, q.Wk, probabilities): "
+                                  + ("IEEE fp16 (option dec_fp16 = 1)" if dec_fp16 else "bf16 (option dec_fp16 = 0)")
                                   + "; fp32 accumulation, residual streams, statistics, softmax"),
                    **({"options": args.opt} if args.opt else {})},
         "ranks_seen": ranks_seen,

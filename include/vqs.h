@@ -222,6 +222,13 @@ int vqs_score_head(const float* d_logits, int32_t ldl, int32_t V, const int32_t*
  *                  too (the reference's dtype, rounds 1-4's encoder).  1 needs gemm_variant 3 and fused_norm 0.  Weight range as for
  *                  vit_fp16 (the Python binding checks at bind time); an activation that leaves the fp16 range turns into a non-finite
  *                  score, which vqs_score reports through its status word (flags bit 1) -- the binding raises and names this option.
+ *   "dec_fp16"     1 (default, round 5; effective with dec_precise = 1 and cross_mode = 1) the precise decoder's cross-attention SCORE path and
+ *                  what it attends over are IEEE fp16: the encoder's output (its final norm writes fp16), the cross q (from both planes of the
+ *                  split norm output, rounded once), q.Wk (fp16 copy of Wk^T, 0.8 GB at XXL), the probabilities; q.Wk, scores and P.E run the
+ *                  batched 8-wave / stream kernels' fp16 instantiations, P.E still leaves as a split-bf16 tensor.  The reassociated
+ *                  cross-attention makes the roundings of q.Wk and P coherent over all keys: these three bf16 roundings were most of the
+ *                  precise decoder's floor (profiles/r5_error_attribution_xxl.md).  0: bf16 there (round 4's precise decoder).  1 needs
+ *                  gemm_variant 3.  vqs_generate and the bf16 decoder always read a bf16 encoder output.
  *   "stream_gemm"  1 (default) skinny batched GEMMs (<= 128 rows per entry: the reassociated cross-attention's two products over
  *                  the encoder output) run the HBM-streaming form (csrc/gemm_stream.inc), 0 the persistent 256-row kernel;
  *                  bitwise equal

@@ -195,11 +195,13 @@ class EngineRoundedOracle(Oracle):
     ENC_FP16_CLASSES = ("enc.norm", "enc.qkv", "enc.p", "enc.attn")
     ENC_FP16_LINEARS = ("SelfAttention.q.weight", "SelfAttention.k.weight", "SelfAttention.v.weight", "SelfAttention.o.weight",
                         "DenseReluDense.wi_0.weight", "DenseReluDense.wi_1.weight")
+    # option dec_fp16: the encoder's output and the precise decoder's cross-attention score path in IEEE fp16
+    DEC_FP16_CLASSES = ("enc.out", "dec.cq", "dec.cqk", "dec.cprobs")
     DEC_SPLIT = ("dec.norm", "dec.sattn", "dec.cctx", "dec.cattn", "dec.act", "dec.out")
     DEC_FP32 = ("dec.qkv", "dec.delta")
 
     def __init__(self, cfg, weights, emulate="engine", round_fn=bf16_round, acc=torch.float64, classes=None, dec_precise=True,
-                 split_classes=(), half_classes=(), vit_fp16=True, device="cpu", enc_fp16=True):
+                 split_classes=(), half_classes=(), vit_fp16=True, device="cpu", enc_fp16=True, dec_fp16=True):
         """`split_classes`: classes (of the tower / projector / encoder) to model as split-bf16 tensors instead of bf16 ones -- a
         what-if for tools/error_attribution.py, nothing the engine does today; the extra name "vit.v" splits the value heads only
         (q and k stay bf16: the score path).  `half_classes`: classes to model as IEEE fp16 tensors (11 significant bits instead of
@@ -209,7 +211,10 @@ class EngineRoundedOracle(Oracle):
         output is rounded ONCE, from the fp32 accumulator to the C ABI's bf16 feature tensor (round 4 rounded to fp16 first).
         `enc_fp16` = the engine's option of that name (round 5, default 1): the ATTENTION SIDE of the T5 encoder -- both norm outputs, q / k / v,
         the probabilities, the attention output -- is IEEE fp16 and q / k / v / o / wi_0 / wi_1 are read as fp16 copies; the sub-layer outputs,
-        the gated product, the wo GEMM and the encoder's final output stay bf16 (vqs_api.cpp encoder_pass)."""
+        the gated product, the wo GEMM and the encoder's final output stay bf16 (vqs_api.cpp encoder_pass).
+        `dec_fp16` = the engine's option of that name (round 5, default 1; only with the precise decoder): the encoder's OUTPUT and the decoder's
+        cross-attention score path -- q (from the full split norm output, rounded once), q.Wk (fp16 copy of Wk), the probabilities -- are IEEE fp16
+        tensors; P.E runs on fp16 operands and still leaves as a split tensor (vqs_api.cpp decoder_pass_precise)."""
         super().__init__(cfg, weights, device=device)     # device != "cpu": the what-if runs of tools/error_attribution.py evaluated on the GPU (under `with torch.device(dev)`)
         self.r = round_fn
         self.acc = acc
@@ -231,6 +236,9 @@ class EngineRoundedOracle(Oracle):
         self.enc_fp16 = bool(enc_fp16)
         if self.enc_fp16:
             half_classes = tuple(half_classes) + self.ENC_FP16_CLASSES
+        self.dec_fp16 = bool(dec_fp16) and self.dec_precise
+        if self.dec_fp16:
+            half_classes = tuple(half_classes) + self.DEC_FP16_CLASSES
         self.half_extra = frozenset(half_classes)
         self.half_stacks = frozenset(c.split(".")[0] for c in self.half_extra)
         self.rh = (lambda x: x.to(torch.float16).to(torch.float32)) if round_fn is bf16_round else round_fn
@@ -409,9 +417,12 @@ class EngineRoundedOracle(Oracle):
         H, dk = t.heads, t.d_kv
         # precise decoder: the score path reads the HI plane of the split norm output (xn_hi = bf16 of the norm's fp32 result: what
         # it read before round 4).  Not bf16(hi + lo): lo is itself rounded and can land hi + lo exactly on a tie.
-        xq = xn if xn_hi is None else xn_hi
+        xq = xn if (xn_hi is None or self.dec_fp16) else xn_hi       # option dec_fp16: q from BOTH planes (stacked-plane GEMM), rounded once to fp16
         q = self._emit(n + "cq", rc("dec.cq", self._mm(xq, p + "q.weight"))).reshape(B, T, H, dk)
-        wk = self.w[p + "k.weight"].detach().to(self.device).to(self.acc).reshape(H, dk, D)
+        wk = self.w[p + "k.weight"].detach().to(self.device)
+        if self.dec_fp16:
+            wk = wk.to(torch.float16)               # the fp16 copy of Wk^T made at bind time
+        wk = wk.to(self.acc).reshape(H, dk, D)
         wv = self.w[p + "v.weight"].detach().to(self.device).to(self.acc).reshape(H, dk, D)
         qk = self._emit(n + "cqk", rc("dec.cqk", torch.einsum("bthd,hdD->bthD", q.to(self.acc), wk).float()))      # "cross q.Wk" -> bf16
         # the engine's score / probability rows are S_pad wide (keys >= S: zero-padded E^T columns; keys >= enc_len: masked)
@@ -494,7 +505,8 @@ class EngineRoundedOracle(Oracle):
         f32_names = {"cscores"} | ({"qkv", "d_self", "d_cross", "d_ff"} if self.dec_precise else set())
         for i in range(t.dec_layers):
             for nm in self.TAP_NAMES_DEC:
-                out[f"dec.{i}.{nm}"] = ((MT, width[nm]), "split" if nm in split else (f32 if nm in f32_names else bf))
+                d16 = torch.float16 if (self.dec_fp16 and nm in ("cq", "cqk", "cprobs")) else bf       # option dec_fp16: the score path's tensors
+                out[f"dec.{i}.{nm}"] = ((MT, width[nm]), "split" if nm in split else (f32 if nm in f32_names else d16))
         return out
 
     @staticmethod

@@ -786,6 +786,11 @@ __global__ void __launch_bounds__(256) sum_planes_kernel(const float* __restrict
         const float4 y = gather(c4 * 4);
         if (MODE == SUM_F32) {
             *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)r * ld_out + c4 * 4) = y;
+        } else if (MODE == SUM_F16) {
+            uint2 o;
+            o.x = e_pack2_h(y.x, y.y);
+            o.y = e_pack2_h(y.z, y.w);
+            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(out) + (size_t)r * ld_out + c4 * 4) = o;
         } else {
             bf16_t* oh = reinterpret_cast<bf16_t*>(out) + (size_t)r * ld_out + c4 * 4;
             e_split4_store(oh, oh + out_plane, y);
@@ -810,6 +815,7 @@ hipError_t launch_sum_planes(const float* part, int nslices, long long slice_str
         return hipGetLastError();
     }
     if (mode == SUM_F32) hipLaunchKernelGGL((sum_planes_kernel<SUM_F32>), grid, block, 0, s, part, nslices, slice_stride, rows, cols4, ldp, out, ld_out, out_plane);
+    else if (mode == SUM_F16) hipLaunchKernelGGL((sum_planes_kernel<SUM_F16>), grid, block, 0, s, part, nslices, slice_stride, rows, cols4, ldp, out, ld_out, out_plane);
     else if (mode == SUM_SPLIT) hipLaunchKernelGGL((sum_planes_kernel<SUM_SPLIT>), grid, block, 0, s, part, nslices, slice_stride, rows, cols4, ldp, out, ld_out, out_plane);
     else if (mode == SUM_GATED_SPLIT) hipLaunchKernelGGL((sum_planes_kernel<SUM_GATED_SPLIT>), grid, block, 0, s, part, nslices, slice_stride, rows, cols4, ldp, out, ld_out, out_plane);
     else return hipErrorInvalidValue;
@@ -1022,6 +1028,7 @@ hipError_t launch_transpose_pad(const bf16_t* in, bf16_t* out, int B, int S, int
 }
 
 // scores fp32 [B*rows, S_pad] -> probs bf16 [B*rows, S_pad]; one wave per row; keys >= key_len[b] get 0
+template <bool F16>      // F16: the probabilities leave as IEEE fp16 (the decoder's cross-attention of option dec_fp16), else bf16
 __global__ void __launch_bounds__(256) masked_softmax_kernel(const float* __restrict__ scores, bf16_t* __restrict__ probs,
                                                              const int* __restrict__ key_len, int rows, int S_pad,
                                                              int total_rows) {
@@ -1038,14 +1045,18 @@ __global__ void __launch_bounds__(256) masked_softmax_kernel(const float* __rest
     for (int j = lane; j < klen; j += 64) sm += __expf(sr[j] - mx);
     sm = wave_sum(sm);
     const float inv = sm > 0.0f ? 1.0f / sm : 0.0f;
-    for (int j = lane; j < S_pad; j += 64) pr[j] = j < klen ? e_f2bf(__expf(sr[j] - mx) * inv) : (bf16_t)0;
+    for (int j = lane; j < S_pad; j += 64) {
+        const float pv = j < klen ? __expf(sr[j] - mx) * inv : 0.0f;
+        if (F16) pr[j] = (bf16_t)(e_pack2_h(pv, 0.0f) & 0xffff);
+        else pr[j] = e_f2bf(pv);
+    }
 }
 
 hipError_t launch_masked_softmax(const float* scores, bf16_t* probs, const int* key_len, int B, int rows, int S_pad,
-                                 hipStream_t s) {
+                                 hipStream_t s, bool out_f16) {
     const int total = B * rows;
-    hipLaunchKernelGGL(masked_softmax_kernel, dim3((total + 3) / 4), dim3(256), 0, s, scores, probs, key_len, rows, S_pad,
-                       total);
+    if (out_f16) hipLaunchKernelGGL(masked_softmax_kernel<true>, dim3((total + 3) / 4), dim3(256), 0, s, scores, probs, key_len, rows, S_pad, total);
+    else hipLaunchKernelGGL(masked_softmax_kernel<false>, dim3((total + 3) / 4), dim3(256), 0, s, scores, probs, key_len, rows, S_pad, total);
     return hipGetLastError();
 }
 

@@ -29,6 +29,7 @@
 namespace vqs {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
@@ -386,7 +387,7 @@ __device__ __forceinline__ void st16(void* p, float4 v) { *reinterpret_cast<floa
 //   fp32 outputs : four passes of 32 rows x 256 B
 // LDS image: 16-B chunk index XOR-ed with the row (conflict-free b128 reads, <= 2-way writes).
 // ----------------------------------------------------------------------------------------------------
-template <int EPI>
+template <int EPI, bool OUT_F16 = false>      // OUT_F16: the 16-bit result is IEEE fp16 (GemmParams::f16 == 1; the persistent kernel's FT)
 __device__ __forceinline__ void staged_epilogue(const GemmParams& p, f32x16 (&acc)[4][2], char* reg, int m0, int n0, int bz,
                                                 int wr, int wc, int lane, bool full, float* rowred) {
     const int hh = lane >> 5, lr = lane & 31;
@@ -658,8 +659,8 @@ __device__ __forceinline__ void staged_epilogue(const GemmParams& p, f32x16 (&ac
                                 for (int e = 0; e < 4; ++e) o[e] = act_gelu_erf(o[e]);
                             }
                             uint2 v;
-                            v.x = pack2(o[0], o[1]);
-                            v.y = pack2(o[2], o[3]);
+                            v.x = OUT_F16 ? pack2h(o[0], o[1]) : pack2(o[0], o[1]);
+                            v.y = OUT_F16 ? pack2h(o[2], o[3]) : pack2(o[2], o[3]);
                             const int ch = n * 4 + g;         // 16-B chunk (8 bf16) within the 128-B row; hh picks its half
                             *reinterpret_cast<uint2*>(reg + r * 128 + ((ch ^ (r & 7)) << 4) + hh * 8) = v;
                         }
@@ -779,7 +780,9 @@ __device__ __forceinline__ v4i_t make_rsrc(const void* base) {
 // TOUCH (lab, VQS_L2_TOUCH): waves 0 and 4 pull the lines of the K-tile TWO ahead into L2 with one dword LDS-DMA per
 // K-tile (64 A rows / 32 W rows each: the 4 / 8 workgroups of an XCD's 8x4 tile window that share a panel split it), so
 // that the real staging DMA of an operand streamed from HBM finds it in L2.  A hint only: results are unaffected.
-template <int EPI, int TOUCH = 0>   // TOUCH: 0 off, 1 A and W panels, 2 A panel only
+// FT (round 5, GemmParams::f16; plain / fp32-result epilogues, TOUCH 0 only): 0 bf16 operands; 1 fp16 operands and fp16 result; 2 fp16 operands,
+// bf16 (or split-bf16) result -- the batched launches of the decoder's cross-attention score path under option dec_fp16.
+template <int EPI, int TOUCH = 0, int FT = 0>   // TOUCH: 0 off, 1 A and W panels, 2 A panel only
 __global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) {
     __shared__ __attribute__((aligned(16))) char lds[2 * STAGE_BYTES];
     __shared__ float rowred[EPI == EPI_RESID_RMS ? 1024 : 1];   // per-row partial sums of squares of the 4 wave columns
@@ -964,9 +967,14 @@ __global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) 
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
 #pragma unroll
-                    for (int n = 0; n < 2; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                            __builtin_bit_cast(bf16x8, wf[n]), __builtin_bit_cast(bf16x8, af[m]), acc[m][n], 0, 0, 0);
+                    for (int n = 0; n < 2; ++n) {
+                        if constexpr (FT != 0)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                                __builtin_bit_cast(f16x8_t, wf[n]), __builtin_bit_cast(f16x8_t, af[m]), acc[m][n], 0, 0, 0);
+                        else
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                __builtin_bit_cast(bf16x8, wf[n]), __builtin_bit_cast(bf16x8, af[m]), acc[m][n], 0, 0, 0);
+                    }
             }
             buf ^= 1;
         }
@@ -976,7 +984,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) 
         // cycles per tile; staged, every store instruction writes 8 full 128-B rows / 4 full 256-B rows.)
         const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
         __builtin_amdgcn_s_barrier();                       // every wave is done reading stage buf^1
-        staged_epilogue<EPI>(p, acc, lds + (buf ^ 1) * STAGE_BYTES + w * 8192, m0, n0, bz, wr, wc, lane, full, rowred);
+        staged_epilogue<EPI, FT == 1>(p, acc, lds + (buf ^ 1) * STAGE_BYTES + w * 8192, m0, n0, bz, wr, wc, lane, full, rowred);
         counted = full;
         if (!has_next) break;
         pid = next_pid;
@@ -1256,8 +1264,17 @@ static bool quad_eligible(const GemmParams& p) { return quad_eligible_rt(p, EPI)
 int gemm_form(const GemmParams& p, int epilogue, int variant) {
     if (p.f16)      // fp16 operands: the quad form only (every 16-bit-result linear of the vision tower, the projector and -- option enc_fp16 --
                     // the T5 encoder's attention side resolves to it); 1 = fp16 result (no gated epilogue), 2 = bf16 result (plain / gated only)
-        return (variant == 3 || variant == 10) && quad_eligible_rt(p, epilogue) &&
-                       (p.f16 == 1 ? epilogue != EPI_GATED : (p.f16 == 2 && (epilogue == EPI_BF16 || epilogue == EPI_GATED))) ? 10 : -1;
+    {
+        if ((variant == 3 || variant == 10) && quad_eligible_rt(p, epilogue))
+            return (p.f16 == 1 ? epilogue != EPI_GATED : (p.f16 == 2 && (epilogue == EPI_BF16 || epilogue == EPI_GATED))) ? 10 : -1;
+        // round 5: the batched / fp32-result launches of the decoder's cross-attention score path (option dec_fp16) -- plain epilogues of the
+        // stream form and of the persistent 8-wave kernel (bias-free, no row scale; fp32 result, fp16 result, bf16 / split-bf16 result)
+        if (variant != 3 || !(epilogue == EPI_BF16 || epilogue == EPI_F32) || p.bias != nullptr || p.rowss_in != nullptr) return -1;
+        if (p.f16 == 1 && p.split_off != 0) return -1;
+        if (stream_eligible(p, epilogue)) return 12;
+        const bool fit16 = (uint64_t)p.M * (uint64_t)p.lda * 2ull < (1ull << 32) && (uint64_t)p.N * (uint64_t)p.ldw * 2ull < (1ull << 32);
+        return fit16 ? 3 : -1;
+    }
     if (epilogue == EPI_RESID_RMS) variant = variant == 5 ? 5 : 3;
     const bool plain_v0 = !(p.hd > 64 || p.hd_src > 0 || p.inner_kv > 0 || p.Hkv > 0 || p.gate_act != 0 || (epilogue == EPI_GATED && p.bias != nullptr) || p.rowss_in != nullptr ||
                             p.split_off != 0) &&
@@ -1298,7 +1315,19 @@ static hipError_t launch_epi(const GemmParams& p, int variant, hipStream_t strea
     else if (form == 12) {
         if constexpr (EPI == EPI_F32 || EPI == EPI_BF16) {
             const int items = ((p.N + 127) / 128) * (p.batch > 0 ? p.batch : 1);
-            hipLaunchKernelGGL((gemm_bf16_stream<EPI>), dim3(items), dim3(256), 0, stream, p);
+            if (p.f16 == 1) hipLaunchKernelGGL((gemm_bf16_stream<EPI, 1>), dim3(items), dim3(256), 0, stream, p);
+            else if (p.f16 == 2) hipLaunchKernelGGL((gemm_bf16_stream<EPI, 2>), dim3(items), dim3(256), 0, stream, p);
+            else hipLaunchKernelGGL((gemm_bf16_stream<EPI>), dim3(items), dim3(256), 0, stream, p);
+        }
+    } else if (p.f16 != 0 && form == 3) {
+        // fp16 operands on the persistent 8-wave kernel (plain schedule, no touch): gemm_form let only EPI_BF16 / EPI_F32 through
+        if constexpr (EPI == EPI_F32 || EPI == EPI_BF16) {
+            const int nwg = tiles_m * tiles_n * (p.batch > 0 ? p.batch : 1);
+            dim3 pgrid(nwg < PERSISTENT_WGS ? nwg : PERSISTENT_WGS);
+            if (p.f16 == 1) hipLaunchKernelGGL((gemm_bf16_persistent<EPI, 0, 1>), pgrid, block, 0, stream, p);
+            else hipLaunchKernelGGL((gemm_bf16_persistent<EPI, 0, 2>), pgrid, block, 0, stream, p);
+        } else {
+            return hipErrorInvalidValue;
         }
     } else if (form == 10) {
         // quad form (gemm_quad.inc): every bf16-result launch of a call site, WHATEVER its M -- the form's k-order differs from the

@@ -60,6 +60,14 @@ struct vqs_handle {
                           // modeling_t5.py _keep_in_fp32_modules); the residual stream is fp32 here anyway.  Same MFMA rate, same bytes, three more
                           // significant bits on five of the encoder's seven 16-bit tensor classes (profiles/r5_error_attribution_xxl.md).  0 = bf16
     std::vector<const bf16_t*> enc_qkv16, enc_o16, enc_wi16;   // the fp16 copies (packed buffer)
+    int dec_fp16 = 1;     // 1 (default, round 5; effective with dec_precise = 1 and cross_mode = 1) = the precise decoder's cross-attention SCORE path
+                          // and the tensor it attends over are IEEE fp16: the encoder's output E (its final norm writes fp16), the cross q (from BOTH
+                          // planes of the split norm output, rounded once to fp16), q.Wk (fp16 copy of Wk^T), the probabilities; the three products
+                          // q.Wk, (q.Wk).E^T and P.E run on fp16 MFMAs (the batched 8-wave and stream kernels' fp16 instantiations), P.E still leaves as
+                          // a split-bf16 tensor.  The reassociated cross-attention makes the rounding of q.Wk and of P COHERENT over all ~600 keys,
+                          // which is why these three bf16 roundings were most of the precise decoder's floor (profiles/r5_error_attribution_xxl.md).
+                          // 0 = bf16 there (round 4's precise decoder).  vqs_generate and dec_precise = 0 / cross_mode = 0 always run bf16.
+    std::vector<const bf16_t*> dec_ckT16;                      // fp16 copies of Wk^T (packed buffer)
     const int* lut_bidir = nullptr;
     const int* lut_causal = nullptr;
     int lut_len = 0;
@@ -232,6 +240,7 @@ struct PackedLayout {
     std::vector<size_t> vit_qkv_w16, vit_out_w16, vit_fc1_w16, vit_fc2_w16;    // fp16 copies for option vit_fp16 (always laid out: 0.45 GB for ViT-L)
     size_t proj0_w16, proj2_w16;
     std::vector<size_t> enc_qkv16, enc_o16, enc_wi16;                          // fp16 copies for option enc_fp16 (always laid out: 7.2 GB at XXL, 1.9 GB at XL)
+    std::vector<size_t> dec_ckT16;                                             // fp16 copies of Wk^T for option dec_fp16 (0.8 GB at XXL)
     size_t lut_bidir, lut_causal;
     size_t total;
 };
@@ -275,6 +284,7 @@ PackedLayout packed_layout(const vqs_handle* h) {
         pl.enc_o16.push_back(take(D * I));
         pl.enc_wi16.push_back(take(2 * F * D));
     }
+    for (int i = 0; i < c.dec_layers; ++i) pl.dec_ckT16.push_back(take(I * D));
     pl.lut_bidir = take(2 * (size_t)(c.rel_max_distance + 1));   // int32 = 2 bf16 slots each
     pl.lut_causal = take(2 * (size_t)(c.rel_max_distance + 1));
     pl.total = align_up(cv.off);
@@ -463,6 +473,8 @@ int vqs_debug_gemm_batched(const void* A, const void* W, void* C, int32_t M, int
     p.S = 1; p.H = 0; p.inner = 1;
     p.batch = batch; p.sA = sA; p.sW = sW; p.sC = sC;
     p.split_off = split_off; p.no_stream = no_stream;
+    p.f16 = (variant >> 27) & 3;           // bits 27-28 of `variant`, as in vqs_gemm: 0 bf16, 1 fp16 operands and result, 2 fp16 operands / bf16 (split) result
+    if (p.f16 == 3) return VQS_ERR_INVALID;
     return vqs::launch_gemm(p, epilogue, variant & 0xff, (hipStream_t)stream) == hipSuccess ? VQS_OK : VQS_ERR_HIP;
 }
 
@@ -567,6 +579,7 @@ int vqs_set_option(vqs_handle* h, const char* name, int32_t value) {
     else if (n == "dec_precise" && (value == 0 || value == 1)) h->dec_precise = value;
     else if (n == "vit_fp16" && (value == 0 || value == 1)) h->vit_fp16 = value;
     else if (n == "enc_fp16" && (value == 0 || value == 1)) h->enc_fp16 = value;
+    else if (n == "dec_fp16" && (value == 0 || value == 1)) h->dec_fp16 = value;
     else if (n == "stream_gemm" && (value == 0 || value == 1)) h->stream_gemm = value;
     else if (n == "gemm_variant" && (value == 0 || value == 2 || value == 3 || value == 5 || value == 11)) h->gemm_variant = value;
     else if (n.rfind("l2_touch:", 0) == 0 || n.rfind("nt_store:", 0) == 0 || n.rfind("tile_order:", 0) == 0) {
@@ -608,6 +621,7 @@ int vqs_get_option(const vqs_handle* h, const char* name, int32_t* value) {
     else if (n == "dec_precise") *value = h->dec_precise;
     else if (n == "vit_fp16") *value = h->vit_fp16;
     else if (n == "enc_fp16") *value = h->enc_fp16;
+    else if (n == "dec_fp16") *value = h->dec_fp16;
     else if (n == "stream_gemm") *value = h->stream_gemm;
     else if (n == "gemm_variant") *value = h->gemm_variant;
     else return VQS_ERR_INVALID;
@@ -699,7 +713,7 @@ int vqs_bind_weights(vqs_handle* h, const vqs_weight_desc* weights, int32_t n, v
         HIPCHK(h, vqs::launch_interleave_gate(w0, w1, dst, F, D, st), "pack wi");
         return VQS_OK;
     };
-    h->enc_qkv16.clear(); h->enc_o16.clear(); h->enc_wi16.clear();
+    h->enc_qkv16.clear(); h->enc_o16.clear(); h->enc_wi16.clear(); h->dec_ckT16.clear();
     h->enc_qkv.clear(); h->enc_wi.clear(); h->dec_qkv.clear(); h->dec_ckv.clear(); h->dec_wi.clear(); h->dec_ckT.clear();
     for (int i = 0; i < c.enc_layers; ++i) {
         const std::string p = "encoder.block." + std::to_string(i) + ".";
@@ -727,6 +741,8 @@ int vqs_bind_weights(vqs_handle* h, const vqs_weight_desc* weights, int32_t n, v
             GETW(wk, p + "layer.1.EncDecAttention.k.weight", (int64_t)I * D);
             HIPCHK(h, vqs::launch_transpose(wk, at(pl.dec_ckT[i]), I, D, st), "pack cross k^T");
             h->dec_ckT.push_back(at(pl.dec_ckT[i]));
+            HIPCHK(h, vqs::launch_cast16(at(pl.dec_ckT[i]), at(pl.dec_ckT16[i]), (size_t)I * D, true, st), "fp16 cross k^T");
+            h->dec_ckT16.push_back(at(pl.dec_ckT16[i]));
         }
         h->dec_wi.push_back(at(pl.dec_wi[i]));
     }
@@ -892,8 +908,9 @@ size_t vqs_score_workspace_bytes(const vqs_handle* h, int32_t B, int32_t L, int3
 
 // Encoder half of the scoring pass: prompt scan, bias table, embed + splice, 24 encoder blocks, final norm
 // (+ the transposed copy the reassociated cross-attention reads).  Leaves enc_out / enc_outT / enc_len in the workspace.
+// e_out_f16: the encoder's output (enc_out / enc_outT) leaves as IEEE fp16 instead of bf16 -- what the precise decoder of option dec_fp16 reads
 static int encoder_pass(vqs_handle* h, const ScoreWs& w, const void* d_feats, const int32_t* d_img_index,
-                        const int32_t* d_input_ids, int B, int L, hipStream_t st) {
+                        const int32_t* d_input_ids, int B, int L, hipStream_t st, bool e_out_f16 = false) {
     const int T = 1;
     const vqs_config& c = h->c;
     const int P = h->P, S = L - 1 + P;
@@ -1019,9 +1036,9 @@ static int encoder_pass(vqs_handle* h, const ScoreWs& w, const void* d_feats, co
     {
         GETW(fin, "encoder.final_layer_norm.weight", D);
         if (pend_attn)
-            HIPCHK(h, vqs::launch_rmsnorm(w.hidden, pend_attn, fin, w.enc_out, M, D, c.t5_ln_eps, st, pend), "enc final norm");
+            HIPCHK(h, vqs::launch_rmsnorm(w.hidden, pend_attn, fin, w.enc_out, M, D, c.t5_ln_eps, st, pend, true, 0, e_out_f16), "enc final norm");
         else
-            HIPCHK(h, vqs::launch_rmsnorm(w.hidden, pend, fin, w.enc_out, M, D, c.t5_ln_eps, st), "enc final norm");
+            HIPCHK(h, vqs::launch_rmsnorm(w.hidden, pend, fin, w.enc_out, M, D, c.t5_ln_eps, st, nullptr, true, 0, e_out_f16), "enc final norm");
         if (h->cross_mode != 0)
             HIPCHK(h, vqs::launch_transpose_pad(w.enc_out, w.enc_outT, B, S, D, w.S_pad, st), "enc_out transpose");
     }
@@ -1232,6 +1249,7 @@ static int decoder_pass(vqs_handle* h, const ScoreWs& w, const int32_t* d_labels
 // tensors to bf16 (mm_utils.py:228), so this is a deviation TOWARDS fp32 arithmetic, like the fp32 residual stream.
 static int decoder_pass_precise(vqs_handle* h, const ScoreWs& w, const int32_t* d_labels, int ld_labels, int B, int L, int T, hipStream_t st) {
     const vqs_config& c = h->c;
+    const bool x16 = h->dec_fp16 != 0;      // the encoder pass before this call wrote enc_out / enc_outT as fp16 tensors (vqs_score)
     const int P = h->P, S = L - 1 + P;
     const int D = c.d_model, I = h->I, F = c.d_ff, H = c.n_heads, V = c.vocab;
     const int MT = B * T;
@@ -1276,13 +1294,18 @@ static int decoder_pass_precise(vqs_handle* h, const ScoreWs& w, const int32_t* 
         // ---- cross-attention (reassociated, vqs_api.cpp decoder_pass): score path in bf16 off the hi plane, value path precise
         HIPCHK(h, vqs::launch_rmsnorm_split(w.dhid, w.ddelta32, ln1, w.dxn, pD, MT, D, c.t5_ln_eps, st), "dec rmsnorm1");
         TAP2("dec", i, "xn1", w.dxn, pD);
-        RUN(dec_linear(h, w.dxn, cq, w.dq, MT, I, D, scratch, sb, st, "dec cross q"));
+        // option dec_fp16 (x16): q from BOTH planes of the split norm output, rounded once to fp16; q.Wk, the probabilities and E are fp16 tensors
+        if (x16)
+            RUN(dec_linear_split(h, w.dxn, cq, MT, I, D, scratch, sb, vqs::SUM_F16, w.dq, I, 0, st, "dec cross q"));
+        else
+            RUN(dec_linear(h, w.dxn, cq, w.dq, MT, I, D, scratch, sb, st, "dec cross q"));
         TAP("dec", i, "cq", w.dq, (size_t)MT * I);
         const int R = T * H;        // rows per pair, ordered (t, h)
         {   // q'[(b,t), h, :] = q[(b,t), h*64:(h+1)*64] . Wk_h            batched over heads
-            GemmCall g{w.dq, h->dec_ckT[i], w.cqk};
+            GemmCall g{w.dq, x16 ? h->dec_ckT16[i] : h->dec_ckT[i], w.cqk};
             g.M = MT; g.N = D; g.K = 64; g.lda = I; g.ldw = I; g.ldc = H * D; g.epi = vqs::EPI_BF16;
             g.batch = H; g.sA = 64; g.sW = 64; g.sC = D;
+            g.f16 = x16 ? 1 : 0;
             RUN(run_gemm(h, g, st, "cross q.Wk"));
             TAP("dec", i, "cqk", w.cqk, (size_t)MT * H * D);
         }
@@ -1290,16 +1313,18 @@ static int decoder_pass_precise(vqs_handle* h, const ScoreWs& w, const int32_t* 
             GemmCall g{w.cqk, w.enc_out, w.cscores};
             g.M = R; g.N = S; g.K = D; g.lda = D; g.ldw = D; g.ldc = w.S_pad; g.epi = vqs::EPI_F32;
             g.batch = B; g.sA = (long long)R * D; g.sW = (long long)S * D; g.sC = (long long)R * w.S_pad;
+            g.f16 = x16 ? 1 : 0;
             RUN(run_gemm(h, g, st, "cross scores"));
             TAP("dec", i, "cscores", w.cscores, (size_t)MT * H * w.S_pad);
         }
-        HIPCHK(h, vqs::launch_masked_softmax(w.cscores, w.cprobs, w.enc_len, B, R, w.S_pad, st), "cross softmax");
+        HIPCHK(h, vqs::launch_masked_softmax(w.cscores, w.cprobs, w.enc_len, B, R, w.S_pad, st, x16), "cross softmax");
         TAP("dec", i, "cprobs", w.cprobs, (size_t)MT * H * w.S_pad);
         {   // ctx[b] [R, D] = P[b] [R, S_pad] . E[b]   -> split-bf16: hi plane = the tensor of rounds 1-3, lo plane behind it
             GemmCall g{w.cprobs, w.enc_outT, w.cctx};
             g.M = R; g.N = D; g.K = w.S_pad; g.lda = w.S_pad; g.ldw = w.S_pad; g.ldc = D; g.epi = vqs::EPI_BF16;
             g.batch = B; g.sA = (long long)R * w.S_pad; g.sW = (long long)D * w.S_pad; g.sC = (long long)R * D;
             g.split_off = pC;
+            g.f16 = x16 ? 2 : 0;          // fp16 operands (P, E^T), split-bf16 result
             g.no_stream = 1;      // K = S_pad = 640: ten slabs per item -- the stream form's pipeline fill per item costs more than its
                                   // deeper ring gains (0.50 vs 0.41 ms per launch, profiles/r4_call4_*); the scores launch (K = D) streams
             RUN(run_gemm(h, g, st, "cross P.E"));
@@ -1352,8 +1377,11 @@ int vqs_score(vqs_handle* h, const void* d_feats, const int32_t* d_img_index, co
     hipStream_t st = (hipStream_t)stream;
     const int V = c.vocab;
 
-    RUN(encoder_pass(h, w, d_feats, d_img_index, d_input_ids, B, L, st));
-    if (h->dec_precise && h->cross_mode != 0)
+    const bool precise = h->dec_precise && h->cross_mode != 0;
+    if (precise && h->dec_fp16 && h->gemm_variant != 3)
+        return fail(h, VQS_ERR_STATE, "score: the fp16 cross-attention score path (option dec_fp16, default 1) needs gemm_variant 3; set dec_fp16=0 to A/B other GEMM forms");
+    RUN(encoder_pass(h, w, d_feats, d_img_index, d_input_ids, B, L, st, precise && h->dec_fp16 != 0));
+    if (precise)
         RUN(decoder_pass_precise(h, w, d_labels, T, B, L, T, st));
     else                                             // bf16 decoder of rounds 1-3 (option dec_precise=0, or the direct cross-attention form)
         RUN(decoder_pass(h, w, d_labels, T, B, L, T, st));

@@ -270,7 +270,7 @@ hipError_t launch_rmsnorm_split(float* x, const float* delta, const bf16_t* w, b
 //   y[r][c] = (sum_k part[k][r][c]) + (sum_k part[k][rows + r][c])   -- hi rows first, slices in index order (deterministic)
 // mode 0: out fp32 [rows, ld_out] = y;  mode 1: out = split(y), planes [rows, cols] at out and out + out_plane (ld_out = cols);
 // mode 2: cols = 2F in the packed wi order (blocks of 32 gate | 32 linear columns): out = split(gelu_new(gate) * linear), [rows, F] planes
-enum SumPlanesMode : int { SUM_F32 = 0, SUM_SPLIT = 1, SUM_GATED_SPLIT = 2 };
+enum SumPlanesMode : int { SUM_F32 = 0, SUM_SPLIT = 1, SUM_GATED_SPLIT = 2, SUM_F16 = 3 };   // SUM_F16: out IEEE fp16 [rows, ld_out] = y (one rounding)
 // out bf16 [rows, ld_out] = f(sum of fp32 partial slices (+ bias)); gated: packed gate|up columns -> SiLU(gate) * up  (elementwise.hip)
 hipError_t launch_reduce_slices_act(const float* part, int nslices, long long slice_stride, int rows, int cols, int ldp, const bf16_t* bias,
                                     int gated, bf16_t* out, int ld_out, hipStream_t s);
@@ -289,7 +289,7 @@ hipError_t launch_score_head(const float* logits, int ldl, int V, const int* lab
 // reassociated decoder cross-attention helpers
 hipError_t launch_transpose_pad(const bf16_t* in, bf16_t* out, int B, int S, int D, int S_pad, hipStream_t s);
 hipError_t launch_masked_softmax(const float* scores, bf16_t* probs, const int* key_len, int B, int rows, int S_pad,
-                                 hipStream_t s);
+                                 hipStream_t s, bool out_f16 = false);
 hipError_t launch_transpose(const bf16_t* in, bf16_t* out, int rows, int cols, hipStream_t s);
 // weight packing helpers (bind time)
 hipError_t launch_copy_rows(const bf16_t* src, bf16_t* dst, int rows, int cols, int src_ld, int dst_ld,

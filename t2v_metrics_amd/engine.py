@@ -266,6 +266,7 @@ class VqsEngine:
             rc = self.lib.vqs_score(self._h, feats.data_ptr(), idx.data_ptr(), ids.data_ptr(), lab.data_ptr(), B, L, T,
                                     lp.data_ptr(), sc.data_ptr(), self._ws.data_ptr(), self._ws.numel(), _stream_ptr())
             self._check(rc, "vqs_score")
+            self._enc_out_f16 = bool(self.get_option("dec_precise") and self.get_option("cross_mode") and self.get_option("dec_fp16"))
             return lp, sc
 
     def normalize_u8(self, x_u8: torch.Tensor, mean, std) -> torch.Tensor:
@@ -294,6 +295,7 @@ class VqsEngine:
             rc = self.lib.vqs_generate(self._h, feats.data_ptr(), idx.data_ptr(), ids.data_ptr(), B, L, max_new_tokens,
                                        tokens.data_ptr(), self._ws.data_ptr(), self._ws.numel(), _stream_ptr())
             self._check(rc, "vqs_generate")
+            self._enc_out_f16 = False          # generation runs the bf16 decoder over a bf16 encoder output
             return tokens
 
     # ------------------------------------------------------------------ introspection (tests / bench)
@@ -316,7 +318,9 @@ class VqsEngine:
         if name == "enc_in":
             return self._ws[off: off + 4 * B * S * t5.d_model].view(torch.float32).view(B, S, t5.d_model)
         if name == "enc_out":
-            return self._ws[off: off + 2 * B * S * t5.d_model].view(torch.bfloat16).view(B, S, t5.d_model)
+            # IEEE fp16 when the last call was a scoring pass of the precise decoder with option dec_fp16 (default), bf16 otherwise
+            dt = torch.float16 if getattr(self, "_enc_out_f16", False) else torch.bfloat16
+            return self._ws[off: off + 2 * B * S * t5.d_model].view(dt).view(B, S, t5.d_model)
         if name == "dec_out":
             # the final norm's output is a split-bf16 tensor (planes hi | lo) under the precise decoder: its value is hi + lo;
             # the bf16 decoder (option dec_precise=0, vqs_generate) writes plane 0 only
@@ -420,14 +424,18 @@ def gemm(A, W, epilogue: int, bias=None, resid=None, out=None, S: int = 0, H: in
     return out
 
 
-def gemm_batched(A, W, epilogue: int, split: bool = False, no_stream: bool = False, variant: int = 3, ldc: int = None):
+def gemm_batched(A, W, epilogue: int, split: bool = False, no_stream: bool = False, variant: int = 3, ldc: int = None, ftype: int = 0):
     """Test hook (vqs_debug_gemm_batched): C[z] = A[z] @ W[z].T for A [Z, M, K] bf16 (any row stride), W [Z, N, K] bf16, epilogue 3
-    (fp32) or 0 (bf16; split=True also returns the lo plane of the split-bf16 result).  -> C [Z, M, ldc] (and lo)."""
+    (fp32) or 0 (bf16; split=True also returns the lo plane of the split-bf16 result).  -> C [Z, M, ldc] (and lo).
+    ftype (bits 27-28 of the variant word): 1 = fp16 operands (and an fp16 result for epilogue 0), 2 = fp16 operands, bf16 / split-bf16 result."""
     lib = load_library()
     Z, M, K = A.shape
     N = W.shape[1]
     ldc = N if ldc is None else ldc
-    dt = torch.float32 if epilogue == 3 else torch.bfloat16
+    if A.dtype != (torch.float16 if ftype else torch.bfloat16) or W.dtype != A.dtype:
+        raise VqsError("gemm_batched: operand dtype does not match ftype")
+    variant |= (int(ftype) & 3) << 27
+    dt = torch.float32 if epilogue == 3 else (torch.float16 if ftype == 1 else torch.bfloat16)
     out = torch.zeros((2 if split else 1), Z, M, ldc, dtype=dt, device=A.device)
     rc = lib.vqs_debug_gemm_batched(A.data_ptr(), W.data_ptr(), out.data_ptr(), M, N, K, A.stride(1), W.stride(1), ldc, epilogue, Z,
                                     A.stride(0), W.stride(0), M * ldc, (Z * M * ldc) if split else 0, 1 if no_stream else 0, variant,

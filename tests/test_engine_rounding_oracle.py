@@ -45,8 +45,11 @@ def test_with_roundings_it_sits_at_the_bf16_floor_and_dispatches_from_oracle(nam
     out = emu.forward(pix.float(), idx, ids, labels, return_stages=True)
     d = (out["label_logprobs"] - ref).abs().max().item()
     assert 1e-5 < d < 8e-2, d                    # roundings are really applied, and only roundings
-    for k in ("proj", "enc_out"):                                # bf16-held tensors are exactly representable
-        assert torch.equal(out[k], bf16_round(out[k])), k
+    assert torch.equal(out["proj"], bf16_round(out["proj"]))     # the feature tensor of the C ABI is bf16: exactly representable
+    # the encoder's output is an fp16 tensor under option dec_fp16 (the default), a bf16 one without it
+    assert emu.dec_fp16 and torch.equal(out["enc_out"], out["enc_out"].half().float()) and not torch.equal(out["enc_out"], bf16_round(out["enc_out"]))
+    no_x16 = EngineRoundedOracle(cfg, w, dec_fp16=False).forward(pix.float(), idx, ids, labels, return_stages=True)
+    assert torch.equal(no_x16["enc_out"], bf16_round(no_x16["enc_out"]))
     assert emu.vit_fp16 and torch.equal(out["vit_feats"], out["vit_feats"].half().float())     # the tower ships in fp16 (option vit_fp16 = 1)
     bf_tower = EngineRoundedOracle(cfg, w, vit_fp16=False).forward(pix.float(), idx, ids, labels, return_stages=True)
     assert torch.equal(bf_tower["vit_feats"], bf16_round(bf_tower["vit_feats"]))               # rounds 1-3's tower: bf16
@@ -142,12 +145,13 @@ def test_fp16_tower_mode_is_the_same_function_with_finer_roundings(name):
     assert (hf["proj"] - ref["proj"]).abs().mean().item() < (bf["proj"] - ref["proj"]).abs().mean().item()
     # taps: the tower's 16-bit tensors are fp16, everything else what it was
     shapes = emu.tap_shapes(pix.shape[0], ids.shape[0], ids.shape[1], labels.shape[1])
-    base = EngineRoundedOracle(cfg, w, vit_fp16=False, enc_fp16=False).tap_shapes(pix.shape[0], ids.shape[0], ids.shape[1], labels.shape[1])
+    base = EngineRoundedOracle(cfg, w, vit_fp16=False, enc_fp16=False, dec_fp16=False).tap_shapes(pix.shape[0], ids.shape[0], ids.shape[1], labels.shape[1])
     assert set(shapes) == set(base)
     for n in shapes:
         tower16 = n.startswith("vit.") and n not in ("vit.patch_out", "vit.h0")
         enc16 = n.startswith("enc.") and n.split(".")[-1] in ("xn0", "q", "k", "v", "attn", "xn1")      # option enc_fp16 (default): the attention side
-        assert shapes[n][0] == base[n][0] and shapes[n][1] == (torch.float16 if (tower16 or enc16) else base[n][1]), n
+        dec16 = n.startswith("dec.") and n.split(".")[-1] in ("cq", "cqk", "cprobs")                    # option dec_fp16 (default): the cross score path
+        assert shapes[n][0] == base[n][0] and shapes[n][1] == (torch.float16 if (tower16 or enc16 or dec16) else base[n][1]), n
     hi = {n: rec.pop(n) for n in list(rec) if n.endswith("#hi")}
     taps = {n: (rec[n].reshape(shapes[n][0]) if n in shapes and shapes[n][1] == "split" else rec[n].reshape(shapes[n][0]).to(shapes[n][1]) if n in shapes else rec[n])
             for n in rec}
@@ -155,7 +159,8 @@ def test_fp16_tower_mode_is_the_same_function_with_finer_roundings(name):
     report, lp = emu.forward_locked(taps, pix.float(), idx, ids, labels)
     assert all(r["max_abs"] == 0.0 for r in report.values()), {n: r for n, r in report.items() if r["max_abs"] > 0}
     assert torch.equal(lp, hf["label_logprobs"])
-    assert sum(r["mant_bits"] == 10 for r in report.values()) == 9 * cfg.vision.layers_run + 2 + 6 * cfg.t5.layers
+    # the stage-locked run on its own record carries enc_out as fp32 values of an fp16 tensor: the count here is of taps DECLARED fp16
+    assert sum(r["mant_bits"] == 10 for r in report.values()) == 9 * cfg.vision.layers_run + 2 + 6 * cfg.t5.layers + 3 * cfg.t5.dec_layers
     # one fp16 ulp planted in a tower tensor is seen as one ulp (with bf16 ulps it would read as 1/8 and pass any bound)
     t = taps["vit.0.mid"].clone()
     k = int(t.abs().float().argmax())
@@ -176,7 +181,7 @@ def test_fp16_encoder_attention_side_mode(name):
     assert (ref["label_logprobs"] - off["label_logprobs"]).abs().max().item() <= 5e-5
     e = {}
     for flag in (False, True):
-        o = EngineRoundedOracle(cfg, w, enc_fp16=flag, classes=tuple(c for c in EngineRoundedOracle.CLASSES if c.startswith("enc.")))
+        o = EngineRoundedOracle(cfg, w, enc_fp16=flag, dec_fp16=False, classes=tuple(c for c in EngineRoundedOracle.CLASSES if c.startswith("enc.")))
         assert o.enc_fp16 is flag and (set(o.ENC_FP16_CLASSES) <= o.half_extra) is flag
         o.record = {}
         out = o.forward(pix.float(), idx, ids, labels, return_stages=True)
@@ -188,3 +193,28 @@ def test_fp16_encoder_attention_side_mode(name):
             assert torch.equal(rec[f"enc.0.{nm}"], bf16_round(rec[f"enc.0.{nm}"])), nm
         assert torch.equal(out["enc_out"], bf16_round(out["enc_out"]))
     assert e[True] < 0.8 * e[False], e
+
+
+@pytest.mark.parametrize("name", ["tiny", "small"])
+def test_fp16_cross_attention_score_path_mode(name):
+    """`dec_fp16=True` (the engine's option, default since round 5; precise decoder only): the encoder's output, the cross q (from the full
+    split norm output), q.Wk and the probabilities are IEEE fp16 tensors; everything else of the precise decoder is what it was.  Roundings
+    off = the fp32 oracle; with the decoder's classes alone rounding, the label log-probs are closer to fp32 than with the bf16 score path."""
+    cfg, w, pix, idx, ids, labels = _case(name)
+    ref = Oracle(cfg, w).forward(pix.float(), idx, ids, labels, return_stages=True)
+    off = EngineRoundedOracle(cfg, w, round_fn=lambda x: x.float()).forward(pix.float(), idx, ids, labels, return_stages=True)
+    assert (ref["label_logprobs"] - off["label_logprobs"]).abs().max().item() <= 5e-5
+    assert not EngineRoundedOracle(cfg, w, dec_precise=False).dec_fp16                      # the option exists for the precise decoder only
+    dec = tuple(c for c in EngineRoundedOracle.CLASSES if c.startswith("dec.")) + ("enc.out",)
+    e = {}
+    for flag in (False, True):
+        o = EngineRoundedOracle(cfg, w, dec_fp16=flag, classes=dec)
+        o.record = {}
+        out = o.forward(pix.float(), idx, ids, labels, return_stages=True)
+        rec = o.record
+        for nm in ("cq", "cqk", "cprobs"):
+            x = rec[f"dec.0.{nm}"]
+            assert torch.equal(x, x.half().float()) if flag else torch.equal(x, bf16_round(x)), nm
+        assert (torch.equal(out["enc_out"], out["enc_out"].half().float()) and not torch.equal(out["enc_out"], bf16_round(out["enc_out"]))) is flag
+        e[flag] = (out["label_logprobs"] - ref["label_logprobs"]).abs().mean().item()
+    assert e[True] < e[False], e

@@ -364,7 +364,7 @@ def test_fp16_encoder_attention_side_is_closer_to_fp32_than_the_bf16_encoder():
             out[mode], enc[mode] = lp.cpu(), eng.stage("enc_out").float().cpu().clone()
         eng.set_option("enc_fp16", 1)
         eng.set_option("gemm_variant", 11)
-        with pytest.raises(VqsError, match="enc_fp16"):
+        with pytest.raises(VqsError, match="fp16.*gemm_variant 3"):      # the first fp16 option the pass meets names itself and the way out
             eng.score(feats, img_index, ids, labels)
     finally:
         eng.close()

@@ -553,3 +553,42 @@ def test_norms_with_fp16_operand_out(eng, M, D):
     xs = x + h1.float()
     assert_close(x4, xs, 1e-6, 1e-6, "layernorm fp16 delta write-back")
     assert_close(out, torch.nn.functional.layer_norm(xs, (D,), w.float(), b.float(), 1e-5), 1.5e-3, 1e-3, "layernorm fp16")
+
+
+@pytest.mark.parametrize("Z,M,N,K,epi,ftype", [
+    (256, 128, 608, 512, 3, 1),      # the cross scores' form: rows of q.Wk x the fp16 encoder output -> fp32 (stream form)
+    (200, 100, 600, 192, 3, 1),      # ragged M / N
+    (64, 16, 512, 64, 0, 1),         # q.Wk's form: K = 64, fp16 result (batched over heads: the persistent kernel)
+    (256, 128, 512, 640, 0, 2),      # P.E's form: fp16 operands, split-bf16 result (kept off the stream form by the engine)
+    (3, 40, 72, 128, 3, 1), (5, 130, 264, 192, 0, 2)])   # too few items for the stream form / more than 128 rows: the persistent kernel
+def test_batched_gemms_on_fp16_operands(eng, Z, M, N, K, epi, ftype):
+    """Option dec_fp16: gemm_bf16_stream<EPI, FT> and gemm_bf16_persistent<EPI, 0, FT> on IEEE fp16 operands -- the decoder's cross-attention score
+    path.  Against fp32 torch on the same fp16 inputs at the result type's rounding; stream form == persistent kernel bit for bit where both
+    apply; the split result carries 16 bits of the fp32 accumulator; the fp16-result form is eight times closer than the bf16 kernel."""
+    from t2v_metrics_amd.engine import load_library
+    g = torch.Generator(device="cuda").manual_seed(131)
+    A = torch.randn(Z, M, K, device="cuda", generator=g).to(torch.float16)
+    W = (torch.randn(Z, N, K, device="cuda", generator=g) * K ** -0.5).to(torch.float16)
+    ref = torch.einsum("zmk,znk->zmn", A.float(), W.float())
+    split = epi == 0 and ftype == 2
+    got = eng.gemm_batched(A, W, epi, split=split, ftype=ftype)
+    again = eng.gemm_batched(A, W, epi, split=split, ftype=ftype)
+    hi = got[0] if split else got
+    assert torch.equal(hi, again[0] if split else again)
+    if epi == 3:
+        assert hi.dtype == torch.float32
+        assert_close(hi, ref, 2e-4, 2e-5, f"f16 batched -> fp32 {Z}x{M}x{N}x{K}")
+    elif ftype == 1:
+        assert hi.dtype == torch.float16
+        assert_close(hi, ref, 2.5e-3, 1.5e-3, "f16 batched -> fp16")
+    else:
+        assert hi.dtype == torch.bfloat16
+        assert_close(hi, ref, 2e-2, 1e-2, "f16 batched -> bf16 hi plane")
+        two = got[0].float() + got[1].float()
+        rel = ((two - ref).abs() / ref.abs().clamp(min=1e-2)).max().item()
+        assert rel <= 1e-3, rel                                      # hi + lo = the fp32 accumulator to 2^-16; ref differs by fp32 summation order
+        assert ((two - ref).abs().mean() * 20 < (got[0].float() - ref).abs().mean())
+    lib = load_library()
+    if lib.vqs_debug_gemm_form(M, N, K, K, K, epi, Z, 3, 0, 0, 0) == 12 and not split:      # the bf16 rule; the fp16 launch follows the same rule
+        other = eng.gemm_batched(A, W, epi, no_stream=True, ftype=ftype)
+        assert torch.equal(hi, other)

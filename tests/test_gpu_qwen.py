@@ -18,6 +18,10 @@ pytestmark = pytest.mark.gpu
 # tests below.
 LOGPROB_TOL_BF16 = 2.5e-2
 LOGPROB_CEILING = 5e-2
+# Round 5, with the precise tail (the last prompt position re-evaluated with 16 significant bits, profiles/r5_qwen_error_attribution.md): the
+# 7B sample measured 5.2e-3 over its five most likely tokens and the answer id (rounds 2-4: 9.1e-3 .. 1.9e-2); 16 bench samples max 4.3e-3 on
+# the answer token.  Gate = 3 x the measured value.
+LOGPROB_TOL_7B = 1.6e-2
 
 
 def _calibrated_bound(cfg, w, grids, ids, mask, px, ref_lp, toks):
@@ -392,7 +396,7 @@ def test_qwen_7b_full_size_one_sample_against_the_cpu_oracle():
     with open(os.path.join(out, "parity_e2e.jsonl"), "a") as f:
         f.write(json.dumps({"case": "fullsize/qwen2.5-vl-7b", "max_abs_dlogp_top5_and_answer": d,
                             "logp_top1_fp32": ref_lp.max().item()}) + "\n")
-    assert d <= LOGPROB_TOL_BF16, d
+    assert d <= LOGPROB_TOL_7B, d
     assert lp.argmax().item() == ref_lp.argmax().item() or (ref_lp.topk(2).values[0] - ref_lp.topk(2).values[1]).item() < 2 * LOGPROB_TOL_BF16
     eng.close()
 

@@ -44,7 +44,8 @@ def run_stage_locked(cfg, w, eng, pix, idx, ids, labels, tag, window=None, vit_f
         vit_fp16 = bool(eng.get_option("vit_fp16"))          # the engine's own setting (default: fp16 tower)
     assert vit_fp16 == bool(eng.get_option("vit_fp16"))
     # enc_fp16 (round 5, default 1): likewise for the encoder's attention side -- the oracle follows the engine's setting
-    emu = Oracle(cfg, w_cpu, emulate="engine", vit_fp16=vit_fp16, enc_fp16=bool(eng.get_option("enc_fp16")), device=odev)
+    emu = Oracle(cfg, w_cpu, emulate="engine", vit_fp16=vit_fp16, enc_fp16=bool(eng.get_option("enc_fp16")), dec_fp16=bool(eng.get_option("dec_fp16")),
+                 device=odev)
     B, L = ids.shape
     T = labels.shape[1]
     if window is None:
@@ -156,12 +157,17 @@ def test_every_launch_matches_the_oracle_with_the_fp16_vision_tower(name, B, n_i
         assert eng.get_option("vit_fp16") == 1 and eng.get_option("dec_precise") == 1 and eng.get_option("enc_fp16") == 1          # what ships
         report, _ = run_stage_locked(cfg, w, eng, pix, img_index, ids, labels, f"{name}-B{B}-L{L}-T{T}-gain{gain}-vit_fp16")
         # fp16 tensors: 9 per tower layer + feature select + projector hidden; 6 per encoder layer (both norm outputs, q, k, v, attention output)
-        assert sum(r["mant_bits"] == 10 for r in report.values()) == 9 * cfg.vision.layers_run + 2 + 6 * cfg.t5.layers
+        # + option dec_fp16: the encoder's output and 3 per decoder layer (cross q, q.Wk, probabilities)
+        assert eng.get_option("dec_fp16") == 1
+        assert sum(r["mant_bits"] == 10 for r in report.values()) == 9 * cfg.vision.layers_run + 2 + 6 * cfg.t5.layers + 1 + 3 * cfg.t5.dec_layers
         eng.set_option("vit_fp16", 0)                                                         # ... the bf16 tower of rounds 1-3, same handle
         report, _ = run_stage_locked(cfg, w, eng, pix, img_index, ids, labels, f"{name}-B{B}-L{L}-T{T}-gain{gain}-vit_bf16")
-        assert sum(r["mant_bits"] == 10 for r in report.values()) == 6 * cfg.t5.layers
-        assert all(n.startswith("enc.") for n, r in report.items() if r["mant_bits"] == 10)
-        eng.set_option("enc_fp16", 0)                                                         # ... and the bf16 encoder of rounds 1-4
+        assert sum(r["mant_bits"] == 10 for r in report.values()) == 6 * cfg.t5.layers + 1 + 3 * cfg.t5.dec_layers
+        assert all(n.startswith(("enc", "dec.")) for n, r in report.items() if r["mant_bits"] == 10)
+        eng.set_option("enc_fp16", 0)                                                         # ... the bf16 encoder of rounds 1-4
+        report, _ = run_stage_locked(cfg, w, eng, pix, img_index, ids, labels, f"{name}-B{B}-L{L}-T{T}-gain{gain}-enc_bf16")
+        assert sum(r["mant_bits"] == 10 for r in report.values()) == 1 + 3 * cfg.t5.dec_layers
+        eng.set_option("dec_fp16", 0)                                                         # ... and round 4's bf16 score path
         report, _ = run_stage_locked(cfg, w, eng, pix, img_index, ids, labels, f"{name}-B{B}-L{L}-T{T}-gain{gain}-all_bf16")
         assert not any(r["mant_bits"] == 10 for r in report.values())
     finally:

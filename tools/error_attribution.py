@@ -56,7 +56,8 @@ class Runner:
         split = tuple(c for c in split if not c.startswith(("half:", "ship:")))
         # vit_fp16=False: the table models every class as a bf16 rounding (the engine of rounds 1-3) and adds fp16 / split stages explicitly
         return EngineRoundedOracle(self.cfg, self.w, acc=self.acc, classes=classes, dec_precise=dec_precise, split_classes=split,
-                                   half_classes=half, vit_fp16=ship, device=self.pix.device, enc_fp16=enc16)
+                                   half_classes=half, vit_fp16=ship, device=self.pix.device, enc_fp16=enc16,
+                                   dec_fp16=("ship:dec_fp16" in split))
 
     def run(self, classes, dec_precise=False, split=()):
         classes = frozenset(classes)
@@ -184,7 +185,9 @@ def main():
              ("r5: the engine as shipped in round 5 (precise decoder + vit_fp16 + enc_fp16)", ALL, True, ("ship:vit_fp16", "ship:enc_fp16")),
              ("r5: as round 5 but only the attention sub-block in fp16 (FFN norm output and wi stay bf16)", ALL, True, ("ship:vit_fp16", "ship:enc_fp16_attn")),
              ("r5: round 5 + decoder cross score path (q, q.Wk, probabilities) and the encoder output in fp16", ALL, True,
-              ("ship:vit_fp16", "ship:enc_fp16", "half:enc.out", "half:dec.cq", "half:dec.cqk", "half:dec.cprobs"))]
+              ("ship:vit_fp16", "ship:enc_fp16", "half:enc.out", "half:dec.cq", "half:dec.cqk", "half:dec.cprobs")),
+             ("r5: the engine with options vit_fp16 + enc_fp16 + dec_fp16 (what ships at the end of round 5)", ALL, True,
+              ("ship:vit_fp16", "ship:enc_fp16", "ship:dec_fp16"))]
     runs = [(r + (False, ()))[:4] if len(r) < 4 else r for r in runs]          # (name, classes, precise decoder, split set)
     if a.only:
         keep = set(a.only.split(";"))
