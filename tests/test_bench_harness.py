@@ -88,11 +88,13 @@ def test_traffic_provenance_stamps():
     assert g and len(g) == 16 and g == bench.gemm_kernels_hash(so) and bench.gemm_kernels_hash(__file__) is None
     ks = bench.device_kernels(so)
     assert len(ks) > 100 and all(len(kd) == 64 and len(code) > 0 for code, kd in ks.values())
-    assert sum("gemm_bf16_quad" in n for n in ks) == 5 and sum("gemm_f16_quad" in n for n in ks) == 4
+    assert sum("gemm_bf16_quad" in n for n in ks) == 5 and sum("gemm_f16_quad" in n for n in ks) == 4 and sum("gemm_f16b_quad" in n for n in ks) == 2
     ok, how = bench.traffic_stamp_matches({"gemm_kernels_sha256_16": g, "device_code_sha256_16": "stale"})
     assert ok and g in how                                                            # ... and it wins over the whole-library stamp
     assert not bench.traffic_stamp_matches({"gemm_kernels_sha256_16": "0" * 16, "device_code_sha256_16": h})[0]
-    assert rec["gemm_kernels_sha256_16"] == g, "profiles/gemm_traffic_xxl_b256.json was measured on other GEMM kernels: re-run tools/gpu_pmc_bench.sh"
+    # the committed record names the kernel families it was collected on (round 5: bf16, fp16 and fp16-operand / bf16-result quad kernels)
+    ok, how = bench.traffic_stamp_matches(rec)
+    assert ok, "profiles/gemm_traffic_xxl_b256.json was measured on other GEMM kernels (%s): re-run tools/gpu_pmc_bench.sh" % how
 
 
 def test_pmc_summary_counts_both_gemm_kernel_families_and_stamps_the_record(tmp_path):

@@ -495,8 +495,11 @@ def test_fp16_gemm_refuses_what_it_has_no_kernel_for(eng):
         eng.gemm(A, W, 1, variant=3, ftype=2)          # fp16 in / bf16 out: plain and gated only
     with pytest.raises(VqsError):
         eng.gemm(A, W, 0, variant=11, ftype=1)         # the 8-wave forms have no fp16 instantiation
+    # K < 128 is not a quad launch: since option dec_fp16 it runs the persistent 8-wave kernel's fp16 instantiation (plain epilogues only)
+    a64, w64 = A[:, :64].contiguous(), W[:, :64].contiguous()
+    assert_close(eng.gemm(a64, w64, 0, variant=3, ftype=1), a64.float() @ w64.float().t(), 2.5e-3, 1.5e-3, "K = 64 on the fp16 persistent kernel")
     with pytest.raises(VqsError):
-        eng.gemm(A[:, :64].contiguous(), W[:, :64].contiguous(), 0, variant=3, ftype=1)   # K < 128 is not a quad launch
+        eng.gemm(a64, w64, 1, variant=3, ftype=1)      # ... which carries no activation epilogue
 
 
 @pytest.mark.parametrize("B,H,S,use_bias,ragged", [(2, 3, 577, False, False), (3, 2, 608, True, True), (2, 4, 333, True, False),

@@ -40,15 +40,15 @@ if cnt["FETCH_SIZE"] and cnt["WRITE_SIZE"]:
     fetch = 2.0 * 1024.0 * tot["FETCH_SIZE"] / cnt["FETCH_SIZE"]
     write = 1024.0 * tot["WRITE_SIZE"] / cnt["WRITE_SIZE"]
     out = {"source": "rocprofv3 --kernel-trace --pmc (separate FETCH_SIZE / WRITE_SIZE passes) over bench.py --steps 1 --warmup 1",
-           "kernels": "vqs::gemm_bf16_* + vqs::gemm_f16_* (all GEMM launches of the run)", "launches_per_pass": cnt["FETCH_SIZE"],
-           "vit_fp16": seen_f16,           # were fp16 GEMM launches (the fp16 vision tower) part of the collection?
+           "kernels": "vqs::gemm_bf16_* + vqs::gemm_f16_* + vqs::gemm_f16b_* (all GEMM launches of the run)", "launches_per_pass": cnt["FETCH_SIZE"],
+           "vit_fp16": seen_f16,           # were fp16 GEMM launches (the fp16 vision tower / encoder attention side) part of the collection?
            "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write, "traffic_bytes_per_launch": fetch + write,
            "corrections": "FETCH_SIZE KiB x 1024 x 2 (gfx950 128-B requests tallied at 64 B); WRITE_SIZE KiB x 1024 as reported"}
     try:                                    # stamp with the kernel sources the counters were taken on (bench.py checks it)
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         import bench
         out["csrc_sha256_16"] = bench.csrc_hash()
-        out["gemm_kernels_patterns"] = ["gemm_bf16_", "gemm_f16_"]
+        out["gemm_kernels_patterns"] = ["gemm_bf16_", "gemm_f16"]      # gemm_f16_quad (fp16 -> fp16) and gemm_f16b_quad (fp16 -> bf16) too
         out["gemm_kernels_sha256_16"] = bench.gemm_kernels_hash(patterns=tuple(out["gemm_kernels_patterns"]))   # machine code + descriptors of the GEMM kernels alone
         out["device_code_sha256_16"] = bench.device_code_hash()       # the .hip_fatbin section of the library the passes ran
     except Exception as e:
