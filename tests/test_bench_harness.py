@@ -109,7 +109,7 @@ def test_pmc_summary_counts_both_gemm_kernel_families_and_stamps_the_record(tmp_
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     if not os.path.exists(os.path.join(root, "t2v_metrics_amd", "libvqs_hip.so")):
         pytest.skip("library not built")
-    rows = {"FETCH_SIZE": [("void vqs::gemm_bf16_quad<5>(vqs::GemmParams)", 65536, 3, 4000.0), ("void vqs::gemm_f16_quad<0>(vqs::GemmParams)", 65536, 1, 2000.0),
+    rows = {"FETCH_SIZE": [("void vqs::gemm_bf16_quad<5>(vqs::GemmParams)", 65536, 3, 4000.0), ("void vqs::gemm_f16b_quad<0>(vqs::GemmParams)", 65536, 1, 2000.0),
                            ("void vqs::attn_fwd_dma_kernel<true>(vqs::AttnParams)", 1024, 5, 9e9)],
             "WRITE_SIZE": [("void vqs::gemm_bf16_quad<5>(vqs::GemmParams)", 65536, 3, 1000.0), ("void vqs::gemm_f16_quad<0>(vqs::GemmParams)", 65536, 1, 3000.0)]}
     for with_f16 in (True, False):
@@ -134,7 +134,7 @@ def test_pmc_summary_counts_both_gemm_kernel_families_and_stamps_the_record(tmp_
         assert rec["launches_per_pass"] == n and rec["vit_fp16"] is with_f16
         assert rec["fetch_bytes_per_launch"] == pytest.approx(fetch) and rec["write_bytes_per_launch"] == pytest.approx(write)
         assert rec["traffic_bytes_per_launch"] == pytest.approx(fetch + write)
-        assert rec["gemm_kernels_patterns"] == ["gemm_bf16_", "gemm_f16_"]
-        assert rec["gemm_kernels_sha256_16"] == bench.gemm_kernels_hash(patterns=("gemm_bf16_", "gemm_f16_")) != bench.gemm_kernels_hash()
+        assert rec["gemm_kernels_patterns"] == ["gemm_bf16_", "gemm_f16"]            # "gemm_f16": gemm_f16_quad (fp16 result) and gemm_f16b_quad (bf16 result)
+        assert rec["gemm_kernels_sha256_16"] == bench.gemm_kernels_hash(patterns=("gemm_bf16_", "gemm_f16")) != bench.gemm_kernels_hash()
         ok, how = bench.traffic_stamp_matches(rec)
         assert ok and rec["gemm_kernels_sha256_16"] in how

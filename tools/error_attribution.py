@@ -52,12 +52,13 @@ class Runner:
     def _oracle(self, classes, dec_precise, split=()):
         ship = "ship:vit_fp16" in split                                      # the engine's option itself (fp16 GEMM result of the projector, then bf16)
         enc16 = "attn" if "ship:enc_fp16_attn" in split else ("ship:enc_fp16" in split)   # the engine's option enc_fp16 (round 5) / its attention-sub-block-only what-if
+        dec16 = "ship:dec_fp16" in split                                     # the engine's option dec_fp16 (round 5)
         half = tuple(c[5:] for c in split if c.startswith("half:"))          # "half:<class>" entries of a what-if's set: fp16 tensors
         split = tuple(c for c in split if not c.startswith(("half:", "ship:")))
         # vit_fp16=False: the table models every class as a bf16 rounding (the engine of rounds 1-3) and adds fp16 / split stages explicitly
         return EngineRoundedOracle(self.cfg, self.w, acc=self.acc, classes=classes, dec_precise=dec_precise, split_classes=split,
                                    half_classes=half, vit_fp16=ship, device=self.pix.device, enc_fp16=enc16,
-                                   dec_fp16=("ship:dec_fp16" in split))
+                                   dec_fp16=dec16)
 
     def run(self, classes, dec_precise=False, split=()):
         classes = frozenset(classes)
