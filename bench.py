@@ -617,8 +617,8 @@ def main():
     }
     if n_gemm > 0 and gemm_ms > 0:
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12
-        out["roofline"] = {"kernel": "vqs::gemm_bf16_quad / gemm_f16_quad (16-bit-result launches: the same kernel on bf16 / fp16 fragments) + gemm_bf16_persistent / "
-                                     "gemm_bf16_stream (fp32-result / batched): every GEMM launch of the step",
+        out["roofline"] = {"kernel": "vqs::gemm_bf16_quad / gemm_f16_quad / gemm_f16b_quad (16-bit-result launches: the same kernel on bf16 / fp16 fragments; dominant: "
+                                     "gemm_f16b_quad<5>, the encoder's gated wi) + gemm_bf16_persistent / gemm_bf16_stream (fp32-result / batched): every GEMM launch of the step",
                            "bound": "mfma", "achieved": achieved,
                            "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
                            "traffic": None, "launches": n_gemm, "avg_launch_ms": gemm_ms / n_gemm,
