@@ -885,7 +885,7 @@ def cpu_baseline(cfg, weights, job, n_pairs, lp_gpu, reps, with_emulation=False,
            "port_fp32": {"value": n_port / t_port, "unit": "pairs/s", "kind": "port",
                          "sample": f"oracle/clip_t5_oracle.py, fp32, the first {n_port} of those pairs, one cold pass ({t_port:.1f} s)"},
            "dlogp": {"pairs": parity["pairs"] if parity else n_pairs,
-                     "hip_vs_fp32_truth": parity,          # >= 16 pairs, head gains 1 and 4 (peaked): BASELINE.md section 3, row (iii) vs (i)
+                     "hip_vs_fp32_truth": parity,          # >= 64 pairs by default, head gains 1 and 4 (peaked): BASELINE.md section 3, row (iii) vs (i)
                      "device_truth_vs_host_oracle_max": truth_check,
                      "reference_pairs": n_pairs,
                      "per_pair_abs_hip_vs_fp32_truth": [round(float(x), 6) for x in hip_pair],

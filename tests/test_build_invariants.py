@@ -23,7 +23,8 @@ pytestmark = pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipc
 
 
 def _kernels(src):
-    deps = [os.path.join(CSRC, src), os.path.join(CSRC, "vqs_kernels.h")] + ([os.path.join(CSRC, "gemm_quad.inc")] if src == "gemm.hip" else [])
+    incs = {"gemm.hip": ["gemm_quad.inc", "gemm_quad_kernel.inc", "gemm_stream.inc"], "attn.hip": ["attn_dma_kernel.inc"]}.get(src, [])
+    deps = [os.path.join(CSRC, src), os.path.join(CSRC, "vqs_kernels.h")] + [os.path.join(CSRC, i) for i in incs]
     key = "_".join("%d-%d" % (os.path.getsize(d), int(os.path.getmtime(d))) for d in deps)
     out_dir = os.path.join(ROOT, "build", "isa")
     os.makedirs(out_dir, exist_ok=True)
@@ -59,6 +60,59 @@ def test_no_kernel_spills_or_exceeds_the_cu(src):
         assert k["lds"] <= LDS_PER_CU, (name, k)
         # a 512-thread workgroup is two waves per SIMD: at most 256 registers per lane each
         assert k["vgpr"] <= (256 if k["wg"] > 256 else 512), (name, k)
+
+
+@pytest.mark.parametrize("src", ["gemm.hip", "attn.hip", "elementwise.hip", "qwen_decode.hip"])
+def test_no_valu_written_sgpr_feeds_an_inline_asm_memory_instruction_within_five_wait_states(src):
+    """gfx9 hazard: an SGPR written by a VALU instruction (v_readlane_b32 = the reload of a spilled scalar, v_readfirstlane_b32) must not be read
+    by a vector-memory instruction -- as descriptor or scalar offset, or through M0 by an LDS-DMA -- within the next 5 wait states.  The compiler
+    pads its own instructions, but its hazard recogniser does not look into INLINE ASM, which is how this library issues its scheduled LDS-DMA
+    loads: a lab kernel of round 5 stored one of 32 row pieces to the wrong row exactly this way (profiles/r5_gemm_gap.md section 8).  Checked
+    on the ISA of every kernel: no VALU-written SGPR is an operand of a memory instruction (or M0 write) INSIDE an asm statement fewer than 5
+    instructions later (each instruction is at least one wait state; s_nop N counts N + 1; a scalar instruction re-defining the register ends
+    the window -- its consumers read the scalar unit's value)."""
+    text = _kernels(src)["__asm__"]
+    found, n_asm_mem, n_hint = [], 0, 0
+    for m in re.finditer(r"^(_ZN3vqs\w+):[^\n]*\n(.*?)^\.Lfunc_end", text, flags=re.S | re.M):
+        code, in_asm = [], False
+        for raw in m.group(2).splitlines():
+            if "#ASMSTART" in raw:
+                in_asm = True
+            elif "#ASMEND" in raw:
+                in_asm = False
+            ln = raw.split(";")[0].strip()
+            if ln and not ln.startswith(".") and not ln.endswith(":"):
+                code.append((ln, in_asm))
+        n_asm_mem += sum(1 for ln, a in code if a and ln.startswith(("buffer_", "global_", "flat_")))
+        for i, (ln, _) in enumerate(code):
+            if not ln.startswith(("v_readlane_b32", "v_readfirstlane_b32")):
+                continue
+            dst = ln.split()[1].rstrip(",")
+            if not re.fullmatch(r"s\d+", dst):
+                continue
+            n, waited = int(dst[1:]), 0
+            for nxt, in_asm in code[i + 1:i + 6]:
+                if waited >= 5:
+                    break
+                if nxt.startswith("s_") and re.match(r"s_\w+ %s\b" % dst, nxt):
+                    break
+                if in_asm and nxt.startswith(("buffer_", "global_", "flat_")):
+                    regs = set(int(x) for x in re.findall(r"\bs(\d+)\b", nxt))
+                    for a, b in re.findall(r"s\[(\d+):(\d+)\]", nxt):
+                        regs |= set(range(int(a), int(b) + 1))
+                    # tolerated: the persistent kernels' L2 TOUCH (`buffer_load_dword ... lds`: one dword per lane into a sink nobody reads, a
+                    # prefetch hint whose asm block opens with three scalar instructions) -- a stale scalar offset there fetches another line
+                    hint = nxt.startswith("buffer_load_dword ") and nxt.endswith("lds")
+                    if n in regs and not hint:
+                        found.append((m.group(1), ln, nxt))
+                    n_hint += 1 if (n in regs and hint) else 0
+                if in_asm and nxt.startswith("s_mov_b32 m0") and re.search(r"\b%s\b" % dst, nxt):
+                    found.append((m.group(1), ln, nxt))
+                waited += (int(nxt.split()[1]) + 1) if nxt.startswith("s_nop") else 1
+    assert not found, found[:5]
+    if src in ("gemm.hip", "attn.hip"):
+        assert n_asm_mem >= 32, n_asm_mem          # the scan saw the asm statements it is about (ASMSTART / ASMEND markers present)
+    assert n_hint <= 40, n_hint                    # (the tolerated hint loads: 36 at the time of writing, TOUCH instantiations only)
 
 
 def test_decode_attention_fits_its_largest_cache_in_lds():

@@ -1,5 +1,5 @@
 """CPU tests of the round-4 parity tooling: the per-class switches of the rounding-matched oracle (what tools/error_attribution.py
-varies), the split-bf16 rounding, and the arithmetic of bench.py's 16-pair |delta log P| table (parity_sample) on an engine double."""
+varies), the split-bf16 rounding, and the arithmetic of bench.py's |delta log P| table (parity_sample, parity_jobs) on an engine double."""
 import pytest
 import torch
 
