@@ -207,7 +207,7 @@ int vqs_score_head(const float* d_logits, int32_t ldl, int32_t V, const int32_t*
  *                  exact for 2^-14 <= |w| < 65 520), fp16 activations through the same kernels on fp16 MFMAs (same rate, same bytes),
  *                  fp32 accumulation / residual stream / statistics unchanged, the feature tensor still bf16 (written by the projector's last GEMM: fp16 operands, bf16 result).  11
  *                  significant bits instead of 8 where the error attribution (profiles/r4_error_attribution.md) puts most of what is
- *                  left of the end-to-end |delta log P| (measured on the benchmarked batch: max 1.45e-3 -> 7.0e-4, mean 7.0e-4 -> 3.3e-4,
+ *                  left of the end-to-end |delta log P| (round 4's 16-pair sample of the benchmarked batch: max 1.45e-3 -> 7.0e-4, mean 7.0e-4 -> 3.3e-4,
  *                  throughput 201.0 -> 200.5 pairs/s; profiles/r4_call18_*).  CLIP was trained in fp16; the T5 stack is not fp16-safe and
  *                  is not touched.  0: bf16 there too, the reference's dtype (mm_utils.py:228) and rounds 1-3's tower.  1 needs
  *                  gemm_variant 3.  The tower's / projector's
