@@ -24,7 +24,7 @@ from t2v_metrics_amd.weights import make_seeded_weights
 pytestmark = pytest.mark.gpu
 
 LOGPROB_TOL = 1e-3          # north_star
-LOGPROB_TOL_BF16 = 7.5e-3   # 16-bit-operand bound per unit of logit scale on the 128/256-wide test configurations (round 5: 2.5 x the measured 1.0e-3 .. 3.1e-3 per unit; round 4: 1.5e-2 =) 3 x the then measured
+LOGPROB_TOL_BF16 = 4.0e-3   # 16-bit-operand bound per unit of logit scale on the 128/256-wide test configurations: 2 x the largest measured with the round-5 defaults (0.7e-3 .. 2.0e-3 per unit over the nine cases; round 4: 1.5e-2)
                             # 3.5e-3 .. 5e-3 at gain 1 with the precise decoder (round 3: 2.5e-2 against 4e-3 .. 1e-2)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -297,7 +297,7 @@ def test_precise_decoder_is_closer_to_fp32_than_the_bf16_decoder():
     assert torch.equal(out["precise"], out["precise-b"])
     err = {k: (v - ref).abs() for k, v in out.items()}
     _record("precise-decoder", {k: {"max": float(e.max()), "mean": float(e.mean())} for k, e in err.items()})
-    assert float(err["bf16"].max()) <= 2 * LOGPROB_TOL_BF16 * 4.0
+    assert float(err["bf16"].max()) <= 6e-2          # the bf16 decoder of rounds 1-3 at gain 4 (measured 3.4e-2)
     assert float(err["precise"].mean()) < float(err["bf16"].mean()), (float(err["precise"].mean()), float(err["bf16"].mean()))
     assert float(err["precise"].max()) <= 2.5e-2 and float(err["precise"].mean()) <= 8e-3       # CPU attribution at gain 4 (small): 8.7e-3 / 3.0e-3
     assert float((out["precise"] - out["precise-unsplit"]).abs().max()) <= 2e-3                  # only the bf16 score path can flip a rounding

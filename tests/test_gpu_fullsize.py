@@ -157,8 +157,9 @@ def _one_pair_three_way(cfg, w, eng, tag, seed, check_random=True):
     if "random-head" in out:
         o = out["random-head"]
         # round 5 (fp16 tower + fp16 encoder attention side): one pair is one draw of a distribution whose maximum over 256 bench pairs
-        # measured 7.6e-4 (XXL) / 8.3e-4 (XL), mean 2.9e-4 / 3.1e-4 (profiles/r5_call2_*): gate 1.5e-3 (round 4: 4.5e-3, round 3: 2.5e-2)
-        assert o["dlogp_vs_fp32"] <= min(1.5e-3, 3.0 * o["rounding_matched_vs_fp32"] + 1e-3), out
+        # this pair measures 2.3e-4 (XXL) / 3.3e-4 (XL); over 256 pairs of the bench batch max 5.2e-4 / 5.8e-4 (profiles/r5_call7_*): the gate is
+        # north_star's 1e-3 itself (round 4: 4.5e-3, round 3: 2.5e-2)
+        assert o["dlogp_vs_fp32"] <= min(1.0e-3, 3.0 * o["rounding_matched_vs_fp32"] + 1e-3), out
     assert rel <= 0.02, rel
 
 
