@@ -14,10 +14,12 @@ pytestmark = pytest.mark.gpu
 # End-to-end criterion of the CLIP-FlanT5 row (tests/test_gpu_fullsize.py): the engine differs from fp32 arithmetic by
 # the bf16 operand noise of the pass.  That floor is MEASURED per case by the rounding-matched oracle run free on the host (same
 # roundings, different summation order): |d log P| of the engine against the fp32 oracle must stay within max(2.5e-2, 3 x that floor),
-# never above the absolute ceiling 5e-2 -- while the kernel arithmetic itself is held to <= 1 bf16 ulp per launch by the stage-locked
-# tests below.
+# never above the absolute ceiling -- while the kernel arithmetic itself is held to <= 1 bf16 ulp per launch by the stage-locked
+# tests below.  Ceiling: 3 x the largest value measured with the precise tail over the four small configurations (5.7e-3 .. 1.22e-2 on the
+# five most likely tokens; 5e-2 before the tail existed).
 LOGPROB_TOL_BF16 = 2.5e-2
-LOGPROB_CEILING = 5e-2
+LOGPROB_CEILING = 3.7e-2
+DECODE_CEILING = 5e-2        # the cached decode step runs the bf16 row (no precise tail): measured 1.0e-2 .. 4.0e-2 over three steps of three configurations
 # Round 5, with the precise tail (the last prompt position re-evaluated with 16 significant bits, profiles/r5_qwen_error_attribution.md): the
 # 7B sample measured 5.2e-3 over its five most likely tokens and the answer id (rounds 2-4: 9.1e-3 .. 1.9e-2); 16 bench samples max 4.3e-3 on
 # the answer token.  Gate = 3 x the measured value.
@@ -492,7 +494,7 @@ def test_qwen_kv_cache_decode_matches_a_prefill_over_the_longer_sequence(name):
         worst = max(worst, d_re, d_ref)
         _record({"case": f"qwen/kv-cache/{name}/step{t + 1}", "max_abs_dlogp_top5_decode_vs_prefill_over_longer_sequence": d_re,
                  "max_abs_dlogp_top5_decode_vs_fp32_oracle": d_ref})
-        assert d_re <= LOGPROB_CEILING and d_ref <= LOGPROB_CEILING, (t, d_re, d_ref)
+        assert d_re <= DECODE_CEILING and d_ref <= DECODE_CEILING, (t, d_re, d_ref)
     assert int(state["len"].max()) == int(n_tok.max()) + steps
     from t2v_metrics_amd.engine import VqsError
     with pytest.raises(VqsError, match="KV cache is full"):
