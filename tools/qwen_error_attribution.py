@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--device", default="cuda:0")
     ap.add_argument("--engine", action="store_true", help="also score the samples with the HIP engine")
     ap.add_argument("--only", default="")
+    ap.add_argument("--set", default="r5", choices=["r5", "r6", "r6b"], help="r5: the round-5 table; r6: what-ifs for the >= 11-bit forms (all with the last row exact)")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     cfg = get_qwen_config(a.model)
@@ -147,6 +148,53 @@ def main():
     ]
     for c in ("txt.norm", "txt.qkv", "txt.rope", "txt.p", "txt.attn", "txt.delta", "txt.act", "txt.out"):
         runs.append((f"class {c} alone", {c: bf16}, False))
+    if a.set == "r6":
+        # round 6: which 16-bit classes have to carry >= 11 bits for the row to sit under 1e-3 (all with the precise tail = last row exact).
+        # exact = the class stays fp32 (what an fp32 / split result of that GEMM would hold); vis.in stays bf16 (the ABI's input dtype)
+        exact = lambda x: x  # noqa: E731
+        T16 = {"txt.*": fp16}
+        V16 = {"vis.*": fp16, "vis.in": bf16}
+        TA = {"txt.norm": fp16, "txt.qkv": fp16, "txt.rope": fp16, "txt.p": fp16, "txt.attn": fp16}
+        VA = {"vis.norm": fp16, "vis.qkv": fp16, "vis.rope": fp16, "vis.p": fp16, "vis.attn": fp16, "vis.in": bf16}
+        runs = [
+            ("r5 ships: all bf16, last row exact", {**TXT_ALL, **VIS_ALL}, True),
+            ("all fp16", {**T16, **V16}, True),
+            ("all fp16, merged bf16", {**T16, **V16, "vis.merged": bf16}, True),
+            ("all fp16, txt.delta bf16", {**T16, **V16, "txt.delta": bf16}, True),
+            ("all fp16, txt.act bf16", {**T16, **V16, "txt.act": bf16}, True),
+            ("all fp16, txt.delta + txt.act bf16", {**T16, **V16, "txt.delta": bf16, "txt.act": bf16}, True),
+            ("all fp16, txt.delta exact", {**T16, **V16, "txt.delta": exact}, True),
+            ("all fp16, vis.delta bf16", {**T16, **V16, "vis.delta": bf16}, True),
+            ("all fp16, vis.act bf16", {**T16, **V16, "vis.act": bf16}, True),
+            ("all fp16, vis.delta + vis.act bf16", {**T16, **V16, "vis.delta": bf16, "vis.act": bf16}, True),
+            ("all fp16, vis.delta + vis.act + txt.delta + txt.act bf16", {**T16, **V16, "vis.delta": bf16, "vis.act": bf16, "txt.delta": bf16, "txt.act": bf16}, True),
+            ("attention sides fp16 only (both stacks), rest bf16", {**TXT_ALL, **VIS_ALL, **TA, **VA}, True),
+            ("txt all fp16, tower bf16", {**T16, **VIS_ALL}, True),
+            ("txt all fp16, tower exact", {**T16}, True),
+            ("tower all fp16, txt exact", {**V16}, True),
+            ("tower all bf16, txt exact", {**VIS_ALL}, True),
+            ("all fp16, last row NOT exact", {**T16, **V16}, False),
+            ("all split-bf16 (16 bits)", {"txt.*": split16, "vis.*": split16, "vis.in": bf16}, True),
+        ]
+    if a.set == "r6b":
+        # second pass: with every class in fp16 (6.9e-4 / 2.5e-4 over 32 samples), which classes are worth MORE than 11 bits
+        exact = lambda x: x  # noqa: E731
+        sc16 = lambda k: (lambda x: fp16(x * 2.0 ** -k) * 2.0 ** k)  # noqa: E731  (fp16 behind a power-of-two pre-scale: the range-safe delta form)
+        A16 = {"txt.*": fp16, "vis.*": fp16, "vis.in": bf16}
+        runs = [("all fp16", A16, True)]
+        for c in ("vis.norm", "vis.qkv", "vis.rope", "vis.p", "vis.attn", "vis.delta", "vis.act", "vis.mid", "vis.merged",
+                  "txt.norm", "txt.qkv", "txt.rope", "txt.p", "txt.attn", "txt.delta", "txt.act"):
+            runs.append((f"all fp16, {c} exact", {**A16, c: exact}, True))
+        runs += [
+            ("all fp16, vis.delta + txt.delta exact", {**A16, "vis.delta": exact, "txt.delta": exact}, True),
+            ("all fp16, vis.delta + vis.act exact", {**A16, "vis.delta": exact, "vis.act": exact}, True),
+            ("all fp16, both deltas + both acts exact", {**A16, "vis.delta": exact, "txt.delta": exact, "vis.act": exact, "txt.act": exact}, True),
+            ("all fp16, both deltas + both acts + vis.norm + txt.norm exact", {**A16, "vis.delta": exact, "txt.delta": exact, "vis.act": exact, "txt.act": exact, "vis.norm": exact, "txt.norm": exact}, True),
+            ("all fp16, deltas as fp16 behind a 2^-6 pre-scale", {**A16, "vis.delta": sc16(6), "txt.delta": sc16(6)}, True),
+            ("all fp16, deltas as fp16 behind a 2^-10 pre-scale", {**A16, "vis.delta": sc16(10), "txt.delta": sc16(10)}, True),
+            ("all fp16, deltas + acts behind a 2^-8 pre-scale", {**A16, "vis.delta": sc16(8), "txt.delta": sc16(8), "vis.act": sc16(8), "txt.act": sc16(8)}, True),
+            ("all fp16, deltas split-bf16", {**A16, "vis.delta": split16, "txt.delta": split16}, True),
+        ]
     if a.only:
         keep = set(a.only.split(";"))
         runs = [r for r in runs if r[0] in keep]
