@@ -213,6 +213,16 @@ int vqs_score_head(const float* d_logits, int32_t ldl, int32_t V, const int32_t*
  *                  gemm_variant 3.  The tower's / projector's
  *                  linear weights must be finite and below 65 520 in magnitude (any CLIP checkpoint is: the model was trained in fp16);
  *                  the library does not look -- the Python binding checks at bind time and names the tensors (engine.fp16_unsafe_weights).
+ *   "proj_fp16"    1 (default) with vit_fp16 the selected features (hidden_states[-2]: the residual STREAM cast to 16 bits) and the projector's hidden
+ *                  tensor are fp16 as well; 0 = those two stay bf16 while the tower's blocks run fp16.  The stream is a sum over every block's
+ *                  output: it is the tower site whose bind-time range proof fails first (see "Range safety" below).
+ *   Range safety of the three fp16 options (round 6).  The library does not look at weights; the Python binding does, at bind time
+ *                  (t2v_metrics_amd/engine.py fp16_range_proof): for every fp16 site of an option it computes a bound of |T| from the weights
+ *                  alone -- norm outputs sqrt(D) |g| (+ |b|), norm-fed linears by Cauchy-Schwarz, attention outputs by the value bound, sum-fed
+ *                  linears by the row's l1 norm, the tower's stream by the sum of its blocks' output bounds -- and switches an option that is on BY
+ *                  DEFAULT off (one warning) where a bound exceeds half of the fp16 maximum: fp16 runs only where no input can overflow it.  An
+ *                  option the caller set explicitly is honoured.  Backstop for that case: flags bit 1 (a non-finite label log-prob); the model
+ *                  wrapper then re-scores the batch with the fp16 options off instead of raising (clip_t5_model.py score_pairs).
  *   "enc_fp16"     1 (default, round 5) the ATTENTION SIDE of the T5 encoder holds its 16-bit tensors in IEEE fp16: both RMSNorm outputs, q / k / v, the
  *                  softmax probabilities and the attention output; q|k|v, o and the gated wi read fp16 copies of their weights (made by
  *                  vqs_bind_weights: 7.2 GB more packed buffer at XXL) -- what HF's own fp16 T5 path holds in fp16.  The sub-layer outputs (the

@@ -47,6 +47,25 @@ const char* vqs_qwen_last_error(const vqs_qwen_handle* h);
 int vqs_qwen_profile_enable(vqs_qwen_handle* h, int32_t on);
 int vqs_qwen_profile_read(vqs_qwen_handle* h, double* gemm_ms, double* gemm_flops, double* gemm_bytes, int32_t reset);
 
+/* ---- The range-safe fp16 forms (round 6; option "fp16", default 1 where the model is eligible).
+ * The reference runs this model in bf16 (qwen2vl_model.py:110-133, torch_dtype bfloat16); BASELINE.json asks for |delta log P| <= 1e-3 against fp32,
+ * which a bf16 prefill misses by 4-6 x (profiles/r5_qwen_error_attribution.md, r6_call1_*: every 16-bit activation class has to carry >= 11 bits).
+ * With "fp16" = 1 every 16-bit activation T of the tower, the merger and the prefill is held as IEEE fp16(T * sigma_T) and every GEMM reads fp16
+ * copies of the packed weights.  sigma_T = 2^-s is fixed at BIND time from a bound of |T| PROVEN from the weights alone (RMSNorm output <=
+ * sqrt(D) |g|; a norm-fed linear by Cauchy-Schwarz; attention output = a convex combination of value rows; |SiLU(g) u| <= |g| |u|; a sum-fed
+ * linear by its row's l1 norm: csrc/qwen_decode.hip) so that no input can drive a stored fp16 value beyond half of the fp16 maximum --
+ * range-safe by construction, no calibration data.  GEMM epilogues and norm kernels carry the scales (powers of two: exact); accumulation,
+ * statistics and softmax stay fp32; the precise tail and the decode step are unchanged (the KV cache stays bf16 in true units).
+ * vqs_qwen_bind_weights computes the bounds on the device and SYNCHRONISES THE STREAM ONCE to read them (only with the option on).
+ * If a weight does not fit fp16 or a bound is not finite the handle falls back to the bf16 forms (vqs_qwen_get_option "fp16" reads 0, the reason
+ * is in vqs_qwen_last_error).  d_merged of vqs_qwen_encode_vision is an OPAQUE 16-bit tensor in the handle's operand format (bf16, or fp16 behind
+ * the merger's scale): hand it to vqs_qwen_score / prefill of the same handle under the same option value.
+ * "fp16" may be set to 0 / back to 1 on a bound handle (the bf16 forms are always resident); 1 needs the option on when the weights were bound. */
+int vqs_qwen_get_option(const vqs_qwen_handle* h, const char* name, int64_t* value);   /* "fp16" (what runs), "fp16_requested", "fp16_eligible", "tail_precise", "x_pitch" */
+/* The proof's result: per site the bound of |T| and sigma_T, in the order vision blocks (x0, qkv, dattn, x1, act, dmlp each), merger
+ * (norm output, mlp.0 output, merged tokens), language-model layers (six each).  Returns the number of sites (0: no proof made); fills at most cap. */
+int vqs_qwen_range_report(const vqs_qwen_handle* h, float* bounds, float* sigmas, int32_t cap);
+
 size_t vqs_qwen_packed_bytes(const vqs_qwen_handle* h);
 int vqs_qwen_bind_weights(vqs_qwen_handle* h, const vqs_weight_desc* descs, int32_t n, void* d_packed, size_t packed_bytes,
                           void* stream);
@@ -61,7 +80,7 @@ int vqs_qwen_bind_weights(vqs_qwen_handle* h, const vqs_weight_desc* descs, int3
  *   d_cell_inv   int32 [N / merge_unit]          original merged cell -> windowed cell slot
  *   d_cos_w/d_sin_w  fp32 [Np, head_dim/2]       2-D rotary tables in windowed order;  d_cos_f/d_sin_f [N, ...] original order
  *   frame_len    patches per frame (h * w)
- *   d_merged     bf16 [N / merge_unit, v_out_hidden]   out, ORIGINAL cell order */
+ *   d_merged     16-bit [N / merge_unit, v_out_hidden] out, ORIGINAL cell order (bf16; with option fp16: fp16 behind the merger's scale -- opaque, see above) */
 size_t vqs_qwen_vision_workspace_bytes(const vqs_qwen_handle* h, int32_t N, int32_t Np);
 int vqs_qwen_encode_vision(vqs_qwen_handle* h, const void* d_patches, int32_t N, const int32_t* d_row_map,
                            const int32_t* d_inv_row, const int32_t* d_win_valid, const int32_t* d_cell_inv, const float* d_cos_w,
@@ -112,7 +131,8 @@ int vqs_qwen_debug_tap(vqs_qwen_handle* h, const char* name, void* d_dst, size_t
  * of every sample's last prompt position -- the one row the reference reads (qwen2vl_model.py:222-301: scores[0] of generate) -- carried
  * layer by layer beside the bf16 prefill with 16 significant bits (split-bf16 operands as stacked rows of the same GEMMs, fp32 partial sums,
  * fp32 q / softmax / sub-layer outputs; attention over the layer's bf16 K / V); 0 = the logits of the bf16 prefill's last row (rounds 2-4).
- * Same function either way; the attribution behind it and the measured effect: profiles/r5_qwen_error_attribution.md.  Any time after create. */
+ * Same function either way; the attribution behind it and the measured effect: profiles/r5_qwen_error_attribution.md.  Any time after create.
+ * "fp16": see "The range-safe fp16 forms" above. */
 int vqs_qwen_debug_option(vqs_qwen_handle* h, const char* name, int64_t value);
 
 #ifdef __cplusplus

@@ -201,7 +201,7 @@ class EngineRoundedOracle(Oracle):
     DEC_FP32 = ("dec.qkv", "dec.delta")
 
     def __init__(self, cfg, weights, emulate="engine", round_fn=bf16_round, acc=torch.float64, classes=None, dec_precise=True,
-                 split_classes=(), half_classes=(), vit_fp16=True, device="cpu", enc_fp16=True, dec_fp16=True):
+                 split_classes=(), half_classes=(), vit_fp16=True, device="cpu", enc_fp16=True, dec_fp16=True, proj_shifts=(0, 0)):
         """`split_classes`: classes (of the tower / projector / encoder) to model as split-bf16 tensors instead of bf16 ones -- a
         what-if for tools/error_attribution.py, nothing the engine does today; the extra name "vit.v" splits the value heads only
         (q and k stay bf16: the score path).  `half_classes`: classes to model as IEEE fp16 tensors (11 significant bits instead of
@@ -215,6 +215,9 @@ class EngineRoundedOracle(Oracle):
         `dec_fp16` = the engine's option of that name (round 5, default 1; only with the precise decoder): the encoder's OUTPUT and the decoder's
         cross-attention score path -- q (from the full split norm output, rounded once), q.Wk (fp16 copy of Wk), the probabilities -- are IEEE fp16
         tensors; P.E runs on fp16 operands and still leaves as a split tensor (vqs_api.cpp decoder_pass_precise)."""
+        # proj_shifts = the engine's options (proj_fs_shift, proj_mid_shift) (round 6): with the fp16 tower the selected features are held as
+        # fp16(x * 2^-fs) and the projector's hidden tensor as fp16(x * 2^-mid) -- the scales the bind-time range proof asks for (engine.py)
+        self.proj_sigma = (2.0 ** -int(proj_shifts[0]), 2.0 ** -int(proj_shifts[1]))
         super().__init__(cfg, weights, device=device)     # device != "cpu": the what-if runs of tools/error_attribution.py evaluated on the GPU (under `with torch.device(dev)`)
         self.r = round_fn
         self.acc = acc
@@ -263,6 +266,8 @@ class EngineRoundedOracle(Oracle):
             raise KeyError(f"stage-locked run needs the engine tap {name!r}")
         mant = 10 if self.locked[name].dtype == torch.float16 else 7
         e = self.locked[name].detach().to(self.device, torch.float32)
+        if mant == 10 and name in ("vit.feat_in", "vit.pmid"):          # fp16 tensors behind the projector's scales: back to true units
+            e = e / self.proj_sigma[0 if name == "vit.feat_in" else 1]
         e = e.reshape(-1)[: y.numel()].reshape(y.shape) if e.numel() >= y.numel() and e.shape != y.shape else e
         self.report[name] = compare_tap(y, e, valid, mant)
         return e
@@ -280,6 +285,12 @@ class EngineRoundedOracle(Oracle):
         if cls in self.half_extra:
             return self.rh(x)
         return self.r(x)
+
+    def _rc_scaled(self, cls: str, x: torch.Tensor, sigma: float) -> torch.Tensor:
+        """rc() of a class the engine holds behind a power-of-two scale when it is an fp16 tensor (true units in and out)"""
+        if sigma == 1.0 or cls not in self.half_extra:
+            return self.rc(cls, x)
+        return self.rc(cls, x * sigma) / sigma
 
     def rcf(self, cls: str):
         if self.classes is not None and cls not in self.classes:
@@ -332,11 +343,11 @@ class EngineRoundedOracle(Oracle):
             mid = self._emit(t + "mid", rc("vit.act", quick_gelu(self._mm(xn, pfx + "mlp.fc1.weight", pfx + "mlp.fc1.bias"))))
             d_mlp = self._emit(t + "d_mlp", rc("vit.delta", self._mm(mid, pfx + "mlp.fc2.weight", pfx + "mlp.fc2.bias")))
             h = h1 + d_mlp
-        return self._emit("vit.feat_in", rc("vit.feat", h[:, 1:]))               # drop_cls_cast: bf16 operand of the projector
+        return self._emit("vit.feat_in", self._rc_scaled("vit.feat", h[:, 1:], self.proj_sigma[0]))      # drop_cls_cast: 16-bit operand of the projector
 
     def projector(self, feats: torch.Tensor) -> torch.Tensor:
         rc = self.rc
-        x = self._emit("vit.pmid", rc("proj.mid", gelu_erf(self._mm(feats, "mm_projector.0.weight", "mm_projector.0.bias"))))
+        x = self._emit("vit.pmid", self._rc_scaled("proj.mid", gelu_erf(self._mm(feats, "mm_projector.0.weight", "mm_projector.0.bias")), self.proj_sigma[1]))
         y = self._mm(x, "mm_projector.2.weight", "mm_projector.2.bias")
         # round 5: the fp16-operand GEMM rounds its fp32 accumulator to the bf16 feature tensor directly (round 4: to fp16, then a cast)
         return self._emit("proj", rc("proj.out", y))

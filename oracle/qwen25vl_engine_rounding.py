@@ -40,6 +40,85 @@ import torch.nn.functional as F
 
 from .clip_t5_engine_rounding import bf16_round, compare_tap, tiled_attention
 
+
+def fp16_round(x: torch.Tensor) -> torch.Tensor:
+    """Round-to-nearest-even to IEEE fp16 (overflow -> inf, like v_cvt_pk_f16_f32), returned as fp32."""
+    return x.to(torch.float32).to(torch.float16).to(torch.float32)
+
+
+_SITE_OF_TAP = {"xn0": "x0", "q0": "qkv", "k0": "qkv", "q": "qkv", "k": "qkv", "v": "qkv", "attn": "qkv", "d_attn": "dattn", "xn1": "x1", "ff": "act",
+                "d_mlp": "dmlp", "xnm": "m_x", "mid": "m_mid", "merged_w": "m_out", "merged": "m_out"}
+SITE_KINDS = ("x0", "qkv", "dattn", "x1", "act", "dmlp")
+
+
+def sites_from_report(cfg, values) -> Dict[tuple, float]:
+    """vqs_qwen_range_report's flat order (vision blocks x six sites, merger x three, language-model layers x six) -> {(stack, layer, kind): value}."""
+    v = [float(x) for x in values]
+    out, k = {}, 0
+    for i in range(cfg.vision.depth):
+        for kind in SITE_KINDS:
+            out[("vis", i, kind)] = v[k]
+            k += 1
+    for kind in ("m_x", "m_mid", "m_out"):
+        out[("vis", -1, kind)] = v[k]
+        k += 1
+    for i in range(cfg.text.layers):
+        for kind in SITE_KINDS:
+            out[("txt", i, kind)] = v[k]
+            k += 1
+    assert k == len(v), (k, len(v))
+    return out
+
+
+def range_bounds(cfg, weights: Dict[str, torch.Tensor]) -> Dict[tuple, float]:
+    """The bind-time range proof of the fp16 forms restated in torch (csrc/qwen_decode.hip "Bind-time range proof"; vqs_qwen.cpp
+    compute_ranges): for every 16-bit activation site a bound of |T| from the weights alone.  Same inequalities, computed independently on the
+    UNPACKED checkpoint tensors in fp64: RMSNorm output <= sqrt(D) |g|; a norm-fed linear <= ||W_j o g||_2 sqrt(D) + |b_j|; rotary <= sqrt 2;
+    attention output <= the q|k|v maximum; a sum-fed linear <= sum_k |W_jk| u_k + |b_j|; |SiLU(g) u| <= |g| |u|."""
+    W = lambda n: weights[n].detach().to("cpu", torch.float64)  # noqa: E731
+    out = {}
+
+    def chain(stack, i, D, g1, g2, qkv_w, qkv_b, o_w, o_b, gate_w, gate_b, up_w, up_b, down_w, down_b):
+        R = D ** 0.5
+        out[(stack, i, "x0")] = float(R * g1.abs().max())
+        pre = R * (qkv_w * g1[None, :]).norm(dim=1) + (qkv_b.abs() if qkv_b is not None else 0.0)
+        out[(stack, i, "qkv")] = float(2.0 ** 0.5 * pre.max())
+        out[(stack, i, "dattn")] = float((o_w.abs().sum(dim=1) * pre.max() + (o_b.abs() if o_b is not None else 0.0)).max())
+        out[(stack, i, "x1")] = float(R * g2.abs().max())
+        gb = R * (gate_w * g2[None, :]).norm(dim=1) + (gate_b.abs() if gate_b is not None else 0.0)
+        ub = R * (up_w * g2[None, :]).norm(dim=1) + (up_b.abs() if up_b is not None else 0.0)
+        act = gb * ub
+        out[(stack, i, "act")] = float(act.max())
+        out[(stack, i, "dmlp")] = float((down_w.abs() @ act + (down_b.abs() if down_b is not None else 0.0)).max())
+
+    v, t = cfg.vision, cfg.text
+    for i in range(v.depth):
+        p = f"model.visual.blocks.{i}."
+        chain("vis", i, v.hidden, W(p + "norm1.weight"), W(p + "norm2.weight"), W(p + "attn.qkv.weight"), W(p + "attn.qkv.bias"), W(p + "attn.proj.weight"),
+              W(p + "attn.proj.bias"), W(p + "mlp.gate_proj.weight"), W(p + "mlp.gate_proj.bias"), W(p + "mlp.up_proj.weight"), W(p + "mlp.up_proj.bias"),
+              W(p + "mlp.down_proj.weight"), W(p + "mlp.down_proj.bias"))
+    g = W("model.visual.merger.ln_q.weight")
+    mh = v.hidden * v.merge_unit
+    out[("vis", -1, "m_x")] = float(v.hidden ** 0.5 * g.abs().max())
+    mid = mh ** 0.5 * (W("model.visual.merger.mlp.0.weight") * g.repeat(v.merge_unit)[None, :]).norm(dim=1) + W("model.visual.merger.mlp.0.bias").abs()
+    out[("vis", -1, "m_mid")] = float(mid.max())
+    out[("vis", -1, "m_out")] = float((W("model.visual.merger.mlp.2.weight").abs() @ mid + W("model.visual.merger.mlp.2.bias").abs()).max())
+    for i in range(t.layers):
+        p = f"model.language_model.layers.{i}."
+        qkv_w = torch.cat([W(p + f"self_attn.{n}_proj.weight") for n in "qkv"])
+        qkv_b = torch.cat([W(p + f"self_attn.{n}_proj.bias") for n in "qkv"])
+        chain("txt", i, t.hidden, W(p + "input_layernorm.weight"), W(p + "post_attention_layernorm.weight"), qkv_w, qkv_b, W(p + "self_attn.o_proj.weight"), None,
+              W(p + "mlp.gate_proj.weight"), None, W(p + "mlp.up_proj.weight"), None, W(p + "mlp.down_proj.weight"), None)
+    return out
+
+
+def sigma_of_bound(B: float, head: float = 32768.0) -> float:
+    """vqs_qwen.cpp site_from_bound: the largest power of two <= 1 with B * sigma <= head (half of the fp16 maximum)."""
+    e = 0
+    while B * 2.0 ** -e > head:
+        e += 1
+    return 2.0 ** -e
+
 HDP = 128          # lanes per head in the engine's Q / K / V / attention tensors (vqs_qwen.cpp)
 
 
@@ -59,10 +138,15 @@ class QwenEngineRounded:
     """See the module docstring.  ``layers`` (stage-locked runs only): restrict the check to these block / layer indices
     (None = all) -- every launch is evaluated on the engine's own inputs, so a subset is a valid, cheaper check."""
 
-    def __init__(self, cfg, weights: Dict[str, torch.Tensor], round_fn=bf16_round, acc=torch.float64):
+    def __init__(self, cfg, weights: Dict[str, torch.Tensor], round_fn=bf16_round, acc=torch.float64, sites: Optional[Dict[tuple, float]] = None):
+        """``sites`` (round 6): {(stack, layer, kind): sigma} of the engine's range-safe fp16 forms (``sites_from_report(cfg, sigmas)``) --
+        the tower, merger and prefill then hold every 16-bit tensor as fp16(T * sigma) (computed here in TRUE units: fp16_round(x * sigma) /
+        sigma), P as plain fp16, the language model's final norm output as bf16; taps are fp16 tensors divided by their sigma on read.
+        None = every tensor rounded with ``round_fn`` (bf16: the reference's dtype)."""
         self.cfg = cfg
         self._raw = weights                      # converted on use: the 7B weight set is 33 GB in fp32
         self.r = round_fn
+        self.sites = sites
         self.acc = acc
         self.locked: Optional[Dict[str, torch.Tensor]] = None
         self.record: Optional[Dict[str, torch.Tensor]] = None
@@ -81,6 +165,24 @@ class QwenEngineRounded:
     def w(self):
         return QwenEngineRounded._W(self._raw)
 
+    def _rf(self, stack: str, i: int, kind: str):
+        """rounding function (true units in and out) of a 16-bit site"""
+        if self.sites is None:
+            return self.r
+        s = self.sites[(stack, i, kind)]
+        return lambda x: fp16_round(x.to(torch.float32) * s) / s
+
+    def _tap_sigma_bits(self, name: str):
+        """(sigma, stored mantissa bits) of the engine tensor behind a tap name"""
+        if self.sites is None:
+            return 1.0, 7
+        parts = name.split(".")
+        kind = _SITE_OF_TAP.get(parts[-1])
+        if kind is None or parts[0] == "dec":
+            return 1.0, 7                        # fp32 tensors, the final norm's bf16 output, the decode step (bf16)
+        i = int(parts[1]) if len(parts) == 3 else -1
+        return self.sites[(parts[0], i, kind)], 10
+
     def _emit(self, name: str, y: torch.Tensor, cols: Optional[int] = None) -> torch.Tensor:
         """Free-running: record and pass through.  Stage-locked: compare with the engine's tensor of that name and return the
         ENGINE's tensor.  ``cols``: the engine's rows are wider than ``y``'s (zero padding behind ``cols`` columns): compare
@@ -91,7 +193,8 @@ class QwenEngineRounded:
             return y
         if name not in self.locked:
             raise KeyError(f"stage-locked run needs the engine tap {name!r}")
-        e = self.locked[name].detach().to("cpu", torch.float32)
+        sigma, bits = self._tap_sigma_bits(name)
+        e = self.locked[name].detach().to("cpu", torch.float32) / sigma
         pad_nonzero = 0
         if cols is not None:
             e = e.reshape(y.shape[0], -1)
@@ -99,8 +202,9 @@ class QwenEngineRounded:
             e = e[:, :cols]
         else:
             e = e.reshape(y.shape)
-        self.report[name] = compare_tap(y, e)
+        self.report[name] = compare_tap(y, e, mant_bits=bits)
         self.report[name]["pad_nonzero"] = pad_nonzero
+        self.report[name]["stored_absmax"] = float(e.abs().max()) * sigma       # what the 16-bit tensor itself holds (fp16 forms: <= 65504)
         return e
 
     def _have(self, name: str) -> bool:
@@ -112,17 +216,17 @@ class QwenEngineRounded:
         y = (x.to(self.acc) @ w.reshape(w.shape[0], -1).to(self.acc).t()).float()
         return y + self.w[bname] if bname is not None else y
 
-    def _norm(self, h: torch.Tensor, wname: str, eps: float) -> torch.Tensor:
+    def _norm(self, h: torch.Tensor, wname: str, eps: float, rf=None) -> torch.Tensor:
         ms = (h.double() ** 2).mean(-1, keepdim=True).float()
         rs = torch.rsqrt(ms + eps)
-        return self.r((h * rs) * self.w[wname])
+        return (rf or self.r)((h * rs) * self.w[wname])
 
-    def _heads(self, y: torch.Tensor, nseg: int, S: int, H: int, hd: int) -> torch.Tensor:
+    def _heads(self, y: torch.Tensor, nseg: int, S: int, H: int, hd: int, rf=None) -> torch.Tensor:
         """[nseg*S, H*hd] -> bf16, head-major, 128-lane heads: [nseg, H, S, 128]."""
-        y = self.r(y).reshape(nseg, S, H, hd)
+        y = (rf or self.r)(y).reshape(nseg, S, H, hd)
         return F.pad(y, (0, HDP - hd)).permute(0, 2, 1, 3).contiguous()
 
-    def _rope(self, x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, hd: int) -> torch.Tensor:
+    def _rope(self, x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, hd: int, rf=None) -> torch.Tensor:
         """x [nseg, H, S, 128], cos / sin [nseg*S, hd/2] -> rotated, bf16 (rope_kernel: a*c - b*s, b*c + a*s in fp32)."""
         nseg, H, S, _ = x.shape
         half = hd // 2
@@ -130,8 +234,8 @@ class QwenEngineRounded:
         s = sin.reshape(nseg, 1, S, half).double()
         a, b = x[..., :half].double(), x[..., half: 2 * half].double()
         out = x.clone()
-        out[..., :half] = self.r((a * c - b * s).float())
-        out[..., half: 2 * half] = self.r((b * c + a * s).float())
+        out[..., :half] = (rf or self.r)((a * c - b * s).float())
+        out[..., half: 2 * half] = (rf or self.r)((b * c + a * s).float())
         return out
 
     def _unpad_heads(self, a: torch.Tensor, H: int, hd: int) -> torch.Tensor:
@@ -158,6 +262,8 @@ class QwenEngineRounded:
         real = row_map >= 0
         H, hd, VH = v.heads, v.head_dim, v.hidden
         scale = hd ** -0.5
+        F16 = self.sites is not None
+        rp = fp16_round if F16 else r            # probabilities: plain fp16 in the fp16 forms (P <= 1 needs no scale)
         pre = self._emit("vis.pre", self._lin(r(pixel_values), "model.visual.patch_embed.proj.weight"))
         h = torch.where(real[:, None], pre[row_map.clamp(min=0)], torch.zeros(1, VH))        # window permutation, zero padding rows
         d_attn = d_mlp = None
@@ -167,7 +273,8 @@ class QwenEngineRounded:
                 h = None             # skipped block of a stage-locked run: the next checked block starts from the engine's stream
                 continue
             h = self._stream(t + "h", h, d_attn, d_mlp, (Np, VH), first=(i == 0))
-            xn = self._emit(t + "xn0", self._norm(h, p + "norm1.weight", v.rms_eps))
+            r_x0, r_qkv, r_da, r_x1, r_act, r_dm = (self._rf("vis", i, k) for k in SITE_KINDS)
+            xn = self._emit(t + "xn0", self._norm(h, p + "norm1.weight", v.rms_eps, r_x0))
             full = i in v.fullatt_blocks
             if full:
                 xin, rows, S, cos, sin, klen = xn[inv_row], N, S_f, lay["cos_f"], lay["sin_f"], None
@@ -175,30 +282,30 @@ class QwenEngineRounded:
                 xin, rows, S, cos, sin, klen = xn, Np, S_w, lay["cos_w"], lay["sin_w"], lay["win_valid"].long()
             nseg = rows // S
             qkv = self._lin(xin, p + "attn.qkv.weight", p + "attn.qkv.bias").reshape(rows, 3, H * hd)
-            q0 = self._emit(t + "q0", self._heads(qkv[:, 0], nseg, S, H, hd))
-            k0 = self._emit(t + "k0", self._heads(qkv[:, 1], nseg, S, H, hd))
-            val = self._emit(t + "v", self._heads(qkv[:, 2], nseg, S, H, hd))
-            q = self._emit(t + "q", self._rope(q0, cos, sin, hd))
-            k = self._emit(t + "k", self._rope(k0, cos, sin, hd))
-            a = tiled_attention(q, k, val, scale, key_len=klen, round_fn=r, acc=self.acc).reshape(rows, H * HDP)
+            q0 = self._emit(t + "q0", self._heads(qkv[:, 0], nseg, S, H, hd, r_qkv))
+            k0 = self._emit(t + "k0", self._heads(qkv[:, 1], nseg, S, H, hd, r_qkv))
+            val = self._emit(t + "v", self._heads(qkv[:, 2], nseg, S, H, hd, r_qkv))
+            q = self._emit(t + "q", self._rope(q0, cos, sin, hd, r_qkv))
+            k = self._emit(t + "k", self._rope(k0, cos, sin, hd, r_qkv))
+            a = tiled_attention(q, k, val, scale, key_len=klen, round_fn=rp, round_out=r_qkv, acc=self.acc).reshape(rows, H * HDP)
             if vision_heads_compact(self.cfg):
                 a = self._emit(t + "attn", self._unpad_heads(a, H, hd))
             else:
                 a = self._unpad_heads(self._emit(t + "attn", a), H, hd)
-            d = r(self._lin(a, p + "attn.proj.weight", p + "attn.proj.bias"))
+            d = r_da(self._lin(a, p + "attn.proj.weight", p + "attn.proj.bias"))
             if full:
                 d = torch.where(real[:, None], d[row_map.clamp(min=0)], torch.zeros(1, VH))   # scatter back, zero padding rows
             d_attn = self._emit(t + "d_attn", d)
-            xn = self._emit(t + "xn1", self._norm(h + d_attn, p + "norm2.weight", v.rms_eps))
+            xn = self._emit(t + "xn1", self._norm(h + d_attn, p + "norm2.weight", v.rms_eps, r_x1))
             g = self._lin(xn, p + "mlp.gate_proj.weight", p + "mlp.gate_proj.bias")
             u = self._lin(xn, p + "mlp.up_proj.weight", p + "mlp.up_proj.bias")
-            ff = self._emit(t + "ff", r(g * torch.sigmoid(g) * u), cols=v.mlp)
-            d_mlp = self._emit(t + "d_mlp", r(self._lin(ff, p + "mlp.down_proj.weight", p + "mlp.down_proj.bias")))
+            ff = self._emit(t + "ff", r_act(g * torch.sigmoid(g) * u), cols=v.mlp)
+            d_mlp = self._emit(t + "d_mlp", r_dm(self._lin(ff, p + "mlp.down_proj.weight", p + "mlp.down_proj.bias")))
         h = self._stream("vis.h_out", h, d_attn, d_mlp, (Np, VH))
-        xn = self._emit("vis.xnm", self._norm(h, "model.visual.merger.ln_q.weight", 1e-6))
+        xn = self._emit("vis.xnm", self._norm(h, "model.visual.merger.ln_q.weight", 1e-6, self._rf("vis", -1, "m_x")))
         x = xn.reshape(Np // v.merge_unit, v.merge_unit * VH)
-        mid = self._emit("vis.mid", r(F.gelu(self._lin(x, "model.visual.merger.mlp.0.weight", "model.visual.merger.mlp.0.bias"))))
-        mw = self._emit("vis.merged_w", r(self._lin(mid, "model.visual.merger.mlp.2.weight", "model.visual.merger.mlp.2.bias")))
+        mid = self._emit("vis.mid", self._rf("vis", -1, "m_mid")(F.gelu(self._lin(x, "model.visual.merger.mlp.0.weight", "model.visual.merger.mlp.0.bias"))))
+        mw = self._emit("vis.merged_w", self._rf("vis", -1, "m_out")(self._lin(mid, "model.visual.merger.mlp.2.weight", "model.visual.merger.mlp.2.bias")))
         return self._emit("vis.merged", mw[lay["cell_inv"].long()])
 
     # ------------------------------------------------------------------------------------------------ language model
@@ -212,8 +319,10 @@ class QwenEngineRounded:
         scale = hd ** -0.5
         slot = lay["vis_slot"].reshape(-1).long()
         ids = input_ids.reshape(-1).long().clamp(0, t_.vocab - 1)
+        F16 = self.sites is not None
+        rp = fp16_round if F16 else r
         emb = r(self.w["model.language_model.embed_tokens.weight"])[ids]
-        h = self._emit("txt.emb", torch.where((slot >= 0)[:, None], r(merged)[slot.clamp(min=0)], emb))
+        h = self._emit("txt.emb", torch.where((slot >= 0)[:, None], (self._rf("vis", -1, "m_out") if F16 else r)(merged)[slot.clamp(min=0)], emb))
         klen = lay["seq_len"].long()
         d_attn = d_mlp = None
         for i in range(t_.layers):
@@ -222,24 +331,25 @@ class QwenEngineRounded:
                 h = None
                 continue
             h = self._stream(t + "h", h, d_attn, d_mlp, (M, TH), first=(i == 0))
-            xn = self._emit(t + "xn0", self._norm(h, p + "input_layernorm.weight", t_.rms_eps))
-            q0 = self._emit(t + "q0", self._heads(self._lin(xn, p + "self_attn.q_proj.weight", p + "self_attn.q_proj.bias"), B, L, H, hd))
-            k0 = self._emit(t + "k0", self._heads(self._lin(xn, p + "self_attn.k_proj.weight", p + "self_attn.k_proj.bias"), B, L, Hkv, hd))
-            val = self._emit(t + "v", self._heads(self._lin(xn, p + "self_attn.v_proj.weight", p + "self_attn.v_proj.bias"), B, L, Hkv, hd))
-            q = self._emit(t + "q", self._rope(q0, lay["cos"], lay["sin"], hd))
-            k = self._emit(t + "k", self._rope(k0, lay["cos"], lay["sin"], hd))
+            r_x0, r_qkv, r_da, r_x1, r_act, r_dm = (self._rf("txt", i, k) for k in SITE_KINDS)
+            xn = self._emit(t + "xn0", self._norm(h, p + "input_layernorm.weight", t_.rms_eps, r_x0))
+            q0 = self._emit(t + "q0", self._heads(self._lin(xn, p + "self_attn.q_proj.weight", p + "self_attn.q_proj.bias"), B, L, H, hd, r_qkv))
+            k0 = self._emit(t + "k0", self._heads(self._lin(xn, p + "self_attn.k_proj.weight", p + "self_attn.k_proj.bias"), B, L, Hkv, hd, r_qkv))
+            val = self._emit(t + "v", self._heads(self._lin(xn, p + "self_attn.v_proj.weight", p + "self_attn.v_proj.bias"), B, L, Hkv, hd, r_qkv))
+            q = self._emit(t + "q", self._rope(q0, lay["cos"], lay["sin"], hd, r_qkv))
+            k = self._emit(t + "k", self._rope(k0, lay["cos"], lay["sin"], hd, r_qkv))
             rep = H // Hkv
-            a = tiled_attention(q, k.repeat_interleave(rep, dim=1), val.repeat_interleave(rep, dim=1), scale, key_len=klen, round_fn=r,
-                                acc=self.acc, causal=True).reshape(M, H * HDP)
+            a = tiled_attention(q, k.repeat_interleave(rep, dim=1), val.repeat_interleave(rep, dim=1), scale, key_len=klen, round_fn=rp,
+                                round_out=r_qkv, acc=self.acc, causal=True).reshape(M, H * HDP)
             a = self._emit(t + "attn", a)
-            d_attn = self._emit(t + "d_attn", r(self._lin(self._unpad_heads(a, H, hd), p + "self_attn.o_proj.weight")))
-            xn = self._emit(t + "xn1", self._norm(h + d_attn, p + "post_attention_layernorm.weight", t_.rms_eps))
+            d_attn = self._emit(t + "d_attn", r_da(self._lin(self._unpad_heads(a, H, hd), p + "self_attn.o_proj.weight")))
+            xn = self._emit(t + "xn1", self._norm(h + d_attn, p + "post_attention_layernorm.weight", t_.rms_eps, r_x1))
             g = self._lin(xn, p + "mlp.gate_proj.weight")
             u = self._lin(xn, p + "mlp.up_proj.weight")
-            ff = self._emit(t + "ff", r(g * torch.sigmoid(g) * u), cols=t_.mlp)
-            d_mlp = self._emit(t + "d_mlp", r(self._lin(ff, p + "mlp.down_proj.weight")))
+            ff = self._emit(t + "ff", r_act(g * torch.sigmoid(g) * u), cols=t_.mlp)
+            d_mlp = self._emit(t + "d_mlp", r_dm(self._lin(ff, p + "mlp.down_proj.weight")))
         h = self._stream("txt.h_out", h, d_attn, d_mlp, (M, TH))
-        xn = self._emit("txt.xnf", self._norm(h, "model.language_model.norm.weight", t_.rms_eps))
+        xn = self._emit("txt.xnf", self._norm(h, "model.language_model.norm.weight", t_.rms_eps, bf16_round if F16 else None))
         last = xn[lay["last_row"].long()]
         return self._emit("txt.logits", self._lin(last, "lm_head.weight"))
 

@@ -173,14 +173,14 @@ class QwenOracle:
         for i in range(v.depth):
             p = f"model.visual.blocks.{i}."
             r = self._r
-            x = r("vis.norm", rms_norm(h, self._w(p + "norm1.weight"), v.rms_eps))
+            x = r(f"vis.norm.{i}", rms_norm(h, self._w(p + "norm1.weight"), v.rms_eps))
             qkv = r("vis.qkv", x @ self._w(p + "attn.qkv.weight").t() + self._w(p + "attn.qkv.bias"))
             q, k, val = qkv.reshape(N, 3, v.heads, v.head_dim).permute(1, 0, 2, 3).unbind(0)
             q = r("vis.rope", q * cos + rotate_half(q) * sin)                            # :160-172
             k = r("vis.rope", k * cos + rotate_half(k) * sin)
             a = r("vis.attn", self._segment_attention(q, k, val, cu_full if i in v.fullatt_blocks else cu_win, v.head_dim ** -0.5))
             h = h + r("vis.delta", a @ self._w(p + "attn.proj.weight").t() + self._w(p + "attn.proj.bias"))
-            x = r("vis.norm", rms_norm(h, self._w(p + "norm2.weight"), v.rms_eps))
+            x = r(f"vis.norm.{i}", rms_norm(h, self._w(p + "norm2.weight"), v.rms_eps))
             g = F.silu(x @ self._w(p + "mlp.gate_proj.weight").t() + self._w(p + "mlp.gate_proj.bias"))
             u = x @ self._w(p + "mlp.up_proj.weight").t() + self._w(p + "mlp.up_proj.bias")
             h = h + r("vis.delta", r("vis.act", g * u) @ self._w(p + "mlp.down_proj.weight").t() + self._w(p + "mlp.down_proj.bias"))
@@ -188,7 +188,7 @@ class QwenOracle:
                 stages[f"vis_block{i}"] = h.clone()
         # merger (:137-150): RMSNorm, 4 neighbouring patches concatenated, Linear - GELU(erf) - Linear; then undo the
         # window permutation (:463-465)
-        x = self._r("vis.norm", rms_norm(h, self._w("model.visual.merger.ln_q.weight"), 1e-6)).reshape(N // v.merge_unit, -1)
+        x = self._r("vis.norm.merger", rms_norm(h, self._w("model.visual.merger.ln_q.weight"), 1e-6)).reshape(N // v.merge_unit, -1)
         x = self._r("vis.mid", F.gelu(x @ self._w("model.visual.merger.mlp.0.weight").t() + self._w("model.visual.merger.mlp.0.bias")))
         x = self._r("vis.merged", x @ self._w("model.visual.merger.mlp.2.weight").t() + self._w("model.visual.merger.mlp.2.bias"))
         merged = x[torch.argsort(widx)]

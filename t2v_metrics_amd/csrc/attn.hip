@@ -213,8 +213,13 @@ hipError_t lab_set_attn_timing(unsigned long long* d_buf) { return hipMemcpyToSy
 // sub-tiles [32 keys][16 d], read with ds_read_b64_tr_b16.
 // q [B, H, S, HD]; k, v [B, Hkv, S, HD]; out [B*S, H*HD].
 // =====================================================================================================
-template <int HD, bool CAUSAL>
+// F16 (round 6): q / k / v / out are IEEE fp16 tensors (the Qwen2.5-VL row's range-safe fp16 forms; power-of-two scales on q, k fold into
+// p.scale on the host, a scale on v passes through to the output).
+template <int HD, bool CAUSAL, bool F16 = false>
 __global__ void __launch_bounds__(256) attn_fwd_hd_kernel(const AttnParams p) {
+#define HD_MFMA(a, b, c) (F16 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0) \
+                              : __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0))
+#define HD_PACK2(a, b) (F16 ? a_pack2h(a, b) : a_pack2(a, b))
     constexpr int KS = HD / 16;                 // k-steps of the QK^T product
     constexpr int DF = HD / 32;                 // 32-wide output blocks
     constexpr int ROWB = HD * 2;                // bytes per K row
@@ -297,7 +302,7 @@ __global__ void __launch_bounds__(256) attn_fwd_hd_kernel(const AttnParams p) {
     for (int r = 0; r < 16; ++r) osum[r] = 0.0f;
     float m_run = NEG_BIG;
     uint4 ones;
-    ones.x = ones.y = ones.z = ones.w = 0x3f803f80u;
+    ones.x = ones.y = ones.z = ones.w = F16 ? 0x3c003c00u : 0x3f803f80u;
 
     const int swr = lane & 15;                                  // row & 15 of this lane's K rows (kf*32 + lane&31)
     const int k_rd = (lane & 31) * ROWB;
@@ -335,8 +340,7 @@ __global__ void __launch_bounds__(256) attn_fwd_hd_kernel(const AttnParams p) {
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
                 for (int kf = 0; kf < 2; ++kf)
-                    s[kf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kfr[ks][kf]),
-                                                                    __builtin_bit_cast(bf16x8, qf[k4 + ks]), s[kf], 0, 0, 0);
+                    s[kf] = HD_MFMA(kfr[ks][kf], qf[k4 + ks], s[kf]);
         }
 
         // ---- masks (ragged last tile, causal diagonal), running max with deferred rescale, p = 2^(s*c - m)
@@ -381,12 +385,11 @@ __global__ void __launch_bounds__(256) attn_fwd_hd_kernel(const AttnParams p) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 uint4 pb;
-                pb.x = a_pack2(s[kf][8 * t + 0], s[kf][8 * t + 1]);
-                pb.y = a_pack2(s[kf][8 * t + 2], s[kf][8 * t + 3]);
-                pb.z = a_pack2(s[kf][8 * t + 4], s[kf][8 * t + 5]);
-                pb.w = a_pack2(s[kf][8 * t + 6], s[kf][8 * t + 7]);
-                osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, pb),
-                                                                osum, 0, 0, 0);
+                pb.x = HD_PACK2(s[kf][8 * t + 0], s[kf][8 * t + 1]);
+                pb.y = HD_PACK2(s[kf][8 * t + 2], s[kf][8 * t + 3]);
+                pb.z = HD_PACK2(s[kf][8 * t + 4], s[kf][8 * t + 5]);
+                pb.w = HD_PACK2(s[kf][8 * t + 6], s[kf][8 * t + 7]);
+                osum = HD_MFMA(ones, pb, osum);
 #pragma unroll
                 for (int df = 0; df < DF; ++df) {
                     const char* vp = k_lds + (kf * NDB + 2 * df) * 1024;
@@ -397,8 +400,7 @@ __global__ void __launch_bounds__(256) attn_fwd_hd_kernel(const AttnParams p) {
                     const uint2 lo2 = __builtin_bit_cast(uint2, lo), hi2 = __builtin_bit_cast(uint2, hi);
                     uint4 va;
                     va.x = lo2.x; va.y = lo2.y; va.z = hi2.x; va.w = hi2.y;
-                    o[df] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, va),
-                                                                   __builtin_bit_cast(bf16x8, pb), o[df], 0, 0, 0);
+                    o[df] = HD_MFMA(va, pb, o[df]);
                 }
             }
     }
@@ -413,11 +415,13 @@ __global__ void __launch_bounds__(256) attn_fwd_hd_kernel(const AttnParams p) {
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 uint2 v;
-                v.x = a_pack2(o[df][4 * gq + 0] * inv, o[df][4 * gq + 1] * inv);
-                v.y = a_pack2(o[df][4 * gq + 2] * inv, o[df][4 * gq + 3] * inv);
+                v.x = HD_PACK2(o[df][4 * gq + 0] * inv, o[df][4 * gq + 1] * inv);
+                v.y = HD_PACK2(o[df][4 * gq + 2] * inv, o[df][4 * gq + 3] * inv);
                 if (df * 32 + 8 * gq + 4 * hh < ohd) *reinterpret_cast<uint2*>(orow + df * 32 + 8 * gq + 4 * hh) = v;
             }
     }
+#undef HD_MFMA
+#undef HD_PACK2
 }
 
 static constexpr int attn_variant() { return 1; }        // the shipped library holds the LDS-DMA kernel only
@@ -441,10 +445,12 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
     if (p.B <= 0 || p.H <= 0 || p.S <= 0) return hipErrorInvalidValue;
     if (p.hd == 128) {
         const int Hkv = p.Hkv > 0 ? p.Hkv : p.H;
-        if (p.f16) return hipErrorInvalidValue;
         if (p.bias_table != nullptr || Hkv <= 0 || (p.H % Hkv) != 0) return hipErrorInvalidValue;
         if (p.out_hd < 0 || p.out_hd > 128 || (p.out_hd & 3)) return hipErrorInvalidValue;
         const size_t lds = 2 * 2 * (size_t)KT * 128 * 2;            // two stages of K + V tiles
+        if (p.f16)
+            return p.causal ? launch_attn_t(attn_fwd_hd_kernel<128, true, true>, p, lds, stream)
+                            : launch_attn_t(attn_fwd_hd_kernel<128, false, true>, p, lds, stream);
         return p.causal ? launch_attn_t(attn_fwd_hd_kernel<128, true>, p, lds, stream)
                         : launch_attn_t(attn_fwd_hd_kernel<128, false>, p, lds, stream);
     }

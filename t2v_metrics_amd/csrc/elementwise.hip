@@ -99,11 +99,14 @@ __device__ __forceinline__ void st_stream(float4* p, float4 v) {
 // KIND 0: RMSNorm (bsh unused); KIND 1: LayerNorm.  F16: the 16-bit output is IEEE fp16; DF16: the deltas are (w, bsh stay bf16).  The
 // vision tower has both (its sub-layer outputs are fp16 tensors); the T5 encoder of option enc_fp16 has an fp16 operand out and bf16
 // deltas in (Flan-T5's sub-layer outputs do not fit fp16).
-template <int NV, int KIND, int ADD, bool OUT_F32, bool F16 = false, bool DF16 = F16>
+// SC (round 6, the Qwen2.5-VL row's range-safe fp16 forms): the deltas are held behind power-of-two scales -- x += delta * sc.d1 (+ delta2 *
+// sc.d2) -- and the operand leaves as fp16(value * sc.out); all three 1: the unscaled kernel bit for bit.
+struct NormScales { float d1, d2, out; };
+template <int NV, int KIND, int ADD, bool OUT_F32, bool F16 = false, bool DF16 = F16, bool SC = false>
 __global__ void __launch_bounds__(256) norm_rows_reg_kernel(float* __restrict__ x, const bf16_t* __restrict__ delta,
                                                             const bf16_t* __restrict__ delta2,
                                                             const bf16_t* __restrict__ w, const bf16_t* __restrict__ bsh,
-                                                            void* __restrict__ out, int M, float eps, int out_ld) {
+                                                            void* __restrict__ out, int M, float eps, int out_ld, NormScales sc) {
     constexpr int D = NV * 256;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -124,7 +127,11 @@ __global__ void __launch_bounds__(256) norm_rows_reg_kernel(float* __restrict__ 
             for (int j = 0; j < NV; ++j) e[j] = ld_delta_last(er + lane + 64 * j);
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
-                const float4 f = d4_to_f4<DF16>(d[j]), g = d4_to_f4<DF16>(e[j]);
+                float4 f = d4_to_f4<DF16>(d[j]), g = d4_to_f4<DF16>(e[j]);
+                if constexpr (SC) {
+                    f.x *= sc.d1; f.y *= sc.d1; f.z *= sc.d1; f.w *= sc.d1;
+                    g.x *= sc.d2; g.y *= sc.d2; g.z *= sc.d2; g.w *= sc.d2;
+                }
                 v[j].x = (v[j].x + f.x) + g.x; v[j].y = (v[j].y + f.y) + g.y;
                 v[j].z = (v[j].z + f.z) + g.z; v[j].w = (v[j].w + f.w) + g.w;
                 st_stream(xr + lane + 64 * j, v[j]);
@@ -132,7 +139,8 @@ __global__ void __launch_bounds__(256) norm_rows_reg_kernel(float* __restrict__ 
         } else {
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
-                const float4 f = d4_to_f4<DF16>(d[j]);
+                float4 f = d4_to_f4<DF16>(d[j]);
+                if constexpr (SC) { f.x *= sc.d1; f.y *= sc.d1; f.z *= sc.d1; f.w *= sc.d1; }
                 v[j].x += f.x; v[j].y += f.y; v[j].z += f.z; v[j].w += f.w;
                 if (ADD == 1) st_stream(xr + lane + 64 * j, v[j]);
             }
@@ -160,8 +168,9 @@ __global__ void __launch_bounds__(256) norm_rows_reg_kernel(float* __restrict__ 
         const float4 wv = bf4_to_f4(wr[i]);
         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (KIND == 1) bv = bf4_to_f4(br[i]);
-        const float o0 = (v[j].x - mu) * rs * wv.x + bv.x, o1 = (v[j].y - mu) * rs * wv.y + bv.y;
-        const float o2 = (v[j].z - mu) * rs * wv.z + bv.z, o3 = (v[j].w - mu) * rs * wv.w + bv.w;
+        float o0 = (v[j].x - mu) * rs * wv.x + bv.x, o1 = (v[j].y - mu) * rs * wv.y + bv.y;
+        float o2 = (v[j].z - mu) * rs * wv.z + bv.z, o3 = (v[j].w - mu) * rs * wv.w + bv.w;
+        if constexpr (SC) { o0 *= sc.out; o1 *= sc.out; o2 *= sc.out; o3 *= sc.out; }
         if (OUT_F32) {
             reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)row * out_ld)[i] = make_float4(o0, o1, o2, o3);
         } else {
@@ -174,11 +183,11 @@ __global__ void __launch_bounds__(256) norm_rows_reg_kernel(float* __restrict__ 
 }
 
 // any D % 4 == 0
-template <int KIND, int ADD, bool OUT_F32, bool F16 = false, bool DF16 = F16>
+template <int KIND, int ADD, bool OUT_F32, bool F16 = false, bool DF16 = F16, bool SC = false>
 __global__ void __launch_bounds__(256) norm_rows_loop_kernel(float* __restrict__ x, const bf16_t* __restrict__ delta,
                                                              const bf16_t* __restrict__ delta2,
                                                              const bf16_t* __restrict__ w, const bf16_t* __restrict__ bsh,
-                                                             void* __restrict__ out, int M, int D, float eps, int out_ld) {
+                                                             void* __restrict__ out, int M, int D, float eps, int out_ld, NormScales sc) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= M) return;
@@ -191,7 +200,8 @@ __global__ void __launch_bounds__(256) norm_rows_loop_kernel(float* __restrict__
     auto value = [&](int i) {
         float4 v = xr[i];
         if (ADD == 2) {
-            const float4 d = d4_to_f4<DF16>(dr[i]);
+            float4 d = d4_to_f4<DF16>(dr[i]);
+            if constexpr (SC) { d.x *= sc.d1; d.y *= sc.d1; d.z *= sc.d1; d.w *= sc.d1; }
             v.x += d.x; v.y += d.y; v.z += d.z; v.w += d.w;
         }
         return v;
@@ -200,10 +210,12 @@ __global__ void __launch_bounds__(256) norm_rows_loop_kernel(float* __restrict__
     if (ADD == 1 || ADD == 3) {
         for (int i = lane; i < nv; i += 64) {
             float4 v = xr[i];
-            const float4 d = d4_to_f4<DF16>(dr[i]);
+            float4 d = d4_to_f4<DF16>(dr[i]);
+            if constexpr (SC) { d.x *= sc.d1; d.y *= sc.d1; d.z *= sc.d1; d.w *= sc.d1; }
             v.x += d.x; v.y += d.y; v.z += d.z; v.w += d.w;
             if (ADD == 3) {
-                const float4 e = d4_to_f4<DF16>(er[i]);
+                float4 e = d4_to_f4<DF16>(er[i]);
+                if constexpr (SC) { e.x *= sc.d2; e.y *= sc.d2; e.z *= sc.d2; e.w *= sc.d2; }
                 v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w;
             }
             xr[i] = v;
@@ -230,8 +242,9 @@ __global__ void __launch_bounds__(256) norm_rows_loop_kernel(float* __restrict__
         const float4 wv = bf4_to_f4(wr[i]);
         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (KIND == 1) bv = bf4_to_f4(br[i]);
-        const float o0 = (v.x - mu) * rs * wv.x + bv.x, o1 = (v.y - mu) * rs * wv.y + bv.y;
-        const float o2 = (v.z - mu) * rs * wv.z + bv.z, o3 = (v.w - mu) * rs * wv.w + bv.w;
+        float o0 = (v.x - mu) * rs * wv.x + bv.x, o1 = (v.y - mu) * rs * wv.y + bv.y;
+        float o2 = (v.z - mu) * rs * wv.z + bv.z, o3 = (v.w - mu) * rs * wv.w + bv.w;
+        if constexpr (SC) { o0 *= sc.out; o1 *= sc.out; o2 *= sc.out; o3 *= sc.out; }
         if (OUT_F32) {
             reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)row * out_ld)[i] = make_float4(o0, o1, o2, o3);
         } else {
@@ -244,24 +257,24 @@ __global__ void __launch_bounds__(256) norm_rows_loop_kernel(float* __restrict__
 }
 
 // out_ld: row pitch of `out` in elements (0 = D; a multiple of 4).  The stream x and the deltas are always dense.
-template <int KIND, int ADD, bool OUT_F32, bool F16 = false, bool DF16 = F16>
+template <int KIND, int ADD, bool OUT_F32, bool F16 = false, bool DF16 = F16, bool SC = false>
 static hipError_t launch_norm_t(float* x, const bf16_t* delta, const bf16_t* delta2, const bf16_t* w, const bf16_t* b, void* out,
-                                int M, int D, float eps, hipStream_t s, int out_ld = 0) {
+                                int M, int D, float eps, hipStream_t s, int out_ld = 0, NormScales sc = NormScales{1.0f, 1.0f, 1.0f}) {
     const dim3 grid((M + 3) / 4), block(256);
     if (out_ld <= 0) out_ld = D;
     if (out_ld < D || (out_ld & 3)) return hipErrorInvalidValue;
     if (D == 1024)
-        hipLaunchKernelGGL((norm_rows_reg_kernel<4, KIND, ADD, OUT_F32, F16, DF16>), grid, block, 0, s, x, delta, delta2, w, b, out, M, eps, out_ld);
+        hipLaunchKernelGGL((norm_rows_reg_kernel<4, KIND, ADD, OUT_F32, F16, DF16, SC>), grid, block, 0, s, x, delta, delta2, w, b, out, M, eps, out_ld, sc);
     else if (D == 2048)
-        hipLaunchKernelGGL((norm_rows_reg_kernel<8, KIND, ADD, OUT_F32, F16, DF16>), grid, block, 0, s, x, delta, delta2, w, b, out, M, eps, out_ld);
+        hipLaunchKernelGGL((norm_rows_reg_kernel<8, KIND, ADD, OUT_F32, F16, DF16, SC>), grid, block, 0, s, x, delta, delta2, w, b, out, M, eps, out_ld, sc);
     else if (D == 4096)
-        hipLaunchKernelGGL((norm_rows_reg_kernel<16, KIND, ADD, OUT_F32, F16, DF16>), grid, block, 0, s, x, delta, delta2, w, b, out, M, eps, out_ld);
+        hipLaunchKernelGGL((norm_rows_reg_kernel<16, KIND, ADD, OUT_F32, F16, DF16, SC>), grid, block, 0, s, x, delta, delta2, w, b, out, M, eps, out_ld, sc);
     else if (D == 1280)     // Qwen2.5-VL vision tower
-        hipLaunchKernelGGL((norm_rows_reg_kernel<5, KIND, ADD, OUT_F32, F16, DF16>), grid, block, 0, s, x, delta, delta2, w, b, out, M, eps, out_ld);
+        hipLaunchKernelGGL((norm_rows_reg_kernel<5, KIND, ADD, OUT_F32, F16, DF16, SC>), grid, block, 0, s, x, delta, delta2, w, b, out, M, eps, out_ld, sc);
     else if (D == 3584)     // Qwen2.5-VL-7B language model
-        hipLaunchKernelGGL((norm_rows_reg_kernel<14, KIND, ADD, OUT_F32, F16, DF16>), grid, block, 0, s, x, delta, delta2, w, b, out, M, eps, out_ld);
+        hipLaunchKernelGGL((norm_rows_reg_kernel<14, KIND, ADD, OUT_F32, F16, DF16, SC>), grid, block, 0, s, x, delta, delta2, w, b, out, M, eps, out_ld, sc);
     else
-        hipLaunchKernelGGL((norm_rows_loop_kernel<KIND, ADD, OUT_F32, F16, DF16>), grid, block, 0, s, x, delta, delta2, w, b, out, M, D, eps, out_ld);
+        hipLaunchKernelGGL((norm_rows_loop_kernel<KIND, ADD, OUT_F32, F16, DF16, SC>), grid, block, 0, s, x, delta, delta2, w, b, out, M, D, eps, out_ld, sc);
     return hipGetLastError();
 }
 
@@ -289,6 +302,28 @@ hipError_t launch_rmsnorm(float* x, const bf16_t* delta, const bf16_t* w, bf16_t
         case 1: return launch_norm_t<0, 1, false>(x, delta, delta2, w, nullptr, out, M, D, eps, s, out_ld);
         case 2: return launch_norm_t<0, 2, false>(x, delta, delta2, w, nullptr, out, M, D, eps, s, out_ld);
         case 3: return launch_norm_t<0, 3, false>(x, delta, delta2, w, nullptr, out, M, D, eps, s, out_ld);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// RMSNorm of the scaled fp16 forms (the Qwen2.5-VL row, vqs_qwen.cpp): fp16 deltas behind 1 / d1 and 1 / d2, fp16 operand out behind `out`
+hipError_t launch_rmsnorm_f16s(float* x, const bf16_t* delta, const bf16_t* w, bf16_t* out, int M, int D, float eps, hipStream_t s,
+                               const bf16_t* delta2, bool store_x, int out_ld, float d1, float d2, float osc, bool out_bf16) {
+    if (D % 4) return hipErrorInvalidValue;
+    const NormScales sc{d1, d2, osc};
+    if (out_bf16) {         // the language model's final norm: fp16 deltas in, bf16 operand out (the lm_head's bf16 weights)
+        switch (norm_add_mode(delta, delta2, store_x)) {
+            case 0: return launch_norm_t<0, 0, false, false, true, true>(x, delta, delta2, w, nullptr, out, M, D, eps, s, out_ld, sc);
+            case 1: return launch_norm_t<0, 1, false, false, true, true>(x, delta, delta2, w, nullptr, out, M, D, eps, s, out_ld, sc);
+            case 3: return launch_norm_t<0, 3, false, false, true, true>(x, delta, delta2, w, nullptr, out, M, D, eps, s, out_ld, sc);
+            default: return hipErrorInvalidValue;
+        }
+    }
+    switch (norm_add_mode(delta, delta2, store_x)) {
+        case 0: return launch_norm_t<0, 0, false, true, true, true>(x, delta, delta2, w, nullptr, out, M, D, eps, s, out_ld, sc);
+        case 1: return launch_norm_t<0, 1, false, true, true, true>(x, delta, delta2, w, nullptr, out, M, D, eps, s, out_ld, sc);
+        case 2: return launch_norm_t<0, 2, false, true, true, true>(x, delta, delta2, w, nullptr, out, M, D, eps, s, out_ld, sc);
+        case 3: return launch_norm_t<0, 3, false, true, true, true>(x, delta, delta2, w, nullptr, out, M, D, eps, s, out_ld, sc);
         default: return hipErrorInvalidValue;
     }
 }
@@ -374,10 +409,11 @@ hipError_t launch_vit_assemble(const float* patch_out, const bf16_t* cls, const 
 }
 
 // feature select: hidden_states[-2][:, 1:] -> bf16 rows for the projector GEMM
-template <bool F16>
+// F16: the pending delta is an fp16 tensor (the fp16 tower blocks); OF16: the selected features leave as fp16 (option proj_fp16)
+template <bool F16, bool OF16 = F16>
 __global__ void __launch_bounds__(256) drop_cls_cast_kernel(float* __restrict__ hidden,
                                                             const bf16_t* __restrict__ delta, bf16_t* __restrict__ out,
-                                                            int P, int D) {
+                                                            int P, int D, float oscale) {
     const int n = blockIdx.y, pidx = blockIdx.x;
     const size_t roff = ((size_t)n * (P + 1) + 1 + pidx) * D;
     float4* src = reinterpret_cast<float4*>(hidden + roff);
@@ -391,9 +427,9 @@ __global__ void __launch_bounds__(256) drop_cls_cast_kernel(float* __restrict__ 
             src[i] = v;      // materialise hidden_states[-2] for the patch rows (the CLS row is never needed)
         }
         uint2 o;
-        if constexpr (F16) {
-            o.x = e_pack2_h(v.x, v.y);
-            o.y = e_pack2_h(v.z, v.w);
+        if constexpr (OF16) {     // oscale: a power of two the range proof put the stream behind (1 = none; exact)
+            o.x = e_pack2_h(v.x * oscale, v.y * oscale);
+            o.y = e_pack2_h(v.z * oscale, v.w * oscale);
         } else {
             o.x = e_pack2(v.x, v.y);
             o.y = e_pack2(v.z, v.w);
@@ -402,10 +438,14 @@ __global__ void __launch_bounds__(256) drop_cls_cast_kernel(float* __restrict__ 
     }
 }
 
-hipError_t launch_drop_cls_cast(float* hidden, const bf16_t* delta, bf16_t* out, int N, int P, int D, hipStream_t s, bool f16) {
+hipError_t launch_drop_cls_cast(float* hidden, const bf16_t* delta, bf16_t* out, int N, int P, int D, hipStream_t s, bool f16, int out_f16, float oscale) {
     if (D % 4) return hipErrorInvalidValue;
-    if (f16) hipLaunchKernelGGL(drop_cls_cast_kernel<true>, dim3(P, N), dim3(256), 0, s, hidden, delta, out, P, D);
-    else hipLaunchKernelGGL(drop_cls_cast_kernel<false>, dim3(P, N), dim3(256), 0, s, hidden, delta, out, P, D);
+    const bool of16 = out_f16 < 0 ? f16 : out_f16 != 0;
+    if (!of16 && oscale != 1.0f) return hipErrorInvalidValue;
+    if (f16 && of16) hipLaunchKernelGGL((drop_cls_cast_kernel<true, true>), dim3(P, N), dim3(256), 0, s, hidden, delta, out, P, D, oscale);
+    else if (f16) hipLaunchKernelGGL((drop_cls_cast_kernel<true, false>), dim3(P, N), dim3(256), 0, s, hidden, delta, out, P, D, oscale);
+    else if (of16) hipLaunchKernelGGL((drop_cls_cast_kernel<false, true>), dim3(P, N), dim3(256), 0, s, hidden, delta, out, P, D, oscale);
+    else hipLaunchKernelGGL((drop_cls_cast_kernel<false, false>), dim3(P, N), dim3(256), 0, s, hidden, delta, out, P, D, oscale);
     return hipGetLastError();
 }
 
@@ -606,6 +646,8 @@ __global__ void __launch_bounds__(256) rope_grid_kernel(bf16_t* __restrict__ x, 
 // Q and K of one layer in ONE launch, 16-byte accesses: thread = (8-lane chunk c of the first half, position), it rotates lanes
 // [8c, 8c+8) against [half + 8c, half + 8c + 8) -- same fp32 expressions as rope_kernel, element for element.  blockIdx.y walks the
 // Hq query heads, then the Hk key heads.  The 4-byte kernels above move 16 B per thread and are issue-bound at half the HBM rate.
+// F16: q / k are IEEE fp16 tensors (the Qwen2.5-VL row's fp16 forms; a power-of-two scale on them passes through: the rotation is linear)
+template <bool F16>
 __global__ void __launch_bounds__(256) rope_qk_kernel(bf16_t* __restrict__ q, bf16_t* __restrict__ k, const float* __restrict__ cs,
                                                       const float* __restrict__ sn, int Hq, int Hk, int S, int hd, int half) {
     const int c = threadIdx.x, s_ = blockIdx.x * 32 + threadIdx.y;
@@ -624,10 +666,16 @@ __global__ void __launch_bounds__(256) rope_qk_kernel(bf16_t* __restrict__ q, bf
     uint32_t ol[4], oh[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const float a0 = e_bf2f((bf16_t)(lw[j] & 0xffff)), a1 = e_bf2f((bf16_t)(lw[j] >> 16));
-        const float b0 = e_bf2f((bf16_t)(hw[j] & 0xffff)), b1 = e_bf2f((bf16_t)(hw[j] >> 16));
-        ol[j] = e_pack2_hw(a0 * cc[2 * j] - b0 * ss[2 * j], a1 * cc[2 * j + 1] - b1 * ss[2 * j + 1]);
-        oh[j] = e_pack2_hw(b0 * cc[2 * j] + a0 * ss[2 * j], b1 * cc[2 * j + 1] + a1 * ss[2 * j + 1]);
+        float a0, a1, b0, b1;
+        if constexpr (F16) {
+            const e_f16x2 la = __builtin_bit_cast(e_f16x2, lw[j]), hb = __builtin_bit_cast(e_f16x2, hw[j]);
+            a0 = (float)la[0]; a1 = (float)la[1]; b0 = (float)hb[0]; b1 = (float)hb[1];
+        } else {
+            a0 = e_bf2f((bf16_t)(lw[j] & 0xffff)); a1 = e_bf2f((bf16_t)(lw[j] >> 16));
+            b0 = e_bf2f((bf16_t)(hw[j] & 0xffff)); b1 = e_bf2f((bf16_t)(hw[j] >> 16));
+        }
+        ol[j] = e_pack2_t<F16>(a0 * cc[2 * j] - b0 * ss[2 * j], a1 * cc[2 * j + 1] - b1 * ss[2 * j + 1]);
+        oh[j] = e_pack2_t<F16>(b0 * cc[2 * j] + a0 * ss[2 * j], b1 * cc[2 * j + 1] + a1 * ss[2 * j + 1]);
     }
     *reinterpret_cast<uint4*>(xr + 8 * c) = make_uint4(ol[0], ol[1], ol[2], ol[3]);
     *reinterpret_cast<uint4*>(xr + half + 8 * c) = make_uint4(oh[0], oh[1], oh[2], oh[3]);
@@ -635,13 +683,15 @@ __global__ void __launch_bounds__(256) rope_qk_kernel(bf16_t* __restrict__ q, bf
 
 hipError_t launch_rope(bf16_t* x, const float* cs, const float* sn, int B, int H, int S, int hd, int half, hipStream_t s);
 hipError_t launch_rope_qk(bf16_t* q, bf16_t* k, const float* cs, const float* sn, int B, int Hq, int Hk, int S, int hd, int half,
-                          hipStream_t s) {
+                          hipStream_t s, bool f16) {
     if ((half & 1) || 2 * half > hd || (hd & 1)) return hipErrorInvalidValue;
     if ((half & 7) == 0 && (hd & 7) == 0 && half <= 64 && B <= 65535 && Hq + Hk <= 65535) {
-        hipLaunchKernelGGL(rope_qk_kernel, dim3((unsigned)((S + 31) / 32), (unsigned)(Hq + Hk), (unsigned)B), dim3(8, 32), 0, s, q, k, cs,
-                           sn, Hq, Hk, S, hd, half);
+        const dim3 grid((unsigned)((S + 31) / 32), (unsigned)(Hq + Hk), (unsigned)B), block(8, 32);
+        if (f16) hipLaunchKernelGGL(rope_qk_kernel<true>, grid, block, 0, s, q, k, cs, sn, Hq, Hk, S, hd, half);
+        else hipLaunchKernelGGL(rope_qk_kernel<false>, grid, block, 0, s, q, k, cs, sn, Hq, Hk, S, hd, half);
         return hipGetLastError();
     }
+    if (f16) return hipErrorInvalidValue;      // the fp16 forms exist for 16-byte head halves only (vqs_qwen.cpp checks at create)
     const hipError_t e = launch_rope(q, cs, sn, B, Hq, S, hd, half, s);
     return e != hipSuccess ? e : launch_rope(k, cs, sn, B, Hk, S, hd, half, s);
 }
@@ -1163,18 +1213,23 @@ hipError_t launch_gather_rows_f32(const float* src, const int* map, float* dst, 
 
 // Qwen2.5-VL input embeddings (HF modeling_qwen2_5_vl.py:1205-1232): token row = embed[id], or the merged vision token
 // vis_slot[row] where that is >= 0 (masked_scatter of the video/image features in order).  fp32 residual stream out.
+// merged_f16: the vision tokens are an fp16 tensor held behind a power-of-two scale (the tower's fp16 forms): value = fp16 * unscale
 __global__ void __launch_bounds__(256) qwen_embed_kernel(const int* __restrict__ ids, const int* __restrict__ vis_slot,
                                                          const bf16_t* __restrict__ embed, const bf16_t* __restrict__ merged,
-                                                         float* __restrict__ out, int D, int vocab) {
+                                                         float* __restrict__ out, int D, int vocab, int merged_f16, float unscale) {
     const int r = blockIdx.x;
     const int vs = vis_slot[r];
     const bf16_t* s = vs >= 0 ? merged + (size_t)vs * D : embed + (size_t)min(max(ids[r], 0), vocab - 1) * D;
     float* o = out + (size_t)r * D;
+    if (vs >= 0 && merged_f16) {
+        for (int i = threadIdx.x; i < D; i += 256) o[i] = (float)__builtin_bit_cast(_Float16, s[i]) * unscale;
+        return;
+    }
     for (int i = threadIdx.x; i < D; i += 256) o[i] = e_bf2f(s[i]);
 }
 hipError_t launch_qwen_embed(const int* ids, const int* vis_slot, const bf16_t* embed, const bf16_t* merged, float* out, int rows,
-                             int D, int vocab, hipStream_t s) {
-    hipLaunchKernelGGL(qwen_embed_kernel, dim3(rows), dim3(256), 0, s, ids, vis_slot, embed, merged, out, D, vocab);
+                             int D, int vocab, hipStream_t s, bool merged_f16, float merged_unscale) {
+    hipLaunchKernelGGL(qwen_embed_kernel, dim3(rows), dim3(256), 0, s, ids, vis_slot, embed, merged, out, D, vocab, merged_f16 ? 1 : 0, merged_unscale);
     return hipGetLastError();
 }
 

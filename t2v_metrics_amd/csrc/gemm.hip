@@ -1266,7 +1266,8 @@ int gemm_form(const GemmParams& p, int epilogue, int variant) {
                     // the T5 encoder's attention side resolves to it); 1 = fp16 result (no gated epilogue), 2 = bf16 result (plain / gated only)
     {
         if ((variant == 3 || variant == 10) && quad_eligible_rt(p, epilogue))
-            return (p.f16 == 1 ? epilogue != EPI_GATED : (p.f16 == 2 && (epilogue == EPI_BF16 || epilogue == EPI_GATED))) ? 10 : -1;
+            return (p.f16 == 4 ? epilogue == EPI_BF16 : p.f16 == 3 ? epilogue != EPI_BF16_QGELU : p.f16 == 1 ? epilogue != EPI_GATED : (p.f16 == 2 && (epilogue == EPI_BF16 || epilogue == EPI_GATED))) ? 10 : -1;
+        if (p.f16 >= 3) return -1;      // the scaled families exist in the quad form only
         // round 5: the batched / fp32-result launches of the decoder's cross-attention score path (option dec_fp16) -- plain epilogues of the
         // stream form and of the persistent 8-wave kernel (bias-free, no row scale; fp32 result, fp16 result, bf16 / split-bf16 result)
         if (variant != 3 || !(epilogue == EPI_BF16 || epilogue == EPI_F32) || p.bias != nullptr || p.rowss_in != nullptr) return -1;
@@ -1335,7 +1336,13 @@ static hipError_t launch_epi(const GemmParams& p, int variant, hipStream_t strea
         if constexpr (EPI == EPI_BF16 || EPI == EPI_BF16_QGELU || EPI == EPI_BF16_GELU || EPI == EPI_GATED || EPI == EPI_HEADS) {
             const int nwg = tiles_m * tiles_n;
             const dim3 qgrid(nwg < PERSISTENT_WGS ? nwg : PERSISTENT_WGS);
-            if (p.f16 == 2) {
+            if (p.f16 == 4) {
+                if constexpr (EPI == EPI_BF16) hipLaunchKernelGGL((gemm_f16bs_quad<EPI>), qgrid, dim3(256), 0, stream, p);
+                else return hipErrorInvalidValue;
+            } else if (p.f16 == 3) {
+                if constexpr (EPI != EPI_BF16_QGELU) hipLaunchKernelGGL((gemm_f16s_quad<EPI>), qgrid, dim3(256), 0, stream, p);
+                else return hipErrorInvalidValue;
+            } else if (p.f16 == 2) {
                 if constexpr (EPI == EPI_BF16 || EPI == EPI_GATED) hipLaunchKernelGGL((gemm_f16b_quad<EPI>), qgrid, dim3(256), 0, stream, p);
                 else return hipErrorInvalidValue;
             } else if (p.f16) {

@@ -7,6 +7,8 @@
 // arithmetic, no matrix pipe -- one query row per (sample, head) is 1/128 of an MFMA tile.
 #include "vqs_kernels.h"
 
+#include <algorithm>
+
 namespace vqs {
 
 namespace {
@@ -74,11 +76,22 @@ hipError_t launch_qwen_decode_rope_append(const bf16_t* qkv, const float* cs, co
 // PRECISE (the precise tail of vqs_qwen_score, vqs_qwen.cpp): q is an fp32 row (already rotated), `len` holds the COUNT of valid keys
 // (the prompt's own length: the row attends to itself through the K / V rows the prefill wrote), and the output leaves as a split-bf16
 // tensor: hi plane at out, lo = bf16(o - hi) at out + out_plane.
-template <bool PRECISE>
+// KVH (round 6, PRECISE only): the K / V rows are IEEE fp16 (the prefill's range-safe fp16 forms, held behind power-of-two scales: the key
+// scale is folded into `scale` by the host, the output is multiplied by `vscale` = 1 / the value scale).
+typedef __attribute__((ext_vector_type(2))) _Float16 d_f16x2;
+__device__ __forceinline__ void d_cvt2(uint32_t w, bool f16, float& a, float& b) {
+    if (f16) {
+        const d_f16x2 h = __builtin_bit_cast(d_f16x2, w);
+        a = (float)h[0]; b = (float)h[1];
+    } else {
+        a = __uint_as_float(w << 16); b = __uint_as_float(w & 0xffff0000u);
+    }
+}
+template <bool PRECISE, bool KVH = false>
 __global__ void __launch_bounds__(256) qwen_decode_attn_kernel(const void* __restrict__ q_, const bf16_t* __restrict__ kc,
                                                                const bf16_t* __restrict__ vc, const int* __restrict__ len,
                                                                bf16_t* __restrict__ out, int Hq, int Hkv, int Lmax, float scale,
-                                                               long long out_plane) {
+                                                               long long out_plane, float vscale) {
     constexpr int HD = 128;
     extern __shared__ __attribute__((aligned(16))) float d_smem[];
     __shared__ float qs[HD];
@@ -105,8 +118,10 @@ __global__ void __launch_bounds__(256) qwen_decode_attn_kernel(const void* __res
             const uint32_t w4[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                acc = fmaf(__uint_as_float(w4[e] << 16), qs[8 * c + 2 * e], acc);
-                acc = fmaf(__uint_as_float(w4[e] & 0xffff0000u), qs[8 * c + 2 * e + 1], acc);
+                float k0, k1;
+                d_cvt2(w4[e], KVH, k0, k1);
+                acc = fmaf(k0, qs[8 * c + 2 * e], acc);
+                acc = fmaf(k1, qs[8 * c + 2 * e + 1], acc);
             }
         }
         const float tj = acc * scale;
@@ -134,14 +149,17 @@ __global__ void __launch_bounds__(256) qwen_decode_attn_kernel(const void* __res
     for (int j = wv; j < n; j += 4) {
         const uint32_t u = reinterpret_cast<const uint32_t*>(V + (size_t)j * HD)[lane];
         const float p = d_smem[j];
-        o0 = fmaf(p, __uint_as_float(u << 16), o0);
-        o1 = fmaf(p, __uint_as_float(u & 0xffff0000u), o1);
+        float v0, v1;
+        d_cvt2(u, KVH, v0, v1);
+        o0 = fmaf(p, v0, o0);
+        o1 = fmaf(p, v1, o1);
     }
     part[wv][2 * lane] = o0;
     part[wv][2 * lane + 1] = o1;
     __syncthreads();
     if (t < HD) {
-        const float o = ((part[0][t] + part[1][t]) + (part[2][t] + part[3][t])) / l;
+        float o = ((part[0][t] + part[1][t]) + (part[2][t] + part[3][t])) / l;
+        if (KVH) o *= vscale;
         const bf16_t hi = d_f2bf(o);
         out[((size_t)b * Hq + h) * HD + t] = hi;
         if (PRECISE) out[out_plane + ((size_t)b * Hq + h) * HD + t] = d_f2bf(o - d_bf2f(hi));
@@ -158,11 +176,11 @@ __global__ void __launch_bounds__(256) qwen_decode_attn_kernel(const void* __res
 // xor-shuffles (16, 32), the four waves' partial rows added in wave order, one division, bf16.  Dynamic LDS: G * Lmax floats.
 static constexpr int QD_GMAX = 8;
 static constexpr int QD_NW = 8;            // waves per block: eight split the key range, two per SIMD cover each other's load latency
-template <bool PRECISE>
+template <bool PRECISE, bool KVH = false>
 __global__ void __launch_bounds__(64 * QD_NW) qwen_decode_attn_gqa_kernel(const void* __restrict__ q_, const bf16_t* __restrict__ kc,
                                                                    const bf16_t* __restrict__ vc, const int* __restrict__ len,
                                                                    bf16_t* __restrict__ out, int Hq, int Hkv, int Lmax, float scale,
-                                                                   long long out_plane) {
+                                                                   long long out_plane, float vscale) {
     constexpr int HD = 128, U = 8;
     extern __shared__ __attribute__((aligned(16))) float d_smem[];      // sc[G][Lp]
     __shared__ float red[QD_NW][QD_GMAX];
@@ -176,13 +194,15 @@ __global__ void __launch_bounds__(64 * QD_NW) qwen_decode_attn_gqa_kernel(const 
     const bf16_t* K = kc + ((size_t)b * Hkv + hk) * Lmax * HD;
     const bf16_t* V = vc + ((size_t)b * Hkv + hk) * Lmax * HD;
     const int sub = lane >> 4, c = lane & 15;
-    auto cvt8 = [](const uint4& u, float (&f)[8]) {
+    auto cvt8 = [](const uint4& u, float (&f)[8]) {                     // a cached K / V chunk
         const uint32_t w4[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            f[2 * e] = __uint_as_float(w4[e] << 16);
-            f[2 * e + 1] = __uint_as_float(w4[e] & 0xffff0000u);
-        }
+        for (int e = 0; e < 4; ++e) d_cvt2(w4[e], KVH, f[2 * e], f[2 * e + 1]);
+    };
+    auto cvt8q = [](const uint4& u, float (&f)[8]) {                    // the decode step's bf16 q row
+        const uint32_t w4[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d_cvt2(w4[e], false, f[2 * e], f[2 * e + 1]);
     };
     // ---- scores
     {
@@ -197,7 +217,7 @@ __global__ void __launch_bounds__(64 * QD_NW) qwen_decode_attn_gqa_kernel(const 
                     qf[g][0] = a.x; qf[g][1] = a.y; qf[g][2] = a.z; qf[g][3] = a.w;
                     qf[g][4] = bq.x; qf[g][5] = bq.y; qf[g][6] = bq.z; qf[g][7] = bq.w;
                 } else {
-                    cvt8(*reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(q_) + qo), qf[g]);
+                    cvt8q(*reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(q_) + qo), qf[g]);
                 }
             }
         float mx[QD_GMAX];
@@ -328,34 +348,35 @@ __global__ void __launch_bounds__(64 * QD_NW) qwen_decode_attn_gqa_kernel(const 
 #pragma unroll
         for (int i2 = 1; i2 < QD_NW; ++i2) o += part[i2][g][d];
         o = o / stat[1][g];
+        if (KVH) o *= vscale;
         const bf16_t hi = d_f2bf(o);
         out[((size_t)b * Hq + (size_t)hk * G + g) * HD + d] = hi;
         if (PRECISE) out[out_plane + ((size_t)b * Hq + (size_t)hk * G + g) * HD + d] = d_f2bf(o - d_bf2f(hi));
     }
 }
 
-template <bool PRECISE>
+template <bool PRECISE, bool KVH = false>
 static hipError_t launch_decode_attn_t(const void* q, const bf16_t* kc, const bf16_t* vc, const int* len, bf16_t* out, int B, int Hq, int Hkv, int Lmax,
-                                       float scale, long long out_plane, hipStream_t s) {
+                                       float scale, long long out_plane, hipStream_t s, float vscale = 1.0f) {
     if (B <= 0 || Hq <= 0 || Hkv <= 0 || (Hq % Hkv) != 0 || Lmax <= 0 || Lmax > 36864 /* VQS_QWEN_MAX_CACHE_POSITIONS */ || B > 65535) return hipErrorInvalidValue;
     {   // grouped-query form wherever its G score rows fit LDS (Lmax <= ~4 300 positions at G = 7); the per-query-head kernel beyond
         const int G = Hq / Hkv;
         const size_t glds = (size_t)G * ((Lmax + 3) & ~3) * sizeof(float);
         if (G <= QD_GMAX && glds <= 120 * 1024) {
             if (glds > 48 * 1024) {
-                const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(qwen_decode_attn_gqa_kernel<PRECISE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds);
+                const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(qwen_decode_attn_gqa_kernel<PRECISE, KVH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds);
                 if (e != hipSuccess) return e;
             }
-            hipLaunchKernelGGL(qwen_decode_attn_gqa_kernel<PRECISE>, dim3((unsigned)Hkv, (unsigned)B), dim3(64 * QD_NW), glds, s, q, kc, vc, len, out, Hq, Hkv, Lmax, scale, out_plane);
+            hipLaunchKernelGGL((qwen_decode_attn_gqa_kernel<PRECISE, KVH>), dim3((unsigned)Hkv, (unsigned)B), dim3(64 * QD_NW), glds, s, q, kc, vc, len, out, Hq, Hkv, Lmax, scale, out_plane, vscale);
             return hipGetLastError();
         }
     }
     const size_t lds = (size_t)Lmax * sizeof(float);
     if (lds > 48 * 1024) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(qwen_decode_attn_kernel<PRECISE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(qwen_decode_attn_kernel<PRECISE, KVH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(qwen_decode_attn_kernel<PRECISE>, dim3((unsigned)Hq, (unsigned)B), dim3(256), lds, s, q, kc, vc, len, out, Hq, Hkv, Lmax, scale, out_plane);
+    hipLaunchKernelGGL((qwen_decode_attn_kernel<PRECISE, KVH>), dim3((unsigned)Hq, (unsigned)B), dim3(256), lds, s, q, kc, vc, len, out, Hq, Hkv, Lmax, scale, out_plane, vscale);
     return hipGetLastError();
 }
 
@@ -367,8 +388,36 @@ hipError_t launch_qwen_decode_attn(const bf16_t* q, const bf16_t* kc, const bf16
 // The precise tail's attention (vqs_qwen.cpp): q fp32 [B, Hq * 128] (rotated), keys / values = the prefill's head-major K / V of this layer
 // ([B, Hkv, Lmax, 128] bf16, Lmax = the batch's padded length), count[b] = the sample's valid length; out = split-bf16 [2][B][Hq * 128].
 hipError_t launch_qwen_tail_attn(const float* q, const bf16_t* k, const bf16_t* v, const int* count, bf16_t* out, long long out_plane, int B, int Hq,
-                                 int Hkv, int Lmax, float scale, hipStream_t s) {
+                                 int Hkv, int Lmax, float scale, hipStream_t s, bool kv_f16, float vscale) {
+    // kv_f16: K / V are the fp16 prefill's tensors; `scale` already carries 1 / the key scale, the output is multiplied by vscale
+    if (kv_f16) return launch_decode_attn_t<true, true>(q, k, v, count, out, B, Hq, Hkv, Lmax, scale, out_plane, s, vscale);
     return launch_decode_attn_t<true>(q, k, v, count, out, B, Hq, Hkv, Lmax, scale, out_plane, s);
+}
+
+// K / V of an fp16 prefill layer into the bf16 cache the decode step reads: dst[r][0 : cols) = bf16(fp16 src[r][0 : cols) * unscale),
+// rows `src_ld` / `dst_ld` elements apart (cols % 8 == 0)
+__global__ void __launch_bounds__(256) f16_to_bf16_rows_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int cols8, long long src_ld,
+                                                               long long dst_ld, float unscale) {
+    const long long r = blockIdx.y;
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < cols8; c += gridDim.x * 256) {
+        const uint4 u = *reinterpret_cast<const uint4*>(src + r * src_ld + 8 * (long long)c);
+        const uint32_t w4[4] = {u.x, u.y, u.z, u.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float a, b;
+            d_cvt2(w4[e], true, a, b);
+            o[e] = (uint32_t)d_f2bf(a * unscale) | ((uint32_t)d_f2bf(b * unscale) << 16);
+        }
+        *reinterpret_cast<uint4*>(dst + r * dst_ld + 8 * (long long)c) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+hipError_t launch_f16_to_bf16_rows(const bf16_t* src, bf16_t* dst, int rows, long long cols, long long src_ld, long long dst_ld, float unscale, hipStream_t s) {
+    if (rows <= 0 || rows > 65535 || cols <= 0 || (cols % 8) != 0) return hipErrorInvalidValue;
+    const long long c8 = cols / 8;
+    hipLaunchKernelGGL(f16_to_bf16_rows_kernel, dim3((unsigned)std::min<long long>((c8 + 255) / 256, 1024), (unsigned)rows), dim3(256), 0, s, src, dst, (int)c8,
+                       src_ld, dst_ld, unscale);
+    return hipGetLastError();
 }
 
 // The precise tail's rotary embedding: q columns of the fp32 q|k|v row of each sample's LAST position, rotated by that position's table
@@ -408,6 +457,100 @@ hipError_t launch_qwen_tail_rope_q(const float* qkv, int ld, const float* cs, co
                                    int half, hipStream_t s) {
     if (B <= 0 || Hq <= 0 || half <= 0 || half > 64 || 2 * half > hd || B > 65535) return hipErrorInvalidValue;
     hipLaunchKernelGGL(qwen_tail_rope_q_kernel, dim3((unsigned)Hq, (unsigned)B), dim3(64), 0, s, qkv, ld, cs, sn, row, q_out, Hq, hd, half);
+    return hipGetLastError();
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Bind-time range proof of the fp16 forms (vqs_qwen.cpp compute_ranges; round 6).  Every 16-bit activation T of the fp16 forms is held as
+// fp16(T * 2^-s); s comes from a PROVEN bound of |T| that depends on the weights only:
+//   * RMSNorm output  x^ * g:  |x^_k| <= ||x^||_2 = sqrt(D / (1 + eps D / sum x^2)) <= sqrt(D), so |out_k| <= sqrt(D) |g_k|;
+//   * a linear fed by a norm output (q|k|v, gate|up, merger mlp.0):  |sum_k W_jk g_k x^_k + b_j| <= ||W_j o g||_2 ||x^||_2 + |b_j|   (Cauchy-Schwarz);
+//   * a linear fed by a tensor with element bounds u_k (o / proj over the attention output -- a convex combination of value rows --,
+//     down_proj over the gated product, merger mlp.2):  |sum_k W_jk a_k + b_j| <= sum_k |W_jk| u_k + |b_j|;
+//   * |SiLU(g) u| <= |g| |u| (|SiLU(x)| <= |x|, |GELU(x)| <= |x|);  rotary embedding: |x'| <= sqrt(2) max|x|.
+// One wave per weight row, 16-byte loads; the row's bound goes to out[j] (optional) and its maximum over rows into `slot` (atomicMax on
+// the bit pattern: the values are non-negative floats; a NaN weight poisons the slot with a NaN-patterned maximum, which the host refuses).
+// ---------------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float d_wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+__device__ __forceinline__ void d_slot_max(float* slot, float v) {
+    if (!(v == v)) v = __uint_as_float(0x7fc00000u);                     // NaN: the largest bit pattern wins and stays
+    atomicMax(reinterpret_cast<unsigned int*>(slot), __float_as_uint(v));
+}
+// mode 0: out[j] = R * sqrt(sum_k (W[j,k] g[k % g_len])^2) + |bias[j]|      (g bf16)
+// mode 1: out[j] = sum_k |W[j,k]| u[k] + |bias[j]|                           (u fp32 [K]; u == nullptr: the constant *uconst)
+__global__ void __launch_bounds__(256) rowbound_kernel(const bf16_t* __restrict__ W, long long ldw, int N, int K, int mode, const bf16_t* __restrict__ g,
+                                                       int g_len, float R, const float* __restrict__ u, const float* __restrict__ uconst,
+                                                       const bf16_t* __restrict__ bias, float* __restrict__ out, float* __restrict__ slot) {
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (j >= N) return;
+    const bf16_t* wr = W + (size_t)j * ldw;
+    const float uc = (mode == 1 && u == nullptr) ? *uconst : 0.0f;
+    float acc = 0.0f;
+    for (int k = lane; k < K; k += 64) {
+        const float w = d_bf2f(wr[k]);
+        if (mode == 0) {
+            const float t = w * d_bf2f(g[k % g_len]);
+            acc = fmaf(t, t, acc);
+        } else {
+            acc = fmaf(fabsf(w), u ? u[k] : uc, acc);
+        }
+    }
+    acc = d_wave_sum(acc);
+    float b = mode == 0 ? R * sqrtf(acc) : acc;
+    if (bias) b += fabsf(d_bf2f(bias[j]));
+    if (lane == 0) {
+        if (out) out[j] = b;
+        d_slot_max(slot, b);
+    }
+}
+hipError_t launch_rowbound(const bf16_t* W, long long ldw, int N, int K, int mode, const bf16_t* g, int g_len, float R, const float* u,
+                           const float* uconst, const bf16_t* bias, float* out, float* slot, hipStream_t s) {
+    if (N <= 0 || K <= 0 || (mode == 0 && (!g || g_len <= 0)) || (mode == 1 && !u && !uconst) || !slot) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(rowbound_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, W, ldw, N, K, mode, g, g_len, R, u, uconst, bias, out, slot);
+    return hipGetLastError();
+}
+// slot = max(slot, R * max_k |x[k]|) over a bf16 vector / matrix of n elements (norm weights: the norm output's bound; weights: their fp16 range check)
+__global__ void __launch_bounds__(256) absmax_bf16_kernel(const bf16_t* __restrict__ x, size_t n, float R, float* __restrict__ slot) {
+    float m = 0.0f;
+    bool nan = false;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float v = fabsf(d_bf2f(x[i]));
+        nan |= !(v == v);
+        m = fmaxf(m, v);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if (__any(nan)) m = __uint_as_float(0x7fc00000u);
+    if ((threadIdx.x & 63) == 0) d_slot_max(slot, R * m);
+}
+hipError_t launch_absmax_bf16(const bf16_t* x, size_t n, float R, float* slot, hipStream_t s) {
+    if (!x || n == 0 || !slot) return hipErrorInvalidValue;
+    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(absmax_bf16_kernel, dim3(blocks), dim3(256), 0, s, x, n, R, slot);
+    return hipGetLastError();
+}
+// gated product: rb = row bounds of the PACKED gate|up weight (blocks of 32 gate rows | 32 up rows); u_act[j] = rb[gate(j)] * rb[up(j)] for
+// j < mlp_p, 0 for the pad columns up to ld; slot = max_j
+__global__ void __launch_bounds__(256) gate_pair_bound_kernel(const float* __restrict__ rb, int mlp_p, int ld, float* __restrict__ u_act, float* __restrict__ slot) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    float v = 0.0f;
+    if (j < mlp_p) v = rb[(j >> 5) * 64 + (j & 31)] * rb[(j >> 5) * 64 + 32 + (j & 31)];
+    if (j < ld) u_act[j] = v;
+    float m = v;
+    const bool nan = !(v == v);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if (__any(nan)) m = __uint_as_float(0x7fc00000u);
+    if ((threadIdx.x & 63) == 0) d_slot_max(slot, m);
+}
+hipError_t launch_gate_pair_bound(const float* rb, int mlp_p, int ld, float* u_act, float* slot, hipStream_t s) {
+    if (!rb || mlp_p <= 0 || ld < mlp_p || (mlp_p & 31) || !u_act || !slot) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gate_pair_bound_kernel, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, s, rb, mlp_p, ld, u_act, slot);
     return hipGetLastError();
 }
 

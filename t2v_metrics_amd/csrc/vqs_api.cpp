@@ -53,6 +53,11 @@ struct vqs_handle {
     const bf16_t* proj0_w16 = nullptr;
     const bf16_t* proj2_w16 = nullptr;
     int dec_precise = 1;  // 1 = the scoring decoder holds its activations as split-bf16 / fp32 (decoder_pass_precise), 0 = bf16 (rounds 1-3)
+    int proj_fp16 = 1;    // 1 (default) = with vit_fp16 the selected features (hidden_states[-2], the residual STREAM itself cast to 16 bits) and the projector's
+                          // hidden tensor are fp16 too; 0 = they stay bf16 while the tower's blocks run fp16.  Round 6: the stream is a sum over all
+                          // blocks' outputs -- the one site of the tower whose bind-time range proof (engine.py fp16_range_proof) fails first
+    int proj_fs_shift = 0, proj_mid_shift = 0;   // with proj_fp16: the selected features are held as fp16(x * 2^-fs), the projector's hidden tensor as
+                          // fp16(x * 2^-mid) -- the scales the bind-time range proof asks for (engine.py; 0 = none: the unscaled kernels, bit for bit round 5)
     int enc_fp16 = 1;     // 1 (default, round 5) = the ATTENTION SIDE of the T5 encoder runs on IEEE fp16 tensors: both norm outputs, q / k / v, the
                           // softmax probabilities and the attention output are fp16, and q|k|v, o and the gated wi read fp16 copies of their weights
                           // (made at bind time) -- what HF's own fp16 T5 path holds in fp16.  The sub-layer outputs (o / wo results), the gated FFN
@@ -338,6 +343,7 @@ struct GemmCall {
     float rs_invd = 0.0f, rs_eps = 0.0f;
     int nt_store = 0;          // result rows leave with the non-temporal hint (call sites whose multi-GB output is streamed once)
     long long split_off = 0;   // EPI_BF16: also store the lo plane of a split-bf16 result at C + split_off (vqs_kernels.h)
+    float acc_scale = 1.0f, out_scale = 1.0f;   // f16 = 3 / 4: the scaled quad families (vqs_kernels.h)
     int no_stream = 0;         // 1: keep this launch off the stream form (same bits either way)
     int f16 = 0;               // A, W and the 16-bit result are IEEE fp16 (the fp16 vision tower; quad form only)
 };
@@ -355,7 +361,7 @@ int run_gemm(vqs_handle* h, const GemmCall& g, hipStream_t st, const char* what)
         if (t.N == g.N && t.K == g.K) { p.tile_gm = t.gm; p.tile_ns = t.ns; }
     p.nt_store = g.nt_store;
     p.split_off = g.split_off;
-    p.f16 = g.f16;
+    p.f16 = g.f16; p.acc_scale = g.acc_scale; p.out_scale = g.out_scale;
     p.no_stream = (h->stream_gemm && !g.no_stream) ? 0 : 1;
     for (const vqs_handle::NtStore& t : h->l2_touches)
         if (t.N == g.N && t.K == g.K && g.M >= 4096) p.l2_touch = t.on;
@@ -579,6 +585,9 @@ int vqs_set_option(vqs_handle* h, const char* name, int32_t value) {
     else if (n == "dec_precise" && (value == 0 || value == 1)) h->dec_precise = value;
     else if (n == "vit_fp16" && (value == 0 || value == 1)) h->vit_fp16 = value;
     else if (n == "enc_fp16" && (value == 0 || value == 1)) h->enc_fp16 = value;
+    else if (n == "proj_fp16" && (value == 0 || value == 1)) h->proj_fp16 = value;
+    else if (n == "proj_fs_shift" && value >= 0 && value <= 60) h->proj_fs_shift = value;
+    else if (n == "proj_mid_shift" && value >= 0 && value <= 60) h->proj_mid_shift = value;
     else if (n == "dec_fp16" && (value == 0 || value == 1)) h->dec_fp16 = value;
     else if (n == "stream_gemm" && (value == 0 || value == 1)) h->stream_gemm = value;
     else if (n == "gemm_variant" && (value == 0 || value == 2 || value == 3 || value == 5 || value == 11)) h->gemm_variant = value;
@@ -621,6 +630,9 @@ int vqs_get_option(const vqs_handle* h, const char* name, int32_t* value) {
     else if (n == "dec_precise") *value = h->dec_precise;
     else if (n == "vit_fp16") *value = h->vit_fp16;
     else if (n == "enc_fp16") *value = h->enc_fp16;
+    else if (n == "proj_fp16") *value = h->proj_fp16;
+    else if (n == "proj_fs_shift") *value = h->proj_fs_shift;
+    else if (n == "proj_mid_shift") *value = h->proj_mid_shift;
     else if (n == "dec_fp16") *value = h->dec_fp16;
     else if (n == "stream_gemm") *value = h->stream_gemm;
     else if (n == "gemm_variant") *value = h->gemm_variant;
@@ -874,16 +886,20 @@ int vqs_encode_images(vqs_handle* h, const void* d_pixels, int32_t N, void* d_fe
         }
     }
     // hidden_states[-2][:, 1:] = hidden + pending fc2 output, CLS dropped, cast to the projector's operand type
-    HIPCHK(h, vqs::launch_drop_cls_cast(w.hidden, pend, w.feat_in, N, P, hid, st, f16), "feature select");
+    const bool p16 = f16 && h->proj_fp16 != 0;       // operand type of the selected features and the projector
+    const bool psc = p16 && (h->proj_fs_shift != 0 || h->proj_mid_shift != 0);      // scaled forms only where the proof asked for a scale
+    const float s_fs = psc ? std::ldexp(1.0f, -h->proj_fs_shift) : 1.0f, s_mid = psc ? std::ldexp(1.0f, -h->proj_mid_shift) : 1.0f;
+    HIPCHK(h, vqs::launch_drop_cls_cast(w.hidden, pend, w.feat_in, N, P, hid, st, f16, p16 ? 1 : 0, s_fs), "feature select");
     TAP("vit", -1, "feat_in", w.feat_in, (size_t)NP * hid);
     GETW(p0w, "mm_projector.0.weight", (int64_t)D * hid);
     GETW(p0b, "mm_projector.0.bias", D);
     GETW(p2w, "mm_projector.2.weight", (int64_t)D * D);
     GETW(p2b, "mm_projector.2.bias", D);
     {
-        GemmCall g{w.feat_in, f16 ? h->proj0_w16 : p0w, w.pmid};
+        GemmCall g{w.feat_in, p16 ? h->proj0_w16 : p0w, w.pmid};
         g.bias = p0b;
-        g.f16 = f16;
+        g.f16 = psc ? 3 : (p16 ? 1 : 0);
+        g.acc_scale = 1.0f / s_fs; g.out_scale = s_mid;
         g.M = NP; g.N = D; g.K = hid; g.lda = hid; g.ldw = hid; g.ldc = D; g.epi = vqs::EPI_BF16_GELU;
         RUN(run_gemm(h, g, st, "mm_projector.0"));
         TAP("vit", -1, "pmid", w.pmid, (size_t)NP * D);
@@ -892,9 +908,10 @@ int vqs_encode_images(vqs_handle* h, const void* d_pixels, int32_t N, void* d_fe
         // the image features are a bf16 tensor of the C ABI (vqs_score reads them as such).  Round 4 wrote the fp16 result and cast it
         // (two roundings, one more pass over 2.4 GB); the fp16-operand / bf16-result instantiation of the quad kernel (round 5,
         // gemm_f16b_quad) rounds the fp32 accumulator to bf16 ONCE and writes the feature tensor itself
-        GemmCall g{w.pmid, f16 ? h->proj2_w16 : p2w, d_feats};
+        GemmCall g{w.pmid, p16 ? h->proj2_w16 : p2w, d_feats};
         g.bias = p2b;
-        g.f16 = f16 ? 2 : 0;
+        g.f16 = psc ? 4 : (p16 ? 2 : 0);
+        g.acc_scale = 1.0f / s_mid;
         g.M = NP; g.N = D; g.K = D; g.lda = D; g.ldw = D; g.ldc = D; g.epi = vqs::EPI_BF16;
         RUN(run_gemm(h, g, st, "mm_projector.2"));
     }

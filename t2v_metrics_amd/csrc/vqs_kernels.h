@@ -33,7 +33,7 @@ struct GemmParams {
     int lda, ldw, ldc;       // in elements
     // EPI_HEADS
     int S, H, inner;
-    int f16 = 0;             // any epilogue; host-side only (selects the kernel): 1 = A, W and the 16-bit result are IEEE fp16 instead of bf16
+    int f16 = 0;             // any epilogue; host-side only (selects the kernel): 4 = as 2 and 3 = as 1 with the scaled epilogue (acc_scale / out_scale below); 1 = A, W and the 16-bit result are IEEE fp16 instead of bf16
                              // (quad form only; bias stays bf16) -- the fp16 vision tower; 2 = A and W fp16, the 16-bit result bf16 (plain and
                              // gated epilogue: the T5 encoder's o / wi of option enc_fp16).  Sits in what was alignment padding: no other
                              // field moved, the kernels' argument block is byte for byte what it was.
@@ -69,6 +69,11 @@ struct GemmParams {
     const float* rowss_in = nullptr;
     int rowss_parts = 0;
     float rs_invd = 0.0f, rs_eps = 0.0f;
+    // f16 == 3 (quad form only, round 6): fp16 operands and an fp16 result behind power-of-two scales -- the range-safe fp16 forms of the
+    // Qwen2.5-VL row (vqs_qwen.cpp: every 16-bit activation T is held as fp16(T * sigma_T), sigma_T = 2^-s chosen at bind time from a proven
+    // bound of |T|).  The epilogue computes t = acc * acc_scale + bias (acc_scale = 1 / sigma of the A operand: t is in true units), applies
+    // the activation / gate to t and stores fp16(result * out_scale).  Both 1: bitwise gemm_f16_quad.  Appended: no other field moved.
+    float acc_scale = 1.0f, out_scale = 1.0f;
 };
 
 // EPI_HEADS row split, shared by the kernel and its host-side test hook (vqs_debug_heads_rows): GEMM row -> (sample,
@@ -231,7 +236,7 @@ hipError_t launch_vit_assemble(const float* patch_out, const bf16_t* cls, const 
                                int P, int D, hipStream_t s);
 // stream fp32 [N, 1+P, D] -> bf16 [N*P, D] dropping the CLS row
 hipError_t launch_drop_cls_cast(float* hidden, const bf16_t* delta, bf16_t* out, int N, int P, int D,
-                                hipStream_t s, bool f16 = false);   // f16: `delta` and `out` are IEEE fp16 tensors
+                                hipStream_t s, bool f16 = false, int out_f16 = -1, float out_scale = 1.0f);   // f16: `delta` is an IEEE fp16 tensor; out_f16: is `out` (-1 = as delta); out = 16-bit(value * out_scale)
 // n 16-bit elements (n % 8 == 0, 16-byte aligned): bf16 -> fp16 (to_f16) or fp16 -> bf16, round-to-nearest-even
 hipError_t launch_cast16(const bf16_t* in, bf16_t* out, size_t n, bool to_f16, hipStream_t s);
 // per sample: sentinel position and spliced length from int32 ids [B,L] (pad = 0 trailing, sentinel = -200)
@@ -253,12 +258,22 @@ hipError_t launch_qwen_decode_rope_append(const bf16_t* qkv, const float* cs, co
 hipError_t launch_qwen_decode_attn(const bf16_t* q, const bf16_t* kc, const bf16_t* vc, const int* len, bf16_t* out, int B, int Hq,
                                    int Hkv, int Lmax, float scale, hipStream_t s);
 hipError_t launch_qwen_tail_attn(const float* q, const bf16_t* k, const bf16_t* v, const int* count, bf16_t* out, long long out_plane, int B, int Hq,
-                                 int Hkv, int Lmax, float scale, hipStream_t s);
+                                 int Hkv, int Lmax, float scale, hipStream_t s, bool kv_f16 = false, float vscale = 1.0f);
+// bind-time range proof of the Qwen2.5-VL row's fp16 forms (qwen_decode.hip): per-row bounds of a linear's output, their maximum into `slot`
+hipError_t launch_rowbound(const bf16_t* W, long long ldw, int N, int K, int mode, const bf16_t* g, int g_len, float R, const float* u,
+                           const float* uconst, const bf16_t* bias, float* out, float* slot, hipStream_t s);
+hipError_t launch_absmax_bf16(const bf16_t* x, size_t n, float R, float* slot, hipStream_t s);
+hipError_t launch_gate_pair_bound(const float* rb, int mlp_p, int ld, float* u_act, float* slot, hipStream_t s);
+hipError_t launch_f16_to_bf16_rows(const bf16_t* src, bf16_t* dst, int rows, long long cols, long long src_ld, long long dst_ld, float unscale, hipStream_t s);
 hipError_t launch_gather_rows_f32(const float* src, const int* map, float* dst, int rows, int cols, int src_ld, hipStream_t s);
 hipError_t launch_qwen_tail_rope_q(const float* qkv, int ld, const float* cs, const float* sn, const int* row, float* q_out, int B, int Hq, int hd,
                                    int half, hipStream_t s);
 hipError_t launch_rope_qk(bf16_t* q, bf16_t* k, const float* cs, const float* sn, int B, int Hq, int Hk, int S, int hd, int half,
-                          hipStream_t s);
+                          hipStream_t s, bool f16 = false);   // f16: q / k are IEEE fp16 tensors (half % 8 == 0 only)
+// RMSNorm of the Qwen2.5-VL row's scaled fp16 forms: deltas are fp16 tensors held behind power-of-two scales (x += delta * d1 (+ delta2 * d2)),
+// the operand leaves as fp16(value * osc)
+hipError_t launch_rmsnorm_f16s(float* x, const bf16_t* delta, const bf16_t* w, bf16_t* out, int M, int D, float eps, hipStream_t s,
+                               const bf16_t* delta2, bool store_x, int out_ld, float d1, float d2, float osc, bool out_bf16 = false);
 hipError_t launch_rowss_to_rs(const float* rowss, int parts, int M, float invd, float eps, float* rs, hipStream_t s);
 hipError_t launch_reduce_slices(const float* part, int nslices, size_t n, bf16_t* out, hipStream_t s);
 // ---- the precise decoder's glue (elementwise.hip).  A split-bf16 tensor is two bf16 planes [2][rows][cols]: hi = bf16(x),
@@ -300,7 +315,7 @@ hipError_t launch_gather_cols_bf16(const bf16_t* src, const int* cmap, bf16_t* d
                                    hipStream_t s);
 hipError_t launch_gather_rows_f32(const float* src, const int* map, float* dst, int rows, int D, hipStream_t s);
 hipError_t launch_qwen_embed(const int* ids, const int* vis_slot, const bf16_t* embed, const bf16_t* merged, float* out, int rows,
-                             int D, int vocab, hipStream_t s);
+                             int D, int vocab, hipStream_t s, bool merged_f16 = false, float merged_unscale = 1.0f);
 hipError_t launch_u8_to_norm_bf16(const unsigned char* in, bf16_t* out, int N, int H, int W, const float* mean3,
                                   const float* std3, hipStream_t s);
 hipError_t launch_interleave_gate(const bf16_t* wi0, const bf16_t* wi1, bf16_t* dst, int F, int D, hipStream_t s);

@@ -11,6 +11,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -68,6 +69,22 @@ struct vqs_qwen_handle {
     // CLIP-FlanT5 row's precise decoder).  The error attribution (profiles/r5_qwen_error_attribution.md) puts two thirds of the row's
     // |delta log P| into this one row's bf16 roundings.  0 = logits from the bf16 prefill's last row (rounds 2-4)
     int tail_precise = 1;
+    // ---- the range-safe fp16 forms (round 6; include/vqs_qwen.h "fp16").  fp16_req: what the caller asked for (default 1 where every
+    // contraction of the model can run the quad GEMM form); fp16_active: what vqs_qwen_bind_weights established -- fp16 copies of the packed
+    // weights exist, every weight fits fp16, and every 16-bit activation site has a finite proven bound (compute_ranges) and with it a
+    // power-of-two scale sigma = 2^-s under which fp16(T * sigma) cannot overflow.  Sites per block / layer: x0 = norm1 output, qkv = q | k | v
+    // (after the rotary embedding), dattn = attention sub-layer output, x1 = norm2 output, act = gated product, dmlp = FFN sub-layer output.
+    int fp16_req = 0, fp16_active = 0;
+    bool fp16_eligible = false;
+    struct Site { float bound = 0.0f, sigma = 1.0f; };
+    struct LayerSites { Site x0, qkv, dattn, x1, act, dmlp; };
+    std::vector<LayerSites> v_sc, t_sc;
+    Site m_x, m_mid, m_out;                     // merger: norm output, GELU(mlp.0), merged tokens
+    float w_absmax = 0.0f;                      // largest |weight| among the tensors that get fp16 copies
+    std::vector<const bf16_t*> v_qkv_h, v_proj_h, v_gu_h, v_down_h, t_qkv_h, t_o_h, t_gu_h, t_down_h;
+    const bf16_t *m0_h = nullptr, *m2_h = nullptr;
+    float *d_rb = nullptr, *d_ucol = nullptr, *d_slots = nullptr;     // bind-time scratch of compute_ranges (inside the packed buffer)
+    size_t n_rb = 0, n_ucol = 0, n_slots = 0;
 };
 
 namespace {
@@ -163,6 +180,8 @@ struct GCall {
     int M = 0, N = 0, K = 0, lda = 0, ldw = 0, ldc = 0, epi = 0;
     int S = 0, H = 0, inner = 0, hd = 0, inner_kv = 0, Hkv = 0, gate_act = 0, hd_src = 0;
     bf16_t* heads[3] = {nullptr, nullptr, nullptr};
+    int f16 = 0;                         // 3: the scaled fp16 family (A, W, result fp16; acc_scale / out_scale)
+    float acc_scale = 1.0f, out_scale = 1.0f;
 };
 
 int qgemm(vqs_qwen_handle* h, const GCall& g, hipStream_t st, const char* what) {
@@ -172,6 +191,7 @@ int qgemm(vqs_qwen_handle* h, const GCall& g, hipStream_t st, const char* what) 
     p.S = g.S > 0 ? g.S : 1; p.H = g.H; p.inner = g.inner > 0 ? g.inner : 1;
     p.heads_out[0] = g.heads[0]; p.heads_out[1] = g.heads[1]; p.heads_out[2] = g.heads[2];
     p.hd = g.hd; p.inner_kv = g.inner_kv; p.Hkv = g.Hkv; p.gate_act = g.gate_act; p.hd_src = g.hd_src;
+    p.f16 = g.f16; p.acc_scale = g.acc_scale; p.out_scale = g.out_scale;
     if (h->prof) {
         while (h->ev.size() < h->ev_used + 2) {
             hipEvent_t e;
@@ -227,6 +247,8 @@ int pack(vqs_qwen_handle* h, char* base, size_t* total, hipStream_t st) {
         h->v_gu_w.assign(c.v_depth, nullptr); h->v_gu_b.assign(c.v_depth, nullptr); h->v_down_w.assign(c.v_depth, nullptr);
         h->t_qkv_w.assign(c.t_layers, nullptr); h->t_qkv_b.assign(c.t_layers, nullptr); h->t_o_w.assign(c.t_layers, nullptr);
         h->t_gu_w.assign(c.t_layers, nullptr); h->t_down_w.assign(c.t_layers, nullptr);
+        h->v_qkv_h.assign(c.v_depth, nullptr); h->v_proj_h.assign(c.v_depth, nullptr); h->v_gu_h.assign(c.v_depth, nullptr); h->v_down_h.assign(c.v_depth, nullptr);
+        h->t_qkv_h.assign(c.t_layers, nullptr); h->t_o_h.assign(c.t_layers, nullptr); h->t_gu_h.assign(c.t_layers, nullptr); h->t_down_h.assign(c.t_layers, nullptr);
     }
     for (int i = 0; i < c.v_depth; ++i) {
         const std::string p = "model.visual.blocks." + std::to_string(i) + ".";
@@ -237,6 +259,13 @@ int pack(vqs_qwen_handle* h, char* base, size_t* total, hipStream_t st) {
         bf16_t* gu = cv.take<bf16_t>((size_t)2 * h->v_mlp_p * VH);
         bf16_t* gub = cv.take<bf16_t>((size_t)2 * h->v_mlp_p);
         bf16_t* down = cv.take<bf16_t>((size_t)VH * h->v_ffld);
+        // fp16 copies of the four GEMM weights (option fp16): the packed layouts above, cast element for element
+        const size_t n_qkv = cp ? (size_t)3 * VH * VH : (size_t)3 * VPK * VH, n_proj = cp ? (size_t)VH * VH : (size_t)VH * VPK;
+        const size_t n_gu = (size_t)2 * h->v_mlp_p * VH, n_down = (size_t)VH * h->v_ffld;
+        bf16_t *qkv_h = nullptr, *proj_h = nullptr, *gu_h = nullptr, *down_h = nullptr;
+        if (h->fp16_req) {
+            qkv_h = cv.take<bf16_t>(n_qkv); proj_h = cv.take<bf16_t>(n_proj); gu_h = cv.take<bf16_t>(n_gu); down_h = cv.take<bf16_t>(n_down);
+        }
         if (!base) continue;
         QW(wqkv, p + "attn.qkv.weight", (int64_t)3 * VH * VH);
         QW(bqkv, p + "attn.qkv.bias", 3 * VH);
@@ -259,6 +288,25 @@ int pack(vqs_qwen_handle* h, char* base, size_t* total, hipStream_t st) {
         QHIP(h, vqs::launch_gather_rows_bf16(wd, nullptr, nullptr, down, VH, c.v_mlp, c.v_mlp, h->v_ffld, st), "pack vision down");
         (void)VHD;
         h->v_qkv_w[i] = qkv; h->v_qkv_b[i] = qkvb; h->v_proj_w[i] = proj; h->v_gu_w[i] = gu; h->v_gu_b[i] = gub; h->v_down_w[i] = down;
+        if (h->fp16_req) {
+            QHIP(h, vqs::launch_cast16(qkv, qkv_h, n_qkv, true, st), "fp16 vision qkv");
+            QHIP(h, vqs::launch_cast16(proj, proj_h, n_proj, true, st), "fp16 vision proj");
+            QHIP(h, vqs::launch_cast16(gu, gu_h, n_gu, true, st), "fp16 vision gate|up");
+            QHIP(h, vqs::launch_cast16(down, down_h, n_down, true, st), "fp16 vision down");
+            h->v_qkv_h[i] = qkv_h; h->v_proj_h[i] = proj_h; h->v_gu_h[i] = gu_h; h->v_down_h[i] = down_h;
+        }
+    }
+    {   // merger weights: used where they lie in bf16; fp16 copies for the fp16 forms
+        const size_t n0 = (size_t)h->merge_hidden * h->merge_hidden, n2 = (size_t)c.v_out_hidden * h->merge_hidden;
+        bf16_t *m0 = nullptr, *m2 = nullptr;
+        if (h->fp16_req) { m0 = cv.take<bf16_t>(n0); m2 = cv.take<bf16_t>(n2); }
+        if (base && h->fp16_req) {
+            QW(m0w, "model.visual.merger.mlp.0.weight", (int64_t)n0);
+            QW(m2w, "model.visual.merger.mlp.2.weight", (int64_t)n2);
+            QHIP(h, vqs::launch_cast16(m0w, m0, n0, true, st), "fp16 merger mlp.0");
+            QHIP(h, vqs::launch_cast16(m2w, m2, n2, true, st), "fp16 merger mlp.2");
+            h->m0_h = m0; h->m2_h = m2;
+        }
     }
     const int TH = c.t_hidden, IQ = h->t_iq, IKV = h->t_ikv, QN = IQ + 2 * IKV, thd = h->t_hd;
     for (int i = 0; i < c.t_layers; ++i) {
@@ -268,6 +316,11 @@ int pack(vqs_qwen_handle* h, char* base, size_t* total, hipStream_t st) {
         bf16_t* ow = cv.take<bf16_t>((size_t)TH * IQ);
         bf16_t* gu = cv.take<bf16_t>((size_t)2 * h->t_mlp_p * h->t_xld);
         bf16_t* down = cv.take<bf16_t>((size_t)TH * h->t_ffld);
+        const size_t n_qkv = (size_t)QN * TH, n_o = (size_t)TH * IQ, n_gu = (size_t)2 * h->t_mlp_p * h->t_xld, n_down = (size_t)TH * h->t_ffld;
+        bf16_t *qkv_h = nullptr, *o_h = nullptr, *gu_h = nullptr, *down_h = nullptr;
+        if (h->fp16_req) {
+            qkv_h = cv.take<bf16_t>(n_qkv); o_h = cv.take<bf16_t>(n_o); gu_h = cv.take<bf16_t>(n_gu); down_h = cv.take<bf16_t>(n_down);
+        }
         if (!base) continue;
         const int64_t qn = (int64_t)c.t_heads * thd, kn = (int64_t)c.t_kv_heads * thd;
         QW(wq, p + "self_attn.q_proj.weight", qn * TH);
@@ -290,8 +343,144 @@ int pack(vqs_qwen_handle* h, char* base, size_t* total, hipStream_t st) {
         QHIP(h, vqs::launch_gather_rows_bf16(wg, wu, h->d_tgate, gu, 2 * h->t_mlp_p, TH, TH, h->t_xld, st), "pack gate|up");
         QHIP(h, vqs::launch_gather_rows_bf16(wd, nullptr, nullptr, down, TH, c.t_mlp, c.t_mlp, h->t_ffld, st), "pack down");
         h->t_qkv_w[i] = qkv; h->t_qkv_b[i] = qkvb; h->t_o_w[i] = ow; h->t_gu_w[i] = gu; h->t_down_w[i] = down;
+        if (h->fp16_req) {
+            QHIP(h, vqs::launch_cast16(qkv, qkv_h, n_qkv, true, st), "fp16 qkv");
+            QHIP(h, vqs::launch_cast16(ow, o_h, n_o, true, st), "fp16 o");
+            QHIP(h, vqs::launch_cast16(gu, gu_h, n_gu, true, st), "fp16 gate|up");
+            QHIP(h, vqs::launch_cast16(down, down_h, n_down, true, st), "fp16 down");
+            h->t_qkv_h[i] = qkv_h; h->t_o_h[i] = o_h; h->t_gu_h[i] = gu_h; h->t_down_h[i] = down_h;
+        }
+    }
+    if (h->fp16_req) {   // scratch of compute_ranges: row bounds of the widest packed weight, column bounds of the widest contraction, the sites' maxima
+        const size_t QNp = (size_t)h->t_iq + 2 * h->t_ikv;
+        h->n_rb = std::max({(size_t)2 * h->t_mlp_p, (size_t)2 * h->v_mlp_p, QNp, (size_t)3 * c.v_heads * HDP, (size_t)h->merge_hidden, (size_t)c.v_out_hidden});
+        h->n_ucol = std::max({(size_t)h->t_ffld, (size_t)h->v_ffld, (size_t)h->merge_hidden});
+        h->n_slots = (size_t)8 * (c.v_depth + c.t_layers) + 8;
+        float* rb = cv.take<float>(h->n_rb);
+        float* uc = cv.take<float>(h->n_ucol);
+        float* sl = cv.take<float>(h->n_slots);
+        if (base) { h->d_rb = rb; h->d_ucol = uc; h->d_slots = sl; }
     }
     *total = align_up(cv.off);
+    return VQS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Bind-time range proof of the fp16 forms (kernels + the inequalities: qwen_decode.hip "Bind-time range proof").  For every 16-bit
+// activation site of the tower, the merger and the language model a bound of |T| is computed from the weights alone, its maximum lands
+// in a slot, one copy + stream synchronisation brings the slots to the host (the ONE synchronisation of vqs_qwen_bind_weights, only with
+// option fp16), and the host turns a bound B into sigma = 2^-s, the largest power of two <= 1 with B * sigma <= FP16_HEAD (half of the
+// fp16 maximum: room for the fp32 accumulation order and the final rounding).  A non-finite bound (NaN / inf weight) or a weight beyond
+// the fp16 range switches the fp16 forms off for this handle (fp16_active = 0, reason in vqs_qwen_last_error): the bf16 forms run.
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr float FP16_HEAD = 32768.0f;
+bool site_from_bound(vqs_qwen_handle::Site& s, float B) {
+    s.bound = B;
+    s.sigma = 1.0f;
+    if (!(B >= 0.0f) || std::isinf(B)) return false;
+    int e = 0;
+    while (B * std::ldexp(1.0f, -e) > FP16_HEAD && e < 120) ++e;
+    s.sigma = std::ldexp(1.0f, -e);
+    return e < 120;
+}
+
+int compute_ranges(vqs_qwen_handle* h, hipStream_t st) {
+    const vqs_qwen_config& c = h->c;
+    const int VH = c.v_hidden, VNH = c.v_heads, VPK = VNH * HDP, TH = c.t_hidden, IQ = h->t_iq, IKV = h->t_ikv, QN = IQ + 2 * IKV;
+    const bool cp = h->v_compact;
+    const int VAK = cp ? VH : VPK, VQN = cp ? 3 * VH : 3 * VPK;
+    float* sl = h->d_slots;
+    QHIP(h, hipMemsetAsync(sl, 0, h->n_slots * sizeof(float), st), "clear range slots");
+    // slot layout: block / layer l at 8 l: [x0, qkv (before the rotary embedding), dattn, x1, gate|up rows (unused), act, dmlp, -]; then the
+    // merger's [x, mid, out] and the largest |weight|
+    auto layer_chain = [&](float* s8, const bf16_t* g1, const bf16_t* g2, int D, const bf16_t* wqkv, int nq, const bf16_t* bqkv, const bf16_t* wo,
+                           int ko, const bf16_t* bo, const bf16_t* wgu, long long ld_gu, int mlp_p, const bf16_t* bgu, const bf16_t* wd, int ffld,
+                           const bf16_t* bd) -> int {
+        const float R = std::sqrt((float)D);
+        QHIP(h, vqs::launch_absmax_bf16(g1, (size_t)D, R, s8 + 0, st), "range x0");
+        QHIP(h, vqs::launch_rowbound(wqkv, D, nq, D, 0, g1, D, R, nullptr, nullptr, bqkv, nullptr, s8 + 1, st), "range qkv");
+        QHIP(h, vqs::launch_rowbound(wo, ko, D, ko, 1, nullptr, 0, 0.0f, nullptr, s8 + 1, bo, nullptr, s8 + 2, st), "range attention output");
+        QHIP(h, vqs::launch_absmax_bf16(g2, (size_t)D, R, s8 + 3, st), "range x1");
+        QHIP(h, vqs::launch_rowbound(wgu, ld_gu, 2 * mlp_p, D, 0, g2, D, R, nullptr, nullptr, bgu, h->d_rb, s8 + 4, st), "range gate|up");
+        QHIP(h, vqs::launch_gate_pair_bound(h->d_rb, mlp_p, ffld, h->d_ucol, s8 + 5, st), "range gated product");
+        QHIP(h, vqs::launch_rowbound(wd, ffld, D, ffld, 1, nullptr, 0, 0.0f, h->d_ucol, nullptr, bd, nullptr, s8 + 6, st), "range FFN output");
+        return VQS_OK;
+    };
+    float* wmax = sl + (size_t)8 * (c.v_depth + c.t_layers) + 3;
+    auto wrange = [&](const bf16_t* w, size_t n) -> int {
+        QHIP(h, vqs::launch_absmax_bf16(w, n, 1.0f, wmax, st), "weight range");
+        return VQS_OK;
+    };
+    for (int i = 0; i < c.v_depth; ++i) {
+        const std::string p = "model.visual.blocks." + std::to_string(i) + ".";
+        QW(n1, p + "norm1.weight", VH);
+        QW(n2, p + "norm2.weight", VH);
+        QW(pb, p + "attn.proj.bias", VH);
+        QW(db, p + "mlp.down_proj.bias", VH);
+        QRUN(layer_chain(sl + (size_t)8 * i, n1, n2, VH, h->v_qkv_w[i], VQN, h->v_qkv_b[i], h->v_proj_w[i], VAK, pb, h->v_gu_w[i], VH, h->v_mlp_p,
+                         h->v_gu_b[i], h->v_down_w[i], h->v_ffld, db));
+        QRUN(wrange(h->v_qkv_w[i], (size_t)VQN * VH));
+        QRUN(wrange(h->v_proj_w[i], (size_t)VH * VAK));
+        QRUN(wrange(h->v_gu_w[i], (size_t)2 * h->v_mlp_p * VH));
+        QRUN(wrange(h->v_down_w[i], (size_t)VH * h->v_ffld));
+    }
+    {   // merger: RMSNorm over VH, merge_unit rows concatenated (||x^cat||_2 <= sqrt(merge_unit VH)), Linear-GELU-Linear
+        float* sm = sl + (size_t)8 * (c.v_depth + c.t_layers);
+        QW(lnq, "model.visual.merger.ln_q.weight", VH);
+        QW(m0w, "model.visual.merger.mlp.0.weight", (int64_t)h->merge_hidden * h->merge_hidden);
+        QW(m0b, "model.visual.merger.mlp.0.bias", h->merge_hidden);
+        QW(m2w, "model.visual.merger.mlp.2.weight", (int64_t)c.v_out_hidden * h->merge_hidden);
+        QW(m2b, "model.visual.merger.mlp.2.bias", c.v_out_hidden);
+        QHIP(h, vqs::launch_absmax_bf16(lnq, (size_t)VH, std::sqrt((float)VH), sm + 0, st), "range merger norm");
+        QHIP(h, vqs::launch_rowbound(m0w, h->merge_hidden, h->merge_hidden, h->merge_hidden, 0, lnq, VH, std::sqrt((float)h->merge_hidden), nullptr, nullptr,
+                                     m0b, h->d_ucol, sm + 1, st), "range merger mlp.0");
+        QHIP(h, vqs::launch_rowbound(m2w, h->merge_hidden, c.v_out_hidden, h->merge_hidden, 1, nullptr, 0, 0.0f, h->d_ucol, nullptr, m2b, nullptr, sm + 2,
+                                     st), "range merger mlp.2");
+        QRUN(wrange(m0w, (size_t)h->merge_hidden * h->merge_hidden));
+        QRUN(wrange(m2w, (size_t)c.v_out_hidden * h->merge_hidden));
+    }
+    for (int i = 0; i < c.t_layers; ++i) {
+        const std::string p = "model.language_model.layers." + std::to_string(i) + ".";
+        QW(ln1, p + "input_layernorm.weight", TH);
+        QW(ln2, p + "post_attention_layernorm.weight", TH);
+        QRUN(layer_chain(sl + (size_t)8 * (c.v_depth + i), ln1, ln2, TH, h->t_qkv_w[i], QN, h->t_qkv_b[i], h->t_o_w[i], IQ, nullptr, h->t_gu_w[i],
+                         h->t_xld, h->t_mlp_p, nullptr, h->t_down_w[i], h->t_ffld, nullptr));
+        QRUN(wrange(h->t_qkv_w[i], (size_t)QN * TH));
+        QRUN(wrange(h->t_o_w[i], (size_t)TH * IQ));
+        QRUN(wrange(h->t_gu_w[i], (size_t)2 * h->t_mlp_p * h->t_xld));
+        QRUN(wrange(h->t_down_w[i], (size_t)TH * h->t_ffld));
+    }
+    std::vector<float> host(h->n_slots);
+    QHIP(h, hipMemcpyAsync(host.data(), sl, h->n_slots * sizeof(float), hipMemcpyDeviceToHost, st), "read range slots");
+    QHIP(h, hipStreamSynchronize(st), "range proof synchronise");
+    bool ok = true;
+    auto layer_sites = [&](vqs_qwen_handle::LayerSites& L, const float* s8) {
+        ok &= site_from_bound(L.x0, s8[0]);
+        ok &= site_from_bound(L.qkv, 1.41421357f * s8[1]);           // after the rotary embedding: |x'| <= sqrt(2) max|x| (v, unrotated, is below it)
+        ok &= site_from_bound(L.dattn, s8[2]);
+        ok &= site_from_bound(L.x1, s8[3]);
+        ok &= site_from_bound(L.act, s8[5]);
+        ok &= site_from_bound(L.dmlp, s8[6]);
+    };
+    h->v_sc.assign(c.v_depth, vqs_qwen_handle::LayerSites{});
+    h->t_sc.assign(c.t_layers, vqs_qwen_handle::LayerSites{});
+    for (int i = 0; i < c.v_depth; ++i) layer_sites(h->v_sc[i], host.data() + (size_t)8 * i);
+    for (int i = 0; i < c.t_layers; ++i) layer_sites(h->t_sc[i], host.data() + (size_t)8 * (c.v_depth + i));
+    const float* sm = host.data() + (size_t)8 * (c.v_depth + c.t_layers);
+    ok &= site_from_bound(h->m_x, sm[0]);
+    ok &= site_from_bound(h->m_mid, sm[1]);
+    ok &= site_from_bound(h->m_out, sm[2]);
+    h->w_absmax = sm[3];
+    // d_attn's bound used the PRE-rotation q|k|v maximum as the value bound: v is not rotated, so that is the right constant
+    if (!ok) {
+        h->fp16_active = 0;
+        h->err = "fp16 forms off: a range bound is not finite (NaN / inf in the weights?); the bf16 forms run";
+    } else if (!(h->w_absmax < 65504.0f)) {
+        h->fp16_active = 0;
+        h->err = "fp16 forms off: a weight of magnitude " + std::to_string(h->w_absmax) + " does not fit IEEE fp16; the bf16 forms run";
+    } else {
+        h->fp16_active = 1;
+    }
     return VQS_OK;
 }
 
@@ -426,6 +615,14 @@ int vqs_qwen_create(const vqs_qwen_config* cfg, vqs_qwen_handle** out) {
     h->m_tkv = head_pad_map(c.t_kv_heads, h->t_hd);
     h->m_vgate = gate_up_map(c.v_mlp, h->v_mlp_p);
     h->m_tgate = gate_up_map(c.t_mlp, h->t_mlp_p);
+    // fp16 forms: every 16-bit-result GEMM must resolve to the quad form (K >= 128; the scaled family exists only there) and both rotary
+    // embeddings to the 16-byte kernel
+    {
+        const int VAK = h->v_compact ? c.v_hidden : c.v_heads * HDP;
+        h->fp16_eligible = c.v_hidden >= 128 && VAK >= 128 && h->v_ffld >= 128 && h->merge_hidden >= 128 && c.t_hidden >= 128 && h->t_ffld >= 128 &&
+                           ((h->v_hd / 2) % 8) == 0 && ((h->t_hd / 2) % 8) == 0;
+        h->fp16_req = h->fp16_eligible ? 1 : 0;
+    }
     *out = h;
     return VQS_OK;
 }
@@ -468,12 +665,52 @@ int vqs_qwen_debug_option(vqs_qwen_handle* h, const char* name, int64_t value) {
         h->t_xld = (int)value;
         return VQS_OK;
     }
+    if (std::string(name) == "fp16") {           // see include/vqs_qwen.h: 1 needs an eligible model and must be asked for BEFORE the weights are bound
+        if (value != 0 && value != 1) return qfail(h, VQS_ERR_INVALID, "fp16: 0 or 1");
+        if (value == 1 && !h->fp16_eligible) return qfail(h, VQS_ERR_INVALID, "fp16: this configuration has contractions narrower than 128 or rotary halves that are not multiples of 8");
+        if (!h->bound) { h->fp16_req = (int)value; return VQS_OK; }
+        if (value == 0) { h->fp16_active = 0; return VQS_OK; }              // the bf16 forms are always there
+        if (!h->fp16_req) return qfail(h, VQS_ERR_STATE, "fp16: the weights were bound without fp16 copies; set the option before vqs_qwen_bind_weights");
+        if (h->t_sc.empty()) return qfail(h, VQS_ERR_STATE, "fp16: the range proof did not complete at bind time");
+        if (!(h->w_absmax < 65504.0f)) return qfail(h, VQS_ERR_STATE, "fp16: a weight does not fit IEEE fp16");
+        h->fp16_active = 1;
+        return VQS_OK;
+    }
     if (std::string(name) == "tail_precise") {   // see vqs_qwen_handle::tail_precise
         if (value != 0 && value != 1) return qfail(h, VQS_ERR_INVALID, "tail_precise: 0 or 1");
         h->tail_precise = (int)value;
         return VQS_OK;
     }
     return qfail(h, VQS_ERR_INVALID, std::string("unknown option ") + name);
+}
+
+int vqs_qwen_get_option(const vqs_qwen_handle* h, const char* name, int64_t* value) {
+    if (!h || !name || !value) return VQS_ERR_INVALID;
+    const std::string n(name);
+    if (n == "fp16") *value = h->fp16_active;                  // what runs (0 before the weights are bound)
+    else if (n == "fp16_requested") *value = h->fp16_req;
+    else if (n == "fp16_eligible") *value = h->fp16_eligible ? 1 : 0;
+    else if (n == "tail_precise") *value = h->tail_precise;
+    else if (n == "x_pitch") *value = h->t_xld;
+    else return VQS_ERR_INVALID;
+    return VQS_OK;
+}
+
+int vqs_qwen_range_report(const vqs_qwen_handle* h, float* bounds, float* sigmas, int32_t cap) {
+    if (!h) return VQS_ERR_INVALID;
+    if (h->t_sc.empty()) return 0;                              // no proof was made (option fp16 off at bind time)
+    std::vector<float> b, s;
+    auto push = [&](const vqs_qwen_handle::Site& x) { b.push_back(x.bound); s.push_back(x.sigma); };
+    auto layer = [&](const vqs_qwen_handle::LayerSites& L) { push(L.x0); push(L.qkv); push(L.dattn); push(L.x1); push(L.act); push(L.dmlp); };
+    for (const auto& L : h->v_sc) layer(L);
+    push(h->m_x); push(h->m_mid); push(h->m_out);
+    for (const auto& L : h->t_sc) layer(L);
+    const int n = (int)b.size();
+    for (int i = 0; i < n && i < cap; ++i) {
+        if (bounds) bounds[i] = b[i];
+        if (sigmas) sigmas[i] = s[i];
+    }
+    return n;
 }
 
 int vqs_qwen_debug_tap(vqs_qwen_handle* h, const char* name, void* d_dst, size_t bytes) {
@@ -528,6 +765,8 @@ int vqs_qwen_bind_weights(vqs_qwen_handle* h, const vqs_weight_desc* descs, int3
     }
     QRUN(get_w(h, "model.language_model.norm.weight", c.t_hidden, &dummy));
     QRUN(get_w(h, "lm_head.weight", (int64_t)c.t_vocab * c.t_hidden, &dummy));
+    h->fp16_active = 0;
+    if (h->fp16_req) QRUN(compute_ranges(h, (hipStream_t)stream));
     h->bound = true;
     return VQS_OK;
 }
@@ -571,19 +810,31 @@ int vqs_qwen_encode_vision(vqs_qwen_handle* h, const void* d_patches, int32_t N,
     const int VAK = cp ? VH : VPK;       // width of the attention output = K of the proj GEMM
     if (cp)   // lanes [v_hd, 128) of every head slot: written by nobody, read by the attention kernel (q | k | v are contiguous)
         QHIP(h, hipMemsetAsync(w.q, 0, (size_t)((char*)w.attn - (char*)w.q), st), "clear head padding");
+    // F: the range-safe fp16 forms (every 16-bit tensor below is fp16(T * sigma_T), sigma_T from the bind-time proof); else bf16
+    const bool F = h->fp16_active != 0;
+    if (F && (win_len < 8 || frame_len < 8)) return qfail(h, VQS_ERR_INVALID, "encode_vision: the fp16 forms need windows and frames of >= 8 patches (option fp16 = 0 runs any)");
+    const vqs_qwen_handle::LayerSites one{};
+    // RMSNorm whose pending deltas sit behind sd1 / sd2 and whose operand leaves behind so
+    auto norm = [&](const bf16_t* d, const bf16_t* g, const bf16_t* d2, bool store, float eps, float sd1, float sd2, float so, const char* what) -> int {
+        if (F) QHIP(h, vqs::launch_rmsnorm_f16s(w.hidden, d, g, w.xn, Np, VH, eps, st, d2, store, 0, 1.0f / sd1, 1.0f / sd2, so), what);
+        else QHIP(h, vqs::launch_rmsnorm(w.hidden, d, g, w.xn, Np, VH, eps, st, d2, store), what);
+        return VQS_OK;
+    };
 
     const bf16_t* pend = nullptr;
     const bf16_t* pend_attn = nullptr;   // attention delta the fp32 stream has not absorbed yet
+    float s_pend = 1.0f, s_pend_attn = 1.0f;     // their scales
     for (int i = 0; i < c.v_depth; ++i) {
         const std::string p = "model.visual.blocks." + std::to_string(i) + ".";
         QW(n1, p + "norm1.weight", VH);
         QW(n2, p + "norm2.weight", VH);
         QW(pb, p + "attn.proj.bias", VH);
         QW(db, p + "mlp.down_proj.bias", VH);
+        const vqs_qwen_handle::LayerSites& sc = F ? h->v_sc[i] : one;
         const bool full = ((c.v_fullatt_mask >> i) & 1) != 0;
         // deferred store: norm2 normalises hidden + attention delta without writing the stream; the next norm1 (or the
         // merger norm) stores (hidden + attention delta) + mlp delta -- same fp32 sums, 22 instead of 24 B per element
-        QHIP(h, vqs::launch_rmsnorm(w.hidden, pend_attn ? pend_attn : pend, n1, w.xn, Np, VH, c.v_eps, st, pend_attn ? pend : nullptr), "vision norm1");
+        QRUN(norm(pend_attn ? pend_attn : pend, n1, pend_attn ? pend : nullptr, true, c.v_eps, pend_attn ? s_pend_attn : s_pend, s_pend, sc.x0.sigma, "vision norm1"));
         QTAP("vis", i, "h", w.hidden, (size_t)Np * VH);          // the fp32 stream this block starts from (norm1 stored it)
         QTAP("vis", i, "xn0", w.xn, (size_t)Np * VH);
         // window blocks run on the padded windowed layout (every window = win_len slots, d_win_valid of them real);
@@ -596,50 +847,54 @@ int vqs_qwen_encode_vision(vqs_qwen_handle* h, const void* d_patches, int32_t N,
         }
         const int Bseg = rows / S;
         {
-            GCall g{xin, h->v_qkv_w[i], nullptr};
+            GCall g{xin, F ? h->v_qkv_h[i] : h->v_qkv_w[i], nullptr};
             g.bias = h->v_qkv_b[i];
             g.M = rows; g.N = cp ? 3 * VH : 3 * VPK; g.K = VH; g.lda = VH; g.ldw = VH; g.epi = vqs::EPI_HEADS;
             g.S = S; g.H = VNH; g.inner = cp ? VH : VPK; g.hd = HDP; g.hd_src = cp ? h->v_hd : 0;
             g.heads[0] = w.q; g.heads[1] = w.k; g.heads[2] = w.v;
+            if (F) { g.f16 = 3; g.acc_scale = 1.0f / sc.x0.sigma; g.out_scale = sc.qkv.sigma; }
             QRUN(qgemm(h, g, st, "vision qkv"));
         }
         QTAP("vis", i, "q0", w.q, (size_t)rows * VPK);           // projection output, before the rotary embedding
         QTAP("vis", i, "k0", w.k, (size_t)rows * VPK);
-        QHIP(h, vqs::launch_rope_qk(w.q, w.k, full ? d_cos_f : d_cos_w, full ? d_sin_f : d_sin_w, Bseg, VNH, VNH, S, HDP, h->v_hd / 2, st), "vision rope");
+        QHIP(h, vqs::launch_rope_qk(w.q, w.k, full ? d_cos_f : d_cos_w, full ? d_sin_f : d_sin_w, Bseg, VNH, VNH, S, HDP, h->v_hd / 2, st, F), "vision rope");
         QTAP("vis", i, "q", w.q, (size_t)rows * VPK);            // after the rotary embedding, head-major [Bseg, heads, S, 128]
         QTAP("vis", i, "k", w.k, (size_t)rows * VPK);
         QTAP("vis", i, "v", w.v, (size_t)rows * VPK);
-        {
-            vqs::AttnParams a{w.q, w.k, w.v, w.attn, nullptr, full ? nullptr : d_win_valid, Bseg, VNH, S, scale};
-            a.hd = HDP; a.out_hd = cp ? h->v_hd : 0;
+        {   // q and k sit behind sigma_qkv each: the scores' scale takes 1 / sigma^2; the output inherits v's sigma
+            vqs::AttnParams a{w.q, w.k, w.v, w.attn, nullptr, full ? nullptr : d_win_valid, Bseg, VNH, S, scale / (sc.qkv.sigma * sc.qkv.sigma)};
+            a.hd = HDP; a.out_hd = cp ? h->v_hd : 0; a.f16 = F ? 1 : 0;
             QHIP(h, vqs::launch_attention(a, st), "vision attention");
         }
         QTAP("vis", i, "attn", w.attn, (size_t)rows * VAK);
         {
-            GCall g{w.attn, h->v_proj_w[i], full ? (void*)w.dc : (void*)w.delta};
+            GCall g{w.attn, F ? h->v_proj_h[i] : h->v_proj_w[i], full ? (void*)w.dc : (void*)w.delta};
             g.bias = pb;
             g.M = rows; g.N = VH; g.K = VAK; g.lda = VAK; g.ldw = VAK; g.ldc = VH; g.epi = vqs::EPI_BF16;
+            if (F) { g.f16 = 3; g.acc_scale = 1.0f / sc.qkv.sigma; g.out_scale = sc.dattn.sigma; }
             QRUN(qgemm(h, g, st, "vision proj"));
         }
         if (full)
             QHIP(h, vqs::launch_gather_rows_bf16(w.dc, nullptr, d_row_map, w.delta, Np, VH, VH, VH, st), "scatter frame rows back");
         QTAP("vis", i, "d_attn", w.delta, (size_t)Np * VH);
-        QHIP(h, vqs::launch_rmsnorm(w.hidden, w.delta, n2, w.xn, Np, VH, c.v_eps, st, nullptr, false), "vision norm2");
+        QRUN(norm(w.delta, n2, nullptr, false, c.v_eps, sc.dattn.sigma, 1.0f, sc.x1.sigma, "vision norm2"));
         QTAP("vis", i, "xn1", w.xn, (size_t)Np * VH);
-        pend_attn = w.delta;
+        pend_attn = w.delta; s_pend_attn = sc.dattn.sigma;
         {
-            GCall g{w.xn, h->v_gu_w[i], w.ff};
+            GCall g{w.xn, F ? h->v_gu_h[i] : h->v_gu_w[i], w.ff};
             g.bias = h->v_gu_b[i];
             g.M = Np; g.N = 2 * h->v_mlp_p; g.K = VH; g.lda = VH; g.ldw = VH; g.ldc = h->v_ffld; g.epi = vqs::EPI_GATED; g.gate_act = 1;
+            if (F) { g.f16 = 3; g.acc_scale = 1.0f / sc.x1.sigma; g.out_scale = sc.act.sigma; }
             QRUN(qgemm(h, g, st, "vision gate|up"));
         }
         QTAP("vis", i, "ff", w.ff, (size_t)Np * h->v_ffld);
         {
-            GCall g{w.ff, h->v_down_w[i], w.delta2};
+            GCall g{w.ff, F ? h->v_down_h[i] : h->v_down_w[i], w.delta2};
             g.bias = db;
             g.M = Np; g.N = VH; g.K = h->v_ffld; g.lda = h->v_ffld; g.ldw = h->v_ffld; g.ldc = VH; g.epi = vqs::EPI_BF16;
+            if (F) { g.f16 = 3; g.acc_scale = 1.0f / sc.act.sigma; g.out_scale = sc.dmlp.sigma; }
             QRUN(qgemm(h, g, st, "vision down"));
-            pend = w.delta2;
+            pend = w.delta2; s_pend = sc.dmlp.sigma;
         }
         QTAP("vis", i, "d_mlp", w.delta2, (size_t)Np * VH);
     }
@@ -651,25 +906,29 @@ int vqs_qwen_encode_vision(vqs_qwen_handle* h, const void* d_patches, int32_t N,
     QW(m2w, "model.visual.merger.mlp.2.weight", (int64_t)c.v_out_hidden * h->merge_hidden);
     QW(m2b, "model.visual.merger.mlp.2.bias", c.v_out_hidden);
     const int NCp = Np / c.v_merge_unit;
-    QHIP(h, vqs::launch_rmsnorm(w.hidden, pend_attn ? pend_attn : pend, lnq, w.xn, Np, VH, 1e-6f, st, pend_attn ? pend : nullptr), "merger norm");
+    const float s_mx = F ? h->m_x.sigma : 1.0f, s_mid = F ? h->m_mid.sigma : 1.0f, s_mo = F ? h->m_out.sigma : 1.0f;
+    QRUN(norm(pend_attn ? pend_attn : pend, lnq, pend_attn ? pend : nullptr, true, 1e-6f, pend_attn ? s_pend_attn : s_pend, s_pend, s_mx, "merger norm"));
     QTAP("vis", -1, "h_out", w.hidden, (size_t)Np * VH);
     QTAP("vis", -1, "xnm", w.xn, (size_t)Np * VH);
     {
-        GCall g{w.xn, m0w, w.mid};
+        GCall g{w.xn, F ? h->m0_h : m0w, w.mid};
         g.bias = m0b;
         g.M = NCp; g.N = h->merge_hidden; g.K = h->merge_hidden; g.lda = h->merge_hidden; g.ldw = h->merge_hidden; g.ldc = h->merge_hidden;
         g.epi = vqs::EPI_BF16_GELU;
+        if (F) { g.f16 = 3; g.acc_scale = 1.0f / s_mx; g.out_scale = s_mid; }
         QRUN(qgemm(h, g, st, "merger mlp.0"));
     }
     QTAP("vis", -1, "mid", w.mid, (size_t)NCp * h->merge_hidden);
     {
-        GCall g{w.mid, m2w, w.merged_w};
+        GCall g{w.mid, F ? h->m2_h : m2w, w.merged_w};
         g.bias = m2b;
         g.M = NCp; g.N = c.v_out_hidden; g.K = h->merge_hidden; g.lda = h->merge_hidden; g.ldw = h->merge_hidden; g.ldc = c.v_out_hidden;
         g.epi = vqs::EPI_BF16;
+        if (F) { g.f16 = 3; g.acc_scale = 1.0f / s_mid; g.out_scale = s_mo; }
         QRUN(qgemm(h, g, st, "merger mlp.2"));
     }
     QTAP("vis", -1, "merged_w", w.merged_w, (size_t)NCp * c.v_out_hidden);
+    // d_merged leaves in the handle's operand format: bf16, or (fp16 forms) fp16 behind the merger's output scale -- vqs_qwen_score reads it back the same way
     QHIP(h, vqs::launch_gather_rows_bf16(w.merged_w, nullptr, d_cell_inv, (bf16_t*)d_merged, NC, c.v_out_hidden, c.v_out_hidden,
                                           c.v_out_hidden, st), "undo window permutation");
     return VQS_OK;
@@ -730,7 +989,7 @@ int tail_linear(vqs_qwen_handle* h, const bf16_t* A2, int lda, const bf16_t* W, 
 
 // One decoder layer of the tail for every chunk of <= TAIL_ROWS samples; w.k / w.v hold THIS layer's K (rotated) and V of the prefill.
 int tail_layer(vqs_qwen_handle* h, const TxtWs& w, int i, const bf16_t* ln1, const bf16_t* ln2, const int32_t* d_seq_len, const int32_t* d_last_row,
-               const float* d_cos, const float* d_sin, int B, int L, bool first, hipStream_t st) {
+               const float* d_cos, const float* d_sin, int B, int L, bool first, hipStream_t st, bool kv_f16 = false, float kv_sigma = 1.0f) {
     const vqs_qwen_config& c = h->c;
     const int TH = c.t_hidden, IQ = h->t_iq, IKV = h->t_ikv, QN = IQ + 2 * IKV;
     const float scale = 1.0f / sqrtf((float)h->t_hd);
@@ -742,8 +1001,9 @@ int tail_layer(vqs_qwen_handle* h, const TxtWs& w, int i, const bf16_t* ln1, con
         QHIP(h, vqs::launch_rmsnorm_split(th, first ? nullptr : td, ln1, w.t_xn, (long long)rows * TH, rows, TH, c.t_eps, st), "tail input_layernorm");
         QRUN(tail_linear(h, w.t_xn, TH, h->t_qkv_w[i], TH, h->t_qkv_b[i], rows, QN, TH, vqs::SUM_F32, w.t_qkv, QN, 0, w, st, "tail qkv"));
         QHIP(h, vqs::launch_qwen_tail_rope_q(w.t_qkv, QN, d_cos, d_sin, d_last_row + c0, w.t_q, rows, c.t_heads, HDP, h->t_hd / 2, st), "tail rope");
+        // kv_f16: the layer's K / V are the fp16 prefill's tensors behind kv_sigma (the tail's own q is in true units)
         QHIP(h, vqs::launch_qwen_tail_attn(w.t_q, w.k + (size_t)c0 * L * IKV, w.v + (size_t)c0 * L * IKV, d_seq_len + c0, w.t_attn, (long long)rows * IQ, rows,
-                                           c.t_heads, c.t_kv_heads, L, scale, st), "tail attention");
+                                           c.t_heads, c.t_kv_heads, L, scale / kv_sigma, st, kv_f16, 1.0f / kv_sigma), "tail attention");
         QRUN(tail_linear(h, w.t_attn, IQ, h->t_o_w[i], IQ, nullptr, rows, TH, IQ, vqs::SUM_F32, td, TH, 0, w, st, "tail o_proj"));
         // ---- gated FFN
         QHIP(h, vqs::launch_rmsnorm_split(th, td, ln2, w.t_xn, (long long)rows * TH, rows, TH, c.t_eps, st), "tail post_attention_layernorm");
@@ -783,77 +1043,99 @@ int score_impl(vqs_qwen_handle* h, const void* d_merged, const int32_t* d_input_
     const int TH = c.t_hidden, M = B * L, IQ = h->t_iq, IKV = h->t_ikv, XLD = h->t_xld;
     const float scale = 1.0f / sqrtf((float)h->t_hd);
     QW(embed, "model.language_model.embed_tokens.weight", (int64_t)c.t_vocab * TH);
-    QHIP(h, vqs::launch_qwen_embed(d_input_ids, d_vis_slot, embed, (const bf16_t*)d_merged, w.hidden, M, TH, c.t_vocab, st), "embed + splice");
+    // F: the range-safe fp16 forms (bind-time proof; every 16-bit tensor is fp16(T * sigma_T)); d_merged arrives in the same format
+    const bool F = h->fp16_active != 0;
+    if (F && L < 8) return qfail(h, VQS_ERR_INVALID, "score: the fp16 forms need L >= 8 (option fp16 = 0 runs any)");
+    QHIP(h, vqs::launch_qwen_embed(d_input_ids, d_vis_slot, embed, (const bf16_t*)d_merged, w.hidden, M, TH, c.t_vocab, st, F, F ? 1.0f / h->m_out.sigma : 1.0f), "embed + splice");
     QHIP(h, hipMemsetAsync(w.ff, 0, (size_t)M * h->t_ffld * sizeof(bf16_t), st), "clear ff padding");
     QTAP("txt", -1, "emb", w.hidden, (size_t)M * TH);
     const bool tail = h->tail_precise != 0 && (c.t_vocab % 4) == 0 && (c.t_hidden % 4) == 0;
     if (tail)      // the tail's starting state: the embedding rows of the last positions (fp32 copies of bf16 values: exact)
         QHIP(h, vqs::launch_gather_rows_f32(w.hidden, d_last_row, w.t_h, B, TH, TH, st), "tail embed rows");
+    const vqs_qwen_handle::LayerSites one{};
+    auto norm = [&](const bf16_t* d, const bf16_t* g, const bf16_t* d2, bool store, float sd1, float sd2, float so, bool out_bf16, const char* what) -> int {
+        if (F) QHIP(h, vqs::launch_rmsnorm_f16s(w.hidden, d, g, w.xn, M, TH, c.t_eps, st, d2, store, XLD, 1.0f / sd1, 1.0f / sd2, so, out_bf16), what);
+        else QHIP(h, vqs::launch_rmsnorm(w.hidden, d, g, w.xn, M, TH, c.t_eps, st, d2, store, XLD), what);
+        return VQS_OK;
+    };
 
     const bf16_t* pend = nullptr;
     const bf16_t* pend_attn = nullptr;   // attention delta the fp32 stream has not absorbed yet
+    float s_pend = 1.0f, s_pend_attn = 1.0f;
     for (int i = 0; i < c.t_layers; ++i) {
         const std::string p = "model.language_model.layers." + std::to_string(i) + ".";
         QW(ln1, p + "input_layernorm.weight", TH);
         QW(ln2, p + "post_attention_layernorm.weight", TH);
-        QHIP(h, vqs::launch_rmsnorm(w.hidden, pend_attn ? pend_attn : pend, ln1, w.xn, M, TH, c.t_eps, st, pend_attn ? pend : nullptr, true, XLD), "input_layernorm");
+        const vqs_qwen_handle::LayerSites& sc = F ? h->t_sc[i] : one;
+        QRUN(norm(pend_attn ? pend_attn : pend, ln1, pend_attn ? pend : nullptr, true, pend_attn ? s_pend_attn : s_pend, s_pend, sc.x0.sigma, false, "input_layernorm"));
         QTAP("txt", i, "h", w.hidden, (size_t)M * TH);            // the fp32 stream this layer starts from (input_layernorm stored it)
         QRUN(qtap2d(h, "txt", i, "xn0", w.xn, TH, M, XLD, st));
         {
-            GCall g{w.xn, h->t_qkv_w[i], nullptr};
+            GCall g{w.xn, F ? h->t_qkv_h[i] : h->t_qkv_w[i], nullptr};
             g.bias = h->t_qkv_b[i];
             g.M = M; g.N = IQ + 2 * IKV; g.K = TH; g.lda = XLD; g.ldw = TH; g.epi = vqs::EPI_HEADS;
             g.S = L; g.H = c.t_heads; g.inner = IQ; g.hd = HDP; g.inner_kv = IKV; g.Hkv = c.t_kv_heads;
             g.heads[0] = w.q; g.heads[1] = w.k; g.heads[2] = w.v;
+            if (F) { g.f16 = 3; g.acc_scale = 1.0f / sc.x0.sigma; g.out_scale = sc.qkv.sigma; }
             QRUN(qgemm(h, g, st, "qkv"));
         }
         QTAP("txt", i, "q0", w.q, (size_t)M * IQ);                // projection output, before the rotary embedding
         QTAP("txt", i, "k0", w.k, (size_t)M * IKV);
-        QHIP(h, vqs::launch_rope_qk(w.q, w.k, d_cos, d_sin, B, c.t_heads, c.t_kv_heads, L, HDP, h->t_hd / 2, st), "rope");
+        QHIP(h, vqs::launch_rope_qk(w.q, w.k, d_cos, d_sin, B, c.t_heads, c.t_kv_heads, L, HDP, h->t_hd / 2, st, F), "rope");
         QTAP("txt", i, "q", w.q, (size_t)M * IQ);                 // after the rotary embedding, head-major [B, heads, L, 128]
         QTAP("txt", i, "k", w.k, (size_t)M * IKV);
         QTAP("txt", i, "v", w.v, (size_t)M * IKV);
-        if (d_kv) {   // rows [b, head, 0 .. L) of the cache slabs (pitch Lmax positions)
+        if (d_kv) {   // rows [b, head, 0 .. L) of the cache slabs (pitch Lmax positions); the cache (and the decode step) is bf16 in true units
             bf16_t* kc = (bf16_t*)d_kv + (size_t)(2 * i) * kv_slab(h, B, Lmax);
             bf16_t* vc = kc + kv_slab(h, B, Lmax);
             const size_t wb = (size_t)L * HDP * sizeof(bf16_t), pb = (size_t)Lmax * HDP * sizeof(bf16_t), nr = (size_t)B * c.t_kv_heads;
-            QHIP(h, hipMemcpy2DAsync(kc, pb, w.k, wb, wb, nr, hipMemcpyDeviceToDevice, st), "keep K");
-            QHIP(h, hipMemcpy2DAsync(vc, pb, w.v, wb, wb, nr, hipMemcpyDeviceToDevice, st), "keep V");
+            if (F) {
+                if (nr > 65535) return qfail(h, VQS_ERR_INVALID, "prefill: B * kv_heads exceeds 65535");
+                QHIP(h, vqs::launch_f16_to_bf16_rows(w.k, kc, (int)nr, (long long)L * HDP, (long long)L * HDP, (long long)Lmax * HDP, 1.0f / sc.qkv.sigma, st), "keep K");
+                QHIP(h, vqs::launch_f16_to_bf16_rows(w.v, vc, (int)nr, (long long)L * HDP, (long long)L * HDP, (long long)Lmax * HDP, 1.0f / sc.qkv.sigma, st), "keep V");
+            } else {
+                QHIP(h, hipMemcpy2DAsync(kc, pb, w.k, wb, wb, nr, hipMemcpyDeviceToDevice, st), "keep K");
+                QHIP(h, hipMemcpy2DAsync(vc, pb, w.v, wb, wb, nr, hipMemcpyDeviceToDevice, st), "keep V");
+            }
         }
         {
-            vqs::AttnParams a{w.q, w.k, w.v, w.attn, nullptr, d_seq_len, B, c.t_heads, L, scale};
-            a.hd = HDP; a.Hkv = c.t_kv_heads; a.causal = 1;
+            vqs::AttnParams a{w.q, w.k, w.v, w.attn, nullptr, d_seq_len, B, c.t_heads, L, scale / (sc.qkv.sigma * sc.qkv.sigma)};
+            a.hd = HDP; a.Hkv = c.t_kv_heads; a.causal = 1; a.f16 = F ? 1 : 0;
             QHIP(h, vqs::launch_attention(a, st), "attention");
         }
         QTAP("txt", i, "attn", w.attn, (size_t)M * IQ);
         if (tail)      // this layer's K / V are in w.k / w.v until the next layer's qkv launch
-            QRUN(tail_layer(h, w, i, ln1, ln2, d_seq_len, d_last_row, d_cos, d_sin, B, L, i == 0, st));
+            QRUN(tail_layer(h, w, i, ln1, ln2, d_seq_len, d_last_row, d_cos, d_sin, B, L, i == 0, st, F, sc.qkv.sigma));
         {
-            GCall g{w.attn, h->t_o_w[i], w.delta};
+            GCall g{w.attn, F ? h->t_o_h[i] : h->t_o_w[i], w.delta};
             g.M = M; g.N = TH; g.K = IQ; g.lda = IQ; g.ldw = IQ; g.ldc = TH; g.epi = vqs::EPI_BF16;
+            if (F) { g.f16 = 3; g.acc_scale = 1.0f / sc.qkv.sigma; g.out_scale = sc.dattn.sigma; }
             QRUN(qgemm(h, g, st, "o_proj"));
         }
         QTAP("txt", i, "d_attn", w.delta, (size_t)M * TH);
-        QHIP(h, vqs::launch_rmsnorm(w.hidden, w.delta, ln2, w.xn, M, TH, c.t_eps, st, nullptr, false, XLD), "post_attention_layernorm");
+        QRUN(norm(w.delta, ln2, nullptr, false, sc.dattn.sigma, 1.0f, sc.x1.sigma, false, "post_attention_layernorm"));
         QRUN(qtap2d(h, "txt", i, "xn1", w.xn, TH, M, XLD, st));
-        pend_attn = w.delta;
+        pend_attn = w.delta; s_pend_attn = sc.dattn.sigma;
         {
-            GCall g{w.xn, h->t_gu_w[i], w.ff};
+            GCall g{w.xn, F ? h->t_gu_h[i] : h->t_gu_w[i], w.ff};
             g.M = M; g.N = 2 * h->t_mlp_p; g.K = TH; g.lda = XLD; g.ldw = XLD; g.ldc = h->t_ffld; g.epi = vqs::EPI_GATED; g.gate_act = 1;
+            if (F) { g.f16 = 3; g.acc_scale = 1.0f / sc.x1.sigma; g.out_scale = sc.act.sigma; }
             QRUN(qgemm(h, g, st, "gate|up"));
         }
         QTAP("txt", i, "ff", w.ff, (size_t)M * h->t_ffld);
         {
-            GCall g{w.ff, h->t_down_w[i], w.delta2};
+            GCall g{w.ff, F ? h->t_down_h[i] : h->t_down_w[i], w.delta2};
             g.M = M; g.N = TH; g.K = h->t_ffld; g.lda = h->t_ffld; g.ldw = h->t_ffld; g.ldc = TH; g.epi = vqs::EPI_BF16;
+            if (F) { g.f16 = 3; g.acc_scale = 1.0f / sc.act.sigma; g.out_scale = sc.dmlp.sigma; }
             QRUN(qgemm(h, g, st, "down_proj"));
-            pend = w.delta2;
+            pend = w.delta2; s_pend = sc.dmlp.sigma;
         }
         QTAP("txt", i, "d_mlp", w.delta2, (size_t)M * TH);
     }
     QW(fin, "model.language_model.norm.weight", TH);
     QW(head, "lm_head.weight", (int64_t)c.t_vocab * TH);
-    QHIP(h, vqs::launch_rmsnorm(w.hidden, pend_attn ? pend_attn : pend, fin, w.xn, M, TH, c.t_eps, st, pend_attn ? pend : nullptr, true, XLD), "final norm");
+    // the final norm's operand is bf16 in true units either way: lm_head (bf16 weights, fp32 logits) reads it when the tail is off
+    QRUN(norm(pend_attn ? pend_attn : pend, fin, pend_attn ? pend : nullptr, true, pend_attn ? s_pend_attn : s_pend, s_pend, 1.0f, true, "final norm"));
     QTAP("txt", -1, "h_out", w.hidden, (size_t)M * TH);
     QRUN(qtap2d(h, "txt", -1, "xnf", w.xn, TH, M, XLD, st));
     if (tail) {

@@ -140,6 +140,8 @@ def fp16_unsafe_weights(weights: Dict[str, torch.Tensor], stack: str = "vit") ->
             continue
         if stack == "vit":
             mine = k.startswith("vision.encoder.layers.") or k.startswith("mm_projector.")
+        elif stack == "dec":          # option dec_fp16 reads an fp16 copy of the cross-attention's Wk^T
+            mine = k.startswith("decoder.block.") and k.endswith("layer.1.EncDecAttention.k.weight")
         else:
             mine = k.startswith("encoder.block.") and k.endswith(_ENC_FP16_LINEARS)
         if mine:
@@ -147,6 +149,94 @@ def fp16_unsafe_weights(weights: Dict[str, torch.Tensor], stack: str = "vit") ->
             if not (m < FP16_MAX_FINITE_ROUNDED):          # also catches NaN / inf
                 bad.append(k)
     return bad
+
+
+FP16_HEAD = 32768.0        # what a proven bound must stay under for an fp16 site to run: half of the fp16 maximum (room for the fp32 accumulation order)
+FP16_OPTIONS = ("vit_fp16", "proj_fp16", "enc_fp16", "dec_fp16")
+
+
+@torch.no_grad()
+def fp16_range_proof(cfg: ClipT5Config, weights: Dict[str, torch.Tensor]) -> Dict[str, dict]:
+    """Bind-time range proof of the fp16 execution options (include/vqs.h "Range safety"): for every tensor an option holds
+    in IEEE fp16 a bound of its magnitude that follows from the WEIGHTS ALONE, so that "the option is on" means "no input can overflow it".
+      * LayerNorm / RMSNorm output: |x^_k| <= ||x^||_2 <= sqrt(D), so |out_k| <= sqrt(D) |g_k| (+ |b_k|);
+      * a linear fed by a norm output: |sum_k W_jk (g_k x^_k + b_k) + c_j| <= sqrt(D) ||W_j o g||_2 + |W_j . b + c_j|   (Cauchy-Schwarz);
+      * softmax probabilities <= 1; an attention output is a convex combination of value rows: <= the value bound;
+      * a linear fed by a tensor with element bounds u: <= sum_k |W_jk| u_k + |c_j|;  |quick_gelu(t)|, |gelu(t)| <= |t|;
+      * the tower's residual stream (what option proj_fp16 casts to 16 bits): pre-LN output bound + the sum of every block's two output bounds.
+    -> {option: {"holds": bound <= FP16_HEAD at every site, "worst_site": name, "worst_bound": float}}.  Any device; a second or two at XXL."""
+    W = lambda n: weights[n].detach().float()       # noqa: E731
+    worst: Dict[str, Tuple[str, float]] = {k: ("", 0.0) for k in FP16_OPTIONS}
+
+    def note(opt: str, site: str, b) -> float:
+        b = float(b.max()) if torch.is_tensor(b) else float(b)
+        if not (b <= worst[opt][1]):                 # NaN-poisoning: a NaN bound replaces everything and stays
+            worst[opt] = (site, b)
+        return b
+
+    v, t = cfg.vision, cfg.t5
+    # ---- vision tower blocks (vit_fp16) and the stream-fed projector (proj_fp16)
+    D, R = v.hidden, float(v.hidden) ** 0.5
+    u_stream = R * W("vision.pre_layrnorm.weight").abs() + W("vision.pre_layrnorm.bias").abs()
+    for i in range(v.layers_run):
+        p = f"vision.encoder.layers.{i}."
+        g1, b1 = W(p + "layer_norm1.weight"), W(p + "layer_norm1.bias")
+        note("vit_fp16", p + "layer_norm1", R * g1.abs() + b1.abs())
+        vmax = 0.0
+        for nm in ("q_proj", "k_proj", "v_proj"):
+            w_ = W(p + f"self_attn.{nm}.weight")
+            rows = R * (w_ * g1[None, :]).norm(dim=1) + (w_ @ b1 + W(p + f"self_attn.{nm}.bias")).abs()
+            note("vit_fp16", p + nm, rows)
+            if nm == "v_proj":
+                vmax = float(rows.max())
+        d_attn = W(p + "self_attn.out_proj.weight").abs().sum(dim=1) * vmax + W(p + "self_attn.out_proj.bias").abs()
+        note("vit_fp16", p + "out_proj", d_attn)
+        g2, b2 = W(p + "layer_norm2.weight"), W(p + "layer_norm2.bias")
+        note("vit_fp16", p + "layer_norm2", R * g2.abs() + b2.abs())
+        w1 = W(p + "mlp.fc1.weight")
+        u1 = R * (w1 * g2[None, :]).norm(dim=1) + (w1 @ b2 + W(p + "mlp.fc1.bias")).abs()
+        note("vit_fp16", p + "fc1", u1)
+        d_mlp = W(p + "mlp.fc2.weight").abs() @ u1 + W(p + "mlp.fc2.bias").abs()
+        note("vit_fp16", p + "fc2", d_mlp)
+        u_stream = u_stream + d_attn + d_mlp
+    # proj_fp16's two sites sit behind power-of-two scales (options proj_fs_shift / proj_mid_shift, set from these bounds at bind time): the stream
+    # is a sum over every block, its worst-case bound is out of fp16's reach on any real tower
+    b_fs = note("proj_fp16", "hidden_states[-2] (the residual stream)", u_stream)
+    b_mid = note("proj_fp16", "mm_projector.0", W("mm_projector.0.weight").abs() @ u_stream + W("mm_projector.0.bias").abs())
+    # ---- T5 encoder attention side (enc_fp16); its final norm output is what dec_fp16 reads
+    D, R = t.d_model, float(t.d_model) ** 0.5
+    for i in range(t.layers):
+        p = f"encoder.block.{i}."
+        g = W(p + "layer.0.layer_norm.weight")
+        note("enc_fp16", p + "layer.0.layer_norm", R * g.abs())
+        for nm in ("q", "k", "v"):
+            note("enc_fp16", p + "SelfAttention." + nm, R * (W(p + f"layer.0.SelfAttention.{nm}.weight") * g[None, :]).norm(dim=1))
+        note("enc_fp16", p + "layer.1.layer_norm", R * W(p + "layer.1.layer_norm.weight").abs())
+    note("dec_fp16", "encoder.final_layer_norm", R * W("encoder.final_layer_norm.weight").abs())
+    # ---- precise decoder's cross-attention score path (dec_fp16): cross q (norm-fed), q . Wk_h (64 terms per head)
+    for i in range(t.dec_layers):
+        p = f"decoder.block.{i}.layer.1."
+        g = W(p + "layer_norm.weight")
+        q_rows = R * (W(p + "EncDecAttention.q.weight") * g[None, :]).norm(dim=1)
+        qmax = note("dec_fp16", p + "EncDecAttention.q", q_rows)
+        wk = W(p + "EncDecAttention.k.weight").abs().reshape(t.heads, t.d_kv, D)
+        note("dec_fp16", p + "q.Wk", wk.sum(dim=1) * qmax)
+    out = {k: {"holds": bool(b <= FP16_HEAD), "worst_site": s_, "worst_bound": b} for k, (s_, b) in worst.items()}
+    shifts = [fp16_shift(b_fs), fp16_shift(b_mid)]
+    out["proj_fp16"].update({"fs_shift": shifts[0], "mid_shift": shifts[1], "holds": all(x is not None for x in shifts)})
+    return out
+
+
+def fp16_shift(bound: float) -> Optional[int]:
+    """Smallest s >= 0 with bound * 2^-s <= FP16_HEAD (None: the bound is not finite, or beyond 2^60 x the head room)."""
+    if not (bound >= 0.0) or bound == float("inf"):
+        return None
+    s_ = 0
+    while bound * 2.0 ** -s_ > FP16_HEAD:
+        s_ += 1
+        if s_ > 60:
+            return None
+    return s_
 
 
 class VqsEngine:
@@ -170,6 +260,8 @@ class VqsEngine:
         self._ws_shape = None
         self._ews: Optional[torch.Tensor] = None
         self._options: Dict[str, int] = {}
+        self._explicit = set(options or {})          # options the caller chose: honoured even where the range proof fails (the backstop stays)
+        self.fp16_auto_off: Dict[str, str] = {}      # option -> why the bind-time checks switched a DEFAULT off
         for k, v in (options or {}).items():
             self.set_option(k, v)
         self.bind(weights)
@@ -209,17 +301,39 @@ class VqsEngine:
             torch.cuda.current_stream().synchronize()   # the bucket LUT upload reads handle-owned host memory
             self._check_fp16_weights()
 
+    def _auto_off(self, opt: str, why: str):
+        import warnings
+        self._check(self.lib.vqs_set_option(self._h, opt.encode(), 0), "vqs_set_option")
+        self._options[opt] = 0
+        self.fp16_auto_off[opt] = why
+        warnings.warn(f"t2v_metrics_amd: execution option {opt} switched off at bind time -- {why}; that stage runs on bf16 operands "
+                      "(the reference's dtype)", RuntimeWarning, stacklevel=3)
+
     def _check_fp16_weights(self):
-        """The fp16 vision tower (option vit_fp16, default 1) reads fp16 copies of the tower's and the projector's linear weights: a
-        checkpoint whose weights do not fit the format must say so at bind time, not score with infinities."""
+        """Bind-time range safety of the fp16 execution options (round 6).  (1) The fp16 copies vqs_bind_weights made must hold the weights:
+        an option whose weights do not fit is refused if the caller asked for it, switched off with a warning if it was on by default.
+        (2) fp16_range_proof: an option that is on BY DEFAULT stays on only where every one of its fp16 tensors has a proven bound under
+        half of the fp16 maximum; otherwise it is switched off (one warning) -- a drop-in user never meets an overflow.  An explicitly
+        requested option is honoured (the status word's bit 1 and the wrapper's re-score remain as the backstop)."""
         self._fp16_unsafe = fp16_unsafe_weights(self.weights)
-        if self._fp16_unsafe and self.get_option("vit_fp16"):
-            raise VqsError("these vision-tower / projector weights exceed the fp16 range (|w| >= 65520): %s -- pass options={'vit_fp16': 0} "
-                           "to run the tower on bf16 operands" % ", ".join(self._fp16_unsafe[:4]))
         self._enc_fp16_unsafe = fp16_unsafe_weights(self.weights, "enc")
-        if self._enc_fp16_unsafe and self.get_option("enc_fp16"):
-            raise VqsError("these T5-encoder weights exceed the fp16 range (|w| >= 65520): %s -- pass options={'enc_fp16': 0} to run the "
-                           "encoder's attention side on bf16 operands" % ", ".join(self._enc_fp16_unsafe[:4]))
+        self._dec_fp16_unsafe = fp16_unsafe_weights(self.weights, "dec")
+        for opt, bad in (("vit_fp16", self._fp16_unsafe), ("enc_fp16", self._enc_fp16_unsafe), ("dec_fp16", self._dec_fp16_unsafe)):
+            if bad and self.get_option(opt):
+                if opt in self._explicit:
+                    raise VqsError("%s = 1 refused: these weights exceed the fp16 range (|w| >= 65520): %s" % (opt, ", ".join(bad[:4])))
+                self._auto_off(opt, "weights outside the fp16 range: " + ", ".join(bad[:4]))
+        self.range_proof = fp16_range_proof(self.cfg, self.weights)
+        pr = self.range_proof["proj_fp16"]
+        if pr["holds"]:           # the projector's two stream-fed tensors go behind the scales their bounds ask for (0 = none: round 5's kernels)
+            for opt, key in (("proj_fs_shift", "fs_shift"), ("proj_mid_shift", "mid_shift")):
+                if opt not in self._explicit:
+                    self._check(self.lib.vqs_set_option(self._h, opt.encode(), int(pr[key])), "vqs_set_option")
+                    self._options[opt] = int(pr[key])
+        for opt in FP16_OPTIONS:
+            r = self.range_proof[opt]
+            if not r["holds"] and self.get_option(opt) and opt not in self._explicit:
+                self._auto_off(opt, "no proof that %s stays inside the fp16 range (bound %.3g from the weights alone)" % (r["worst_site"], r["worst_bound"]))
 
     # ------------------------------------------------------------------ the two stages
     def encode_images(self, pixels: torch.Tensor) -> torch.Tensor:
@@ -347,6 +461,8 @@ class VqsEngine:
             raise VqsError("vit_fp16 = 1 refused: weights outside the fp16 range: " + ", ".join(self._fp16_unsafe[:4]))
         if name == "enc_fp16" and int(value) == 1 and getattr(self, "_enc_fp16_unsafe", None):
             raise VqsError("enc_fp16 = 1 refused: weights outside the fp16 range: " + ", ".join(self._enc_fp16_unsafe[:4]))
+        if name == "dec_fp16" and int(value) == 1 and getattr(self, "_dec_fp16_unsafe", None):
+            raise VqsError("dec_fp16 = 1 refused: weights outside the fp16 range: " + ", ".join(self._dec_fp16_unsafe[:4]))
         self._check(self.lib.vqs_set_option(self._h, name.encode(), int(value)), "vqs_set_option")
         self._options[name] = int(value)
 

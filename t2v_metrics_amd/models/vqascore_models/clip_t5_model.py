@@ -267,8 +267,9 @@ class CLIPT5Model(VQAScoreModel):
     # ------------------------------------------------------------------ scoring
     @torch.no_grad()
     def score_pairs(self, images: Sequence[str], pair_image: Sequence[int], questions: Sequence[str],
-                    answers: Sequence[str], return_logprobs: bool = False):
-        """Score pairs (images[pair_image[k]], questions[k], answers[k]).  Unique images are encoded once."""
+                    answers: Sequence[str], return_logprobs: bool = False, _retry: bool = False):
+        """Score pairs (images[pair_image[k]], questions[k], answers[k]).  Unique images are encoded once.  (_retry: the one re-score on bf16
+        operands after an fp16 execution option produced a non-finite score -- see the end of this method.)"""
         n = len(questions)
         assert len(answers) == n and len(pair_image) == n
         if n == 0:           # empty M x N grids are legal in the reference (score.py:104 builds a [M, N] tensor of zeros)
@@ -321,15 +322,21 @@ class CLIPT5Model(VQAScoreModel):
         inv[order] = torch.arange(n)
         sc = torch.cat(scores).float().cpu()[inv]
         if not bool(torch.isfinite(sc).all()):
-            # Non-finite scores: with the fp16 execution options (the vision tower and the T5 encoder's attention side hold their 16-bit
-            # tensors in IEEE fp16) an activation beyond 65 504 is stored as inf and reaches the score as NaN (the library raises status
-            # bit 1 for the same condition, include/vqs.h "flags").  bf16 operands do not overflow -- say how to get them.
+            # Non-finite scores.  With an fp16 execution option on, an activation beyond 65 504 is stored as inf and reaches the score as NaN (the
+            # library raises status bit 1 for the same condition, include/vqs.h "flags").  The options that are on by DEFAULT carry a bind-time
+            # range proof (engine.fp16_range_proof) and cannot get here; one the caller insisted on can.  The reference returns a score for any
+            # finite input (score.py:104-106), so: switch the fp16 options off, say so once, and score the batch again on bf16 operands.
             bad = int((~torch.isfinite(sc)).sum())
-            opts = {k: self.engine.get_option(k) for k in ("vit_fp16", "enc_fp16")} if hasattr(self.engine, "get_option") else {}
-            raise RuntimeError(f"{bad} of {sc.numel()} scores are not finite"
-                               + (f" with the fp16 execution options {opts}: an activation left the fp16 range -- construct the scorer with "
-                                  "engine_options={'vit_fp16': 0, 'enc_fp16': 0} to run those stages on bf16 operands" if any(opts.values()) else
-                                  ": the checkpoint's weights or the inputs are not finite"))
+            on = [k for k in ("vit_fp16", "enc_fp16", "dec_fp16") if hasattr(self.engine, "get_option") and self.engine.get_option(k)]
+            if on and not _retry:
+                import warnings
+                warnings.warn(f"t2v_metrics_amd: {bad} of {sc.numel()} scores were not finite with the fp16 execution options {on}: an activation left "
+                              "the fp16 range.  Those options are now OFF for this scorer (bf16 operands, the reference's dtype) and the batch is re-scored.",
+                              RuntimeWarning, stacklevel=2)
+                for k in on:
+                    self.engine.set_option(k, 0)
+                return self.score_pairs(images, pair_image, questions, answers, return_logprobs, _retry=True)
+            raise RuntimeError(f"{bad} of {sc.numel()} scores are not finite on bf16 operands: the checkpoint's weights or the inputs are not finite")
         if return_logprobs:
             return sc, torch.cat(lps).float().cpu()[inv]
         return sc

@@ -116,6 +116,10 @@ def chat_prompt(question: str, placeholder: str) -> str:
             "<|vision_end|>" + question + "<|im_end|>\n<|im_start|>assistant\n")
 
 
+class _NonFiniteUnderFp16(Exception):
+    """raised inside a pass when the fp16 forms' logits are not finite; caught by Qwen25VLModel._with_bf16_fallback"""
+
+
 class Qwen25VLModel(VQAScoreModel):
     video_mode = "direct"
     allows_image = True
@@ -301,7 +305,21 @@ class Qwen25VLModel(VQAScoreModel):
         p = torch.softmax(scores.float() / temperature, dim=-1)                 # engine doubles in the CPU tests
         return p[torch.arange(p.shape[0]), token_ids.to(p.device)].cpu()
 
-    def _generate_scores(self, images, texts, fps, question_template, answer_template, max_new_tokens):
+    def _with_bf16_fallback(self, fn):
+        """fn(), and once more on the bf16 forms (one warning, the option stays off) if the fp16 forms produced a non-finite logit."""
+        try:
+            return fn()
+        except _NonFiniteUnderFp16:
+            import warnings
+            warnings.warn("t2v_metrics_amd: non-finite logits under the Qwen2.5-VL row's fp16 forms; option fp16 is now OFF for this scorer (bf16 "
+                          "everywhere, the reference's dtype) and the call is run again.", RuntimeWarning, stacklevel=3)
+            self.engine.set_option("fp16", 0)
+            return fn()
+
+    def _generate_scores(self, *args):
+        return self._with_bf16_fallback(lambda: self._generate_scores_impl(*args))
+
+    def _generate_scores_impl(self, images, texts, fps, question_template, answer_template, max_new_tokens):
         """Shared front half of forward / forward_with_trace: load, preprocess, batch by grid, greedy generation.
         -> per sample (processed score rows, generated ids, answer ids)."""
         assert len(images) == len(texts), "Number of images/videos and texts must match"
@@ -450,6 +468,10 @@ class Qwen25VLModel(VQAScoreModel):
             logits = self.engine.score_logits(merged, ids, mask, grids)
         else:
             logits, state = self.engine.prefill(merged, ids, mask, grids, max_new_tokens)
+        # Backstop of the fp16 forms (include/vqs_qwen.h): their scales come from a bind-time PROOF, so a non-finite logit cannot be an fp16
+        # overflow -- but a drop-in user gets a score for every finite input either way: _with_bf16_fallback re-runs the call on the bf16 forms
+        if getattr(self.engine, "fp16_active", False) and not bool(torch.isfinite(logits).all()):
+            raise _NonFiniteUnderFp16()
         for step in range(max_new_tokens):
             if step > 0:
                 logits = self.engine.decode(state, torch.tensor([gen[k][-1] for k in range(n)], dtype=torch.long))
@@ -465,9 +487,12 @@ class Qwen25VLModel(VQAScoreModel):
                 break
         return step_scores, gen
 
+    def generate(self, *args, **kw) -> List[str]:
+        return self._with_bf16_fallback(lambda: self._generate_impl(*args, **kw))
+
     @torch.no_grad()
-    def generate(self, images: List[str], texts: List[str], fps=None, max_new_tokens: int = 2048, temperature: float = 0.0,
-                 do_sample: bool = None, top_p: float = 0.9) -> List[str]:
+    def _generate_impl(self, images: List[str], texts: List[str], fps=None, max_new_tokens: int = 2048, temperature: float = 0.0,
+                       do_sample: bool = None, top_p: float = 0.9) -> List[str]:
         """Free-form answers (qwen2vl_model.py:495-563): the text is the whole user turn; greedy unless temperature > 0, then
         HF's sampling chain for those kwargs: temperature, the generation config's top-k (default 50), nucleus top_p (`_warp`).
         Decoded with skip_special_tokens=True and stripped."""

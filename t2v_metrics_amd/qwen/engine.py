@@ -37,12 +37,16 @@ _SIGS = {
     "vqs_qwen_decode": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _sz, _vp, _vp, _sz, _vp]),
     "vqs_qwen_debug_tap": (_i32, [_vp, ctypes.c_char_p, _vp, _sz]),
     "vqs_qwen_debug_option": (_i32, [_vp, ctypes.c_char_p, ctypes.c_int64]),
+    "vqs_qwen_get_option": (_i32, [_vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64)]),
+    "vqs_qwen_range_report": (_i32, [_vp, ctypes.POINTER(_f32), ctypes.POINTER(_f32), _i32]),
     "vqs_qwen_score": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _sz, _vp]),
 }
 
 
 class QwenEngine:
-    def __init__(self, cfg: Qwen25VLConfig, weights: Dict[str, torch.Tensor], device="cuda:0", x_pitch: int = None):
+    def __init__(self, cfg: Qwen25VLConfig, weights: Dict[str, torch.Tensor], device="cuda:0", x_pitch: int = None, fp16: bool = None):
+        """fp16: None = the library's default (the range-safe fp16 forms wherever the model is eligible: include/vqs_qwen.h), False = bind
+        without fp16 weight copies (the reference's bf16 everywhere), True = insist (raises on an ineligible configuration)."""
         if not torch.cuda.is_available():
             raise VqsError("the Qwen2.5-VL HIP path needs an MI355X (no CPU fallback)")
         self.lib = load_library()
@@ -63,6 +67,8 @@ class QwenEngine:
         self._h = h
         if x_pitch is not None:          # test hook (include/vqs_qwen.h): row pitch of the normalised activations / gate|up weight rows
             self._check(self.lib.vqs_qwen_debug_option(self._h, b"x_pitch", int(x_pitch)), "vqs_qwen_debug_option")
+        if fp16 is not None:
+            self._check(self.lib.vqs_qwen_debug_option(self._h, b"fp16", 1 if fp16 else 0), "vqs_qwen_debug_option")
         with torch.cuda.device(self.device):
             self._weights = {k: w.to(self.device, torch.bfloat16).contiguous() for k, w in weights.items()}
             descs = (VqsWeightDesc * len(self._weights))(*[VqsWeightDesc(k.encode(), w.data_ptr(), w.numel())
@@ -75,8 +81,39 @@ class QwenEngine:
 
     def set_option(self, name: str, value: int):
         """Execution-form switches of include/vqs_qwen.h (vqs_qwen_debug_option): "tail_precise" 1 (default) = the logits come from the
-        precise re-evaluation of every sample's last prompt position, 0 = from the bf16 prefill's last row (rounds 2-4)."""
+        precise re-evaluation of every sample's last prompt position, 0 = from the bf16 prefill's last row (rounds 2-4); "fp16" 0 / 1 = the
+        bf16 forms / the range-safe fp16 forms (1 only if the weights were bound with it)."""
         self._check(self.lib.vqs_qwen_debug_option(self._h, name.encode(), int(value)), "vqs_qwen_debug_option")
+
+    def get_option(self, name: str) -> int:
+        v = ctypes.c_int64(0)
+        self._check(self.lib.vqs_qwen_get_option(self._h, name.encode(), ctypes.byref(v)), "vqs_qwen_get_option")
+        return int(v.value)
+
+    @property
+    def fp16_active(self) -> bool:
+        return self.get_option("fp16") == 1
+
+    def range_report(self):
+        """-> (bounds, sigmas) float32 tensors of the bind-time range proof (vqs_qwen_range_report; empty when none was made)."""
+        n = self.lib.vqs_qwen_range_report(self._h, None, None, 0)
+        if n < 0:
+            self._check(n, "vqs_qwen_range_report")
+        b, s = (ctypes.c_float * max(n, 1))(), (ctypes.c_float * max(n, 1))()
+        self.lib.vqs_qwen_range_report(self._h, b, s, n)
+        return torch.tensor(list(b)[:n]), torch.tensor(list(s)[:n])
+
+    def merged_values(self, merged: torch.Tensor) -> torch.Tensor:
+        """fp32 values of an encode_vision result (undoes the fp16 forms' scale)."""
+        if merged.dtype == torch.float16:
+            _, sig = self.range_report()
+            return merged.float() / float(sig[6 * self.cfg.vision.depth + 2])
+        return merged.float()
+
+    def _merged_matches_mode(self, merged: torch.Tensor):
+        want = torch.float16 if self.fp16_active else torch.bfloat16
+        if merged.dtype != want:
+            raise VqsError(f"merged vision tokens are {merged.dtype}, the engine's operand format is {want}: option fp16 changed between encode_vision and score?")
 
     def _check(self, rc, what):
         if rc != 0:
@@ -91,7 +128,8 @@ class QwenEngine:
         return self._ws
 
     def encode_vision(self, patches: torch.Tensor, grids: Sequence[Tuple[int, int, int]]) -> torch.Tensor:
-        """patches [N, patch_dim] (HF processor order) -> merged vision tokens bf16 [N/4, out_hidden]."""
+        """patches [N, patch_dim] (HF processor order) -> merged vision tokens [N/4, out_hidden]: bf16, or with the fp16 forms a float16 tensor
+        holding value * sigma (opaque: feed it to score_logits / prefill of THIS engine; merged_values() gives the numbers)."""
         lay = vision_layout(self.cfg, grids)
         with torch.cuda.device(self.device):
             dev = self.device
@@ -100,7 +138,9 @@ class QwenEngine:
             if px.shape[0] != N:
                 raise VqsError(f"{px.shape[0]} patch rows for grids that hold {N}")
             d = {k: lay[k].to(dev) for k in ("row_map", "inv_row", "win_valid", "cell_inv", "cos_w", "sin_w", "cos_f", "sin_f")}
-            out = torch.empty(N // self.cfg.vision.merge_unit, self.cfg.vision.out_hidden, dtype=torch.bfloat16, device=dev)
+            # the handle's operand format (include/vqs_qwen.h): bf16, or -- fp16 forms -- IEEE fp16 behind the merger's power-of-two scale
+            f16 = self.fp16_active
+            out = torch.empty(N // self.cfg.vision.merge_unit, self.cfg.vision.out_hidden, dtype=torch.float16 if f16 else torch.bfloat16, device=dev)
             ws = self._workspace(self.lib.vqs_qwen_vision_workspace_bytes(self._h, N, Np))
             self._check(self.lib.vqs_qwen_encode_vision(self._h, px.data_ptr(), N, d["row_map"].data_ptr(), d["inv_row"].data_ptr(),
                                                         d["win_valid"].data_ptr(), d["cell_inv"].data_ptr(), d["cos_w"].data_ptr(),
@@ -119,6 +159,7 @@ class QwenEngine:
             ids = input_ids.to(dev, torch.int32).contiguous()
             t = {k: lay[k].to(dev) for k in ("vis_slot", "seq_len", "last_row", "cos", "sin")}
             logits = torch.empty(B, self.cfg.text.vocab, dtype=torch.float32, device=dev)
+            self._merged_matches_mode(merged)
             ws = self._workspace(self.lib.vqs_qwen_score_workspace_bytes(self._h, B, L))
             self._check(self.lib.vqs_qwen_score(self._h, merged.contiguous().data_ptr(), ids.data_ptr(), t["vis_slot"].data_ptr(),
                                                 t["seq_len"].data_ptr(), t["last_row"].data_ptr(), t["cos"].data_ptr(),
@@ -138,6 +179,7 @@ class QwenEngine:
             ids = input_ids.to(dev, torch.int32).contiguous()
             t = {k: lay[k].to(dev) for k in ("vis_slot", "seq_len", "last_row", "cos", "sin")}
             logits = torch.empty(B, self.cfg.text.vocab, dtype=torch.float32, device=dev)
+            self._merged_matches_mode(merged)
             kv = torch.empty(self.lib.vqs_qwen_kv_bytes(self._h, B, Lmax), dtype=torch.uint8, device=dev)
             ws = self._workspace(self.lib.vqs_qwen_score_workspace_bytes(self._h, B, L))
             self._check(self.lib.vqs_qwen_prefill(self._h, merged.contiguous().data_ptr(), ids.data_ptr(), t["vis_slot"].data_ptr(),

@@ -9,8 +9,11 @@ with the two hot loops rebuilt as real batches:
     encoded once and all M*N pairs go through the T5 passes in engine-sized batches (``model.forward_grid``).
   * reference ``batch_forward`` (score.py:143-153) iterates DataLoader batches but still scores ONE pair per model
     call.  Here every DataLoader batch is flattened into one pair list (images deduplicated) and scored in one call.
-  * with ``torch.distributed`` initialised, ``forward`` shards the grid by IMAGE and ``batch_forward`` the samples over ranks
-    (contiguous blocks) and all-gathers the scores (t2v_metrics_amd/sharding.py) -- the reference has no multi-GPU path.
+  * multi-GPU (the reference has none) is OPT-IN: ``Score(..., distributed=True)`` (or ``shard=True`` on a call) with
+    ``torch.distributed`` initialised makes ``forward`` shard the grid by IMAGE and ``batch_forward`` the samples over ranks (contiguous
+    blocks) and all-gather the scores (t2v_metrics_amd/sharding.py).  These calls are then COLLECTIVES: every rank must make the same call
+    with the same inputs -- checked (a digest of the inputs is all-gathered first; a mismatch raises on every rank).  The default keeps the
+    reference's semantics: a call scores what it is given on the calling process, whatever process group the caller's training loop has.
 
 Video inputs: as in the reference the decision is the model's ``video_mode`` (score.py:69-101): "direct" models get the
 container paths untouched (Qwen2.5-VL reads frame arrays; container decode needs decord/ffmpeg, which this image does
@@ -35,10 +38,13 @@ _VIDEO_EXT = {'.mp4', '.avi', '.mov', '.mkv'}
 
 
 class Score(nn.Module):
-    def __init__(self, model: str, device: str = 'cuda', cache_dir: str = HF_CACHE_DIR, **kwargs):
+    def __init__(self, model: str, device: str = 'cuda', cache_dir: str = HF_CACHE_DIR, distributed: bool = False, **kwargs):
+        """distributed (not in the reference; default False = its semantics): True = forward / batch_forward shard their work over the ranks of
+        the initialised torch.distributed group and gather the scores -- collective calls, see the module docstring."""
         super().__init__()
         assert model in self.list_all_models()
         self.device = device
+        self.distributed = bool(distributed)
         self.model = self.prepare_scoremodel(model, device, cache_dir, **kwargs)
         self.model_name = model
 
@@ -72,12 +78,13 @@ class Score(nn.Module):
             elif mode != "direct":
                 print("Invalid `video_mode` for the given model. Please check model's class attributes")
                 return
-        # With torch.distributed initialised (one process per GPU, every rank making the SAME call) the grid is sharded BY IMAGE: rank r
-        # encodes and scores the rows of its contiguous block of images, so each image still goes through the vision tower once in the
-        # whole job, and one gather of fp32 rows hands every rank the [m, n] grid (the reference's row loop,
-        # score.py:104-106, is the unit that is sharded).  `shard=False` keeps the whole grid on the calling rank (ranks scoring
-        # DIFFERENT grids at the same time must say so: the gather is a collective).
-        shard = kwargs.pop("shard", True) and sharding.world()[1] > 1
+        # Opt-in (distributed=True on the constructor, or shard=True here) with torch.distributed initialised (one process per GPU, every rank
+        # making the SAME call): the grid is sharded BY IMAGE -- rank r encodes and scores the rows of its contiguous block of images, so each
+        # image still goes through the vision tower once in the whole job, and one gather of fp32 rows hands every rank the [m, n] grid
+        # (the reference's row loop, score.py:104-106, is the unit that is sharded).  The ranks' inputs are checked first.
+        shard = bool(kwargs.pop("shard", self.distributed)) and sharding.world()[1] > 1
+        if shard:
+            sharding.assert_same_call("forward", [str(i) for i in images], list(texts))
         m = len(images)
         lo, hi = sharding.shard_range(m) if shard else (0, m)
         mine = images[lo:hi]
@@ -104,7 +111,11 @@ class Score(nn.Module):
                                       "models is outside the MI355X hot path")
         num_visuals = len(dataset[0][media_type])
         num_texts = len(dataset[0]['texts'])
-        lo, hi = sharding.shard_range(num_samples)
+        shard = bool(kwargs.pop("shard", self.distributed)) and sharding.world()[1] > 1
+        if shard:      # a collective: the ranks must hold the same dataset (checked on its size and its first / last samples)
+            sharding.assert_same_call("batch_forward", num_samples, num_visuals, num_texts, [str(v) for v in dataset[0][media_type]], list(dataset[0]['texts']),
+                                      [str(v) for v in dataset[-1][media_type]], list(dataset[-1]['texts']))
+        lo, hi = sharding.shard_range(num_samples) if shard else (0, num_samples)
         local = torch.zeros(hi - lo, num_visuals, num_texts)
         for start in range(lo, hi, batch_size):
             stop = min(hi, start + batch_size)
@@ -122,5 +133,5 @@ class Score(nn.Module):
                         texts.append(t)
             s = self.model.forward(images, texts, **kwargs)
             local[start - lo: stop - lo] = s.reshape(stop - start, num_visuals, num_texts).float().cpu()
-        scores = sharding.gather_rows(local, num_samples)
+        scores = sharding.gather_rows(local, num_samples) if shard else local
         return scores.to(self._out_device())

@@ -26,6 +26,28 @@ def shard_range(n: int, rank: int = None, world_size: int = None) -> Tuple[int, 
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def assert_same_call(*parts) -> None:
+    """The sharded scoring calls are COLLECTIVES: every rank must make the same call with the same inputs.  All-gathers a 64-bit digest of
+    `parts` (lengths, paths, texts ...) and raises ValueError ON EVERY RANK when they differ -- instead of a deadlock (ranks disagreeing on
+    whether to enter) or a silently mixed result (equal shapes, different inputs).  No-op without an initialised process group."""
+    d = _dist()
+    if d is None:
+        return
+    import hashlib
+    h = hashlib.blake2b(repr(parts).encode("utf-8", "surrogatepass"), digest_size=8).digest()
+    mine = torch.tensor([int.from_bytes(h, "little", signed=True)], dtype=torch.int64)
+    backend = d.get_backend()
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    mine = mine.to(dev)
+    out = [torch.empty_like(mine) for _ in range(d.get_world_size())]
+    d.all_gather(out, mine)
+    vals = [int(x.item()) for x in out]
+    if any(v != vals[0] for v in vals):
+        raise ValueError("distributed scoring call: the ranks do not agree on the inputs (digests %s). With distributed=True every rank must call "
+                         "with the SAME images / texts / dataset; ranks that score different inputs must not shard (distributed=False or shard=False)"
+                         % [hex(v & 0xffffffffffffffff) for v in vals])
+
+
 def gather_rows(local: torch.Tensor, n_total: int) -> torch.Tensor:
     """Inverse of shard_range: every rank contributes its block of rows, every rank receives all n_total rows."""
     d = _dist()

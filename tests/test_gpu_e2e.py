@@ -383,10 +383,13 @@ def test_fp16_encoder_attention_side_is_closer_to_fp32_than_the_bf16_encoder():
 
 
 @pytest.mark.parametrize("stack,option", [("vit", "vit_fp16"), ("enc", "enc_fp16")])
-def test_an_activation_beyond_the_fp16_range_raises_the_status_bit_and_names_the_option(stack, option):
-    """v_cvt_pk_f16_f32 stores +-inf for |x| >= 65 520 without a trace.  A planted activation of ~1e5 (a norm gain of the
-    first layer scaled up) must (a) set bit 1 of the pass's status word, (b) make the scores non-finite rather than silently wrong,
-    (c) make the model wrapper raise and name the fp16 options -- and with that stage on bf16 operands the same weights score finitely."""
+def test_an_activation_beyond_the_fp16_range_never_reaches_a_drop_in_user(stack, option):
+    """v_cvt_pk_f16_f32 stores +-inf for |x| >= 65 520 without a trace.  A checkpoint with a planted activation
+    of ~1e5 (a) loses that fp16 option AT BIND TIME when it was on by default -- the range proof (engine.fp16_range_proof) cannot bound the site --
+    and scores finitely on bf16 operands, with a warning, never an exception; (b) when the caller INSISTS on the option, the pass sets bit 1 of
+    its status word and the scores are non-finite rather than silently wrong; (c) the model wrapper then re-scores the batch with the fp16
+    options off and returns what the bf16 engine returns."""
+    import warnings
     import t2v_metrics_amd as t2v
     from t2v_metrics_amd.engine import VqsEngine
     from tests.test_host_api import FakeTokenizer
@@ -404,21 +407,40 @@ def test_an_activation_beyond_the_fp16_range_raises_the_status_bit_and_names_the
         key = "encoder.block.0.layer.0.layer_norm.weight"
         w[key] = (w[key].float() * 0 + 1.0e5).to(torch.bfloat16)  # the norm's output (an fp16 tensor under the option) is ~1e5 x a unit-variance row
     pix, img_index, ids, labels = _inputs(cfg, 4, 2, 12, 2, seed=16)
-    eng = VqsEngine(cfg, w, device="cuda:0")
+    # (a) defaults: the proof switches the option off at bind time
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        eng = VqsEngine(cfg, w, device="cuda:0")
     try:
+        assert option in eng.fp16_auto_off and eng.get_option(option) == 0 and any(option in str(r.message) for r in rec)
+        assert not eng.range_proof[option]["holds"] and eng.range_proof[option]["worst_bound"] > 65504.0
+        lp, sc_bf16 = eng.score(eng.encode_images(pix.cuda()), img_index, ids, labels)
+        torch.cuda.synchronize()
+        assert int(eng.stage("flags")[0]) == 0 and bool(torch.isfinite(sc_bf16).all()) and bool(torch.isfinite(lp).all())
+    finally:
+        eng.close()
+    # (b) the caller insists: honoured, and the overflow is reported, not hidden
+    eng = VqsEngine(cfg, w, device="cuda:0", options={option: 1})
+    try:
+        assert eng.get_option(option) == 1 and option not in eng.fp16_auto_off
         lp, sc = eng.score(eng.encode_images(pix.cuda()), img_index, ids, labels)
         torch.cuda.synchronize()
         assert int(eng.stage("flags")[0]) & 2 and not bool(torch.isfinite(sc).all())
-        eng.set_option(option, 0)
-        lp, sc = eng.score(eng.encode_images(pix.cuda()), img_index, ids, labels)
-        torch.cuda.synchronize()
-        assert int(eng.stage("flags")[0]) == 0 and bool(torch.isfinite(sc).all()) and bool(torch.isfinite(lp).all())
     finally:
         eng.close()
-    model = t2v.VQAScore(model="clip-flant5-xl", device="cuda:0", config=cfg, weights=w, tokenizer=FakeTokenizer(cfg.t5.vocab), image_workers="thread").model
+    # (c) the wrapper: one warning, the options go off, the batch is scored again -- the reference's behaviour (a score for every finite input)
+    model = t2v.VQAScore(model="clip-flant5-xl", device="cuda:0", config=cfg, weights=w, tokenizer=FakeTokenizer(cfg.t5.vocab), image_workers="thread",
+                         engine_options={option: 1}).model
     model.load_images = lambda paths: pix[: len(paths)].cuda()
-    with pytest.raises(RuntimeError, match="fp16 range.*enc_fp16"):
-        model.score_pairs(["a", "b"], [0, 1], ["one caption", "another caption"], ["Yes", "Yes"])
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        s1 = model.score_pairs(["a", "b"], [0, 1], ["one caption", "another caption"], ["Yes", "Yes"])
+    assert bool(torch.isfinite(s1).all()) and any("re-scored" in str(r.message) for r in rec)
+    assert model.engine.get_option(option) == 0
+    with warnings.catch_warnings(record=True) as rec2:
+        warnings.simplefilter("always")
+        s2 = model.score_pairs(["a", "b"], [0, 1], ["one caption", "another caption"], ["Yes", "Yes"])
+    assert torch.equal(s1, s2) and not any("re-scored" in str(r.message) for r in rec2)      # warned once; the scorer stays on bf16 operands
 
 
 def test_fused_residual_rmsnorm_matches_separate_kernels():

@@ -44,8 +44,10 @@ def run_stage_locked(cfg, w, eng, pix, idx, ids, labels, tag, window=None, vit_f
         vit_fp16 = bool(eng.get_option("vit_fp16"))          # the engine's own setting (default: fp16 tower)
     assert vit_fp16 == bool(eng.get_option("vit_fp16"))
     # enc_fp16 (round 5, default 1): likewise for the encoder's attention side -- the oracle follows the engine's setting
+    # proj_shifts (round 6): the scales the bind-time range proof put the selected features / the projector's hidden tensor behind
+    shifts = (eng.get_option("proj_fs_shift"), eng.get_option("proj_mid_shift")) if (vit_fp16 and eng.get_option("proj_fp16")) else (0, 0)
     emu = Oracle(cfg, w_cpu, emulate="engine", vit_fp16=vit_fp16, enc_fp16=bool(eng.get_option("enc_fp16")), dec_fp16=bool(eng.get_option("dec_fp16")),
-                 device=odev)
+                 device=odev, proj_shifts=shifts)
     B, L = ids.shape
     T = labels.shape[1]
     if window is None:

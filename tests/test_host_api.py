@@ -350,23 +350,100 @@ def test_weights_that_do_not_fit_fp16_are_named_before_the_fp16_tower_reads_them
     w[t5] = w[t5].clone(); w[t5][0, 0] = 1.0e6                                   # the T5 stacks stay bf16: not this check's business
     w["vision.encoder.layers.0.layer_norm1.weight"] = w["vision.encoder.layers.0.layer_norm1.weight"] * 1e5   # norm parameters stay bf16 too
     assert sorted(fp16_unsafe_weights(w)) == sorted([k1, k2])
-    # the engine's bind-time check and the option guard, on an engine object without a device (the handle's option is stubbed)
-    from t2v_metrics_amd.engine import VqsEngine, VqsError
-    e = object.__new__(VqsEngine)
-    e.weights, e._h = w, None
-    for on in (1, 0):
-        e.get_option = lambda name, on=on: on
-        if on:
-            with pytest.raises(VqsError, match="exceed the fp16 range.*vit_fp16"):
-                e._check_fp16_weights()
-        else:
-            e._check_fp16_weights()                                              # bf16 tower: nothing to refuse
+    # the engine's bind-time check and the option guard, on an engine object without a device (the handle's options live in a dict)
+    import ctypes
+    import types
+    import warnings
+    from t2v_metrics_amd.engine import FP16_OPTIONS, VqsEngine, VqsError
+
+    def fake_engine(weights, explicit=()):
+        e = object.__new__(VqsEngine)
+        e.cfg, e.weights, e._h, e._options, e._explicit, e.fp16_auto_off = cfg, weights, None, {}, set(explicit), {}
+        state = {k: 1 for k in FP16_OPTIONS}
+        e.get_option = lambda name: state.get(name, 0)
+        e.lib = types.SimpleNamespace(vqs_set_option=lambda h, n, v: (state.__setitem__(n.decode(), int(v)), 0)[1],
+                                      vqs_last_error=lambda h: b"")
+        return e, state
+
+    # (a) the caller asked for the fp16 tower: refused, naming the tensors
+    e, _ = fake_engine(w, explicit={"vit_fp16"})
+    with pytest.raises(VqsError, match="vit_fp16 = 1 refused.*exceed the fp16 range"):
+        e._check_fp16_weights()
+    # (b) the option is on by default: switched off with one warning, the reference's bf16 runs -- no exception for a drop-in user
+    e, state = fake_engine(w)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        e._check_fp16_weights()
+    assert state["vit_fp16"] == 0 and "vit_fp16" in e.fp16_auto_off and any("vit_fp16" in str(r.message) for r in rec)
     with pytest.raises(VqsError, match="vit_fp16 = 1 refused"):
         e.set_option("vit_fp16", 1)
-    e.weights = make_seeded_weights(cfg, seed=3, device="cpu")
-    e.get_option = lambda name: 1
+    # (c) clean weights: nothing switched off, the range proof holds for every option and the projector needs no scale at this size
+    e, state = fake_engine(make_seeded_weights(cfg, seed=3, device="cpu"))
     e._check_fp16_weights()
-    assert e._fp16_unsafe == []
+    assert e._fp16_unsafe == [] and e.fp16_auto_off == {} and all(state[k] == 1 for k in FP16_OPTIONS)
+    assert all(e.range_proof[k]["holds"] for k in FP16_OPTIONS) and state.get("proj_fs_shift") == 0 and state.get("proj_mid_shift") == 0
+
+
+def test_fp16_range_proof_bounds_hold_and_switch_defaults_off():
+    """engine.fp16_range_proof (VERDICT r5 item 2): every bound follows from the weights alone and is >= what a pass produces at that site;
+    a heavy-tailed checkpoint (norm weights x 10^3 on the encoder stream) loses enc_fp16 / dec_fp16 BY DEFAULT with a warning and keeps them
+    when the caller insists; the projector's stream-fed sites get the shifts their bounds ask for."""
+    import types
+    import warnings
+    from oracle.clip_t5_engine_rounding import EngineRoundedOracle
+    from t2v_metrics_amd.engine import FP16_HEAD, FP16_OPTIONS, VqsEngine, fp16_range_proof, fp16_shift
+    from t2v_metrics_amd.weights import make_seeded_weights
+    cfg = get_config("small")
+    w = make_seeded_weights(cfg, seed=1, device="cpu")
+    proof = fp16_range_proof(cfg, w)
+    assert all(proof[k]["holds"] for k in FP16_OPTIONS)
+    # observed maxima of an unrounded pass against the proof's worst bounds, per option
+    g = torch.Generator().manual_seed(2)
+    pix = torch.randn(2, 3, cfg.vision.image, cfg.vision.image, generator=g).to(torch.bfloat16)
+    ids = torch.tensor([[11, 12, -200, 13, 14, 1], [21, -200, 22, 1, 0, 0]])
+    o = EngineRoundedOracle(cfg, w, round_fn=lambda x: x.float())
+    o.record = {}
+    o.forward(pix.float(), torch.tensor([0, 1]), ids, torch.tensor([[40, 1], [41, 1]]))
+    seen = {"vit_fp16": 0.0, "proj_fp16": 0.0, "enc_fp16": 0.0, "dec_fp16": 0.0}
+    for name, x in o.record.items():
+        parts = name.split(".")
+        m = float(x.abs().max())
+        if parts[0] == "vit" and parts[-1] in ("feat_in", "pmid"):
+            seen["proj_fp16"] = max(seen["proj_fp16"], m)
+        elif parts[0] == "vit" and parts[-1] in ("xn0", "q", "k", "v", "attn", "d_attn", "xn1", "mid", "d_mlp"):
+            seen["vit_fp16"] = max(seen["vit_fp16"], m)
+        elif parts[0] == "enc" and parts[-1] in ("xn0", "q", "k", "v", "attn", "xn1"):
+            seen["enc_fp16"] = max(seen["enc_fp16"], m)
+        elif (parts[0] == "enc" and parts[-1] == "out") or (parts[0] == "dec" and parts[-1] in ("cq", "cqk")):
+            seen["dec_fp16"] = max(seen["dec_fp16"], m)
+    for k in FP16_OPTIONS:
+        assert 0.0 < seen[k] <= proof[k]["worst_bound"] * (1 + 1e-5), (k, seen[k], proof[k])
+    assert fp16_shift(FP16_HEAD) == 0 and fp16_shift(FP16_HEAD * 2 + 1) == 2 and fp16_shift(float("nan")) is None and fp16_shift(float("inf")) is None
+    # heavy tail on the encoder stream
+    w2 = dict(w)
+    for k in ("encoder.block.1.layer.0.layer_norm.weight", "encoder.final_layer_norm.weight"):
+        w2[k] = w[k].clone()
+        w2[k][:3] *= 3.0e3
+    proof2 = fp16_range_proof(cfg, w2)
+    assert not proof2["enc_fp16"]["holds"] and not proof2["dec_fp16"]["holds"] and proof2["vit_fp16"]["holds"]
+
+    def fake_engine(explicit=()):
+        e = object.__new__(VqsEngine)
+        e.cfg, e.weights, e._h, e._options, e._explicit, e.fp16_auto_off = cfg, w2, None, {}, set(explicit), {}
+        state = {k: 1 for k in FP16_OPTIONS}
+        e.get_option = lambda name: state.get(name, 0)
+        e.lib = types.SimpleNamespace(vqs_set_option=lambda h, n, v: (state.__setitem__(n.decode(), int(v)), 0)[1], vqs_last_error=lambda h: b"")
+        return e, state
+
+    e, state = fake_engine()
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        e._check_fp16_weights()
+    assert state["enc_fp16"] == 0 and state["dec_fp16"] == 0 and state["vit_fp16"] == 1 and len(rec) == 2
+    assert "no proof" in e.fp16_auto_off["enc_fp16"]
+    e, state = fake_engine(explicit={"enc_fp16", "dec_fp16"})
+    e._check_fp16_weights()
+    assert state["enc_fp16"] == 1 and state["dec_fp16"] == 1 and e.fp16_auto_off == {}
 
 
 def test_gpu_numa_lookup_formats_the_pci_address_from_torchs_integer_fields(tmp_path, monkeypatch):

@@ -541,3 +541,42 @@ def test_decode_workspace_covers_the_partials_of_every_linear_at_other_model_siz
                 assert lib.vqs_qwen_decode_workspace_bytes(h, B) >= B * widest * 4, (hidden, mlp, B)
         finally:
             lib.vqs_qwen_destroy(h)
+
+
+def test_non_finite_logits_under_the_fp16_forms_fall_back_to_bf16_once(tmp_path):
+    """VERDICT r5 item 2, Qwen row: the wrapper never raises on finite inputs -- a non-finite logit while the engine's fp16 forms are active
+    switches option fp16 off (one warning) and the call is run again; scores equal the bf16 run's, later calls stay on bf16 without a warning."""
+    import warnings
+    import t2v_metrics_amd as t2v
+    cfg = get_qwen_config("qwen-tiny")
+    w = make_seeded_qwen_weights(cfg, seed=3, dtype=torch.bfloat16, lm_head_gain=4.0)
+
+    class Overflowing(OracleQwenEngine):
+        fp16_active = True
+        switched = []
+
+        def set_option(self, name, value):
+            self.switched.append((name, value))
+            if name == "fp16":
+                self.fp16_active = bool(value)
+
+        def score_logits(self, *a):
+            lg = super().score_logits(*a)
+            return lg * float("nan") if self.fp16_active else lg
+
+    rng = np.random.RandomState(5)
+    p = tmp_path / "v.npy"
+    np.save(p, rng.randint(0, 256, (2, 56, 56, 3), dtype=np.uint8))
+    tok = FakeQwenTokenizer(cfg.text.vocab)
+    eng = Overflowing(cfg, w)
+    m = t2v.VQAScore(model="qwen2.5-vl-7b", device="cpu", config=cfg, engine=eng, tokenizer=tok).model
+    ref = t2v.VQAScore(model="qwen2.5-vl-7b", device="cpu", config=cfg, engine=OracleQwenEngine(cfg, w), tokenizer=tok).model
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        s = m.forward([str(p)], ["a thing happens"])
+    assert torch.isfinite(s).all() and torch.equal(s, ref.forward([str(p)], ["a thing happens"]))
+    assert eng.switched == [("fp16", 0)] and sum("fp16" in str(r.message) for r in rec) == 1
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        m.forward([str(p)], ["a thing happens"])
+    assert not rec and eng.switched == [("fp16", 0)]

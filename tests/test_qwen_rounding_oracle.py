@@ -165,3 +165,109 @@ def test_decode_step_with_roundings_off_equals_a_forward_over_the_longer_sequenc
         want = ref.decode(r_state, forced[t])
         assert (lg - want).abs().max().item() <= 5e-5 * max(1.0, want.abs().max().item()), t
         length, pos = length + 1, pos + 1
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# Round 6: the range-safe fp16 forms.  The proof (csrc/qwen_decode.hip "Bind-time range proof", restated in torch by
+# oracle/qwen25vl_engine_rounding.py::range_bounds) bounds every 16-bit activation site from the weights alone; here it is held against
+# what the forward pass actually produces, on ordinary and on heavy-tailed weights.
+# ------------------------------------------------------------------------------------------------------------------------------
+def heavy_tailed(w, cfg, seed=3):
+    """A checkpoint with the outliers real language models carry, exaggerated: norm weights with channels x 10^3, a down_proj / proj row
+    x 10^3, large q|k|v biases, a few weight columns x 10^2 -- sites whose proven bound exceeds the fp16 range and need a scale."""
+    g = torch.Generator().manual_seed(seed)
+    w = {k: v.clone().float() for k, v in w.items()}
+
+    def bump(name, rows, factor, dim=0):
+        t = w[name]
+        idx = torch.randperm(t.shape[dim], generator=g)[:rows]
+        if dim == 0:
+            t[idx] *= factor
+        else:
+            t[:, idx] *= factor
+
+    v, t = cfg.vision, cfg.text
+    for i in range(v.depth):
+        p = f"model.visual.blocks.{i}."
+        bump(p + "norm1.weight", 3, 1e3)
+        bump(p + "mlp.down_proj.weight", 2, 1e3)
+        bump(p + "attn.qkv.bias", 4, 3e3)
+    bump("model.visual.merger.ln_q.weight", 2, 1e3)
+    for i in range(t.layers):
+        p = f"model.language_model.layers.{i}."
+        bump(p + "post_attention_layernorm.weight", 3, 1e3)
+        bump(p + "input_layernorm.weight", 2, 3e2)
+        bump(p + "mlp.down_proj.weight", 2, 1e3)
+        bump(p + "self_attn.o_proj.weight", 2, 1e2, dim=1)
+        bump(p + "self_attn.k_proj.bias", 4, 2e3)
+    return {k: x.to(torch.bfloat16) for k, x in w.items()}
+
+
+def _observed_site_maxima(cfg, w, grids, ids, mask, px):
+    """max |T| of every 16-bit site of a free-running pass with NO rounding (the tensors the proof bounds), by (stack, layer, kind)."""
+    from oracle.qwen25vl_engine_rounding import _SITE_OF_TAP
+    o = QwenEngineRounded(cfg, w, round_fn=_identity)
+    o.record = {}
+    with torch.no_grad():
+        _run(o, cfg, grids, ids, mask, px)
+    seen = {}
+    for name, x in o.record.items():
+        parts = name.split(".")
+        kind = _SITE_OF_TAP.get(parts[-1])
+        if kind is None:
+            continue
+        key = (parts[0], int(parts[1]) if len(parts) == 3 else -1, kind)
+        seen[key] = max(seen.get(key, 0.0), float(x.abs().max()))
+    return seen
+
+
+@pytest.mark.parametrize("heavy", [False, True])
+def test_range_proof_bounds_hold_on_real_activations(heavy):
+    """Every site's proven bound is >= what a pass produces there (and not absurdly loose on ordinary weights: the sum-fed sites are the
+    loose ones, which is why they sit behind scales)."""
+    from oracle.qwen25vl_engine_rounding import range_bounds, sigma_of_bound
+    cfg, w, grids, ids, mask, px = synthetic_case("qwen-small-c80", C80_GRIDS)
+    if heavy:
+        w = heavy_tailed(w, cfg)
+    bounds = range_bounds(cfg, w)
+    seen = _observed_site_maxima(cfg, w, grids, ids, mask, px)
+    assert set(seen) == set(bounds)
+    for key, b in bounds.items():
+        assert np.isfinite(b) and seen[key] <= b * (1 + 1e-5), (key, seen[key], b)
+        # under its scale the site's largest stored value stays below half of the fp16 maximum
+        assert seen[key] * sigma_of_bound(b) <= 32768.0
+    if heavy:
+        assert sum(sigma_of_bound(b) < 1.0 for b in bounds.values()) >= 8      # the outliers do push sites behind scales
+        assert max(seen.values()) > 65504.0                                     # ... and an unscaled fp16 tensor WOULD have overflowed
+
+
+@pytest.mark.parametrize("heavy", [False, True])
+def test_fp16_sites_oracle_is_closer_to_fp32_than_the_bf16_one(heavy):
+    """The free-running oracle with the fp16 forms' roundings (fp16 behind each site's scale) beside the bf16 one, on what the 16-bit prefill
+    hands to the head -- the merged vision tokens and the language model's final fp32 stream (the head itself is the precise tail's business):
+    finite everywhere and several times closer to the unrounded pass, with and without outliers."""
+    from oracle.qwen25vl_engine_rounding import range_bounds, sigma_of_bound
+    cfg, w, grids, ids, mask, px = synthetic_case("qwen-small-c80", C80_GRIDS)
+    if heavy:
+        w = heavy_tailed(w, cfg)
+    sites = {k: sigma_of_bound(b) for k, b in range_bounds(cfg, w).items()}
+
+    def run(**kw):
+        o = QwenEngineRounded(cfg, w, **kw)
+        o.record = {}
+        with torch.no_grad():
+            merged, _ = _run(o, cfg, grids, ids, mask, px)
+        return merged, o.record["txt.h_out"]
+
+    m0, h0 = run(round_fn=_identity)
+    m16, h16 = run(sites=sites)
+    mb, hb = run()
+    assert torch.isfinite(h16).all() and torch.isfinite(m16).all()
+    valid = mask.reshape(-1).bool()
+    rel = lambda a, b: float((a - b).norm() / b.norm())     # noqa: E731
+    e16, eb = rel(h16[valid], h0[valid]), rel(hb[valid], h0[valid])
+    # ordinary weights: 3 more significant bits everywhere.  Heavy-tailed ones: the worst-case bounds of the sum-fed sites sit 2^30 and more above
+    # what a pass produces, small values reach the fp16 subnormals -- still finite and still closer than bf16, by less
+    gain = 0.7 if heavy else 0.3
+    assert e16 < gain * eb, (e16, eb)
+    assert rel(m16, m0) < gain * rel(mb, m0), (rel(m16, m0), rel(mb, m0))

@@ -45,7 +45,7 @@ def _worker(rank, ws, port, tmp, out_path):
         cfg = get_config("tiny")
         eng = RecordingEngine(cfg)
         s = t2v.VQAScore(model="clip-flant5-xl", device="cpu", cache_dir=os.path.join(tmp, f"c{rank}"), config=cfg,
-                         engine=eng, tokenizer=FakeTokenizer(cfg.t5.vocab))
+                         engine=eng, tokenizer=FakeTokenizer(cfg.t5.vocab), distributed=True)
         imgs = sorted(os.path.join(tmp, f) for f in os.listdir(tmp) if f.endswith(".png"))
         dataset = [{"images": [imgs[k % len(imgs)]], "texts": [f"caption number {k}", f"other {k}"]} for k in range(7)]
         out = s.batch_forward(dataset, batch_size=3)
@@ -67,6 +67,20 @@ def _worker(rank, ws, port, tmp, out_path):
             np.save(out_path.replace(".npy", f"_{tag}_r{rank}.npy"), grid.numpy())
         whole = s(images=imgs, texts=["a", "b"], shard=False)     # opt-out: the whole grid on the calling rank, no collective
         assert whole.shape == (3, 2) and sum(c[0] for c in eng.encode_calls) >= 3
+        # the sharded calls are collectives -- ranks that disagree on the inputs get a ValueError (all of them), not a deadlock
+        # or rows mixed from different inputs
+        import pytest as _pytest
+        with _pytest.raises(ValueError, match="do not agree on the inputs"):
+            s(images=imgs[:2], texts=[f"rank {rank} asks something else"])
+        with _pytest.raises(ValueError, match="do not agree on the inputs"):
+            s.batch_forward(dataset[: 5 + rank], batch_size=3)
+        # ... and the DEFAULT scorer (distributed=False: the reference's semantics) never enters a collective: a rank-0-only call returns
+        plain = t2v.VQAScore(model="clip-flant5-xl", device="cpu", cache_dir=os.path.join(tmp, f"p{rank}"), config=cfg,
+                             engine=RecordingEngine(cfg), tokenizer=FakeTokenizer(cfg.t5.vocab))
+        if rank == 0:
+            assert plain(images=imgs[:2], texts=["only rank 0 calls"]).shape == (2, 1)
+            assert plain.batch_forward(dataset[:3], batch_size=2).shape == (3, 1, 2)
+        dist.barrier()
     finally:
         dist.destroy_process_group()
 

@@ -36,14 +36,17 @@ def main():
     ap.add_argument("--parity-samples", type=int, default=0, help="|delta log P(answer)| of the first N samples against the fp32 oracle evaluated "
                     "in torch fp32 on the device (oracle/qwen25vl_oracle.py; 8 samples: ~3 s)")
     ap.add_argument("--tail", type=int, default=1, help="option tail_precise (1 = the default: logits from the precise re-evaluation of the last position)")
+    ap.add_argument("--fp16", type=int, default=1, help="option fp16 (1 = the default: the range-safe fp16 forms; 0 = bf16 everywhere, the reference's dtype)")
     args = ap.parse_args()
     from t2v_metrics_amd.qwen.engine import QwenEngine
     cfg = get_qwen_config(args.model)
     dev = torch.device("cuda:0")
     t0 = time.perf_counter()
     w = make_seeded_qwen_weights(cfg, seed=0, device="cpu")
-    eng = QwenEngine(cfg, w, device=dev)
+    eng = QwenEngine(cfg, w, device=dev, fp16=bool(args.fp16))
     eng.set_option("tail_precise", args.tail)
+    fp16_on = eng.fp16_active
+    rb, rs = eng.range_report()
     t_init = time.perf_counter() - t0
     B = args.batch
     grid = (4, 24, 32)
@@ -81,7 +84,11 @@ def main():
     L = ids.shape[1]
     fl = flops_per_sample(cfg, n_patches, L)
     out = {"metric": "videos scored/sec, " + cfg.name, "value": B * args.steps / dt, "unit": "samples/s", "n_gpus": 1,
-           "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "dtype": "bf16",
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+           "dtype": ("fp16 behind bind-time power-of-two scales (every 16-bit activation of tower, merger and prefill; fp16 weight copies) + split-bf16 / fp32 "
+                     "precise tail; fp32 accumulation, statistics, softmax, residual stream" if fp16_on else "bf16 (16-bit activations and weights) + split-bf16 / fp32 precise tail"),
+           "fp16_forms": {"active": fp16_on, "sites": int(len(rs)), "sites_behind_a_scale": int((rs < 1.0).sum()) if len(rs) else 0,
+                          "largest_proven_bound": float(rb.max()) if len(rb) else None, "smallest_scale": float(rs.min()) if len(rs) else None},
            "data": "synthetic (seeded patches, token ids, weights)",
            "config": {"workload": f"{cfg.name}, batch={B} x 8-frame 336x448 video (3072 patches -> 768 vision tokens) + 40 text tokens", "L": L},
            "algorithmic_tflop_per_sample": fl / 1e12, "model_tflops": B * args.steps / dt * fl / 1e12,
@@ -89,7 +96,7 @@ def main():
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "tail_precise": args.tail}
     if n_gemm > 0 and gemm_ms > 0:
         ach = gemm_flops / (gemm_ms * 1e-3) / 1e12
-        out["roofline"] = {"kernel": "vqs::gemm_bf16_quad + gemm_bf16_persistent (every GEMM launch of the step; "
+        out["roofline"] = {"kernel": ("vqs::gemm_f16s_quad" if fp16_on else "vqs::gemm_bf16_quad") + " + gemm_bf16_persistent / stream forms (every GEMM launch of the step; "
                                      "gate|up-interleaved shapes as executed; language-model heads padded to 128 lanes)", "bound": "mfma", "achieved": ach, "peak": 2500.0,
                            "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": None, "launches": n_gemm,
                            "avg_launch_ms": gemm_ms / n_gemm, "algorithmic_bytes_per_launch": gemm_bytes / n_gemm,
@@ -157,8 +164,8 @@ def main():
                                          "top5_max": float(d_top.max()), "top5_mean": float(d_top.mean()),
                                          "logp_yes_range": [round(float(lr[:, yes_id].min()), 3), round(float(lr[:, yes_id].max()), 3)]}},
                          "status": ("within the 1e-3 bound" if float(d_ans.max()) <= BOUND else
-                                    "ABOVE the 1e-3 bound: this row's language model and tower hold every 16-bit tensor in bf16 (what the checkpoint was "
-                                    "trained in); the attribution of what is left is profiles/r5_qwen_error_attribution.md")}
+                                    "ABOVE the 1e-3 bound" + ("" if fp16_on else ": option fp16 is off -- the bf16 forms hold every 16-bit tensor at 8 significant bits "
+                                                              "(profiles/r5_qwen_error_attribution.md, r6_call1_*)"))}
     print(json.dumps(out), flush=True)
 
 

@@ -68,9 +68,13 @@ class Hook:
         self.how, self.last, self.lastrow_exact = how, last, lastrow_exact
 
     def fn(self, cls):
-        if cls in self.how:
-            return self.how[cls]
-        return self.how.get(cls.split(".")[0] + ".*")
+        # most specific first: "vis.norm.7" -> "vis.norm" -> "vis.*"
+        parts = cls.split(".")
+        for n in range(len(parts), 1, -1):
+            k = ".".join(parts[:n])
+            if k in self.how:
+                return self.how[k]
+        return self.how.get(parts[0] + ".*")
 
     def __call__(self, cls, x, pos_dim):
         f = self.fn(cls)
@@ -95,7 +99,7 @@ def main():
     ap.add_argument("--device", default="cuda:0")
     ap.add_argument("--engine", action="store_true", help="also score the samples with the HIP engine")
     ap.add_argument("--only", default="")
-    ap.add_argument("--set", default="r5", choices=["r5", "r6", "r6b"], help="r5: the round-5 table; r6: what-ifs for the >= 11-bit forms (all with the last row exact)")
+    ap.add_argument("--set", default="r5", choices=["r5", "r6", "r6b", "r6c"], help="r5: the round-5 table; r6: what-ifs for the >= 11-bit forms (all with the last row exact)")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     cfg = get_qwen_config(a.model)
@@ -195,6 +199,24 @@ def main():
             ("all fp16, deltas + acts behind a 2^-8 pre-scale", {**A16, "vis.delta": sc16(8), "txt.delta": sc16(8), "vis.act": sc16(8), "txt.act": sc16(8)}, True),
             ("all fp16, deltas split-bf16", {**A16, "vis.delta": split16, "txt.delta": split16}, True),
         ]
+    if a.set == "r6c":
+        # third pass: WHICH tower norm outputs carry the fp16 forms' residual (vis.norm exact halves the mean: r6_call2)
+        exact = lambda x: x  # noqa: E731
+        A16 = {"txt.*": fp16, "vis.*": fp16, "vis.in": bf16}
+        blocks = list(range(cfg.vision.depth))
+        full = list(cfg.vision.fullatt_blocks)
+        runs = [("all fp16", A16, True), ("all fp16, vis.norm exact", {**A16, "vis.norm": exact}, True),
+                ("all fp16, merger norm exact", {**A16, "vis.norm.merger": exact}, True),
+                ("all fp16, block norms exact (merger fp16)", {**A16, "vis.norm": exact, "vis.norm.merger": fp16}, True),
+                ("all fp16, merger norm + mid + merged exact", {**A16, "vis.norm.merger": exact, "vis.mid": exact, "vis.merged": exact}, True),
+                ("all fp16, norms of the full-attention blocks exact", {**A16, **{f"vis.norm.{i}": exact for i in full}}, True),
+                ("all fp16, norms of blocks 0-7 exact", {**A16, **{f"vis.norm.{i}": exact for i in blocks[:8]}}, True),
+                ("all fp16, norms of blocks 8-15 exact", {**A16, **{f"vis.norm.{i}": exact for i in blocks[8:16]}}, True),
+                ("all fp16, norms of blocks 16-23 exact", {**A16, **{f"vis.norm.{i}": exact for i in blocks[16:24]}}, True),
+                ("all fp16, norms of blocks 24-31 exact", {**A16, **{f"vis.norm.{i}": exact for i in blocks[24:]}}, True),
+                ("all fp16, merger norm split-bf16", {**A16, "vis.norm.merger": split16}, True),
+                ("all fp16, merger norm exact + both deltas exact", {**A16, "vis.norm.merger": exact, "vis.delta": exact, "txt.delta": exact}, True),
+                ]
     if a.only:
         keep = set(a.only.split(";"))
         runs = [r for r in runs if r[0] in keep]
