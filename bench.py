@@ -241,6 +241,34 @@ def gemm_kernels_hash(path=None, patterns=GEMM_KERNEL_PATTERNS):
     return h.hexdigest()[:16]
 
 
+# The execution options that decide which 16-bit type a stage computes in (include/vqs.h): option -> (stage, what is fp16 when it is on).  The
+# bench line's `dtype`, `config.workload` label and `config.arithmetic` are all built from THIS table and the engine's current option values.
+ARITHMETIC_OPTIONS = (
+    ("vit_fp16", "vision tower", "norm outputs, q / k / v, probabilities, attention output, sub-layer outputs, FFN product; every linear's weights"),
+    ("proj_fp16", "feature select + projector", "hidden_states[-2] cast and the projector's hidden tensor (behind the bind-time scales proj_fs_shift / proj_mid_shift); its weights"),
+    ("enc_fp16", "T5 encoder attention side", "both norm outputs, q / k / v, probabilities, attention output; q|k|v, o, wi weights (sub-layer outputs, FFN product, wo stay bf16)"),
+    ("dec_fp16", "decoder cross-attention score path", "encoder output, cross q, q.Wk, probabilities"),
+)
+
+
+def describe_arithmetic(eng):
+    """-> {"on": {option: bool}, "dtype", "label", "arithmetic"}: what the engine computes in, from its option values (engine doubles: all off)."""
+    get = (lambda k: int(eng.get_option(k))) if hasattr(eng, "get_option") else (lambda k: 0)
+    on = {k: bool(get(k)) for k, _, _ in ARITHMETIC_OPTIONS}
+    on["proj_fp16"] = on["proj_fp16"] and on["vit_fp16"]
+    on["dec_fp16"] = on["dec_fp16"] and bool(get("dec_precise")) and bool(get("cross_mode"))
+    enc_mode = get("enc_fp16")
+    fp16_stages = [stage + (" (attention sub-block only)" if k == "enc_fp16" and enc_mode == 2 else " (FFN input side only)" if k == "enc_fp16" and enc_mode == 3 else "")
+                   for k, stage, _ in ARITHMETIC_OPTIONS if on[k]]
+    label = "bf16 + fp16 (" + ", ".join(fp16_stages) + ")" if fp16_stages else "bf16"
+    dtype = ("bf16 (T5 GEMM operands elsewhere; decoder activations split-bf16 / fp32)" + (" + IEEE fp16 (" + "; ".join(fp16_stages) + ")" if fp16_stages else "")
+             + ": 16-bit MFMA operands at one rate, fp32 accumulation, residual streams, statistics and softmax")
+    arithmetic = "; ".join("%s: %s" % (stage, ("IEEE fp16 (option %s = %d): %s" % (k, get(k), what)) if on[k] else "bf16 (option %s = %d)" % (k, get(k)))
+                           for k, stage, what in ARITHMETIC_OPTIONS)
+    arithmetic += "; everything else: bf16 operands (the reference's dtype, mm_utils.py:228), decoder activations split-bf16 / fp32"
+    return {"on": on, "dtype": dtype, "label": label, "arithmetic": arithmetic}
+
+
 def traffic_stamp_matches(tj):
     """Is the PMC record `tj` (profiles/gemm_traffic_*.json) about the code this process runs?  The stamp of the GEMM kernels' machine
     code if the record has one, else the whole-library device-code stamp, else the source stamp of older records.  -> (bool, description)."""
@@ -551,6 +579,14 @@ def main():
         pr = [torch.empty_like(per_rank) for _ in range(world)]
         dist.all_gather(pr, per_rank)
         per_rank_list = [float(x.item()) for x in pr]
+    # per-rank footprint (weights + packed copies incl. the fp16 ones + workspaces + inputs): what N replicas ask of N GPUs' HBM
+    mem_local = float(torch.cuda.max_memory_allocated(device)) if device.type == "cuda" else 0.0
+    mem_t = torch.tensor([mem_local], device=coll_device, dtype=torch.float64)
+    mem_list = [mem_local]
+    if dist is not None:
+        mm = [torch.empty_like(mem_t) for _ in range(world)]
+        dist.all_gather(mm, mem_t)
+        mem_list = [float(x.item()) for x in mm]
     elapsed = float(t_el.item())
     total_pairs = n_total if ordered else pairs_local * world
     value = total_pairs / elapsed if elapsed > 0 and total_pairs > 0 else 0.0
@@ -572,9 +608,8 @@ def main():
         n_len += len(lens)
     flops_pair = flops_sum / max(n_len, 1)
     s_e = (jobs[0][2].shape[1] - 1 + cfg.vision.n_patches) if jobs else 0
-    tower_fp16 = bool(eng.get_option("vit_fp16")) if hasattr(eng, "get_option") else False
-    enc_fp16 = bool(eng.get_option("enc_fp16")) if hasattr(eng, "get_option") else False
-    dec_fp16 = bool(eng.get_option("dec_fp16") and eng.get_option("dec_precise") and eng.get_option("cross_mode")) if hasattr(eng, "get_option") else False
+    arith = describe_arithmetic(eng)
+    tower_fp16 = arith["on"].get("vit_fp16", False)
     out = {
         "metric": METRIC + cfg.name,
         "value": value,
@@ -586,26 +621,19 @@ def main():
         "higher_is_better": True,
         "scaling": info["scaling"],
         "vs_baseline": None,
-        "dtype": ("bf16 (T5 GEMM operands; decoder activations split-bf16 / fp32)"
-                  + (" + fp16 (vision tower + projector" + (", T5 encoder attention side" if enc_fp16 else "") + (", decoder cross-attention score path" if dec_fp16 else "") + ")"
-                     if tower_fp16 else (" + fp16 (T5 encoder attention side)" if enc_fp16 else ""))
-                  + ": 16-bit MFMA operands at one rate, fp32 accumulation"),
+        "dtype": arith["dtype"],
         "data": "synthetic (seeded 224x224 uint8 images resized to 336, seeded token ids, seeded random weights)"
                 if not double else "ENGINE DOUBLE -- harness self-test, not a measurement",
-        "config": {"workload": f"{cfg.name} bf16, {info['name']}",
+        "config": {"workload": f"{cfg.name} {arith['label']}, {info['name']}",
                    "pairs_per_gpu_per_step": B, "encoder_len": s_e, "decoder_len": T, "total_pairs": total_pairs,
                    "parallelism": f"replica x{world} (pairs sharded, RCCL all_gather of scores)",
-                   "arithmetic": ("T5 stacks: bf16 operands (the reference's dtype, mm_utils.py:228), decoder activations split-bf16 / fp32; vision tower + projector: "
-                                  + ("IEEE fp16 operands (option vit_fp16 = 1: 11 significant bits, same MFMA rate and bytes)" if tower_fp16 else "bf16 operands (option vit_fp16 = 0)")
-                                  + "; T5 encoder attention side (norm outputs, q / k / v, probabilities, attention output; q|k|v, o, wi weights): "
-                                  + ("IEEE fp16 (option enc_fp16 = 1), sub-layer outputs / FFN product / wo bf16" if enc_fp16 else "bf16 (option enc_fp16 = 0)")
-                                  + "; encoder output + decoder cross-attention score path (q, q.Wk, probabilities): "
-                                  + ("IEEE fp16 (option dec_fp16 = 1)" if dec_fp16 else "bf16 (option dec_fp16 = 0)")
-                                  + "; fp32 accumulation, residual streams, statistics, softmax"),
+                   "arithmetic": arith["arithmetic"],
+                   "fp16_options_switched_off_at_bind_time": getattr(eng, "fp16_auto_off", {}) or None,
                    **({"options": args.opt} if args.opt else {})},
         "ranks_seen": ranks_seen,
         "collective": (backend + (" (RCCL over xGMI)" if backend == "nccl" else "")) if dist is not None else None,
         "per_rank_pairs_per_s": per_rank_list,
+        "per_rank_peak_hbm_gb": [round(x / 1e9, 3) for x in mem_list],
         "step_ms_rank0": step_ms,
         "scores_checksum": float(final.double().sum().item()),
         # FLOPs of the REFERENCE algorithm (SURVEY.md §8d formula).  The engine's reassociated decoder

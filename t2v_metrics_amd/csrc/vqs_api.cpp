@@ -584,7 +584,7 @@ int vqs_set_option(vqs_handle* h, const char* name, int32_t value) {
     else if (n == "norm_defer" && (value == 0 || value == 1)) h->norm_defer = value;
     else if (n == "dec_precise" && (value == 0 || value == 1)) h->dec_precise = value;
     else if (n == "vit_fp16" && (value == 0 || value == 1)) h->vit_fp16 = value;
-    else if (n == "enc_fp16" && (value == 0 || value == 1)) h->enc_fp16 = value;
+    else if (n == "enc_fp16" && value >= 0 && value <= 3) h->enc_fp16 = value;      // 2 / 3: attention sub-block only / FFN input side only (A/B)
     else if (n == "proj_fp16" && (value == 0 || value == 1)) h->proj_fp16 = value;
     else if (n == "proj_fs_shift" && value >= 0 && value <= 60) h->proj_fs_shift = value;
     else if (n == "proj_mid_shift" && value >= 0 && value <= 60) h->proj_mid_shift = value;
@@ -961,7 +961,10 @@ static int encoder_pass(vqs_handle* h, const ScoreWs& w, const void* d_feats, co
     // option enc_fp16: the attention side on IEEE fp16 tensors (see the option's comment in vqs_handle): xn (both norms), q / k / v, P, the
     // attention output are fp16 and q|k|v, o, wi read their fp16 weight copies; o's and wo's results (the deltas) and the gated product stay
     // bf16, wo runs as before.  The final norm's output (the tensor the decoder reads) stays bf16.
+    // Values 2 / 3 (round 6, the per-call-site A/B of VERDICT r5 item 4): only the attention sub-block (norm0 output, q / k / v, P, attention
+    // output; q|k|v and o weights) / only the FFN's input side (norm1 output; wi weights) on fp16, the other on bf16.
     const bool e16 = h->enc_fp16 != 0;
+    const bool e16a = h->enc_fp16 == 1 || h->enc_fp16 == 2, e16f = h->enc_fp16 == 1 || h->enc_fp16 == 3;
     if (e16 && (h->gemm_variant != 3 || fused))
         return fail(h, VQS_ERR_STATE, "score: the fp16 encoder attention side (option enc_fp16, default 1) needs gemm_variant 3 and fused_norm 0 -- its linears "
                                       "exist in the quad form only; set enc_fp16=0 to A/B other GEMM forms");
@@ -981,25 +984,25 @@ static int encoder_pass(vqs_handle* h, const ScoreWs& w, const void* d_feats, co
         GETW(wo, p + "layer.1.DenseReluDense.wo.weight", (int64_t)D * F);
         if (!scaled) {
             if (pend_attn)
-                HIPCHK(h, vqs::launch_rmsnorm(w.hidden, pend_attn, ln0, w.xn, M, D, c.t5_ln_eps, st, pend, true, 0, e16), "enc rmsnorm0");
+                HIPCHK(h, vqs::launch_rmsnorm(w.hidden, pend_attn, ln0, w.xn, M, D, c.t5_ln_eps, st, pend, true, 0, e16a), "enc rmsnorm0");
             else
-                HIPCHK(h, vqs::launch_rmsnorm(w.hidden, pend, ln0, w.xn, M, D, c.t5_ln_eps, st, nullptr, true, 0, e16), "enc rmsnorm0");
+                HIPCHK(h, vqs::launch_rmsnorm(w.hidden, pend, ln0, w.xn, M, D, c.t5_ln_eps, st, nullptr, true, 0, e16a), "enc rmsnorm0");
             pend = nullptr;
             pend_attn = nullptr;
         }
         TAP("enc", i, "xn0", w.xn, (size_t)M * D);
         {
-            GemmCall g{w.xn, e16 ? h->enc_qkv16[i] : h->enc_qkv[i], nullptr};
+            GemmCall g{w.xn, e16a ? h->enc_qkv16[i] : h->enc_qkv[i], nullptr};
             g.M = M; g.N = 3 * I; g.K = D; g.lda = D; g.ldw = D; g.ldc = 0; g.epi = vqs::EPI_HEADS;
             g.S = S; g.H = H; g.inner = I;
             g.heads[0] = w.q; g.heads[1] = w.k; g.heads[2] = w.v;
-            g.f16 = e16 ? 1 : 0;
+            g.f16 = e16a ? 1 : 0;
             consume(g);
             RUN(run_gemm(h, g, st, "enc qkv"));
         }
         {
             vqs::AttnParams a{w.q, w.k, w.v, w.attn, w.enc_table, w.enc_len, B, H, S, 1.0f};
-            a.f16 = e16 ? 1 : 0;
+            a.f16 = e16a ? 1 : 0;
             TAP("enc", i, "q", w.q, (size_t)M * I);
             TAP("enc", i, "k", w.k, (size_t)M * I);
             TAP("enc", i, "v", w.v, (size_t)M * I);
@@ -1007,9 +1010,9 @@ static int encoder_pass(vqs_handle* h, const ScoreWs& w, const void* d_feats, co
             TAP("enc", i, "attn", w.attn, (size_t)M * I);
         }
         {
-            GemmCall g{w.attn, e16 ? h->enc_o16[i] : ow, w.delta};
+            GemmCall g{w.attn, e16a ? h->enc_o16[i] : ow, w.delta};
             g.M = M; g.N = D; g.K = I; g.lda = I; g.ldw = I; g.ldc = D; g.epi = vqs::EPI_BF16;
-            g.f16 = e16 ? 2 : 0;                 // fp16 operands, bf16 delta
+            g.f16 = e16a ? 2 : 0;                // fp16 operands, bf16 delta
             if (fused) produce(g, ln1);
             RUN(run_gemm(h, g, st, "enc o"));
             if (!fused) TAP("enc", i, "d_attn", w.delta, (size_t)M * D);
@@ -1018,15 +1021,15 @@ static int encoder_pass(vqs_handle* h, const ScoreWs& w, const void* d_feats, co
         if (fused) {
             scaled = true;
         } else {
-            HIPCHK(h, vqs::launch_rmsnorm(w.hidden, w.delta, ln1, w.xn, M, D, c.t5_ln_eps, st, nullptr, !defer, 0, e16), "enc rmsnorm1");
+            HIPCHK(h, vqs::launch_rmsnorm(w.hidden, w.delta, ln1, w.xn, M, D, c.t5_ln_eps, st, nullptr, !defer, 0, e16f), "enc rmsnorm1");
             if (defer) pend_attn = w.delta;
             scaled = false;
             TAP("enc", i, "xn1", w.xn, (size_t)M * D);
         }
         {
-            GemmCall g{w.xn, e16 ? h->enc_wi16[i] : h->enc_wi[i], w.ff};
+            GemmCall g{w.xn, e16f ? h->enc_wi16[i] : h->enc_wi[i], w.ff};
             g.M = M; g.N = 2 * F; g.K = D; g.lda = D; g.ldw = D; g.ldc = F; g.epi = vqs::EPI_GATED;
-            g.f16 = e16 ? 2 : 0;                 // fp16 operands, bf16 gated product
+            g.f16 = e16f ? 2 : 0;                // fp16 operands, bf16 gated product
             consume(g);
             RUN(run_gemm(h, g, st, "enc wi"));
             TAP("enc", i, "ff", w.ff, (size_t)M * F);
