@@ -12,7 +12,7 @@ for db in sorted(glob.glob(d + "/*_results.db")):
     except Exception as e:
         print(db, "ERR", e, cols); continue
     for kn, cn, gs, n, v, dur in rows:
-        if filt not in kn: continue
+        if not any(f in kn for f in filt.split("|")): continue          # "a|b": either substring
         key = (kn.split("(")[0][-40:], gs)
         res.setdefault(key, {})[cn] = (v, n, dur)
 for key, c in res.items():
