@@ -9,6 +9,6 @@ for CTRS in "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum"
   echo "pass $i ($CTRS) exit $?"
 done
 cd $REPO
-python tools/pmc_summary.py gpurun_out/$TAG/pmc_wo "gemm_bf16_quad|Cijk" > $OUT/summary.txt 2>&1; tail -40 $OUT/summary.txt | cut -c1-220
+python tools/pmc_summary.py gpurun_out/$TAG/pmc_wo "gemm_bf16_quad|Cijk" --each > $OUT/summary.txt 2>&1; grep -c . $OUT/summary.txt
 python tools/lab_gemm_wo.py T > $OUT/tile_order_sweep.jsonl 2>&1; tail -3 $OUT/tile_order_sweep.jsonl | cut -c1-1500
 rm -f $OUT/*.db

@@ -57,7 +57,8 @@ def main():
     g = torch.Generator(device="cuda").manual_seed(7)
     # ---- part C: same bits
     small = [(1000, 768, 512), (512, 512, 256), (2048, 1024, 1024), (256, 256, 320), (3000, 1280, 2048), (777, 520, 640), (4096, 2048, 256)]
-    for epi in [e for e in epis if e in (0, 1, 2, 5, 6)]:
+    only_timing = "T" in (sys.argv[3] if len(sys.argv) > 3 else "")       # ablation flavours produce garbage by design: timing only
+    for epi in [e for e in epis if e in (0, 1, 2, 5, 6) and not only_timing]:
         for M, N, K in small:
             for ft in (0, 1, 2):
                 if epi == 5 and ft == 1:

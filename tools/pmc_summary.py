@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-kernel PMC averages from rocprofv3 rocpd databases: pmc_summary.py <dir with pass*_results.db> [name filter]"""
-import glob, sqlite3, sys, collections
+import glob, os, sqlite3, sys, collections
 d = sys.argv[1]; filt = sys.argv[2] if len(sys.argv) > 2 else "gemm"
 res = collections.OrderedDict()
 for db in sorted(glob.glob(d + "/*_results.db")):
@@ -15,6 +15,17 @@ for db in sorted(glob.glob(d + "/*_results.db")):
         if not any(f in kn for f in filt.split("|")): continue          # "a|b": either substring
         key = (kn.split("(")[0][-40:], gs)
         res.setdefault(key, {})[cn] = (v, n, dur)
+if "--each" in sys.argv:      # every dispatch in launch order (shapes that share a kernel name and a grid: tools/lab_gemm_wo.py)
+    for db in sorted(glob.glob(d + "/*_results.db")):
+        con = sqlite3.connect(db)
+        try:
+            rows = con.execute("select dispatch_id, kernel_name, counter_name, value, end-start from counters_collection order by dispatch_id").fetchall()
+        except Exception as e:
+            print(db, "ERR", e); continue
+        print("==", os.path.basename(db) if "os" in dir() else db)
+        for did, kn, cn, v, dur in rows:
+            if any(f in kn for f in filt.split("|")):
+                print(f"  {did:5d} {kn.split('(')[0][-44:]:44s} {cn:30s} {v:16.1f} {dur/1e3:10.1f} us")
 for key, c in res.items():
     print(key)
     for cn, (v, n, dur) in c.items():
