@@ -120,7 +120,7 @@ def test_decode_attention_fits_its_largest_cache_in_lds():
     the launcher's Lmax limit (36 864 positions) must fit the CU together with them."""
     ks = _kernels("qwen_decode.hip")
     k = [v for n, v in ks.items() if "qwen_decode_attn_kernel" in n]
-    assert len(k) == 2                                  # <PRECISE = false> (the decode step) and <true> (the precise tail of the prefill)
+    assert len(k) == 3                                  # <PRECISE = false> (the decode step), <true> (the precise tail over bf16 K / V) and <true, KVH> (over the fp16 forms' K / V)
     for v in k:
         assert v["lds"] + 36864 * 4 <= LDS_PER_CU, v
     src = open(os.path.join(CSRC, "qwen_decode.hip")).read()
@@ -139,7 +139,7 @@ def test_attention_lds_budget_keeps_its_occupancy():
     ks = {n: k for n, k in ks.items() if n != "__asm__"}
     dma = {n: k for n, k in ks.items() if "attn_fwd_dma_kernel" in n}
     hd = {n: k for n, k in ks.items() if "attn_fwd_hd_kernel" in n}
-    assert len(dma) == 2 and len(hd) == 2
+    assert len(dma) == 2 and len(hd) == 4              # hd: <causal> x <bf16 | fp16 tensors (the Qwen row's range-safe fp16 forms)>
     for name, k in {**dma, **hd}.items():
         assert k["lds"] == 0, (name, "static LDS in an attention kernel changes its occupancy", k)
     # T5-XL / XXL encoder (S = 32-token prompt + 576 patches = 608, position bias): three workgroups per CU
