@@ -330,6 +330,7 @@ def run_also_leg(name):
         out["dlogp_hip_vs_fp32_truth"] = {g: {k: v.get(k) for k in ("max", "mean", "yes_token_max", "pairs_over_bound", "per_job")} for g, v in j["parity"]["gains"].items()}
         out["dlogp_pairs"] = j["parity"].get("pairs")
         out["dlogp_max"] = j["parity"]["gains"].get("1", {}).get("max")            # gain 1 = the model as seeded: the number the bound is about
+        out["dlogp_gain4_max"] = j["parity"]["gains"].get("4", {}).get("max")      # the peaked regime, held to DLOGP_BOUND_GAIN4
         out["dlogp_bound"] = j["parity"].get("bound")
         out["dlogp_encoder_len_range"] = j["parity"].get("encoder_len_range")
         if j["parity"].get("status"):
@@ -728,6 +729,8 @@ def main():
             out["cpu_baseline"]["dlogp_also_%s_max" % k] = leg["dlogp_max"]
             if k in ("xl", "genai1600", "qwen") and leg["dlogp_max"] > DLOGP_BOUND and not failed:
                 failed = "also.%s: max |dlogP| HIP vs fp32 truth %.3e > %.1e over %s pairs" % (k, leg["dlogp_max"], DLOGP_BOUND, leg.get("dlogp_pairs"))
+            if k in ("xl", "genai1600") and (leg.get("dlogp_gain4_max") or 0.0) > DLOGP_BOUND_GAIN4 and not failed:
+                failed = "also.%s: head gain 4: max |dlogP| HIP vs fp32 truth %.3e > %.1e over %s pairs" % (k, leg["dlogp_gain4_max"], DLOGP_BOUND_GAIN4, leg.get("dlogp_pairs"))
         out["cpu_baseline"]["dlogp"]["violation"] = out["cpu_baseline"]["dlogp_violation"] = failed
     if rank == 0 and world == 1 and args.parity_only > 0 and args.cpu_pairs <= 0 and not double and jobs:
         try:
@@ -764,6 +767,8 @@ def run_config0():
 
 
 PARITY_GAINS = (1.0, 4.0)          # lm_head x gain: 1 = the seeded head (log P ~ -10), 4 = the peaked-head regime (the head is linear: re-read)
+DLOGP_BOUND_GAIN4 = 4e-3           # the PEAKED regime SURVEY.md section 7 asks about (lm_head x 4: logits four times as steep, so a given operand error moves log P four
+                                   # times as far): gated at 4 x the bound -- the same relative accuracy of the logits.  Measured in round 6: 2.2e-3 over 256 pairs
 DLOGP_BOUND = 1e-3                 # north_star's tolerance itself: max |delta log P| of the HIP path vs fp32 truth over the parity sample at gain 1
                                    # (>= 64 pairs of the bench batch; every `also` leg carries its own table and is held to the same number).
                                    # History: round 3's bf16 decoder measured 2.6e-3 .. 9.0e-3 (gate 2.5e-2), round 4 6.98e-4 over 16 pairs (gate 2.1e-3)
@@ -900,6 +905,9 @@ def cpu_baseline(cfg, weights, job, n_pairs, lp_gpu, reps, with_emulation=False,
     worst = max(float(hip_pair.max()), parity["gains"]["1"]["max"] if parity else 0.0)
     if worst > DLOGP_BOUND:
         violation = "max |dlogP| HIP vs fp32 truth %.3e > %.1e" % (worst, DLOGP_BOUND)
+    worst4 = parity["gains"].get("4", {}).get("max") if parity else None
+    if violation is None and worst4 is not None and worst4 > DLOGP_BOUND_GAIN4:
+        violation = "head gain 4 (peaked regime): max |dlogP| HIP vs fp32 truth %.3e > %.1e" % (worst4, DLOGP_BOUND_GAIN4)
     if truth_check is not None and truth_check > 2e-4:
         violation = "device-evaluated fp32 truth differs from the host-evaluated oracle by %.3e" % truth_check
     if float(hip_pair.mean()) > 1.5 * float(ref_pair.mean()):
@@ -929,7 +937,7 @@ def cpu_baseline(cfg, weights, job, n_pairs, lp_gpu, reps, with_emulation=False,
                      "violation": violation, "warning": warning, "bound": DLOGP_BOUND},
            "max_abs_dlogp_hip_vs_oracle": worst,
            # the same facts as flat scalars (a driver that keeps only scalar fields of this object still carries the gate)
-           "dlogp_bound": DLOGP_BOUND, "dlogp_pairs": parity["pairs"] if parity else n_pairs,
+           "dlogp_bound": DLOGP_BOUND, "dlogp_bound_gain4": DLOGP_BOUND_GAIN4, "dlogp_gain4_max": worst4, "dlogp_pairs": parity["pairs"] if parity else n_pairs,
            "dlogp_max": worst, "dlogp_mean": parity["gains"]["1"]["mean"] if parity else float(hip_pair.mean()),
            "dlogp_yes_token_max": parity["gains"]["1"]["yes_token_max"] if parity else float(e_hip[:, 0].abs().max()),
            "dlogp_pairs_over_bound": parity["gains"]["1"]["pairs_over_bound"] if parity else int((hip_pair > DLOGP_BOUND).sum()),

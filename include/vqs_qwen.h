@@ -61,7 +61,7 @@ int vqs_qwen_profile_read(vqs_qwen_handle* h, double* gemm_ms, double* gemm_flop
  * is in vqs_qwen_last_error).  d_merged of vqs_qwen_encode_vision is an OPAQUE 16-bit tensor in the handle's operand format (bf16, or fp16 behind
  * the merger's scale): hand it to vqs_qwen_score / prefill of the same handle under the same option value.
  * "fp16" may be set to 0 / back to 1 on a bound handle (the bf16 forms are always resident); 1 needs the option on when the weights were bound. */
-int vqs_qwen_get_option(const vqs_qwen_handle* h, const char* name, int64_t* value);   /* "fp16" (what runs), "fp16_requested", "fp16_eligible", "tail_precise", "x_pitch" */
+int vqs_qwen_get_option(const vqs_qwen_handle* h, const char* name, int64_t* value);   /* "fp16" (what runs), "fp16_requested", "fp16_eligible", "tail_precise", "rope_fused" (what runs), "x_pitch" */
 /* The proof's result: per site the bound of |T| and sigma_T, in the order vision blocks (x0, qkv, dattn, x1, act, dmlp each), merger
  * (norm output, mlp.0 output, merged tokens), language-model layers (six each).  Returns the number of sites (0: no proof made); fills at most cap. */
 int vqs_qwen_range_report(const vqs_qwen_handle* h, float* bounds, float* sigmas, int32_t cap);
@@ -132,7 +132,11 @@ int vqs_qwen_debug_tap(vqs_qwen_handle* h, const char* name, void* d_dst, size_t
  * layer by layer beside the bf16 prefill with 16 significant bits (split-bf16 operands as stacked rows of the same GEMMs, fp32 partial sums,
  * fp32 q / softmax / sub-layer outputs; attention over the layer's bf16 K / V); 0 = the logits of the bf16 prefill's last row (rounds 2-4).
  * Same function either way; the attribution behind it and the measured effect: profiles/r5_qwen_error_attribution.md.  Any time after create.
- * "fp16": see "The range-safe fp16 forms" above. */
+ * "fp16": see "The range-safe fp16 forms" above.
+ * "rope_fused" 1 (default): under the fp16 forms, with 128-lane language-model heads, the rotary embedding of q / k is applied in
+ * the q|k|v GEMM's epilogue -- on the fp32 projection, before its ONE rounding -- and rope_qk_kernel is not launched for the language model (the taps
+ * txt.<i>.q0 / k0 then do not exist).  0: the separate kernel on the rounded projection (two roundings; rounds 2-5).  vqs_qwen_get_option reads what runs.
+ * The tower's 80-lane heads are not aligned to the epilogue's 128-column blocks and keep the separate kernel. */
 int vqs_qwen_debug_option(vqs_qwen_handle* h, const char* name, int64_t value);
 
 #ifdef __cplusplus

@@ -138,7 +138,8 @@ class QwenEngineRounded:
     """See the module docstring.  ``layers`` (stage-locked runs only): restrict the check to these block / layer indices
     (None = all) -- every launch is evaluated on the engine's own inputs, so a subset is a valid, cheaper check."""
 
-    def __init__(self, cfg, weights: Dict[str, torch.Tensor], round_fn=bf16_round, acc=torch.float64, sites: Optional[Dict[tuple, float]] = None):
+    def __init__(self, cfg, weights: Dict[str, torch.Tensor], round_fn=bf16_round, acc=torch.float64, sites: Optional[Dict[tuple, float]] = None,
+                 rope_fused: bool = False):
         """``sites`` (round 6): {(stack, layer, kind): sigma} of the engine's range-safe fp16 forms (``sites_from_report(cfg, sigmas)``) --
         the tower, merger and prefill then hold every 16-bit tensor as fp16(T * sigma) (computed here in TRUE units: fp16_round(x * sigma) /
         sigma), P as plain fp16, the language model's final norm output as bf16; taps are fp16 tensors divided by their sigma on read.
@@ -147,6 +148,9 @@ class QwenEngineRounded:
         self._raw = weights                      # converted on use: the 7B weight set is 33 GB in fp32
         self.r = round_fn
         self.sites = sites
+        # the engine's option of that name (what vqs_qwen_get_option "rope_fused" reads): the language model's q / k are rotated inside the q|k|v
+        # GEMM's epilogue on the UNROUNDED projection and rounded once; there are no q0 / k0 tensors
+        self.rope_fused = bool(rope_fused)
         self.acc = acc
         self.locked: Optional[Dict[str, torch.Tensor]] = None
         self.record: Optional[Dict[str, torch.Tensor]] = None
@@ -333,8 +337,12 @@ class QwenEngineRounded:
             h = self._stream(t + "h", h, d_attn, d_mlp, (M, TH), first=(i == 0))
             r_x0, r_qkv, r_da, r_x1, r_act, r_dm = (self._rf("txt", i, k) for k in SITE_KINDS)
             xn = self._emit(t + "xn0", self._norm(h, p + "input_layernorm.weight", t_.rms_eps, r_x0))
-            q0 = self._emit(t + "q0", self._heads(self._lin(xn, p + "self_attn.q_proj.weight", p + "self_attn.q_proj.bias"), B, L, H, hd, r_qkv))
-            k0 = self._emit(t + "k0", self._heads(self._lin(xn, p + "self_attn.k_proj.weight", p + "self_attn.k_proj.bias"), B, L, Hkv, hd, r_qkv))
+            if self.rope_fused:
+                q0 = self._heads(self._lin(xn, p + "self_attn.q_proj.weight", p + "self_attn.q_proj.bias"), B, L, H, hd, _identity)
+                k0 = self._heads(self._lin(xn, p + "self_attn.k_proj.weight", p + "self_attn.k_proj.bias"), B, L, Hkv, hd, _identity)
+            else:
+                q0 = self._emit(t + "q0", self._heads(self._lin(xn, p + "self_attn.q_proj.weight", p + "self_attn.q_proj.bias"), B, L, H, hd, r_qkv))
+                k0 = self._emit(t + "k0", self._heads(self._lin(xn, p + "self_attn.k_proj.weight", p + "self_attn.k_proj.bias"), B, L, Hkv, hd, r_qkv))
             val = self._emit(t + "v", self._heads(self._lin(xn, p + "self_attn.v_proj.weight", p + "self_attn.v_proj.bias"), B, L, Hkv, hd, r_qkv))
             q = self._emit(t + "q", self._rope(q0, lay["cos"], lay["sin"], hd, r_qkv))
             k = self._emit(t + "k", self._rope(k0, lay["cos"], lay["sin"], hd, r_qkv))
@@ -467,8 +475,8 @@ def vision_tap_shapes(cfg, lay, layers: Optional[Sequence[int]] = None):
     return out
 
 
-def text_tap_shapes(cfg, B: int, L: int, layers: Optional[Sequence[int]] = None):
-    """{tap name: (shape, dtype)} of one vqs_qwen_score call."""
+def text_tap_shapes(cfg, B: int, L: int, layers: Optional[Sequence[int]] = None, rope_fused: bool = False):
+    """{tap name: (shape, dtype)} of one vqs_qwen_score call (rope_fused: the engine rotates q / k in the q|k|v epilogue: no q0 / k0)."""
     t = cfg.text
     M, TH = B * L, t.hidden
     f32, b16 = torch.float32, torch.bfloat16
@@ -479,6 +487,8 @@ def text_tap_shapes(cfg, B: int, L: int, layers: Optional[Sequence[int]] = None)
                     f"txt.{i}.k": hk, f"txt.{i}.v": hk, f"txt.{i}.attn": ((M, t.heads * HDP), b16), f"txt.{i}.d_attn": ((M, TH), b16),
                     f"txt.{i}.xn1": ((M, TH), b16), f"txt.{i}.ff": ((M, _ffld(t.mlp)), b16), f"txt.{i}.d_mlp": ((M, TH), b16)})
     out.update({"txt.h_out": ((M, TH), f32), "txt.xnf": ((M, TH), b16)})
+    if rope_fused:
+        out = {n: v for n, v in out.items() if not (n.endswith(".q0") or n.endswith(".k0"))}
     return out
 
 

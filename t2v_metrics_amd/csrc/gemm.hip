@@ -1392,6 +1392,9 @@ static hipError_t launch_epi(const GemmParams& p, int variant, hipStream_t strea
 
 hipError_t launch_gemm(const GemmParams& p_in, int epilogue, int variant, hipStream_t stream) {
     GemmParams p = p_in;
+    if (p.rope_cos != nullptr || p.rope_sin != nullptr) {     // rotary embedding in the epilogue: scaled fp16 family, head-major scatter of whole 128-lane heads only
+        if (!(p.rope_cos && p.rope_sin) || p.f16 != 3 || epilogue != EPI_HEADS || p.hd != 128 || (p.hd_src != 0 && p.hd_src != 128)) return hipErrorInvalidValue;
+    }
     resolve_tile_order(p, PERSISTENT_WGS);
     if (variant == 1 || variant == 4 || variant == 6 || variant == 7 || variant == 8 || variant == 9) return hipErrorInvalidValue;     // lab-only forms (see the file header)
     // N: a lane stores 4 consecutive columns; fp32 output may have a ragged N if ldc leaves room for the overhang

@@ -74,6 +74,11 @@ struct GemmParams {
     // bound of |T|).  The epilogue computes t = acc * acc_scale + bias (acc_scale = 1 / sigma of the A operand: t is in true units), applies
     // the activation / gate to t and stores fp16(result * out_scale).  Both 1: bitwise gemm_f16_quad.  Appended: no other field moved.
     float acc_scale = 1.0f, out_scale = 1.0f;
+    // f16 == 3 with EPI_HEADS, 128-lane heads (round 6): the rotary embedding of q and k inside the epilogue -- per GEMM row
+    // (token) a table row of rope_half = 64 cos / sin values (fp32 [M, 64]); lane d < 64 of a q / k head pairs with lane d + 64 (both sit in the same
+    // MFMA lane, four blocks apart), rotated in fp32 on the UNROUNDED projection (one rounding instead of two), v heads untouched.  nullptr: no rotation.
+    const float* rope_cos = nullptr;
+    const float* rope_sin = nullptr;
 };
 
 // EPI_HEADS row split, shared by the kernel and its host-side test hook (vqs_debug_heads_rows): GEMM row -> (sample,

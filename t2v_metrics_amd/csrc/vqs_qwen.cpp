@@ -76,6 +76,10 @@ struct vqs_qwen_handle {
     // (after the rotary embedding), dattn = attention sub-layer output, x1 = norm2 output, act = gated product, dmlp = FFN sub-layer output.
     int fp16_req = 0, fp16_active = 0;
     bool fp16_eligible = false;
+    // with the fp16 forms and 128-lane language-model heads the rotary embedding of q / k runs inside the q|k|v GEMM's
+    // epilogue (on the unrounded projection: one rounding instead of two, one launch less per layer); 0 = the separate rope_qk_kernel (A/B, tests).
+    // The tower's 80-lane heads straddle the epilogue's 128-column blocks -- a rotation partner can sit in another wave's block -- and keep the kernel.
+    int rope_fused = 1;
     struct Site { float bound = 0.0f, sigma = 1.0f; };
     struct LayerSites { Site x0, qkv, dattn, x1, act, dmlp; };
     std::vector<LayerSites> v_sc, t_sc;
@@ -182,6 +186,7 @@ struct GCall {
     bf16_t* heads[3] = {nullptr, nullptr, nullptr};
     int f16 = 0;                         // 3: the scaled fp16 family (A, W, result fp16; acc_scale / out_scale)
     float acc_scale = 1.0f, out_scale = 1.0f;
+    const float *rope_cos = nullptr, *rope_sin = nullptr;     // f16 = 3, EPI_HEADS: rotary embedding in the epilogue (vqs_kernels.h)
 };
 
 int qgemm(vqs_qwen_handle* h, const GCall& g, hipStream_t st, const char* what) {
@@ -192,6 +197,7 @@ int qgemm(vqs_qwen_handle* h, const GCall& g, hipStream_t st, const char* what) 
     p.heads_out[0] = g.heads[0]; p.heads_out[1] = g.heads[1]; p.heads_out[2] = g.heads[2];
     p.hd = g.hd; p.inner_kv = g.inner_kv; p.Hkv = g.Hkv; p.gate_act = g.gate_act; p.hd_src = g.hd_src;
     p.f16 = g.f16; p.acc_scale = g.acc_scale; p.out_scale = g.out_scale;
+    p.rope_cos = g.rope_cos; p.rope_sin = g.rope_sin;
     if (h->prof) {
         while (h->ev.size() < h->ev_used + 2) {
             hipEvent_t e;
@@ -676,6 +682,11 @@ int vqs_qwen_debug_option(vqs_qwen_handle* h, const char* name, int64_t value) {
         h->fp16_active = 1;
         return VQS_OK;
     }
+    if (std::string(name) == "rope_fused") {     // see vqs_qwen_handle::rope_fused
+        if (value != 0 && value != 1) return qfail(h, VQS_ERR_INVALID, "rope_fused: 0 or 1");
+        h->rope_fused = (int)value;
+        return VQS_OK;
+    }
     if (std::string(name) == "tail_precise") {   // see vqs_qwen_handle::tail_precise
         if (value != 0 && value != 1) return qfail(h, VQS_ERR_INVALID, "tail_precise: 0 or 1");
         h->tail_precise = (int)value;
@@ -691,6 +702,7 @@ int vqs_qwen_get_option(const vqs_qwen_handle* h, const char* name, int64_t* val
     else if (n == "fp16_requested") *value = h->fp16_req;
     else if (n == "fp16_eligible") *value = h->fp16_eligible ? 1 : 0;
     else if (n == "tail_precise") *value = h->tail_precise;
+    else if (n == "rope_fused") *value = (h->fp16_active && h->rope_fused && h->t_hd == HDP) ? 1 : 0;      // what runs
     else if (n == "x_pitch") *value = h->t_xld;
     else return VQS_ERR_INVALID;
     return VQS_OK;
@@ -1053,6 +1065,7 @@ int score_impl(vqs_qwen_handle* h, const void* d_merged, const int32_t* d_input_
     if (tail)      // the tail's starting state: the embedding rows of the last positions (fp32 copies of bf16 values: exact)
         QHIP(h, vqs::launch_gather_rows_f32(w.hidden, d_last_row, w.t_h, B, TH, TH, st), "tail embed rows");
     const vqs_qwen_handle::LayerSites one{};
+    const bool rope_in_gemm = F && h->rope_fused != 0 && h->t_hd == HDP;      // K12: 128-lane heads, scaled fp16 family (gemm_quad.inc ROPE)
     auto norm = [&](const bf16_t* d, const bf16_t* g, const bf16_t* d2, bool store, float sd1, float sd2, float so, bool out_bf16, const char* what) -> int {
         if (F) QHIP(h, vqs::launch_rmsnorm_f16s(w.hidden, d, g, w.xn, M, TH, c.t_eps, st, d2, store, XLD, 1.0f / sd1, 1.0f / sd2, so, out_bf16), what);
         else QHIP(h, vqs::launch_rmsnorm(w.hidden, d, g, w.xn, M, TH, c.t_eps, st, d2, store, XLD), what);
@@ -1077,11 +1090,14 @@ int score_impl(vqs_qwen_handle* h, const void* d_merged, const int32_t* d_input_
             g.S = L; g.H = c.t_heads; g.inner = IQ; g.hd = HDP; g.inner_kv = IKV; g.Hkv = c.t_kv_heads;
             g.heads[0] = w.q; g.heads[1] = w.k; g.heads[2] = w.v;
             if (F) { g.f16 = 3; g.acc_scale = 1.0f / sc.x0.sigma; g.out_scale = sc.qkv.sigma; }
+            if (rope_in_gemm) { g.rope_cos = d_cos; g.rope_sin = d_sin; }
             QRUN(qgemm(h, g, st, "qkv"));
         }
-        QTAP("txt", i, "q0", w.q, (size_t)M * IQ);                // projection output, before the rotary embedding
-        QTAP("txt", i, "k0", w.k, (size_t)M * IKV);
-        QHIP(h, vqs::launch_rope_qk(w.q, w.k, d_cos, d_sin, B, c.t_heads, c.t_kv_heads, L, HDP, h->t_hd / 2, st, F), "rope");
+        if (!rope_in_gemm) {
+            QTAP("txt", i, "q0", w.q, (size_t)M * IQ);            // projection output, before the rotary embedding
+            QTAP("txt", i, "k0", w.k, (size_t)M * IKV);
+            QHIP(h, vqs::launch_rope_qk(w.q, w.k, d_cos, d_sin, B, c.t_heads, c.t_kv_heads, L, HDP, h->t_hd / 2, st, F), "rope");
+        }
         QTAP("txt", i, "q", w.q, (size_t)M * IQ);                 // after the rotary embedding, head-major [B, heads, L, 128]
         QTAP("txt", i, "k", w.k, (size_t)M * IKV);
         QTAP("txt", i, "v", w.v, (size_t)M * IKV);

@@ -144,7 +144,8 @@ def _stage_locked_impl(tag, cfg, w, eng, px, grid, ids, mask, grids, vis_layers=
     # are fp16 tensors (the language model's final norm output stays bf16), and no stored value may come near the fp16 maximum
     F16 = eng.fp16_active
     sites = sites_from_report(cfg, eng.range_report()[1]) if F16 else None
-    emu = QwenEngineRounded(cfg, {k: v.cpu() for k, v in w.items()}, acc=acc, sites=sites)
+    fused = eng.get_option("rope_fused") == 1       # K12: q / k rotated inside the q|k|v epilogue (fp16 forms, 128-lane heads): no q0 / k0 tensors
+    emu = QwenEngineRounded(cfg, {k: v.cpu() for k, v in w.items()}, acc=acc, sites=sites, rope_fused=fused)
     tap_dt = lambda n, dt: torch.float16 if (F16 and dt == torch.bfloat16 and not n.endswith("xnf")) else dt      # noqa: E731
     eng.set_option("tail_precise", 0)        # the launches checked here are the 16-bit prefill's, its last row's logits included; the tail has its own tests
     reports = {}
@@ -168,7 +169,7 @@ def _stage_locked_impl(tag, cfg, w, eng, px, grid, ids, mask, grids, vis_layers=
     if ids is not None:
         B, L = ids.shape
         lay = text_layout(cfg, ids, mask, grids)
-        shapes = text_tap_shapes(cfg, B, L, txt_layers)
+        shapes = text_tap_shapes(cfg, B, L, txt_layers, rope_fused=fused)
         bufs = {n: torch.zeros(sh, dtype=tap_dt(n, dt), device="cuda") for n, (sh, dt) in shapes.items()}
         for n, b in bufs.items():
             eng.tap(n, b)
@@ -337,7 +338,8 @@ def test_qwen_every_launch_stage_locked(golden_dir, name, fixture):
         off += n
     merged = torch.cat(merged)
     n_checked += len(_stage_locked(f"qwen/{fixture}/prefill", cfg, w, eng, None, None, ids, mask, grids, merged=merged))
-    assert n_checked == len(grids) * (12 * cfg.vision.depth + 6) + 12 * cfg.text.layers + 4
+    per_txt_layer = 10 if eng.get_option("rope_fused") == 1 else 12          # fused rotary embedding: no q0 / k0 launch outputs
+    assert n_checked == len(grids) * (12 * cfg.vision.depth + 6) + per_txt_layer * cfg.text.layers + 4
     eng.close()
 
 

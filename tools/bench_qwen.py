@@ -37,6 +37,7 @@ def main():
                     "in torch fp32 on the device (oracle/qwen25vl_oracle.py; 8 samples: ~3 s)")
     ap.add_argument("--tail", type=int, default=1, help="option tail_precise (1 = the default: logits from the precise re-evaluation of the last position)")
     ap.add_argument("--fp16", type=int, default=1, help="option fp16 (1 = the default: the range-safe fp16 forms; 0 = bf16 everywhere, the reference's dtype)")
+    ap.add_argument("--rope-fused", type=int, default=1, help="option rope_fused (1 = the default: q / k rotated inside the q|k|v epilogue under the fp16 forms)")
     args = ap.parse_args()
     from t2v_metrics_amd.qwen.engine import QwenEngine
     cfg = get_qwen_config(args.model)
@@ -45,6 +46,7 @@ def main():
     w = make_seeded_qwen_weights(cfg, seed=0, device="cpu")
     eng = QwenEngine(cfg, w, device=dev, fp16=bool(args.fp16))
     eng.set_option("tail_precise", args.tail)
+    eng.set_option("rope_fused", args.rope_fused)
     fp16_on = eng.fp16_active
     rb, rs = eng.range_report()
     t_init = time.perf_counter() - t0
@@ -87,6 +89,7 @@ def main():
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
            "dtype": ("fp16 behind bind-time power-of-two scales (every 16-bit activation of tower, merger and prefill; fp16 weight copies) + split-bf16 / fp32 "
                      "precise tail; fp32 accumulation, statistics, softmax, residual stream" if fp16_on else "bf16 (16-bit activations and weights) + split-bf16 / fp32 precise tail"),
+           "rope_in_qkv_epilogue": bool(eng.get_option("rope_fused")),
            "fp16_forms": {"active": fp16_on, "sites": int(len(rs)), "sites_behind_a_scale": int((rs < 1.0).sum()) if len(rs) else 0,
                           "largest_proven_bound": float(rb.max()) if len(rb) else None, "smallest_scale": float(rs.min()) if len(rs) else None},
            "data": "synthetic (seeded patches, token ids, weights)",
