@@ -927,17 +927,20 @@ hipError_t launch_reduce_slices_act(const float* part, int nslices, long long sl
 
 // Greedy step of vqs_generate: tokens[b, T-1] = argmax_v logits[(b*T + T-1), v] (lowest index on ties, as torch.argmax)
 __global__ void __launch_bounds__(256) argmax_append_kernel(const float* __restrict__ logits, int ldl, int V,
-                                                            int* __restrict__ tokens, int ld_tokens, int T, int dst_col) {
+                                                            int* __restrict__ tokens, int ld_tokens, int T, int dst_col, int* __restrict__ flags) {
     __shared__ float s_val[256];
     __shared__ int s_idx[256];
     const int b = blockIdx.x;
     const float* row = logits + ((size_t)b * T + (T - 1)) * ldl;
     float best = -3.0e38f;
     int bi = 0;
+    bool bad = false;                   // a NaN never wins a comparison: a non-finite row would otherwise emit token 0 silently
     for (int v = threadIdx.x; v < V; v += 256) {
         const float x = row[v];
+        bad |= !(fabsf(x) <= 3.0e38f);
         if (x > best) { best = x; bi = v; }
     }
+    if (flags != nullptr && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(flags, 2);      // status bit 1, as vqs_score's head sets it
     s_val[threadIdx.x] = best;
     s_idx[threadIdx.x] = bi;
     __syncthreads();
@@ -956,8 +959,8 @@ __global__ void __launch_bounds__(256) argmax_append_kernel(const float* __restr
 }
 
 hipError_t launch_argmax_append(const float* logits, int ldl, int V, int* tokens, int ld_tokens, int B, int T,
-                                hipStream_t s, int dst_col) {
-    hipLaunchKernelGGL(argmax_append_kernel, dim3(B), dim3(256), 0, s, logits, ldl, V, tokens, ld_tokens, T, dst_col < 0 ? T - 1 : dst_col);
+                                hipStream_t s, int dst_col, int* flags) {
+    hipLaunchKernelGGL(argmax_append_kernel, dim3(B), dim3(256), 0, s, logits, ldl, V, tokens, ld_tokens, T, dst_col < 0 ? T - 1 : dst_col, flags);
     return hipGetLastError();
 }
 

@@ -1438,7 +1438,7 @@ int vqs_generate(vqs_handle* h, const void* d_feats, const int32_t* d_img_index,
     for (int t = 0; t < max_new; ++t) {
         // one new decoder row per pair: position t, input = token t-1 (start token for t = 0), self-attention over the cache
         RUN(decoder_pass(h, w, d_tokens, max_new, B, L, 1, st, t, true));
-        HIPCHK(h, vqs::launch_argmax_append(w.logits, w.ldl, h->c.vocab, d_tokens, max_new, B, 1, st, t), "argmax");
+        HIPCHK(h, vqs::launch_argmax_append(w.logits, w.ldl, h->c.vocab, d_tokens, max_new, B, 1, st, t, w.flags), "argmax");   // + status bit 1 on a non-finite logit
     }
     return VQS_OK;
 }

@@ -298,7 +298,7 @@ hipError_t launch_sum_planes(const float* part, int nslices, long long slice_str
                              int ld_out, long long out_plane, hipStream_t s, const bf16_t* bias = nullptr, int silu = 0);
 // argmax of logits row (b*T + T-1) -> tokens[b, dst_col] (dst_col < 0: T-1)
 hipError_t launch_argmax_append(const float* logits, int ldl, int V, int* tokens, int ld_tokens, int B, int T,
-                                hipStream_t s, int dst_col = -1);
+                                hipStream_t s, int dst_col = -1, int* flags = nullptr);   // flags: bit 1 is set when a logit of a scanned row is not finite
 // bias tables from the [buckets,H] bf16 embedding and a host-computed bucket LUT
 hipError_t launch_relpos_table(const bf16_t* rel_weight, const int* bucket_lut_bidir, const int* bucket_lut_causal,
                                int lut_len, int buckets, float* enc_table, int H, int S, float* dec_table, int T,

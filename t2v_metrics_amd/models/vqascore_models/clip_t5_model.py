@@ -364,8 +364,9 @@ class CLIPT5Model(VQAScoreModel):
         return self.score_pairs(list(uniq.keys()), pair_image, questions, answers).reshape(M, N)
 
     @torch.no_grad()
-    def generate_ids(self, images: List[str], texts: List[str], max_new_tokens: int = 16) -> List[List[int]]:
-        """Greedy decoding of one answer per (image, prompt) pair -> token ids, each cut after its first EOS."""
+    def generate_ids(self, images: List[str], texts: List[str], max_new_tokens: int = 16, _retry: bool = False) -> List[List[int]]:
+        """Greedy decoding of one answer per (image, prompt) pair -> token ids, each cut after its first EOS.  (_retry: the one re-run on bf16
+        operands after an fp16 execution option produced a non-finite logit -- status bit 1 of the pass, as in score_pairs.)"""
         assert len(images) == len(texts), "Number of images and texts must match"
         if not 1 <= max_new_tokens <= 512:
             raise ValueError("max_new_tokens must be in [1, 512]")
@@ -381,6 +382,18 @@ class CLIPT5Model(VQAScoreModel):
         for s in range(0, len(texts), self.max_pairs):
             e = min(len(texts), s + self.max_pairs)
             toks = self.engine.generate(feats, idx[s:e], ids[s:e], max_new_tokens).cpu().tolist()
+            if hasattr(self.engine, "stage") and hasattr(self.engine, "get_option") and int(self.engine.stage("flags")[0]) & 2:
+                # a non-finite logit (argmax would have emitted token 0 silently): an fp16 tensor overflowed -- only possible with an option forced
+                # against the bind-time range proof.  Same answer as score_pairs: fp16 options off, one warning, run again.
+                on = [k for k in ("vit_fp16", "enc_fp16", "dec_fp16") if self.engine.get_option(k)]
+                if on and not _retry:
+                    import warnings
+                    warnings.warn(f"t2v_metrics_amd: non-finite logits while generating with the fp16 execution options {on}; they are now OFF for this "
+                                  "scorer (bf16 operands, the reference's dtype) and the call is run again.", RuntimeWarning, stacklevel=2)
+                    for k in on:
+                        self.engine.set_option(k, 0)
+                    return self.generate_ids(images, texts, max_new_tokens, _retry=True)
+                raise RuntimeError("non-finite logits while generating on bf16 operands: the checkpoint's weights or the inputs are not finite")
             for row in toks:
                 out.append(row[: row.index(eos) + 1] if eos in row else row)
         return out

@@ -441,6 +441,18 @@ def test_an_activation_beyond_the_fp16_range_never_reaches_a_drop_in_user(stack,
         warnings.simplefilter("always")
         s2 = model.score_pairs(["a", "b"], [0, 1], ["one caption", "another caption"], ["Yes", "Yes"])
     assert torch.equal(s1, s2) and not any("re-scored" in str(r.message) for r in rec2)      # warned once; the scorer stays on bf16 operands
+    # (d) generate(): a non-finite logit would make argmax emit token 0 silently -- vqs_generate raises status bit 1 and the wrapper runs
+    # the call again on bf16 operands; the tokens are the bf16 scorer's
+    gen_bf16 = model.generate_ids(["a", "b"], ["one caption", "another caption"], max_new_tokens=4)
+    forced = t2v.VQAScore(model="clip-flant5-xl", device="cuda:0", config=cfg, weights=w, tokenizer=FakeTokenizer(cfg.t5.vocab), image_workers="thread",
+                          engine_options={option: 1}).model
+    forced.load_images = lambda paths: pix[: len(paths)].cuda()
+    with warnings.catch_warnings(record=True) as rec3:
+        warnings.simplefilter("always")
+        gen = forced.generate_ids(["a", "b"], ["one caption", "another caption"], max_new_tokens=4)
+    if stack == "enc":          # the generation path runs the encoder (and its fp16 attention side); the tower's overflow reaches it through the features
+        assert any("generating" in str(r.message) for r in rec3)
+    assert gen == gen_bf16 and forced.engine.get_option(option) == (0 if any("generating" in str(r.message) for r in rec3) else 1)
 
 
 def test_fused_residual_rmsnorm_matches_separate_kernels():

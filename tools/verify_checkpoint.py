@@ -154,12 +154,16 @@ def main():
     ap.add_argument("--device", default=None, help="cuda:0 (default when a device is visible) | cpu (skips the HIP leg)")
     ap.add_argument("--skip-fp32", action="store_true", help="skip leg (i) (46 GB of fp32 weights at XXL, minutes per pair on the host)")
     ap.add_argument("--json", default="")
+    ap.add_argument("--allow-incomplete", action="store_true", help="exit 0 on an INCOMPLETE verdict (default: exit 2 -- the criterion was not evaluated)")
     a = ap.parse_args()
     rep = run(a.checkpoint, a.vision_tower, a.model, a.images, a.texts, a.device, a.skip_fp32)
     if a.json:
         with open(a.json, "w") as f:
             json.dump(rep, f, indent=1)
-    sys.exit(0 if rep["verdict"] in ("PASS",) or rep["verdict"].startswith("INCOMPLETE") else 1)
+    # PASS 0, FAIL 1, INCOMPLETE 2 (the 1e-3 criterion was not evaluated: no HIP device or --skip-fp32) unless --allow-incomplete
+    if rep["verdict"].startswith("INCOMPLETE"):
+        sys.exit(0 if getattr(a, "allow_incomplete", False) else 2)
+    sys.exit(0 if rep["verdict"] == "PASS" else 1)
 
 
 if __name__ == "__main__":
