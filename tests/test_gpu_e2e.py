@@ -165,7 +165,9 @@ def test_greedy_generate_matches_hf_fixture(golden_dir, fixture):
     top2 = logits.topk(2, -1).values
     decided = (top2[..., 0] - top2[..., 1]) >= GEN_MARGIN
     assert bool(((logits.argmax(-1) == toks) | ~decided).all()) and int(decided.sum()) >= toks.numel() // 2, (logits.argmax(-1).tolist(), toks.tolist())
-    _record(fixture, {"steps_compared": compared, "steps_total": int(ref.numel())})
+    #  what the margin filter lets through is recorded, so that a decoder regression cannot hide behind it unnoticed
+    _record(fixture, {"steps_compared": compared, "steps_total": int(ref.numel()), "teacher_forced_steps_decided": int(decided.sum()),
+                      "teacher_forced_steps_total": int(toks.numel()), "teacher_forced_argmax_equal_on_decided": int(((logits.argmax(-1) == toks) & decided).sum())})
     eng.close()
 
 
