@@ -44,11 +44,12 @@ def main():
         A = torch.randn(M, pk, device="cuda", generator=g).to(torch.float16)
         W = (torch.randn(N, pk, device="cuda", generator=g) * K ** -0.5).to(torch.float16)
         NO = N // 2 if epi == 5 else N
-        out = torch.empty(M, NO, dtype=torch.float16, device="cuda")
+        ft = 2 if epi == 5 else 1                              # the unscaled gated form writes bf16 (gemm_f16b_quad<5>: the T5 encoder's wi); same K loop as the product's gemm_f16s_quad<5>
+        out = torch.empty(M, NO, dtype=torch.bfloat16 if ft == 2 else torch.float16, device="cuda")
         flops = 2.0 * M * N * K
 
         def launch(n_lo, n_cnt, gm, ns, dst):
-            variant = 3 | (gm << 8) | (ns << 16) | (1 << 27)
+            variant = 3 | (gm << 8) | (ns << 16) | (ft << 27)
             o_off = (n_lo // 2 if epi == 5 else n_lo) * 2
             rc = lib.vqs_gemm(A.data_ptr(), W.data_ptr() + n_lo * pk * 2, dst.data_ptr() + o_off, None, None, M, n_cnt, K, pk, pk, NO, epi, 0, 0,
                               variant, engine._stream_ptr())
