@@ -39,6 +39,9 @@ static constexpr int BM = GEMM_BM, BN = GEMM_BN, BK = 64;
 static constexpr int STAGE_BYTES = 65536;   // A 32 KiB + W 32 KiB
 static constexpr int W_OFF = 32768;
 static constexpr int PERSISTENT_WGS = 256;   // one 128-KiB-LDS workgroup per CU
+#ifndef VQS_QUAD_WGS                         // lab (make variant VFLAGS=-DVQS_QUAD_WGS=1073741824): one workgroup per TILE, the vendor kernel's launch shape -- the
+#define VQS_QUAD_WGS PERSISTENT_WGS          // hardware dispatcher starts a CU's next tile when the previous one exits, so the chip's epilogues drift out of phase
+#endif
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
@@ -1335,7 +1338,7 @@ static hipError_t launch_epi(const GemmParams& p, int variant, hipStream_t strea
         // 8-wave forms' in the last ulp, so a weight must not change form with the batch size (a pair's bits are batch-invariant)
         if constexpr (EPI == EPI_BF16 || EPI == EPI_BF16_QGELU || EPI == EPI_BF16_GELU || EPI == EPI_GATED || EPI == EPI_HEADS) {
             const int nwg = tiles_m * tiles_n;
-            const dim3 qgrid(nwg < PERSISTENT_WGS ? nwg : PERSISTENT_WGS);
+            const dim3 qgrid(nwg < VQS_QUAD_WGS ? nwg : VQS_QUAD_WGS);
             if (p.f16 == 4) {
                 if constexpr (EPI == EPI_BF16) hipLaunchKernelGGL((gemm_f16bs_quad<EPI>), qgrid, dim3(256), 0, stream, p);
                 else return hipErrorInvalidValue;
