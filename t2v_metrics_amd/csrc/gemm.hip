@@ -1337,6 +1337,9 @@ static hipError_t launch_epi(const GemmParams& p, int variant, hipStream_t strea
         // quad form (gemm_quad.inc): every bf16-result launch of a call site, WHATEVER its M -- the form's k-order differs from the
         // 8-wave forms' in the last ulp, so a weight must not change form with the batch size (a pair's bits are batch-invariant)
         if constexpr (EPI == EPI_BF16 || EPI == EPI_BF16_QGELU || EPI == EPI_BF16_GELU || EPI == EPI_GATED || EPI == EPI_HEADS) {
+            // (Round 6 tried the few-row launches of a plain bias-free call site -- the T5 encoder's `o` / `wo` at M = 608: three 256-row tiles, 48 workgroups -- as row
+            // blocks of 128 in the stream form, all blocks on one weight: bitwise equal, but SLOWER (B = 1 pass 23.7 -> 25.9 ms, profiles/r6_call24_*): the stream
+            // form's 128 x 32 wave tiles are built to keep HBM busy, not the matrix pipe.  What those launches want is a narrow-tile instantiation of THIS kernel.)
             const int nwg = tiles_m * tiles_n;
             const dim3 qgrid(nwg < VQS_QUAD_WGS ? nwg : VQS_QUAD_WGS);
             if (p.f16 == 4) {

@@ -122,7 +122,10 @@ def test_gemm_quad_form_is_bitwise_the_other_forms(eng, M, N, K, epi, S, H):
 
 
 @pytest.mark.parametrize("Z,M,N,K,epi", [(256, 128, 608, 256, 3), (256, 128, 512, 640, 0), (300, 64, 96, 64, 3), (200, 100, 264, 192, 0),
-                                         (1, 128, 24576 + 132, 128, 3), (1500, 33, 40, 320, 0), (40, 128, 4096, 128, 0)])
+                                         (1, 128, 24576 + 132, 128, 3), (1500, 33, 40, 320, 0), (40, 128, 4096, 128, 0),
+                                         # round 6 (VQS_STREAM_MIN_ITEMS 192 -> 4): the decoder's linears at B = 1 .. 32 -- 4 K-slices of a 4 096-wide weight with 4 stacked
+                                         # rows (128 items), q|k|v (96 items), the cross scores of ONE pair (5 items), 128 stacked rows of B = 32
+                                         (4, 4, 4096, 1024, 3), (1, 4, 12288, 512, 3), (1, 128, 608, 1024, 3), (4, 128, 4096, 640, 3), (2, 16, 520, 192, 0)])
 def test_gemm_stream_form_is_bitwise_the_persistent_kernel(eng, Z, M, N, K, epi):
     """gemm_stream.inc (<= 128 rows per batch entry, W streamed through a five-stage LDS ring) against the 256-row persistent kernel
     on the same batched launch (option no_stream) and against one-tile-per-workgroup launches entry by entry: torch.equal -- same

@@ -274,11 +274,14 @@ def test_gemm_form_depends_on_the_weight_never_on_the_row_count(M, shape):
 
 
 def test_stream_form_takes_skinny_launches_with_many_columns_only():
-    """gemm_stream.inc: <= 128 rows per batch entry, >= 192 (entry, 128-column) items, plain fp32 / bf16 results that are not quad call
-    sites; everything else keeps its kernel."""
+    """gemm_stream.inc: <= 128 rows per batch entry, >= 4 (entry, 128-column) items (rounds 4-5: 192; round 6 lets the decoder's linears of a
+    B <= 32 call stream their weights too), plain fp32 / bf16 results that are not quad call sites; everything else keeps its kernel."""
     assert _form(128, 608, 4096, 3, batch=256) == 12          # cross scores at the bench batch: 5 x 256 items
     assert _form(128, 4096, 640, 0, batch=256) == 12          # cross P.E (bf16 result, batched: never a quad launch)
-    assert _form(128, 608, 4096, 3, batch=16) == 3            # 80 items: the persistent kernel
+    assert _form(128, 608, 4096, 3, batch=16) == 12           # 80 items (the persistent kernel until round 6)
+    assert _form(4, 4096, 1024, 3, batch=4) == 12 and _form(4, 12288, 4096, 3) == 12      # a decoder linear of ONE pair: 4 K-slices x 32 blocks / 96 blocks
+    assert _form(128, 608, 4096, 3, batch=1) == 12            # one pair's cross scores: 5 items
+    assert _form(64, 384, 4096, 3) == 3                       # 3 items: not worth a launch shape of its own
     assert _form(129, 608, 4096, 3, batch=256) == 3           # more rows than the form holds
     assert _form(64, 152064, 3584, 3) == 12                   # a decode step's lm_head
     assert _form(64, 32768, 4096, 0) == 10                    # a bf16-result nn.Linear is a quad call site for EVERY M

@@ -7,6 +7,7 @@ bound.  The library never allocates, never synchronises and reads nothing from t
 vqs_score, so the whole pass is capturable with hipStreamBeginCapture -- here through torch.cuda.CUDAGraph (which is a
 hipGraph on ROCm).  Prints one JSON line per batch size."""
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -39,6 +40,7 @@ def main():
     ap.add_argument("--model", default="clip-flant5-xxl")
     ap.add_argument("--batches", default="1,4,16,64")
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--no-graph", action="store_true", help="eager timing and a digest of the scores only (A/B of library builds: VQS_LIB_PATH)")
     args = ap.parse_args()
     cfg = get_config(args.model)
     dev = torch.device("cuda:0")
@@ -55,6 +57,11 @@ def main():
         eager = timed(step, args.reps)
         lp_e, sc_e = step()
         lp_e, sc_e = lp_e.clone(), sc_e.clone()
+        digest = hashlib.sha256(lp_e.cpu().numpy().tobytes() + sc_e.cpu().numpy().tobytes()).hexdigest()[:16]
+        if args.no_graph:
+            print(json.dumps({"model": cfg.name, "batch": B, "eager_ms": 1e3 * eager, "pairs_per_s_eager": B / eager, "scores_sha256_16": digest,
+                              "library": os.environ.get("VQS_LIB_PATH", "product")}), flush=True)
+            continue
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):               # warm-up on the capture stream (workspaces are sized here)
@@ -69,7 +76,7 @@ def main():
         graph = timed(g.replay, args.reps)
         print(json.dumps({"model": cfg.name, "batch": B, "eager_ms": 1e3 * eager, "hip_graph_ms": 1e3 * graph,
                           "speedup": eager / graph, "pairs_per_s_eager": B / eager, "pairs_per_s_graph": B / graph,
-                          "bitwise_equal": same}), flush=True)
+                          "bitwise_equal": same, "scores_sha256_16": digest}), flush=True)
         del g
 
 
