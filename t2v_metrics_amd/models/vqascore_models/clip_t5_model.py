@@ -202,6 +202,11 @@ class CLIPT5Model(VQAScoreModel):
         S = self.cfg.vision.image
         k, out = self._staging_buffer(len(image))
         arr = out.numpy()
+        if len(image) == 1:
+            # one image (the reference's per-pair loops, score.py:143-153): decode on the calling thread -- handing a single file to a worker process and
+            # waiting for its reply costs more than it saves (a 512 x 512 PNG: 7-11 ms through the pool, tools/bench_call_latency.py); same bytes either way
+            arr[0] = self._preprocess_one_u8(image[0])
+            return k, out
         if self._use_process_pool():
             if self._proc_pool is None:
                 from ...imgpool import ImageProcessPool

@@ -98,3 +98,23 @@ def test_model_uses_worker_processes_by_default_and_threads_for_a_custom_loader(
     assert torch.equal(out["process"], out["thread"])
     S = cfg.vision.image
     assert out["process"].shape == (6, S, S, 3) and torch.equal(out["process"][0], torch.from_numpy(clip_preprocess_u8(image_loader(paths[0]), S, True)))
+
+
+def test_a_single_image_is_decoded_on_the_calling_thread_with_the_pools_bytes(tmp_path):
+    """The reference's per-pair loops (score.py:143-153) hand the model one image per call: no worker process is started or waited for, and the staged
+    bytes are the pooled path's."""
+    import t2v_metrics_amd as t2v
+    from t2v_metrics_amd.config import get_config
+    from tests.test_host_api import RecordingEngine as FakeEngine, FakeTokenizer
+    cfg = get_config("tiny")
+    paths = _files(tmp_path, 3)
+    m = t2v.VQAScore(model="clip-flant5-xl", device="cpu", config=cfg, engine=FakeEngine(cfg), tokenizer=FakeTokenizer(cfg.t5.vocab), num_workers=2).model
+    _, one = m._load_images_host_u8(paths[1:2])
+    one = one.clone()
+    assert m._proc_pool is None, "one image must not start the worker processes"
+    _, three = m._load_images_host_u8(paths)
+    assert m._proc_pool is not None and torch.equal(three[1], one[0])
+    with pytest.raises(FileNotFoundError):
+        m._load_images_host_u8([str(tmp_path / "missing.png")])
+    m._proc_pool.close()
+
