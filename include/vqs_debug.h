@@ -30,8 +30,9 @@ int vqs_debug_tile_order(int32_t M, int32_t N, int32_t K, int32_t batch, int32_t
 /* Host-side test hook, no device access: the kernel family a vqs_gemm launch of this shape resolves to, by the launcher's own
  * function (gemm.hip gemm_form): 10 = the quad form (four waves, 16x16x32 MFMAs; operand offsets relative to the output tile, no
  * size limit), 3 = an 8-wave persistent kernel (32-bit byte offsets into a batch entry's operands), 12 = the stream form (<= 128 rows
- * per batch entry, W streamed from HBM; bitwise the results of 3: one family), 0 = one tile per workgroup
- * (64-bit pointers), -1 = not launchable.  Two properties the tests pin: the form of a bf16-result launch is a function of the
+ * per batch entry, W streamed from HBM; bitwise the results of 3: one family), 13 = a quad call site's few-row launch in the slim form
+ * (gemm_slim.inc, round 6: 128 x 128 tiles for launches whose 256 x 256 tiles leave most CUs idle; bitwise the results of 10: one family),
+ * 0 = one tile per workgroup (64-bit pointers), -1 = not launchable.  Two properties the tests pin: the form of a bf16-result launch is a function of the
  * epilogue and the WEIGHT's shape only, never of M (a pair's bits must not depend on its batch), and an operand of 4 GiB or more
  * per batch entry never reaches a 32-bit kernel (it falls back to family 0 where that computes the same function, else -1). */
 int vqs_debug_gemm_form(int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t epilogue, int32_t batch, int32_t variant,

@@ -31,6 +31,7 @@ namespace vqs {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
@@ -1007,6 +1008,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_persistent(const GemmParams p) 
 
 #include "gemm_quad.inc"
 #include "gemm_stream.inc"
+#include "gemm_slim.inc"
 
 // =====================================================================================================
 // Persistent PING-PONG variant (VAR 5).  Same tile, LDS image, tile map and staged epilogue as the persistent kernel
@@ -1294,6 +1296,10 @@ int gemm_form(const GemmParams& p, int epilogue, int variant) {
     return plain_v0 ? 0 : -1;
 }
 
+bool gemm_takes_slim(const GemmParams& p, int epilogue, int variant) {
+    return variant == 3 && !p.no_stream && gemm_form(p, epilogue, variant) == 10 && slim_eligible(p, epilogue);
+}
+
 template <int EPI>
 static hipError_t launch_epi(const GemmParams& p, int variant, hipStream_t stream) {   // NOLINT(variant is resolved below)
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
@@ -1337,9 +1343,20 @@ static hipError_t launch_epi(const GemmParams& p, int variant, hipStream_t strea
         // quad form (gemm_quad.inc): every bf16-result launch of a call site, WHATEVER its M -- the form's k-order differs from the
         // 8-wave forms' in the last ulp, so a weight must not change form with the batch size (a pair's bits are batch-invariant)
         if constexpr (EPI == EPI_BF16 || EPI == EPI_BF16_QGELU || EPI == EPI_BF16_GELU || EPI == EPI_GATED || EPI == EPI_HEADS) {
-            // (Round 6 tried the few-row launches of a plain bias-free call site -- the T5 encoder's `o` / `wo` at M = 608: three 256-row tiles, 48 workgroups -- as row
-            // blocks of 128 in the stream form, all blocks on one weight: bitwise equal, but SLOWER (B = 1 pass 23.7 -> 25.9 ms, profiles/r6_call24_*): the stream
-            // form's 128 x 32 wave tiles are built to keep HBM busy, not the matrix pipe.  What those launches want is a narrow-tile instantiation of THIS kernel.)
+            // Few-row launches (a caller that scores one or two pairs): the slim form, gemm_slim.inc -- same bits, so the switch is a function of the launch's shape
+            // that never shows in a score.  variant 10 = the quad kernel whatever the shape (tests, A/B).  (As 128-row blocks of the STREAM form the same launches
+            // were slower than the quad kernel: its 128 x 32 wave tiles are built to keep HBM busy, not the matrix pipe -- profiles/r6_call24_*.)
+            if (gemm_takes_slim(p, EPI, variant)) {
+                const dim3 sgrid(((p.M + 127) / 128) * (p.N / 128));
+                if (p.f16 == 2) {
+                    if constexpr (EPI == EPI_BF16 || EPI == EPI_GATED) hipLaunchKernelGGL((gemm_slim<EPI, 2>), sgrid, dim3(256), 0, stream, p);
+                } else if (p.f16 == 1) {
+                    if constexpr (EPI != EPI_GATED) hipLaunchKernelGGL((gemm_slim<EPI, 1>), sgrid, dim3(256), 0, stream, p);
+                } else {
+                    hipLaunchKernelGGL((gemm_slim<EPI, 0>), sgrid, dim3(256), 0, stream, p);
+                }
+                return hipGetLastError();
+            }
             const int nwg = tiles_m * tiles_n;
             const dim3 qgrid(nwg < VQS_QUAD_WGS ? nwg : VQS_QUAD_WGS);
             if (p.f16 == 4) {

@@ -466,7 +466,8 @@ int vqs_debug_gemm_form(int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ld
     vqs::GemmParams p{};
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = N; p.batch = batch > 0 ? batch : 1;
     p.S = S; p.inner = inner; p.inner_kv = inner_kv;
-    return vqs::gemm_form(p, epilogue, variant & 0xff);
+    const int form = vqs::gemm_form(p, epilogue, variant & 0xff);
+    return (form == 10 && vqs::gemm_takes_slim(p, epilogue, variant & 0xff)) ? 13 : form;      // 13: a quad call site's few-row launch (gemm_slim.inc, same bits)
 }
 
 int vqs_debug_gemm_batched(const void* A, const void* W, void* C, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t ldc,

@@ -56,7 +56,7 @@ struct GemmParams {
     // lo = bf16(acc - hi) at C + split_off (elements; 0 = off).  hi + lo carries 16 significant bits of the fp32 accumulator;
     // the consumer stacks the two planes as rows of one GEMM and adds the two fp32 results (the precise decoder, vqs_api.cpp).
     long long split_off = 0;
-    int no_stream = 0;       // 1: never the stream form (gemm_stream.inc) -- A/B switch; results are bitwise the same either way
+    int no_stream = 0;       // 1: never the stream form (gemm_stream.inc) nor the slim form (gemm_slim.inc) -- A/B switch; results are bitwise the same either way
     int l2_touch = 0;        // lock-step persistent kernel: L2 prefetch of the A panel two K-tiles ahead; 0 = by shape (gemm.hip), 1 on, 2 off (a hint)
     int nt_store = 0;        // persistent kernels: result rows leave with the non-temporal hint (same bytes; a cache-policy hint)
     // EPI_RESID_RMS (producer side of the fused residual + RMSNorm)
@@ -179,6 +179,7 @@ inline void resolve_tile_order(GemmParams& p, int persistent_wgs) {
 
 // variant 0 = direct-to-LDS (global_load_lds) staging; variant 1 = register-staged (debug / A-B)
 int gemm_form(const GemmParams& p, int epilogue, int variant);   // kernel family a launch resolves to (gemm.hip), host arithmetic
+bool gemm_takes_slim(const GemmParams& p, int epilogue, int variant);   // a quad call site (form 10) whose launch runs the few-row slim form (gemm_slim.inc: same bits)
 hipError_t launch_gemm(const GemmParams& p, int epilogue, int variant, hipStream_t stream);
 
 // ---------------------------------------------------------------- attention (attn.hip)

@@ -34,10 +34,13 @@ int main() {
     assert(vqs_debug_tap(h, "enc.3.xn0", &dummy, 4) == 0 && vqs_debug_tap(h, "enc.3.xn0", nullptr, 0) == 0 && vqs_debug_tap(h, nullptr, nullptr, 0) == 0);
     assert(vqs_debug_tap_window(h, 3, 2) == 0 && vqs_debug_tap_window(h, 0, 0) == 0 && vqs_debug_tap_window(h, -1, 2) != 0);
     // GEMM form resolution (host arithmetic): the quad form for bf16 results whatever M, the 32-bit kernels refuse >= 4 GiB operands
-    assert(vqs_debug_gemm_form(155648, 20480, 4096, 4096, 4096, 5, 1, 3, 0, 0, 0) == 10 && vqs_debug_gemm_form(2, 20480, 4096, 4096, 4096, 5, 1, 3, 0, 0, 0) == 10);
-    // round 4: the stream form's rule (<= 128 rows per entry, >= 192 items, not a quad call site) and the batched debug launch's argument checks
-    assert(vqs_debug_gemm_form(128, 608, 4096, 4096, 4096, 3, 256, 3, 0, 0, 0) == 12 && vqs_debug_gemm_form(128, 608, 4096, 4096, 4096, 3, 16, 3, 0, 0, 0) == 3);
-    assert(vqs_debug_gemm_form(64, 32768, 4096, 4096, 4096, 0, 1, 3, 0, 0, 0) == 10);
+    // (13 = the quad family's few-row launch shape, gemm_slim.inc, round 6: same bits; variant 10 = the quad kernel whatever the shape)
+    assert(vqs_debug_gemm_form(155648, 20480, 4096, 4096, 4096, 5, 1, 3, 0, 0, 0) == 10 && vqs_debug_gemm_form(2, 20480, 4096, 4096, 4096, 5, 1, 3, 0, 0, 0) == 13 &&
+           vqs_debug_gemm_form(2, 20480, 4096, 4096, 4096, 5, 1, 10, 0, 0, 0) == 10);
+    // round 4: the stream form's rule (<= 128 rows per entry, >= 4 items since round 6 (192 before), not a quad call site) and the batched debug launch's argument checks
+    assert(vqs_debug_gemm_form(128, 608, 4096, 4096, 4096, 3, 256, 3, 0, 0, 0) == 12 && vqs_debug_gemm_form(128, 608, 4096, 4096, 4096, 3, 16, 3, 0, 0, 0) == 12 &&
+           vqs_debug_gemm_form(64, 384, 4096, 4096, 4096, 3, 1, 3, 0, 0, 0) == 3);
+    assert(vqs_debug_gemm_form(64, 32768, 4096, 4096, 4096, 0, 1, 3, 0, 0, 0) == 13 && vqs_debug_gemm_form(64, 32768, 4096, 4096, 4096, 0, 1, 10, 0, 0, 0) == 10);
     assert(vqs_debug_gemm_batched(nullptr, nullptr, nullptr, 128, 608, 4096, 4096, 4096, 640, 3, 256, 0, 0, 0, 0, 0, 3, nullptr) == VQS_ERR_INVALID);
     {
         int dummy2 = 0;

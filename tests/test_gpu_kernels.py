@@ -121,6 +121,49 @@ def test_gemm_quad_form_is_bitwise_the_other_forms(eng, M, N, K, epi, S, H):
         assert_close(out, full, 2e-2, 1e-2, "quad form vs fp32")
 
 
+@pytest.mark.parametrize("M,N,K,epi,S,H,ftype,with_bias", [
+    (608, 4096, 4096, 0, 0, 0, 2, False),      # T5-XXL encoder o of one pair (fp16 operands, bf16 delta)
+    (608, 4096, 10240, 0, 0, 0, 0, False),     # ... wo (bf16 operands, K = 10 240)
+    (1216, 2048, 1024, 0, 0, 0, 0, True),      # two pairs at T5-XL's width; plain + bias
+    (608, 3 * 1024, 1024, 6, 608, 16, 1, False),   # q|k|v of one pair: head-major scatter, fp16 in / out
+    (2 * 608 - 600, 3 * 1024, 320, 6, 8, 16, 0, True),   # S = 8: sample boundaries inside a row block; ragged M; bf16
+    (577, 3 * 1024, 1024, 6, 577, 16, 1, True),    # the tower's q|k|v of one image (odd sequence length, bias)
+    (577, 4096, 1024, 1, 0, 0, 1, True),       # the tower's fc1: quick-GELU + bias, fp16
+    (577, 1024, 4096, 0, 0, 0, 1, True),       # ... fc2
+    (576, 4096, 1024, 2, 0, 0, 1, True),       # the projector's first GEMM: erf-GELU + bias
+    (300, 2048, 512, 5, 0, 0, 2, False),       # gated gelu_new over interleaved wi_0 | wi_1 blocks, fp16 operands -> bf16
+    (130, 1024, 256, 5, 0, 0, 0, False),       # ... bf16 operands, one full and one 2-row block
+    (1, 1024, 256, 0, 0, 0, 0, False), (129, 128, 2048, 0, 0, 0, 2, False)])
+def test_slim_form_is_bitwise_the_quad_form(eng, M, N, K, epi, S, H, ftype, with_bias):
+    """gemm_slim.inc (round 6): the few-row launches of a quad call site -- 128 x 128 tiles, four waves of 64 x 64 on the quad form's MFMA, a five-stage
+    LDS ring -- against the quad kernel on the same launch (variant 10: the quad kernel whatever the shape): torch.equal on every epilogue and operand type
+    the path carries, ragged M, sample boundaries inside row blocks, rows beyond M untouched, repeated.  The launcher's own host function says which launches
+    take the form (13)."""
+    from t2v_metrics_amd.engine import load_library
+    lib = load_library()
+    inner = N // 3 if epi == 6 else 0
+    assert lib.vqs_debug_gemm_form(M, N, K, K, K, epi, 1, 3, S, inner, 0) == 13, "this shape must take the slim form"
+    assert lib.vqs_debug_gemm_form(M, N, K, K, K, epi, 1, 10, S, inner, 0) == 10
+    g = torch.Generator(device="cuda").manual_seed(163)
+    dt = torch.float16 if ftype else torch.bfloat16
+    A = torch.randn(M, K, device="cuda", generator=g).to(dt)
+    W = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(dt)
+    bias = randn_bf16(N, seed=173) if with_bias else None
+    quad = eng.gemm(A, W, epi, bias=bias, S=S, H=H, variant=10, ftype=ftype)
+    for _ in range(2):
+        got = torch.full_like(quad, 3.0)
+        eng.gemm(A, W, epi, bias=bias, S=S, H=H, variant=3, ftype=ftype, out=got)
+        assert torch.equal(got.view(torch.int16), quad.view(torch.int16)), describe(got, quad)
+    if epi in (0, 1, 2):                   # and against fp32 torch, so that the two forms cannot be wrong together
+        full = A.float() @ W.float().t() + (bias.float() if with_bias else 0.0)
+        full = quick_gelu(full) if epi == 1 else (gelu_erf(full) if epi == 2 else full)
+        assert_close(got, full, 2e-2, 1e-2, "slim form vs fp32")
+    if epi == 0:                           # rows past M are not touched
+        pad = torch.full((M + 16, N), 5.0, dtype=quad.dtype, device="cuda")
+        eng.gemm(A, W, epi, bias=bias, variant=3, ftype=ftype, out=pad[:M])
+        assert torch.equal(pad[:M], quad) and float((pad[M:].float() - 5.0).abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("Z,M,N,K,epi", [(256, 128, 608, 256, 3), (256, 128, 512, 640, 0), (300, 64, 96, 64, 3), (200, 100, 264, 192, 0),
                                          (1, 128, 24576 + 132, 128, 3), (1500, 33, 40, 320, 0), (40, 128, 4096, 128, 0),
                                          # round 6 (VQS_STREAM_MIN_ITEMS 192 -> 4): the decoder's linears at B = 1 .. 32 -- 4 K-slices of a 4 096-wide weight with 4 stacked

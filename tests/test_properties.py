@@ -267,7 +267,7 @@ def test_gemm_form_depends_on_the_weight_never_on_the_row_count(M, shape):
     S, inner = (608, N // 3) if epi == 6 else (0, 0)
     # 3 (persistent 8-wave) and 12 (stream form, round 4: few rows, many columns) produce the same bits -- one family; what must
     # not move with M is membership in the quad form (10), whose summation order differs
-    fam = lambda f: 3 if f == 12 else f
+    fam = lambda f: 3 if f == 12 else (10 if f == 13 else f)      # 13 (round 6): the quad family's few-row launch shape, gemm_slim.inc -- same bits as 10
     f = fam(_form(M, N, K, epi, S=S, inner=inner))
     assert f == fam(_form(7, N, K, epi, S=S, inner=inner)) == fam(_form(155648, N, K, epi, S=S, inner=inner))
     assert f == (10 if epi in (0, 1, 2, 5, 6) and K >= 128 else 3)
@@ -284,9 +284,23 @@ def test_stream_form_takes_skinny_launches_with_many_columns_only():
     assert _form(64, 384, 4096, 3) == 3                       # 3 items: not worth a launch shape of its own
     assert _form(129, 608, 4096, 3, batch=256) == 3           # more rows than the form holds
     assert _form(64, 152064, 3584, 3) == 12                   # a decode step's lm_head
-    assert _form(64, 32768, 4096, 0) == 10                    # a bf16-result nn.Linear is a quad call site for EVERY M
+    assert _form(64, 32768, 4096, 0) == 13 and _form(64, 32768, 4096, 0, variant=10) == 10      # a bf16-result nn.Linear is a quad call site for EVERY M (13: its few-row launch shape, same bits)
     assert _form(64, 32768, 4096, 0, variant=11) == 12        # under the 8-wave rule the same launch may stream (same bits as 3)
-    assert _form(128, 32768, 4096, 5) == 10 and _form(128, 32768, 4096, 3, variant=0) == 0
+    assert _form(128, 32768, 4096, 5) == 13 and _form(128, 32768, 4096, 3, variant=0) == 0
+
+
+def test_slim_form_takes_the_few_row_launches_of_quad_call_sites_only():
+    """gemm_slim.inc: a quad call site whose 256 x 256 tiles would leave most of the chip idle (one or two pairs per call) runs 128 x 128 tiles instead --
+    a function of (M, N, K) and the epilogue; variant 10 = the quad kernel whatever the shape; nothing changes at the bench batch."""
+    assert _form(608, 4096, 4096, 0) == 13 and _form(608, 4096, 10240, 0) == 13          # T5-XXL encoder o / wo of one pair: 48 quad tiles
+    assert _form(608, 12288, 4096, 6, S=608, inner=4096) == 10                            # q|k|v: 144 quad tiles against 480 slim tiles in two rounds (measured: 83 vs 94 us)
+    assert _form(608, 20480, 4096, 5) == 10                                               # gated wi: 240 quad tiles fill the chip
+    assert _form(577, 1024, 4096, 0) == 13 and _form(577, 4096, 1024, 1) == 13            # the tower's fc2 / fc1 of one image
+    assert _form(1216, 4096, 4096, 0) == 10 and _form(1154, 1024, 4096, 0) == 13          # two pairs: 320 slim tiles = two rounds, the quad launch; the tower's fc2 of two images: 80
+    assert _form(155648, 4096, 4096, 0) == 10 and _form(155648, 12288, 4096, 6, S=608, inner=4096) == 10   # the bench batch
+    assert _form(608, 4096, 4096, 0, variant=10) == 10                                    # the quad kernel on request
+    assert _form(608, 4000, 4096, 0) == 10 and _form(608, 4096, 128, 0) == 10             # N not a multiple of 128 / a short K: not worth it
+    assert _form(4, 4096, 1024, 3, batch=4) == 12                                         # fp32-result decoder linears: the stream form as before
 
 
 def test_gemm_operands_of_4_gib_never_reach_a_32_bit_kernel():
